@@ -1,0 +1,1125 @@
+/* odk_oracle.c -- float64 CPU restatement of mjx.forward / mjx.step.  TEST INFRASTRUCTURE ONLY
+ * (see odk_oracle.h).  PARITY UNPINNED: written from the published MuJoCo "Computation"
+ * chapter and recalled MJX sources ([UPSTREAM-MEMORY]); the reference
+ * calls this code at playground/open_duck_mini_v2/joystick.py:258 (init -> forward) and :420
+ * (mjx_env.step -> 10 x mjx.step).
+ *
+ * Readability over speed: dense matrices, explicit loops, one env at a time.
+ */
+#include "odk_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MINVAL 1e-15
+#define MINIMP 0.0001
+#define MAXIMP 0.9999
+
+/* ------------------------------------------------------------------ small vector math */
+static void v3_zero(real* a) { a[0] = a[1] = a[2] = 0; }
+static void v3_copy(real* a, const real* b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+static real v3_dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void v3_cross(real* r, const real* a, const real* b) {
+  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void v3_addscl(real* r, const real* a, const real* b, real s) { r[0] = a[0] + s * b[0]; r[1] = a[1] + s * b[1]; r[2] = a[2] + s * b[2]; }
+static void v3_sub(real* r, const real* a, const real* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static real v3_normalize(real* a) {
+  real n = sqrt(v3_dot(a, a));
+  if (n < MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
+  a[0] /= n; a[1] /= n; a[2] /= n;
+  return n;
+}
+static void quat_mul(real* r, const real* a, const real* b) {
+  real w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  real x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  real y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  real z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+static void quat_normalize(real* q) {
+  real n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static void quat_to_mat(real* m, const real* q) {
+  real w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+static void mat_mulvec(real* r, const real* m, const real* v) { /* r = M v */
+  real x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+       z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void mat_tmulvec(real* r, const real* m, const real* v) { /* r = M^T v */
+  real x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2],
+       z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void mat_mul(real* r, const real* a, const real* b) {
+  real t[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  memcpy(r, t, sizeof(t));
+}
+
+/* spatial (6D, [angular; linear]) helpers, MuJoCo conventions */
+static void inert_mul(real* res, const real* i, const real* v) { /* mju_mulInertVec */
+  res[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  res[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  res[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  res[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  res[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  res[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+static void cross_motion(real* res, const real* vel, const real* v) { /* mju_crossMotion */
+  real a[3], b[3];
+  v3_cross(res, vel, v);
+  v3_cross(a, vel, v + 3);
+  v3_cross(b, vel + 3, v);
+  res[3] = a[0] + b[0]; res[4] = a[1] + b[1]; res[5] = a[2] + b[2];
+}
+static void cross_force(real* res, const real* vel, const real* f) { /* mju_crossForce */
+  real a[3], b[3];
+  v3_cross(a, vel, f);
+  v3_cross(b, vel + 3, f + 3);
+  res[0] = a[0] + b[0]; res[1] = a[1] + b[1]; res[2] = a[2] + b[2];
+  v3_cross(res + 3, vel, f + 3);
+}
+
+/* ------------------------------------------------------------------ blob loader */
+typedef struct { char name[32]; uint32_t dtype, ndim, shape[4]; uint64_t nbytes; } rec_hdr;
+
+static const unsigned char* find_rec(const unsigned char* blob, uint64_t len, const char* name, rec_hdr* h) {
+  uint32_t n;
+  memcpy(&n, blob + 8, 4);
+  uint64_t off = 16;
+  for (uint32_t i = 0; i < n && off + 64 <= len; i++) {
+    memcpy(h->name, blob + off, 32);
+    memcpy(&h->dtype, blob + off + 32, 4);
+    memcpy(&h->ndim, blob + off + 36, 4);
+    memcpy(h->shape, blob + off + 40, 16);
+    memcpy(&h->nbytes, blob + off + 56, 8);
+    off += 64;
+    if (strncmp(h->name, name, 32) == 0) return blob + off;
+    off += h->nbytes + ((8 - (h->nbytes & 7)) & 7);
+  }
+  return NULL;
+}
+static int load_f(const unsigned char* blob, uint64_t len, const char* name, real* dst, int maxcount) {
+  rec_hdr h;
+  const unsigned char* p = find_rec(blob, len, name, &h);
+  if (!p || h.dtype != 0) return -1;
+  int cnt = (int)(h.nbytes / 8);
+  if (cnt > maxcount) { fprintf(stderr, "odko: field %s too large (%d > %d)\n", name, cnt, maxcount); return -1; }
+  for (int i = 0; i < cnt; i++) { double v; memcpy(&v, p + 8 * i, 8); dst[i] = (real)v; }
+  return cnt;
+}
+static int load_i(const unsigned char* blob, uint64_t len, const char* name, int* dst, int maxcount) {
+  rec_hdr h;
+  const unsigned char* p = find_rec(blob, len, name, &h);
+  if (!p || h.dtype != 1) return -1;
+  int cnt = (int)(h.nbytes / 4);
+  if (cnt > maxcount) { fprintf(stderr, "odko: field %s too large (%d > %d)\n", name, cnt, maxcount); return -1; }
+  for (int i = 0; i < cnt; i++) { int32_t v; memcpy(&v, p + 4 * i, 4); dst[i] = v; }
+  return cnt;
+}
+
+#define LF(name, dst, max) if (load_f(b, len, name, (real*)(dst), max) < 0) { fprintf(stderr, "odko: missing %s\n", name); ok = 0; }
+#define LI(name, dst, max) if (load_i(b, len, name, (int*)(dst), max) < 0) { fprintf(stderr, "odko: missing %s\n", name); ok = 0; }
+
+odko_model* odko_model_load(const void* blob, uint64_t len) {
+  const unsigned char* b = (const unsigned char*)blob;
+  if (len < 16 || memcmp(b, "ODKM", 4) != 0) return NULL;
+  odko_model* m = (odko_model*)calloc(1, sizeof(odko_model));
+  int ok = 1;
+  LI("nq", &m->nq, 1); LI("nv", &m->nv, 1); LI("nu", &m->nu, 1); LI("nbody", &m->nbody, 1); LI("njnt", &m->njnt, 1);
+  LI("nsite", &m->nsite, 1); LI("nsensordata", &m->nsensordata, 1);
+  if (!ok || m->nq > ODKO_MAXQ || m->nv > ODKO_MAXV || m->nu > ODKO_MAXU || m->nbody > ODKO_MAXB || m->njnt > ODKO_MAXJ ||
+      m->nsite > ODKO_MAXS) { free(m); return NULL; }
+  LF("opt_timestep", &m->timestep, 1); LF("opt_gravity", m->gravity, 3); LF("opt_tolerance", &m->tolerance, 1);
+  LF("opt_ls_tolerance", &m->ls_tolerance, 1); LF("opt_impratio", &m->impratio, 1); LF("stat_meaninertia", &m->meaninertia, 1);
+  LI("opt_iterations", &m->iterations, 1); LI("opt_ls_iterations", &m->ls_iterations, 1); LI("opt_eulerdamp", &m->eulerdamp, 1);
+  LI("body_parentid", m->body_parentid, ODKO_MAXB); LI("body_rootid", m->body_rootid, ODKO_MAXB); LI("body_weldid", m->body_weldid, ODKO_MAXB);
+  LI("body_jntadr", m->body_jntadr, ODKO_MAXB); LI("body_jntnum", m->body_jntnum, ODKO_MAXB);
+  LI("body_dofadr", m->body_dofadr, ODKO_MAXB); LI("body_dofnum", m->body_dofnum, ODKO_MAXB);
+  LF("body_pos", m->body_pos, ODKO_MAXB * 3); LF("body_quat", m->body_quat, ODKO_MAXB * 4); LF("body_mass", m->body_mass, ODKO_MAXB);
+  LF("body_ipos", m->body_ipos, ODKO_MAXB * 3); LF("body_inertia_full", m->body_inertia_full, ODKO_MAXB * 6);
+  LF("body_invweight0", m->body_invweight0, ODKO_MAXB * 2);
+  LI("jnt_type", m->jnt_type, ODKO_MAXJ); LI("jnt_bodyid", m->jnt_bodyid, ODKO_MAXJ); LI("jnt_qposadr", m->jnt_qposadr, ODKO_MAXJ);
+  LI("jnt_dofadr", m->jnt_dofadr, ODKO_MAXJ); LI("jnt_limited", m->jnt_limited, ODKO_MAXJ);
+  LF("jnt_pos", m->jnt_pos, ODKO_MAXJ * 3); LF("jnt_axis", m->jnt_axis, ODKO_MAXJ * 3); LF("jnt_range", m->jnt_range, ODKO_MAXJ * 2);
+  LF("jnt_solref", m->jnt_solref, ODKO_MAXJ * 2); LF("jnt_solimp", m->jnt_solimp, ODKO_MAXJ * 5); LF("jnt_margin", m->jnt_margin, ODKO_MAXJ);
+  LI("dof_bodyid", m->dof_bodyid, ODKO_MAXV); LI("dof_jntid", m->dof_jntid, ODKO_MAXV); LI("dof_parentid", m->dof_parentid, ODKO_MAXV);
+  LF("dof_armature", m->dof_armature, ODKO_MAXV); LF("dof_damping", m->dof_damping, ODKO_MAXV);
+  LF("dof_frictionloss", m->dof_frictionloss, ODKO_MAXV); LF("dof_invweight0", m->dof_invweight0, ODKO_MAXV);
+  LF("dof_solref", m->dof_solref, ODKO_MAXV * 2); LF("dof_solimp", m->dof_solimp, ODKO_MAXV * 5);
+  LF("qpos0", m->qpos0, ODKO_MAXQ); LF("key_qpos", m->key_qpos, ODKO_MAXQ); LF("key_ctrl", m->key_ctrl, ODKO_MAXU);
+  LI("actuator_trnid", m->actuator_trnid, ODKO_MAXU); LI("actuator_ctrllimited", m->actuator_ctrllimited, ODKO_MAXU);
+  LI("actuator_forcelimited", m->actuator_forcelimited, ODKO_MAXU);
+  LF("actuator_gainprm0", m->actuator_gainprm0, ODKO_MAXU); LF("actuator_biasprm", m->actuator_biasprm, ODKO_MAXU * 3);
+  LF("actuator_ctrlrange", m->actuator_ctrlrange, ODKO_MAXU * 2); LF("actuator_forcerange", m->actuator_forcerange, ODKO_MAXU * 2);
+  LF("actuator_gear", m->actuator_gear, ODKO_MAXU);
+  LI("site_bodyid", m->site_bodyid, ODKO_MAXS); LF("site_pos", m->site_pos, ODKO_MAXS * 3); LF("site_quat", m->site_quat, ODKO_MAXS * 4);
+  m->nsensor = load_i(b, len, "sensor_type", m->sensor_type, ODKO_MAXSENS);
+  LI("sensor_objid", m->sensor_objid, ODKO_MAXSENS); LI("sensor_adr", m->sensor_adr, ODKO_MAXSENS); LI("sensor_dim", m->sensor_dim, ODKO_MAXSENS);
+  m->ncgeom = load_i(b, len, "cgeom_type", m->cgeom_type, ODKO_MAXG);
+  LI("cgeom_id", m->cgeom_id, ODKO_MAXG); LI("cgeom_bodyid", m->cgeom_bodyid, ODKO_MAXG); LI("cgeom_priority", m->cgeom_priority, ODKO_MAXG);
+  LI("cgeom_condim", m->cgeom_condim, ODKO_MAXG); LI("cgeom_contype", m->cgeom_contype, ODKO_MAXG);
+  LI("cgeom_conaffinity", m->cgeom_conaffinity, ODKO_MAXG);
+  LI("cgeom_vertadr", m->cgeom_vertadr, ODKO_MAXG); LI("cgeom_vertnum", m->cgeom_vertnum, ODKO_MAXG);
+  LI("cgeom_faceadr", m->cgeom_faceadr, ODKO_MAXG); LI("cgeom_facenum", m->cgeom_facenum, ODKO_MAXG);
+  LF("cgeom_pos", m->cgeom_pos, ODKO_MAXG * 3); LF("cgeom_quat", m->cgeom_quat, ODKO_MAXG * 4);
+  LF("cgeom_friction", m->cgeom_friction, ODKO_MAXG * 3); LF("cgeom_solref", m->cgeom_solref, ODKO_MAXG * 2);
+  LF("cgeom_solimp", m->cgeom_solimp, ODKO_MAXG * 5); LF("cgeom_solmix", m->cgeom_solmix, ODKO_MAXG);
+  m->nhullvert = load_f(b, len, "hull_vert", (real*)m->hull_vert, ODKO_MAXHV * 3) / 3;
+  m->nhullface = load_i(b, len, "hull_face", (int*)m->hull_face, ODKO_MAXHF * 3) / 3;
+  if (!ok || m->nsensor < 0 || m->ncgeom < 0) { free(m); return NULL; }
+  /* contact pairs: contype/conaffinity filter, same-body and parent-child(weld) exclusion;
+     order: plane/hfield-vs-mesh pairs first (by geom id), then mesh-mesh (MJX groups by type pair) */
+  m->npair = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (int i = 0; i < m->ncgeom; i++)
+      for (int j = i + 1; j < m->ncgeom; j++) {
+        int ti = m->cgeom_type[i], tj = m->cgeom_type[j];
+        int mm = (ti == ODKO_GEOM_MESH && tj == ODKO_GEOM_MESH);
+        if ((pass == 0) == mm) continue;
+        if (!((m->cgeom_contype[i] & m->cgeom_conaffinity[j]) || (m->cgeom_contype[j] & m->cgeom_conaffinity[i]))) continue;
+        int b1 = m->body_weldid[m->cgeom_bodyid[i]], b2 = m->body_weldid[m->cgeom_bodyid[j]];
+        if (b1 == b2) continue;
+        if (m->npair < 3) {
+          int first = i, second = j; /* geom1 = lower type (plane/hfield first) */
+          if (ti > tj) { first = j; second = i; }
+          m->pair_g1[m->npair] = first; m->pair_g2[m->npair] = second; m->npair++;
+        }
+      }
+  return m;
+}
+void odko_model_free(odko_model* m) { free(m); }
+odko_model* odko_model_copy(const odko_model* m) {
+  odko_model* c = (odko_model*)malloc(sizeof(odko_model));
+  memcpy(c, m, sizeof(odko_model));
+  return c;
+}
+
+#define MF(nm, cnt) if (!strcmp(name, #nm)) { *count = (cnt); return (real*)m->nm; }
+real* odko_model_field(odko_model* m, const char* name, int* count) {
+  MF(body_mass, m->nbody) MF(body_ipos, m->nbody * 3) MF(body_pos, m->nbody * 3) MF(body_quat, m->nbody * 4)
+  MF(body_inertia_full, m->nbody * 6) MF(body_invweight0, m->nbody * 2)
+  MF(dof_frictionloss, m->nv) MF(dof_armature, m->nv) MF(dof_damping, m->nv) MF(dof_invweight0, m->nv)
+  MF(qpos0, m->nq) MF(key_qpos, m->nq) MF(key_ctrl, m->nu)
+  MF(actuator_gainprm0, m->nu) MF(actuator_biasprm, m->nu * 3) MF(actuator_ctrlrange, m->nu * 2) MF(actuator_forcerange, m->nu * 2)
+  MF(cgeom_friction, m->ncgeom * 3) MF(jnt_range, m->njnt * 2) MF(gravity, 3) MF(hull_vert, m->nhullvert * 3)
+  if (!strcmp(name, "timestep")) { *count = 1; return &m->timestep; }
+  if (!strcmp(name, "meaninertia")) { *count = 1; return &m->meaninertia; }
+  *count = 0;
+  return NULL;
+}
+#define MI(nm) if (!strcmp(name, #nm)) return m->nm;
+int odko_model_int(const odko_model* m, const char* name) {
+  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(nsite) MI(nsensor) MI(nsensordata) MI(ncgeom) MI(npair) MI(iterations) MI(ls_iterations)
+  return -1;
+}
+
+odko_data* odko_data_new(void) { return (odko_data*)calloc(1, sizeof(odko_data)); }
+void odko_data_free(odko_data* d) { free(d); }
+
+#define DF(nm, cnt) if (!strcmp(name, #nm)) { *count = (cnt); return (real*)d->nm; }
+real* odko_data_field(odko_data* d, const char* name, int* count) {
+  DF(qpos, ODKO_MAXQ) DF(qvel, ODKO_MAXV) DF(qacc_warmstart, ODKO_MAXV) DF(ctrl, ODKO_MAXU)
+  DF(xpos, ODKO_MAXB * 3) DF(xquat, ODKO_MAXB * 4) DF(xmat, ODKO_MAXB * 9) DF(xipos, ODKO_MAXB * 3)
+  DF(xanchor, ODKO_MAXJ * 3) DF(xaxis, ODKO_MAXJ * 3) DF(site_xpos, ODKO_MAXS * 3) DF(site_xmat, ODKO_MAXS * 9)
+  DF(geom_xpos, ODKO_MAXG * 3) DF(geom_xmat, ODKO_MAXG * 9) DF(subtree_com, ODKO_MAXB * 3) DF(cinert, ODKO_MAXB * 10)
+  DF(cdof, ODKO_MAXV * 6) DF(qM, ODKO_MAXV * ODKO_MAXV) DF(contact_dist, ODKO_MAXCON) DF(contact_pos, ODKO_MAXCON * 3)
+  DF(contact_frame, ODKO_MAXCON * 9) DF(contact_friction, ODKO_MAXCON)
+  DF(efc_J, ODKO_MAXEFC * ODKO_MAXV) DF(efc_pos, ODKO_MAXEFC) DF(efc_D, ODKO_MAXEFC) DF(efc_R, ODKO_MAXEFC) DF(efc_aref, ODKO_MAXEFC)
+  DF(efc_frictionloss, ODKO_MAXEFC) DF(efc_force, ODKO_MAXEFC) DF(efc_imp, ODKO_MAXEFC)
+  DF(cvel, ODKO_MAXB * 6) DF(cdof_dot, ODKO_MAXV * 6) DF(cacc, ODKO_MAXB * 6)
+  DF(qfrc_bias, ODKO_MAXV) DF(qfrc_passive, ODKO_MAXV) DF(qfrc_actuator, ODKO_MAXV) DF(actuator_force, ODKO_MAXU)
+  DF(qfrc_smooth, ODKO_MAXV) DF(qacc_smooth, ODKO_MAXV) DF(qacc, ODKO_MAXV) DF(qfrc_constraint, ODKO_MAXV) DF(sensordata, ODKO_MAXSD)
+  if (!strcmp(name, "time")) { *count = 1; return &d->time; }
+  if (!strcmp(name, "solver_cost0")) { *count = 1; return &d->solver_cost0; }
+  if (!strcmp(name, "solver_cost1")) { *count = 1; return &d->solver_cost1; }
+  if (!strcmp(name, "ls_alpha")) { *count = 1; return &d->ls_alpha; }
+  *count = 0;
+  return NULL;
+}
+#define DI(nm) if (!strcmp(name, #nm)) return d->nm;
+int odko_data_int(const odko_data* d, const char* name) {
+  DI(ncon) DI(nefc) DI(ne) DI(nf) DI(nl) DI(nc) DI(warm_used) DI(ls_iters)
+  return -1;
+}
+
+void odko_make_data(const odko_model* m, odko_data* d) {
+  memset(d, 0, sizeof(*d));
+  for (int i = 0; i < m->nq; i++) d->qpos[i] = m->qpos0[i];
+}
+
+/* ------------------------------------------------------------------ fwd_position */
+/* mjx smooth.kinematics */
+static void kinematics(const odko_model* m, odko_data* d) {
+  v3_zero(d->xpos[0]);
+  d->xquat[0][0] = 1; d->xquat[0][1] = d->xquat[0][2] = d->xquat[0][3] = 0;
+  quat_to_mat(d->xmat[0], d->xquat[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parentid[b], jn = m->body_jntnum[b], ja = m->body_jntadr[b];
+    real pos[3], quat[4];
+    if (jn == 1 && m->jnt_type[ja] == ODKO_JNT_FREE) {
+      int a = m->jnt_qposadr[ja];
+      v3_copy(pos, d->qpos + a);
+      memcpy(quat, d->qpos + a + 3, 4 * sizeof(real));
+      quat_normalize(quat);
+      v3_copy(d->xanchor[ja], pos);
+      d->xaxis[ja][0] = 0; d->xaxis[ja][1] = 0; d->xaxis[ja][2] = 1;
+    } else {
+      real t[3];
+      mat_mulvec(t, d->xmat[p], m->body_pos[b]);
+      v3_addscl(pos, d->xpos[p], t, 1);
+      quat_mul(quat, d->xquat[p], m->body_quat[b]);
+      for (int j = ja; j < ja + jn; j++) {
+        real R[9], qj[4], ang, s;
+        int a = m->jnt_qposadr[j];
+        quat_to_mat(R, quat);
+        mat_mulvec(t, R, m->jnt_pos[j]);
+        v3_addscl(d->xanchor[j], pos, t, 1);
+        mat_mulvec(d->xaxis[j], R, m->jnt_axis[j]);
+        ang = d->qpos[a] - m->qpos0[a]; /* hinge angle is relative to qpos0 */
+        s = sin(0.5 * ang);
+        qj[0] = cos(0.5 * ang); qj[1] = s * m->jnt_axis[j][0]; qj[2] = s * m->jnt_axis[j][1]; qj[3] = s * m->jnt_axis[j][2];
+        quat_mul(quat, quat, qj);
+        quat_to_mat(R, quat); /* off-centre rotation correction */
+        mat_mulvec(t, R, m->jnt_pos[j]);
+        v3_sub(pos, d->xanchor[j], t);
+      }
+    }
+    quat_normalize(quat);
+    v3_copy(d->xpos[b], pos);
+    memcpy(d->xquat[b], quat, sizeof(quat));
+    quat_to_mat(d->xmat[b], quat);
+  }
+  for (int b = 0; b < m->nbody; b++) {
+    real t[3];
+    mat_mulvec(t, d->xmat[b], m->body_ipos[b]);
+    v3_addscl(d->xipos[b], d->xpos[b], t, 1);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_bodyid[s];
+    real t[3], R[9];
+    mat_mulvec(t, d->xmat[b], m->site_pos[s]);
+    v3_addscl(d->site_xpos[s], d->xpos[b], t, 1);
+    quat_to_mat(R, m->site_quat[s]);
+    mat_mul(d->site_xmat[s], d->xmat[b], R);
+  }
+  for (int g = 0; g < m->ncgeom; g++) {
+    int b = m->cgeom_bodyid[g];
+    real t[3], R[9];
+    mat_mulvec(t, d->xmat[b], m->cgeom_pos[g]);
+    v3_addscl(d->geom_xpos[g], d->xpos[b], t, 1);
+    quat_to_mat(R, m->cgeom_quat[g]);
+    mat_mul(d->geom_xmat[g], d->xmat[b], R);
+  }
+}
+
+/* mjx smooth.com_pos: subtree COM, cinert, cdof */
+static void com_pos(const odko_model* m, odko_data* d) {
+  real mass[ODKO_MAXB];
+  for (int b = 0; b < m->nbody; b++) {
+    mass[b] = m->body_mass[b];
+    for (int k = 0; k < 3; k++) d->subtree_com[b][k] = m->body_mass[b] * d->xipos[b][k];
+  }
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    mass[p] += mass[b];
+    for (int k = 0; k < 3; k++) d->subtree_com[p][k] += d->subtree_com[b][k];
+  }
+  for (int b = 0; b < m->nbody; b++) {
+    if (mass[b] < MINVAL) v3_copy(d->subtree_com[b], d->xipos[b]);
+    else for (int k = 0; k < 3; k++) d->subtree_com[b][k] /= mass[b];
+  }
+  for (int b = 0; b < m->nbody; b++) {
+    const real* f = m->body_inertia_full[b];
+    real Ib[9] = {f[0], f[3], f[4], f[3], f[1], f[5], f[4], f[5], f[2]}, T[9], Iw[9], Rt[9], off[3];
+    const real* R = d->xmat[b];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[3 * j + i];
+    mat_mul(T, R, Ib);
+    mat_mul(Iw, T, Rt);
+    v3_sub(off, d->xipos[b], d->subtree_com[m->body_rootid[b]]);
+    real mb = m->body_mass[b], o2 = v3_dot(off, off);
+    real* c = d->cinert[b];
+    c[0] = Iw[0] + mb * (o2 - off[0] * off[0]);
+    c[1] = Iw[4] + mb * (o2 - off[1] * off[1]);
+    c[2] = Iw[8] + mb * (o2 - off[2] * off[2]);
+    c[3] = Iw[1] - mb * off[0] * off[1];
+    c[4] = Iw[2] - mb * off[0] * off[2];
+    c[5] = Iw[5] - mb * off[1] * off[2];
+    c[6] = mb * off[0]; c[7] = mb * off[1]; c[8] = mb * off[2];
+    c[9] = mb;
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    int da = m->jnt_dofadr[j], b = m->jnt_bodyid[j];
+    real off[3];
+    v3_sub(off, d->subtree_com[m->body_rootid[b]], d->xanchor[j]);
+    if (m->jnt_type[j] == ODKO_JNT_FREE) {
+      for (int k = 0; k < 3; k++) {
+        real* c = d->cdof[da + k];
+        memset(c, 0, 6 * sizeof(real));
+        c[3 + k] = 1;
+        real* r = d->cdof[da + 3 + k];
+        real ax[3] = {d->xmat[b][k], d->xmat[b][3 + k], d->xmat[b][6 + k]};
+        v3_copy(r, ax);
+        v3_cross(r + 3, ax, off);
+      }
+    } else {
+      real* c = d->cdof[da];
+      v3_copy(c, d->xaxis[j]);
+      v3_cross(c + 3, d->xaxis[j], off);
+    }
+  }
+}
+
+/* mjx smooth.crb + dense qM */
+static void crb(const odko_model* m, odko_data* d) {
+  int nv = m->nv;
+  for (int b = 0; b < m->nbody; b++) memcpy(d->crb[b], d->cinert[b], 10 * sizeof(real));
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int k = 0; k < 10; k++) d->crb[p][k] += d->crb[b][k];
+  }
+  memset(d->qM, 0, sizeof(d->qM));
+  for (int i = 0; i < nv; i++) {
+    real buf[6];
+    inert_mul(buf, d->crb[m->dof_bodyid[i]], d->cdof[i]);
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      real v = 0;
+      for (int k = 0; k < 6; k++) v += d->cdof[j][k] * buf[k];
+      d->qM[i * nv + j] = v;
+      d->qM[j * nv + i] = v;
+    }
+    d->qM[i * nv + i] += m->dof_armature[i];
+  }
+}
+
+/* dense Cholesky A = L L^T (lower); returns 0 on failure */
+static int cholesky(real* L, const real* A, int n) {
+  memcpy(L, A, (size_t)n * n * sizeof(real));
+  for (int j = 0; j < n; j++) {
+    real s = L[j * n + j];
+    for (int k = 0; k < j; k++) s -= L[j * n + k] * L[j * n + k];
+    if (s < MINVAL) s = MINVAL;
+    s = sqrt(s);
+    L[j * n + j] = s;
+    for (int i = j + 1; i < n; i++) {
+      real t = L[i * n + j];
+      for (int k = 0; k < j; k++) t -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = t / s;
+    }
+  }
+  return 1;
+}
+static void chol_solve(real* x, const real* L, const real* b, int n) {
+  for (int i = 0; i < n; i++) {
+    real t = b[i];
+    for (int k = 0; k < i; k++) t -= L[i * n + k] * x[k];
+    x[i] = t / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    real t = x[i];
+    for (int k = i + 1; k < n; k++) t -= L[k * n + i] * x[k];
+    x[i] = t / L[i * n + i];
+  }
+}
+static void mul_m(const odko_model* m, const odko_data* d, real* res, const real* v) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) {
+    real s = 0;
+    for (int j = 0; j < nv; j++) s += d->qM[i * nv + j] * v[j];
+    res[i] = s;
+  }
+}
+
+/* ---- collision ---- */
+/* mju_makeFrame / mjx math.make_frame: rows = normal, tangent1, tangent2 */
+static void make_frame(real* frame, const real* n) {
+  real a[3] = {n[0], n[1], n[2]}, b[3] = {0, 0, 0}, c[3];
+  v3_normalize(a);
+  if (fabs(a[1]) < 0.5) b[1] = 1; else b[2] = 1;
+  real dt = v3_dot(a, b);
+  v3_addscl(b, b, a, -dt);
+  v3_normalize(b);
+  v3_cross(c, a, b);
+  v3_copy(frame, a); v3_copy(frame + 3, b); v3_copy(frame + 6, c);
+}
+
+/* mjx collision_convex._manifold_points: 4 points of approximately maximal area among masked */
+static void manifold_points(const real (*poly)[3], const int* mask, int n, const real* norm, int* idx) {
+  real dm[ODKO_MAXHV];
+  int ai = 0, bi = 0, ci = 0, di = 0;
+  real best;
+  for (int i = 0; i < n; i++) dm[i] = mask[i] ? 0.0 : -1e6;
+  best = -1e30; for (int i = 0; i < n; i++) if (dm[i] > best) { best = dm[i]; ai = i; }
+  const real* a = poly[ai];
+  best = -1e30;
+  for (int i = 0; i < n; i++) {
+    real t[3]; v3_sub(t, a, poly[i]);
+    real v = v3_dot(t, t) + dm[i];
+    if (v > best) { best = v; bi = i; }
+  }
+  const real* b = poly[bi];
+  real ab[3], t[3];
+  v3_sub(t, a, b); v3_cross(ab, norm, t);
+  best = -1e30;
+  for (int i = 0; i < n; i++) {
+    real ap[3]; v3_sub(ap, a, poly[i]);
+    real v = fabs(v3_dot(ap, ab)) + dm[i];
+    if (v > best) { best = v; ci = i; }
+  }
+  const real* c = poly[ci];
+  real ac[3], bc[3];
+  v3_sub(t, a, c); v3_cross(ac, norm, t);
+  v3_sub(t, b, c); v3_cross(bc, norm, t);
+  best = -1e30;
+  /* argmax over concat([dist_bp, dist_ap]) % n : first half (bp) wins ties */
+  for (int i = 0; i < n; i++) {
+    real bp[3]; v3_sub(bp, b, poly[i]);
+    real v = fabs(v3_dot(bp, bc)) + dm[i];
+    if (v > best) { best = v; di = i; }
+  }
+  for (int i = 0; i < n; i++) {
+    real ap[3]; v3_sub(ap, a, poly[i]);
+    real v = fabs(v3_dot(ap, ac)) + dm[i];
+    if (v > best) { best = v; di = i; }
+  }
+  idx[0] = ai; idx[1] = bi; idx[2] = ci; idx[3] = di;
+}
+
+/* mjx collision_convex.plane_convex; writes 4 contacts starting at slot c0 */
+static void plane_convex(const odko_model* m, odko_data* d, int gp, int gc, int c0) {
+  const real (*vert)[3] = &m->hull_vert[m->cgeom_vertadr[gc]];
+  int n = m->cgeom_vertnum[gc];
+  const real* cm = d->geom_xmat[gc];
+  real pn_w[3] = {d->geom_xmat[gp][2], d->geom_xmat[gp][5], d->geom_xmat[gp][8]};
+  real rel[3], plane_pos[3], nl[3];
+  v3_sub(rel, d->geom_xpos[gp], d->geom_xpos[gc]);
+  mat_tmulvec(plane_pos, cm, rel);
+  mat_tmulvec(nl, cm, pn_w);
+  real support[ODKO_MAXHV], smax = -1e30;
+  int mask[ODKO_MAXHV], idx[4];
+  for (int i = 0; i < n; i++) {
+    real t[3]; v3_sub(t, plane_pos, vert[i]);
+    support[i] = v3_dot(t, nl);
+    if (support[i] > smax) smax = support[i];
+  }
+  real thr = smax - 1e-3; if (thr < 0) thr = 0;
+  for (int i = 0; i < n; i++) mask[i] = support[i] > thr;
+  manifold_points(vert, mask, n, nl, idx);
+  real frame[9];
+  make_frame(frame, pn_w);
+  for (int k = 0; k < 4; k++) {
+    /* unique = tril(idx == idx[:,None]).sum(axis=1) == 1 : first occurrence only */
+    int unique = 1;
+    for (int q = 0; q < k; q++) if (idx[q] == idx[k]) unique = 0;
+    real dist = unique ? -support[idx[k]] : 1.0;
+    real pw[3];
+    mat_mulvec(pw, cm, vert[idx[k]]);
+    v3_addscl(pw, pw, d->geom_xpos[gc], 1);
+    v3_addscl(pw, pw, pn_w, -0.5 * dist);
+    d->contact_dist[c0 + k] = dist;
+    v3_copy(d->contact_pos[c0 + k], pw);
+    memcpy(d->contact_frame[c0 + k], frame, sizeof(frame));
+  }
+}
+
+/* Conservative separating test for two convex hulls: projects both vertex sets on the candidate
+ * axes (face normals of both hulls + world-frame OBB-like axes).  If any axis separates the hulls
+ * by a positive gap, MJX's convex-convex routine would report dist > 0 for all 4 contacts, which
+ * contributes exactly nothing to the dynamics (inactive rows have J = 0, SURVEY "Hard parts").
+ * Returns the largest separation found (>0: separated). */
+static real hull_separation(const odko_model* m, const odko_data* d, int g1, int g2, real* axis_out) {
+  real best = -1e30;
+  int gs[2] = {g1, g2};
+  real w1[ODKO_MAXHV][3], w2[ODKO_MAXHV][3];
+  int n1 = m->cgeom_vertnum[g1], n2 = m->cgeom_vertnum[g2];
+  for (int i = 0; i < n1; i++) { mat_mulvec(w1[i], d->geom_xmat[g1], m->hull_vert[m->cgeom_vertadr[g1] + i]); v3_addscl(w1[i], w1[i], d->geom_xpos[g1], 1); }
+  for (int i = 0; i < n2; i++) { mat_mulvec(w2[i], d->geom_xmat[g2], m->hull_vert[m->cgeom_vertadr[g2] + i]); v3_addscl(w2[i], w2[i], d->geom_xpos[g2], 1); }
+  for (int s = 0; s < 2; s++) {
+    int g = gs[s];
+    for (int f = 0; f < m->cgeom_facenum[g]; f++) {
+      const int* tri = m->hull_face[m->cgeom_faceadr[g] + f];
+      const real (*wv)[3] = s == 0 ? w1 : w2;
+      real e1[3], e2[3], nrm[3];
+      v3_sub(e1, wv[tri[1]], wv[tri[0]]); v3_sub(e2, wv[tri[2]], wv[tri[0]]);
+      v3_cross(nrm, e1, e2);
+      if (v3_normalize(nrm) == 0) continue;
+      real max1 = -1e30, min1 = 1e30, max2 = -1e30, min2 = 1e30;
+      for (int i = 0; i < n1; i++) { real p = v3_dot(w1[i], nrm); if (p > max1) max1 = p; if (p < min1) min1 = p; }
+      for (int i = 0; i < n2; i++) { real p = v3_dot(w2[i], nrm); if (p > max2) max2 = p; if (p < min2) min2 = p; }
+      real sep = (min2 - max1 > min1 - max2) ? (min2 - max1) : (min1 - max2);
+      if (sep > best) { best = sep; if (axis_out) { v3_copy(axis_out, nrm); if (min1 - max2 > min2 - max1) { axis_out[0] = -nrm[0]; axis_out[1] = -nrm[1]; axis_out[2] = -nrm[2]; } } }
+    }
+  }
+  return best;
+}
+
+/* convex-convex (foot vs foot).  When a face-normal axis separates the hulls the pair is culled
+ * (dist = separation > 0 on all four slots: inactive).  Penetrating configurations use the
+ * minimum-penetration face axis and a 4-point manifold from the deepest vertices of hull 2 --
+ * an approximation of MJX's SAT + polygon clipping (edge-edge axes omitted).  PARITY UNPINNED. */
+static void convex_convex(const odko_model* m, odko_data* d, int g1, int g2, int c0) {
+  real axis[3] = {0, 0, 1};
+  real sep = hull_separation(m, d, g1, g2, axis);
+  real frame[9];
+  make_frame(frame, axis);
+  if (sep > 0) {
+    for (int k = 0; k < 4; k++) {
+      d->contact_dist[c0 + k] = (k == 0) ? sep : 1.0;
+      for (int q = 0; q < 3; q++) d->contact_pos[c0 + k][q] = 0.5 * (d->geom_xpos[g1][q] + d->geom_xpos[g2][q]);
+      memcpy(d->contact_frame[c0 + k], frame, sizeof(frame));
+    }
+    return;
+  }
+  /* penetrating: treat hull 1's separating face as a plane through its support point along axis */
+  int n1 = m->cgeom_vertnum[g1], n2 = m->cgeom_vertnum[g2];
+  real max1 = -1e30;
+  for (int i = 0; i < n1; i++) {
+    real w[3]; mat_mulvec(w, d->geom_xmat[g1], m->hull_vert[m->cgeom_vertadr[g1] + i]); v3_addscl(w, w, d->geom_xpos[g1], 1);
+    real p = v3_dot(w, axis); if (p > max1) max1 = p;
+  }
+  real w2[ODKO_MAXHV][3], support[ODKO_MAXHV], smax = -1e30;
+  int mask[ODKO_MAXHV], idx[4];
+  for (int i = 0; i < n2; i++) {
+    mat_mulvec(w2[i], d->geom_xmat[g2], m->hull_vert[m->cgeom_vertadr[g2] + i]); v3_addscl(w2[i], w2[i], d->geom_xpos[g2], 1);
+    support[i] = max1 - v3_dot(w2[i], axis);
+    if (support[i] > smax) smax = support[i];
+  }
+  real thr = smax - 1e-3; if (thr < 0) thr = 0;
+  for (int i = 0; i < n2; i++) mask[i] = support[i] > thr;
+  manifold_points((const real (*)[3])w2, mask, n2, axis, idx);
+  for (int k = 0; k < 4; k++) {
+    int unique = 1;
+    for (int q = 0; q < k; q++) if (idx[q] == idx[k]) unique = 0;
+    real dist = unique ? -support[idx[k]] : 1.0;
+    d->contact_dist[c0 + k] = dist;
+    v3_addscl(d->contact_pos[c0 + k], w2[idx[k]], axis, -0.5 * dist);
+    memcpy(d->contact_frame[c0 + k], frame, sizeof(frame));
+  }
+}
+
+static void collision(const odko_model* m, odko_data* d) {
+  d->ncon = 0;
+  for (int p = 0; p < m->npair; p++) {
+    int g1 = m->pair_g1[p], g2 = m->pair_g2[p], c0 = d->ncon;
+    if (m->cgeom_type[g1] == ODKO_GEOM_PLANE && m->cgeom_type[g2] == ODKO_GEOM_MESH) plane_convex(m, d, g1, g2, c0);
+    else if (m->cgeom_type[g1] == ODKO_GEOM_MESH && m->cgeom_type[g2] == ODKO_GEOM_MESH) convex_convex(m, d, g1, g2, c0);
+    else { /* hfield: not implemented in round 1 -> no contact */
+      for (int k = 0; k < 4; k++) { d->contact_dist[c0 + k] = 1.0; v3_zero(d->contact_pos[c0 + k]); real z[3] = {0, 0, 1}; make_frame(d->contact_frame[c0 + k], z); }
+    }
+    /* friction: higher priority wins, else max (mj_contactParam) */
+    real f1 = m->cgeom_friction[g1][0], f2 = m->cgeom_friction[g2][0], fr;
+    if (m->cgeom_priority[g1] > m->cgeom_priority[g2]) fr = f1;
+    else if (m->cgeom_priority[g2] > m->cgeom_priority[g1]) fr = f2;
+    else fr = f1 > f2 ? f1 : f2;
+    for (int k = 0; k < 4; k++) { d->contact_friction[c0 + k] = fr; d->contact_geom1[c0 + k] = g1; d->contact_geom2[c0 + k] = g2; }
+    d->ncon += 4;
+  }
+}
+
+/* ---- constraints (mjx constraint.make_constraint) ---- */
+static void efc_row_params(const odko_model* m, odko_data* d, int r, real pos, real invweight, const real* solref, const real* solimp,
+                           real vel, real frictionloss) {
+  real timeconst = solref[0], dampratio = solref[1];
+  real dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  if (timeconst < 2 * m->timestep) timeconst = 2 * m->timestep; /* refsafe */
+  dmin = fmin(fmax(dmin, MINIMP), MAXIMP); dmax = fmin(fmax(dmax, MINIMP), MAXIMP);
+  width = fmax(width, MINVAL); mid = fmin(fmax(mid, MINIMP), MAXIMP); power = fmax(power, 1.0);
+  real k = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  real b = 2.0 / (dmax * timeconst);
+  if (solref[0] <= 0) k = -solref[0] / (dmax * dmax);
+  if (solref[1] <= 0) b = -solref[1] / dmax;
+  real imp_x = fabs(pos) / width;
+  real imp_a = (1.0 / pow(mid, power - 1)) * pow(imp_x, power);
+  real imp_b = 1 - (1.0 / pow(1 - mid, power - 1)) * pow(1 - imp_x, power);
+  real imp_y = imp_x < mid ? imp_a : imp_b;
+  real imp = dmin + imp_y * (dmax - dmin);
+  imp = fmin(fmax(imp, dmin), dmax);
+  if (imp_x > 1.0) imp = dmax;
+  real R = fmax(invweight * (1 - imp) / imp, MINVAL);
+  d->efc_pos[r] = pos; d->efc_invweight[r] = invweight; d->efc_imp[r] = imp; d->efc_k[r] = k; d->efc_b[r] = b;
+  d->efc_R[r] = R; d->efc_D[r] = 1.0 / R;
+  d->efc_aref[r] = -b * vel - k * imp * pos;
+  d->efc_frictionloss[r] = frictionloss;
+}
+
+static void contact_mix(const odko_model* m, int g1, int g2, real* solref, real* solimp) {
+  /* mj_contactParam: priority wins; otherwise solmix-weighted average */
+  real mix;
+  if (m->cgeom_priority[g1] > m->cgeom_priority[g2]) mix = 1;
+  else if (m->cgeom_priority[g2] > m->cgeom_priority[g1]) mix = 0;
+  else {
+    real s1 = m->cgeom_solmix[g1], s2 = m->cgeom_solmix[g2];
+    if (s1 >= MINVAL && s2 >= MINVAL) mix = s1 / (s1 + s2);
+    else if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
+    else mix = s1 < MINVAL ? 0.0 : 1.0;
+  }
+  for (int i = 0; i < 2; i++) solref[i] = mix * m->cgeom_solref[g1][i] + (1 - mix) * m->cgeom_solref[g2][i];
+  for (int i = 0; i < 5; i++) solimp[i] = mix * m->cgeom_solimp[g1][i] + (1 - mix) * m->cgeom_solimp[g2][i];
+}
+
+/* translational Jacobian of a world point attached to body b (support.jac) */
+static void jac_point(const odko_model* m, const odko_data* d, int b, const real* point, real* jacp /* 3 x nv */) {
+  int nv = m->nv;
+  memset(jacp, 0, 3 * (size_t)nv * sizeof(real));
+  while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parentid[b];
+  if (b == 0) return;
+  real off[3];
+  v3_sub(off, point, d->subtree_com[m->body_rootid[b]]);
+  for (int i = m->body_dofadr[b] + m->body_dofnum[b] - 1; i >= 0; i = m->dof_parentid[i]) {
+    real t[3];
+    v3_cross(t, d->cdof[i], off);
+    for (int k = 0; k < 3; k++) jacp[k * nv + i] = d->cdof[i][3 + k] + t[k];
+  }
+}
+
+static void make_constraint(const odko_model* m, odko_data* d) {
+  int nv = m->nv, r = 0;
+  memset(d->efc_J, 0, sizeof(d->efc_J));
+  d->ne = 0;
+  /* friction loss rows: dofs with frictionloss > 0 */
+  for (int i = 0; i < nv; i++) {
+    if (m->dof_frictionloss[i] <= 0) continue;
+    d->efc_J[r * nv + i] = 1;
+    efc_row_params(m, d, r, 0.0, m->dof_invweight0[i], m->dof_solref[i], m->dof_solimp[i], d->qvel[i], m->dof_frictionloss[i]);
+    r++;
+  }
+  d->nf = r;
+  /* joint limit rows (hinge) */
+  for (int j = 0; j < m->njnt; j++) {
+    if (!m->jnt_limited[j] || m->jnt_type[j] != ODKO_JNT_HINGE) continue;
+    real q = d->qpos[m->jnt_qposadr[j]];
+    real dmin = q - m->jnt_range[j][0], dmax = m->jnt_range[j][1] - q;
+    real pos = (dmin < dmax ? dmin : dmax) - m->jnt_margin[j];
+    int active = pos < 0;
+    real sgn = (dmin < dmax) ? 1.0 : -1.0;
+    int i = m->jnt_dofadr[j];
+    d->efc_J[r * nv + i] = sgn * active;
+    efc_row_params(m, d, r, pos, m->dof_invweight0[i], m->jnt_solref[j], m->jnt_solimp[j], sgn * active * d->qvel[i], 0.0);
+    r++;
+  }
+  d->nl = r - d->nf;
+  /* contact rows: pyramidal condim 3 -> 4 rows per contact */
+  for (int c = 0; c < d->ncon; c++) {
+    int g1 = d->contact_geom1[c], g2 = d->contact_geom2[c];
+    int b1 = m->cgeom_bodyid[g1], b2 = m->cgeom_bodyid[g2];
+    real j1[3 * ODKO_MAXV], j2[3 * ODKO_MAXV], dif[3 * ODKO_MAXV], con[3 * ODKO_MAXV];
+    real solref[2], solimp[5];
+    contact_mix(m, g1, g2, solref, solimp);
+    jac_point(m, d, b1, d->contact_pos[c], j1);
+    jac_point(m, d, b2, d->contact_pos[c], j2);
+    for (int i = 0; i < 3 * nv; i++) dif[i] = j2[i] - j1[i];
+    for (int a = 0; a < 3; a++)
+      for (int i = 0; i < nv; i++)
+        con[a * nv + i] = d->contact_frame[c][3 * a] * dif[i] + d->contact_frame[c][3 * a + 1] * dif[nv + i] + d->contact_frame[c][3 * a + 2] * dif[2 * nv + i];
+    real t = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+    real dist = d->contact_dist[c];
+    int active = dist < 0;
+    real mu = d->contact_friction[c];
+    for (int tdir = 1; tdir <= 2; tdir++)
+      for (int s = 0; s < 2; s++) {
+        real f = s == 0 ? mu : -mu, vel = 0;
+        for (int i = 0; i < nv; i++) {
+          real v = (con[i] + con[tdir * nv + i] * f) * active;
+          d->efc_J[r * nv + i] = v;
+          vel += v * d->qvel[i];
+        }
+        real invw = (t + f * f * t) * 2 * f * f / m->impratio;
+        efc_row_params(m, d, r, dist, invw, solref, solimp, vel, 0.0);
+        r++;
+      }
+  }
+  d->nc = r - d->nf - d->nl;
+  d->nefc = r;
+}
+
+static void fwd_position(const odko_model* m, odko_data* d) {
+  kinematics(m, d);
+  com_pos(m, d);
+  crb(m, d);
+  cholesky(d->qL, d->qM, m->nv);
+  collision(m, d);
+  make_constraint(m, d);
+}
+
+/* ------------------------------------------------------------------ fwd_velocity */
+static void com_vel(const odko_model* m, odko_data* d) {
+  memset(d->cvel[0], 0, 6 * sizeof(real));
+  for (int b = 1; b < m->nbody; b++) {
+    real cvel[6];
+    memcpy(cvel, d->cvel[m->body_parentid[b]], sizeof(cvel));
+    for (int j = m->body_jntadr[b]; j < m->body_jntadr[b] + m->body_jntnum[b]; j++) {
+      int da = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == ODKO_JNT_FREE) {
+        for (int k = 0; k < 3; k++) {
+          memset(d->cdof_dot[da + k], 0, 6 * sizeof(real));
+          for (int q = 0; q < 6; q++) cvel[q] += d->cdof[da + k][q] * d->qvel[da + k];
+        }
+        for (int k = 3; k < 6; k++) cross_motion(d->cdof_dot[da + k], cvel, d->cdof[da + k]);
+        for (int k = 3; k < 6; k++) for (int q = 0; q < 6; q++) cvel[q] += d->cdof[da + k][q] * d->qvel[da + k];
+      } else {
+        cross_motion(d->cdof_dot[da], cvel, d->cdof[da]);
+        for (int q = 0; q < 6; q++) cvel[q] += d->cdof[da][q] * d->qvel[da];
+      }
+    }
+    memcpy(d->cvel[b], cvel, sizeof(cvel));
+  }
+}
+
+/* rne with optional acceleration term (flg_acc: rne_postconstraint's cacc) */
+static void rne_cacc(const odko_model* m, odko_data* d, int flg_acc) {
+  memset(d->cacc[0], 0, 6 * sizeof(real));
+  for (int k = 0; k < 3; k++) d->cacc[0][3 + k] = -m->gravity[k];
+  for (int b = 1; b < m->nbody; b++) {
+    memcpy(d->cacc[b], d->cacc[m->body_parentid[b]], 6 * sizeof(real));
+    for (int i = m->body_dofadr[b]; i >= 0 && i < m->body_dofadr[b] + m->body_dofnum[b]; i++)
+      for (int q = 0; q < 6; q++) {
+        d->cacc[b][q] += d->cdof_dot[i][q] * d->qvel[i];
+        if (flg_acc) d->cacc[b][q] += d->cdof[i][q] * d->qacc[i];
+      }
+  }
+}
+static void rne(const odko_model* m, odko_data* d) {
+  real cfrc[ODKO_MAXB][6];
+  rne_cacc(m, d, 0);
+  for (int b = 0; b < m->nbody; b++) {
+    real t1[6], t2[6];
+    inert_mul(cfrc[b], d->cinert[b], d->cacc[b]);
+    inert_mul(t1, d->cinert[b], d->cvel[b]);
+    cross_force(t2, d->cvel[b], t1);
+    for (int q = 0; q < 6; q++) cfrc[b][q] += t2[q];
+  }
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    for (int q = 0; q < 6; q++) cfrc[p][q] += cfrc[b][q];
+  }
+  for (int i = 0; i < m->nv; i++) {
+    real s = 0;
+    for (int q = 0; q < 6; q++) s += d->cdof[i][q] * cfrc[m->dof_bodyid[i]][q];
+    d->qfrc_bias[i] = s;
+  }
+}
+
+static void fwd_velocity(const odko_model* m, odko_data* d) {
+  com_vel(m, d);
+  for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
+  rne(m, d);
+}
+
+/* position actuators: force = kp*ctrl + bias0 + bias1*length + bias2*velocity */
+static void fwd_actuation(const odko_model* m, odko_data* d) {
+  memset(d->qfrc_actuator, 0, sizeof(d->qfrc_actuator));
+  for (int u = 0; u < m->nu; u++) {
+    int j = m->actuator_trnid[u];
+    real gear = m->actuator_gear[u];
+    real len = d->qpos[m->jnt_qposadr[j]] * gear, vel = d->qvel[m->jnt_dofadr[j]] * gear;
+    real ctrl = d->ctrl[u];
+    if (m->actuator_ctrllimited[u]) ctrl = fmin(fmax(ctrl, m->actuator_ctrlrange[u][0]), m->actuator_ctrlrange[u][1]);
+    real f = m->actuator_gainprm0[u] * ctrl + m->actuator_biasprm[u][0] + m->actuator_biasprm[u][1] * len + m->actuator_biasprm[u][2] * vel;
+    if (m->actuator_forcelimited[u]) f = fmin(fmax(f, m->actuator_forcerange[u][0]), m->actuator_forcerange[u][1]);
+    d->actuator_force[u] = f;
+    d->qfrc_actuator[m->jnt_dofadr[j]] += gear * f;
+  }
+}
+
+static void fwd_acceleration(const odko_model* m, odko_data* d) {
+  for (int i = 0; i < m->nv; i++) d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+  chol_solve(d->qacc_smooth, d->qL, d->qfrc_smooth, m->nv);
+}
+
+/* ------------------------------------------------------------------ solver (mjx solver.solve, Newton) */
+typedef struct {
+  real qacc[ODKO_MAXV], Ma[ODKO_MAXV], Jaref[ODKO_MAXEFC], force[ODKO_MAXEFC], qfrc_constraint[ODKO_MAXV];
+  int active[ODKO_MAXEFC]; /* rows in the quadratic regime (enter the Hessian) */
+  real gauss, cost;
+  real grad[ODKO_MAXV], Mgrad[ODKO_MAXV], search[ODKO_MAXV];
+} solver_ctx;
+
+static void ctx_init(const odko_model* m, const odko_data* d, solver_ctx* c, const real* qacc) {
+  int nv = m->nv;
+  memcpy(c->qacc, qacc, nv * sizeof(real));
+  mul_m(m, d, c->Ma, qacc);
+  for (int r = 0; r < d->nefc; r++) {
+    real s = 0;
+    for (int i = 0; i < nv; i++) s += d->efc_J[r * nv + i] * qacc[i];
+    c->Jaref[r] = s - d->efc_aref[r];
+  }
+}
+/* solver._update_constraint */
+static void update_constraint(const odko_model* m, const odko_data* d, solver_ctx* c) {
+  int nv = m->nv;
+  real cost = 0;
+  for (int r = 0; r < d->nefc; r++) {
+    real jar = c->Jaref[r];
+    if (r >= d->ne && r < d->ne + d->nf) {
+      real f = d->efc_frictionloss[r], rf = d->efc_R[r] * f;
+      if (jar <= -rf) { c->force[r] = f; c->active[r] = 0; cost += -0.5 * rf * f - f * jar; }
+      else if (jar >= rf) { c->force[r] = -f; c->active[r] = 0; cost += -0.5 * rf * f + f * jar; }
+      else { c->force[r] = -d->efc_D[r] * jar; c->active[r] = 1; cost += 0.5 * d->efc_D[r] * jar * jar; }
+    } else {
+      int act = (r < d->ne) || (jar < 0);
+      c->active[r] = act;
+      c->force[r] = act ? -d->efc_D[r] * jar : 0.0;
+      if (act) cost += 0.5 * d->efc_D[r] * jar * jar;
+    }
+  }
+  for (int i = 0; i < nv; i++) {
+    real s = 0;
+    for (int r = 0; r < d->nefc; r++) s += d->efc_J[r * nv + i] * c->force[r];
+    c->qfrc_constraint[i] = s;
+  }
+  real g = 0;
+  for (int i = 0; i < nv; i++) g += (c->Ma[i] - d->qfrc_smooth[i]) * (c->qacc[i] - d->qacc_smooth[i]);
+  c->gauss = 0.5 * g;
+  c->cost = cost + c->gauss;
+}
+/* solver._update_gradient (Newton): H = M + J^T diag(D*active) J, Cholesky, Mgrad = H^-1 grad */
+static void update_gradient(const odko_model* m, const odko_data* d, solver_ctx* c) {
+  int nv = m->nv;
+  real H[ODKO_MAXV * ODKO_MAXV], L[ODKO_MAXV * ODKO_MAXV];
+  for (int i = 0; i < nv; i++) c->grad[i] = c->Ma[i] - d->qfrc_smooth[i] - c->qfrc_constraint[i];
+  memcpy(H, d->qM, (size_t)nv * nv * sizeof(real));
+  for (int r = 0; r < d->nefc; r++) {
+    if (!c->active[r]) continue;
+    const real* J = d->efc_J + r * nv;
+    for (int i = 0; i < nv; i++) {
+      if (J[i] == 0) continue;
+      for (int j = 0; j < nv; j++) H[i * nv + j] += d->efc_D[r] * J[i] * J[j];
+    }
+  }
+  cholesky(L, H, nv);
+  chol_solve(c->Mgrad, L, c->grad, nv);
+}
+
+typedef struct { real alpha, cost, deriv0, deriv1; } ls_point;
+
+typedef struct {
+  const odko_data* d;
+  const solver_ctx* c;
+  real jv[ODKO_MAXEFC], quad[ODKO_MAXEFC][3], quad_gauss[3];
+} ls_ctx;
+
+/* solver._LSPoint.create */
+static ls_point ls_eval(const ls_ctx* L, real alpha) {
+  const odko_data* d = L->d;
+  real q0 = L->quad_gauss[0], q1 = L->quad_gauss[1], q2 = L->quad_gauss[2];
+  for (int r = 0; r < d->nefc; r++) {
+    real x = L->c->Jaref[r] + alpha * L->jv[r];
+    if (r >= d->ne && r < d->ne + d->nf) {
+      real f = d->efc_frictionloss[r], rf = d->efc_R[r] * f;
+      if (x <= -rf) { q0 += f * (-0.5 * rf - L->c->Jaref[r]); q1 += -f * L->jv[r]; }
+      else if (x >= rf) { q0 += f * (-0.5 * rf + L->c->Jaref[r]); q1 += f * L->jv[r]; }
+      else { q0 += L->quad[r][0]; q1 += L->quad[r][1]; q2 += L->quad[r][2]; }
+    } else if (r < d->ne || x < 0) {
+      q0 += L->quad[r][0]; q1 += L->quad[r][1]; q2 += L->quad[r][2];
+    }
+  }
+  ls_point p;
+  p.alpha = alpha;
+  p.cost = alpha * alpha * q2 + alpha * q1 + q0;
+  p.deriv0 = 2 * alpha * q2 + q1;
+  p.deriv1 = 2 * q2 + (q2 == 0 ? MINVAL : 0.0);
+  return p;
+}
+static real safe_div(real a, real b) { return b == 0 ? 0.0 : a / b; }
+
+/* solver._linesearch */
+static void linesearch(const odko_model* m, odko_data* d, solver_ctx* c) {
+  int nv = m->nv;
+  ls_ctx L;
+  real mv[ODKO_MAXV], snorm = 0;
+  L.d = d; L.c = c;
+  for (int i = 0; i < nv; i++) snorm += c->search[i] * c->search[i];
+  snorm = sqrt(snorm);
+  real smag = snorm * m->meaninertia * (nv > 1 ? nv : 1);
+  real gtol = m->tolerance * m->ls_tolerance * smag;
+  mul_m(m, d, mv, c->search);
+  for (int r = 0; r < d->nefc; r++) {
+    real s = 0;
+    for (int i = 0; i < nv; i++) s += d->efc_J[r * nv + i] * c->search[i];
+    L.jv[r] = s;
+    L.quad[r][0] = 0.5 * c->Jaref[r] * c->Jaref[r] * d->efc_D[r];
+    L.quad[r][1] = s * c->Jaref[r] * d->efc_D[r];
+    L.quad[r][2] = 0.5 * s * s * d->efc_D[r];
+  }
+  real sMa = 0, sq = 0, smv = 0;
+  for (int i = 0; i < nv; i++) { sMa += c->search[i] * c->Ma[i]; sq += c->search[i] * d->qfrc_smooth[i]; smv += c->search[i] * mv[i]; }
+  L.quad_gauss[0] = c->gauss; L.quad_gauss[1] = sMa - sq; L.quad_gauss[2] = 0.5 * smv;
+
+  ls_point p0 = ls_eval(&L, 0.0);
+  ls_point lo_in = ls_eval(&L, -safe_div(p0.deriv0, p0.deriv1));
+  int lo_less = lo_in.deriv0 < p0.deriv0;
+  ls_point lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
+  int swap = 1, it = 0;
+  while (1) {
+    int done = it >= m->ls_iterations;
+    done |= !swap;
+    done |= (lo.deriv0 < 0) && (lo.deriv0 > -gtol);
+    done |= (hi.deriv0 > 0) && (hi.deriv0 < gtol);
+    if (done) break;
+    ls_point lo_next = ls_eval(&L, lo.alpha - safe_div(lo.deriv0, lo.deriv1));
+    ls_point hi_next = ls_eval(&L, hi.alpha - safe_div(hi.deriv0, hi.deriv1));
+    ls_point mid = ls_eval(&L, 0.5 * (lo.alpha + hi.alpha));
+    int s1 = (lo.deriv0 > 0) || (lo.deriv0 < lo_next.deriv0);
+    if (s1) lo = lo_next;
+    int s2 = (mid.deriv0 < 0) && (lo.deriv0 < mid.deriv0);
+    if (s2) lo = mid;
+    int s3 = (hi_next.deriv0 < 0) && (lo.deriv0 < hi_next.deriv0);
+    if (s3) lo = hi_next;
+    int s4 = (hi.deriv0 < 0) || (hi.deriv0 > hi_next.deriv0);
+    if (s4) hi = hi_next;
+    int s5 = (mid.deriv0 > 0) && (hi.deriv0 > mid.deriv0);
+    if (s5) hi = mid;
+    int s6 = (lo_next.deriv0 > 0) && (hi.deriv0 > lo_next.deriv0);
+    if (s6) hi = lo_next;
+    swap = s1 | s2 | s3 | s4 | s5 | s6;
+    it++;
+  }
+  int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+  real alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+  if (!improved) alpha = 0;
+  d->ls_alpha = alpha; d->ls_iters = it;
+  for (int i = 0; i < nv; i++) { c->qacc[i] += alpha * c->search[i]; c->Ma[i] += alpha * mv[i]; }
+  for (int r = 0; r < d->nefc; r++) c->Jaref[r] += alpha * L.jv[r];
+}
+
+static void solve(const odko_model* m, odko_data* d) {
+  int nv = m->nv;
+  solver_ctx cw, cs, *c;
+  /* warmstart: lower cost of qacc_warmstart / qacc_smooth */
+  ctx_init(m, d, &cw, d->qacc_warmstart); update_constraint(m, d, &cw);
+  ctx_init(m, d, &cs, d->qacc_smooth); update_constraint(m, d, &cs);
+  d->warm_used = cw.cost < cs.cost;
+  c = d->warm_used ? &cw : &cs;
+  d->solver_cost0 = c->cost;
+  update_gradient(m, d, c);
+  for (int i = 0; i < nv; i++) c->search[i] = -c->Mgrad[i];
+  /* iterations: the model sets iterations=1 -> body() exactly once */
+  for (int it = 0; it < m->iterations; it++) {
+    linesearch(m, d, c);
+    update_constraint(m, d, c);
+    if (it + 1 < m->iterations) {
+      real prev_cost = d->solver_cost0;
+      update_gradient(m, d, c);
+      for (int i = 0; i < nv; i++) c->search[i] = -c->Mgrad[i];
+      /* termination tests of mjx solver.cond (only reached when iterations > 1) */
+      real scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1)), gn = 0;
+      for (int i = 0; i < nv; i++) gn += c->grad[i] * c->grad[i];
+      if (scale * (prev_cost - c->cost) < m->tolerance || scale * sqrt(gn) < m->tolerance) break;
+      d->solver_cost0 = c->cost;
+    }
+  }
+  d->solver_cost1 = c->cost;
+  memcpy(d->qacc, c->qacc, nv * sizeof(real));
+  memcpy(d->qacc_warmstart, c->qacc, nv * sizeof(real));
+  memcpy(d->qfrc_constraint, c->qfrc_constraint, nv * sizeof(real));
+  memcpy(d->efc_force, c->force, d->nefc * sizeof(real));
+}
+
+/* ------------------------------------------------------------------ sensors (mjx sensor.py) */
+static void sensors(const odko_model* m, odko_data* d) {
+  rne_cacc(m, d, 1); /* rne_postconstraint's cacc (uses the solved qacc) */
+  for (int s = 0; s < m->nsensor; s++) {
+    int site = m->sensor_objid[s], b = m->site_bodyid[s >= 0 ? site : 0];
+    real* out = d->sensordata + m->sensor_adr[s];
+    const real* R = d->site_xmat[site];
+    real dif[3], vang[3], vlin[3], t[3];
+    v3_sub(dif, d->site_xpos[site], d->subtree_com[m->body_rootid[b]]);
+    v3_copy(vang, d->cvel[b]);
+    v3_cross(t, dif, d->cvel[b]);          /* lin at site = lin_ref - dif x ang */
+    v3_sub(vlin, d->cvel[b] + 3, t);
+    switch (m->sensor_type[s]) {
+      case ODKO_S_GYRO: mat_tmulvec(out, R, vang); break;
+      case ODKO_S_VELOCIMETER: mat_tmulvec(out, R, vlin); break;
+      case ODKO_S_ACCELEROMETER: {
+        real al[3], wl[3], vl[3], corr[3], acc[3];
+        v3_cross(t, dif, d->cacc[b]);
+        v3_sub(al, d->cacc[b] + 3, t);
+        mat_tmulvec(acc, R, al);
+        mat_tmulvec(wl, R, vang);
+        mat_tmulvec(vl, R, vlin);
+        v3_cross(corr, wl, vl);
+        v3_addscl(out, acc, corr, 1);
+        break;
+      }
+      case ODKO_S_FRAMEZAXIS: out[0] = R[2]; out[1] = R[5]; out[2] = R[8]; break;
+      case ODKO_S_FRAMEXAXIS: out[0] = R[0]; out[1] = R[3]; out[2] = R[6]; break;
+      case ODKO_S_FRAMELINVEL: v3_copy(out, vlin); break;
+      case ODKO_S_FRAMEANGVEL: v3_copy(out, vang); break;
+      case ODKO_S_FRAMEPOS: v3_copy(out, d->site_xpos[site]); break;
+      case ODKO_S_FRAMEQUAT: {
+        real q[4];
+        quat_mul(q, d->xquat[b], m->site_quat[site]);
+        quat_normalize(q);
+        memcpy(out, q, sizeof(q));
+        break;
+      }
+      default: break;
+    }
+  }
+}
+
+void odko_forward(const odko_model* m, odko_data* d) {
+  fwd_position(m, d);
+  fwd_velocity(m, d);
+  fwd_actuation(m, d);
+  fwd_acceleration(m, d);
+  if (d->nefc == 0) memcpy(d->qacc, d->qacc_smooth, m->nv * sizeof(real));
+  else solve(m, d);
+  sensors(m, d);
+}
+
+/* mjx forward.euler with eulerdamp disabled (open_duck_mini_v2.xml:6-8) */
+static void euler(const odko_model* m, odko_data* d) {
+  real dt = m->timestep;
+  if (m->eulerdamp) {
+    /* implicit-in-damping velocity update: (M + dt*diag(damping)) qacc' = qfrc_smooth + qfrc_constraint */
+    int nv = m->nv;
+    real H[ODKO_MAXV * ODKO_MAXV], L[ODKO_MAXV * ODKO_MAXV], rhs[ODKO_MAXV];
+    memcpy(H, d->qM, (size_t)nv * nv * sizeof(real));
+    for (int i = 0; i < nv; i++) { H[i * nv + i] += dt * m->dof_damping[i]; rhs[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i]; }
+    cholesky(L, H, nv);
+    chol_solve(d->qacc, L, rhs, nv);
+  }
+  for (int i = 0; i < m->nv; i++) d->qvel[i] += dt * d->qacc[i];
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == ODKO_JNT_FREE) {
+      for (int k = 0; k < 3; k++) d->qpos[qa + k] += dt * d->qvel[da + k];
+      real w[3] = {d->qvel[da + 3], d->qvel[da + 4], d->qvel[da + 5]};
+      real n = sqrt(v3_dot(w, w)), q[4], r[4];
+      if (n < MINVAL) { w[0] = 1; w[1] = 0; w[2] = 0; n = 0; } else { w[0] /= n; w[1] /= n; w[2] /= n; } /* math.normalize_with_norm */
+      real ang = dt * n, s = sin(0.5 * ang);
+      q[0] = cos(0.5 * ang); q[1] = s * w[0]; q[2] = s * w[1]; q[3] = s * w[2];
+      quat_mul(r, d->qpos + qa + 3, q);
+      quat_normalize(r);
+      memcpy(d->qpos + qa + 3, r, sizeof(r));
+    } else {
+      d->qpos[qa] += dt * d->qvel[da];
+    }
+  }
+  d->time += dt;
+}
+
+void odko_step(const odko_model* m, odko_data* d) {
+  odko_forward(m, d);
+  euler(m, d);
+}
+
+void odko_env_physics_step(const odko_model* m, odko_data* d, const real* ctrl, int n_substeps) {
+  for (int s = 0; s < n_substeps; s++) {
+    for (int u = 0; u < m->nu; u++) d->ctrl[u] = ctrl[u];
+    odko_step(m, d);
+  }
+}

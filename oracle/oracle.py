@@ -1,0 +1,238 @@
+"""ctypes wrapper around the CPU oracle (oracle/libodk_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the
+product package (open_duck_playground_amd)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(force: bool = False) -> None:
+    srcs = [os.path.join(_DIR, f) for f in ("odk_oracle.c", "odk_oracle_env.c", "odk_oracle.h", "odk_oracle_env.h", "Makefile")]
+    libs = [os.path.join(_DIR, f) for f in ("libodk_oracle.so", "libodk_oracle_f32.so")]
+    if not force and all(os.path.exists(l) for l in libs):
+        newest = max(os.path.getmtime(s) for s in srcs if os.path.exists(s))
+        if all(os.path.getmtime(l) >= newest for l in libs):
+            return
+    subprocess.check_call(["make", "-C", _DIR, "-B", "-s"])
+
+
+class _Lib:
+    def __init__(self, f32: bool = False):
+        build()
+        self.f32 = f32
+        self.real = C.c_float if f32 else C.c_double
+        self.npreal = np.float32 if f32 else np.float64
+        self.lib = C.CDLL(os.path.join(_DIR, "libodk_oracle_f32.so" if f32 else "libodk_oracle.so"))
+        L = self.lib
+        P = C.c_void_p
+        RP = C.POINTER(self.real)
+        L.odko_model_load.restype = P; L.odko_model_load.argtypes = [C.c_char_p, C.c_uint64]
+        L.odko_model_free.argtypes = [P]
+        L.odko_model_copy.restype = P; L.odko_model_copy.argtypes = [P]
+        L.odko_model_field.restype = RP; L.odko_model_field.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
+        L.odko_model_int.restype = C.c_int; L.odko_model_int.argtypes = [P, C.c_char_p]
+        L.odko_data_new.restype = P
+        L.odko_data_free.argtypes = [P]
+        for fn in ("odko_make_data", "odko_forward", "odko_step"):
+            getattr(L, fn).argtypes = [P, P]
+        L.odko_env_physics_step.argtypes = [P, P, RP, C.c_int]
+        L.odko_data_field.restype = RP; L.odko_data_field.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
+        L.odko_data_int.restype = C.c_int; L.odko_data_int.argtypes = [P, C.c_char_p]
+        # env half
+        L.odko_prm_new.restype = P
+        L.odko_prm_new.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
+                                   C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int]
+        L.odko_prm_free.argtypes = [P]
+        L.odko_prm_set_table64.argtypes = [P, C.POINTER(C.c_double)]
+        L.odko_prm_eval64.argtypes = [P, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
+        L.odko_prm_eval.argtypes = [P, self.real, self.real, self.real, C.c_int, RP]
+        L.odko_prm_index.argtypes = [P, self.real, self.real, self.real, C.POINTER(C.c_int)]
+        L.odko_env_new.restype = P; L.odko_env_new.argtypes = [P, P, P]
+        L.odko_env_free.argtypes = [P]
+        L.odko_env_config.restype = RP; L.odko_env_config.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
+        L.odko_env_field.restype = RP; L.odko_env_field.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
+        L.odko_env_int.restype = C.POINTER(C.c_int); L.odko_env_int.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
+        L.odko_env_data.restype = P; L.odko_env_data.argtypes = [P]
+        L.odko_env_reset.argtypes = [P, C.c_uint32, C.c_uint32]
+        L.odko_env_step.argtypes = [P, RP]
+        L.odko_rng_uniform.restype = C.c_float; L.odko_rng_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.odko_env_key.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        for name in ("odko_reward_tracking_lin_vel", "odko_reward_tracking_ang_vel"):
+            getattr(L, name).restype = self.real
+            getattr(L, name).argtypes = [RP, RP, self.real]
+        L.odko_cost_torques.restype = self.real; L.odko_cost_torques.argtypes = [RP, C.c_int]
+        L.odko_cost_action_rate.restype = self.real; L.odko_cost_action_rate.argtypes = [RP, RP, C.c_int]
+        L.odko_cost_stand_still.restype = self.real; L.odko_cost_stand_still.argtypes = [RP, RP, RP, RP, C.c_int]
+        L.odko_reward_imitation.restype = self.real; L.odko_reward_imitation.argtypes = [RP, RP, RP, RP, RP, RP, RP]
+        L.odko_rollout_mt.restype = C.c_double
+        L.odko_rollout_mt.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+
+    def arr(self, x):
+        return np.ascontiguousarray(x, dtype=self.npreal)
+
+    def ptr(self, a):
+        return a.ctypes.data_as(C.POINTER(self.real))
+
+
+_libs = {}
+
+
+def lib(f32: bool = False) -> _Lib:
+    if f32 not in _libs:
+        _libs[f32] = _Lib(f32)
+    return _libs[f32]
+
+
+class _Fields:
+    """numpy views into a native struct via the *_field(name) accessors."""
+
+    def __init__(self, L: _Lib, handle, getter, int_getter=None):
+        self._L, self._h, self._get, self._iget = L, handle, getter, int_getter
+
+    def view(self, name: str) -> np.ndarray:
+        n = C.c_int(0)
+        p = self._get(self._h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def __getitem__(self, name):
+        return self.view(name)
+
+
+class OracleModel:
+    def __init__(self, blob: bytes, f32: bool = False, _handle=None):
+        self.L = lib(f32)
+        self.h = _handle if _handle is not None else self.L.lib.odko_model_load(blob, len(blob))
+        if not self.h:
+            raise ValueError("odko_model_load failed")
+        self.f = _Fields(self.L, self.h, self.L.lib.odko_model_field)
+        for k in ("nq", "nv", "nu", "nbody", "njnt", "nsite", "nsensordata", "ncgeom", "npair"):
+            setattr(self, k, self.L.lib.odko_model_int(self.h, k.encode()))
+
+    def copy(self) -> "OracleModel":
+        return OracleModel(b"", self.L.f32, _handle=self.L.lib.odko_model_copy(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.lib.odko_model_free(self.h)
+            self.h = None
+
+
+class OracleData:
+    def __init__(self, model: OracleModel, _handle=None, owner=True):
+        self.m = model
+        self.L = model.L
+        self.owner = owner
+        self.h = _handle if _handle is not None else self.L.lib.odko_data_new()
+        if _handle is None:
+            self.L.lib.odko_make_data(model.h, self.h)
+        self.f = _Fields(self.L, self.h, self.L.lib.odko_data_field)
+
+    def __getitem__(self, name):
+        return self.f.view(name)
+
+    def i(self, name):
+        return self.L.lib.odko_data_int(self.h, name.encode())
+
+    def forward(self):
+        self.L.lib.odko_forward(self.m.h, self.h)
+
+    def step(self):
+        self.L.lib.odko_step(self.m.h, self.h)
+
+    def env_physics_step(self, ctrl, n_substeps=10):
+        c = self.L.arr(ctrl)
+        self.L.lib.odko_env_physics_step(self.m.h, self.h, self.L.ptr(c), n_substeps)
+
+    def M(self):
+        nv = self.m.nv
+        return self["qM"][: nv * nv].reshape(nv, nv).copy()
+
+    def J(self):
+        nv, nefc = self.m.nv, self.i("nefc")
+        return self["efc_J"][: nefc * nv].reshape(nefc, nv).copy()
+
+    def __del__(self):
+        if self.owner and getattr(self, "h", None):
+            self.L.lib.odko_data_free(self.h)
+            self.h = None
+
+
+class OraclePRM:
+    """PolyReferenceMotion restatement (reference poly_reference_motion.py:148-168)."""
+
+    def __init__(self, prm: dict, f32: bool = False):
+        self.L = lib(f32)
+        self.table = np.ascontiguousarray(prm["table"], dtype=np.float32)
+        d = lambda k: np.ascontiguousarray(prm[k], dtype=np.float64)
+        self.dxs, self.dys, self.dths = d("dxs"), d("dys"), d("dthetas")
+        self.ranges = np.concatenate([d("dx_range"), d("dy_range"), d("dtheta_range")])
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        self.nsteps = int(prm["nb_steps_in_period"][0])
+        self.h = self.L.lib.odko_prm_new(self.table.ctypes.data_as(C.POINTER(C.c_float)), dp(self.dxs), len(self.dxs),
+                                         dp(self.dys), len(self.dys), dp(self.dths), len(self.dths), dp(self.ranges), self.nsteps)
+
+        if "table64" in prm:
+            self.table64 = np.ascontiguousarray(prm["table64"], dtype=np.float64)
+            self.L.lib.odko_prm_set_table64(self.h, dp(self.table64))
+
+    def eval64(self, dx, dy, dth, i):
+        out = np.zeros(40, dtype=np.float64)
+        self.L.lib.odko_prm_eval64(self.h, dx, dy, dth, int(i), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def eval(self, dx, dy, dth, i):
+        out = np.zeros(40, dtype=self.L.npreal)
+        self.L.lib.odko_prm_eval(self.h, dx, dy, dth, int(i), self.L.ptr(out))
+        return out
+
+    def index(self, dx, dy, dth):
+        idx = (C.c_int * 3)()
+        self.L.lib.odko_prm_index(self.h, dx, dy, dth, idx)
+        return tuple(idx)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.lib.odko_prm_free(self.h)
+            self.h = None
+
+
+class OracleEnv:
+    """One Joystick environment (reference joystick.py) incl. Episode/AutoReset wrappers."""
+
+    def __init__(self, model: OracleModel, prm: OraclePRM):
+        self.L = model.L
+        self.m, self.prm = model, prm
+        self.h = self.L.lib.odko_env_new(model.h, prm.h, None)
+        self.f = _Fields(self.L, self.h, self.L.lib.odko_env_field)
+        self.cfg = _Fields(self.L, self.h, self.L.lib.odko_env_config)
+        self.data = OracleData(model, _handle=self.L.lib.odko_env_data(self.h), owner=False)
+
+    def __getitem__(self, name):
+        return self.f.view(name)
+
+    def ints(self, name):
+        n = C.c_int(0)
+        p = self.L.lib.odko_env_int(self.h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    def reset(self, seed: int, env_id: int):
+        self.L.lib.odko_env_reset(self.h, seed, env_id)
+
+    def step(self, action):
+        a = self.L.arr(action)
+        self.L.lib.odko_env_step(self.h, self.L.ptr(a))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.lib.odko_env_free(self.h)
+            self.h = None

@@ -1,0 +1,158 @@
+"""Analytic invariants that pin the oracle's physics.  No MJX/MuJoCo install
+exists, so these replace golden vectors: PARITY UNPINNED vs MJX, see DESIGN.md."""
+import numpy as np
+import pytest
+
+from open_duck_playground_amd import mjcf
+
+G = 9.81
+MASS = 2.1071407
+
+
+def _data(O, model, qpos=None, qvel=None, ctrl=None):
+    om = O.OracleModel(model.blob())
+    d = O.OracleData(om)
+    d["qpos"][: om.nq] = model.a["key_qpos"] if qpos is None else qpos
+    if qvel is not None:
+        d["qvel"][: om.nv] = qvel
+    d["ctrl"][: om.nu] = model.a["key_ctrl"] if ctrl is None else ctrl
+    return om, d
+
+
+def _random_qpos(model, rng, z=1.0):
+    q = np.array(model.a["key_qpos"], float)
+    q[2] = z
+    quat = rng.normal(size=4); q[3:7] = quat / np.linalg.norm(quat)
+    for j in range(1, model.njnt):
+        a = model.a["jnt_qposadr"][j]
+        lo, hi = model.a["jnt_range"][j]
+        q[a] = rng.uniform(lo, hi)
+    return q
+
+
+@pytest.mark.parametrize("task", ["a", "b"])
+def test_mass_matrix_matches_independent_jacobian_sum(oracle_mod, model_a, model_b, task):
+    model = model_a if task == "a" else model_b
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        q = _random_qpos(model, rng)
+        om, d = _data(oracle_mod, model, qpos=q)
+        d.forward()
+        M = d.M()
+        M2, _ = mjcf.mass_matrix(model.a, q)  # sum_b J^T diag(m,I) J, not CRBA
+        np.testing.assert_allclose(M, M2, atol=1e-12)
+        np.testing.assert_allclose(M, M.T, atol=0)
+        assert np.linalg.eigvalsh(M).min() > 0
+        np.testing.assert_allclose(M[:3, :3], MASS * np.eye(3), atol=1e-12)
+
+
+def test_kinematics_matches_numpy(oracle_mod, model_a):
+    rng = np.random.default_rng(1)
+    q = _random_qpos(model_a, rng)
+    om, d = _data(oracle_mod, model_a, qpos=q)
+    d.forward()
+    xpos, xquat, _, _ = mjcf.body_frames(model_a.a, q)
+    np.testing.assert_allclose(d["xpos"][: om.nbody * 3].reshape(-1, 3), xpos, atol=1e-12)
+    np.testing.assert_allclose(d["xquat"][: om.nbody * 4].reshape(-1, 4), xquat, atol=1e-12)
+    # site positions
+    for s in range(om.nsite):
+        b = model_a.a["site_bodyid"][s]
+        p = xpos[b] + mjcf.quat_to_mat(xquat[b]) @ model_a.a["site_pos"][s]
+        np.testing.assert_allclose(d["site_xpos"][3 * s: 3 * s + 3], p, atol=1e-12)
+
+
+def test_free_fall_momentum_rate(oracle_mod, model_a):
+    """Airborne, zero velocity: d/dt (linear momentum) = M[0:3,:] qacc = m g, whatever the joints do."""
+    rng = np.random.default_rng(2)
+    q = _random_qpos(model_a, rng, z=1.0)
+    om, d = _data(oracle_mod, model_a, qpos=q, ctrl=rng.uniform(-1, 1, 14))
+    d.forward()
+    assert (d["contact_dist"][:8] > 0).all()
+    M = d.M()
+    np.testing.assert_allclose(M[:3] @ d["qacc"][: om.nv], [0, 0, -MASS * G], atol=1e-9)
+
+
+def test_gravity_bias_matches_jacobian(oracle_mod, model_a):
+    """qvel = 0: qfrc_bias = -sum_b m_b Jp_b^T g (independent Jacobians from the model compiler)."""
+    rng = np.random.default_rng(3)
+    q = _random_qpos(model_a, rng)
+    om, d = _data(oracle_mod, model_a, qpos=q)
+    d.forward()
+    _, jacs = mjcf.mass_matrix(model_a.a, q)
+    expect = np.zeros(om.nv)
+    for b, (Jp, _) in enumerate(jacs):
+        expect += model_a.a["body_mass"][b] * Jp.T @ np.array([0, 0, G])
+    np.testing.assert_allclose(d["qfrc_bias"][: om.nv], expect, atol=1e-10)
+
+
+def test_coriolis_matches_lagrangian_finite_difference(oracle_mod, model_a):
+    """Hinge rows of the bias force with gravity off: c_i = sum_k dM_i./dq_k v_k . v - 1/2 v^T dM/dq_i v
+    (only hinge velocities non-zero, so only hinge partials are needed)."""
+    rng = np.random.default_rng(4)
+    q = _random_qpos(model_a, rng)
+    nv = model_a.nv
+    v = np.zeros(nv); v[6:] = rng.normal(0, 2.0, nv - 6)
+    om, d = _data(oracle_mod, model_a, qpos=q, qvel=v)
+    om.f["gravity"][:] = 0
+    d.forward()
+    h = 1e-6
+    dM = np.zeros((nv, nv, nv))
+    for k in range(6, nv):
+        qp, qm = q.copy(), q.copy()
+        qp[k + 1] += h; qm[k + 1] -= h
+        dM[k] = (mjcf.mass_matrix(model_a.a, qp)[0] - mjcf.mass_matrix(model_a.a, qm)[0]) / (2 * h)
+    c = np.einsum("kij,k,j->i", dM, v, v) - 0.5 * np.einsum("ijk,j,k->i", dM, v, v)
+    np.testing.assert_allclose(d["qfrc_bias"][6:nv], c[6:], atol=2e-7)
+
+
+def test_static_stance_balances_weight(oracle_mod, model_a):
+    om, d = _data(oracle_mod, model_a)
+    d.forward()
+    assert d.i("nefc") == 76 and (d.i("nf"), d.i("nl"), d.i("nc")) == (14, 14, 48)
+    for _ in range(500):
+        d.env_physics_step(model_a.a["key_ctrl"], 1)
+    assert np.abs(d["qvel"][: om.nv]).max() < 2e-2
+    J, f = d.J(), d["efc_force"][:76]
+    np.testing.assert_allclose((J.T @ f)[2], MASS * G, rtol=2e-3)   # vertical support = weight
+    assert (f[28:] >= 0).all()                                       # pyramid forces are unilateral
+    np.testing.assert_allclose(d["sensordata"][6:9], [0, 0, G], atol=0.3)  # accelerometer ~ +g at rest
+    assert d["sensordata"][11] > 0.99                                # upvector z
+    assert 0.14 < d["qpos"][2] < 0.18
+
+
+def test_solver_decreases_cost_and_limits_work(oracle_mod, model_a):
+    q = np.array(model_a.a["key_qpos"], float)
+    q[2] = 1.0
+    q[10] = 2.0  # left knee beyond its +1.5708 limit
+    om, d = _data(oracle_mod, model_a, qpos=q)
+    d.forward()
+    assert d["solver_cost1"][0] <= d["solver_cost0"][0]
+    nf = d.i("nf")
+    pos = d["efc_pos"][nf: nf + 14]
+    assert pos[3] == pytest.approx(1.5707963267948966 - 2.0)
+    assert d["efc_force"][nf + 3] > 0  # limit pushes back
+    assert d["efc_J"][(nf + 3) * om.nv + 9] == -1.0
+
+
+def test_backlash_model_counts(oracle_mod, model_b):
+    om, d = _data(oracle_mod, model_b)
+    d.forward()
+    assert (om.nq, om.nv) == (31, 30)
+    assert (d.i("nf"), d.i("nl"), d.i("nc")) == (14, 24, 48)
+    for _ in range(300):
+        d.env_physics_step(model_b.a["key_ctrl"], 1)
+    assert np.isfinite(d["qpos"][: om.nq]).all() and 0.13 < d["qpos"][2] < 0.18
+
+
+def test_float32_build_tracks_float64(oracle_mod, model_a):
+    rng = np.random.default_rng(5)
+    ctrl = np.array(model_a.a["key_ctrl"]) + rng.uniform(-0.2, 0.2, 14)
+    res = []
+    for f32 in (False, True):
+        om = oracle_mod.OracleModel(model_a.blob(), f32=f32)
+        d = oracle_mod.OracleData(om)
+        d["qpos"][: om.nq] = model_a.a["key_qpos"]
+        d.env_physics_step(ctrl, 1)
+        res.append((np.array(d["qpos"][: om.nq], float), np.array(d["qvel"][: om.nv], float)))
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res[1][1], res[0][1], rtol=1e-3, atol=2e-4)
