@@ -1,0 +1,132 @@
+/* odk.h -- C-ABI of the MI355X-native Open Duck env engine (libodk.so).
+ *
+ * Drop-in boundary for the physics + Joystick-task hot path of apirrone/Open_Duck_Playground
+ * (SURVEY.md section 8b).  The reference has no FFI: its boundary is the Python/JAX API
+ *     mjx.put_model(mj_model)                                  playground/open_duck_mini_v2/base.py:61
+ *     Joystick.reset(rng) -> State                              playground/open_duck_mini_v2/joystick.py:206
+ *     Joystick.step(State, action) -> State                     playground/open_duck_mini_v2/joystick.py:323
+ *       (which calls mjx_env.init :258 and mjx_env.step(model, data, motor_targets, n_substeps) :420)
+ *     randomize.domain_randomize(model, rng) -> batched fields  playground/common/randomize.py:26-146
+ *     wrapper.wrap_for_brax_training (Vmap/Episode/AutoReset)   playground/common/runner.py:117
+ * Each entry point below names the call it replaces.  Plain pointers and sizes only; all
+ * `*_dev` pointers are device (HIP) addresses owned by the caller; calls are ordered on the caller's
+ * stream (`hipStream_t` passed as void*), never synchronise the host, and never allocate in step.
+ *
+ * Every function returns 0 on success or a negative odk_status; odk_last_error() gives the
+ * thread-local message.  Numerical failure inside an env is NOT an error: it yields NaN ->
+ * done = 1 for that env (reference joystick.py:483-485).
+ */
+#ifndef ODK_H
+#define ODK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct odk_model odk_model;
+typedef struct odk_batch odk_batch;
+
+enum odk_status {
+  ODK_OK = 0,
+  ODK_ERR_INVALID = -1,      /* bad argument / malformed blob */
+  ODK_ERR_UNSUPPORTED = -2,  /* model shape or option the kernels were not built for */
+  ODK_ERR_HIP = -3,          /* HIP runtime failure */
+  ODK_ERR_NOMEM = -4
+};
+
+#define ODK_NOBS 101     /* obs["state"]            joystick.py:570-589 */
+#define ODK_NPRIV 212    /* obs["privileged_state"] joystick.py:596-615 */
+#define ODK_NMETRIC 8    /* reward/cost terms (7) + swing_peak, joystick.py:304-311 */
+#define ODK_NU 14
+
+/* Environment configuration == default_config() of the reference (joystick.py:49-102). */
+typedef struct {
+  float ctrl_dt, action_scale, dof_vel_scale, max_motor_velocity;
+  float noise_level, noise_gyro, noise_accelerometer, noise_gravity, noise_joint_vel;
+  float qpos_noise_scale[16];
+  float reward_scales[7];  /* tracking_lin_vel, tracking_ang_vel, torques, action_rate, stand_still, alive, imitation */
+  float tracking_sigma;
+  float push_enable, push_interval_range[2], push_magnitude_range[2];
+  float cmd_range[7][2];   /* lin_vel_x, lin_vel_y, ang_vel_yaw, neck_pitch, head_pitch, head_yaw, head_roll */
+  int32_t use_imitation, use_motor_speed_limits;
+  int32_t autoreset;       /* BraxAutoResetWrapper on/off */
+  int32_t episode_length;  /* EpisodeWrapper */
+  int32_t n_substeps;      /* ctrl_dt / sim_dt */
+  int32_t lanes_per_env;   /* kernel geometry: 32 or 64 (0 = default) */
+} odk_env_config;
+
+/* Caller-owned device outputs of reset/step (any pointer may be NULL to skip it). */
+typedef struct {
+  float* obs_dev;         /* [nenv, 101] */
+  float* priv_dev;        /* [nenv, 212] */
+  float* reward_dev;      /* [nenv] */
+  float* done_dev;        /* [nenv] */
+  float* truncation_dev;  /* [nenv] */
+  float* metrics_dev;     /* [nenv, 8] */
+} odk_outputs;
+
+/* Per-env randomised model fields == the 8 fields of randomize.py:119-144 (geom_friction is a
+ * visual geom in the reference and therefore has no physical effect; it is not taken). */
+enum odk_param {
+  ODK_PARAM_BODY_MASS = 0,        /* [nenv, nbody] */
+  ODK_PARAM_BODY_IPOS_TORSO = 1,  /* [nenv, 3]   body_ipos[TORSO_BODY_ID=1] */
+  ODK_PARAM_DOF_FRICTIONLOSS = 2, /* [nenv, nu]  actuated dofs */
+  ODK_PARAM_DOF_ARMATURE = 3,     /* [nenv, nu] */
+  ODK_PARAM_QPOS0 = 4,            /* [nenv, nu]  actuated joints */
+  ODK_PARAM_KP = 5                /* [nenv, nu]  gainprm[:,0]; biasprm[:,1] = -kp */
+};
+
+const char* odk_last_error(void);
+void odk_default_config(odk_env_config* cfg);
+
+/* mjx.put_model: parse a ModelBlob (open_duck_playground_amd/model.py) */
+int odk_model_load(const void* blob, uint64_t len, odk_model** out);
+void odk_model_free(odk_model* m);
+int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int* nbody);
+
+/* One batch of `nenv` environments resident on HIP device `device`.  `prm_table` is the host
+ * [nx,ny,nth,40,16] float32 reference-motion table (poly_reference_motion.py), grids in float64. */
+int odk_batch_create(const odk_model* m, const odk_env_config* cfg, int nenv, int device, const float* prm_table,
+                     const double* dxs, int nx, const double* dys, int ny, const double* dths, int nth, const double* ranges6,
+                     int nsteps_in_period, odk_batch** out);
+void odk_batch_destroy(odk_batch* b);
+int odk_batch_set_config(odk_batch* b, const odk_env_config* cfg);
+
+/* domain_randomize: per-env model fields, host pointer, copied synchronously */
+int odk_batch_set_param(odk_batch* b, int param, const float* host_values, int count_per_env);
+
+/* Joystick.reset (vmapped) + wrapper resets.  Env e uses key(seed, env_id_offset + e). */
+int odk_reset(odk_batch* b, uint32_t seed, uint32_t env_id_offset, const odk_outputs* outs, void* stream);
+
+/* AutoReset.step -> Episode.step -> Joystick.step for all envs; action_dev is [nenv, nu]. */
+int odk_step(odk_batch* b, const float* action_dev, const odk_outputs* outs, void* stream);
+
+/* mjx_env.step alone (physics only, n_substeps, ctrl = ctrl_dev [nenv, nu]); for parity tests */
+int odk_physics_step(odk_batch* b, const float* ctrl_dev, int n_substeps, void* stream);
+
+/* state access (host pointers, synchronous): qpos [nenv,nq], qvel [nenv,nv], qacc_warmstart [nenv,nv] */
+int odk_batch_get_state(odk_batch* b, float* qpos, float* qvel, float* warm);
+int odk_batch_set_state(odk_batch* b, const float* qpos, const float* qvel, const float* warm);
+/* debug read-back of the last forward pass of every env: sensordata [nenv,46], actuator_force [nenv,14],
+ * contact_dist [nenv,12], qacc [nenv,nv]  (any may be NULL) */
+int odk_batch_get_debug(odk_batch* b, float* sensordata, float* actuator_force, float* contact_dist, float* qacc);
+/* debug: LDS image (floats) of every env's last forward pass, taken at reset / physics_step and, when
+ * odk_set_debug_dump(1), at step; odk_lds_offset names the arrays inside it (csrc/odk_kernels.h Shape) */
+void odk_set_debug_dump(int on);
+int odk_batch_lds_size(const odk_batch* b);
+int odk_batch_get_lds(odk_batch* b, float* host_image);
+int odk_lds_offset(const odk_batch* b, const char* name);
+/* raw per-env info record (floats, layout in csrc/odk_engine.hip) for tests */
+int odk_batch_record_size(const odk_batch* b);
+int odk_batch_get_records(odk_batch* b, float* host_records);
+
+/* live timing of the most recent odk_step launches with HIP events on the launch stream:
+ * returns average milliseconds per launch since the last call (and resets the window) */
+int odk_batch_timing(odk_batch* b, int enable, float* avg_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

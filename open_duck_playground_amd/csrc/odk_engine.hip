@@ -1,0 +1,1042 @@
+// odk_engine.hip -- fused env-step kernels + the C-ABI of include/odk.h (libodk.so).
+//
+// Host side: blob -> DevModel, device buffers, launches on the caller's stream.  Device side:
+// reset / step / physics-only kernels built from odk_kernels.h.  Env logic follows the reference
+// playground/open_duck_mini_v2/joystick.py (line map next to each block) and the brax
+// Episode/AutoReset wrappers.  gfx950 only; no CPU fallback of any kind.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/odk.h"
+#include "odk_kernels.h"
+
+using namespace odk;
+
+// ================================================================================================
+// per-env HBM records (floats; ints stored bit-exact in float slots)
+namespace rec {
+constexpr int CMD = 0, LAST = 7, LAST2 = 21, LAST3 = 35, MT = 49, AIR = 63, PEAK = 65, PUSH = 67, AHIST = 69, IMU = 111;
+constexpr int EPSTEPS = 120, TRUNC = 121, DONE = 122, EPSUM = 123, EPLEN = 124, EPMET = 125;
+constexpr int KEY0 = 133, KEY1 = 134, CTR = 135, STEP = 136, PSTEP = 137, PINT = 138, IMI = 139, LCON = 140;
+constexpr int NINFO = 141;
+}  // namespace rec
+
+template <class S> struct Rec {
+  static constexpr int INFO = S::NQ + 2 * S::NV;
+  static constexpr int SIZE = ((INFO + rec::NINFO + 3) / 4) * 4;
+  static constexpr int FOBS = S::NQ + 2 * S::NV;
+  static constexpr int FSIZE = ((FOBS + ODK_NOBS + ODK_NPRIV + 3) / 4) * 4;
+};
+
+// extra LDS used by the env logic, placed after the physics arrays
+template <class S> struct EnvL {
+  static constexpr int O_INFO = S::TOTAL;          // [144]
+  static constexpr int O_REF = O_INFO + 144;       // [40] current_reference_motion
+  static constexpr int O_ACT = O_REF + 40;         // [16] this step's action
+  static constexpr int O_PRIV = S::O_M;            // [212] aliases M|HL (dead after the last forward)
+  static constexpr int TOTAL = O_ACT + 16;
+  static_assert(S::NM + S::NH >= ODK_NPRIV, "privileged obs must fit in the M|HL region");
+};
+
+using ShapeA = Shape<21, 20, 18, 14, 145, 170, 76>;   // flat_terrain
+using ShapeB = Shape<31, 30, 18, 14, 285, 385, 86>;   // *_backlash
+
+struct KArgs {
+  const DevModel* m;
+  const DevPRM* prm;
+  const float* prm_table;
+  float* recs;        // [nenv][Rec::SIZE]
+  float* first;       // [nenv][Rec::FSIZE]
+  const float* dr;    // [nenv][NDR] or null
+  const float* action;  // [nenv][nu]
+  float* obs; float* priv; float* reward; float* done; float* trunc; float* metrics;
+  float* dbg_lds;     // [nenv][TOTAL] or null: LDS image after the last forward
+  int nenv;
+  uint32_t seed, env_offset;
+  int n_substeps;
+  EnvCfg cfg;
+};
+
+// DR buffer layout per env
+template <class S> struct DRL {
+  static constexpr int MASS = 0, IPOS = S::NB, FRL = S::NB + 3, ARM = FRL + S::NU, Q0 = ARM + S::NU, KP = Q0 + S::NU, SIZE = KP + S::NU;
+};
+
+__device__ __forceinline__ float i2f(int v) { return __int_as_float(v); }
+__device__ __forceinline__ int f2i(float v) { return __float_as_int(v); }
+__device__ __forceinline__ float nan_to_num(float x) {
+  if (isnan(x)) return 0.0f;
+  if (isinf(x)) return x > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+  return x;
+}
+
+// effective per-env model parameters -> LDS
+template <class S, int G>
+__device__ void load_params(float* L, const DevModel* m, const float* dr, int lane) {
+  for (int i = lane; i < S::NQ; i += G) L[S::O_Q0 + i] = m->qpos0[i];
+  for (int i = lane; i < S::NB; i += G) L[S::O_MASS + i] = dr ? dr[DRL<S>::MASS + i] : m->body_mass[i];
+  for (int i = lane; i < S::NV; i += G) { L[S::O_ARM + i] = m->dof_armature[i]; L[S::O_FRL + i] = m->dof_frictionloss[i]; }
+  for (int i = lane; i < S::NU; i += G) L[S::O_KP + i] = dr ? dr[DRL<S>::KP + i] : m->act_kp[i];
+  if (lane < 3) L[S::O_IPOS1 + lane] = dr ? dr[DRL<S>::IPOS + lane] : m->body_ipos[1][lane];
+  ODK_SYNC();
+  if (dr) {
+    for (int u = lane; u < S::NU; u += G) {
+      L[S::O_Q0 + m->act_qposadr[u]] = dr[DRL<S>::Q0 + u];
+      L[S::O_ARM + m->act_dofadr[u]] = dr[DRL<S>::ARM + u];
+      L[S::O_FRL + m->act_dofadr[u]] = dr[DRL<S>::FRL + u];
+    }
+    ODK_SYNC();
+  }
+}
+
+// PolyReferenceMotion.get_reference_motion (reference poly_reference_motion.py:148-168): float32 fma Horner
+__device__ inline int prm_nearest(const float* grid, int n, float v) {
+  int best = 0;
+  float bd = fabsf(grid[0] - v);
+  for (int i = 1; i < n; i++) { const float d = fabsf(grid[i] - v); if (d < bd) { bd = d; best = i; } }
+  return best;
+}
+template <int G>
+__device__ void prm_eval(const DevPRM* p, const float* table, float dx, float dy, float dth, int i, float* out, int lane) {
+  const float x = fminf(fmaxf(dx, p->ranges[0]), p->ranges[1]);
+  const float y = fminf(fmaxf(dy, p->ranges[2]), p->ranges[3]);
+  const float t3 = fminf(fmaxf(dth, p->ranges[4]), p->ranges[5]);
+  const int ix = prm_nearest(p->dxs, p->nx, x), iy = prm_nearest(p->dys, p->ny, y), it = prm_nearest(p->dths, p->nth, t3);
+  float t = (float)(i % p->nsteps) / (float)p->nsteps;
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  const float* c = table + ((size_t)((ix * p->ny + iy) * p->nth + it)) * 640;
+  for (int k = lane; k < 40; k += G) {
+    float yv = c[k * 16];
+#pragma unroll
+    for (int q = 1; q < 16; q++) yv = fmaf(yv, t, c[k * 16 + q]);
+    out[k] = yv;
+  }
+}
+
+// sample_command (joystick.py:671-725); draws base..base+7 of stream (k0,k1,ctr)
+__device__ inline void sample_command(const EnvCfg& c, uint32_t k0, uint32_t k1, uint32_t ctr, uint32_t base, int k, float& out) {
+  const float z = rng_uniform(k0, k1, ctr, base + 7);
+  const float u = rng_uniform(k0, k1, ctr, base + k);
+  out = (z < 0.1f) ? 0.0f : c.cmd_range[k][0] + u * (c.cmd_range[k][1] - c.cmd_range[k][0]);
+}
+
+// _get_obs (joystick.py:487-620): builds privileged_state[212] (whose first 101 entries are `state`) in LDS
+template <class S, int G>
+__device__ void build_obs(float* L, const DevModel* m, const EnvCfg& c, const float* contact, uint32_t k0, uint32_t k1, uint32_t ctr,
+                          int imitation_i, const float* phase, int lane) {
+  using E = EnvL<S>;
+  float* P = L + E::O_PRIV; float* INFO = L + E::O_INFO; const float* SENS = L + S::O_SENS; const float* SCR = L + S::O_SCR;
+  const float* QPOS = L + S::O_QPOS; const float* QVEL = L + S::O_QVEL;
+  const float lvl = c.noise_level;
+  constexpr int NU = S::NU;
+  // imu history ring (noisy gravity, never emitted: joystick.py:522-530)
+  float ng = 0;
+  if (lane < 3) ng = SCR[S::S_MISC + 10 + lane] + (2.0f * rng_uniform(k0, k1, ctr, 10 + lane) - 1.0f) * lvl * c.noise_gravity;
+  float h0 = 0, h1 = 0;
+  if (lane < 3) { h0 = INFO[rec::IMU + lane]; h1 = INFO[rec::IMU + 3 + lane]; }
+  ODK_SYNC();
+  if (lane < 3) { INFO[rec::IMU + lane] = ng; INFO[rec::IMU + 3 + lane] = h0; INFO[rec::IMU + 6 + lane] = h1; }
+  for (int k = lane; k < ODK_NPRIV; k += G) {
+    float v = 0;
+    if (k < 3) v = SENS[m->adr_gyro + k] + (2.0f * rng_uniform(k0, k1, ctr, 4 + k) - 1.0f) * lvl * c.noise_gyro;
+    else if (k < 6) v = SENS[m->adr_accelerometer + k - 3] + (2.0f * rng_uniform(k0, k1, ctr, 7 + k - 3) - 1.0f) * lvl * c.noise_accelerometer;
+    else if (k < 13) v = INFO[rec::CMD + k - 6];
+    else if (k < 13 + NU) {
+      const int u = k - 13, bq = m->act_backlash_qposadr[u];
+      const float ja = QPOS[m->act_qposadr[u]] + (bq >= 0 ? QPOS[bq] : 0.0f);
+      v = ja + (2.0f * rng_uniform(k0, k1, ctr, 13 + u) - 1.0f) * lvl * c.qpos_noise_scale[u] - m->key_ctrl[u];
+    } else if (k < 13 + 2 * NU) {
+      const int u = k - 13 - NU;
+      v = (QVEL[m->act_dofadr[u]] + (2.0f * rng_uniform(k0, k1, ctr, 27 + u) - 1.0f) * lvl * c.noise_joint_vel) * c.dof_vel_scale;
+    } else if (k < 13 + 3 * NU) v = INFO[rec::LAST + k - 13 - 2 * NU];
+    else if (k < 13 + 4 * NU) v = INFO[rec::LAST2 + k - 13 - 3 * NU];
+    else if (k < 13 + 5 * NU) v = INFO[rec::LAST3 + k - 13 - 4 * NU];
+    else if (k < 13 + 6 * NU) v = INFO[rec::MT + k - 13 - 5 * NU];
+    else if (k < 15 + 6 * NU) v = contact[k - 13 - 6 * NU];
+    else if (k < 17 + 6 * NU) v = phase[k - 15 - 6 * NU];
+    else {
+      int q = k - ODK_NOBS;  // privileged tail (joystick.py:596-615)
+      if (q < 3) v = SENS[m->adr_gyro + q];
+      else if (q < 6) v = SENS[m->adr_accelerometer + q - 3];
+      else if (q < 9) v = SCR[S::S_MISC + 10 + q - 6];
+      else if (q < 12) v = SENS[m->adr_local_linvel + q - 9];
+      else if (q < 15) v = SENS[m->adr_global_angvel + q - 12];
+      else if (q < 15 + NU) { const int u = q - 15, bq = m->act_backlash_qposadr[u]; v = QPOS[m->act_qposadr[u]] + (bq >= 0 ? QPOS[bq] : 0.0f) - m->key_ctrl[u]; }
+      else if (q < 15 + 2 * NU) v = QVEL[m->act_dofadr[q - 15 - NU]];
+      else if (q == 15 + 2 * NU) v = QPOS[2];
+      else if (q < 16 + 3 * NU) v = L[S::O_ACTF + q - 16 - 2 * NU];
+      else if (q < 18 + 3 * NU) v = contact[q - 16 - 3 * NU];
+      else if (q < 24 + 3 * NU) { const int t = q - 18 - 3 * NU; v = SENS[m->adr_foot_linvel[t / 3] + t % 3]; }
+      else if (q < 26 + 3 * NU) v = INFO[rec::AIR + q - 24 - 3 * NU];
+      else if (q < 66 + 3 * NU) v = L[E::O_REF + q - 26 - 3 * NU];
+      else if (q == 66 + 3 * NU) v = (float)imitation_i;
+      else v = phase[q - 67 - 3 * NU];
+    }
+    P[k] = v;
+  }
+  ODK_SYNC();
+}
+
+__device__ __forceinline__ void foot_contact_flags(const float* CDIST, float* contact) {
+  for (int f = 0; f < 2; f++) {
+    float md = 1e4f;
+    for (int k = 0; k < 4; k++) md = fminf(md, CDIST[4 * f + k]);
+    contact[f] = md < 0 ? 1.0f : 0.0f;
+  }
+}
+
+template <class S, int G>
+__device__ void write_outputs(const KArgs& a, const float* L, int env, float reward, float done, float trunc, const float* metrics, int lane) {
+  using E = EnvL<S>;
+  const float* P = L + E::O_PRIV;
+  if (a.obs) for (int k = lane; k < ODK_NOBS; k += G) a.obs[(size_t)env * ODK_NOBS + k] = P[k];
+  if (a.priv) for (int k = lane; k < ODK_NPRIV; k += G) a.priv[(size_t)env * ODK_NPRIV + k] = P[k];
+  if (lane == 0) {
+    if (a.reward) a.reward[env] = reward;
+    if (a.done) a.done[env] = done;
+    if (a.trunc) a.trunc[env] = trunc;
+  }
+  if (a.metrics && lane < ODK_NMETRIC) a.metrics[(size_t)env * ODK_NMETRIC + lane] = metrics[lane];
+}
+
+// ================================================================================================
+// Joystick.reset (joystick.py:206-321) + Episode/AutoReset wrapper resets
+template <class S, int G>
+__global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
+  extern __shared__ float lds[];
+  using E = EnvL<S>; using R = Rec<S>;
+  const int slot = threadIdx.x / G, lane = threadIdx.x % G;
+  const int env = blockIdx.x * (64 / G) + slot;
+  const bool live = env < a.nenv;
+  const int e = live ? env : a.nenv - 1;
+  float* L = lds + slot * E::TOTAL;
+  const DevModel* m = a.m;
+  const EnvCfg& c = a.cfg;
+  float* INFO = L + E::O_INFO;
+  load_params<S, G>(L, m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);
+  uint32_t k0, k1;
+  threefry2x32(a.seed, 0x4F444B31u, a.env_offset + (uint32_t)e, 0u, k0, k1);
+  const uint32_t kr = k1 ^ 0x52535421u;
+  for (int i = lane; i < S::NQ; i += G) L[S::O_QPOS + i] = m->key_qpos[i];
+  for (int i = lane; i < S::NV; i += G) { L[S::O_QVEL + i] = 0; L[S::O_WARM + i] = 0; }
+  for (int i = lane; i < 144; i += G) INFO[i] = 0;
+  ODK_SYNC();
+  if (lane < 2) L[S::O_QPOS + lane] += -0.05f + rng_uniform(k0, kr, 0, lane) * 0.1f;
+  if (lane == 2) {
+    const float yaw = -3.14f + rng_uniform(k0, kr, 0, 2) * 6.28f;
+    float s, co;
+    sincosf(0.5f * yaw, &s, &co);
+    float q0[4] = {L[S::O_QPOS + 3], L[S::O_QPOS + 4], L[S::O_QPOS + 5], L[S::O_QPOS + 6]}, qz[4] = {co, 0, 0, s}, r[4];
+    qmul(r, q0, qz);
+    for (int k = 0; k < 4; k++) L[S::O_QPOS + 3 + k] = r[k];
+  }
+  if (lane >= 3 && lane < 9) L[S::O_QVEL + lane - 3] = -0.05f + rng_uniform(k0, kr, 0, 17 + lane - 3) * 0.1f;
+  for (int u = lane; u < S::NU; u += G) {
+    const float v = L[S::O_QPOS + m->act_qposadr[u]] * (0.5f + rng_uniform(k0, kr, 0, 3 + u));
+    L[S::O_QPOS + m->act_qposadr[u]] = v;
+    L[S::O_CTRL + u] = v;
+    INFO[rec::MT + u] = m->key_ctrl[u];
+  }
+  if (lane < 7) sample_command(c, k0, kr, 0, 23, lane, INFO[rec::CMD + lane]);
+  ODK_SYNC();
+  forward_env<S, G>(L, m, lane, 1);
+  if (a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
+  const float pint = c.push_interval_range[0] + rng_uniform(k0, kr, 0, 31) * (c.push_interval_range[1] - c.push_interval_range[0]);
+  const int push_interval_steps = (int)rintf(pint / c.ctrl_dt);
+  if (c.use_imitation) prm_eval<G>(a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], 0, L + E::O_REF, lane);
+  else for (int k = lane; k < 40; k += G) L[E::O_REF + k] = 0;
+  ODK_SYNC();
+  float contact[2];
+  foot_contact_flags(L + S::O_CDIST, contact);
+  const float phase[2] = {0, 0};
+  // stash state before the obs overwrites the M|HL region?  (qpos/qvel/warm live elsewhere: safe)
+  build_obs<S, G>(L, m, c, contact, k0, k1, 0u, 0, phase, lane);
+  if (lane == 0) {
+    INFO[rec::KEY0] = i2f((int)k0); INFO[rec::KEY1] = i2f((int)k1); INFO[rec::CTR] = i2f(1);
+    INFO[rec::STEP] = i2f(0); INFO[rec::PSTEP] = i2f(0); INFO[rec::PINT] = i2f(push_interval_steps);
+    INFO[rec::IMI] = i2f(0); INFO[rec::LCON] = i2f(0);
+  }
+  ODK_SYNC();
+  if (live) {
+    float* rc = a.recs + (size_t)env * R::SIZE;
+    float* fs = a.first + (size_t)env * R::FSIZE;
+    for (int i = lane; i < S::NQ; i += G) { rc[i] = L[S::O_QPOS + i]; fs[i] = L[S::O_QPOS + i]; }
+    for (int i = lane; i < S::NV; i += G) {
+      rc[S::NQ + i] = L[S::O_QVEL + i]; fs[S::NQ + i] = L[S::O_QVEL + i];
+      rc[S::NQ + S::NV + i] = L[S::O_WARM + i]; fs[S::NQ + S::NV + i] = L[S::O_WARM + i];
+    }
+    for (int k = lane; k < ODK_NPRIV; k += G) {
+      if (k < ODK_NOBS) fs[R::FOBS + k] = L[E::O_PRIV + k];
+      fs[R::FOBS + ODK_NOBS + k] = L[E::O_PRIV + k];
+    }
+    for (int k = lane; k < rec::NINFO; k += G) rc[R::INFO + k] = INFO[k];
+    float metrics[ODK_NMETRIC] = {0, 0, 0, 0, 0, 0, 0, 0};
+    write_outputs<S, G>(a, L, env, 0.0f, 0.0f, 0.0f, metrics, lane);
+  }
+}
+
+// ================================================================================================
+// AutoReset.step -> Episode.step -> Joystick.step (joystick.py:323-481), all substeps fused
+template <class S, int G>
+__global__ void __launch_bounds__(64) step_kernel(KArgs a) {
+  extern __shared__ float lds[];
+  using E = EnvL<S>; using R = Rec<S>;
+  constexpr int NU = S::NU;
+  const int slot = threadIdx.x / G, lane = threadIdx.x % G;
+  const int env = blockIdx.x * (64 / G) + slot;
+  const bool live = env < a.nenv;
+  const int e = live ? env : a.nenv - 1;
+  float* L = lds + slot * E::TOTAL;
+  const DevModel* m = a.m;
+  const EnvCfg& c = a.cfg;
+  float* INFO = L + E::O_INFO; float* ACT = L + E::O_ACT; float* CTRL = L + S::O_CTRL;
+  float* rc = a.recs + (size_t)e * R::SIZE;
+  // ---- load state record (coalesced: the group's lanes read consecutive floats)
+  for (int i = lane; i < S::NQ + 2 * S::NV; i += G) L[S::O_QPOS + i] = rc[i];  // qpos|qvel|warm are contiguous in LDS too
+  for (int k = lane; k < rec::NINFO; k += G) INFO[k] = rc[R::INFO + k];
+  for (int u = lane; u < NU; u += G) ACT[u] = a.action[(size_t)e * NU + u];
+  load_params<S, G>(L, m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);  // syncs
+  const uint32_t k0 = (uint32_t)f2i(INFO[rec::KEY0]), k1 = (uint32_t)f2i(INFO[rec::KEY1]), ctr = (uint32_t)f2i(INFO[rec::CTR]);
+  int step = f2i(INFO[rec::STEP]), push_step = f2i(INFO[rec::PSTEP]);
+  const int push_int = f2i(INFO[rec::PINT]);
+  int imi = f2i(INFO[rec::IMI]);
+  const int lcon = f2i(INFO[rec::LCON]);
+  const float prev_done = INFO[rec::DONE];
+  float ep_steps = prev_done != 0.0f ? 0.0f : INFO[rec::EPSTEPS];  // AutoReset.step prologue
+  const float dt = c.ctrl_dt;
+  // ---- imitation phase + reference motion (:325-355)
+  float phase[2] = {0, 0};
+  if (c.use_imitation) {
+    imi = (imi + 1) % a.prm->nsteps;
+    const float ph = ((float)imi / (float)a.prm->nsteps) * 2.0f * PI_F;
+    phase[0] = cosf(ph); phase[1] = sinf(ph);
+    prm_eval<G>(a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], imi, L + E::O_REF, lane);
+  } else {
+    imi = 0;
+    for (int k = lane; k < 40; k += G) L[E::O_REF + k] = 0;
+  }
+  // ---- action delay ring (:362-376): roll by nu, newest first
+  float h0 = 0, h1 = 0;
+  for (int u = lane; u < NU; u += G) { h0 = INFO[rec::AHIST + u]; h1 = INFO[rec::AHIST + NU + u]; }
+  ODK_SYNC();
+  for (int u = lane; u < NU; u += G) { INFO[rec::AHIST + u] = ACT[u]; INFO[rec::AHIST + NU + u] = h0; INFO[rec::AHIST + 2 * NU + u] = h1; }
+  ODK_SYNC();
+  const int aidx = randint3(rng_uniform(k0, k1, ctr, 0));
+  // ---- push (:381-398)
+  const float theta = rng_uniform(k0, k1, ctr, 2) * (2.0f * PI_F);
+  const float mag = c.push_magnitude_range[0] + rng_uniform(k0, k1, ctr, 3) * (c.push_magnitude_range[1] - c.push_magnitude_range[0]);
+  const float gate = (((push_step + 1) % push_int) == 0 ? 1.0f : 0.0f) * c.push_enable;
+  const float push[2] = {cosf(theta) * gate, sinf(theta) * gate};
+  if (lane < 2) L[S::O_QVEL + lane] += push[lane] * mag;
+  // ---- motor targets with speed limit (:404-417)
+  for (int u = lane; u < NU; u += G) {
+    float mt = m->key_ctrl[u] + INFO[rec::AHIST + aidx * NU + u] * c.action_scale;
+    if (c.use_motor_speed_limits) {
+      const float prev = INFO[rec::MT + u], lim = c.max_motor_velocity * dt;
+      mt = fminf(fmaxf(mt, prev - lim), prev + lim);
+    }
+    CTRL[u] = mt;
+  }
+  ODK_SYNC();
+  // ---- mjx_env.step: n_substeps x (forward + Euler)   (:420)
+  for (int s = 0; s < a.n_substeps; s++) {
+    const bool last = s == a.n_substeps - 1;
+    forward_env<S, G>(L, m, lane, last ? 1 : 0);
+    if (last && a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
+    euler_env<S, G>(L, m, lane);
+  }
+  for (int u = lane; u < NU; u += G) INFO[rec::MT + u] = CTRL[u];  // info["motor_targets"] (:422)
+  // ---- contacts, air time, swing peak (:424-435)
+  float contact[2];
+  foot_contact_flags(L + S::O_CDIST, contact);
+  float air[2], peak[2];
+  for (int f = 0; f < 2; f++) {
+    air[f] = INFO[rec::AIR + f] + dt;
+    peak[f] = fmaxf(INFO[rec::PEAK + f], L[S::O_SCR + S::S_MISC + 8 + f]);
+  }
+  ODK_SYNC();
+  if (lane < 2) INFO[rec::AIR + lane] = air[lane];
+  ODK_SYNC();
+  // ---- termination (:483-485)
+  float nanflag = 0;
+  for (int i = lane; i < S::NQ + S::NV; i += G) nanflag += isnan(L[S::O_QPOS + i]) ? 1.0f : 0.0f;
+  nanflag = gsum<G>(nanflag);
+  const bool done_env = (L[S::O_SENS + m->adr_upvector + 2] < 0.0f) || nanflag > 0;
+  // ---- rewards (:622-669, :440-447); lanes 0..NU-1 hold the per-actuator terms
+  float t_tq = 0, t_ar = 0, t_pose = 0, t_vel = 0, t_jp = 0, t_jv = 0;
+  const float* REF = L + E::O_REF;
+  if (lane < NU) {
+    const int u = lane;
+    const float jq = L[S::O_QPOS + m->act_qposadr[u]], jv = L[S::O_QVEL + m->act_dofadr[u]];
+    const float af = L[S::O_ACTF + u];
+    t_tq = af * af;
+    const float da = ACT[u] - INFO[rec::LAST + u];
+    t_ar = da * da;
+    t_pose = fabsf(jq - m->key_ctrl[u]);
+    t_vel = fabsf(jv);
+    if (u < 5 || u >= 9) {  // joints[:5] ++ joints[9:] vs ref[:5] ++ ref[11:16]  (custom_rewards.py:80-88)
+      const int ri = u < 5 ? u : u + 2;
+      const float dp = jq - REF[ri], dv = jv - REF[16 + ri];
+      t_jp = dp * dp; t_jv = dv * dv;
+    }
+  }
+  t_tq = gsum<G>(t_tq); t_ar = gsum<G>(t_ar); t_pose = gsum<G>(t_pose); t_vel = gsum<G>(t_vel); t_jp = gsum<G>(t_jp); t_jv = gsum<G>(t_jv);
+  float rew[7];
+  {
+    const float* cmd = INFO + rec::CMD;
+    const float* lv = L + S::O_SENS + m->adr_local_linvel;
+    const float* gy = L + S::O_SENS + m->adr_gyro;
+    const float ex = (cmd[0] - lv[0]) * (cmd[0] - lv[0]);
+    const float ey = fmaxf(fabsf(lv[1] - cmd[1]) - 0.1f, 0.0f);
+    rew[0] = nan_to_num(expf(-(ex + ey * ey) / c.tracking_sigma));
+    const float ea = (cmd[2] - gy[2]) * (cmd[2] - gy[2]);
+    rew[1] = nan_to_num(expf(-ea / c.tracking_sigma));
+    rew[2] = nan_to_num(t_tq);
+    rew[3] = nan_to_num(t_ar);
+    const float cn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+    rew[4] = nan_to_num(t_pose + t_vel) * (cn < 0.01f ? 1.0f : 0.0f);
+    rew[5] = 1.0f;
+    rew[6] = 0.0f;
+    if (c.use_imitation) {  // custom_rewards.py:4-148
+      const float* bv = L + S::O_QVEL;
+      const float lin_xy = expf(-8.0f * ((bv[0] - REF[34]) * (bv[0] - REF[34]) + (bv[1] - REF[35]) * (bv[1] - REF[35])));
+      const float lin_z = expf(-8.0f * (bv[2] - REF[36]) * (bv[2] - REF[36]));
+      const float ang_xy = expf(-2.0f * ((bv[3] - REF[37]) * (bv[3] - REF[37]) + (bv[4] - REF[38]) * (bv[4] - REF[38]))) * 0.5f;
+      const float ang_z = expf(-2.0f * (bv[5] - REF[39]) * (bv[5] - REF[39])) * 0.5f;
+      float crew = 0;
+      for (int f = 0; f < 2; f++) crew += (contact[f] == (REF[32 + f] > 0.5f ? 1.0f : 0.0f)) ? 1.0f : 0.0f;
+      float r = lin_xy + lin_z + ang_xy + ang_z - t_jp * 15.0f - t_jv * 1.0e-3f + crew;
+      r *= (cn > 0.01f) ? 1.0f : 0.0f;
+      rew[6] = nan_to_num(r);
+    }
+  }
+  float total = 0;
+  for (int k = 0; k < 7; k++) { rew[k] *= c.reward_scales[k]; total += rew[k]; }
+  const float reward = fminf(fmaxf(total * dt, 0.0f), 10000.0f);
+  // ---- obs (uses the pre-shift last_act and the post-increment air time; :437)
+  build_obs<S, G>(L, m, c, contact, k0, k1, ctr, imi, phase, lane);
+  // ---- info updates (:449-469)
+  step += 1; push_step += 1;
+  float la = 0, lla = 0;
+  for (int u = lane; u < NU; u += G) { la = INFO[rec::LAST + u]; lla = INFO[rec::LAST2 + u]; }
+  ODK_SYNC();
+  for (int u = lane; u < NU; u += G) { INFO[rec::LAST3 + u] = lla; INFO[rec::LAST2 + u] = la; INFO[rec::LAST + u] = ACT[u]; }
+  if (step > 500 && lane < 7) sample_command(c, k0, k1, ctr, 41, lane, INFO[rec::CMD + lane]);
+  if (done_env || step > 500) step = 0;
+  int lcon_new = 0;
+  for (int f = 0; f < 2; f++) {
+    if (contact[f] != 0.0f) { air[f] = 0; peak[f] = 0; lcon_new |= (1 << f); }
+  }
+  (void)lcon;
+  float metrics[ODK_NMETRIC];
+  for (int k = 0; k < 7; k++) metrics[k] = c.reward_scales[k] > 0 ? rew[k] : -rew[k];
+  metrics[7] = 0.5f * (peak[0] + peak[1]);
+  // ---- EpisodeWrapper.step
+  ep_steps += 1.0f;
+  float done_f = done_env ? 1.0f : 0.0f, trunc = 0.0f;
+  if (ep_steps >= (float)c.episode_length) { trunc = 1.0f - done_f; done_f = 1.0f; }
+  const float keep = 1.0f - prev_done;  // info['episode_done'] of the previous step
+  ODK_SYNC();
+  if (lane == 0) {
+    INFO[rec::AIR] = air[0]; INFO[rec::AIR + 1] = air[1]; INFO[rec::PEAK] = peak[0]; INFO[rec::PEAK + 1] = peak[1];
+    INFO[rec::PUSH] = push[0]; INFO[rec::PUSH + 1] = push[1];
+    INFO[rec::EPSTEPS] = ep_steps; INFO[rec::TRUNC] = trunc; INFO[rec::DONE] = done_f;
+    INFO[rec::EPSUM] = (INFO[rec::EPSUM] + reward) * keep; INFO[rec::EPLEN] = (INFO[rec::EPLEN] + 1.0f) * keep;
+    for (int k = 0; k < ODK_NMETRIC; k++) INFO[rec::EPMET + k] = (INFO[rec::EPMET + k] + metrics[k]) * keep;
+    INFO[rec::CTR] = i2f((int)(ctr + 1)); INFO[rec::STEP] = i2f(step); INFO[rec::PSTEP] = i2f(push_step);
+    INFO[rec::IMI] = i2f(imi); INFO[rec::LCON] = i2f(lcon_new);
+  }
+  ODK_SYNC();
+  // ---- AutoReset.step epilogue: data, obs <- first_* where done (info is NOT reset)
+  if (done_f != 0.0f && c.autoreset) {
+    const float* fs = a.first + (size_t)e * R::FSIZE;
+    for (int i = lane; i < S::NQ + 2 * S::NV; i += G) L[S::O_QPOS + i] = fs[i];
+    for (int k = lane; k < ODK_NPRIV; k += G) L[E::O_PRIV + k] = fs[R::FOBS + ODK_NOBS + k];
+    // first_obs["state"] == first_priv[:101] by construction; every lane re-reads only what it wrote: no barrier
+  }
+  if (live) {
+    for (int i = lane; i < S::NQ + 2 * S::NV; i += G) rc[i] = L[S::O_QPOS + i];
+    for (int k = lane; k < rec::NINFO; k += G) rc[R::INFO + k] = INFO[k];
+    write_outputs<S, G>(a, L, env, reward, done_f, trunc, metrics, lane);
+  }
+}
+
+// mjx_env.step alone: ctrl = action buffer, no env logic (parity tests)
+template <class S, int G>
+__global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
+  extern __shared__ float lds[];
+  using E = EnvL<S>; using R = Rec<S>;
+  const int slot = threadIdx.x / G, lane = threadIdx.x % G;
+  const int env = blockIdx.x * (64 / G) + slot;
+  const bool live = env < a.nenv;
+  const int e = live ? env : a.nenv - 1;
+  float* L = lds + slot * E::TOTAL;
+  float* rc = a.recs + (size_t)e * R::SIZE;
+  for (int i = lane; i < S::NQ + 2 * S::NV; i += G) L[S::O_QPOS + i] = rc[i];
+  for (int u = lane; u < S::NU; u += G) L[S::O_CTRL + u] = a.action[(size_t)e * S::NU + u];
+  load_params<S, G>(L, a.m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);
+  for (int s = 0; s < a.n_substeps; s++) {
+    const bool last = s == a.n_substeps - 1;
+    forward_env<S, G>(L, a.m, lane, last ? 1 : 0);
+    if (last && a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
+    euler_env<S, G>(L, a.m, lane);
+  }
+  if (live) for (int i = lane; i < S::NQ + 2 * S::NV; i += G) rc[i] = L[S::O_QPOS + i];
+}
+
+// ================================================================================================
+// host side
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(ODK_ERR_HIP, "%s: %s", #x, hipGetErrorString(_e)); } while (0)
+
+struct odk_model { DevModel h; int shape; };  // shape: 0 = A, 1 = B
+
+struct odk_batch {
+  odk_model model;
+  int nenv, device, G;
+  odk_env_config cfg;
+  DevModel* d_model = nullptr; DevPRM* d_prm = nullptr; float* d_table = nullptr;
+  float* d_recs = nullptr; float* d_first = nullptr; float* d_dr = nullptr; float* d_dbg = nullptr;
+  std::vector<float> h_dr; bool dr_enabled = false;
+  int rec_size, frec_size, lds_total, dr_size, env_lds;
+  bool timing = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t ev_used = 0;
+};
+
+extern "C" const char* odk_last_error(void) { return g_err.c_str(); }
+
+extern "C" void odk_default_config(odk_env_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->ctrl_dt = 0.02f; c->action_scale = 0.25f; c->dof_vel_scale = 0.05f; c->max_motor_velocity = 5.24f;
+  c->noise_level = 1.0f; c->noise_gyro = 0.1f; c->noise_accelerometer = 0.05f; c->noise_gravity = 0.1f; c->noise_joint_vel = 2.5f;
+  const float s10[10] = {0.03f, 0.03f, 0.03f, 0.05f, 0.08f, 0.03f, 0.03f, 0.03f, 0.05f, 0.08f};  // BUG-COMPAT joystick.py:184-200
+  for (int i = 0; i < 10; i++) c->qpos_noise_scale[i] = s10[i];
+  const float rs[7] = {2.5f, 6.0f, -1.0e-3f, -0.5f, -0.2f, 20.0f, 1.0f};
+  memcpy(c->reward_scales, rs, sizeof(rs));
+  c->tracking_sigma = 0.01f;
+  c->push_enable = 1.0f; c->push_interval_range[0] = 5.0f; c->push_interval_range[1] = 10.0f;
+  c->push_magnitude_range[0] = 0.1f; c->push_magnitude_range[1] = 1.0f;
+  const float cr[7][2] = {{-0.15f, 0.15f}, {-0.2f, 0.2f}, {-1.0f, 1.0f}, {-0.34f, 1.1f}, {-0.78f, 0.78f}, {-1.5f, 1.5f}, {-0.5f, 0.5f}};
+  memcpy(c->cmd_range, cr, sizeof(cr));
+  c->use_imitation = 1; c->use_motor_speed_limits = 1; c->autoreset = 1; c->episode_length = 1000; c->n_substeps = 10; c->lanes_per_env = 0;
+}
+
+// ---- blob parsing
+struct RecHdr { char name[32]; uint32_t dtype, ndim, shape[4]; uint64_t nbytes; };
+static const unsigned char* find_rec(const unsigned char* b, uint64_t len, const char* name, RecHdr* h) {
+  uint32_t n;
+  memcpy(&n, b + 8, 4);
+  uint64_t off = 16;
+  for (uint32_t i = 0; i < n && off + 64 <= len; i++) {
+    memcpy(h, b + off, 64);
+    off += 64;
+    if (strncmp(h->name, name, 32) == 0) return b + off;
+    off += h->nbytes + ((8 - (h->nbytes & 7)) & 7);
+  }
+  return nullptr;
+}
+struct Blob {
+  const unsigned char* b; uint64_t len; bool ok = true; std::string missing;
+  int F(const char* name, float* dst, int maxc) {
+    RecHdr h; const unsigned char* p = find_rec(b, len, name, &h);
+    if (!p || h.dtype != 0) { ok = false; missing = name; return -1; }
+    int cnt = (int)(h.nbytes / 8);
+    if (cnt > maxc) { ok = false; missing = std::string(name) + " (too large)"; return -1; }
+    for (int i = 0; i < cnt; i++) { double v; memcpy(&v, p + 8 * i, 8); dst[i] = (float)v; }
+    return cnt;
+  }
+  int D(const char* name, double* dst, int maxc) {
+    RecHdr h; const unsigned char* p = find_rec(b, len, name, &h);
+    if (!p || h.dtype != 0) { ok = false; missing = name; return -1; }
+    int cnt = (int)(h.nbytes / 8);
+    if (cnt > maxc) { ok = false; missing = std::string(name) + " (too large)"; return -1; }
+    memcpy(dst, p, 8 * (size_t)cnt);
+    return cnt;
+  }
+  int I(const char* name, int* dst, int maxc) {
+    RecHdr h; const unsigned char* p = find_rec(b, len, name, &h);
+    if (!p || h.dtype != 1) { ok = false; missing = name; return -1; }
+    int cnt = (int)(h.nbytes / 4);
+    if (cnt > maxc) { ok = false; missing = std::string(name) + " (too large)"; return -1; }
+    memcpy(dst, p, 4 * (size_t)cnt);
+    return cnt;
+  }
+  // 2D int table [rows][srccols] -> dst[rows][dstcols]
+  void I2(const char* name, int* dst, int rows_max, int dstcols) {
+    RecHdr h; const unsigned char* p = find_rec(b, len, name, &h);
+    if (!p || h.dtype != 1 || h.ndim != 2) { ok = false; missing = name; return; }
+    int rows = (int)h.shape[0], cols = (int)h.shape[1];
+    if (rows > rows_max || cols > dstcols) { ok = false; missing = std::string(name) + " (shape)"; return; }
+    for (int r = 0; r < rows; r++)
+      for (int c2 = 0; c2 < cols; c2++) memcpy(&dst[r * dstcols + c2], p + 4 * ((size_t)r * cols + c2), 4);
+  }
+};
+
+static void quat2mat(const double* q, double* m) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w * w + x * x - y * y - z * z; m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = w * w - x * x + y * y - z * z; m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = w * w - x * x - y * y + z * z;
+}
+static void make_frame_h(const double* n, float* frame) {
+  double a[3] = {n[0], n[1], n[2]}, b[3] = {0, 0, 0}, c[3];
+  double na = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  for (int k = 0; k < 3; k++) a[k] /= na;
+  if (fabs(a[1]) < 0.5) b[1] = 1; else b[2] = 1;
+  double dt = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  for (int k = 0; k < 3; k++) b[k] -= a[k] * dt;
+  double nb = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+  for (int k = 0; k < 3; k++) b[k] /= nb;
+  c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+  for (int k = 0; k < 3; k++) { frame[k] = (float)a[k]; frame[3 + k] = (float)b[k]; frame[6 + k] = (float)c[k]; }
+}
+// constant impedance of a row at pos = 0 (friction loss): returns R, b
+static void row_consts(const double* solref, const double* solimp, double dt, double invweight, double* R, double* bb) {
+  double timeconst = fmax(solref[0], 2 * dt), dmin = fmin(fmax(solimp[0], 0.0001), 0.9999), dmax = fmin(fmax(solimp[1], 0.0001), 0.9999);
+  double b = 2.0 / (dmax * timeconst);
+  if (solref[1] <= 0) b = -solref[1] / dmax;
+  double imp = dmin;  // imp_x = 0 -> imp_y = 0
+  *R = fmax(invweight * (1 - imp) / imp, 1e-15);
+  *bb = b;
+}
+
+extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
+  if (!blob || !out || len < 16 || memcmp(blob, "ODKM", 4) != 0) return fail(ODK_ERR_INVALID, "odk_model_load: not an ODKM blob");
+  Blob B{(const unsigned char*)blob, len};
+  odk_model* mo = new odk_model();
+  DevModel& m = mo->h;
+  memset(&m, 0, sizeof(m));
+  int one[1];
+  B.I("nq", one, 1); m.nq = one[0]; B.I("nv", one, 1); m.nv = one[0]; B.I("nu", one, 1); m.nu = one[0];
+  B.I("nbody", one, 1); m.nb = one[0]; B.I("njnt", one, 1); m.nj = one[0]; B.I("nsite", one, 1); m.nsite = one[0];
+  if (!B.ok) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
+  if (m.nq > MAXQ || m.nv > MAXV || m.nu > MAXU || m.nb > MAXB || m.nj > MAXJ || m.nsite > MAXSITE) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model too large"); }
+  double dtv[1], g3[3], t1[1];
+  B.D("opt_timestep", dtv, 1); m.dt = (float)dtv[0];
+  B.D("opt_gravity", g3, 3); for (int k = 0; k < 3; k++) m.gravity[k] = (float)g3[k];
+  B.D("opt_tolerance", t1, 1); m.tolerance = (float)t1[0]; B.D("opt_ls_tolerance", t1, 1); m.ls_tolerance = (float)t1[0];
+  B.D("opt_impratio", t1, 1); m.impratio = (float)t1[0]; B.D("stat_meaninertia", t1, 1); m.meaninertia = (float)t1[0];
+  B.I("opt_iterations", &m.iterations, 1); B.I("opt_ls_iterations", &m.ls_iterations, 1);
+  int eulerdamp = 0; B.I("opt_eulerdamp", &eulerdamp, 1);
+  // bodies
+  B.I("k_base_body", &m.base_body, 1); B.I("k_body_in_tree", m.body_in_tree, MAXB); B.I("body_parentid", m.body_parent, MAXB);
+  B.I("body_jntadr", m.body_jntadr, MAXB); B.I("body_jntnum", m.body_jntnum, MAXB);
+  B.I2("k_body_chain", &m.body_chain[0][0], MAXB, MAXCHAIN); B.I("k_body_chain_len", m.body_chain_len, MAXB);
+  B.I2("k_body_ancdof", &m.body_ancdof[0][0], MAXB, MAXV); B.I("k_body_nancdof", m.body_nancdof, MAXB);
+  B.I2("k_body_sub", &m.body_sub[0][0], MAXB, MAXB); B.I("k_body_nsub", m.body_nsub, MAXB);
+  B.F("body_pos", &m.body_pos[0][0], MAXB * 3); B.F("body_quat", &m.body_quat[0][0], MAXB * 4); B.F("body_ipos", &m.body_ipos[0][0], MAXB * 3);
+  B.F("body_mass", m.body_mass, MAXB); B.F("body_inertia_full", &m.body_inertia[0][0], MAXB * 6);
+  // joints
+  B.I("jnt_qposadr", m.jnt_qposadr, MAXJ); B.I("jnt_dofadr", m.jnt_dofadr, MAXJ); B.I("jnt_bodyid", m.jnt_bodyid, MAXJ);
+  B.F("jnt_axis", &m.jnt_axis[0][0], MAXJ * 3); B.F("jnt_pos", &m.jnt_pos[0][0], MAXJ * 3); B.F("jnt_range", &m.jnt_range[0][0], MAXJ * 2);
+  B.F("qpos0", m.qpos0, MAXQ); B.F("key_qpos", m.key_qpos, MAXQ); B.F("key_ctrl", m.key_ctrl, MAXU);
+  // dofs
+  B.I("dof_bodyid", m.dof_body, MAXV); B.I("k_dof_depth", m.dof_depth, MAXV); B.I2("k_dof_anc", &m.dof_anc[0][0], MAXV, MAXV);
+  B.I("k_dof_Madr", m.dof_Madr, MAXV); B.I2("k_dof_anc_adr", &m.dof_anc_adr[0][0], MAXV, MAXV);
+  B.I("k_dof_ndesc", m.dof_ndesc, MAXV); B.I2("k_dof_desc", &m.dof_desc[0][0], MAXV, MAXV); B.I2("k_dof_desc_adr", &m.dof_desc_adr[0][0], MAXV, MAXV);
+  B.I("k_dof_nprefix", m.dof_nprefix, MAXV); B.I2("k_dof_prefix", &m.dof_prefix[0][0], MAXV, MAXV);
+  B.I("k_dof_nsym", m.dof_nsym, MAXV); B.I2("k_dof_sym_dof", &m.dof_sym_dof[0][0], MAXV, MAXV); B.I2("k_dof_sym_adr", &m.dof_sym_adr[0][0], MAXV, MAXV);
+  B.I("k_dof_act", m.dof_act, MAXV); B.I("k_dof_flrow", m.dof_flrow, MAXV); B.I("k_dof_limrow", m.dof_limrow, MAXV);
+  B.F("dof_armature", m.dof_armature, MAXV); B.F("dof_damping", m.dof_damping, MAXV); B.F("dof_frictionloss", m.dof_frictionloss, MAXV);
+  B.F("dof_invweight0", m.dof_invweight0, MAXV);
+  B.I("k_nM", &m.nM, 1); B.I("k_M_i", m.M_i, MAXNZ); B.I("k_M_j", m.M_j, MAXNZ);
+  B.I("k_vdof_depth", m.vdof_depth, MAXV); B.I2("k_vdof_anc", &m.vdof_anc[0][0], MAXV, MAXV); B.I("k_vdof_Madr", m.vdof_Madr, MAXV);
+  B.I2("k_vdof_anc_adr", &m.vdof_anc_adr[0][0], MAXV, MAXV); B.I("k_vdof_ndesc", m.vdof_ndesc, MAXV);
+  B.I2("k_vdof_desc", &m.vdof_desc[0][0], MAXV, MAXV); B.I2("k_vdof_desc_adr", &m.vdof_desc_adr[0][0], MAXV, MAXV);
+  B.I("k_nH", &m.nH, 1); B.I("k_H_i", m.H_i, MAXNZ); B.I("k_H_j", m.H_j, MAXNZ); B.I("k_H_src", m.H_src, MAXNZ);
+  B.I("k_tri_m", m.tri_m, MAXNZ); B.I("k_tri_q", m.tri_q, MAXNZ);
+  // actuators
+  B.I("k_act_qposadr", m.act_qposadr, MAXU); B.I("k_act_dofadr", m.act_dofadr, MAXU); B.I("k_act_backlash_qposadr", m.act_backlash_qposadr, MAXU);
+  B.F("actuator_gainprm0", m.act_kp, MAXU);
+  {
+    float bias[MAXU * 3], gear[MAXU];
+    B.F("actuator_biasprm", bias, MAXU * 3); B.F("actuator_gear", gear, MAXU);
+    for (int u = 0; u < m.nu; u++) {
+      m.act_bias1[u] = bias[3 * u + 1]; m.act_bias2[u] = bias[3 * u + 2];
+      if (bias[3 * u] != 0.0f || gear[u] != 1.0f || fabsf(bias[3 * u + 1] + m.act_kp[u]) > 1e-6f) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "only gear-1 position actuators are supported"); }
+    }
+  }
+  B.F("actuator_ctrlrange", &m.act_ctrlrange[0][0], MAXU * 2); B.F("actuator_forcerange", &m.act_forcerange[0][0], MAXU * 2);
+  B.I("actuator_ctrllimited", m.act_ctrllimited, MAXU); B.I("actuator_forcelimited", m.act_forcelimited, MAXU);
+  // rows
+  m.nfl = B.I("k_fl_dof", m.fl_dof, MAXV); m.nlim = B.I("k_lim_jnt", m.lim_jnt, MAXJ);
+  if (!B.ok) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
+  m.nrow = m.nfl + m.nlim + 48;
+  double dof_solref[MAXV * 2], dof_solimp[MAXV * 5], dof_iw[MAXV], jnt_solref[MAXJ * 2], jnt_solimp[MAXJ * 5], jnt_margin[MAXJ];
+  B.D("dof_solref", dof_solref, MAXV * 2); B.D("dof_solimp", dof_solimp, MAXV * 5); B.D("dof_invweight0", dof_iw, MAXV);
+  B.D("jnt_solref", jnt_solref, MAXJ * 2); B.D("jnt_solimp", jnt_solimp, MAXJ * 5); B.D("jnt_margin", jnt_margin, MAXJ);
+  for (int r = 0; r < m.nfl; r++) {
+    int d = m.fl_dof[r];
+    double R, bb;
+    row_consts(dof_solref + 2 * d, dof_solimp + 5 * d, dtv[0], dof_iw[d], &R, &bb);
+    m.fl_R[r] = (float)R; m.fl_D[r] = (float)(1.0 / R); m.fl_b[r] = (float)bb;
+  }
+  for (int r = 0; r < m.nlim; r++) {
+    int j = m.lim_jnt[r];
+    if (jnt_margin[j] != 0) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "joint margin"); }
+    for (int k = 0; k < 2; k++) m.lim_solref[r][k] = (float)jnt_solref[2 * j + k];
+    for (int k = 0; k < 5; k++) m.lim_solimp[r][k] = (float)jnt_solimp[5 * j + k];
+    m.lim_invweight[r] = (float)dof_iw[m.jnt_dofadr[j]];
+  }
+  // geoms: feet + floor
+  int foot_cg[2], floor_cg[1], cg_type[4], cg_body[4], cg_prio[4], cg_vadr[4], cg_vnum[4], cg_fadr[4], cg_fnum[4], cg_condim[4];
+  double cg_pos[12], cg_quat[16], cg_fric[12], cg_solref[8], cg_solimp[20], cg_solmix[4], hv[64 * 3], biw[MAXB * 2];
+  int hf[128 * 3];
+  B.I("k_foot_cgeom", foot_cg, 2); B.I("k_floor_cgeom", floor_cg, 1); int ncg = B.I("cgeom_type", cg_type, 4);
+  B.I("cgeom_bodyid", cg_body, 4); B.I("cgeom_priority", cg_prio, 4); B.I("cgeom_condim", cg_condim, 4);
+  B.I("cgeom_vertadr", cg_vadr, 4); B.I("cgeom_vertnum", cg_vnum, 4); B.I("cgeom_faceadr", cg_fadr, 4); B.I("cgeom_facenum", cg_fnum, 4);
+  B.D("cgeom_pos", cg_pos, 12); B.D("cgeom_quat", cg_quat, 16); B.D("cgeom_friction", cg_fric, 12);
+  B.D("cgeom_solref", cg_solref, 8); B.D("cgeom_solimp", cg_solimp, 20); B.D("cgeom_solmix", cg_solmix, 4);
+  int nhv = B.D("hull_vert", hv, 64 * 3) / 3; int nhf = B.I("hull_face", hf, 128 * 3) / 3;
+  B.D("body_invweight0", biw, MAXB * 2);
+  B.I("k_foot_body", m.foot_body, 2); B.I2("k_foot_dofmask", &m.foot_dofmask[0][0], 2, MAXV);
+  if (!B.ok || ncg != 3) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
+  (void)nhv; (void)nhf;
+  for (int f = 0; f < 2; f++) {
+    int g = foot_cg[f];
+    if (cg_vnum[g] > MAXHV || cg_fnum[g] > MAXHF || cg_condim[g] != 3) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull too large / condim != 3"); }
+    double gm[9];
+    quat2mat(cg_quat + 4 * g, gm);
+    m.foot_nvert[f] = cg_vnum[g]; m.foot_nface[f] = cg_fnum[g];
+    double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+    for (int v = 0; v < cg_vnum[g]; v++) {
+      const double* p = hv + 3 * (cg_vadr[g] + v);
+      for (int k = 0; k < 3; k++) {
+        m.foot_vert[f][v][k] = (float)(cg_pos[3 * g + k] + gm[3 * k] * p[0] + gm[3 * k + 1] * p[1] + gm[3 * k + 2] * p[2]);
+        lo[k] = fmin(lo[k], p[k]); hi[k] = fmax(hi[k], p[k]);
+      }
+    }
+    for (int t = 0; t < cg_fnum[g]; t++) for (int k = 0; k < 3; k++) m.foot_face[f][t][k] = hf[3 * (cg_fadr[g] + t) + k];
+    double cl[3];
+    for (int k = 0; k < 3; k++) { cl[k] = 0.5 * (lo[k] + hi[k]); m.foot_obb_half[f][k] = (float)(0.5 * (hi[k] - lo[k])); }
+    for (int k = 0; k < 3; k++) m.foot_obb_center[f][k] = (float)(cg_pos[3 * g + k] + gm[3 * k] * cl[0] + gm[3 * k + 1] * cl[1] + gm[3 * k + 2] * cl[2]);
+    for (int k = 0; k < 9; k++) m.foot_obb_axes[f][k] = (float)gm[k];
+  }
+  {
+    int g = floor_cg[0];
+    m.floor_is_plane = cg_type[g] == 0;
+    double pm[9];
+    quat2mat(cg_quat + 4 * g, pm);
+    // floor body is static at the world origin in every reference scene
+    double n[3] = {pm[2], pm[5], pm[8]};
+    for (int k = 0; k < 3; k++) { m.plane_pos[k] = (float)cg_pos[3 * g + k]; m.plane_n[k] = (float)n[k]; }
+    make_frame_h(n, m.plane_frame);
+    // contact parameter mixing (mj_contactParam): pairs 0,1 = floor vs foot, pair 2 = foot vs foot
+    for (int pr = 0; pr < 3; pr++) {
+      int g1 = pr < 2 ? g : foot_cg[0], g2 = pr < 2 ? foot_cg[pr] : foot_cg[1];
+      double mix;
+      if (cg_prio[g1] > cg_prio[g2]) mix = 1; else if (cg_prio[g2] > cg_prio[g1]) mix = 0;
+      else { double s1 = cg_solmix[g1], s2 = cg_solmix[g2]; mix = (s1 >= 1e-15 && s2 >= 1e-15) ? s1 / (s1 + s2) : ((s1 < 1e-15 && s2 < 1e-15) ? 0.5 : (s1 < 1e-15 ? 0.0 : 1.0)); }
+      for (int k = 0; k < 2; k++) m.pair_solref[pr][k] = (float)(mix * cg_solref[2 * g1 + k] + (1 - mix) * cg_solref[2 * g2 + k]);
+      for (int k = 0; k < 5; k++) m.pair_solimp[pr][k] = (float)(mix * cg_solimp[5 * g1 + k] + (1 - mix) * cg_solimp[5 * g2 + k]);
+      double mu = cg_prio[g1] > cg_prio[g2] ? cg_fric[3 * g1] : (cg_prio[g2] > cg_prio[g1] ? cg_fric[3 * g2] : fmax(cg_fric[3 * g1], cg_fric[3 * g2]));
+      m.pair_mu[pr] = (float)mu;
+      double t = biw[2 * cg_body[g1]] + biw[2 * cg_body[g2]];
+      m.pair_invweight[pr] = (float)((t + mu * mu * t) * 2 * mu * mu / (double)m.impratio);
+    }
+  }
+  // sites / sensors
+  B.I("site_bodyid", m.site_body, MAXSITE); B.F("site_pos", &m.site_pos[0][0], MAXSITE * 3); B.F("site_quat", &m.site_quat[0][0], MAXSITE * 4);
+  {
+    double sq[MAXSITE * 4];
+    B.D("site_quat", sq, MAXSITE * 4);
+    for (int s = 0; s < m.nsite; s++) { double mm[9]; quat2mat(sq + 4 * s, mm); for (int k = 0; k < 9; k++) m.site_mat[s][k] = (float)mm[k]; }
+  }
+  B.I("k_site_imu", &m.site_imu, 1); B.I("k_site_feet", m.site_feet, 2);
+  m.nsensor = B.I("sensor_type", m.sensor_type, MAXSENS); B.I("sensor_objid", m.sensor_site, MAXSENS); B.I("sensor_adr", m.sensor_adr, MAXSENS);
+  int adr[7];
+  B.I("k_adr", adr, 7);
+  m.adr_gyro = adr[0]; m.adr_local_linvel = adr[1]; m.adr_accelerometer = adr[2]; m.adr_upvector = adr[3]; m.adr_global_angvel = adr[4];
+  m.adr_foot_linvel[0] = adr[5]; m.adr_foot_linvel[1] = adr[6];
+  int nsd[1]; B.I("nsensordata", nsd, 1);
+  if (!B.ok) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
+  if (nsd[0] != NSENSD) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "sensordata size %d != %d", nsd[0], NSENSD); }
+  if (eulerdamp != 0 || m.iterations != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "kernels implement iterations=1, eulerdamp=disable (open_duck_mini_v2.xml:6-8)"); }
+  for (int s = 0; s < m.nsensor; s++) {
+    int b = m.site_body[m.sensor_site[s]];
+    bool ok = (b == m.base_body) || (b == m.foot_body[0]) || (b == m.foot_body[1]);
+    if (!ok || ((m.sensor_type[s] == 2 || m.sensor_type[s] == 8) && b != m.base_body)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "sensor %d placement", s); }
+  }
+  if (m.nq == ShapeA::NQ && m.nv == ShapeA::NV && m.nb == ShapeA::NB && m.nu == ShapeA::NU && m.nM == ShapeA::NM && m.nH == ShapeA::NH && m.nrow == ShapeA::NROW) mo->shape = 0;
+  else if (m.nq == ShapeB::NQ && m.nv == ShapeB::NV && m.nb == ShapeB::NB && m.nu == ShapeB::NU && m.nM == ShapeB::NM && m.nH == ShapeB::NH && m.nrow == ShapeB::NROW) mo->shape = 1;
+  else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
+  *out = mo;
+  return ODK_OK;
+}
+extern "C" void odk_model_free(odk_model* m) { delete m; }
+extern "C" int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int* nbody) {
+  if (!m) return fail(ODK_ERR_INVALID, "null model");
+  if (nq) *nq = m->h.nq; if (nv) *nv = m->h.nv; if (nu) *nu = m->h.nu; if (nbody) *nbody = m->h.nb;
+  return ODK_OK;
+}
+
+template <class S> static void fill_sizes(odk_batch* b) {
+  b->rec_size = Rec<S>::SIZE; b->frec_size = Rec<S>::FSIZE; b->lds_total = S::TOTAL; b->dr_size = DRL<S>::SIZE; b->env_lds = EnvL<S>::TOTAL;
+}
+
+static void to_dev_cfg(const odk_env_config& c, EnvCfg& d) {
+  d.ctrl_dt = c.ctrl_dt; d.action_scale = c.action_scale; d.dof_vel_scale = c.dof_vel_scale; d.max_motor_velocity = c.max_motor_velocity;
+  d.noise_level = c.noise_level; d.noise_gyro = c.noise_gyro; d.noise_accelerometer = c.noise_accelerometer; d.noise_gravity = c.noise_gravity;
+  d.noise_joint_vel = c.noise_joint_vel;
+  memcpy(d.qpos_noise_scale, c.qpos_noise_scale, sizeof(d.qpos_noise_scale)); memcpy(d.reward_scales, c.reward_scales, sizeof(d.reward_scales));
+  d.tracking_sigma = c.tracking_sigma; d.push_enable = c.push_enable;
+  memcpy(d.push_interval_range, c.push_interval_range, 8); memcpy(d.push_magnitude_range, c.push_magnitude_range, 8);
+  memcpy(d.cmd_range, c.cmd_range, sizeof(d.cmd_range));
+  d.use_imitation = c.use_imitation; d.use_motor_speed_limits = c.use_motor_speed_limits; d.autoreset = c.autoreset;
+  d.episode_length = c.episode_length; d.n_substeps = c.n_substeps;
+}
+
+extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, int nenv, int device, const float* prm_table, const double* dxs, int nx,
+                                const double* dys, int ny, const double* dths, int nth, const double* ranges6, int nsteps, odk_batch** out) {
+  if (!m || !cfg || !out || nenv <= 0 || !prm_table || nx > 16 || ny > 16 || nth > 16) return fail(ODK_ERR_INVALID, "odk_batch_create: bad arguments");
+  HIPCHK(hipSetDevice(device));
+  odk_batch* b = new odk_batch();
+  b->model = *m; b->nenv = nenv; b->device = device; b->cfg = *cfg;
+  b->G = cfg->lanes_per_env == 64 ? 64 : 32;
+  if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 32 && cfg->lanes_per_env != 64) { delete b; return fail(ODK_ERR_INVALID, "lanes_per_env must be 0, 32 or 64"); }
+  if (m->shape == 0) fill_sizes<ShapeA>(b); else fill_sizes<ShapeB>(b);
+  DevPRM hp;
+  memset(&hp, 0, sizeof(hp));
+  hp.nx = nx; hp.ny = ny; hp.nth = nth; hp.nsteps = nsteps;
+  for (int i = 0; i < nx; i++) hp.dxs[i] = (float)dxs[i];
+  for (int i = 0; i < ny; i++) hp.dys[i] = (float)dys[i];
+  for (int i = 0; i < nth; i++) hp.dths[i] = (float)dths[i];
+  for (int i = 0; i < 6; i++) hp.ranges[i] = (float)ranges6[i];
+  size_t tbytes = (size_t)nx * ny * nth * 640 * sizeof(float);
+  HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel))); HIPCHK(hipMemcpy(b->d_model, &m->h, sizeof(DevModel), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->d_prm, sizeof(DevPRM))); HIPCHK(hipMemcpy(b->d_prm, &hp, sizeof(DevPRM), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->d_table, tbytes)); HIPCHK(hipMemcpy(b->d_table, prm_table, tbytes, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->d_recs, (size_t)nenv * b->rec_size * sizeof(float))); HIPCHK(hipMemset(b->d_recs, 0, (size_t)nenv * b->rec_size * sizeof(float)));
+  HIPCHK(hipMalloc(&b->d_first, (size_t)nenv * b->frec_size * sizeof(float))); HIPCHK(hipMemset(b->d_first, 0, (size_t)nenv * b->frec_size * sizeof(float)));
+  HIPCHK(hipMalloc(&b->d_dbg, (size_t)nenv * b->lds_total * sizeof(float))); HIPCHK(hipMemset(b->d_dbg, 0, (size_t)nenv * b->lds_total * sizeof(float)));
+  *out = b;
+  return ODK_OK;
+}
+extern "C" void odk_batch_destroy(odk_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  for (void* p : {(void*)b->d_model, (void*)b->d_prm, (void*)b->d_table, (void*)b->d_recs, (void*)b->d_first, (void*)b->d_dr, (void*)b->d_dbg}) (void)hipFree(p);
+  for (auto& ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  delete b;
+}
+extern "C" int odk_batch_set_config(odk_batch* b, const odk_env_config* cfg) {
+  if (!b || !cfg) return fail(ODK_ERR_INVALID, "null");
+  int g = b->cfg.lanes_per_env;
+  b->cfg = *cfg;
+  b->cfg.lanes_per_env = g;
+  return ODK_OK;
+}
+
+extern "C" int odk_batch_set_param(odk_batch* b, int param, const float* v, int count) {
+  if (!b || !v) return fail(ODK_ERR_INVALID, "null");
+  const DevModel& m = b->model.h;
+  const int nb = m.nb, nu = m.nu;
+  const int MASS = 0, IPOS = nb, FRL = nb + 3, ARM = FRL + nu, Q0 = ARM + nu, KP = Q0 + nu, SIZE = KP + nu;
+  if (SIZE != b->dr_size) return fail(ODK_ERR_INVALID, "dr layout");
+  if (!b->dr_enabled) {  // start from the nominal model
+    b->h_dr.resize((size_t)b->nenv * SIZE);
+    for (int e = 0; e < b->nenv; e++) {
+      float* d = &b->h_dr[(size_t)e * SIZE];
+      for (int i = 0; i < nb; i++) d[MASS + i] = m.body_mass[i];
+      for (int k = 0; k < 3; k++) d[IPOS + k] = m.body_ipos[1][k];
+      for (int u = 0; u < nu; u++) { d[FRL + u] = m.dof_frictionloss[m.act_dofadr[u]]; d[ARM + u] = m.dof_armature[m.act_dofadr[u]]; d[Q0 + u] = m.qpos0[m.act_qposadr[u]]; d[KP + u] = m.act_kp[u]; }
+    }
+    b->dr_enabled = true;
+  }
+  int off, n;
+  switch (param) {
+    case ODK_PARAM_BODY_MASS: off = MASS; n = nb; break;
+    case ODK_PARAM_BODY_IPOS_TORSO: off = IPOS; n = 3; break;
+    case ODK_PARAM_DOF_FRICTIONLOSS: off = FRL; n = nu; break;
+    case ODK_PARAM_DOF_ARMATURE: off = ARM; n = nu; break;
+    case ODK_PARAM_QPOS0: off = Q0; n = nu; break;
+    case ODK_PARAM_KP: off = KP; n = nu; break;
+    default: return fail(ODK_ERR_INVALID, "unknown param %d", param);
+  }
+  if (count != n) return fail(ODK_ERR_INVALID, "param %d expects %d values per env, got %d", param, n, count);
+  for (int e = 0; e < b->nenv; e++) memcpy(&b->h_dr[(size_t)e * SIZE + off], v + (size_t)e * n, n * sizeof(float));
+  HIPCHK(hipSetDevice(b->device));
+  if (!b->d_dr) HIPCHK(hipMalloc(&b->d_dr, b->h_dr.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(b->d_dr, b->h_dr.data(), b->h_dr.size() * sizeof(float), hipMemcpyHostToDevice));
+  return ODK_OK;
+}
+
+enum { K_RESET = 0, K_STEP = 1, K_PHYS = 2 };
+
+template <class S, int G> static hipError_t launch_sg(int which, const KArgs& a, hipStream_t st) {
+  const int per_block = 64 / G;
+  const int grid = (a.nenv + per_block - 1) / per_block;
+  const size_t lds = (size_t)per_block * EnvL<S>::TOTAL * sizeof(float);
+  if (which == K_RESET) hipLaunchKernelGGL((reset_kernel<S, G>), dim3(grid), dim3(64), lds, st, a);
+  else if (which == K_STEP) hipLaunchKernelGGL((step_kernel<S, G>), dim3(grid), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL((physics_kernel<S, G>), dim3(grid), dim3(64), lds, st, a);
+  return hipGetLastError();
+}
+static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st) {
+  if (b->model.shape == 0) return b->G == 64 ? launch_sg<ShapeA, 64>(which, a, st) : launch_sg<ShapeA, 32>(which, a, st);
+  return b->G == 64 ? launch_sg<ShapeB, 64>(which, a, st) : launch_sg<ShapeB, 32>(which, a, st);
+}
+
+static void base_args(odk_batch* b, KArgs& a, const odk_outputs* o) {
+  memset(&a, 0, sizeof(a));
+  a.m = b->d_model; a.prm = b->d_prm; a.prm_table = b->d_table; a.recs = b->d_recs; a.first = b->d_first;
+  a.dr = b->dr_enabled ? b->d_dr : nullptr; a.nenv = b->nenv; a.n_substeps = b->cfg.n_substeps;
+  a.dbg_lds = nullptr;
+  if (o) { a.obs = o->obs_dev; a.priv = o->priv_dev; a.reward = o->reward_dev; a.done = o->done_dev; a.trunc = o->truncation_dev; a.metrics = o->metrics_dev; }
+  to_dev_cfg(b->cfg, a.cfg);
+}
+
+static int g_debug_dump = 0;
+extern "C" void odk_set_debug_dump(int on) { g_debug_dump = on; }
+
+extern "C" int odk_reset(odk_batch* b, uint32_t seed, uint32_t env_id_offset, const odk_outputs* outs, void* stream) {
+  if (!b) return fail(ODK_ERR_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  KArgs a;
+  base_args(b, a, outs);
+  a.seed = seed; a.env_offset = env_id_offset;
+  a.dbg_lds = b->d_dbg;
+  HIPCHK(launch(b, K_RESET, a, (hipStream_t)stream));
+  return ODK_OK;
+}
+
+extern "C" int odk_step(odk_batch* b, const float* action_dev, const odk_outputs* outs, void* stream) {
+  if (!b || !action_dev) return fail(ODK_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  KArgs a;
+  base_args(b, a, outs);
+  a.action = action_dev;
+  a.dbg_lds = g_debug_dump ? b->d_dbg : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (b->timing) {
+    if (b->ev_used == b->events.size()) {
+      hipEvent_t e0, e1;
+      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+      b->events.push_back({e0, e1});
+    }
+    HIPCHK(hipEventRecord(b->events[b->ev_used].first, st));
+    HIPCHK(launch(b, K_STEP, a, st));
+    HIPCHK(hipEventRecord(b->events[b->ev_used].second, st));
+    b->ev_used++;
+  } else {
+    HIPCHK(launch(b, K_STEP, a, st));
+  }
+  return ODK_OK;
+}
+
+extern "C" int odk_physics_step(odk_batch* b, const float* ctrl_dev, int n_substeps, void* stream) {
+  if (!b || !ctrl_dev) return fail(ODK_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  KArgs a;
+  base_args(b, a, nullptr);
+  a.action = ctrl_dev; a.n_substeps = n_substeps;
+  a.dbg_lds = b->d_dbg;
+  HIPCHK(launch(b, K_PHYS, a, (hipStream_t)stream));
+  return ODK_OK;
+}
+
+extern "C" int odk_batch_timing(odk_batch* b, int enable, float* avg_ms, int* launches) {
+  if (!b) return fail(ODK_ERR_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
+  double tot = 0;
+  for (size_t i = 0; i < b->ev_used; i++) {
+    float ms = 0;
+    HIPCHK(hipEventSynchronize(b->events[i].second));
+    HIPCHK(hipEventElapsedTime(&ms, b->events[i].first, b->events[i].second));
+    tot += ms;
+  }
+  if (avg_ms) *avg_ms = b->ev_used ? (float)(tot / b->ev_used) : 0.0f;
+  if (launches) *launches = (int)b->ev_used;
+  b->ev_used = 0;
+  b->timing = enable != 0;
+  return ODK_OK;
+}
+
+extern "C" int odk_batch_record_size(const odk_batch* b) { return b ? b->rec_size : -1; }
+extern "C" int odk_batch_lds_size(const odk_batch* b) { return b ? b->lds_total : -1; }
+extern "C" int odk_batch_get_records(odk_batch* b, float* host) {
+  if (!b || !host) return fail(ODK_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host, b->d_recs, (size_t)b->nenv * b->rec_size * sizeof(float), hipMemcpyDeviceToHost));
+  return ODK_OK;
+}
+extern "C" int odk_batch_get_lds(odk_batch* b, float* host) {  // debug image of the last forward pass (reset / physics_step / step with dump on)
+  if (!b || !host) return fail(ODK_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host, b->d_dbg, (size_t)b->nenv * b->lds_total * sizeof(float), hipMemcpyDeviceToHost));
+  return ODK_OK;
+}
+// named offsets into the LDS image for tests
+extern "C" int odk_lds_offset(const odk_batch* b, const char* name) {
+  if (!b || !name) return -1;
+#define OFF(nm, field) if (!strcmp(name, nm)) return b->model.shape == 0 ? ShapeA::field : ShapeB::field;
+  OFF("qpos", O_QPOS) OFF("qvel", O_QVEL) OFF("warm", O_WARM) OFF("ctrl", O_CTRL) OFF("xpos", O_XPOS) OFF("xmat", O_XMAT) OFF("cinert", O_CINERT)
+  OFF("cdof", O_CDOF) OFF("M", O_M) OFF("HL", O_HL) OFF("qfrc_smooth", O_QFS) OFF("qacc_smooth", O_QAS) OFF("x", O_X) OFF("Ma", O_MA)
+  OFF("search", O_GRAD) OFF("mv", O_MV) OFF("efc_D", O_D) OFF("efc_aref", O_AREF) OFF("jar", O_JAR) OFF("jv", O_JV) OFF("W", O_W)
+  OFF("contact_dist", O_CDIST) OFF("contact_r", O_CR) OFF("scr", O_SCR) OFF("sensordata", O_SENS) OFF("actuator_force", O_ACTF) OFF("qacc", O_QACC)
+#undef OFF
+  return -1;
+}
+
+extern "C" int odk_batch_get_state(odk_batch* b, float* qpos, float* qvel, float* warm) {
+  if (!b) return fail(ODK_ERR_INVALID, "null");
+  std::vector<float> h((size_t)b->nenv * b->rec_size);
+  int rc = odk_batch_get_records(b, h.data());
+  if (rc) return rc;
+  const int nq = b->model.h.nq, nv = b->model.h.nv;
+  for (int e = 0; e < b->nenv; e++) {
+    const float* r = &h[(size_t)e * b->rec_size];
+    if (qpos) memcpy(qpos + (size_t)e * nq, r, nq * sizeof(float));
+    if (qvel) memcpy(qvel + (size_t)e * nv, r + nq, nv * sizeof(float));
+    if (warm) memcpy(warm + (size_t)e * nv, r + nq + nv, nv * sizeof(float));
+  }
+  return ODK_OK;
+}
+extern "C" int odk_batch_set_state(odk_batch* b, const float* qpos, const float* qvel, const float* warm) {
+  if (!b) return fail(ODK_ERR_INVALID, "null");
+  std::vector<float> h((size_t)b->nenv * b->rec_size);
+  int rc = odk_batch_get_records(b, h.data());
+  if (rc) return rc;
+  const int nq = b->model.h.nq, nv = b->model.h.nv;
+  for (int e = 0; e < b->nenv; e++) {
+    float* r = &h[(size_t)e * b->rec_size];
+    if (qpos) memcpy(r, qpos + (size_t)e * nq, nq * sizeof(float));
+    if (qvel) memcpy(r + nq, qvel + (size_t)e * nv, nv * sizeof(float));
+    if (warm) memcpy(r + nq + nv, warm + (size_t)e * nv, nv * sizeof(float));
+  }
+  HIPCHK(hipMemcpy(b->d_recs, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return ODK_OK;
+}
+extern "C" int odk_batch_get_debug(odk_batch* b, float* sensordata, float* actuator_force, float* contact_dist, float* qacc) {
+  if (!b) return fail(ODK_ERR_INVALID, "null");
+  std::vector<float> h((size_t)b->nenv * b->lds_total);
+  int rc = odk_batch_get_lds(b, h.data());
+  if (rc) return rc;
+  const int nv = b->model.h.nv, nu = b->model.h.nu;
+  const int o_s = odk_lds_offset(b, "sensordata"), o_a = odk_lds_offset(b, "actuator_force"), o_c = odk_lds_offset(b, "contact_dist"), o_q = odk_lds_offset(b, "qacc");
+  for (int e = 0; e < b->nenv; e++) {
+    const float* r = &h[(size_t)e * b->lds_total];
+    if (sensordata) memcpy(sensordata + (size_t)e * NSENSD, r + o_s, NSENSD * sizeof(float));
+    if (actuator_force) memcpy(actuator_force + (size_t)e * nu, r + o_a, nu * sizeof(float));
+    if (contact_dist) memcpy(contact_dist + (size_t)e * NCON, r + o_c, NCON * sizeof(float));
+    if (qacc) memcpy(qacc + (size_t)e * nv, r + o_q, nv * sizeof(float));
+  }
+  return ODK_OK;
+}

@@ -1,0 +1,78 @@
+// odk_model.h -- device-resident model: constants + static topology tables (tables.py).
+// Replaces mjx.Model (reference base.py:61) for the kernels in odk_engine.hip.
+#pragma once
+#include <stdint.h>
+
+namespace odk {
+
+constexpr int MAXV = 32;     // dofs
+constexpr int MAXQ = 32;     // qpos
+constexpr int MAXB = 20;     // bodies
+constexpr int MAXJ = 26;     // joints
+constexpr int MAXU = 16;     // actuators
+constexpr int MAXNZ = 512;   // sparse matrix entries
+constexpr int MAXHV = 20;    // hull vertices per foot
+constexpr int MAXHF = 40;    // hull faces per foot
+constexpr int MAXCHAIN = 8;
+constexpr int MAXSITE = 8;
+constexpr int MAXSENS = 16;
+constexpr int NCON = 12;     // 3 geom pairs x 4 contacts
+constexpr int NSENSD = 46;
+
+struct DevModel {
+  int nq, nv, nu, nb, nj, nM, nH, nfl, nlim, nrow, nsite, nsensor;
+  float dt, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
+  int ls_iterations, iterations;
+  // bodies
+  int base_body, body_in_tree[MAXB], body_parent[MAXB], body_jntadr[MAXB], body_jntnum[MAXB];
+  int body_chain[MAXB][MAXCHAIN], body_chain_len[MAXB];
+  int body_ancdof[MAXB][MAXV], body_nancdof[MAXB];
+  int body_sub[MAXB][MAXB], body_nsub[MAXB];
+  float body_pos[MAXB][3], body_quat[MAXB][4], body_ipos[MAXB][3], body_mass[MAXB], body_inertia[MAXB][6];
+  // joints
+  int jnt_qposadr[MAXJ], jnt_dofadr[MAXJ], jnt_bodyid[MAXJ];
+  float jnt_axis[MAXJ][3], jnt_pos[MAXJ][3], jnt_range[MAXJ][2], qpos0[MAXQ];
+  // dofs
+  int dof_body[MAXV], dof_depth[MAXV], dof_anc[MAXV][MAXV], dof_Madr[MAXV], dof_anc_adr[MAXV][MAXV];
+  int dof_ndesc[MAXV], dof_desc[MAXV][MAXV], dof_desc_adr[MAXV][MAXV];
+  int dof_nprefix[MAXV], dof_prefix[MAXV][MAXV];
+  int dof_nsym[MAXV], dof_sym_dof[MAXV][MAXV], dof_sym_adr[MAXV][MAXV];
+  int dof_act[MAXV], dof_flrow[MAXV], dof_limrow[MAXV];
+  float dof_armature[MAXV], dof_damping[MAXV], dof_frictionloss[MAXV], dof_invweight0[MAXV];
+  int M_i[MAXNZ], M_j[MAXNZ];
+  // virtual tree (Hessian)
+  int vdof_depth[MAXV], vdof_anc[MAXV][MAXV], vdof_Madr[MAXV], vdof_anc_adr[MAXV][MAXV];
+  int vdof_ndesc[MAXV], vdof_desc[MAXV][MAXV], vdof_desc_adr[MAXV][MAXV];
+  int H_i[MAXNZ], H_j[MAXNZ], H_src[MAXNZ];
+  int tri_m[MAXNZ], tri_q[MAXNZ];
+  // actuators
+  int act_qposadr[MAXU], act_dofadr[MAXU], act_backlash_qposadr[MAXU];
+  float act_kp[MAXU], act_bias1[MAXU], act_bias2[MAXU], act_ctrlrange[MAXU][2], act_forcerange[MAXU][2];
+  int act_ctrllimited[MAXU], act_forcelimited[MAXU];
+  float key_qpos[MAXQ], key_ctrl[MAXU];
+  // constraint rows
+  int fl_dof[MAXV], lim_jnt[MAXJ];
+  float fl_D[MAXV], fl_R[MAXV], fl_b[MAXV];             // friction-loss rows: pos = 0 -> constant impedance
+  float lim_solref[MAXJ][2], lim_solimp[MAXJ][5], lim_invweight[MAXJ];
+  float pair_solref[3][2], pair_solimp[3][5], pair_mu[3], pair_invweight[3];  // pairs: Lfoot-floor, Rfoot-floor, Lfoot-Rfoot
+  // feet / floor
+  int foot_body[2], foot_nvert[2], foot_nface[2], foot_dofmask[2][MAXV];
+  float foot_vert[2][MAXHV][3];  // hull vertices in the BODY frame (geom pos/quat folded in)
+  int foot_face[2][MAXHF][3];
+  float foot_obb_center[2][3], foot_obb_half[2][3], foot_obb_axes[2][9];  // body-frame OBB (columns = axes)
+  float plane_pos[3], plane_n[3], plane_frame[9];
+  int floor_is_plane;
+  // sites / sensors
+  int site_body[MAXSITE], site_imu, site_feet[2];
+  float site_pos[MAXSITE][3], site_mat[MAXSITE][9], site_quat[MAXSITE][4];
+  int sensor_type[MAXSENS], sensor_site[MAXSENS], sensor_adr[MAXSENS];
+  int adr_gyro, adr_local_linvel, adr_accelerometer, adr_upvector, adr_global_angvel, adr_foot_linvel[2];
+};
+
+// reference-motion table header (poly_reference_motion.py)
+struct DevPRM {
+  int nx, ny, nth, nsteps;
+  float dxs[16], dys[16], dths[16], ranges[6];
+};
+
+}  // namespace odk

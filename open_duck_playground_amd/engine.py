@@ -1,0 +1,238 @@
+"""ctypes binding of libodk.so (include/odk.h): the MI355X-native batched env engine.
+
+This is the host side of the drop-in boundary: it owns no arithmetic.  PyTorch-ROCm is
+used for device memory and streams only; every number comes out of the HIP kernels in csrc/.
+There is no CPU fallback: importing works without the library, but constructing a `Batch` raises
+if `csrc/libodk.so` is missing or no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+from .model import Model, asset_path
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libodk.so")
+
+NOBS, NPRIV, NMETRIC, NU = 101, 212, 8, 14
+METRIC_NAMES = ("reward/tracking_lin_vel", "reward/tracking_ang_vel", "cost/torques", "cost/action_rate", "cost/stand_still",
+                "reward/alive", "reward/imitation", "swing_peak")
+
+PARAM_BODY_MASS, PARAM_BODY_IPOS_TORSO, PARAM_DOF_FRICTIONLOSS, PARAM_DOF_ARMATURE, PARAM_QPOS0, PARAM_KP = range(6)
+
+
+class EnvConfig(C.Structure):
+    """odk_env_config (include/odk.h) == default_config() of reference joystick.py:49-102."""
+    _fields_ = [
+        ("ctrl_dt", C.c_float), ("action_scale", C.c_float), ("dof_vel_scale", C.c_float), ("max_motor_velocity", C.c_float),
+        ("noise_level", C.c_float), ("noise_gyro", C.c_float), ("noise_accelerometer", C.c_float), ("noise_gravity", C.c_float),
+        ("noise_joint_vel", C.c_float),
+        ("qpos_noise_scale", C.c_float * 16), ("reward_scales", C.c_float * 7), ("tracking_sigma", C.c_float),
+        ("push_enable", C.c_float), ("push_interval_range", C.c_float * 2), ("push_magnitude_range", C.c_float * 2),
+        ("cmd_range", (C.c_float * 2) * 7),
+        ("use_imitation", C.c_int32), ("use_motor_speed_limits", C.c_int32), ("autoreset", C.c_int32), ("episode_length", C.c_int32),
+        ("n_substeps", C.c_int32), ("lanes_per_env", C.c_int32),
+    ]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("obs_dev", C.c_void_p), ("priv_dev", C.c_void_p), ("reward_dev", C.c_void_p), ("done_dev", C.c_void_p),
+                ("truncation_dev", C.c_void_p), ("metrics_dev", C.c_void_p)]
+
+
+class OdkError(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False) -> str:
+    """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("odk_engine.hip", "odk_kernels.h", "odk_model.h", "Makefile")]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "odk.h"))
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", _CSRC, "-B", "-s", "libodk.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OdkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback for the env engine)")
+    L = C.CDLL(LIB_PATH)
+    P, PP = C.c_void_p, C.POINTER(C.c_void_p)
+    FP, DP = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    L.odk_last_error.restype = C.c_char_p
+    L.odk_default_config.argtypes = [C.POINTER(EnvConfig)]
+    L.odk_model_load.argtypes = [C.c_char_p, C.c_uint64, PP]
+    L.odk_model_free.argtypes = [P]
+    L.odk_model_dims.argtypes = [P] + [C.POINTER(C.c_int)] * 4
+    L.odk_batch_create.argtypes = [P, C.POINTER(EnvConfig), C.c_int, C.c_int, FP, DP, C.c_int, DP, C.c_int, DP, C.c_int, DP, C.c_int, PP]
+    L.odk_batch_destroy.argtypes = [P]
+    L.odk_batch_set_config.argtypes = [P, C.POINTER(EnvConfig)]
+    L.odk_batch_set_param.argtypes = [P, C.c_int, FP, C.c_int]
+    L.odk_reset.argtypes = [P, C.c_uint32, C.c_uint32, C.POINTER(Outputs), P]
+    L.odk_step.argtypes = [P, P, C.POINTER(Outputs), P]
+    L.odk_physics_step.argtypes = [P, P, C.c_int, P]
+    L.odk_batch_get_state.argtypes = [P, FP, FP, FP]
+    L.odk_batch_set_state.argtypes = [P, FP, FP, FP]
+    L.odk_batch_get_debug.argtypes = [P, FP, FP, FP, FP]
+    L.odk_set_debug_dump.argtypes = [C.c_int]
+    L.odk_batch_lds_size.argtypes = [P]
+    L.odk_batch_get_lds.argtypes = [P, FP]
+    L.odk_lds_offset.argtypes = [P, C.c_char_p]
+    L.odk_batch_record_size.argtypes = [P]
+    L.odk_batch_get_records.argtypes = [P, FP]
+    L.odk_batch_timing.argtypes = [P, C.c_int, FP, C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "odk_last_error", "odk_default_config", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_batch_create",
+    "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
+    "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
+    "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing")
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise OdkError(f"odk error {rc}: {load_library().odk_last_error().decode()}")
+
+
+def default_config() -> EnvConfig:
+    cfg = EnvConfig()
+    load_library().odk_default_config(C.byref(cfg))
+    return cfg
+
+
+def load_prm() -> Dict[str, np.ndarray]:
+    z = np.load(asset_path("prm_table.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Batch:
+    """`nenv` environments resident on one GPU.  Thin: every method is one C-ABI call."""
+
+    def __init__(self, model: Model, nenv: int, cfg: Optional[EnvConfig] = None, device: int = 0, prm: Optional[dict] = None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise OdkError("no HIP device visible: the env engine has no CPU path")
+        self.L = load_library()
+        self.torch = torch
+        self.model, self.nenv, self.device = model, int(nenv), int(device)
+        self.cfg = cfg if cfg is not None else default_config()
+        blob = model.blob()
+        self._m = C.c_void_p()
+        _chk(self.L.odk_model_load(blob, len(blob), C.byref(self._m)))
+        prm = prm if prm is not None else load_prm()
+        self._table = np.ascontiguousarray(prm["table"], np.float32)
+        dxs, dys, dths = (np.ascontiguousarray(prm[k], np.float64) for k in ("dxs", "dys", "dthetas"))
+        ranges = np.ascontiguousarray(np.concatenate([prm["dx_range"], prm["dy_range"], prm["dtheta_range"]]), np.float64)
+        self._b = C.c_void_p()
+        _chk(self.L.odk_batch_create(self._m, C.byref(self.cfg), self.nenv, self.device, _fp(self._table), _dp(dxs), len(dxs), _dp(dys),
+                                     len(dys), _dp(dths), len(dths), _dp(ranges), int(prm["nb_steps_in_period"][0]), C.byref(self._b)))
+        dev = torch.device("cuda", self.device)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.obs = torch.zeros(self.nenv, NOBS, **f32)
+        self.priv = torch.zeros(self.nenv, NPRIV, **f32)
+        self.reward = torch.zeros(self.nenv, **f32)
+        self.done = torch.zeros(self.nenv, **f32)
+        self.truncation = torch.zeros(self.nenv, **f32)
+        self.metrics = torch.zeros(self.nenv, NMETRIC, **f32)
+        self._outs = Outputs(self.obs.data_ptr(), self.priv.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                             self.truncation.data_ptr(), self.metrics.data_ptr())
+
+    # -- streams: calls are ordered on torch's current stream
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_config(self, cfg: EnvConfig):
+        self.cfg = cfg
+        _chk(self.L.odk_batch_set_config(self._b, C.byref(cfg)))
+
+    def set_param(self, param: int, values: np.ndarray):
+        v = np.ascontiguousarray(values, np.float32).reshape(self.nenv, -1)
+        _chk(self.L.odk_batch_set_param(self._b, param, _fp(v), v.shape[1]))
+
+    def reset(self, seed: int, env_id_offset: int = 0):
+        _chk(self.L.odk_reset(self._b, seed & 0xFFFFFFFF, env_id_offset, C.byref(self._outs), self._stream()))
+
+    def step(self, action):
+        assert action.is_cuda and action.dtype == self.torch.float32 and action.is_contiguous() and tuple(action.shape) == (self.nenv, NU)
+        _chk(self.L.odk_step(self._b, C.c_void_p(action.data_ptr()), C.byref(self._outs), self._stream()))
+
+    def physics_step(self, ctrl, n_substeps: int = 10):
+        assert ctrl.is_cuda and ctrl.dtype == self.torch.float32 and ctrl.is_contiguous() and tuple(ctrl.shape) == (self.nenv, NU)
+        _chk(self.L.odk_physics_step(self._b, C.c_void_p(ctrl.data_ptr()), n_substeps, self._stream()))
+
+    # -- synchronous host access (tests, checkpoints)
+    def get_state(self):
+        qpos = np.zeros((self.nenv, self.model.nq), np.float32); qvel = np.zeros((self.nenv, self.model.nv), np.float32)
+        warm = np.zeros((self.nenv, self.model.nv), np.float32)
+        _chk(self.L.odk_batch_get_state(self._b, _fp(qpos), _fp(qvel), _fp(warm)))
+        return qpos, qvel, warm
+
+    def set_state(self, qpos=None, qvel=None, warm=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float32) for a in (qpos, qvel, warm)]
+        _chk(self.L.odk_batch_set_state(self._b, *[None if a is None else _fp(a) for a in arrs]))
+
+    def get_debug(self):
+        s = np.zeros((self.nenv, 46), np.float32); a = np.zeros((self.nenv, NU), np.float32)
+        c = np.zeros((self.nenv, 12), np.float32); q = np.zeros((self.nenv, self.model.nv), np.float32)
+        _chk(self.L.odk_batch_get_debug(self._b, _fp(s), _fp(a), _fp(c), _fp(q)))
+        return dict(sensordata=s, actuator_force=a, contact_dist=c, qacc=q)
+
+    def lds_image(self) -> np.ndarray:
+        n = self.L.odk_batch_lds_size(self._b)
+        img = np.zeros((self.nenv, n), np.float32)
+        _chk(self.L.odk_batch_get_lds(self._b, _fp(img)))
+        return img
+
+    def lds_offset(self, name: str) -> int:
+        off = self.L.odk_lds_offset(self._b, name.encode())
+        if off < 0:
+            raise KeyError(name)
+        return off
+
+    def records(self) -> np.ndarray:
+        n = self.L.odk_batch_record_size(self._b)
+        r = np.zeros((self.nenv, n), np.float32)
+        _chk(self.L.odk_batch_get_records(self._b, _fp(r)))
+        return r
+
+    def timing(self, enable: bool):
+        ms, n = C.c_float(0), C.c_int(0)
+        _chk(self.L.odk_batch_timing(self._b, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_b", None):
+            self.L.odk_batch_destroy(self._b); self._b = None
+        if getattr(self, "_m", None):
+            self.L.odk_model_free(self._m); self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -75,7 +75,9 @@ class Model:
         self.nsensordata = int(arrays["nsensordata"][0])
 
     def blob(self) -> bytes:
-        return pack_blob(self.a)
+        """Wire format: compiled arrays + the kernels' static topology tables (tables.py)."""
+        from .tables import build_kernel_tables
+        return pack_blob({**self.a, **build_kernel_tables(self.a)})
 
     # name lookups (mj_name2id equivalents, base.py:136-152)
     def _id(self, table: str, name: str) -> int:

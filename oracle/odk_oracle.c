@@ -565,13 +565,55 @@ static real hull_separation(const odko_model* m, const odko_data* d, int g1, int
   return best;
 }
 
+/* Oriented-bounding-box cull (15-axis SAT on the hull AABBs expressed in each geom frame).  A positive
+ * return value is a lower bound on the true separation of the two hulls: the pair is then inactive
+ * in MJX as well (all dist > 0), so culling is parity-safe. */
+static void hull_aabb(const odko_model* m, int g, real* c, real* h) {
+  real lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
+  for (int i = 0; i < m->cgeom_vertnum[g]; i++)
+    for (int k = 0; k < 3; k++) {
+      real v = m->hull_vert[m->cgeom_vertadr[g] + i][k];
+      if (v < lo[k]) lo[k] = v;
+      if (v > hi[k]) hi[k] = v;
+    }
+  for (int k = 0; k < 3; k++) { c[k] = 0.5 * (lo[k] + hi[k]); h[k] = 0.5 * (hi[k] - lo[k]); }
+}
+static real obb_separation(const odko_model* m, const odko_data* d, int g1, int g2) {
+  real c1[3], h1[3], c2[3], h2[3], w1[3], w2[3], t[3], best = -1e30;
+  hull_aabb(m, g1, c1, h1); hull_aabb(m, g2, c2, h2);
+  const real *R1 = d->geom_xmat[g1], *R2 = d->geom_xmat[g2];
+  mat_mulvec(w1, R1, c1); v3_addscl(w1, w1, d->geom_xpos[g1], 1);
+  mat_mulvec(w2, R2, c2); v3_addscl(w2, w2, d->geom_xpos[g2], 1);
+  v3_sub(t, w2, w1);
+  real ax[15][3];
+  int na = 0;
+  for (int k = 0; k < 3; k++) { ax[na][0] = R1[k]; ax[na][1] = R1[3 + k]; ax[na][2] = R1[6 + k]; na++; }
+  for (int k = 0; k < 3; k++) { ax[na][0] = R2[k]; ax[na][1] = R2[3 + k]; ax[na][2] = R2[6 + k]; na++; }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      v3_cross(ax[na], ax[i], ax[3 + j]);
+      real n = sqrt(v3_dot(ax[na], ax[na]));
+      if (n < 1e-6) continue; /* parallel edges: covered by the face axes */
+      ax[na][0] /= n; ax[na][1] /= n; ax[na][2] /= n;
+      na++;
+    }
+  for (int a = 0; a < na; a++) {
+    real r1 = 0, r2 = 0;
+    for (int k = 0; k < 3; k++) { r1 += h1[k] * fabs(v3_dot(ax[a], ax[k])); r2 += h2[k] * fabs(v3_dot(ax[a], ax[3 + k])); }
+    real sep = fabs(v3_dot(t, ax[a])) - r1 - r2;
+    if (sep > best) best = sep;
+  }
+  return best;
+}
+
 /* convex-convex (foot vs foot).  When a face-normal axis separates the hulls the pair is culled
  * (dist = separation > 0 on all four slots: inactive).  Penetrating configurations use the
  * minimum-penetration face axis and a 4-point manifold from the deepest vertices of hull 2 --
  * an approximation of MJX's SAT + polygon clipping (edge-edge axes omitted).  PARITY UNPINNED. */
 static void convex_convex(const odko_model* m, odko_data* d, int g1, int g2, int c0) {
   real axis[3] = {0, 0, 1};
-  real sep = hull_separation(m, d, g1, g2, axis);
+  real sep = obb_separation(m, d, g1, g2);
+  if (sep <= 0) sep = hull_separation(m, d, g1, g2, axis);
   real frame[9];
   make_frame(frame, axis);
   if (sep > 0) {

