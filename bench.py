@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the fused MI355X env step (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task T] [--lanes G] [--no-cpu-baseline]
+
+One "step" = one env step of every resident env: AutoReset/Episode wrappers + Joystick.step +
+10 x mjx.step + obs/reward, all inside one HIP kernel launch (reference joystick.py:323-481).
+Workload = BASELINE.json configs[1]: open_duck_mini_v2 flat_terrain, 8192 envs per GPU, random
+actions a ~ U(-1,1)^14 fresh every step, observation noise off, pushes off, imitation reward on,
+auto-reset on.  Inputs (state, actions) are resident in HBM before the
+timed region.  Multi-GPU: one process per GPU (torchrun), envs sharded, no data-path collective
+ -> weak scaling; timing = max over ranks between barriers.
+
+Prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "env-steps/sec open_duck_mini_v2 flat_terrain @8192 envs; 1/2/4/8-GPU scaling"
+BYTES_PER_ENV_STEP = {"flat_terrain": 2844, "flat_terrain_backlash": 3564}  # SURVEY.md 8(d), algorithmic HBM bytes
+FLOP_PER_ENV_STEP = 1.2e6                                                   # SURVEY.md 8(d), VALU work estimate
+HBM_PEAK_GBS = 8000.0                                                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(task: str, target_seconds: float = 12.0):
+    """Times the oracle's env step (the CPU restatement, kind='port') on all host cores of this box,
+    on a bounded sample of the same workload: same model, same protocol, fewer envs and steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    from open_duck_playground_amd.model import load_task_model, asset_path
+    model = load_task_model(task)
+    z = np.load(asset_path("prm_table.npz"))
+    prm_arrays = {k: z[k] for k in z.files}
+    om = O.OracleModel(model.blob())
+    prm = O.OraclePRM(prm_arrays)
+    L = O.lib()
+    cores = os.cpu_count() or 1
+    nenv = 16 * cores
+    rate = L.lib.odko_rollout_mt(om.h, prm.h, nenv, 20, 5, cores, 0)          # calibration (~1 s)
+    nsteps = max(20, int(rate * target_seconds / nenv))
+    rate = L.lib.odko_rollout_mt(om.h, prm.h, nenv, nsteps, 10, cores, 0)
+    return {"value": round(rate, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/odk_oracle*.c (float64 C restatement of the same env step), {nenv} envs x {nsteps} steps, "
+                      f"{cores} pthreads, same random-action protocol"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=8192, help="envs per GPU")
+    ap.add_argument("--task", default="flat_terrain")
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path exists for the env engine)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    model = load_task_model(args.task)
+    cfg = engine.default_config()
+    cfg.noise_level = 0.0
+    cfg.push_enable = 0.0
+    cfg.lanes_per_env = args.lanes
+    batch = engine.Batch(model, args.envs, cfg, device=local_rank)
+    batch.reset(seed=0, env_id_offset=rank * args.envs)
+    total = args.steps + args.warmup
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    # fresh action per step, generated before the timed region (HBM-resident inputs)
+    chunk = min(total, 256)
+    actions = torch.empty(chunk, args.envs, 14, device=dev, dtype=torch.float32).uniform_(-1.0, 1.0, generator=gen)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        batch.step(actions[i % chunk])
+    barrier()
+    batch.timing(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        batch.step(actions[(args.warmup + i) % chunk])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = batch.timing(False)
+    done_frac = float(batch.done.mean().item())
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * args.envs * args.steps / elapsed
+
+    if rank == 0:
+        bytes_per_launch = BYTES_PER_ENV_STEP.get(args.task, 2844) * args.envs
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        valu = args.envs * FLOP_PER_ENV_STEP / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": METRIC, "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"open_duck_mini_v2 {args.task}, {args.envs} envs/GPU, random-action rollout "
+                                   "(wrappers + Joystick.step + 10 x mjx.step + obs/reward fused in one launch), "
+                                   "noise off, pushes off, imitation on, auto-reset on",
+                       "envs_per_gpu": args.envs, "global_envs": args.envs * world, "n_substeps": 10,
+                       "lanes_per_env": batch.cfg.lanes_per_env or 32, "parallelism": f"env-sharded x{world}, no collective",
+                       "done_fraction_last_step": round(done_frac, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "kernel": "step_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "fused env step is not HBM-bound (SURVEY.md 0.4); secondary roof = FP32 VALU",
+                         "valu_achieved_tflops": round(valu, 3), "valu_peak_tflops": VALU_PEAK_TFLOPS,
+                         "valu_frac": round(valu / VALU_PEAK_TFLOPS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.task)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
