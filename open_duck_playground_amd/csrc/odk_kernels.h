@@ -19,7 +19,19 @@
 
 namespace odk {
 
-#define ODK_SYNC() __syncthreads()
+// One workgroup == one wavefront: DS (LDS) instructions of a wave are issued and serviced in order, so
+// cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt -- only a compiler barrier that keeps
+// the LDS accesses in program order (and stops values being cached in registers across the hand-off).
+#define ODK_SYNC() asm volatile("" ::: "memory")
+// Phase timing (build with -DODK_PROFILE): lane 0 accumulates shader-clock deltas per phase into the
+// scratch area, which the debug LDS image carries out.  Zero cost when the macro is off.
+#ifdef ODK_PROFILE
+#define ODK_PROF(i) do { if (lane == 0) { long long _t = clock64(); SCR[S::S_PROF + (i)] += (float)(_t - _tprev); _tprev = _t; } } while (0)
+#define ODK_PROF_BEGIN() long long _tprev = clock64()
+#else
+#define ODK_PROF(i) do { } while (0)
+#define ODK_PROF_BEGIN() do { } while (0)
+#endif
 
 constexpr float MINVAL_F = 1e-15f;
 constexpr float PI_F = 3.14159265358979323846f;
@@ -77,20 +89,20 @@ struct Shape {
   static constexpr int O_W = O_JV + NROW;            // [NCROW][6] contact row wrenches [r x dir; dir]
   static constexpr int O_CDIST = O_W + 6 * NCROW;    // [12]
   static constexpr int O_CR = O_CDIST + NCON;        // [12][3] contact position relative to the base origin
-  static constexpr int O_FRAME = O_CR + 3 * NCON;    // [3][9] contact frames per geom pair
-  static constexpr int O_SCR = O_FRAME + 27;         // scratch: foot twists, wrenches, 6x6 blocks, sensor inputs
+  static constexpr int O_SCR = O_CR + 3 * NCON;      // scratch: foot twists, wrenches, 6x6 blocks, sensor inputs
   static constexpr int N_SCR = 192;
   static constexpr int O_SENS = O_SCR + N_SCR;       // sensordata[46]
   static constexpr int O_ACTF = O_SENS + NSENSD;     // actuator_force
-  static constexpr int O_QACC = O_ACTF + NU;         // qacc of the last forward (debug / accelerometer)
-  static constexpr int TOTAL = ((O_QACC + NV + 3) / 4) * 4;
+  static constexpr int O_QACC = O_X;                 // qacc of the last forward == final iterate
+  static constexpr int TOTAL = ((O_ACTF + NU + 3) / 4) * 4;
   // scratch sub-offsets
   static constexpr int S_VF = 0;      // [2][6] foot twist of the current vector
   static constexpr int S_FF = 12;     // [2][6] foot wrench sums
   static constexpr int S_K = 24;      // [3][36] K_L, K_R, K_X
   static constexpr int S_SV = 132;    // [3][6] cvel of base, left foot, right foot (sensors)
   static constexpr int S_CA = 150;    // [6] velocity part of cacc[base]
-  static constexpr int S_MISC = 156;  // misc scalars
+  static constexpr int S_MISC = 156;  // misc scalars (16)
+  static constexpr int S_PROF = 172;  // [20] per-phase cycle counters (ODK_PROFILE builds)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -260,11 +272,12 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
   float* BUF6 = L + S::O_BUF6; float* BODY = L + S::O_BODY; float* M = L + S::O_M; float* HL = L + S::O_HL;
   float* QFS = L + S::O_QFS; float* QAS = L + S::O_QAS; float* X = L + S::O_X; float* MA = L + S::O_MA; float* GRAD = L + S::O_GRAD;
   float* MV = L + S::O_MV; float* ED = L + S::O_D; float* AREF = L + S::O_AREF; float* JAR = L + S::O_JAR; float* JV = L + S::O_JV;
-  float* W = L + S::O_W; float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* FRAME = L + S::O_FRAME; float* SCR = L + S::O_SCR;
+  float* W = L + S::O_W; float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR;
   float* SENS = L + S::O_SENS; float* ACTF = L + S::O_ACTF;
   const int nfl = m->nfl, nlim = m->nlim, r0c = nfl + nlim;
   const float dt = m->dt;
 
+  ODK_PROF_BEGIN();
   // ---------------- P1: kinematics + cinert + cdof (lane = body); spatial reference = base origin
   if (lane < NB) {
     const int b = lane;
@@ -348,6 +361,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
   }
   ODK_SYNC();
 
+  ODK_PROF(0);
   // ---------------- P2: composite inertia times cdof (lane = dof), velocity prefix / cdof_dot
   float dotv[6] = {0, 0, 0, 0, 0, 0};
   if (lane < NV) {
@@ -385,6 +399,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     }
   }
   ODK_SYNC();
+  ODK_PROF(1);
   // ---------------- P3: sparse inertia entries (lane = entry)
   for (int p = lane; p < NM; p += G) {
     const int i = m->M_i[p], j = m->M_j[p];
@@ -400,6 +415,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     for (int k = 0; k < 6; k++) BUF6[k * NV + lane] = dotv[k];
   }
   ODK_SYNC();
+  ODK_PROF(2);
   // ---------------- P4: body velocity, bias acceleration, local force (lane = body)
   if (lane < NB) {
     const int b = lane;
@@ -438,6 +454,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     }
   }
   ODK_SYNC();
+  ODK_PROF(3);
   // ---------------- P5: bias force, passive, actuation -> qfrc_smooth (lane = dof)
   if (lane < NV) {
     const int i = lane, b = m->dof_body[i];
@@ -468,10 +485,13 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
   }
   for (int p = lane; p < NM; p += G) HL[p] = M[p];
   ODK_SYNC();
+  ODK_PROF(4);
   // ---------------- P6: qacc_smooth = M^-1 qfrc_smooth
   factor_ld<G>(HL, NV, m->dof_depth, m->dof_Madr, m->dof_anc_adr, m->tri_m, m->tri_q, lane);
+  ODK_PROF(15);
   solve_ld<G>(HL, QAS, NV, m->dof_depth, m->dof_Madr, m->dof_anc, m->dof_ndesc, m->dof_desc, m->dof_desc_adr, lane);
 
+  ODK_PROF(5);
   // ---------------- P7: collision.  Foot (convex mesh) vs plane: mjx collision_convex.plane_convex
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
   for (int f = 0; f < 2; f++) {
@@ -519,6 +539,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
       }
     }
   }
+  ODK_PROF(6);
   // foot-foot: oriented-box cull (a positive separation of the boxes bounds the hulls' separation from below)
   {
     float c1[3], c2[3], A1[9], A2[9], tt[3];
@@ -563,9 +584,9 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
       if (lane == 0) SCR[S::S_MISC] = best;
     }
   }
-  if (lane < 27) FRAME[lane] = m->plane_frame[lane % 9];
   ODK_SYNC();
 
+  ODK_PROF(7);
   // ---------------- P8: constraint rows (lane = row): D, aref, contact wrenches
   for (int r = lane; r < NROW; r += G) {
     float D = 0, aref = 0;
@@ -587,7 +608,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
       const float dist = CDIST[c];
       const float mu = m->pair_mu[pair];
       const float fs = (s & 1) ? -mu : mu;
-      const float* fr = FRAME + 9 * pair;
+      const float* fr = m->plane_frame;  // pair 2 (foot-foot) frames come with the convex-convex routine
       const int td = 3 * (1 + (s >> 1));
       const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
       const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};
@@ -613,6 +634,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
   }
   ODK_SYNC();
 
+  ODK_PROF(8);
   // ---------------- P9: Newton solver, one iteration (mjx solver.solve)
   // helper lambdas -------------------------------------------------------------
   auto foot_twist = [&](const float* vec) {  // SCR[S_VF + 6 f + k] = sum_{d above foot f} cdof[k][d] vec[d]
@@ -704,6 +726,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
   }
   if (use_warm) for (int r = lane; r < NROW; r += G) JAR[r] = JV[r];
   ODK_SYNC();
+  ODK_PROF(9);
   // forces of the chosen point -> JV (scratch), foot wrench sums, gradient
   for (int r = lane; r < NROW; r += G) {
     float fo = 0; bool qd = false;
@@ -777,6 +800,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     }
   }
   ODK_SYNC();
+  ODK_PROF(10);
   // Hessian entries on the virtual-tree layout
   for (int p = lane; p < NH; p += G) {
     const int i = m->H_i[p], j = m->H_j[p], src = m->H_src[p];
@@ -812,11 +836,14 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     HL[p] = v;
   }
   ODK_SYNC();
+  ODK_PROF(11);
   factor_ld<G>(HL, NV, m->vdof_depth, m->vdof_Madr, m->vdof_anc_adr, m->tri_m, m->tri_q, lane);
+  ODK_PROF(16);
   solve_ld<G>(HL, GRAD, NV, m->vdof_depth, m->vdof_Madr, m->vdof_anc, m->vdof_ndesc, m->vdof_desc, m->vdof_desc_adr, lane);
   if (lane < NV) GRAD[lane] = -GRAD[lane];  // search = -H^-1 grad
   ODK_SYNC();
 
+  ODK_PROF(12);
   // ---- line search (mjx solver._linesearch)
   foot_twist(GRAD);
   float sn = 0, qg1 = 0, qg2 = 0;
@@ -831,6 +858,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
   ODK_SYNC();
   for (int r = lane; r < NROW; r += G) JV[r] = (ED[r] == 0.0f && r >= nfl) ? 0.0f : row_jx(r, GRAD);
   ODK_SYNC();
+  ODK_PROF(13);
   const float gtol = m->tolerance * m->ls_tolerance * sqrtf(sn) * m->meaninertia * (float)(NV > 1 ? NV : 1);
   // evaluate up to three step sizes at once: cost, first and second derivative along the search
   auto ls_eval3 = [&](const float* al, float* cost, float* d0, float* d1) {
@@ -902,11 +930,11 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     const float xa = X[lane] + alpha * GRAD[lane];
     X[lane] = xa;
     WARM[lane] = xa;
-    L[S::O_QACC + lane] = xa;
   }
   if (lane == 0) { SCR[S::S_MISC + 1] = alpha; SCR[S::S_MISC + 2] = use_warm ? 1.0f : 0.0f; SCR[S::S_MISC + 3] = use_warm ? cost_w : cost_s; }
   ODK_SYNC();
 
+  ODK_PROF(14);
   // ---------------- P10: sensors (lane = sensor), only when requested
   if (flags & 1) {
     if (lane < m->nsensor) {
@@ -971,6 +999,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     }
     ODK_SYNC();
   }
+  ODK_PROF(17);
 }
 
 // mjx forward.euler (eulerdamp disabled): qvel += dt qacc; qpos integrated with the NEW qvel

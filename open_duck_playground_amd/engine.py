@@ -17,7 +17,7 @@ import numpy as np
 from .model import Model, asset_path
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libodk.so")
+LIB_PATH = os.environ.get("ODK_LIB", os.path.join(_CSRC, "libodk.so"))  # ODK_LIB: e.g. the -DODK_PROFILE build
 
 NOBS, NPRIV, NMETRIC, NU = 101, 212, 8, 14
 METRIC_NAMES = ("reward/tracking_lin_vel", "reward/tracking_ang_vel", "cost/torques", "cost/action_rate", "cost/stand_still",

@@ -1,0 +1,41 @@
+"""Per-phase shader-clock breakdown of the fused step kernel (needs the -DODK_PROFILE build):
+    ODK_LIB=open_duck_playground_amd/csrc/libodk_prof.so python tools/gpu_phase_profile.py [task] [lanes] [nenv]
+Prints mean cycles per phase per env step (10 forwards), measured by lane 0 of every env."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from open_duck_playground_amd import engine
+from open_duck_playground_amd.model import load_task_model
+
+task = sys.argv[1] if len(sys.argv) > 1 else "flat_terrain"
+lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+nenv = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+NAMES = ["P1 kinematics+cinert+cdof", "P2 crb*cdof, vel prefix", "P3 M entries", "P4 cvel/cacc/cfrc", "P5 bias+act (copy M)",
+         "P6a factor M", "P7 plane-convex x2", "P7b foot-foot OBB", "P8 rows", "P9a warm/smooth costs", "P9b forces,K,grad,T",
+         "P9c Hessian entries", "P9d factor H", "P9e ls setup (mv, jv)", "P9f line search", "P10 sensors", "P6b solve M", "P9d' solve H"]
+ORDER = [0, 1, 2, 3, 4, 15, 16, 5, 6, 7, 8, 9, 10, 11, 12, 17, 13, 14]
+IDX = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 15: 5, 16: 16, 5: 6, 6: 7, 7: 8, 8: 9, 9: 10, 10: 11, 11: 12, 12: 17, 17: 15, 13: 13, 14: 14}
+model = load_task_model(task)
+cfg = engine.default_config(); cfg.noise_level = 0.0; cfg.push_enable = 0.0; cfg.lanes_per_env = lanes
+b = engine.Batch(model, nenv, cfg)
+b.reset(0)
+act = torch.empty(nenv, 14, device="cuda").uniform_(-1, 1)
+for _ in range(20):
+    b.step(act.uniform_(-1, 1))
+b.L.odk_set_debug_dump(1)
+b.step(act.uniform_(-1, 1))
+torch.cuda.synchronize()
+img = b.lds_image()
+o = b.lds_offset("scr") + 172
+prof = img[:, o:o + 20].astype(np.float64)
+mean = prof.mean(axis=0)
+tot = mean[:18].sum()
+# slot i holds the time of the code BEFORE ODK_PROF(i)
+labels = {0: "P1 kinematics+cinert+cdof", 1: "P2 crb*cdof+prefix", 2: "P3 M entries", 3: "P4 cvel/cacc/cfrc", 4: "P5 bias+act+copy",
+          15: "P6 factor M", 5: "P6 solve M", 6: "P7 plane-convex x2", 7: "P7 OBB cull", 8: "P8 rows", 9: "P9 candidate costs",
+          10: "P9 forces/K/grad/T", 11: "P9 Hessian entries", 16: "P9 factor H", 12: "P9 solve H", 13: "P9 ls setup", 14: "P9 line search",
+          17: "P10 sensors(+tail)"}
+print(f"{task} G={lanes} nenv={nenv}: cycles per env step (lane-0 clock, 10 forwards), total {tot:,.0f}")
+for i in [0, 1, 2, 3, 4, 15, 5, 6, 7, 8, 9, 10, 11, 16, 12, 13, 14, 17]:
+    print(f"  {labels[i]:28s} {mean[i]:12,.0f}  {100 * mean[i] / tot:5.1f}%")
