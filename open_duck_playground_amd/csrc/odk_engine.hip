@@ -45,8 +45,8 @@ template <class S> struct EnvL {
   static_assert(S::NM + S::NH >= ODK_NPRIV, "privileged obs must fit in the M|HL region");
 };
 
-using ShapeA = Shape<21, 20, 18, 14, 145, 170, 76>;   // flat_terrain
-using ShapeB = Shape<31, 30, 18, 14, 285, 385, 86>;   // *_backlash
+using ShapeA = Shape<21, 20, 18, 14, 15, 145, 170, 76, 10, 15>;   // flat_terrain
+using ShapeB = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25>;   // *_backlash
 
 struct KArgs {
   const DevModel* m;
@@ -221,6 +221,8 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   const EnvCfg& c = a.cfg;
   float* INFO = L + E::O_INFO;
   load_params<S, G>(L, m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);
+  Statics<S, G> st;
+  load_statics<S, G>(st, m, lane);
   uint32_t k0, k1;
   threefry2x32(a.seed, 0x4F444B31u, a.env_offset + (uint32_t)e, 0u, k0, k1);
   const uint32_t kr = k1 ^ 0x52535421u;
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   }
   if (lane < 7) sample_command(c, k0, kr, 0, 23, lane, INFO[rec::CMD + lane]);
   ODK_SYNC();
-  forward_env<S, G>(L, m, lane, 1);
+  forward_env<S, G>(L, m, st, lane, 1);
   if (a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
   const float pint = c.push_interval_range[0] + rng_uniform(k0, kr, 0, 31) * (c.push_interval_range[1] - c.push_interval_range[0]);
   const int push_interval_steps = (int)rintf(pint / c.ctrl_dt);
@@ -304,6 +306,8 @@ __global__ void __launch_bounds__(64) step_kernel(KArgs a) {
   for (int u = lane; u < NU; u += G) ACT[u] = a.action[(size_t)e * NU + u];
   load_params<S, G>(L, m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);  // syncs
   if (lane < 20) L[S::O_SCR + S::S_PROF + lane] = 0;
+  Statics<S, G> st;
+  load_statics<S, G>(st, m, lane);
   const uint32_t k0 = (uint32_t)f2i(INFO[rec::KEY0]), k1 = (uint32_t)f2i(INFO[rec::KEY1]), ctr = (uint32_t)f2i(INFO[rec::CTR]);
   int step = f2i(INFO[rec::STEP]), push_step = f2i(INFO[rec::PSTEP]);
   const int push_int = f2i(INFO[rec::PINT]);
@@ -349,9 +353,9 @@ __global__ void __launch_bounds__(64) step_kernel(KArgs a) {
   // ---- mjx_env.step: n_substeps x (forward + Euler)   (:420)
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
-    forward_env<S, G>(L, m, lane, last ? 1 : 0);
+    forward_env<S, G>(L, m, st, lane, last ? 1 : 0);
     if (last && a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
-    euler_env<S, G>(L, m, lane);
+    euler_env<S, G>(L, m, st, lane);
   }
   for (int u = lane; u < NU; u += G) INFO[rec::MT + u] = CTRL[u];  // info["motor_targets"] (:422)
   // ---- contacts, air time, swing peak (:424-435)
@@ -485,11 +489,13 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   load_params<S, G>(L, a.m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);
   if (lane < 20) L[S::O_SCR + S::S_PROF + lane] = 0;
   ODK_SYNC();
+  Statics<S, G> st;
+  load_statics<S, G>(st, a.m, lane);
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
-    forward_env<S, G>(L, a.m, lane, last ? 1 : 0);
+    forward_env<S, G>(L, a.m, st, lane, last ? 1 : 0);
     if (last && a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
-    euler_env<S, G>(L, a.m, lane);
+    euler_env<S, G>(L, a.m, st, lane);
   }
   if (live) for (int i = lane; i < S::NQ + 2 * S::NV; i += G) rc[i] = L[S::O_QPOS + i];
 }
@@ -642,6 +648,8 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I2("k_body_chain", &m.body_chain[0][0], MAXB, MAXCHAIN); B.I("k_body_chain_len", m.body_chain_len, MAXB);
   B.I2("k_body_ancdof", &m.body_ancdof[0][0], MAXB, MAXV); B.I("k_body_nancdof", m.body_nancdof, MAXB);
   B.I2("k_body_sub", &m.body_sub[0][0], MAXB, MAXB); B.I("k_body_nsub", m.body_nsub, MAXB);
+  B.I("k_max_level", &m.max_level, 1); B.I("k_body_level", m.body_level, MAXB); B.I2("k_body_children", &m.body_children[0][0], MAXB, 3);
+  B.I("k_body_nchild", m.body_nchild, MAXB);
   B.F("body_pos", &m.body_pos[0][0], MAXB * 3); B.F("body_quat", &m.body_quat[0][0], MAXB * 4); B.F("body_ipos", &m.body_ipos[0][0], MAXB * 3);
   B.F("body_mass", m.body_mass, MAXB); B.F("body_inertia_full", &m.body_inertia[0][0], MAXB * 6);
   // joints
@@ -655,9 +663,19 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I("k_dof_nprefix", m.dof_nprefix, MAXV); B.I2("k_dof_prefix", &m.dof_prefix[0][0], MAXV, MAXV);
   B.I("k_dof_nsym", m.dof_nsym, MAXV); B.I2("k_dof_sym_dof", &m.dof_sym_dof[0][0], MAXV, MAXV); B.I2("k_dof_sym_adr", &m.dof_sym_adr[0][0], MAXV, MAXV);
   B.I("k_dof_act", m.dof_act, MAXV); B.I("k_dof_flrow", m.dof_flrow, MAXV); B.I("k_dof_limrow", m.dof_limrow, MAXV);
+  B.I("k_dof_ancmask", m.dof_ancmask, MAXV); B.I("k_dof_descmask", m.dof_descmask, MAXV);
+  B.I("k_vdof_ancmask", m.vdof_ancmask, MAXV); B.I("k_vdof_descmask", m.vdof_descmask, MAXV);
   B.F("dof_armature", m.dof_armature, MAXV); B.F("dof_damping", m.dof_damping, MAXV); B.F("dof_frictionloss", m.dof_frictionloss, MAXV);
   B.F("dof_invweight0", m.dof_invweight0, MAXV);
   B.I("k_nM", &m.nM, 1); B.I("k_M_i", m.M_i, MAXNZ); B.I("k_M_j", m.M_j, MAXNZ);
+  for (int d = 0; d < MAXV; d++) { m.dof_qadr[d] = -1; m.dof_jnt[d] = -1; }
+  for (int j = 1; j < m.nj; j++) {
+    const int d = m.jnt_dofadr[j];
+    m.dof_qadr[d] = m.jnt_qposadr[j]; m.dof_jnt[d] = j;
+    m.dof_range[d][0] = m.jnt_range[j][0]; m.dof_range[d][1] = m.jnt_range[j][1];
+    if (m.jnt_pos[j][0] != 0.0f || m.jnt_pos[j][1] != 0.0f || m.jnt_pos[j][2] != 0.0f) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "hinge joints must sit at their body origin (jnt_pos == 0)"); }
+  }
+  for (int b2 = 0; b2 < m.nb; b2++) if (m.body_jntnum[b2] > 2) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "more than two joints on one body"); }
   B.I("k_vdof_depth", m.vdof_depth, MAXV); B.I2("k_vdof_anc", &m.vdof_anc[0][0], MAXV, MAXV); B.I("k_vdof_Madr", m.vdof_Madr, MAXV);
   B.I2("k_vdof_anc_adr", &m.vdof_anc_adr[0][0], MAXV, MAXV); B.I("k_vdof_ndesc", m.vdof_ndesc, MAXV);
   B.I2("k_vdof_desc", &m.vdof_desc[0][0], MAXV, MAXV); B.I2("k_vdof_desc_adr", &m.vdof_desc_adr[0][0], MAXV, MAXV);
@@ -775,8 +793,13 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     bool ok = (b == m.base_body) || (b == m.foot_body[0]) || (b == m.foot_body[1]);
     if (!ok || ((m.sensor_type[s] == 2 || m.sensor_type[s] == 8) && b != m.base_body)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "sensor %d placement", s); }
   }
-  if (m.nq == ShapeA::NQ && m.nv == ShapeA::NV && m.nb == ShapeA::NB && m.nu == ShapeA::NU && m.nM == ShapeA::NM && m.nH == ShapeA::NH && m.nrow == ShapeA::NROW) mo->shape = 0;
-  else if (m.nq == ShapeB::NQ && m.nv == ShapeB::NV && m.nb == ShapeB::NB && m.nu == ShapeB::NU && m.nM == ShapeB::NM && m.nH == ShapeB::NH && m.nrow == ShapeB::NROW) mo->shape = 1;
+  int dt_max = 0, dv_max = 0;
+  for (int d = 0; d < m.nv; d++) { dt_max = m.dof_depth[d] > dt_max ? m.dof_depth[d] : dt_max; dv_max = m.vdof_depth[d] > dv_max ? m.vdof_depth[d] : dv_max; }
+  auto fits = [&](int nq, int nv, int nb, int nu, int nj, int nM, int nH, int nrow, int DT, int DV) {
+    return m.nq == nq && m.nv == nv && m.nb == nb && m.nu == nu && m.nj == nj && m.nM == nM && m.nH == nH && m.nrow == nrow && dt_max <= DT && dv_max <= DV;
+  };
+  if (fits(ShapeA::NQ, ShapeA::NV, ShapeA::NB, ShapeA::NU, ShapeA::NJ, ShapeA::NM, ShapeA::NH, ShapeA::NROW, ShapeA::DT, ShapeA::DV)) mo->shape = 0;
+  else if (fits(ShapeB::NQ, ShapeB::NV, ShapeB::NB, ShapeB::NU, ShapeB::NJ, ShapeB::NM, ShapeB::NH, ShapeB::NROW, ShapeB::DT, ShapeB::DV)) mo->shape = 1;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
   *out = mo;
   return ODK_OK;
@@ -990,7 +1013,7 @@ extern "C" int odk_batch_get_lds(odk_batch* b, float* host) {  // debug image of
 extern "C" int odk_lds_offset(const odk_batch* b, const char* name) {
   if (!b || !name) return -1;
 #define OFF(nm, field) if (!strcmp(name, nm)) return b->model.shape == 0 ? ShapeA::field : ShapeB::field;
-  OFF("qpos", O_QPOS) OFF("qvel", O_QVEL) OFF("warm", O_WARM) OFF("ctrl", O_CTRL) OFF("xpos", O_XPOS) OFF("xmat", O_XMAT) OFF("cinert", O_CINERT)
+  OFF("qpos", O_QPOS) OFF("qvel", O_QVEL) OFF("warm", O_WARM) OFF("ctrl", O_CTRL) OFF("xpos", O_XPOS) OFF("xquat", O_XQUAT) OFF("crb", O_CRB)
   OFF("cdof", O_CDOF) OFF("M", O_M) OFF("HL", O_HL) OFF("qfrc_smooth", O_QFS) OFF("qacc_smooth", O_QAS) OFF("x", O_X) OFF("Ma", O_MA)
   OFF("search", O_GRAD) OFF("mv", O_MV) OFF("efc_D", O_D) OFF("efc_aref", O_AREF) OFF("jar", O_JAR) OFF("jv", O_JV) OFF("W", O_W)
   OFF("contact_dist", O_CDIST) OFF("contact_r", O_CR) OFF("scr", O_SCR) OFF("sensordata", O_SENS) OFF("actuator_force", O_ACTF) OFF("qacc", O_QACC)

@@ -3,15 +3,22 @@
 // Geometry: one workgroup = one wavefront (64 lanes) = 64/G environments, G lanes per env
 // (G = 32 or 64).  Every per-env array lives in LDS for the whole env step; HBM is touched once at
 // the start (state record, action) and once at the end (state record, obs, reward...).  Lanes map
-// to bodies / dofs / sparse-matrix entries / constraint rows by phase; cross-lane reductions use
-// sub-wave shuffles.  Physics follows mjx.step as restated in oracle/odk_oracle.c:
-// the reference reaches it through mjx_env.step at playground/open_duck_mini_v2/joystick.py:420.
+// to bodies / dofs / sparse-matrix entries / constraint rows by phase.  Physics follows mjx.step as
+// restated in oracle/odk_oracle.c; the reference reaches it through mjx_env.step at
+// playground/open_duck_mini_v2/joystick.py:420.
 //
-// Restructurings relative to the textbook pipeline (all exact in real arithmetic):
+// What makes it fast (all exact in real arithmetic):
+//  * NO table loads inside the substep loop: everything a lane needs about "its" body / dof / row /
+//    matrix entries is read once per launch into registers (struct Statics); per-step uniform scalars
+//    are pulled out of those registers with v_readlane;
+//  * kinematics, velocities and bias accelerations in ONE top-down level sweep of the body tree,
+//    composite inertias and bias forces in one bottom-up sweep;
 //  * spatial quantities are expressed about the floating-base origin instead of the subtree COM;
 //  * contact Jacobian rows are never formed: J_r = w_r . cdof[d] for dofs d above the foot, with the
 //    6-vector w_r = [r x dir; dir], so J x, J^T f and J^T D J collapse to 6-vector / 6x6 algebra;
-//  * inertia and Newton Hessian share MuJoCo's tree-sparse qM layout and a fill-free L^T D L.
+//  * inertia and Newton Hessian share a tree-sparse row layout (row i = its ancestors by depth) and a
+//    fill-free L^T D L whose rows live in registers; triangular solves and M*v run on dense per-lane
+//    rows in registers with v_readlane broadcasts (no LDS round trips in the dependent chain).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,15 +30,6 @@ namespace odk {
 // cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt -- only a compiler barrier that keeps
 // the LDS accesses in program order (and stops values being cached in registers across the hand-off).
 #define ODK_SYNC() asm volatile("" ::: "memory")
-// Phase timing (build with -DODK_PROFILE): lane 0 accumulates shader-clock deltas per phase into the
-// scratch area, which the debug LDS image carries out.  Zero cost when the macro is off.
-#ifdef ODK_PROFILE
-#define ODK_PROF(i) do { if (lane == 0) { long long _t = clock64(); SCR[S::S_PROF + (i)] += (float)(_t - _tprev); _tprev = _t; } } while (0)
-#define ODK_PROF_BEGIN() long long _tprev = clock64()
-#else
-#define ODK_PROF(i) do { } while (0)
-#define ODK_PROF_BEGIN() do { } while (0)
-#endif
 
 constexpr float MINVAL_F = 1e-15f;
 constexpr float PI_F = 3.14159265358979323846f;
@@ -49,9 +47,11 @@ struct EnvCfg {  // device copy of odk_env_config
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (floats), per environment.  Component-major (SoA) arrays: X[k * N + item].
-template <int NQ_, int NV_, int NB_, int NU_, int NM_, int NH_, int NROW_>
+template <int NQ_, int NV_, int NB_, int NU_, int NJ_, int NM_, int NH_, int NROW_, int DT_, int DV_>
 struct Shape {
-  static constexpr int NQ = NQ_, NV = NV_, NB = NB_, NU = NU_, NM = NM_, NH = NH_, NROW = NROW_;
+  static constexpr int NQ = NQ_, NV = NV_, NB = NB_, NU = NU_, NJ = NJ_, NM = NM_, NH = NH_, NROW = NROW_;
+  static constexpr int DT = DT_;    // max dof depth, kinematic tree
+  static constexpr int DV = DV_;    // max dof depth, virtual (Hessian) tree
   static constexpr int NCROW = 48;  // contact rows
   // persistent over the env step
   static constexpr int O_QPOS = 0;
@@ -65,27 +65,31 @@ struct Shape {
   static constexpr int O_FRL = O_ARM + NV;     // dof_frictionloss
   static constexpr int O_KP = O_FRL + NV;      // actuator kp
   static constexpr int O_IPOS1 = O_KP + NU;    // body_ipos[1]
-  // position stage
+  // tree sweeps (component-major by body)
   static constexpr int O_XPOS = O_IPOS1 + 3;         // [3][NB]
-  static constexpr int O_XMAT = O_XPOS + 3 * NB;     // [9][NB]
-  static constexpr int O_CINERT = O_XMAT + 9 * NB;   // [10][NB]
-  static constexpr int O_CDOF = O_CINERT + 10 * NB;  // [6][NV]
-  static constexpr int O_BUF6 = O_CDOF + 6 * NV;     // [6][NV]  crb*cdof -> cdof_dot*qvel -> K_L*cdof
-  static constexpr int O_BODY = O_BUF6 + 6 * NV;     // [12][NB] cvel | cfrc_local -> K_R*cdof
-  static constexpr int O_M = O_BODY + 12 * NB;       // [NM] sparse inertia
+  static constexpr int O_XQUAT = O_XPOS + 3 * NB;    // [4][NB]
+  static constexpr int O_CVEL = O_XQUAT + 4 * NB;    // [6][NB]
+  static constexpr int O_CACC = O_CVEL + 6 * NB;     // [6][NB] velocity-dependent part of cacc (gravity folded in)
+  static constexpr int O_CFRC = O_CACC + 6 * NB;     // [6][NB] local then subtree-accumulated bias force
+  static constexpr int O_CRB = O_CFRC + 6 * NB;      // [10][NB] cinert then composite inertia
+  static constexpr int O_SC = O_CRB + 10 * NB;       // [2][NJ] sin/cos of the half joint angles
+  static constexpr int O_CDOF = O_SC + 2 * NJ;       // [6][NV]
+  static constexpr int O_BUF6 = O_CDOF + 6 * NV;     // [6][NV] crb*cdof -> K_L*cdof
+  static constexpr int O_BUF6B = O_BUF6 + 6 * NV;    // [6][NV] K_R*cdof
+  static constexpr int O_M = O_BUF6B + 6 * NV;       // [NM] sparse inertia (rows by ancestor depth)
   static constexpr int O_HL = O_M + NM;              // [NH] L^T D L of M, then Hessian and its factor
   // dof vectors
   static constexpr int O_QFS = O_HL + NH;            // qfrc_smooth
   static constexpr int O_QAS = O_QFS + NV;           // qacc_smooth
   static constexpr int O_X = O_QAS + NV;             // current qacc iterate
-  static constexpr int O_MA = O_X + NV;              // M * qacc
-  static constexpr int O_GRAD = O_MA + NV;           // gradient, then search direction
-  static constexpr int O_MV = O_GRAD + NV;           // M * search (scratch: M * warmstart)
+  static constexpr int O_MA = O_X + NV;              // scratch: per-dof friction-row hand-over
+  static constexpr int O_GRAD = O_MA + NV;           // search direction
+  static constexpr int O_MV = O_GRAD + NV;           // scratch: per-dof friction-row hand-over
   // constraint rows
   static constexpr int O_D = O_MV + NV;              // efc_D (0 = structurally inactive row)
   static constexpr int O_AREF = O_D + NROW;
-  static constexpr int O_JAR = O_AREF + NROW;        // J qacc - aref
-  static constexpr int O_JV = O_JAR + NROW;          // J search (scratch: candidate Jaref, forces)
+  static constexpr int O_JAR = O_AREF + NROW;        // J qacc - aref (contact rows)
+  static constexpr int O_JV = O_JAR + NROW;          // J search (scratch: candidate Jaref, forces, Hessian diagonal addend)
   static constexpr int O_W = O_JV + NROW;            // [NCROW][6] contact row wrenches [r x dir; dir]
   static constexpr int O_CDIST = O_W + 6 * NCROW;    // [12]
   static constexpr int O_CR = O_CDIST + NCON;        // [12][3] contact position relative to the base origin
@@ -99,11 +103,20 @@ struct Shape {
   static constexpr int S_VF = 0;      // [2][6] foot twist of the current vector
   static constexpr int S_FF = 12;     // [2][6] foot wrench sums
   static constexpr int S_K = 24;      // [3][36] K_L, K_R, K_X
-  static constexpr int S_SV = 132;    // [3][6] cvel of base, left foot, right foot (sensors)
-  static constexpr int S_CA = 150;    // [6] velocity part of cacc[base]
+  static constexpr int S_VF2 = 132;   // [2][6] second foot twist (warmstart candidate)
   static constexpr int S_MISC = 156;  // misc scalars (16)
   static constexpr int S_PROF = 172;  // [20] per-phase cycle counters (ODK_PROFILE builds)
 };
+
+// Phase timing (build with -DODK_PROFILE): lane 0 accumulates shader-clock deltas per phase into the
+// scratch area, which the debug LDS image carries out.  Zero cost when the macro is off.
+#ifdef ODK_PROFILE
+#define ODK_PROF(i) do { if (lane == 0) { long long _t = clock64(); SCR[S::S_PROF + (i)] += (float)(_t - _tprev); _tprev = _t; } } while (0)
+#define ODK_PROF_BEGIN() long long _tprev = clock64()
+#else
+#define ODK_PROF(i) do { } while (0)
+#define ODK_PROF_BEGIN() do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 template <int G> __device__ __forceinline__ float gsum(float v) {
@@ -126,6 +139,15 @@ template <int G> __device__ __forceinline__ int gargmax(float v, int i) {
   }
   return __shfl(i, 0, G);
 }
+// value held by lane j (uniform j < G) of this env's lane group, via v_readlane (no LDS)
+template <int G> __device__ __forceinline__ float bcast(float v, int j) {
+  const int iv = __float_as_int(v);
+  if (G == 64) return __int_as_float(__builtin_amdgcn_readlane(iv, j));
+  const int lo = __builtin_amdgcn_readlane(iv, j), hi = __builtin_amdgcn_readlane(iv, j + 32);
+  return __int_as_float((threadIdx.x & 32) ? hi : lo);
+}
+// uniform integer static of lane j (identical in every env of the wave)
+__device__ __forceinline__ int ubcast(int v, int j) { return __builtin_amdgcn_readlane(v, j); }
 
 __device__ __forceinline__ void cross3(float* r, const float* a, const float* b) {
   float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
@@ -167,6 +189,13 @@ __device__ __forceinline__ void inert_mul(float* res, const float* i, const floa
   res[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
   res[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
 }
+__device__ __forceinline__ void cross_motion(float* res, const float* vel, const float* v) {  // mju_crossMotion
+  float a[3], b[3];
+  cross3(res, vel, v);
+  cross3(a, vel, v + 3);
+  cross3(b, vel + 3, v);
+  res[3] = a[0] + b[0]; res[4] = a[1] + b[1]; res[5] = a[2] + b[2];
+}
 
 // ---- RNG: threefry2x32-20, stream definition shared with oracle/odk_oracle_env.c
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -195,46 +224,154 @@ __device__ inline float rng_uniform(uint32_t k0, uint32_t k1, uint32_t ctr, uint
 __device__ __forceinline__ int randint3(float u) { int i = (int)(u * 3.0f); return i > 2 ? 2 : i; }
 
 // ------------------------------------------------------------------------------------------------
-// Sparse L^T D L (mj_factorM) on MuJoCo's qM layout.  Pairs (m, q), 1<=m<=q<=depth(k), update entry
-// (anc_m(k), anc_q(k)) from row k; all pairs of one k are independent.
-template <int G>
-__device__ inline void factor_ld(float* A, int nv, const int* depth, const int* Madr, const int (*anc_adr)[MAXV], const int* tri_m,
-                                 const int* tri_q, int lane) {
-  for (int k = nv - 1; k > 0; k--) {
-    int D = depth[k];
-    if (D == 0) continue;
-    int ak = Madr[k];
-    float inv = 1.0f / A[ak];
-    int np = D * (D + 1) / 2;
-    for (int t = lane; t < np; t += G) {
-      int mm = tri_m[t], q = tri_q[t];
-      A[anc_adr[k][mm] + (q - mm)] -= A[ak + mm] * inv * A[ak + q];
+// Per-lane static data, loaded once per launch.  A lane plays several roles (body `lane`, dof `lane`,
+// joint `lane`, hull vertex `lane`, a few matrix entries and constraint rows); roles beyond the
+// model's counts are disabled by their flags.
+template <class S, int G>
+struct Statics {
+  static constexpr int NME = (S::NM + G - 1) / G;   // inertia entries per lane
+  static constexpr int NHE = (S::NH + G - 1) / G;   // Hessian entries per lane
+  // body role
+  int b_level, b_parent, b_nchild, b_child[3], b_njnt, b_jd[2], b_jj[2];
+  float b_pos[3], b_quat[4], b_ipos[3], b_inertia[6], b_ax[2][3];
+  // joint role (sin/cos phase, Euler)
+  int j_qadr, j_dadr;
+  // dof role
+  int d_on, d_body, d_depth, d_Madr, d_ancmask, d_descmask, d_vdepth, d_vMadr, d_vancmask, d_vdescmask;
+  int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
+  int d_qadr, d_lim_on;                  // hinge qpos address (-1: free joint); has a limit row
+  float d_damping, d_lo, d_hi;           // joint range of the dof's hinge
+  float a_bias2, a_clo, a_chi, a_flo, a_fhi;  // actuator of the dof (if d_act >= 0)
+  int a_climited, a_flimited;
+  // matrix entries: i | j << 5 (| foot bits of i << 10 | foot bits of j << 12 | (src + 1) << 14 for H)
+  int ment[NME], hent[NHE];
+  // friction-loss row `lane` (lane < nfl)
+  float fl_D, fl_R, fl_b;
+  int fl_dof;
+  // hull vertices of both feet in the body frame
+  float vert[2][3];
+};
+
+template <class S, int G>
+__device__ void load_statics(Statics<S, G>& st, const DevModel* __restrict__ m, int lane) {
+  const int b = lane < S::NB ? lane : 0;
+  st.b_level = lane < S::NB ? m->body_level[b] : -2;
+  st.b_parent = m->body_parent[b];
+  st.b_nchild = lane < S::NB ? m->body_nchild[b] : 0;
+  for (int k = 0; k < 3; k++) st.b_child[k] = m->body_children[b][k];
+  st.b_njnt = (lane < S::NB && st.b_level > 0) ? m->body_jntnum[b] : 0;
+  for (int k = 0; k < 2; k++) {
+    const bool on = k < st.b_njnt;
+    const int j = on ? m->body_jntadr[b] + k : 0;
+    st.b_jj[k] = j;
+    st.b_jd[k] = m->jnt_dofadr[j];
+    for (int c = 0; c < 3; c++) st.b_ax[k][c] = on ? m->jnt_axis[j][c] : 0.0f;
+  }
+  for (int c = 0; c < 3; c++) { st.b_pos[c] = m->body_pos[b][c]; st.b_ipos[c] = m->body_ipos[b][c]; }
+  for (int c = 0; c < 4; c++) st.b_quat[c] = m->body_quat[b][c];
+  for (int c = 0; c < 6; c++) st.b_inertia[c] = m->body_inertia[b][c];
+  {
+    const bool on = lane >= 1 && lane < S::NJ;
+    st.j_qadr = on ? m->jnt_qposadr[lane] : -1;
+    st.j_dadr = on ? m->jnt_dofadr[lane] : 0;
+  }
+  const int i = lane < S::NV ? lane : 0;
+  st.d_on = lane < S::NV;
+  st.d_body = m->dof_body[i];
+  st.d_depth = m->dof_depth[i]; st.d_Madr = m->dof_Madr[i]; st.d_ancmask = m->dof_ancmask[i]; st.d_descmask = m->dof_descmask[i];
+  st.d_vdepth = m->vdof_depth[i]; st.d_vMadr = m->vdof_Madr[i]; st.d_vancmask = m->vdof_ancmask[i]; st.d_vdescmask = m->vdof_descmask[i];
+  if (!st.d_on) { st.d_ancmask = 0; st.d_descmask = 0; st.d_vancmask = 0; st.d_vdescmask = 0; st.d_depth = 0; st.d_vdepth = 0; }
+  st.d_act = st.d_on ? m->dof_act[i] : -1;
+  st.d_flrow = st.d_on ? m->dof_flrow[i] : -1;
+  st.d_limrow = st.d_on ? m->dof_limrow[i] : -1;
+  st.d_foot = st.d_on ? (m->foot_dofmask[0][i] | (m->foot_dofmask[1][i] << 1)) : 0;
+  st.d_damping = m->dof_damping[i];
+  st.d_lim_on = st.d_limrow >= 0;
+  st.d_qadr = m->dof_qadr[i];
+  st.d_lo = m->dof_range[i][0]; st.d_hi = m->dof_range[i][1];
+  {
+    const int u = st.d_act >= 0 ? st.d_act : 0;
+    st.a_bias2 = m->act_bias2[u]; st.a_clo = m->act_ctrlrange[u][0]; st.a_chi = m->act_ctrlrange[u][1];
+    st.a_flo = m->act_forcerange[u][0]; st.a_fhi = m->act_forcerange[u][1];
+    st.a_climited = m->act_ctrllimited[u]; st.a_flimited = m->act_forcelimited[u];
+  }
+  for (int t = 0; t < Statics<S, G>::NME; t++) {
+    const int p = lane + t * G;
+    st.ment[t] = p < S::NM ? (m->M_i[p] | (m->M_j[p] << 5)) : -1;
+  }
+  for (int t = 0; t < Statics<S, G>::NHE; t++) {
+    const int p = lane + t * G;
+    int e = -1;
+    if (p < S::NH) {
+      const int hi = m->H_i[p], hj = m->H_j[p];
+      const int fi = m->foot_dofmask[0][hi] | (m->foot_dofmask[1][hi] << 1), fj = m->foot_dofmask[0][hj] | (m->foot_dofmask[1][hj] << 1);
+      e = hi | (hj << 5) | (fi << 10) | (fj << 12) | ((m->H_src[p] + 1) << 14);
     }
-    ODK_SYNC();
-    for (int mm = 1 + lane; mm <= D; mm += G) A[ak + mm] *= inv;
-    ODK_SYNC();
+    st.hent[t] = e;
+  }
+  {
+    const int r = lane < m->nfl ? lane : 0;
+    st.fl_D = m->fl_D[r]; st.fl_R = m->fl_R[r]; st.fl_b = m->fl_b[r]; st.fl_dof = m->fl_dof[r];
+  }
+  for (int f = 0; f < 2; f++) {
+    const int v = lane < m->foot_nvert[f] ? lane : 0;
+    for (int c = 0; c < 3; c++) st.vert[f][c] = m->foot_vert[f][v][c];
   }
 }
-// x <- (L^T D L)^-1 x   (mj_solveLD)
-template <int G>
-__device__ inline void solve_ld(const float* A, float* x, int nv, const int* depth, const int* Madr, const int (*anc)[MAXV],
-                                const int* ndesc, const int (*desc)[MAXV], const int (*desc_adr)[MAXV], int lane) {
-  for (int k = nv - 1; k > 0; k--) {
-    int D = depth[k];
-    if (D == 0) continue;
-    float xk = x[k];
-    for (int mm = 1 + lane; mm <= D; mm += G) x[anc[k][mm]] -= A[Madr[k] + mm] * xk;
+
+// ------------------------------------------------------------------------------------------------
+// Sparse L^T D L on the tree layout (row i = [L(i, ancestor at depth 0..d-1), D_i]).  Each lane keeps its
+// own row in registers; at step k lane k publishes its finished row to LDS and the ancestors of k fold it in.
+template <int G, int DMAX, int NVT>
+__device__ __forceinline__ void factor_rows(float* __restrict__ A, int lane, int on, int di, int ai, int descmask, int depth_st, int madr_st) {
+  float row[DMAX > 0 ? DMAX : 1], diag = 1.0f;
+#pragma unroll
+  for (int c = 0; c < DMAX; c++) row[c] = (on && c < di) ? A[ai + c] : 0.0f;
+  if (on) diag = A[ai + di];
+  for (int k = NVT - 1; k > 0; k--) {
+    const int Dk = ubcast(depth_st, k);
+    if (Dk == 0) continue;
+    const int ak = ubcast(madr_st, k);
+    if (lane == k) {
+      const float inv = 1.0f / diag;
+#pragma unroll
+      for (int c = 0; c < DMAX; c++)
+        if (c < di) { row[c] *= inv; A[ai + c] = row[c]; }
+      A[ai + di] = diag;
+    }
+    ODK_SYNC();
+    if ((descmask >> k) & 1) {  // this lane's dof is a strict ancestor of k
+      const float Lki = A[ak + di], dk = A[ak + Dk];
+      const float t = Lki * dk;
+#pragma unroll
+      for (int c = 0; c < DMAX; c++)
+        if (c < di) row[c] -= t * A[ak + c];
+      diag -= t * Lki;
+    }
     ODK_SYNC();
   }
-  for (int i = lane; i < nv; i += G) x[i] /= A[Madr[i]];
+  if (on) A[ai + di] = diag;  // rows at depth 0 were never published
   ODK_SYNC();
-  for (int j = 0; j < nv - 1; j++) {
-    int nd = ndesc[j];
-    if (nd == 0) continue;
-    float xj = x[j];
-    for (int t = lane; t < nd; t += G) x[desc[j][t]] -= A[desc_adr[j][t]] * xj;
-    ODK_SYNC();
+}
+
+// x <- (L^T D L)^-1 x for the vector whose i-th element is held by lane i (returned the same way)
+template <int G, int NVT>
+__device__ __forceinline__ float solve_rows(const float* __restrict__ A, float xi, int lane, int on, int di, int ai, int ancmask, int descmask,
+                                            int depth_st, int madr_st) {
+  float Lcol[NVT], Lrow[NVT];
+#pragma unroll
+  for (int k = 0; k < NVT; k++) {
+    const int ak = ubcast(madr_st, k), dk = ubcast(depth_st, k);
+    Lcol[k] = ((descmask >> k) & 1) ? A[ak + di] : 0.0f;   // L(k, i), k below i
+    Lrow[k] = ((ancmask >> k) & 1) ? A[ai + dk] : 0.0f;    // L(i, k), k above i
   }
+  const float dinv = on ? 1.0f / A[ai + di] : 0.0f;
+#pragma unroll
+  for (int k = NVT - 1; k > 0; k--) xi -= Lcol[k] * bcast<G>(xi, k);
+  xi *= dinv;
+#pragma unroll
+  for (int j = 0; j < NVT - 1; j++) xi -= Lrow[j] * bcast<G>(xi, j);
+  return xi;
 }
 
 // impedance / stiffness of one constraint row (mjx constraint._row); returns D = 1/R and aref
@@ -264,244 +401,257 @@ __device__ inline void row_params(const float* solref, const float* solimp, floa
 // One mjx.forward for one env (all G lanes of the group call this together).
 //   flags bit0: compute sensordata / debug outputs (last substep only)
 template <class S, int G>
-__device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ m, int lane, int flags) {
-  constexpr int NV = S::NV, NB = S::NB, NU = S::NU, NM = S::NM, NH = S::NH, NROW = S::NROW;
+__device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane, int flags) {
+  constexpr int NV = S::NV, NB = S::NB;
+  using ST = Statics<S, G>;
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; float* WARM = L + S::O_WARM; float* CTRL = L + S::O_CTRL;
   float* Q0 = L + S::O_Q0; float* MASS = L + S::O_MASS; float* ARM = L + S::O_ARM; float* FRL = L + S::O_FRL; float* KP = L + S::O_KP;
-  float* XPOS = L + S::O_XPOS; float* XMAT = L + S::O_XMAT; float* CIN = L + S::O_CINERT; float* CDOF = L + S::O_CDOF;
-  float* BUF6 = L + S::O_BUF6; float* BODY = L + S::O_BODY; float* M = L + S::O_M; float* HL = L + S::O_HL;
+  float* XPOS = L + S::O_XPOS; float* XQUAT = L + S::O_XQUAT; float* CVEL = L + S::O_CVEL; float* CACC = L + S::O_CACC;
+  float* CFRC = L + S::O_CFRC; float* CRB = L + S::O_CRB; float* SC = L + S::O_SC; float* CDOF = L + S::O_CDOF;
+  float* BUF6 = L + S::O_BUF6; float* BUF6B = L + S::O_BUF6B; float* M = L + S::O_M; float* HL = L + S::O_HL;
   float* QFS = L + S::O_QFS; float* QAS = L + S::O_QAS; float* X = L + S::O_X; float* MA = L + S::O_MA; float* GRAD = L + S::O_GRAD;
   float* MV = L + S::O_MV; float* ED = L + S::O_D; float* AREF = L + S::O_AREF; float* JAR = L + S::O_JAR; float* JV = L + S::O_JV;
   float* W = L + S::O_W; float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR;
   float* SENS = L + S::O_SENS; float* ACTF = L + S::O_ACTF;
   const int nfl = m->nfl, nlim = m->nlim, r0c = nfl + nlim;
   const float dt = m->dt;
-
+  const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
   ODK_PROF_BEGIN();
-  // ---------------- P1: kinematics + cinert + cdof (lane = body); spatial reference = base origin
-  if (lane < NB) {
-    const int b = lane;
-    float p[3], q[4];
-    const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
-    if (!m->body_in_tree[b]) {
-      for (int k = 0; k < 3; k++) p[k] = m->body_pos[b][k];
-      for (int k = 0; k < 4; k++) q[k] = m->body_quat[b][k];
-    } else {
-      for (int k = 0; k < 3; k++) p[k] = ref[k];
-      for (int k = 0; k < 4; k++) q[k] = QPOS[3 + k];
-      qnormalize(q);
-      if (b == m->base_body) {
-        float R[9];
-        q2mat(R, q);
-        for (int k = 0; k < 3; k++) {
-          for (int c = 0; c < 6; c++) { CDOF[c * NV + k] = (c == 3 + k) ? 1.0f : 0.0f; }
-          CDOF[0 * NV + 3 + k] = R[k]; CDOF[1 * NV + 3 + k] = R[3 + k]; CDOF[2 * NV + 3 + k] = R[6 + k];
-          CDOF[3 * NV + 3 + k] = 0; CDOF[4 * NV + 3 + k] = 0; CDOF[5 * NV + 3 + k] = 0;
-        }
-      }
-      const int len = m->body_chain_len[b];
-      for (int ci = 0; ci < len; ci++) {
-        const int c = m->body_chain[b][ci];
-        float t[3], bq[4] = {m->body_quat[c][0], m->body_quat[c][1], m->body_quat[c][2], m->body_quat[c][3]};
-        float bp[3] = {m->body_pos[c][0], m->body_pos[c][1], m->body_pos[c][2]};
-        qrot(t, q, bp);
-        p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
-        qmul(q, q, bq);
-        const int ja = m->body_jntadr[c], jn = m->body_jntnum[c];
-        for (int j = ja; j < ja + jn; j++) {
-          float ax[3] = {m->jnt_axis[j][0], m->jnt_axis[j][1], m->jnt_axis[j][2]};
-          float jp[3] = {m->jnt_pos[j][0], m->jnt_pos[j][1], m->jnt_pos[j][2]};
-          float anchor[3], axw[3];
-          qrot(t, q, jp);
-          anchor[0] = p[0] + t[0]; anchor[1] = p[1] + t[1]; anchor[2] = p[2] + t[2];
-          qrot(axw, q, ax);
-          if (c == b) {
-            const int d = m->jnt_dofadr[j];
-            float off[3] = {ref[0] - anchor[0], ref[1] - anchor[1], ref[2] - anchor[2]}, lin[3];
-            cross3(lin, axw, off);
-            CDOF[0 * NV + d] = axw[0]; CDOF[1 * NV + d] = axw[1]; CDOF[2 * NV + d] = axw[2];
-            CDOF[3 * NV + d] = lin[0]; CDOF[4 * NV + d] = lin[1]; CDOF[5 * NV + d] = lin[2];
-          }
-          const int qa = m->jnt_qposadr[j];
-          float s, co;
-          sincosf(0.5f * (QPOS[qa] - Q0[qa]), &s, &co);
-          float qj[4] = {co, s * ax[0], s * ax[1], s * ax[2]};
-          qmul(q, q, qj);
-          qrot(t, q, jp);
-          p[0] = anchor[0] - t[0]; p[1] = anchor[1] - t[1]; p[2] = anchor[2] - t[2];
-        }
-      }
-      qnormalize(q);
-    }
-    float R[9];
-    q2mat(R, q);
-    for (int k = 0; k < 3; k++) XPOS[k * NB + b] = p[k];
-    for (int k = 0; k < 9; k++) XMAT[k * NB + b] = R[k];
-    // cinert about the base origin
-    float ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]};
-    if (b == 1) { ip[0] = L[S::O_IPOS1]; ip[1] = L[S::O_IPOS1 + 1]; ip[2] = L[S::O_IPOS1 + 2]; }
-    float off[3];
-    for (int k = 0; k < 3; k++) off[k] = p[k] + R[3 * k] * ip[0] + R[3 * k + 1] * ip[1] + R[3 * k + 2] * ip[2] - ref[k];
-    const float* f = m->body_inertia[b];
-    const float Ib[9] = {f[0], f[3], f[4], f[3], f[1], f[5], f[4], f[5], f[2]};
-    float T[9], Iw[9];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) T[3 * i + j] = R[3 * i] * Ib[j] + R[3 * i + 1] * Ib[3 + j] + R[3 * i + 2] * Ib[6 + j];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) Iw[3 * i + j] = T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2];
-    const float mb = MASS[b], o2 = dot3(off, off);
-    CIN[0 * NB + b] = Iw[0] + mb * (o2 - off[0] * off[0]);
-    CIN[1 * NB + b] = Iw[4] + mb * (o2 - off[1] * off[1]);
-    CIN[2 * NB + b] = Iw[8] + mb * (o2 - off[2] * off[2]);
-    CIN[3 * NB + b] = Iw[1] - mb * off[0] * off[1];
-    CIN[4 * NB + b] = Iw[2] - mb * off[0] * off[2];
-    CIN[5 * NB + b] = Iw[5] - mb * off[1] * off[2];
-    CIN[6 * NB + b] = mb * off[0]; CIN[7 * NB + b] = mb * off[1]; CIN[8 * NB + b] = mb * off[2];
-    CIN[9 * NB + b] = mb;
+
+  // ---------------- P0: half-angle sin/cos of every hinge (lane = joint)
+  if (st.j_qadr >= 0) {
+    float s, c;
+    sincosf(0.5f * (QPOS[st.j_qadr] - Q0[st.j_qadr]), &s, &c);
+    SC[2 * lane] = s; SC[2 * lane + 1] = c;
   }
   ODK_SYNC();
-
   ODK_PROF(0);
-  // ---------------- P2: composite inertia times cdof (lane = dof), velocity prefix / cdof_dot
-  float dotv[6] = {0, 0, 0, 0, 0, 0};
-  if (lane < NV) {
-    const int i = lane, b = m->dof_body[i];
-    float crb[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int ns = m->body_nsub[b];
-    for (int s = 0; s < ns; s++) {
-      const int c = m->body_sub[b][s];
-#pragma unroll
-      for (int k = 0; k < 10; k++) crb[k] += CIN[k * NB + c];
+  // ---------------- P1: top-down level sweep (lane = body): pose, cdof, cvel, velocity part of cacc, local bias force
+  {
+    float p[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}, cvel[6] = {0, 0, 0, 0, 0, 0}, cacc[6] = {0, 0, 0, 0, 0, 0};
+    if (st.b_level == -1) {  // world / static bodies
+      for (int k = 0; k < 3; k++) p[k] = st.b_pos[k];
+      for (int k = 0; k < 4; k++) q[k] = st.b_quat[k];
     }
-    float cd[6], buf[6];
+    for (int lvl = 0; lvl <= m->max_level; lvl++) {
+      if (st.b_level == lvl) {
+        if (lvl == 0) {  // floating base: free joint (mj_comVel free-joint rule)
+          for (int k = 0; k < 3; k++) p[k] = ref[k];
+          for (int k = 0; k < 4; k++) q[k] = QPOS[3 + k];
+          qnormalize(q);
+          float R[9];
+          q2mat(R, q);
+          const float wl[3] = {QVEL[3], QVEL[4], QVEL[5]};
+          float ww[3];
+          for (int k = 0; k < 3; k++) ww[k] = R[3 * k] * wl[0] + R[3 * k + 1] * wl[1] + R[3 * k + 2] * wl[2];
+          const float v[3] = {QVEL[0], QVEL[1], QVEL[2]};
+          for (int k = 0; k < 3; k++) {
+            for (int c = 0; c < 6; c++) CDOF[c * NV + k] = (c == 3 + k) ? 1.0f : 0.0f;
+            CDOF[0 * NV + 3 + k] = R[k]; CDOF[1 * NV + 3 + k] = R[3 + k]; CDOF[2 * NV + 3 + k] = R[6 + k];
+            CDOF[3 * NV + 3 + k] = 0; CDOF[4 * NV + 3 + k] = 0; CDOF[5 * NV + 3 + k] = 0;
+          }
+          float vxw[3];
+          cross3(vxw, v, ww);
+          cvel[0] = ww[0]; cvel[1] = ww[1]; cvel[2] = ww[2]; cvel[3] = v[0]; cvel[4] = v[1]; cvel[5] = v[2];
+          cacc[3] = -m->gravity[0] + vxw[0]; cacc[4] = -m->gravity[1] + vxw[1]; cacc[5] = -m->gravity[2] + vxw[2];
+        } else {
+          const int pb = st.b_parent;
+          float pp[3], pq[4], t[3];
+          for (int k = 0; k < 3; k++) pp[k] = XPOS[k * NB + pb];
+          for (int k = 0; k < 4; k++) pq[k] = XQUAT[k * NB + pb];
+          for (int k = 0; k < 6; k++) { cvel[k] = CVEL[k * NB + pb]; cacc[k] = CACC[k * NB + pb]; }
+          qrot(t, pq, st.b_pos);
+          p[0] = pp[0] + t[0]; p[1] = pp[1] + t[1]; p[2] = pp[2] + t[2];
+          qmul(q, pq, st.b_quat);
 #pragma unroll
-    for (int k = 0; k < 6; k++) cd[k] = CDOF[k * NV + i];
+          for (int jj = 0; jj < 2; jj++) {
+            if (jj < st.b_njnt) {  // hinge at the body origin (jnt_pos == 0, checked at load)
+              float axw[3], cd[6], dot[6];
+              qrot(axw, q, st.b_ax[jj]);
+              const float off[3] = {ref[0] - p[0], ref[1] - p[1], ref[2] - p[2]};
+              cd[0] = axw[0]; cd[1] = axw[1]; cd[2] = axw[2];
+              cross3(cd + 3, axw, off);
+              const int d = st.b_jd[jj];
+#pragma unroll
+              for (int k = 0; k < 6; k++) CDOF[k * NV + d] = cd[k];
+              const float qv = QVEL[d];
+              cross_motion(dot, cvel, cd);
+#pragma unroll
+              for (int k = 0; k < 6; k++) { cacc[k] += dot[k] * qv; cvel[k] += cd[k] * qv; }
+              const float s = SC[2 * st.b_jj[jj]], c = SC[2 * st.b_jj[jj] + 1];
+              const float qj[4] = {c, s * st.b_ax[jj][0], s * st.b_ax[jj][1], s * st.b_ax[jj][2]};
+              qmul(q, q, qj);
+            }
+          }
+          qnormalize(q);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) XPOS[k * NB + lane] = p[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) XQUAT[k * NB + lane] = q[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { CVEL[k * NB + lane] = cvel[k]; CACC[k * NB + lane] = cacc[k]; }
+      }
+      ODK_SYNC();
+    }
+    if (lane < NB) {
+      if (st.b_level < 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) XPOS[k * NB + lane] = p[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) XQUAT[k * NB + lane] = q[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { CVEL[k * NB + lane] = 0; CACC[k * NB + lane] = 0; }
+      }
+      // cinert about the base origin, local bias force
+      float R[9];
+      q2mat(R, q);
+      float ip[3] = {st.b_ipos[0], st.b_ipos[1], st.b_ipos[2]};
+      if (lane == 1) { ip[0] = L[S::O_IPOS1]; ip[1] = L[S::O_IPOS1 + 1]; ip[2] = L[S::O_IPOS1 + 2]; }
+      float off[3];
+      for (int k = 0; k < 3; k++) off[k] = p[k] + R[3 * k] * ip[0] + R[3 * k + 1] * ip[1] + R[3 * k + 2] * ip[2] - ref[k];
+      const float* f = st.b_inertia;
+      const float Ib[9] = {f[0], f[3], f[4], f[3], f[1], f[5], f[4], f[5], f[2]};
+      float T[9], Iw[9];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) T[3 * i + j] = R[3 * i] * Ib[j] + R[3 * i + 1] * Ib[3 + j] + R[3 * i + 2] * Ib[6 + j];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) Iw[3 * i + j] = T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2];
+      const float mb = MASS[lane], o2 = dot3(off, off);
+      float ci[10];
+      ci[0] = Iw[0] + mb * (o2 - off[0] * off[0]);
+      ci[1] = Iw[4] + mb * (o2 - off[1] * off[1]);
+      ci[2] = Iw[8] + mb * (o2 - off[2] * off[2]);
+      ci[3] = Iw[1] - mb * off[0] * off[1];
+      ci[4] = Iw[2] - mb * off[0] * off[2];
+      ci[5] = Iw[5] - mb * off[1] * off[2];
+      ci[6] = mb * off[0]; ci[7] = mb * off[1]; ci[8] = mb * off[2];
+      ci[9] = mb;
+      float fr[6], t1[6], a3[3], c3[3];
+      inert_mul(fr, ci, cacc);
+      inert_mul(t1, ci, cvel);
+      cross3(a3, cvel, t1);
+      cross3(c3, cvel + 3, t1 + 3);
+      fr[0] += a3[0] + c3[0]; fr[1] += a3[1] + c3[1]; fr[2] += a3[2] + c3[2];
+      cross3(a3, cvel, t1 + 3);
+      fr[3] += a3[0]; fr[4] += a3[1]; fr[5] += a3[2];
+      const bool dyn = st.b_level >= 0;
+#pragma unroll
+      for (int k = 0; k < 10; k++) CRB[k * NB + lane] = dyn ? ci[k] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) CFRC[k * NB + lane] = dyn ? fr[k] : 0.0f;
+    }
+    ODK_SYNC();
+  }
+  ODK_PROF(1);
+  // ---------------- P2: bottom-up sweep: composite inertia and subtree bias force
+  for (int lvl = m->max_level - 1; lvl >= 0; lvl--) {
+    if (st.b_level == lvl && st.b_nchild > 0) {
+      float acc[16];
+#pragma unroll
+      for (int k = 0; k < 10; k++) acc[k] = CRB[k * NB + lane];
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[10 + k] = CFRC[k * NB + lane];
+#pragma unroll
+      for (int cidx = 0; cidx < 3; cidx++) {
+        if (cidx < st.b_nchild) {
+          const int c = st.b_child[cidx];
+#pragma unroll
+          for (int k = 0; k < 10; k++) acc[k] += CRB[k * NB + c];
+#pragma unroll
+          for (int k = 0; k < 6; k++) acc[10 + k] += CFRC[k * NB + c];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 10; k++) CRB[k * NB + lane] = acc[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) CFRC[k * NB + lane] = acc[10 + k];
+    }
+    ODK_SYNC();
+  }
+  ODK_PROF(2);
+  // ---------------- P3: per dof: crb*cdof, bias force, passive, actuation -> qfrc_smooth
+  float qfs = 0.0f;
+  if (st.d_on) {
+    const int i = lane, b = st.d_body;
+    float crb[10], cd[6], buf[6], bias = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) crb[k] = CRB[k * NB + b];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { cd[k] = CDOF[k * NV + i]; bias += cd[k] * CFRC[k * NB + b]; }
     inert_mul(buf, crb, cd);
 #pragma unroll
     for (int k = 0; k < 6; k++) BUF6[k * NV + i] = buf[k];
-    // mj_comVel prefix: velocity of the parent chain at the moment dof i is applied
-    float pre[6] = {0, 0, 0, 0, 0, 0};
-    const int np = m->dof_nprefix[i];
-    for (int s = 0; s < np; s++) {
-      const int e = m->dof_prefix[i][s];
-      const float qv = QVEL[e];
-#pragma unroll
-      for (int k = 0; k < 6; k++) pre[k] += CDOF[k * NV + e] * qv;
-    }
-    if (i >= 3) {  // cdof_dot = cross_motion(prefix, cdof); stored pre-multiplied by qvel[i]
-      float a[3], b2[3], c2[3];
-      cross3(a, pre, cd);
-      cross3(b2, pre, cd + 3);
-      cross3(c2, pre + 3, cd);
-      const float qv = QVEL[i];
-      dotv[0] = a[0] * qv; dotv[1] = a[1] * qv; dotv[2] = a[2] * qv;
-      dotv[3] = (b2[0] + c2[0]) * qv; dotv[4] = (b2[1] + c2[1]) * qv; dotv[5] = (b2[2] + c2[2]) * qv;
-    }
-  }
-  ODK_SYNC();
-  ODK_PROF(1);
-  // ---------------- P3: sparse inertia entries (lane = entry)
-  for (int p = lane; p < NM; p += G) {
-    const int i = m->M_i[p], j = m->M_j[p];
-    float v = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) v += CDOF[k * NV + j] * BUF6[k * NV + i];
-    if (i == j) v += ARM[i];
-    M[p] = v;
-  }
-  ODK_SYNC();
-  if (lane < NV) {
-#pragma unroll
-    for (int k = 0; k < 6; k++) BUF6[k * NV + lane] = dotv[k];
-  }
-  ODK_SYNC();
-  ODK_PROF(2);
-  // ---------------- P4: body velocity, bias acceleration, local force (lane = body)
-  if (lane < NB) {
-    const int b = lane;
-    float cvel[6] = {0, 0, 0, 0, 0, 0}, cacc[6] = {0, 0, 0, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
-    const int na = m->body_nancdof[b];
-    for (int s = 0; s < na; s++) {
-      const int d = m->body_ancdof[b][s];
-      const float qv = QVEL[d];
-#pragma unroll
-      for (int k = 0; k < 6; k++) { cvel[k] += CDOF[k * NV + d] * qv; cacc[k] += BUF6[k * NV + d]; }
-    }
-    float ci[10], t1[6], t2[6], fr[6];
-#pragma unroll
-    for (int k = 0; k < 10; k++) ci[k] = CIN[k * NB + b];
-    inert_mul(fr, ci, cacc);
-    inert_mul(t1, ci, cvel);
-    // cross_force(cvel, t1)
-    float a[3], c2[3];
-    cross3(a, cvel, t1);
-    cross3(c2, cvel + 3, t1 + 3);
-    t2[0] = a[0] + c2[0]; t2[1] = a[1] + c2[1]; t2[2] = a[2] + c2[2];
-    cross3(t2 + 3, cvel, t1 + 3);
-#pragma unroll
-    for (int k = 0; k < 6; k++) { BODY[k * NB + b] = cvel[k]; BODY[(6 + k) * NB + b] = fr[k] + t2[k]; }
-    if (b == m->base_body) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) { SCR[S::S_SV + k] = cvel[k]; SCR[S::S_CA + k] = cacc[k]; }
-    }
-    if (b == m->foot_body[0]) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) SCR[S::S_SV + 6 + k] = cvel[k];
-    }
-    if (b == m->foot_body[1]) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) SCR[S::S_SV + 12 + k] = cvel[k];
-    }
-  }
-  ODK_SYNC();
-  ODK_PROF(3);
-  // ---------------- P5: bias force, passive, actuation -> qfrc_smooth (lane = dof)
-  if (lane < NV) {
-    const int i = lane, b = m->dof_body[i];
-    float cf[6] = {0, 0, 0, 0, 0, 0};
-    const int ns = m->body_nsub[b];
-    for (int s = 0; s < ns; s++) {
-      const int c = m->body_sub[b][s];
-#pragma unroll
-      for (int k = 0; k < 6; k++) cf[k] += BODY[(6 + k) * NB + c];
-    }
-    float bias = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) bias += CDOF[k * NV + i] * cf[k];
     const float qv = QVEL[i];
-    float frc = -m->dof_damping[i] * qv - bias;
-    const int u = m->dof_act[i];
+    float frc = -st.d_damping * qv - bias;
+    const int u = st.d_act;
     if (u >= 0) {
       float ctrl = CTRL[u];
-      if (m->act_ctrllimited[u]) ctrl = fminf(fmaxf(ctrl, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
+      if (st.a_climited) ctrl = fminf(fmaxf(ctrl, st.a_clo), st.a_chi);
       const float kp = KP[u];
-      float af = kp * ctrl - kp * QPOS[m->act_qposadr[u]] + m->act_bias2[u] * qv;
-      if (m->act_forcelimited[u]) af = fminf(fmaxf(af, m->act_forcerange[u][0]), m->act_forcerange[u][1]);
+      float af = kp * ctrl - kp * QPOS[st.d_qadr] + st.a_bias2 * qv;
+      if (st.a_flimited) af = fminf(fmaxf(af, st.a_flo), st.a_fhi);
       ACTF[u] = af;
       frc += af;
     }
     QFS[i] = frc;
-    QAS[i] = frc;
+    qfs = frc;
   }
-  for (int p = lane; p < NM; p += G) HL[p] = M[p];
+  ODK_SYNC();
+  ODK_PROF(3);
+  // ---------------- P4: sparse inertia entries (lane = entry), mirrored into HL for the factorisation
+#pragma unroll
+  for (int t = 0; t < ST::NME; t++) {
+    const int e = st.ment[t];
+    if (e >= 0) {
+      const int i = e & 31, j = (e >> 5) & 31;
+      float v = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) v += CDOF[k * NV + j] * BUF6[k * NV + i];
+      if (i == j) v += ARM[i];
+      M[lane + t * G] = v;
+      HL[lane + t * G] = v;
+    }
+  }
   ODK_SYNC();
   ODK_PROF(4);
-  // ---------------- P6: qacc_smooth = M^-1 qfrc_smooth
-  factor_ld<G>(HL, NV, m->dof_depth, m->dof_Madr, m->dof_anc_adr, m->tri_m, m->tri_q, lane);
-  ODK_PROF(15);
-  solve_ld<G>(HL, QAS, NV, m->dof_depth, m->dof_Madr, m->dof_anc, m->dof_ndesc, m->dof_desc, m->dof_desc_adr, lane);
-
+  // ---------------- P5: qacc_smooth = M^-1 qfrc_smooth; dense symmetric row of M into registers
+  factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
   ODK_PROF(5);
+  const float qas = solve_rows<G, NV>(HL, qfs, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
+  if (st.d_on) QAS[lane] = qas;
+  float Mrow[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int aj = ubcast(st.d_Madr, j), dj = ubcast(st.d_depth, j);
+    float v = 0.0f;
+    if ((st.d_ancmask >> j) & 1) v = M[st.d_Madr + dj];
+    else if ((st.d_descmask >> j) & 1) v = M[aj + st.d_depth];
+    else if (j == lane) v = M[st.d_Madr + st.d_depth];
+    Mrow[j] = v;
+  }
+  ODK_SYNC();
+  ODK_PROF(6);
+
   // ---------------- P7: collision.  Foot (convex mesh) vs plane: mjx collision_convex.plane_convex
-  const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
+  float fR[2][9], fP[2][3];
+#pragma unroll
   for (int f = 0; f < 2; f++) {
-    const int fb = m->foot_body[f], nvt = m->foot_nvert[f];
+    const int fb = m->foot_body[f];
+    float q[4];
+    for (int k = 0; k < 4; k++) q[k] = XQUAT[k * NB + fb];
+    for (int k = 0; k < 3; k++) fP[f][k] = XPOS[k * NB + fb];
+    q2mat(fR[f], q);
+  }
+  const float pn[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
+#pragma unroll
+  for (int f = 0; f < 2; f++) {
+    const int nvt = m->foot_nvert[f];
     const bool has = lane < nvt;
     float w[3] = {0, 0, 0}, sup = -3.0e38f;
-    const float pn[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
     if (has) {
-      const float* vb = m->foot_vert[f][lane];
-      for (int k = 0; k < 3; k++) w[k] = XPOS[k * NB + fb] + XMAT[(3 * k) * NB + fb] * vb[0] + XMAT[(3 * k + 1) * NB + fb] * vb[1] + XMAT[(3 * k + 2) * NB + fb] * vb[2];
+      const float* vb = st.vert[f];
+      for (int k = 0; k < 3; k++) w[k] = fP[f][k] + fR[f][3 * k] * vb[0] + fR[f][3 * k + 1] * vb[1] + fR[f][3 * k + 2] * vb[2];
       sup = (m->plane_pos[0] - w[0]) * pn[0] + (m->plane_pos[1] - w[1]) * pn[1] + (m->plane_pos[2] - w[2]) * pn[2];
     }
     const float smax = gmax<G>(sup);
@@ -539,42 +689,50 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
       }
     }
   }
-  ODK_PROF(6);
-  // foot-foot: oriented-box cull (a positive separation of the boxes bounds the hulls' separation from below)
+  ODK_PROF(7);
+  // foot-foot: oriented-box cull, 15 axes on 15 lanes (a positive box separation bounds the hulls' from below)
   {
-    float c1[3], c2[3], A1[9], A2[9], tt[3];
-    for (int f = 0; f < 2; f++) {
-      const int fb = m->foot_body[f];
-      float* cc = f ? c2 : c1; float* AA = f ? A2 : A1;
-      float R[9];
-      for (int k = 0; k < 9; k++) R[k] = XMAT[k * NB + fb];
-      for (int k = 0; k < 3; k++) cc[k] = XPOS[k * NB + fb] + R[3 * k] * m->foot_obb_center[f][0] + R[3 * k + 1] * m->foot_obb_center[f][1] + R[3 * k + 2] * m->foot_obb_center[f][2];
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) AA[3 * i + j] = R[3 * i] * m->foot_obb_axes[f][j] + R[3 * i + 1] * m->foot_obb_axes[f][3 + j] + R[3 * i + 2] * m->foot_obb_axes[f][6 + j];
-    }
-    for (int k = 0; k < 3; k++) tt[k] = c2[k] - c1[k];
-    float best = -3.0e38f;
-    float ax[15][3];
-    int na = 0;
-    for (int k = 0; k < 3; k++) { ax[na][0] = A1[k]; ax[na][1] = A1[3 + k]; ax[na][2] = A1[6 + k]; na++; }
-    for (int k = 0; k < 3; k++) { ax[na][0] = A2[k]; ax[na][1] = A2[3 + k]; ax[na][2] = A2[6 + k]; na++; }
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) {
-        float cr[3];
-        cross3(cr, ax[i], ax[3 + j]);
-        float n = sqrtf(dot3(cr, cr));
-        if (n < 1e-6f) continue;
-        ax[na][0] = cr[0] / n; ax[na][1] = cr[1] / n; ax[na][2] = cr[2] / n;
-        na++;
+    float sep = -3.0e38f;
+    if (lane < 15) {
+      float c1[3], c2[3], A1[9], A2[9], tt[3];
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        float* cc = f ? c2 : c1; float* AA = f ? A2 : A1;
+        for (int k = 0; k < 3; k++) cc[k] = fP[f][k] + fR[f][3 * k] * m->foot_obb_center[f][0] + fR[f][3 * k + 1] * m->foot_obb_center[f][1] + fR[f][3 * k + 2] * m->foot_obb_center[f][2];
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) AA[3 * i + j] = fR[f][3 * i] * m->foot_obb_axes[f][j] + fR[f][3 * i + 1] * m->foot_obb_axes[f][3 + j] + fR[f][3 * i + 2] * m->foot_obb_axes[f][6 + j];
       }
-    for (int a = 0; a < na; a++) {
-      float r1 = 0, r2 = 0;
+      for (int k = 0; k < 3; k++) tt[k] = c2[k] - c1[k];
+      // axis of this lane: 0-2 faces of box 1, 3-5 faces of box 2, 6-14 edge x edge
+      const int ia = lane < 3 ? lane : (lane < 6 ? 0 : (lane - 6) / 3), ib = lane < 3 ? 0 : (lane < 6 ? lane - 3 : (lane - 6) % 3);
+      float e1[3], e2[3], ax[3];
+#pragma unroll
       for (int k = 0; k < 3; k++) {
-        r1 += m->foot_obb_half[0][k] * fabsf(dot3(ax[a], ax[k]));
-        r2 += m->foot_obb_half[1][k] * fabsf(dot3(ax[a], ax[3 + k]));
+        e1[k] = ia == 0 ? A1[3 * k] : (ia == 1 ? A1[3 * k + 1] : A1[3 * k + 2]);
+        e2[k] = ib == 0 ? A2[3 * k] : (ib == 1 ? A2[3 * k + 1] : A2[3 * k + 2]);
       }
-      best = fmaxf(best, fabsf(dot3(tt, ax[a])) - r1 - r2);
+      bool ok = true;
+      if (lane < 3) { ax[0] = e1[0]; ax[1] = e1[1]; ax[2] = e1[2]; }
+      else if (lane < 6) { ax[0] = e2[0]; ax[1] = e2[1]; ax[2] = e2[2]; }
+      else {
+        cross3(ax, e1, e2);
+        const float n = sqrtf(dot3(ax, ax));
+        ok = n >= 1e-6f;
+        const float inv = ok ? 1.0f / n : 0.0f;
+        ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
+      }
+      if (ok) {
+        float r1 = 0, r2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const float b1[3] = {A1[k], A1[3 + k], A1[6 + k]}, b2[3] = {A2[k], A2[3 + k], A2[6 + k]};
+          r1 += m->foot_obb_half[0][k] * fabsf(dot3(ax, b1));
+          r2 += m->foot_obb_half[1][k] * fabsf(dot3(ax, b2));
+        }
+        sep = fabsf(dot3(tt, ax)) - r1 - r2;
+      }
     }
+    const float best = gmax<G>(sep);
     if (lane < 4) {
       const int c = 8 + lane;
       // separated boxes -> inactive pair.  Overlapping boxes (feet about to touch) need the full convex-convex
@@ -585,169 +743,171 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     }
   }
   ODK_SYNC();
+  ODK_PROF(8);
 
-  ODK_PROF(7);
-  // ---------------- P8: constraint rows (lane = row): D, aref, contact wrenches
-  for (int r = lane; r < NROW; r += G) {
+  // ---------------- P8: constraint rows: D, aref, contact wrenches
+  // friction-loss rows: lane = row; limit rows: lane = dof that owns the limit; contact rows: rc = lane + t G
+  float fl_f = 0.0f, fl_rf = 0.0f;
+  if (lane < nfl) {
+    fl_f = FRL[st.fl_dof]; fl_rf = st.fl_R * fl_f;
+    ED[lane] = st.fl_D;
+    AREF[lane] = -st.fl_b * QVEL[st.fl_dof];
+  }
+  float lim_sgn = 0.0f;
+  if (st.d_lim_on) {
+    const int r = nfl + st.d_limrow;
+    const float qv = QPOS[st.d_qadr];
+    const float dlo = qv - st.d_lo, dhi = st.d_hi - qv;
+    const float pos = fminf(dlo, dhi);
+    lim_sgn = dlo < dhi ? 1.0f : -1.0f;
     float D = 0, aref = 0;
-    if (r < nfl) {
-      const int d = m->fl_dof[r];
-      D = m->fl_D[r];
-      aref = -m->fl_b[r] * QVEL[d];
-    } else if (r < r0c) {
-      const int j = m->lim_jnt[r - nfl];
-      const float qv = QPOS[m->jnt_qposadr[j]];
-      const float dlo = qv - m->jnt_range[j][0], dhi = m->jnt_range[j][1] - qv;
-      const float pos = fminf(dlo, dhi);
-      if (pos < 0) {
-        const float sgn = dlo < dhi ? 1.0f : -1.0f;
-        row_params(m->lim_solref[r - nfl], m->lim_solimp[r - nfl], dt, pos, m->lim_invweight[r - nfl], sgn * QVEL[m->jnt_dofadr[j]], D, aref);
-      }
-    } else {
-      const int rc = r - r0c, c = rc >> 2, s = rc & 3, pair = c >> 2;
-      const float dist = CDIST[c];
-      const float mu = m->pair_mu[pair];
-      const float fs = (s & 1) ? -mu : mu;
-      const float* fr = m->plane_frame;  // pair 2 (foot-foot) frames come with the convex-convex routine
-      const int td = 3 * (1 + (s >> 1));
-      const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
-      const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};
-      float ang[3];
-      cross3(ang, rr, dir);
-      float* wr = W + 6 * rc;
-      wr[0] = ang[0]; wr[1] = ang[1]; wr[2] = ang[2]; wr[3] = dir[0]; wr[4] = dir[1]; wr[5] = dir[2];
-      if (dist < 0) {
-        float vel = 0;
-        const float* v2 = SCR + S::S_SV + (pair == 0 ? 6 : 12);  // geom2's body: left foot for pair 0, right foot otherwise
+    if (pos < 0) row_params(m->lim_solref[st.d_limrow], m->lim_solimp[st.d_limrow], dt, pos, m->lim_invweight[st.d_limrow], lim_sgn * QVEL[lane], D, aref);
+    ED[r] = D; AREF[r] = aref;
+  }
+  for (int rc = lane; rc < S::NCROW; rc += G) {
+    const int r = r0c + rc, c = rc >> 2, s = rc & 3, pair = c >> 2;
+    const float dist = CDIST[c];
+    const float mu = m->pair_mu[pair];
+    const float fs = (s & 1) ? -mu : mu;
+    const float* fr = m->plane_frame;  // pair 2 (foot-foot) frames come with the convex-convex routine
+    const int td = 3 * (1 + (s >> 1));
+    const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
+    const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};
+    float ang[3];
+    cross3(ang, rr, dir);
+    float* wr = W + 6 * rc;
+    wr[0] = ang[0]; wr[1] = ang[1]; wr[2] = ang[2]; wr[3] = dir[0]; wr[4] = dir[1]; wr[5] = dir[2];
+    float D = 0, aref = 0;
+    if (dist < 0) {
+      float vel = 0;
+      const int b2 = m->foot_body[pair == 0 ? 0 : 1];  // geom2's body: left foot for pair 0, right foot otherwise
 #pragma unroll
-        for (int k = 0; k < 6; k++) vel += wr[k] * v2[k];
-        if (pair == 2) {
-          const float* v1 = SCR + S::S_SV + 6;
+      for (int k = 0; k < 6; k++) vel += wr[k] * CVEL[k * NB + b2];
+      if (pair == 2) {
+        const int b1 = m->foot_body[0];
 #pragma unroll
-          for (int k = 0; k < 6; k++) vel -= wr[k] * v1[k];
-        }
-        row_params(m->pair_solref[pair], m->pair_solimp[pair], dt, dist, m->pair_invweight[pair], vel, D, aref);
+        for (int k = 0; k < 6; k++) vel -= wr[k] * CVEL[k * NB + b1];
       }
+      row_params(m->pair_solref[pair], m->pair_solimp[pair], dt, dist, m->pair_invweight[pair], vel, D, aref);
     }
     ED[r] = D;
     AREF[r] = aref;
   }
   ODK_SYNC();
+  ODK_PROF(9);
 
-  ODK_PROF(8);
   // ---------------- P9: Newton solver, one iteration (mjx solver.solve)
-  // helper lambdas -------------------------------------------------------------
-  auto foot_twist = [&](const float* vec) {  // SCR[S_VF + 6 f + k] = sum_{d above foot f} cdof[k][d] vec[d]
-    if (lane < 12) {
-      const int f = lane / 6, k = lane % 6;
-      float s = 0;
-      for (int d = 0; d < NV; d++) s += m->foot_dofmask[f][d] ? CDOF[k * NV + d] * vec[d] : 0.0f;
-      SCR[S::S_VF + lane] = s;
+  const float warm = st.d_on ? WARM[lane] : 0.0f;
+  // foot twists of both candidates: VF = sum_{d above foot} cdof[d] qacc_smooth[d], VF2 likewise for the warmstart.
+  // NOTE: v_readlane (ubcast / bcast) must stay in uniform control flow -- inside a divergent branch the source
+  // lanes may be inactive and hold stale (e.g. un-reloaded spill) registers.
+  {
+    const int which = (lane / 12) & 1, f = (lane / 6) & 1, k = lane % 6;
+    float s = 0;
+#pragma unroll
+    for (int d = 0; d < NV; d++) {
+      const int fm = ubcast(st.d_foot, d);
+      const float vq = bcast<G>(qas, d), vw = bcast<G>(warm, d);
+      if ((fm >> f) & 1) s += CDOF[k * NV + d] * (which ? vw : vq);
     }
-  };
-  auto row_jx = [&](int r, const float* vec) -> float {  // (J vec)[r]; needs foot_twist(vec) + sync
-    if (r < nfl) return vec[m->fl_dof[r]];
-    if (r < r0c) {
-      const int j = m->lim_jnt[r - nfl];
-      const float qv = QPOS[m->jnt_qposadr[j]];
-      const float sgn = (qv - m->jnt_range[j][0]) < (m->jnt_range[j][1] - qv) ? 1.0f : -1.0f;
-      return sgn * vec[m->jnt_dofadr[j]];
-    }
-    const int rc = r - r0c, pair = rc >> 4;
+    if (lane < 24) SCR[(which ? S::S_VF2 : S::S_VF) + 6 * f + k] = s;
+  }
+  // M * warmstart from the register row
+  float ma_w = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NV; j++) ma_w += Mrow[j] * bcast<G>(warm, j);
+  const float gw = st.d_on ? (ma_w - qfs) * (warm - qas) : 0.0f;
+  ODK_SYNC();
+  auto contact_jx = [&](int rc, const float* VF) -> float {
+    const int pair = rc >> 4;
     const float* wr = W + 6 * rc;
-    const float* v2 = SCR + S::S_VF + (pair == 0 ? 0 : 6);
+    const float* v2 = VF + (pair == 0 ? 0 : 6);
     float s = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) s += wr[k] * v2[k];
     if (pair == 2) {
-      const float* v1 = SCR + S::S_VF;
 #pragma unroll
-      for (int k = 0; k < 6; k++) s -= wr[k] * v1[k];
+      for (int k = 0; k < 6; k++) s -= wr[k] * VF[k];
     }
     return s;
   };
-  auto row_cost = [&](int r, float jar, float& force, bool& quad) -> float {
-    const float D = ED[r];
-    if (r < nfl) {
-      const float fl = FRL[m->fl_dof[r]], rf = m->fl_R[r] * fl;
-      if (jar <= -rf) { force = fl; quad = false; return -0.5f * rf * fl - fl * jar; }
-      if (jar >= rf) { force = -fl; quad = false; return -0.5f * rf * fl + fl * jar; }
-      force = -D * jar; quad = true;
-      return 0.5f * D * jar * jar;
-    }
-    if (D > 0 && jar < 0) { force = -D * jar; quad = true; return 0.5f * D * jar * jar; }
-    force = 0; quad = false;
+  auto quad_cost = [](float D, float jar, float& force) -> float {
+    if (D > 0 && jar < 0) { force = -D * jar; return 0.5f * D * jar * jar; }
+    force = 0;
     return 0.0f;
   };
-  auto mul_M = [&](int i, const float* vec) -> float {
-    float s = 0;
-    const int n = m->dof_nsym[i];
-    for (int t = 0; t < n; t++) s += M[m->dof_sym_adr[i][t]] * vec[m->dof_sym_dof[i][t]];
-    return s;
+  auto fl_cost = [&](float jar, float& force) -> float {
+    if (jar <= -fl_rf) { force = fl_f; return -0.5f * fl_rf * fl_f - fl_f * jar; }
+    if (jar >= fl_rf) { force = -fl_f; return -0.5f * fl_rf * fl_f + fl_f * jar; }
+    force = -st.fl_D * jar;
+    return 0.5f * st.fl_D * jar * jar;
   };
-
-  // candidate 1: qacc_smooth (Ma = qfrc_smooth, gauss = 0)
-  foot_twist(QAS);
-  ODK_SYNC();
-  float cost_s = 0;
-  for (int r = lane; r < NROW; r += G) {
-    if (ED[r] == 0.0f && r >= nfl) { JAR[r] = 0; continue; }
-    const float jar = row_jx(r, QAS) - AREF[r];
-    JAR[r] = jar;
-    float fo; bool qd;
-    cost_s += row_cost(r, jar, fo, qd);
+  // Jaref and cost of both candidates; rows owned by this lane: friction row `lane`, limit row of dof `lane`, contact rows
+  float cost_s = 0, cost_w = 0, jar_fl_s = 0, jar_fl_w = 0, jar_lim_s = 0, jar_lim_w = 0, fo;
+  if (lane < nfl) {
+    const float ar = AREF[lane];
+    jar_fl_s = QAS[st.fl_dof] - ar; jar_fl_w = WARM[st.fl_dof] - ar;
+    cost_s += fl_cost(jar_fl_s, fo); cost_w += fl_cost(jar_fl_w, fo);
+  }
+  float lim_D = 0.0f;
+  if (st.d_lim_on) {
+    const int r = nfl + st.d_limrow;
+    lim_D = ED[r];
+    const float ar = AREF[r];
+    jar_lim_s = lim_sgn * qas - ar; jar_lim_w = lim_sgn * warm - ar;
+    cost_s += quad_cost(lim_D, jar_lim_s, fo); cost_w += quad_cost(lim_D, jar_lim_w, fo);
+  }
+  for (int rc = lane; rc < S::NCROW; rc += G) {
+    const int r = r0c + rc;
+    const float D = ED[r];
+    float js = 0, jw = 0;
+    if (D > 0) {
+      const float ar = AREF[r];
+      js = contact_jx(rc, SCR + S::S_VF) - ar; jw = contact_jx(rc, SCR + S::S_VF2) - ar;
+      cost_s += quad_cost(D, js, fo); cost_w += quad_cost(D, jw, fo);
+    }
+    JAR[r] = js; JV[r] = jw;
   }
   cost_s = gsum<G>(cost_s);
-  ODK_SYNC();
-  // candidate 2: warmstart
-  foot_twist(WARM);
-  float gw = 0;
-  if (lane < NV) {
-    const float ma = mul_M(lane, WARM);
-    MV[lane] = ma;
-    gw = (ma - QFS[lane]) * (WARM[lane] - QAS[lane]);
-  }
-  ODK_SYNC();
-  float cost_w = 0;
-  for (int r = lane; r < NROW; r += G) {
-    if (ED[r] == 0.0f && r >= nfl) { JV[r] = 0; continue; }
-    const float jar = row_jx(r, WARM) - AREF[r];
-    JV[r] = jar;
-    float fo; bool qd;
-    cost_w += row_cost(r, jar, fo, qd);
-  }
-  cost_w = gsum<G>(cost_w) + 0.5f * gsum<G>(gw);
+  const float gauss_w = 0.5f * gsum<G>(gw);
+  cost_w = gsum<G>(cost_w) + gauss_w;
   const bool use_warm = cost_w < cost_s;
-  float gauss = use_warm ? 0.5f * gsum<G>(gw) : 0.0f;
+  const float gauss = use_warm ? gauss_w : 0.0f;
+  const float x = use_warm ? warm : qas;
+  const float ma = use_warm ? ma_w : qfs;
+  const float jar_fl = use_warm ? jar_fl_w : jar_fl_s, jar_lim = use_warm ? jar_lim_w : jar_lim_s;
   ODK_SYNC();
-  if (lane < NV) {
-    X[lane] = use_warm ? WARM[lane] : QAS[lane];
-    MA[lane] = use_warm ? MV[lane] : QFS[lane];
+  if (use_warm) for (int rc = lane; rc < S::NCROW; rc += G) JAR[r0c + rc] = JV[r0c + rc];
+  ODK_SYNC();
+  ODK_PROF(10);
+  // forces of the chosen point: friction / limit rows stay in registers, contact forces -> JV
+  float f_fl = 0, f_lim = 0;
+  bool quad_fl = false;
+  if (lane < nfl) { fl_cost(jar_fl, f_fl); quad_fl = (jar_fl > -fl_rf) && (jar_fl < fl_rf); }
+  if (st.d_lim_on) quad_cost(lim_D, jar_lim, f_lim);
+  for (int rc = lane; rc < S::NCROW; rc += G) {
+    const int r = r0c + rc;
+    float fo2;
+    quad_cost(ED[r], JAR[r], fo2);
+    JV[r] = fo2;
   }
-  if (use_warm) for (int r = lane; r < NROW; r += G) JAR[r] = JV[r];
+  // friction-row quantities are owned by lane = row; the dof that needs them is another lane: hand over through LDS
+  if (lane < nfl) { MV[st.fl_dof] = f_fl; MA[st.fl_dof] = quad_fl ? st.fl_D : 0.0f; }
   ODK_SYNC();
-  ODK_PROF(9);
-  // forces of the chosen point -> JV (scratch), foot wrench sums, gradient
-  for (int r = lane; r < NROW; r += G) {
-    float fo = 0; bool qd = false;
-    if (!(ED[r] == 0.0f && r >= nfl)) row_cost(r, JAR[r], fo, qd);
-    JV[r] = fo;
-    // mark rows that enter the Hessian by the sign bit trick: keep a separate flag in W? use AREF sign? -> store in MV-free slot below
-  }
-  ODK_SYNC();
+  const bool c_act[3] = {fminf(fminf(CDIST[0], CDIST[1]), fminf(CDIST[2], CDIST[3])) < 0, fminf(fminf(CDIST[4], CDIST[5]), fminf(CDIST[6], CDIST[7])) < 0,
+                         fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0};
   if (lane < 12) {  // FF[f][k] = sum over the foot's contact rows of w_r[k] f_r   (pair 2: +right, -left)
     const int f = lane / 6, k = lane % 6;
     float s = 0;
-    const int rb = 16 * f;
-    for (int rc = rb; rc < rb + 16; rc++) s += W[6 * rc + k] * JV[r0c + rc];
-    for (int rc = 32; rc < 48; rc++) s += (f ? 1.0f : -1.0f) * W[6 * rc + k] * JV[r0c + rc];
+    if (c_act[f]) for (int rc = 16 * f; rc < 16 * f + 16; rc++) s += W[6 * rc + k] * JV[r0c + rc];
+    if (c_act[2]) for (int rc = 32; rc < 48; rc++) s += (f ? 1.0f : -1.0f) * W[6 * rc + k] * JV[r0c + rc];
     SCR[S::S_FF + lane] = s;
   }
-  // K blocks: K_f[a][b] = sum_r D_r [quad] w_r[a] w_r[b]; rows of pair 2 add to both feet and form K_X
+  // K blocks: K_f[a][b] = sum_r D_r [active] w_r[a] w_r[b]; rows of pair 2 add to both feet and form K_X
   for (int t = lane; t < 108; t += G) {
     const int blk = t / 36, a = (t % 36) / 6, b2 = t % 6;
     float s = 0;
-    if (blk < 2) {
+    if (blk < 2 && c_act[blk]) {
       for (int rc = 16 * blk; rc < 16 * blk + 16; rc++) {
         const int r = r0c + rc;
         const float act = (ED[r] > 0 && JAR[r] < 0) ? ED[r] : 0.0f;
@@ -755,133 +915,161 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
       }
     }
     float sx = 0;
-    for (int rc = 32; rc < 48; rc++) {
-      const int r = r0c + rc;
-      const float act = (ED[r] > 0 && JAR[r] < 0) ? ED[r] : 0.0f;
-      sx += act * W[6 * rc + a] * W[6 * rc + b2];
+    if (c_act[2]) {
+      for (int rc = 32; rc < 48; rc++) {
+        const int r = r0c + rc;
+        const float act = (ED[r] > 0 && JAR[r] < 0) ? ED[r] : 0.0f;
+        sx += act * W[6 * rc + a] * W[6 * rc + b2];
+      }
     }
     SCR[S::S_K + t] = (blk < 2) ? s + sx : sx;
   }
   ODK_SYNC();
-  const bool ff_active = SCR[S::S_K + 72 + 21] != 0.0f || SCR[S::S_K + 72 + 28] != 0.0f || SCR[S::S_K + 72 + 35] != 0.0f;  // diag(lin) of K_X
-  if (lane < NV) {
+  const bool ff_active = c_act[2] && (SCR[S::S_K + 72 + 21] != 0.0f || SCR[S::S_K + 72 + 28] != 0.0f || SCR[S::S_K + 72 + 35] != 0.0f);
+  float grad = 0.0f;
+  if (st.d_on) {
     const int i = lane;
-    float qc = 0;
-    const int rf = m->dof_flrow[i], rl = m->dof_limrow[i];
-    if (rf >= 0) qc += JV[rf];
-    if (rl >= 0 && ED[nfl + rl] > 0) {
-      const int j = m->lim_jnt[rl];
-      const float qv = QPOS[m->jnt_qposadr[j]];
-      const float sgn = (qv - m->jnt_range[j][0]) < (m->jnt_range[j][1] - qv) ? 1.0f : -1.0f;
-      qc += sgn * JV[nfl + rl];
-    }
+    float qc = 0, hdiag_extra = 0.0f;
+    if (st.d_flrow >= 0) { qc += MV[i]; hdiag_extra += MA[i]; }
+    if (st.d_lim_on) { qc += lim_sgn * f_lim; if (lim_D > 0 && jar_lim < 0) hdiag_extra += lim_D; }
     float cd[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) cd[k] = CDOF[k * NV + i];
+#pragma unroll
     for (int f = 0; f < 2; f++)
-      if (m->foot_dofmask[f][i]) {
+      if ((st.d_foot >> f) & 1) {
 #pragma unroll
         for (int k = 0; k < 6; k++) qc += cd[k] * SCR[S::S_FF + 6 * f + k];
       }
-    GRAD[i] = MA[i] - QFS[i] - qc;
+    grad = ma - qfs - qc;
     // T_f[i] = K_f cdof[i]
+#pragma unroll
     for (int f = 0; f < 2; f++) {
-      float* T = f ? (BODY) : (BUF6);
-      const int stride = NV;
+      float* T = f ? BUF6B : BUF6;
+      const bool on = ((st.d_foot >> f) & 1) && (c_act[f] || c_act[2]);
 #pragma unroll
       for (int a = 0; a < 6; a++) {
         float s = 0;
-        if (m->foot_dofmask[f][i]) {
+        if (on) {
 #pragma unroll
           for (int b2 = 0; b2 < 6; b2++) s += SCR[S::S_K + 36 * f + 6 * a + b2] * cd[b2];
         }
-        T[a * stride + i] = s;
+        T[a * NV + i] = s;
       }
     }
-  }
-  ODK_SYNC();
-  ODK_PROF(10);
-  // Hessian entries on the virtual-tree layout
-  for (int p = lane; p < NH; p += G) {
-    const int i = m->H_i[p], j = m->H_j[p], src = m->H_src[p];
-    float v = src >= 0 ? M[src] : 0.0f;
-    if (i == j) {
-      const int rf = m->dof_flrow[i], rl = m->dof_limrow[i];
-      if (rf >= 0) { const float fl = FRL[i], rfv = m->fl_R[rf] * fl, jar = JAR[rf]; if (jar > -rfv && jar < rfv) v += ED[rf]; }
-      if (rl >= 0 && ED[nfl + rl] > 0 && JAR[nfl + rl] < 0) v += ED[nfl + rl];
-    }
-    float cj[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NV + j];
-    const int mLi = m->foot_dofmask[0][i], mLj = m->foot_dofmask[0][j], mRi = m->foot_dofmask[1][i], mRj = m->foot_dofmask[1][j];
-    if (mLi && mLj) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) v += cj[k] * BUF6[k * NV + i];
-    }
-    if (mRi && mRj) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) v += cj[k] * BODY[k * NV + i];
-    }
-    if (ff_active) {  // cross terms -(A_R^T K_X A_L + A_L^T K_X A_R); rare
-      const float wgt = (float)(mRi && mLj) + (float)(mLi && mRj);
-      if (wgt != 0.0f) {
-        float ci[6], s = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) ci[k] = CDOF[k * NV + i];
-        for (int a = 0; a < 6; a++)
-          for (int b2 = 0; b2 < 6; b2++) s += ci[a] * SCR[S::S_K + 72 + 6 * a + b2] * cj[b2];
-        v -= wgt * s;
-      }
-    }
-    HL[p] = v;
+    JV[i] = hdiag_extra;  // JV[0..NV) lies below the contact rows: free scratch for the per-dof diagonal addend
   }
   ODK_SYNC();
   ODK_PROF(11);
-  factor_ld<G>(HL, NV, m->vdof_depth, m->vdof_Madr, m->vdof_anc_adr, m->tri_m, m->tri_q, lane);
-  ODK_PROF(16);
-  solve_ld<G>(HL, GRAD, NV, m->vdof_depth, m->vdof_Madr, m->vdof_anc, m->vdof_ndesc, m->vdof_desc, m->vdof_desc_adr, lane);
-  if (lane < NV) GRAD[lane] = -GRAD[lane];  // search = -H^-1 grad
-  ODK_SYNC();
-
-  ODK_PROF(12);
-  // ---- line search (mjx solver._linesearch)
-  foot_twist(GRAD);
-  float sn = 0, qg1 = 0, qg2 = 0;
-  if (lane < NV) {
-    const float s = GRAD[lane], mv = mul_M(lane, GRAD);
-    MV[lane] = mv;
-    sn = s * s;
-    qg1 = s * MA[lane] - s * QFS[lane];
-    qg2 = 0.5f * s * mv;
+  // Hessian entries on the virtual-tree layout
+#pragma unroll
+  for (int t = 0; t < ST::NHE; t++) {
+    const int e = st.hent[t];
+    if (e >= 0) {
+      const int i = e & 31, j = (e >> 5) & 31, fi = (e >> 10) & 3, fj = (e >> 12) & 3, src = (e >> 14) - 1;
+      float v = src >= 0 ? M[src] : 0.0f;
+      if (i == j) v += JV[i];
+      const int both = fi & fj;
+      if (both) {
+        float cj[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NV + j];
+        if (both & 1) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) v += cj[k] * BUF6[k * NV + i];
+        }
+        if (both & 2) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) v += cj[k] * BUF6B[k * NV + i];
+        }
+      }
+      if (ff_active) {  // cross terms -(A_R^T K_X A_L + A_L^T K_X A_R); rare
+        const float wgt = (float)(((fi >> 1) & 1) && (fj & 1)) + (float)((fi & 1) && ((fj >> 1) & 1));
+        if (wgt != 0.0f) {
+          float s = 0;
+          for (int a = 0; a < 6; a++)
+            for (int b2 = 0; b2 < 6; b2++) s += CDOF[a * NV + i] * SCR[S::S_K + 72 + 6 * a + b2] * CDOF[b2 * NV + j];
+          v -= wgt * s;
+        }
+      }
+      HL[lane + t * G] = v;
+    }
   }
+  ODK_SYNC();
+  if (st.d_on) MA[lane] = grad;  // kept for the debug image (gradient at the starting point)
+  ODK_PROF(12);
+  factor_rows<G, S::DV, NV>(HL, lane, st.d_on, st.d_vdepth, st.d_vMadr, st.d_vdescmask, st.d_vdepth, st.d_vMadr);
+  ODK_PROF(13);
+  const float search = -solve_rows<G, NV>(HL, grad, lane, st.d_on, st.d_vdepth, st.d_vMadr, st.d_vancmask, st.d_vdescmask, st.d_vdepth, st.d_vMadr);
+  ODK_PROF(14);
+
+  // ---- line search (mjx solver._linesearch)
+  if (st.d_on) GRAD[lane] = search;
+  float mv = 0.0f;
+#pragma unroll
+  for (int j = 0; j < NV; j++) mv += Mrow[j] * bcast<G>(search, j);
+  float sn = st.d_on ? search * search : 0.0f, qg1 = st.d_on ? search * (ma - qfs) : 0.0f, qg2 = st.d_on ? 0.5f * search * mv : 0.0f;
   sn = gsum<G>(sn); qg1 = gsum<G>(qg1); qg2 = gsum<G>(qg2);
   ODK_SYNC();
-  for (int r = lane; r < NROW; r += G) JV[r] = (ED[r] == 0.0f && r >= nfl) ? 0.0f : row_jx(r, GRAD);
+  {  // foot twists of the search direction, straight from registers
+    const int f = (lane / 6) & 1, k = lane % 6;
+    float s = 0;
+#pragma unroll
+    for (int d = 0; d < NV; d++) {
+      const int fm = ubcast(st.d_foot, d);
+      const float sd = bcast<G>(search, d);
+      if ((fm >> f) & 1) s += CDOF[k * NV + d] * sd;
+    }
+    if (lane < 12) SCR[S::S_VF + lane] = s;
+  }
   ODK_SYNC();
-  ODK_PROF(13);
+  float jv_fl = 0, jv_lim = 0;
+  if (lane < nfl) jv_fl = GRAD[st.fl_dof];
+  if (st.d_lim_on) jv_lim = lim_sgn * search;
+  // contact rows of this lane in registers for the line search
+  constexpr int NCL = (S::NCROW + G - 1) / G;
+  float cD[NCL], cjar[NCL], cjv[NCL];
+#pragma unroll
+  for (int t = 0; t < NCL; t++) {
+    const int rc = lane + t * G;
+    const bool on = rc < S::NCROW;
+    cD[t] = on ? ED[r0c + rc] : 0.0f;
+    cjar[t] = on ? JAR[r0c + rc] : 0.0f;
+    cjv[t] = (on && cD[t] > 0) ? contact_jx(rc, SCR + S::S_VF) : 0.0f;
+    if (on) JV[r0c + rc] = cjv[t];  // debug image only
+  }
+  ODK_PROF(15);
   const float gtol = m->tolerance * m->ls_tolerance * sqrtf(sn) * m->meaninertia * (float)(NV > 1 ? NV : 1);
   // evaluate up to three step sizes at once: cost, first and second derivative along the search
   auto ls_eval3 = [&](const float* al, float* cost, float* d0, float* d1) {
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r = lane; r < NROW; r += G) {
-      const float D = ED[r];
-      if (D == 0.0f && r >= nfl) continue;
-      const float jar = JAR[r], jv = JV[r];
+    if (lane < nfl) {
+      const float D = st.fl_D, jar = jar_fl, jv = jv_fl;
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
-      if (r < nfl) {
-        const float fl = FRL[m->fl_dof[r]], rf = m->fl_R[r] * fl;
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-          const float x = jar + al[a] * jv;
-          if (x <= -rf) { acc[3 * a] += fl * (-0.5f * rf - jar); acc[3 * a + 1] += -fl * jv; }
-          else if (x >= rf) { acc[3 * a] += fl * (-0.5f * rf + jar); acc[3 * a + 1] += fl * jv; }
-          else { acc[3 * a] += q0; acc[3 * a + 1] += q1; acc[3 * a + 2] += q2; }
-        }
-      } else {
+      for (int a = 0; a < 3; a++) {
+        const float xx = jar + al[a] * jv;
+        if (xx <= -fl_rf) { acc[3 * a] += fl_f * (-0.5f * fl_rf - jar); acc[3 * a + 1] += -fl_f * jv; }
+        else if (xx >= fl_rf) { acc[3 * a] += fl_f * (-0.5f * fl_rf + jar); acc[3 * a + 1] += fl_f * jv; }
+        else { acc[3 * a] += q0; acc[3 * a + 1] += q1; acc[3 * a + 2] += q2; }
+      }
+    }
+    if (lim_D > 0) {
+      const float D = lim_D, jar = jar_lim, jv = jv_lim;
+      const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
+      for (int a = 0; a < 3; a++)
+        if (jar + al[a] * jv < 0) { acc[3 * a] += q0; acc[3 * a + 1] += q1; acc[3 * a + 2] += q2; }
+    }
+#pragma unroll
+    for (int t = 0; t < NCL; t++) {
+      const float D = cD[t];
+      if (D > 0) {
+        const float jar = cjar[t], jv = cjv[t];
+        const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
           if (jar + al[a] * jv < 0) { acc[3 * a] += q0; acc[3 * a + 1] += q1; acc[3 * a + 2] += q2; }
-        }
       }
     }
 #pragma unroll
@@ -926,29 +1114,32 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
   }
   const bool improved = (lo_c < p0_cost) || (hi_c < p0_cost);
   const float alpha = improved ? (lo_c < hi_c ? lo_a : hi_a) : 0.0f;
-  if (lane < NV) {
-    const float xa = X[lane] + alpha * GRAD[lane];
+  if (st.d_on) {
+    const float xa = x + alpha * search;
     X[lane] = xa;
     WARM[lane] = xa;
   }
+  if (lane == 0) { SCR[S::S_MISC + 13] = qg1; SCR[S::S_MISC + 14] = qg2; SCR[S::S_MISC + 15] = gauss; }
+  if (lane == 0) { SCR[S::S_MISC + 4] = p0_d0; SCR[S::S_MISC + 5] = p0_d1; SCR[S::S_MISC + 6] = p0_cost; SCR[S::S_MISC + 7] = gtol; }
   if (lane == 0) { SCR[S::S_MISC + 1] = alpha; SCR[S::S_MISC + 2] = use_warm ? 1.0f : 0.0f; SCR[S::S_MISC + 3] = use_warm ? cost_w : cost_s; }
   ODK_SYNC();
+  ODK_PROF(16);
 
-  ODK_PROF(14);
   // ---------------- P10: sensors (lane = sensor), only when requested
   if (flags & 1) {
     if (lane < m->nsensor) {
       const int s = lane, site = m->sensor_site[s], b = m->site_body[site], type = m->sensor_type[s];
-      float R[9], Rs[9], sp[3], dif[3];
-      for (int k = 0; k < 9; k++) R[k] = XMAT[k * NB + b];
+      float R[9], Rs[9], sp[3], dif[3], qb[4];
+      for (int k = 0; k < 4; k++) qb[k] = XQUAT[k * NB + b];
+      q2mat(R, qb);
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) Rs[3 * i + j] = R[3 * i] * m->site_mat[site][j] + R[3 * i + 1] * m->site_mat[site][3 + j] + R[3 * i + 2] * m->site_mat[site][6 + j];
       for (int k = 0; k < 3; k++) {
         sp[k] = XPOS[k * NB + b] + R[3 * k] * m->site_pos[site][0] + R[3 * k + 1] * m->site_pos[site][1] + R[3 * k + 2] * m->site_pos[site][2];
         dif[k] = sp[k] - ref[k];
       }
-      const int slot = (b == m->base_body) ? 0 : (b == m->foot_body[0] ? 1 : 2);
-      const float* cv = SCR + S::S_SV + 6 * slot;
+      float cv[6];
+      for (int k = 0; k < 6; k++) cv[k] = CVEL[k * NB + b];
       float vang[3] = {cv[0], cv[1], cv[2]}, t[3], vlin[3];
       cross3(t, dif, vang);
       vlin[0] = cv[3] - t[0]; vlin[1] = cv[4] - t[1]; vlin[2] = cv[5] - t[2];
@@ -962,7 +1153,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
       else if (type == 1) tmul(out, vlin);
       else if (type == 2) {  // accelerometer: site is on the floating base (asserted at load)
         float ca[6];
-        for (int k = 0; k < 6; k++) ca[k] = SCR[S::S_CA + k];
+        for (int k = 0; k < 6; k++) ca[k] = CACC[k * NB + b];
         for (int d = 0; d < 6; d++) {
           const float qa = X[d];
           for (int k = 0; k < 6; k++) ca[k] += CDOF[k * NV + d] * qa;
@@ -978,9 +1169,8 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
       else if (type == 5) { out[0] = vlin[0]; out[1] = vlin[1]; out[2] = vlin[2]; }
       else if (type == 6) { out[0] = vang[0]; out[1] = vang[1]; out[2] = vang[2]; }
       else if (type == 7) { out[0] = sp[0]; out[1] = sp[1]; out[2] = sp[2]; }
-      else if (type == 8) {  // framequat on the base: qpos quaternion times site quaternion
-        float qb[4] = {QPOS[3], QPOS[4], QPOS[5], QPOS[6]}, qs[4];
-        qnormalize(qb);
+      else if (type == 8) {  // framequat: body quaternion times site quaternion
+        float qs[4];
         qmul(qs, qb, m->site_quat[site]);
         qnormalize(qs);
         out[0] = qs[0]; out[1] = qs[1]; out[2] = qs[2]; out[3] = qs[3];
@@ -989,12 +1179,18 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
     // feet site heights + imu site rotation for the env logic
     if (lane < 2) {
       const int site = m->site_feet[lane], b = m->site_body[site];
-      SCR[S::S_MISC + 8 + lane] = XPOS[2 * NB + b] + XMAT[6 * NB + b] * m->site_pos[site][0] + XMAT[7 * NB + b] * m->site_pos[site][1] + XMAT[8 * NB + b] * m->site_pos[site][2];
+      float qb[4], R[9];
+      for (int k = 0; k < 4; k++) qb[k] = XQUAT[k * NB + b];
+      q2mat(R, qb);
+      SCR[S::S_MISC + 8 + lane] = XPOS[2 * NB + b] + R[6] * m->site_pos[site][0] + R[7] * m->site_pos[site][1] + R[8] * m->site_pos[site][2];
     }
     if (lane >= 2 && lane < 5) {  // gravity = site_xmat[imu]^T (0,0,-1) = -(third row of the site rotation)
       const int site = m->site_imu, b = m->site_body[site], c = lane - 2;
+      float qb[4], R[9];
+      for (int k = 0; k < 4; k++) qb[k] = XQUAT[k * NB + b];
+      q2mat(R, qb);
       float v = 0;
-      for (int k = 0; k < 3; k++) v += XMAT[(6 + k) * NB + b] * m->site_mat[site][3 * k + c];
+      for (int k = 0; k < 3; k++) v += R[6 + k] * m->site_mat[site][3 * k + c];
       SCR[S::S_MISC + 10 + c] = -v;
     }
     ODK_SYNC();
@@ -1004,27 +1200,24 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
 
 // mjx forward.euler (eulerdamp disabled): qvel += dt qacc; qpos integrated with the NEW qvel
 template <class S, int G>
-__device__ void euler_env(float* __restrict__ L, const DevModel* __restrict__ m, int lane) {
+__device__ void euler_env(float* __restrict__ L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane) {
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; const float* X = L + S::O_X;
   const float dt = m->dt;
   if (lane < S::NV) QVEL[lane] += dt * X[lane];
   ODK_SYNC();
-  if (lane < m->nj) {
-    const int j = lane;
-    if (j == 0) {
-      for (int k = 0; k < 3; k++) QPOS[k] += dt * QVEL[k];
-      float w[3] = {QVEL[3], QVEL[4], QVEL[5]};
-      float n = sqrtf(dot3(w, w));
-      if (n < MINVAL_F) { w[0] = 1; w[1] = 0; w[2] = 0; n = 0; } else { const float inv = 1.0f / n; w[0] *= inv; w[1] *= inv; w[2] *= inv; }
-      float s, co;
-      sincosf(0.5f * dt * n, &s, &co);
-      float qr[4] = {co, s * w[0], s * w[1], s * w[2]}, q0[4] = {QPOS[3], QPOS[4], QPOS[5], QPOS[6]}, res[4];
-      qmul(res, q0, qr);
-      qnormalize(res);
-      QPOS[3] = res[0]; QPOS[4] = res[1]; QPOS[5] = res[2]; QPOS[6] = res[3];
-    } else {
-      QPOS[m->jnt_qposadr[j]] += dt * QVEL[m->jnt_dofadr[j]];
-    }
+  if (lane == 0) {
+    for (int k = 0; k < 3; k++) QPOS[k] += dt * QVEL[k];
+    float w[3] = {QVEL[3], QVEL[4], QVEL[5]};
+    float n = sqrtf(dot3(w, w));
+    if (n < MINVAL_F) { w[0] = 1; w[1] = 0; w[2] = 0; n = 0; } else { const float inv = 1.0f / n; w[0] *= inv; w[1] *= inv; w[2] *= inv; }
+    float s, co;
+    sincosf(0.5f * dt * n, &s, &co);
+    float qr[4] = {co, s * w[0], s * w[1], s * w[2]}, q0[4] = {QPOS[3], QPOS[4], QPOS[5], QPOS[6]}, res[4];
+    qmul(res, q0, qr);
+    qnormalize(res);
+    QPOS[3] = res[0]; QPOS[4] = res[1]; QPOS[5] = res[2]; QPOS[6] = res[3];
+  } else if (st.j_qadr >= 0) {
+    QPOS[st.j_qadr] += dt * QVEL[st.j_dadr];
   }
   ODK_SYNC();
 }

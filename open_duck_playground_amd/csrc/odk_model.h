@@ -25,6 +25,7 @@ struct DevModel {
   int ls_iterations, iterations;
   // bodies
   int base_body, body_in_tree[MAXB], body_parent[MAXB], body_jntadr[MAXB], body_jntnum[MAXB];
+  int max_level, body_level[MAXB], body_children[MAXB][3], body_nchild[MAXB];
   int body_chain[MAXB][MAXCHAIN], body_chain_len[MAXB];
   int body_ancdof[MAXB][MAXV], body_nancdof[MAXB];
   int body_sub[MAXB][MAXB], body_nsub[MAXB];
@@ -38,6 +39,9 @@ struct DevModel {
   int dof_nprefix[MAXV], dof_prefix[MAXV][MAXV];
   int dof_nsym[MAXV], dof_sym_dof[MAXV][MAXV], dof_sym_adr[MAXV][MAXV];
   int dof_act[MAXV], dof_flrow[MAXV], dof_limrow[MAXV];
+  int dof_ancmask[MAXV], dof_descmask[MAXV], vdof_ancmask[MAXV], vdof_descmask[MAXV];
+  int dof_qadr[MAXV], dof_jnt[MAXV];   // hinge dofs: qpos address / joint id (-1 for the free joint)
+  float dof_range[MAXV][2];
   float dof_armature[MAXV], dof_damping[MAXV], dof_frictionloss[MAXV], dof_invweight0[MAXV];
   int M_i[MAXNZ], M_j[MAXNZ];
   // virtual tree (Hessian)

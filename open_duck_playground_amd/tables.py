@@ -48,10 +48,17 @@ def _sparse_layout(parent: np.ndarray):
         adr[i] = n
         n += depth[i] + 1
     ei, ej = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    # depth-indexed rows: entry c of row i is the column of i's ancestor at depth c (c = depth[i] is the diagonal)
+    ancd = -np.ones((nv, MAXV), np.int32)
+    ancmask = np.zeros(nv, np.int64); descmask = np.zeros(nv, np.int64)
     for i in range(nv):
         for k in range(depth[i] + 1):
-            ei[adr[i] + k] = i
-            ej[adr[i] + k] = anc[i, k]
+            c = depth[i] - k
+            ei[adr[i] + c] = i
+            ej[adr[i] + c] = anc[i, k]
+            ancd[i, c] = anc[i, k]
+            if k > 0:
+                ancmask[i] |= (1 << int(anc[i, k])); descmask[anc[i, k]] |= (1 << i)
     # descendants: for column j, every row k>j with j in anc(k), plus the address of entry (k, j)
     ndesc = np.zeros(nv, np.int32)
     desc = -np.ones((nv, MAXV), np.int32)
@@ -60,14 +67,16 @@ def _sparse_layout(parent: np.ndarray):
         for q in range(1, depth[k] + 1):
             j = anc[k, q]
             desc[j, ndesc[j]] = k
-            desc_adr[j, ndesc[j]] = adr[k] + q
+            desc_adr[j, ndesc[j]] = adr[k] + depth[j]
             ndesc[j] += 1
     # per-step ancestor row addresses for the factorisation: anc_adr[k, m] = adr[anc_m(k)]
     anc_adr = -np.ones((nv, MAXV), np.int32)
     for k in range(nv):
         for q in range(depth[k] + 1):
             anc_adr[k, q] = adr[anc[k, q]]
-    return dict(anc=anc, depth=depth, adr=adr, nnz=n, ei=ei, ej=ej, ndesc=ndesc, desc=desc, desc_adr=desc_adr, anc_adr=anc_adr)
+    to_i32 = lambda v: np.array([int(x) - (1 << 32) if int(x) >= (1 << 31) else int(x) for x in v], np.int32)
+    return dict(anc=anc, depth=depth, adr=adr, nnz=n, ei=ei, ej=ej, ndesc=ndesc, desc=desc, desc_adr=desc_adr, anc_adr=anc_adr,
+                ancd=ancd, ancmask=to_i32(ancmask), descmask=to_i32(descmask))
 
 
 def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
@@ -111,6 +120,17 @@ def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
         lst.reverse()
         ancdof[b, :len(lst)] = lst; nancdof[b] = len(lst)
     out["k_body_ancdof"] = ancdof; out["k_body_nancdof"] = nancdof
+    level = -np.ones(nb, np.int32); children = -np.ones((nb, 3), np.int32); nchild = np.zeros(nb, np.int32)
+    for b in range(nb):
+        if in_tree[b]:
+            level[b] = chain_len[b]
+            if b != base:
+                p_ = bparent[b]
+                if nchild[p_] >= 3:
+                    raise ValueError("more than three child bodies")
+                children[p_, nchild[p_]] = b; nchild[p_] += 1
+    out["k_body_level"] = level; out["k_body_children"] = children; out["k_body_nchild"] = nchild
+    out["k_max_level"] = I([int(level.max())])
     sub = -np.ones((nb, MAXB), np.int32); nsub = np.zeros(nb, np.int32)
     for c in range(1, nb):
         b = c
@@ -125,6 +145,7 @@ def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     out["k_nM"] = I([true["nnz"]]); out["k_M_i"] = true["ei"]; out["k_M_j"] = true["ej"]
     out["k_dof_ndesc"] = true["ndesc"]; out["k_dof_desc"] = true["desc"]; out["k_dof_desc_adr"] = true["desc_adr"]
     out["k_dof_anc_adr"] = true["anc_adr"]
+    out["k_dof_ancmask"] = true["ancmask"]; out["k_dof_descmask"] = true["descmask"]
     # velocity prefix (mj_comVel): strict ancestors, except that the free joint's rotational dofs
     # see only its three translational dofs
     prefix = -np.ones((nv, MAXV), np.int32); nprefix = np.zeros(nv, np.int32)
@@ -204,6 +225,7 @@ def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     out["k_nH"] = I([virt["nnz"]]); out["k_H_i"] = virt["ei"]; out["k_H_j"] = virt["ej"]
     out["k_vdof_ndesc"] = virt["ndesc"]; out["k_vdof_desc"] = virt["desc"]; out["k_vdof_desc_adr"] = virt["desc_adr"]
     out["k_vdof_anc_adr"] = virt["anc_adr"]
+    out["k_vdof_ancmask"] = virt["ancmask"]; out["k_vdof_descmask"] = virt["descmask"]
     # source address in the true M for every H entry (-1 where M is structurally zero)
     src = -np.ones(virt["nnz"], np.int32)
     lookup = {(int(i), int(j)): p for p, (i, j) in enumerate(zip(true["ei"], true["ej"]))}
