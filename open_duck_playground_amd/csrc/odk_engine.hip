@@ -79,7 +79,7 @@ __device__ __forceinline__ float nan_to_num(float x) {
 
 // effective per-env model parameters -> LDS
 template <class S, int G>
-__device__ void load_params(float* L, const DevModel* m, const float* dr, int lane) {
+__device__ __forceinline__ void load_params(float* L, const DevModel* m, const float* dr, int lane) {
   for (int i = lane; i < S::NQ; i += G) L[S::O_Q0 + i] = m->qpos0[i];
   for (int i = lane; i < S::NB; i += G) L[S::O_MASS + i] = dr ? dr[DRL<S>::MASS + i] : m->body_mass[i];
   for (int i = lane; i < S::NV; i += G) { L[S::O_ARM + i] = m->dof_armature[i]; L[S::O_FRL + i] = m->dof_frictionloss[i]; }
@@ -104,7 +104,7 @@ __device__ inline int prm_nearest(const float* grid, int n, float v) {
   return best;
 }
 template <int G>
-__device__ void prm_eval(const DevPRM* p, const float* table, float dx, float dy, float dth, int i, float* out, int lane) {
+__device__ __forceinline__ void prm_eval(const DevPRM* p, const float* table, float dx, float dy, float dth, int i, float* out, int lane) {
   const float x = fminf(fmaxf(dx, p->ranges[0]), p->ranges[1]);
   const float y = fminf(fmaxf(dy, p->ranges[2]), p->ranges[3]);
   const float t3 = fminf(fmaxf(dth, p->ranges[4]), p->ranges[5]);
@@ -129,7 +129,7 @@ __device__ inline void sample_command(const EnvCfg& c, uint32_t k0, uint32_t k1,
 
 // _get_obs (joystick.py:487-620): builds privileged_state[212] (whose first 101 entries are `state`) in LDS
 template <class S, int G>
-__device__ void build_obs(float* L, const DevModel* m, const EnvCfg& c, const float* contact, uint32_t k0, uint32_t k1, uint32_t ctr,
+__device__ __forceinline__ void build_obs(float* L, const DevModel* m, const EnvCfg& c, const float* contact, uint32_t k0, uint32_t k1, uint32_t ctr,
                           int imitation_i, const float* phase, int lane) {
   using E = EnvL<S>;
   float* P = L + E::O_PRIV; float* INFO = L + E::O_INFO; const float* SENS = L + S::O_SENS; const float* SCR = L + S::O_SCR;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void foot_contact_flags(const float* CDIST, float* co
 }
 
 template <class S, int G>
-__device__ void write_outputs(const KArgs& a, const float* L, int env, float reward, float done, float trunc, const float* metrics, int lane) {
+__device__ __forceinline__ void write_outputs(const KArgs& a, const float* L, int env, float reward, float done, float trunc, const float* metrics, int lane) {
   using E = EnvL<S>;
   const float* P = L + E::O_PRIV;
   if (a.obs) for (int k = lane; k < ODK_NOBS; k += G) a.obs[(size_t)env * ODK_NOBS + k] = P[k];
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
 // ================================================================================================
 // AutoReset.step -> Episode.step -> Joystick.step (joystick.py:323-481), all substeps fused
 template <class S, int G>
-__global__ void __launch_bounds__(64) step_kernel(KArgs a) {
+__global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
   constexpr int NU = S::NU;

@@ -119,25 +119,35 @@ struct Shape {
 #endif
 
 // ------------------------------------------------------------------------------------------------
-template <int G> __device__ __forceinline__ float gsum(float v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
-  return v;
-}
-template <int G> __device__ __forceinline__ float gmax(float v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, G));
-  return v;
-}
-// argmax, lowest index wins ties (jnp.argmax semantics); result broadcast from lane 0 of the group
-template <int G> __device__ __forceinline__ int gargmax(float v, int i) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) {
-    float ov = __shfl_xor(v, o, G);
-    int oi = __shfl_xor(i, o, G);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+// Cross-lane all-reduce over the G lanes of one env with DPP (no LDS traffic): xor-1 / xor-2 quad permutes,
+// row_half_mirror, row_mirror give every lane its 16-lane row total; rows are then combined with row_bcast15
+// (/31) and the group total is read back with v_readlane.  MUST be called in uniform control flow.
+#define ODK_DPP(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xF, false))
+struct OpSum { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+struct OpMin { static __device__ __forceinline__ float f(float a, float b) { return fminf(a, b); } };
+template <int G, class Op> __device__ __forceinline__ float greduce(float v) {
+  v = Op::f(v, ODK_DPP(v, 0xB1, 0xF));    // quad_perm [1,0,3,2]
+  v = Op::f(v, ODK_DPP(v, 0x4E, 0xF));    // quad_perm [2,3,0,1]
+  v = Op::f(v, ODK_DPP(v, 0x141, 0xF));   // row_half_mirror
+  v = Op::f(v, ODK_DPP(v, 0x140, 0xF));   // row_mirror: every lane holds its row's total
+  const int iv = __float_as_int(v);
+  if (G == 32) {
+    const float lo = Op::f(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16)));
+    const float hi = Op::f(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
+    return (threadIdx.x & 32) ? hi : lo;
   }
-  return __shfl(i, 0, G);
+  const float a = Op::f(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16)));
+  const float b = Op::f(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
+  return Op::f(a, b);
+}
+template <int G> __device__ __forceinline__ float gsum(float v) { return greduce<G, OpSum>(v); }
+template <int G> __device__ __forceinline__ float gmax(float v) { return greduce<G, OpMax>(v); }
+// argmax, lowest index wins ties (jnp.argmax semantics): max of the values, then min index among the maxima
+template <int G> __device__ __forceinline__ int gargmax(float v, int i) {
+  const float mx = greduce<G, OpMax>(v);
+  const float cand = (v == mx) ? (float)i : 1.0e9f;
+  return (int)greduce<G, OpMin>(cand);
 }
 // value held by lane j (uniform j < G) of this env's lane group, via v_readlane (no LDS)
 template <int G> __device__ __forceinline__ float bcast(float v, int j) {
@@ -253,7 +263,7 @@ struct Statics {
 };
 
 template <class S, int G>
-__device__ void load_statics(Statics<S, G>& st, const DevModel* __restrict__ m, int lane) {
+__device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* __restrict__ m, int lane) {
   const int b = lane < S::NB ? lane : 0;
   st.b_level = lane < S::NB ? m->body_level[b] : -2;
   st.b_parent = m->body_parent[b];
@@ -324,10 +334,13 @@ __device__ void load_statics(Statics<S, G>& st, const DevModel* __restrict__ m, 
 // own row in registers; at step k lane k publishes its finished row to LDS and the ancestors of k fold it in.
 template <int G, int DMAX, int NVT>
 __device__ __forceinline__ void factor_rows(float* __restrict__ A, int lane, int on, int di, int ai, int descmask, int depth_st, int madr_st) {
-  float row[DMAX > 0 ? DMAX : 1], diag = 1.0f;
+  // all LDS loads are unconditional (in-bounds of the env's LDS image even when they run past a row) and
+  // masked afterwards with selects: a conditional load costs a branch and a full LDS round trip each
+  float row[DMAX > 0 ? DMAX : 1];
 #pragma unroll
-  for (int c = 0; c < DMAX; c++) row[c] = (on && c < di) ? A[ai + c] : 0.0f;
-  if (on) diag = A[ai + di];
+  for (int c = 0; c < DMAX; c++) row[c] = A[ai + c];
+  float diag = A[ai + di];
+  if (!on) diag = 1.0f;
   for (int k = NVT - 1; k > 0; k--) {
     const int Dk = ubcast(depth_st, k);
     if (Dk == 0) continue;
@@ -336,17 +349,20 @@ __device__ __forceinline__ void factor_rows(float* __restrict__ A, int lane, int
       const float inv = 1.0f / diag;
 #pragma unroll
       for (int c = 0; c < DMAX; c++)
-        if (c < di) { row[c] *= inv; A[ai + c] = row[c]; }
-      A[ai + di] = diag;
+        if (c < Dk) { row[c] *= inv; A[ak + c] = row[c]; }   // Dk is scalar: plain scalar branches
+      A[ak + Dk] = diag;
     }
     ODK_SYNC();
-    if ((descmask >> k) & 1) {  // this lane's dof is a strict ancestor of k
-      const float Lki = A[ak + di], dk = A[ak + Dk];
-      const float t = Lki * dk;
+    {
+      const bool anc = (descmask >> k) & 1;  // this lane's dof is a strict ancestor of k
+      float rk[DMAX > 0 ? DMAX : 1];
 #pragma unroll
-      for (int c = 0; c < DMAX; c++)
-        if (c < di) row[c] -= t * A[ak + c];
-      diag -= t * Lki;
+      for (int c = 0; c < DMAX; c++) rk[c] = A[ak + c];
+      const float Lki = A[ak + di], dk = A[ak + Dk];
+      const float t = anc ? Lki * dk : 0.0f;
+#pragma unroll
+      for (int c = 0; c < DMAX; c++) row[c] = anc ? fmaf(-t, rk[c], row[c]) : row[c];
+      diag = anc ? fmaf(-t, Lki, diag) : diag;
     }
     ODK_SYNC();
   }
@@ -362,10 +378,12 @@ __device__ __forceinline__ float solve_rows(const float* __restrict__ A, float x
 #pragma unroll
   for (int k = 0; k < NVT; k++) {
     const int ak = ubcast(madr_st, k), dk = ubcast(depth_st, k);
-    Lcol[k] = ((descmask >> k) & 1) ? A[ak + di] : 0.0f;   // L(k, i), k below i
-    Lrow[k] = ((ancmask >> k) & 1) ? A[ai + dk] : 0.0f;    // L(i, k), k above i
+    const float lc = A[ak + di], lr = A[ai + dk];           // unconditional loads, masked below
+    Lcol[k] = ((descmask >> k) & 1) ? lc : 0.0f;           // L(k, i), k below i
+    Lrow[k] = ((ancmask >> k) & 1) ? lr : 0.0f;            // L(i, k), k above i
   }
-  const float dinv = on ? 1.0f / A[ai + di] : 0.0f;
+  const float dg = A[ai + di];
+  const float dinv = on ? 1.0f / dg : 0.0f;
 #pragma unroll
   for (int k = NVT - 1; k > 0; k--) xi -= Lcol[k] * bcast<G>(xi, k);
   xi *= dinv;
@@ -401,7 +419,7 @@ __device__ inline void row_params(const float* solref, const float* solimp, floa
 // One mjx.forward for one env (all G lanes of the group call this together).
 //   flags bit0: compute sensordata / debug outputs (last substep only)
 template <class S, int G>
-__device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane, int flags) {
+__device__ __forceinline__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane, int flags) {
   constexpr int NV = S::NV, NB = S::NB;
   using ST = Statics<S, G>;
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; float* WARM = L + S::O_WARM; float* CTRL = L + S::O_CTRL;
@@ -624,11 +642,10 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     const int aj = ubcast(st.d_Madr, j), dj = ubcast(st.d_depth, j);
-    float v = 0.0f;
-    if ((st.d_ancmask >> j) & 1) v = M[st.d_Madr + dj];
-    else if ((st.d_descmask >> j) & 1) v = M[aj + st.d_depth];
-    else if (j == lane) v = M[st.d_Madr + st.d_depth];
-    Mrow[j] = v;
+    const bool isanc = (st.d_ancmask >> j) & 1, isdesc = (st.d_descmask >> j) & 1;
+    const int adr = isanc ? st.d_Madr + dj : (isdesc ? aj + st.d_depth : st.d_Madr + st.d_depth);
+    const float v = M[adr];
+    Mrow[j] = (isanc || isdesc || j == lane) ? v : 0.0f;
   }
   ODK_SYNC();
   ODK_PROF(6);
@@ -1200,7 +1217,7 @@ __device__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ 
 
 // mjx forward.euler (eulerdamp disabled): qvel += dt qacc; qpos integrated with the NEW qvel
 template <class S, int G>
-__device__ void euler_env(float* __restrict__ L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane) {
+__device__ __forceinline__ void euler_env(float* __restrict__ L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane) {
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; const float* X = L + S::O_X;
   const float dt = m->dt;
   if (lane < S::NV) QVEL[lane] += dt * X[lane];

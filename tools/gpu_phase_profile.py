@@ -31,11 +31,10 @@ o = b.lds_offset("scr") + 172
 prof = img[:, o:o + 20].astype(np.float64)
 mean = prof.mean(axis=0)
 tot = mean[:18].sum()
-# slot i holds the time of the code BEFORE ODK_PROF(i)
-labels = {0: "P1 kinematics+cinert+cdof", 1: "P2 crb*cdof+prefix", 2: "P3 M entries", 3: "P4 cvel/cacc/cfrc", 4: "P5 bias+act+copy",
-          15: "P6 factor M", 5: "P6 solve M", 6: "P7 plane-convex x2", 7: "P7 OBB cull", 8: "P8 rows", 9: "P9 candidate costs",
-          10: "P9 forces/K/grad/T", 11: "P9 Hessian entries", 16: "P9 factor H", 12: "P9 solve H", 13: "P9 ls setup", 14: "P9 line search",
-          17: "P10 sensors(+tail)"}
+labels = ["P0 sincos", "P1 top-down sweep (pose,cdof,cvel,cacc,cinert)", "P2 bottom-up sweep (crb,cfrc)", "P3 per-dof bias/act/qfrc_smooth",
+          "P4 M entries", "P5 factor M", "P5 solve M + dense M row", "P7 plane-convex x2", "P7 foot-foot OBB cull", "P8 constraint rows",
+          "P9 candidate twists/costs", "P9 forces, K blocks, grad, K*cdof", "P9 Hessian entries", "P9 factor H", "P9 solve H",
+          "P9 line-search setup", "P9 line search", "P10 sensors (+tail)"]
 print(f"{task} G={lanes} nenv={nenv}: cycles per env step (lane-0 clock, 10 forwards), total {tot:,.0f}")
-for i in [0, 1, 2, 3, 4, 15, 5, 6, 7, 8, 9, 10, 11, 16, 12, 13, 14, 17]:
-    print(f"  {labels[i]:28s} {mean[i]:12,.0f}  {100 * mean[i] / tot:5.1f}%")
+for i in range(18):
+    print(f"  {labels[i]:48s} {mean[i]:12,.0f}  {100 * mean[i] / tot:5.1f}%")
