@@ -237,53 +237,33 @@ __device__ __forceinline__ int randint3(float u) { int i = (int)(u * 3.0f); retu
 // Per-lane static data, loaded once per launch.  A lane plays several roles (body `lane`, dof `lane`,
 // joint `lane`, hull vertex `lane`, a few matrix entries and constraint rows); roles beyond the
 // model's counts are disabled by their flags.
+// Persistent part: what the factor / solve / solver phases need all the time (kept small: register pressure
+// decides whether two wavefronts fit on a SIMD).
 template <class S, int G>
 struct Statics {
   static constexpr int NME = (S::NM + G - 1) / G;   // inertia entries per lane
   static constexpr int NHE = (S::NH + G - 1) / G;   // Hessian entries per lane
-  // body role
-  int b_level, b_parent, b_nchild, b_child[3], b_njnt, b_jd[2], b_jj[2];
-  float b_pos[3], b_quat[4], b_ipos[3], b_inertia[6], b_ax[2][3];
-  // joint role (sin/cos phase, Euler)
-  int j_qadr, j_dadr;
-  // dof role
+  int j_qadr, j_dadr;                    // joint role (sin/cos phase, Euler)
   int d_on, d_body, d_depth, d_Madr, d_ancmask, d_descmask, d_vdepth, d_vMadr, d_vancmask, d_vdescmask;
   int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
   int d_qadr, d_lim_on;                  // hinge qpos address (-1: free joint); has a limit row
   float d_damping, d_lo, d_hi;           // joint range of the dof's hinge
-  float a_bias2, a_clo, a_chi, a_flo, a_fhi;  // actuator of the dof (if d_act >= 0)
-  int a_climited, a_flimited;
-  // matrix entries: i | j << 5 (| foot bits of i << 10 | foot bits of j << 12 | (src + 1) << 14 for H)
-  int ment[NME], hent[NHE];
-  // friction-loss row `lane` (lane < nfl)
-  float fl_D, fl_R, fl_b;
-  int fl_dof;
-  // hull vertices of both feet in the body frame
-  float vert[2][3];
 };
+// Phase-local statics: fetched from the model (L1/L2-resident, one batch of loads per phase and substep)
+// right where they are used, so they do not occupy registers for the rest of the substep.
+struct BodySt {
+  int level, parent, nchild, child[3], njnt, jd[2], jj[2];
+  float pos[3], quat[4], ipos[3], inertia[6], ax[2][3];
+};
+struct ActSt { float bias2, clo, chi, flo, fhi; int climited, flimited; };
+struct FlSt { float D, R, b; int dof; };
 
 template <class S, int G>
 __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* __restrict__ m, int lane) {
-  const int b = lane < S::NB ? lane : 0;
-  st.b_level = lane < S::NB ? m->body_level[b] : -2;
-  st.b_parent = m->body_parent[b];
-  st.b_nchild = lane < S::NB ? m->body_nchild[b] : 0;
-  for (int k = 0; k < 3; k++) st.b_child[k] = m->body_children[b][k];
-  st.b_njnt = (lane < S::NB && st.b_level > 0) ? m->body_jntnum[b] : 0;
-  for (int k = 0; k < 2; k++) {
-    const bool on = k < st.b_njnt;
-    const int j = on ? m->body_jntadr[b] + k : 0;
-    st.b_jj[k] = j;
-    st.b_jd[k] = m->jnt_dofadr[j];
-    for (int c = 0; c < 3; c++) st.b_ax[k][c] = on ? m->jnt_axis[j][c] : 0.0f;
-  }
-  for (int c = 0; c < 3; c++) { st.b_pos[c] = m->body_pos[b][c]; st.b_ipos[c] = m->body_ipos[b][c]; }
-  for (int c = 0; c < 4; c++) st.b_quat[c] = m->body_quat[b][c];
-  for (int c = 0; c < 6; c++) st.b_inertia[c] = m->body_inertia[b][c];
   {
     const bool on = lane >= 1 && lane < S::NJ;
-    st.j_qadr = on ? m->jnt_qposadr[lane] : -1;
-    st.j_dadr = on ? m->jnt_dofadr[lane] : 0;
+    st.j_qadr = on ? m->jnt_qposadr[on ? lane : 0] : -1;
+    st.j_dadr = m->jnt_dofadr[on ? lane : 0];
   }
   const int i = lane < S::NV ? lane : 0;
   st.d_on = lane < S::NV;
@@ -299,34 +279,48 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
   st.d_lim_on = st.d_limrow >= 0;
   st.d_qadr = m->dof_qadr[i];
   st.d_lo = m->dof_range[i][0]; st.d_hi = m->dof_range[i][1];
-  {
-    const int u = st.d_act >= 0 ? st.d_act : 0;
-    st.a_bias2 = m->act_bias2[u]; st.a_clo = m->act_ctrlrange[u][0]; st.a_chi = m->act_ctrlrange[u][1];
-    st.a_flo = m->act_forcerange[u][0]; st.a_fhi = m->act_forcerange[u][1];
-    st.a_climited = m->act_ctrllimited[u]; st.a_flimited = m->act_forcelimited[u];
+}
+template <class S>
+__device__ __forceinline__ void load_body(BodySt& b, const DevModel* __restrict__ m, int lane) {
+  const int bi = lane < S::NB ? lane : 0;
+  b.level = lane < S::NB ? m->body_level[bi] : -2;
+  b.parent = m->body_parent[bi];
+  b.nchild = lane < S::NB ? m->body_nchild[bi] : 0;
+  for (int k = 0; k < 3; k++) b.child[k] = m->body_children[bi][k];
+  b.njnt = (lane < S::NB && b.level > 0) ? m->body_jntnum[bi] : 0;
+  for (int k = 0; k < 2; k++) {
+    const bool on = k < b.njnt;
+    const int j = on ? m->body_jntadr[bi] + k : 0;
+    b.jj[k] = j;
+    b.jd[k] = m->jnt_dofadr[j];
+    for (int c = 0; c < 3; c++) b.ax[k][c] = on ? m->jnt_axis[j][c] : 0.0f;
   }
-  for (int t = 0; t < Statics<S, G>::NME; t++) {
-    const int p = lane + t * G;
-    st.ment[t] = p < S::NM ? (m->M_i[p] | (m->M_j[p] << 5)) : -1;
-  }
-  for (int t = 0; t < Statics<S, G>::NHE; t++) {
-    const int p = lane + t * G;
-    int e = -1;
-    if (p < S::NH) {
-      const int hi = m->H_i[p], hj = m->H_j[p];
-      const int fi = m->foot_dofmask[0][hi] | (m->foot_dofmask[1][hi] << 1), fj = m->foot_dofmask[0][hj] | (m->foot_dofmask[1][hj] << 1);
-      e = hi | (hj << 5) | (fi << 10) | (fj << 12) | ((m->H_src[p] + 1) << 14);
-    }
-    st.hent[t] = e;
-  }
-  {
-    const int r = lane < m->nfl ? lane : 0;
-    st.fl_D = m->fl_D[r]; st.fl_R = m->fl_R[r]; st.fl_b = m->fl_b[r]; st.fl_dof = m->fl_dof[r];
-  }
-  for (int f = 0; f < 2; f++) {
-    const int v = lane < m->foot_nvert[f] ? lane : 0;
-    for (int c = 0; c < 3; c++) st.vert[f][c] = m->foot_vert[f][v][c];
-  }
+  for (int c = 0; c < 3; c++) { b.pos[c] = m->body_pos[bi][c]; b.ipos[c] = m->body_ipos[bi][c]; }
+  for (int c = 0; c < 4; c++) b.quat[c] = m->body_quat[bi][c];
+  for (int c = 0; c < 6; c++) b.inertia[c] = m->body_inertia[bi][c];
+}
+__device__ __forceinline__ void load_act(ActSt& a, const DevModel* __restrict__ m, int act) {
+  const int u = act >= 0 ? act : 0;
+  a.bias2 = m->act_bias2[u]; a.clo = m->act_ctrlrange[u][0]; a.chi = m->act_ctrlrange[u][1];
+  a.flo = m->act_forcerange[u][0]; a.fhi = m->act_forcerange[u][1];
+  a.climited = m->act_ctrllimited[u]; a.flimited = m->act_forcelimited[u];
+}
+__device__ __forceinline__ void load_fl(FlSt& f, const DevModel* __restrict__ m, int lane) {
+  const int r = lane < m->nfl ? lane : 0;
+  f.D = m->fl_D[r]; f.R = m->fl_R[r]; f.b = m->fl_b[r]; f.dof = m->fl_dof[r];
+}
+// matrix entries of this lane: i | j << 5 (| foot bits of i << 10 | foot bits of j << 12 | (src + 1) << 14 for H)
+__device__ __forceinline__ int load_ment(const DevModel* __restrict__ m, int p, int nm) {
+  const int q = p < nm ? p : 0;
+  const int e = m->M_i[q] | (m->M_j[q] << 5);
+  return p < nm ? e : -1;
+}
+__device__ __forceinline__ int load_hent(const DevModel* __restrict__ m, int p, int nh) {
+  const int q = p < nh ? p : 0;
+  const int hi = m->H_i[q], hj = m->H_j[q];
+  const int fi = m->foot_dofmask[0][hi] | (m->foot_dofmask[1][hi] << 1), fj = m->foot_dofmask[0][hj] | (m->foot_dofmask[1][hj] << 1);
+  const int e = hi | (hj << 5) | (fi << 10) | (fj << 12) | ((m->H_src[q] + 1) << 14);
+  return p < nh ? e : -1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -346,7 +340,7 @@ __device__ __forceinline__ void factor_rows(float* __restrict__ A, int lane, int
     if (Dk == 0) continue;
     const int ak = ubcast(madr_st, k);
     if (lane == k) {
-      const float inv = 1.0f / diag;
+      const float inv = __builtin_amdgcn_rcpf(diag);
 #pragma unroll
       for (int c = 0; c < DMAX; c++)
         if (c < Dk) { row[c] *= inv; A[ak + c] = row[c]; }   // Dk is scalar: plain scalar branches
@@ -383,7 +377,7 @@ __device__ __forceinline__ float solve_rows(const float* __restrict__ A, float x
     Lrow[k] = ((ancmask >> k) & 1) ? lr : 0.0f;            // L(i, k), k above i
   }
   const float dg = A[ai + di];
-  const float dinv = on ? 1.0f / dg : 0.0f;
+  const float dinv = on ? __builtin_amdgcn_rcpf(dg) : 0.0f;
 #pragma unroll
   for (int k = NVT - 1; k > 0; k--) xi -= Lcol[k] * bcast<G>(xi, k);
   xi *= dinv;
@@ -436,6 +430,8 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
   ODK_PROF_BEGIN();
 
+  BodySt bs;
+  load_body<S>(bs, m, lane);   // issued first: the loads complete under the sin/cos phase
   // ---------------- P0: half-angle sin/cos of every hinge (lane = joint)
   if (st.j_qadr >= 0) {
     float s, c;
@@ -447,12 +443,12 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   // ---------------- P1: top-down level sweep (lane = body): pose, cdof, cvel, velocity part of cacc, local bias force
   {
     float p[3] = {0, 0, 0}, q[4] = {1, 0, 0, 0}, cvel[6] = {0, 0, 0, 0, 0, 0}, cacc[6] = {0, 0, 0, 0, 0, 0};
-    if (st.b_level == -1) {  // world / static bodies
-      for (int k = 0; k < 3; k++) p[k] = st.b_pos[k];
-      for (int k = 0; k < 4; k++) q[k] = st.b_quat[k];
+    if (bs.level == -1) {  // world / static bodies
+      for (int k = 0; k < 3; k++) p[k] = bs.pos[k];
+      for (int k = 0; k < 4; k++) q[k] = bs.quat[k];
     }
     for (int lvl = 0; lvl <= m->max_level; lvl++) {
-      if (st.b_level == lvl) {
+      if (bs.level == lvl) {
         if (lvl == 0) {  // floating base: free joint (mj_comVel free-joint rule)
           for (int k = 0; k < 3; k++) p[k] = ref[k];
           for (int k = 0; k < 4; k++) q[k] = QPOS[3 + k];
@@ -473,31 +469,31 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
           cvel[0] = ww[0]; cvel[1] = ww[1]; cvel[2] = ww[2]; cvel[3] = v[0]; cvel[4] = v[1]; cvel[5] = v[2];
           cacc[3] = -m->gravity[0] + vxw[0]; cacc[4] = -m->gravity[1] + vxw[1]; cacc[5] = -m->gravity[2] + vxw[2];
         } else {
-          const int pb = st.b_parent;
+          const int pb = bs.parent;
           float pp[3], pq[4], t[3];
           for (int k = 0; k < 3; k++) pp[k] = XPOS[k * NB + pb];
           for (int k = 0; k < 4; k++) pq[k] = XQUAT[k * NB + pb];
           for (int k = 0; k < 6; k++) { cvel[k] = CVEL[k * NB + pb]; cacc[k] = CACC[k * NB + pb]; }
-          qrot(t, pq, st.b_pos);
+          qrot(t, pq, bs.pos);
           p[0] = pp[0] + t[0]; p[1] = pp[1] + t[1]; p[2] = pp[2] + t[2];
-          qmul(q, pq, st.b_quat);
+          qmul(q, pq, bs.quat);
 #pragma unroll
           for (int jj = 0; jj < 2; jj++) {
-            if (jj < st.b_njnt) {  // hinge at the body origin (jnt_pos == 0, checked at load)
+            if (jj < bs.njnt) {  // hinge at the body origin (jnt_pos == 0, checked at load)
               float axw[3], cd[6], dot[6];
-              qrot(axw, q, st.b_ax[jj]);
+              qrot(axw, q, bs.ax[jj]);
               const float off[3] = {ref[0] - p[0], ref[1] - p[1], ref[2] - p[2]};
               cd[0] = axw[0]; cd[1] = axw[1]; cd[2] = axw[2];
               cross3(cd + 3, axw, off);
-              const int d = st.b_jd[jj];
+              const int d = bs.jd[jj];
 #pragma unroll
               for (int k = 0; k < 6; k++) CDOF[k * NV + d] = cd[k];
               const float qv = QVEL[d];
               cross_motion(dot, cvel, cd);
 #pragma unroll
               for (int k = 0; k < 6; k++) { cacc[k] += dot[k] * qv; cvel[k] += cd[k] * qv; }
-              const float s = SC[2 * st.b_jj[jj]], c = SC[2 * st.b_jj[jj] + 1];
-              const float qj[4] = {c, s * st.b_ax[jj][0], s * st.b_ax[jj][1], s * st.b_ax[jj][2]};
+              const float s = SC[2 * bs.jj[jj]], c = SC[2 * bs.jj[jj] + 1];
+              const float qj[4] = {c, s * bs.ax[jj][0], s * bs.ax[jj][1], s * bs.ax[jj][2]};
               qmul(q, q, qj);
             }
           }
@@ -513,7 +509,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
       ODK_SYNC();
     }
     if (lane < NB) {
-      if (st.b_level < 0) {
+      if (bs.level < 0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) XPOS[k * NB + lane] = p[k];
 #pragma unroll
@@ -524,11 +520,11 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
       // cinert about the base origin, local bias force
       float R[9];
       q2mat(R, q);
-      float ip[3] = {st.b_ipos[0], st.b_ipos[1], st.b_ipos[2]};
+      float ip[3] = {bs.ipos[0], bs.ipos[1], bs.ipos[2]};
       if (lane == 1) { ip[0] = L[S::O_IPOS1]; ip[1] = L[S::O_IPOS1 + 1]; ip[2] = L[S::O_IPOS1 + 2]; }
       float off[3];
       for (int k = 0; k < 3; k++) off[k] = p[k] + R[3 * k] * ip[0] + R[3 * k + 1] * ip[1] + R[3 * k + 2] * ip[2] - ref[k];
-      const float* f = st.b_inertia;
+      const float* f = bs.inertia;
       const float Ib[9] = {f[0], f[3], f[4], f[3], f[1], f[5], f[4], f[5], f[2]};
       float T[9], Iw[9];
       for (int i = 0; i < 3; i++)
@@ -553,7 +549,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
       fr[0] += a3[0] + c3[0]; fr[1] += a3[1] + c3[1]; fr[2] += a3[2] + c3[2];
       cross3(a3, cvel, t1 + 3);
       fr[3] += a3[0]; fr[4] += a3[1]; fr[5] += a3[2];
-      const bool dyn = st.b_level >= 0;
+      const bool dyn = bs.level >= 0;
 #pragma unroll
       for (int k = 0; k < 10; k++) CRB[k * NB + lane] = dyn ? ci[k] : 0.0f;
 #pragma unroll
@@ -564,7 +560,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   ODK_PROF(1);
   // ---------------- P2: bottom-up sweep: composite inertia and subtree bias force
   for (int lvl = m->max_level - 1; lvl >= 0; lvl--) {
-    if (st.b_level == lvl && st.b_nchild > 0) {
+    if (bs.level == lvl && bs.nchild > 0) {
       float acc[16];
 #pragma unroll
       for (int k = 0; k < 10; k++) acc[k] = CRB[k * NB + lane];
@@ -572,8 +568,8 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
       for (int k = 0; k < 6; k++) acc[10 + k] = CFRC[k * NB + lane];
 #pragma unroll
       for (int cidx = 0; cidx < 3; cidx++) {
-        if (cidx < st.b_nchild) {
-          const int c = st.b_child[cidx];
+        if (cidx < bs.nchild) {
+          const int c = bs.child[cidx];
 #pragma unroll
           for (int k = 0; k < 10; k++) acc[k] += CRB[k * NB + c];
 #pragma unroll
@@ -604,11 +600,13 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
     float frc = -st.d_damping * qv - bias;
     const int u = st.d_act;
     if (u >= 0) {
+      ActSt as;
+      load_act(as, m, u);
       float ctrl = CTRL[u];
-      if (st.a_climited) ctrl = fminf(fmaxf(ctrl, st.a_clo), st.a_chi);
+      if (as.climited) ctrl = fminf(fmaxf(ctrl, as.clo), as.chi);
       const float kp = KP[u];
-      float af = kp * ctrl - kp * QPOS[st.d_qadr] + st.a_bias2 * qv;
-      if (st.a_flimited) af = fminf(fmaxf(af, st.a_flo), st.a_fhi);
+      float af = kp * ctrl - kp * QPOS[st.d_qadr] + as.bias2 * qv;
+      if (as.flimited) af = fminf(fmaxf(af, as.flo), as.fhi);
       ACTF[u] = af;
       frc += af;
     }
@@ -620,7 +618,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   // ---------------- P4: sparse inertia entries (lane = entry), mirrored into HL for the factorisation
 #pragma unroll
   for (int t = 0; t < ST::NME; t++) {
-    const int e = st.ment[t];
+    const int e = load_ment(m, lane + t * G, S::NM);
     if (e >= 0) {
       const int i = e & 31, j = (e >> 5) & 31;
       float v = 0;
@@ -667,7 +665,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
     const bool has = lane < nvt;
     float w[3] = {0, 0, 0}, sup = -3.0e38f;
     if (has) {
-      const float* vb = st.vert[f];
+      const float vb[3] = {m->foot_vert[f][lane][0], m->foot_vert[f][lane][1], m->foot_vert[f][lane][2]};
       for (int k = 0; k < 3; k++) w[k] = fP[f][k] + fR[f][3 * k] * vb[0] + fR[f][3 * k + 1] * vb[1] + fR[f][3 * k + 2] * vb[2];
       sup = (m->plane_pos[0] - w[0]) * pn[0] + (m->plane_pos[1] - w[1]) * pn[1] + (m->plane_pos[2] - w[2]) * pn[2];
     }
@@ -764,11 +762,13 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
 
   // ---------------- P8: constraint rows: D, aref, contact wrenches
   // friction-loss rows: lane = row; limit rows: lane = dof that owns the limit; contact rows: rc = lane + t G
+  FlSt fs;
+  load_fl(fs, m, lane);
   float fl_f = 0.0f, fl_rf = 0.0f;
   if (lane < nfl) {
-    fl_f = FRL[st.fl_dof]; fl_rf = st.fl_R * fl_f;
-    ED[lane] = st.fl_D;
-    AREF[lane] = -st.fl_b * QVEL[st.fl_dof];
+    fl_f = FRL[fs.dof]; fl_rf = fs.R * fl_f;
+    ED[lane] = fs.D;
+    AREF[lane] = -fs.b * QVEL[fs.dof];
   }
   float lim_sgn = 0.0f;
   if (st.d_lim_on) {
@@ -856,14 +856,14 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   auto fl_cost = [&](float jar, float& force) -> float {
     if (jar <= -fl_rf) { force = fl_f; return -0.5f * fl_rf * fl_f - fl_f * jar; }
     if (jar >= fl_rf) { force = -fl_f; return -0.5f * fl_rf * fl_f + fl_f * jar; }
-    force = -st.fl_D * jar;
-    return 0.5f * st.fl_D * jar * jar;
+    force = -fs.D * jar;
+    return 0.5f * fs.D * jar * jar;
   };
   // Jaref and cost of both candidates; rows owned by this lane: friction row `lane`, limit row of dof `lane`, contact rows
   float cost_s = 0, cost_w = 0, jar_fl_s = 0, jar_fl_w = 0, jar_lim_s = 0, jar_lim_w = 0, fo;
   if (lane < nfl) {
     const float ar = AREF[lane];
-    jar_fl_s = QAS[st.fl_dof] - ar; jar_fl_w = WARM[st.fl_dof] - ar;
+    jar_fl_s = QAS[fs.dof] - ar; jar_fl_w = WARM[fs.dof] - ar;
     cost_s += fl_cost(jar_fl_s, fo); cost_w += fl_cost(jar_fl_w, fo);
   }
   float lim_D = 0.0f;
@@ -909,7 +909,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
     JV[r] = fo2;
   }
   // friction-row quantities are owned by lane = row; the dof that needs them is another lane: hand over through LDS
-  if (lane < nfl) { MV[st.fl_dof] = f_fl; MA[st.fl_dof] = quad_fl ? st.fl_D : 0.0f; }
+  if (lane < nfl) { MV[fs.dof] = f_fl; MA[fs.dof] = quad_fl ? fs.D : 0.0f; }
   ODK_SYNC();
   const bool c_act[3] = {fminf(fminf(CDIST[0], CDIST[1]), fminf(CDIST[2], CDIST[3])) < 0, fminf(fminf(CDIST[4], CDIST[5]), fminf(CDIST[6], CDIST[7])) < 0,
                          fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0};
@@ -979,9 +979,12 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   ODK_SYNC();
   ODK_PROF(11);
   // Hessian entries on the virtual-tree layout
+  int hent[ST::NHE];
+#pragma unroll
+  for (int t = 0; t < ST::NHE; t++) hent[t] = load_hent(m, lane + t * G, S::NH);
 #pragma unroll
   for (int t = 0; t < ST::NHE; t++) {
-    const int e = st.hent[t];
+    const int e = hent[t];
     if (e >= 0) {
       const int i = e & 31, j = (e >> 5) & 31, fi = (e >> 10) & 3, fj = (e >> 12) & 3, src = (e >> 14) - 1;
       float v = src >= 0 ? M[src] : 0.0f;
@@ -1041,7 +1044,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   }
   ODK_SYNC();
   float jv_fl = 0, jv_lim = 0;
-  if (lane < nfl) jv_fl = GRAD[st.fl_dof];
+  if (lane < nfl) jv_fl = GRAD[fs.dof];
   if (st.d_lim_on) jv_lim = lim_sgn * search;
   // contact rows of this lane in registers for the line search
   constexpr int NCL = (S::NCROW + G - 1) / G;
@@ -1061,7 +1064,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   auto ls_eval3 = [&](const float* al, float* cost, float* d0, float* d1) {
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (lane < nfl) {
-      const float D = st.fl_D, jar = jar_fl, jv = jv_fl;
+      const float D = fs.D, jar = jar_fl, jv = jv_fl;
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
