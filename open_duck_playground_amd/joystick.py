@@ -1,0 +1,172 @@
+"""Joystick task for Open Duck Mini V2 -- batched, device-resident mirror of the reference env.
+
+Same surface as reference playground/open_duck_mini_v2/joystick.py (`Joystick`, `default_config`,
+`reset`, `step`, `action_size`, `observation_size`, `dt`, `sim_dt`, `n_substeps`) and base.py
+(`mj_model`, `xml_path`), but *batched and stateful on the GPU*: `reset(seed)` / `step(state, action)`
+operate on all `num_envs` envs at once and every tensor in `State` is a torch device tensor.  The
+brax Vmap / Episode / AutoReset wrappers (reference common/runner.py:117) are fused into the same
+kernel launch (config keys `episode_length`, `autoreset`).  All arithmetic happens in csrc/ (HIP).
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from . import constants, engine
+
+USE_IMITATION_REWARD = True       # reference joystick.py:45
+USE_MOTOR_SPEED_LIMITS = True     # reference joystick.py:46
+
+
+class ConfigDict(dict):
+    """Tiny ml_collections.ConfigDict stand-in: attribute + item access, nested."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return ConfigDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def default_config() -> ConfigDict:
+    """reference joystick.py:49-102, key for key."""
+    C = ConfigDict
+    return C(
+        ctrl_dt=0.02, sim_dt=0.002, episode_length=1000, action_repeat=1, action_scale=0.25, dof_vel_scale=0.05, history_len=0,
+        soft_joint_pos_limit_factor=0.95, max_motor_velocity=5.24,
+        noise_config=C(level=1.0, action_min_delay=0, action_max_delay=3, imu_min_delay=0, imu_max_delay=3,
+                       scales=C(hip_pos=0.03, knee_pos=0.05, ankle_pos=0.08, joint_vel=2.5, gravity=0.1, linvel=0.1, gyro=0.1, accelerometer=0.05)),
+        reward_config=C(scales=C(tracking_lin_vel=2.5, tracking_ang_vel=6.0, torques=-1.0e-3, action_rate=-0.5, stand_still=-0.2, alive=20.0, imitation=1.0),
+                        tracking_sigma=0.01),
+        push_config=C(enable=True, interval_range=[5.0, 10.0], magnitude_range=[0.1, 1.0]),
+        lin_vel_x=[-0.15, 0.15], lin_vel_y=[-0.2, 0.2], ang_vel_yaw=[-1.0, 1.0], neck_pitch_range=[-0.34, 1.1], head_pitch_range=[-0.78, 0.78],
+        head_yaw_range=[-1.5, 1.5], head_roll_range=[-0.5, 0.5], head_range_factor=1.0,
+    )
+
+
+def _merge(cfg: ConfigDict, overrides: Optional[Dict[str, Any]]) -> ConfigDict:
+    cfg = copy.deepcopy(cfg)
+    for k, v in (overrides or {}).items():
+        node = cfg
+        parts = k.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg
+
+
+def to_engine_config(cfg: ConfigDict, autoreset: bool = True, lanes_per_env: int = 0) -> engine.EnvConfig:
+    """reference config -> odk_env_config (include/odk.h)."""
+    c = engine.default_config()
+    c.ctrl_dt, c.action_scale, c.dof_vel_scale, c.max_motor_velocity = cfg.ctrl_dt, cfg.action_scale, cfg.dof_vel_scale, cfg.max_motor_velocity
+    n = cfg.noise_config
+    if (n.action_min_delay, n.action_max_delay, n.imu_min_delay, n.imu_max_delay) != (0, 3, 0, 3):
+        raise ValueError("the kernels implement the reference's delay ring of depth 3")
+    c.noise_level, c.noise_gyro, c.noise_accelerometer = n.level, n.scales.gyro, n.scales.accelerometer
+    c.noise_gravity, c.noise_joint_vel = n.scales.gravity, n.scales.joint_vel
+    # BUG-COMPAT (joystick.py:184-200): indices taken on the 10-entry JOINTS_ORDER_NO_HEAD, written into the 14-entry array
+    scale = np.zeros(16, np.float32)
+    for idx, j in enumerate(constants.JOINTS_ORDER_NO_HEAD):
+        scale[idx] = n.scales.hip_pos if "_hip" in j else (n.scales.knee_pos if "_knee" in j else n.scales.ankle_pos)
+    for i in range(16):
+        c.qpos_noise_scale[i] = float(scale[i])
+    s = cfg.reward_config.scales
+    for i, k in enumerate(("tracking_lin_vel", "tracking_ang_vel", "torques", "action_rate", "stand_still", "alive", "imitation")):
+        c.reward_scales[i] = float(s[k])
+    c.tracking_sigma = cfg.reward_config.tracking_sigma
+    c.push_enable = 1.0 if cfg.push_config.enable else 0.0
+    for i in range(2):
+        c.push_interval_range[i] = cfg.push_config.interval_range[i]
+        c.push_magnitude_range[i] = cfg.push_config.magnitude_range[i]
+    f = cfg.head_range_factor
+    ranges = [cfg.lin_vel_x, cfg.lin_vel_y, cfg.ang_vel_yaw, [cfg.neck_pitch_range[0] * f, cfg.neck_pitch_range[1] * f],
+              [cfg.head_pitch_range[0] * f, cfg.head_pitch_range[1] * f], [cfg.head_yaw_range[0] * f, cfg.head_yaw_range[1] * f],
+              [cfg.head_roll_range[0] * f, cfg.head_roll_range[1] * f]]
+    for i, r in enumerate(ranges):
+        c.cmd_range[i][0], c.cmd_range[i][1] = float(r[0]), float(r[1])
+    c.use_imitation = int(USE_IMITATION_REWARD)
+    c.use_motor_speed_limits = int(USE_MOTOR_SPEED_LIMITS)
+    c.autoreset = int(autoreset)
+    c.episode_length = int(cfg.episode_length)
+    c.n_substeps = int(round(cfg.ctrl_dt / cfg.sim_dt))
+    c.lanes_per_env = lanes_per_env
+    return c
+
+
+@dataclass
+class State:
+    """mjx_env.State counterpart (reference joystick.py:321): tensors are views of the engine's output buffers,
+    valid until the next reset/step call."""
+    data: Any                       # the engine Batch (physics state lives on the device)
+    obs: Dict[str, Any]             # {"state": [N,101], "privileged_state": [N,212]}
+    reward: Any                     # [N]
+    done: Any                       # [N]
+    metrics: Dict[str, Any]         # reward/* cost/* swing_peak, each [N]
+    info: Dict[str, Any] = field(default_factory=dict)   # {"truncation": [N]}; the rest of info stays device-side
+
+
+class Joystick:
+    """Track a joystick command (reference joystick.py:105)."""
+
+    def __init__(self, task: str = "flat_terrain", config: Optional[ConfigDict] = None, config_overrides: Optional[Dict[str, Any]] = None,
+                 num_envs: int = 8192, device: int = 0, autoreset: bool = True, lanes_per_env: int = 0, env_id_offset: int = 0):
+        self._config = _merge(config if config is not None else default_config(), config_overrides)
+        self._model = constants.task_to_model(task)      # KeyError for unknown task names
+        self._task = task
+        self.num_envs = int(num_envs)
+        self._env_id_offset = int(env_id_offset)
+        self._batch = engine.Batch(self._model, self.num_envs, to_engine_config(self._config, autoreset, lanes_per_env), device=device)
+
+    # ---- reference accessors (base.py:277-291, MjxEnv)
+    @property
+    def xml_path(self) -> str: return self._model.xml_path
+    @property
+    def action_size(self) -> int: return self._model.nu
+    @property
+    def mj_model(self): return self._model
+    @property
+    def mjx_model(self): return self._batch
+    @property
+    def observation_size(self): return {"state": (engine.NOBS,), "privileged_state": (engine.NPRIV,)}
+    @property
+    def dt(self) -> float: return self._config.ctrl_dt
+    @property
+    def sim_dt(self) -> float: return self._config.sim_dt
+    @property
+    def n_substeps(self) -> int: return int(round(self._config.ctrl_dt / self._config.sim_dt))
+    @property
+    def unwrapped(self): return self
+    @property
+    def batch(self) -> "engine.Batch": return self._batch
+
+    def randomize(self, rng: np.random.Generator):
+        """randomization_fn hook of brax ppo.train (reference runner.py:26, common/runner.py:108)."""
+        from . import randomize
+        fields, _ = randomize.domain_randomize(self._model, rng, self.num_envs)
+        randomize.apply(self._batch, fields)
+        return fields
+
+    def _state(self) -> State:
+        b = self._batch
+        metrics = {name: b.metrics[:, i] for i, name in enumerate(engine.METRIC_NAMES)}
+        return State(data=b, obs={"state": b.obs, "privileged_state": b.priv}, reward=b.reward, done=b.done, metrics=metrics,
+                     info={"truncation": b.truncation})
+
+    def reset(self, rng: int) -> State:
+        """reference joystick.py:206: `rng` is an integer seed; env e draws from key(seed, env_id_offset + e)."""
+        self._batch.reset(int(rng), self._env_id_offset)
+        return self._state()
+
+    def step(self, state: State, action) -> State:
+        """reference joystick.py:323 (+ Episode/AutoReset wrappers): one fused kernel launch."""
+        self._batch.step(action)
+        return self._state()

@@ -1,0 +1,186 @@
+"""PPO on PyTorch-ROCm with brax semantics (brax.training.agents.ppo.train counterpart, reached by the
+reference through playground/common/runner.py:104-118).  Hyper-parameters: the BerkeleyHumanoid table the
+reference asks for (common/runner.py:87-89; values in SURVEY.md Appendix G, [UPSTREAM-MEMORY]).
+
+Data parallelism: one process per GPU, envs sharded, parameters replicated; per SGD step one all-reduce
+(mean) of the flat gradient buffer and, per training step, one all-reduce of the normaliser moments
+(RCCL over xGMI when launched with torchrun on GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .networks import PPONetworks, tanh_normal_entropy, tanh_normal_log_prob
+
+
+def ppo_config() -> Dict:
+    """locomotion_params.brax_ppo_config("BerkeleyHumanoidJoystickFlatTerrain")."""
+    return dict(num_timesteps=150_000_000, num_evals=15, reward_scaling=1.0, episode_length=1000, normalize_observations=True,
+                action_repeat=1, unroll_length=20, num_minibatches=32, num_updates_per_batch=4, discounting=0.97, learning_rate=3e-4,
+                entropy_cost=0.005, num_envs=8192, batch_size=256, max_grad_norm=1.0, clipping_epsilon=0.2, num_resets_per_eval=1,
+                gae_lambda=0.95, normalize_advantage=True,
+                network_factory=dict(policy_hidden_layer_sizes=(512, 256, 128), value_hidden_layer_sizes=(512, 256, 128),
+                                     policy_obs_key="state", value_obs_key="privileged_state"))
+
+
+def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambda_, discount):
+    """brax ppo.losses.compute_gae: time-major [T, B] tensors."""
+    T = rewards.shape[0]
+    trunc_mask = 1.0 - truncation
+    values_t1 = torch.cat([values[1:], bootstrap_value[None]], 0)
+    deltas = (rewards + discount * (1.0 - termination) * values_t1 - values) * trunc_mask
+    acc = torch.zeros_like(bootstrap_value)
+    vs_minus_v = []
+    for t in range(T - 1, -1, -1):
+        acc = deltas[t] + discount * (1.0 - termination[t]) * trunc_mask[t] * lambda_ * acc
+        vs_minus_v.append(acc)
+    vs_minus_v = torch.stack(vs_minus_v[::-1], 0)
+    vs = vs_minus_v + values
+    vs_t1 = torch.cat([vs[1:], bootstrap_value[None]], 0)
+    advantages = (rewards + discount * (1.0 - termination) * vs_t1 - values) * trunc_mask
+    return vs.detach(), advantages.detach()
+
+
+def ppo_loss(net: PPONetworks, mb: Dict[str, torch.Tensor], cfg: Dict):
+    """brax ppo.losses.compute_ppo_loss on a minibatch of trajectories ([B, T, ...] tensors)."""
+    obs, priv = mb["obs"], mb["priv"]
+    loc, scale = net.dist_params(obs)
+    baseline = net.values(priv)
+    bootstrap = net.values(mb["last_priv"])
+    rewards = mb["reward"] * cfg["reward_scaling"]
+    termination = mb["done"] * (1.0 - mb["truncation"])
+    tm = lambda x: x.transpose(0, 1)
+    vs, adv = compute_gae(tm(mb["truncation"]), tm(termination), tm(rewards), tm(baseline.detach()), bootstrap.detach(),
+                          cfg["gae_lambda"], cfg["discounting"])
+    vs, adv = tm(vs), tm(adv)
+    if cfg["normalize_advantage"]:
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+    logp = tanh_normal_log_prob(loc, scale, mb["raw_action"])
+    rho = torch.exp(logp - mb["log_prob"])
+    eps = cfg["clipping_epsilon"]
+    policy_loss = -torch.min(rho * adv, rho.clamp(1 - eps, 1 + eps) * adv).mean()
+    v_loss = ((vs - baseline) ** 2).mean() * 0.5 * 0.5
+    noise = torch.randn_like(loc)
+    entropy = tanh_normal_entropy(loc, scale, loc + scale * noise).mean()
+    ent_loss = -cfg["entropy_cost"] * entropy
+    total = policy_loss + v_loss + ent_loss
+    return total, dict(total_loss=total.detach(), policy_loss=policy_loss.detach(), v_loss=v_loss.detach(), entropy_loss=ent_loss.detach())
+
+
+def _allreduce_grads(params, world: int, group=None):
+    import torch.distributed as dist
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, group=group)   # RCCL (backend "nccl") on GPUs, gloo on CPU
+    flat /= world
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n
+
+
+def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Generator, world: int = 1, group=None):
+    """num_updates_per_batch x num_minibatches clipped-Adam steps over one rollout ([B, T, ...] per rank)."""
+    B = data["reward"].shape[0]
+    nmb = cfg["num_minibatches"]
+    params = [p for p in net.parameters() if p.requires_grad]
+    metrics = {}
+    for _ in range(cfg["num_updates_per_batch"]):
+        perm = torch.randperm(B, generator=gen, device=data["reward"].device)
+        for mbi in perm.chunk(nmb):
+            mb = {k: v[mbi] for k, v in data.items()}
+            loss, metrics = ppo_loss(net, mb, cfg)
+            opt.zero_grad(set_to_none=False)
+            loss.backward()
+            if world > 1:
+                _allreduce_grads(params, world, group)
+            if cfg.get("max_grad_norm"):
+                torch.nn.utils.clip_grad_norm_(params, cfg["max_grad_norm"])
+            opt.step()
+    return metrics
+
+
+@torch.no_grad()
+def rollout(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generator, deterministic: bool = False):
+    """brax acting.generate_unroll: returns ([B, T, ...] transition tensors, final state)."""
+    keys = ("obs", "priv", "raw_action", "log_prob", "reward", "done", "truncation")
+    buf = {k: [] for k in keys}
+    for _ in range(unroll_length):
+        obs, priv = state.obs["state"].clone(), state.obs["privileged_state"].clone()
+        loc, scale = net.dist_params(obs)
+        raw = loc if deterministic else loc + scale * torch.randn(loc.shape, generator=gen, device=loc.device)
+        logp = tanh_normal_log_prob(loc, scale, raw)
+        action = torch.tanh(raw).contiguous()
+        state = env.step(state, action)
+        buf["obs"].append(obs); buf["priv"].append(priv); buf["raw_action"].append(raw); buf["log_prob"].append(logp)
+        buf["reward"].append(state.reward.clone()); buf["done"].append(state.done.clone()); buf["truncation"].append(state.info["truncation"].clone())
+    data = {k: torch.stack(v, 1) for k, v in buf.items()}
+    data["last_priv"] = state.obs["privileged_state"].clone()
+    return data, state
+
+
+def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = None, policy_params_fn: Optional[Callable] = None,
+          restore_checkpoint_path: Optional[str] = None, seed: int = 0, randomization_fn: Optional[Callable] = None,
+          log_path: Optional[str] = None, **overrides):
+    """Trains on `environment` (a batched Joystick).  Returns (networks, metrics)."""
+    import torch.distributed as dist
+    cfg = ppo_config()
+    cfg.update({k: v for k, v in overrides.items() if v is not None})
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    dev = environment.batch.obs.device
+    nf = cfg["network_factory"]
+    net = PPONetworks(environment.observation_size["state"][0], environment.observation_size["privileged_state"][0], environment.action_size,
+                      nf["policy_hidden_layer_sizes"], nf["value_hidden_layer_sizes"]).to(dev)
+    torch.manual_seed(seed)   # identical initial parameters on every rank
+    net = PPONetworks(environment.observation_size["state"][0], environment.observation_size["privileged_state"][0], environment.action_size,
+                      nf["policy_hidden_layer_sizes"], nf["value_hidden_layer_sizes"]).to(dev)
+    if restore_checkpoint_path:
+        net.load_state_dict(torch.load(restore_checkpoint_path, map_location=dev)["networks"])
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=cfg["learning_rate"])
+    gen = torch.Generator(device=dev); gen.manual_seed(seed * 1000 + rank)
+    if randomization_fn is not None:
+        randomization_fn(environment)
+    state = environment.reset(seed)
+    n_local = environment.num_envs
+    steps_per_iter = n_local * world * cfg["unroll_length"]
+    num_iters = max(1, -(-num_timesteps // steps_per_iter))
+    eval_every = max(1, num_iters // max(1, cfg["num_evals"]))
+    t0 = time.time(); done_steps = 0; metrics = {}
+    log = open(log_path, "a") if (log_path and rank == 0) else None
+    for it in range(num_iters):
+        data, state = rollout(environment, net, state, cfg["unroll_length"], gen)
+        if cfg["normalize_observations"]:
+            grp = dist.group.WORLD if world > 1 else None
+            net.norm_obs.update(data["obs"], grp); net.norm_priv.update(data["priv"], grp)
+        loss_metrics = sgd_epoch(net, opt, data, cfg, gen, world)
+        done_steps += steps_per_iter
+        if (it + 1) % eval_every == 0 or it == num_iters - 1:
+            ep_rew = (data["reward"].sum(1)).mean()
+            m = torch.stack([ep_rew, data["done"].mean()])
+            if world > 1:
+                dist.all_reduce(m); m /= world
+            metrics = {"training/sps": done_steps / (time.time() - t0), "training/walltime": time.time() - t0,
+                       "training/unroll_reward": float(m[0]), "training/done_rate": float(m[1]),
+                       **{f"training/{k}": float(v) for k, v in loss_metrics.items()}}
+            if rank == 0:
+                if log:
+                    log.write(json.dumps({"step": done_steps, **metrics}) + "\n"); log.flush()
+                if progress_fn:
+                    progress_fn(done_steps, metrics)
+                if policy_params_fn:
+                    policy_params_fn(done_steps, net)
+    if log:
+        log.close()
+    return net, metrics
+
+
+def save_checkpoint(path: str, net: PPONetworks):
+    """(normalizer, policy, value) triple like the reference's orbax checkpoint (common/runner.py:68-76)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save({"networks": net.state_dict()}, path)

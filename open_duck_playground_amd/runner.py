@@ -1,0 +1,78 @@
+"""Runs training for Open Duck Mini V2 (mirror of reference playground/open_duck_mini_v2/runner.py and
+playground/common/runner.py).  Same flags as the reference (runner.py:36-56) plus additive ones
+(--num_envs, --seed, --device, --no_randomize).  Launch with torchrun for multi-GPU data parallelism.
+
+    python -m open_duck_playground_amd.runner --task flat_terrain --num_timesteps 150000000
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from datetime import datetime
+
+import numpy as np
+
+
+class OpenDuckMiniV2Runner:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from . import joystick
+        from .ppo import train as ppo_train
+        self.args = args
+        self.output_dir = os.path.join(os.getcwd(), args.output_dir)
+        available_envs = {"joystick": joystick.Joystick}   # "standing" is the next env to land
+        if args.env not in available_envs:
+            raise ValueError(f"Unknown env {args.env}")
+        self.world = int(os.environ.get("WORLD_SIZE", "1")); self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        device = args.device if self.world == 1 else local_rank
+        torch.cuda.set_device(device)
+        n_local = args.num_envs // self.world
+        self.env = available_envs[args.env](task=args.task, num_envs=n_local, device=device, env_id_offset=self.rank * n_local)
+        self.action_size = self.env.action_size
+        self.obs_size = int(self.env.observation_size["state"][0])
+        self.randomizer = None if args.no_randomize else (lambda env: env.randomize(np.random.default_rng(args.seed + 7919 * self.rank)))
+        self.ppo = ppo_train
+        print(f"Observation size: {self.obs_size}")
+
+    def progress_callback(self, num_steps, metrics):
+        print("-----------")
+        print(f'STEP: {num_steps} reward: {metrics.get("training/unroll_reward")} sps: {metrics.get("training/sps"):.0f}')
+        print("-----------")
+
+    def policy_params_fn(self, current_step, net):
+        d = datetime.now().strftime("%Y_%m_%d_%H%M%S")
+        path = f"{self.output_dir}/{d}_{current_step}.pt"
+        print(f"Saving checkpoint (step: {current_step}): {path}")
+        self.ppo.save_checkpoint(path, net)
+
+    def train(self):
+        os.makedirs(self.output_dir, exist_ok=True)
+        return self.ppo.train(self.env, num_timesteps=self.args.num_timesteps, progress_fn=self.progress_callback,
+                              policy_params_fn=self.policy_params_fn, restore_checkpoint_path=self.args.restore_checkpoint_path,
+                              seed=self.args.seed, randomization_fn=self.randomizer, log_path=os.path.join(self.output_dir, "metrics.jsonl"),
+                              num_envs=self.args.num_envs)
+
+
+def main():
+    parser = argparse.ArgumentParser(description="Open Duck Mini Runner Script")
+    parser.add_argument("--output_dir", type=str, default="checkpoints", help="Where to save the checkpoints")
+    parser.add_argument("--num_timesteps", type=int, default=150000000)
+    parser.add_argument("--env", type=str, default="joystick", help="env")
+    parser.add_argument("--task", type=str, default="flat_terrain", help="Task to run")
+    parser.add_argument("--restore_checkpoint_path", type=str, default=None, help="Resume training from this checkpoint")
+    parser.add_argument("--num_envs", type=int, default=8192)
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--device", type=int, default=0)
+    parser.add_argument("--no_randomize", action="store_true")
+    args = parser.parse_args()
+    runner = OpenDuckMiniV2Runner(args)
+    runner.train()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""CPU checks: the C-ABI library loads and exports every symbol include/odk.h declares (no compute calls
+without a GPU); model compiler / kernel tables / blob are self-consistent and match SURVEY Appendix A."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_libodk_exports_every_header_symbol():
+    from open_duck_playground_amd import engine
+    engine.build_library()
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "odk.h")).read()
+    declared = sorted(set(re.findall(r"\b(odk_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"libodk.so does not export {name}"
+    assert set(engine.EXPORTED_SYMBOLS) <= set(declared)
+
+
+def test_engine_refuses_to_run_without_gpu(model_a):
+    import torch
+    from open_duck_playground_amd import engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(engine.OdkError):
+        engine.Batch(model_a, 4)
+
+
+def test_default_config_matches_reference_defaults():
+    from open_duck_playground_amd import engine
+    c = engine.default_config()   # odk_default_config == joystick.py:49-102
+    assert (c.ctrl_dt, c.action_scale, c.dof_vel_scale) == pytest.approx((0.02, 0.25, 0.05))
+    assert c.max_motor_velocity == pytest.approx(5.24)
+    assert list(c.reward_scales) == pytest.approx([2.5, 6.0, -1e-3, -0.5, -0.2, 20.0, 1.0])
+    assert list(c.qpos_noise_scale)[:14] == pytest.approx([0.03, 0.03, 0.03, 0.05, 0.08, 0.03, 0.03, 0.03, 0.05, 0.08, 0, 0, 0, 0])  # BUG-COMPAT
+    assert (c.episode_length, c.n_substeps, c.autoreset) == (1000, 10, 1)
+
+
+def test_model_dimension_table(model_a, model_b):
+    # SURVEY.md Appendix A
+    assert (model_a.nq, model_a.nv, model_a.nu, model_a.nbody, model_a.njnt) == (21, 20, 14, 18, 15)
+    assert (model_b.nq, model_b.nv, model_b.nu, model_b.nbody, model_b.njnt) == (31, 30, 14, 18, 25)
+    for m in (model_a, model_b):
+        assert m.nsensordata == 46 and int(m.a["ngeom"][0]) == 47
+        assert m.a["body_mass"].sum() == pytest.approx(2.10714, abs=1e-4)
+        assert m.geom_id("floor") == 46 and m.geom_id("left_foot_bottom_tpu") == 18 and m.geom_id("right_foot_bottom_tpu") == 43
+        assert list(m.a["cgeom_vertnum"]) == [17, 17, 0] and list(m.a["cgeom_facenum"]) == [30, 30, 0]
+        assert m.a["opt_iterations"][0] == 1 and m.a["opt_ls_iterations"][0] == 5 and m.a["opt_eulerdamp"][0] == 0
+        assert m.a["opt_timestep"][0] == pytest.approx(0.002)
+        assert m.body_id("base") == 1 and m.a["body_mass"][1] == 0.0
+        assert list(m.a["sensor_adr"]) == [0, 3, 6, 9, 12, 15, 18, 21, 24, 28, 31, 34, 37, 40, 43]
+        np.testing.assert_allclose(m.a["cgeom_friction"][2], [0.6, 0.005, 0.0001])
+    assert model_a.a["actuator_gainprm0"][0] == pytest.approx(13.37) and model_b.a["actuator_gainprm0"][0] == pytest.approx(17.11)
+    np.testing.assert_allclose(model_a.a["key_qpos"][:7], [0, 0, 0.15, 1, 0, 0, 0])
+    np.testing.assert_allclose(model_a.a["actuator_ctrlrange"], model_a.a["jnt_range"][1:])   # inheritrange="1"
+
+
+def test_blob_roundtrip_and_tables(model_a, model_b):
+    from open_duck_playground_amd.model import unpack_blob
+    from open_duck_playground_amd.tables import build_kernel_tables
+    for m in (model_a, model_b):
+        arrays = unpack_blob(m.blob())
+        np.testing.assert_array_equal(arrays["body_parentid"], m.a["body_parentid"])
+        np.testing.assert_allclose(arrays["qpos0"], m.a["qpos0"])
+        t = build_kernel_tables(m.a)
+        nv = m.nv
+        depth, adr, Mi, Mj = t["k_dof_depth"], t["k_dof_Madr"], t["k_M_i"], t["k_M_j"]
+        assert int(t["k_nM"][0]) == int((depth + 1).sum()) == len(Mi)
+        parent = m.a["dof_parentid"]
+        for i in range(nv):
+            # row i lists its ancestors root-first; the diagonal sits at adr + depth
+            assert Mi[adr[i] + depth[i]] == i and Mj[adr[i] + depth[i]] == i
+            j, c = i, depth[i]
+            while j >= 0:
+                assert Mj[adr[i] + c] == j
+                j, c = parent[j], c - 1
+            anc = {int(Mj[adr[i] + c]) for c in range(depth[i])}
+            assert {b for b in range(nv) if (int(t["k_dof_ancmask"][i]) >> b) & 1} == anc
+        for i in range(nv):
+            desc = {k for k in range(nv) if (int(t["k_dof_ancmask"][k]) >> i) & 1}
+            assert {b for b in range(nv) if (int(t["k_dof_descmask"][i]) >> b) & 1} == desc
+        # virtual tree: every kinematic ancestor stays an ancestor; the right leg additionally hangs below the left leg
+        for i in range(nv):
+            assert (int(t["k_vdof_ancmask"][i]) & int(t["k_dof_ancmask"][i])) == int(t["k_dof_ancmask"][i])
+        src = t["k_H_src"]
+        for p, (i, j) in enumerate(zip(t["k_H_i"], t["k_H_j"])):
+            if src[p] >= 0:
+                assert (Mi[src[p]], Mj[src[p]]) == (i, j)
+        assert (t["k_foot_dofmask"].sum(axis=1) == [6 + (nv - 6 - 4) // 2] * 2).all()
+
+
+def test_unknown_task_and_env_errors():
+    from open_duck_playground_amd import constants
+    with pytest.raises(KeyError):     # reference constants.py:28-34
+        constants.task_to_model("no_such_task")
+    with pytest.raises(KeyError):     # rough_terrain's XML is missing in the reference too (constants.py:23)
+        constants.task_to_model("rough_terrain")
+
+
+def test_domain_randomize_host_mirror(model_b):
+    from open_duck_playground_amd import randomize
+    f, axes = randomize.domain_randomize(model_b, np.random.default_rng(0), 256)
+    assert set(axes) == {"geom_friction", "body_ipos", "dof_frictionloss", "dof_armature", "body_mass", "qpos0", "actuator_gainprm", "actuator_biasprm"}
+    assert f["body_mass"].shape == (256, 18) and f["dof_frictionloss"].shape == (256, 14)
+    assert ((f["dof_frictionloss"] >= 0.068 * 0.9 - 1e-9) & (f["dof_frictionloss"] <= 0.068 * 1.1 + 1e-9)).all()
+    assert ((f["dof_armature"] >= 0.027 - 1e-9) & (f["dof_armature"] <= 0.027 * 1.05 + 1e-9)).all()
+    assert (np.abs(f["body_mass"][:, 1]) <= 0.1).all() and (f["body_mass"][:, 1] < 0).any()   # BUG-COMPAT: massless base gets +-0.1 kg
+    np.testing.assert_allclose(f["actuator_biasprm"], -f["actuator_gainprm"])
+    assert (np.abs(f["qpos0"]) <= 0.03 + 1e-12).all()

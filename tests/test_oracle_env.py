@@ -1,0 +1,138 @@
+"""Known-answer tests of the oracle's env logic, written from the cited reference lines
+(SURVEY.md 8a rows a3-a9, a13, a14): no importable reference exists for these rows."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture()
+def env(oracle_mod, model_a, prm_arrays):
+    om = oracle_mod.OracleModel(model_a.blob())
+    prm = oracle_mod.OraclePRM(prm_arrays)
+    e = oracle_mod.OracleEnv(om, prm)
+    e._keep = (om, prm)
+    return e
+
+
+def test_reset_state_and_obs_layout(env, model_a):
+    env.cfg["noise_level"][0] = 0.0
+    env.reset(3, 7)
+    q = env.data["qpos"][:21]
+    home = model_a.a["key_qpos"]
+    assert abs(q[0]) <= 0.05 and abs(q[1]) <= 0.05 and q[2] == pytest.approx(0.15)   # joystick.py:213-221
+    assert np.linalg.norm(q[3:7]) == pytest.approx(1.0) and q[4] == 0 and q[5] == 0    # pure yaw (:223-231)
+    ratio = q[7:][np.abs(home[7:]) > 0] / home[7:][np.abs(home[7:]) > 0]
+    assert ((ratio >= 0.5) & (ratio <= 1.5)).all()                                     # multiplied, not added (:237-243)
+    assert (np.abs(env.data["qvel"][:6]) <= 0.05).all() and (env.data["qvel"][6:20] == 0).all()
+    obs, priv = env["obs"][:101], env["priv"][:212]
+    np.testing.assert_allclose(obs[6:13], env["command"])                             # Appendix B layout
+    np.testing.assert_allclose(obs[13:27], q[7:] - home[7:], atol=1e-12)
+    np.testing.assert_allclose(obs[41:83], 0)                                         # three action histories
+    np.testing.assert_allclose(obs[83:97], model_a.a["key_ctrl"])                     # motor_targets = default_actuator (:285)
+    np.testing.assert_allclose(obs[99:101], 0)                                        # imitation_phase zeros at reset (:301)
+    np.testing.assert_allclose(priv[:101], obs)
+    np.testing.assert_allclose(priv[101:104], env.data["sensordata"][0:3])            # gyro
+    np.testing.assert_allclose(priv[104:107], env.data["sensordata"][6:9])            # accelerometer, no +1.3 (Appendix E.3)
+    assert priv[144] == pytest.approx(q[2])                                           # root height
+    np.testing.assert_allclose(priv[161:164], env.data["sensordata"][31:34])          # feet_vel: LEFT foot first (A.5)
+    np.testing.assert_allclose(priv[164:167], env.data["sensordata"][28:31])
+    np.testing.assert_allclose(priv[169:209], env["current_reference_motion"])
+    assert priv[209] == 0
+    assert 250 <= env.ints("push_interval_steps")[0] <= 500                           # U(5,10) s / 0.02 (:263-269)
+    assert env["reward"][0] == 0 and env["done"][0] == 0
+
+
+def test_action_delay_ring_and_motor_speed_limit(env, model_a):
+    env.cfg["noise_level"][0] = 0.0
+    env.cfg["push_enable"][0] = 0.0
+    env.reset(1, 0)
+    acts = [np.full(14, v) for v in (0.4, -0.8, 1.0)]
+    prev = np.array(env["motor_targets"][:14])
+    for t, a in enumerate(acts):
+        env.step(a)
+        hist = env["action_history"][:42].reshape(3, 14)
+        for k in range(min(t + 1, 3)):
+            np.testing.assert_allclose(hist[k], acts[t - k])                          # roll by nu, newest first (:362-367)
+        mt = np.array(env["motor_targets"][:14])
+        assert (np.abs(mt - prev) <= 5.24 * 0.02 + 1e-12).all()                       # speed limit (:408-417)
+        cands = [model_a.a["key_ctrl"] + 0.25 * hist[k] for k in range(3)]           # delayed action is one of the ring slots
+        clipped = [np.clip(c, prev - 5.24 * 0.02, prev + 5.24 * 0.02) for c in cands]
+        assert any(np.allclose(mt, c) for c in clipped)
+        np.testing.assert_allclose(env["last_act"][:14], a)
+        prev = mt
+    np.testing.assert_allclose(env["last_last_act"][:14], acts[1]); np.testing.assert_allclose(env["last_last_last_act"][:14], acts[0])
+    assert env.ints("imitation_i")[0] == 3
+    ph = 2 * np.pi * 3 / 27
+    np.testing.assert_allclose(env["obs"][99:101], [np.cos(ph), np.sin(ph)], atol=1e-6)   # (:325-343)
+
+
+def test_reward_clip_alive_and_metrics(env):
+    env.cfg["noise_level"][0] = 0.0
+    env.cfg["push_enable"][0] = 0.0
+    env.reset(2, 0)
+    env.step(np.zeros(14))
+    m = env["metrics"][:8]
+    assert m[5] == pytest.approx(20.0)                        # alive x 20 (joystick.py:84)
+    assert m[2] >= 0 and m[3] >= 0 and m[4] >= 0              # costs are reported positive (:470-476)
+    total = m[0] + m[1] - m[2] - m[3] - m[4] + m[5] + m[6]
+    assert env["reward"][0] == pytest.approx(np.clip(total * 0.02, 0, 10000), rel=1e-12)   # (:447)
+    env.cfg["reward_scales"][5] = -1000.0                     # force a negative total -> clipped to zero
+    env.step(np.zeros(14))
+    assert env["reward"][0] == 0.0
+
+
+def test_termination_autoreset_and_truncation(env):
+    env.cfg["noise_level"][0] = 0.0
+    env.cfg["push_enable"][0] = 0.0
+    env.cfg["episode_length"][0] = 5
+    env.reset(4, 0)
+    first_q = np.array(env.data["qpos"][:21]); first_obs = np.array(env["obs"][:101])
+    for t in range(5):
+        env.step(np.zeros(14))
+        if t < 4:
+            assert env["done"][0] == 0 and env["truncation"][0] == 0
+    assert env["done"][0] == 1 and env["truncation"][0] == 1                         # EpisodeWrapper: steps >= episode_length
+    np.testing.assert_allclose(env.data["qpos"][:21], first_q)                       # AutoReset: data <- first_state
+    np.testing.assert_allclose(env["obs"][:101], first_obs)                          # obs <- first_obs
+    assert env.ints("imitation_i")[0] == 5                                           # info is NOT reset
+    env.step(np.zeros(14))
+    assert env["ep_steps"][0] == 1                                                   # steps restart after done
+    # fall termination: flip the robot upside down -> upvector.z < 0 (:483-485)
+    env.cfg["episode_length"][0] = 1000
+    env.data["qpos"][3:7] = [0, 1, 0, 0]
+    env.data["qpos"][2] = 0.5
+    env.step(np.zeros(14))
+    assert env["done"][0] == 1 and env["truncation"][0] == 0
+
+
+def test_command_resample_after_500_steps(env):
+    env.cfg["noise_level"][0] = 0.0
+    env.cfg["push_enable"][0] = 0.0
+    env.cfg["episode_length"][0] = 100000
+    env.cfg["n_substeps"][0] = 1          # keep it quick: the counters do not depend on the physics
+    env.reset(5, 0)
+    cmd0 = np.array(env["command"])
+    for t in range(500):
+        env.step(np.zeros(14))
+        if env["done"][0]:
+            env.ints("step")[0] = t + 1   # a fall would reset the counter; keep counting for this test
+    np.testing.assert_allclose(env["command"], cmd0)      # step == 500 is not > 500 (:456-461)
+    env.ints("step")[0] = 500
+    env.step(np.zeros(14))
+    assert env.ints("step")[0] == 0                        # reset to 0 when step > 500 (:462-466)
+    lo = np.array([-0.15, -0.2, -1.0, -0.34, -0.78, -1.5, -0.5]); hi = np.array([0.15, 0.2, 1.0, 1.1, 0.78, 1.5, 0.5])
+    c = np.array(env["command"])
+    assert ((c >= lo) & (c <= hi)).all() or (c == 0).all()
+
+
+def test_rng_stream_is_counter_based_and_env_unique(oracle_mod):
+    L = oracle_mod.lib()
+    import ctypes
+    keys = set()
+    for e in range(64):
+        k = (ctypes.c_uint32 * 2)()
+        L.lib.odko_env_key(0, e, k)
+        keys.add((k[0], k[1]))
+    assert len(keys) == 64
+    u = [L.lib.odko_rng_uniform(1, 2, 3, i) for i in range(1000)]
+    assert 0 <= min(u) and max(u) < 1 and abs(np.mean(u) - 0.5) < 0.05
+    assert L.lib.odko_rng_uniform(1, 2, 3, 5) == L.lib.odko_rng_uniform(1, 2, 3, 5)
