@@ -116,6 +116,11 @@ def main():
     value = world * args.envs * args.steps / elapsed
 
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+        if args.task == "flat_terrain" and args.envs == 8192 and os.path.exists(tpath):
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, profiles/README.md)
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         bytes_per_launch = BYTES_PER_ENV_STEP.get(args.task, 2844) * args.envs
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         valu = args.envs * FLOP_PER_ENV_STEP / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
@@ -130,7 +135,7 @@ def main():
                        "lanes_per_env": batch.cfg.lanes_per_env or 32, "parallelism": f"env-sharded x{world}, no collective",
                        "done_fraction_last_step": round(done_frac, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "step_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "fused env step is not HBM-bound (SURVEY.md 0.4); secondary roof = FP32 VALU",
