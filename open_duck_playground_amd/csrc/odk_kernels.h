@@ -104,6 +104,7 @@ struct Shape {
   static constexpr int S_FF = 12;     // [2][6] foot wrench sums
   static constexpr int S_K = 24;      // [3][36] K_L, K_R, K_X
   static constexpr int S_VF2 = 132;   // [2][6] second foot twist (warmstart candidate)
+  static constexpr int S_FFX = 144;   // [6] wrench sum of the foot-foot rows
   static constexpr int S_MISC = 156;  // misc scalars (16)
   static constexpr int S_PROF = 172;  // [20] per-phase cycle counters (ODK_PROFILE builds)
 };
@@ -902,44 +903,66 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   bool quad_fl = false;
   if (lane < nfl) { fl_cost(jar_fl, f_fl); quad_fl = (jar_fl > -fl_rf) && (jar_fl < fl_rf); }
   if (st.d_lim_on) quad_cost(lim_D, jar_lim, f_lim);
-  for (int rc = lane; rc < S::NCROW; rc += G) {
-    const int r = r0c + rc;
-    float fo2;
-    quad_cost(ED[r], JAR[r], fo2);
-    JV[r] = fo2;
-  }
   // friction-row quantities are owned by lane = row; the dof that needs them is another lane: hand over through LDS
   if (lane < nfl) { MV[fs.dof] = f_fl; MA[fs.dof] = quad_fl ? fs.D : 0.0f; }
-  ODK_SYNC();
   const bool c_act[3] = {fminf(fminf(CDIST[0], CDIST[1]), fminf(CDIST[2], CDIST[3])) < 0, fminf(fminf(CDIST[4], CDIST[5]), fminf(CDIST[6], CDIST[7])) < 0,
                          fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0};
-  if (lane < 12) {  // FF[f][k] = sum over the foot's contact rows of w_r[k] f_r   (pair 2: +right, -left)
-    const int f = lane / 6, k = lane % 6;
-    float s = 0;
-    if (c_act[f]) for (int rc = 16 * f; rc < 16 * f + 16; rc++) s += W[6 * rc + k] * JV[r0c + rc];
-    if (c_act[2]) for (int rc = 32; rc < 48; rc++) s += (f ? 1.0f : -1.0f) * W[6 * rc + k] * JV[r0c + rc];
-    SCR[S::S_FF + lane] = s;
-  }
-  // K blocks: K_f[a][b] = sum_r D_r [active] w_r[a] w_r[b]; rows of pair 2 add to both feet and form K_X
-  for (int t = lane; t < 108; t += G) {
-    const int blk = t / 36, a = (t % 36) / 6, b2 = t % 6;
-    float s = 0;
-    if (blk < 2 && c_act[blk]) {
-      for (int rc = 16 * blk; rc < 16 * blk + 16; rc++) {
-        const int r = r0c + rc;
-        const float act = (ED[r] > 0 && JAR[r] < 0) ? ED[r] : 0.0f;
-        s += act * W[6 * rc + a] * W[6 * rc + b2];
+  // Foot wrench sums FF_f = sum_r w_r f_r and 6x6 blocks K_f = sum_r D_r [active] w_r w_r^T.  Contact row rc sits in
+  // lane rc: rows 0-15 (left foot), 16-31 (right foot) and 32-47 (foot-foot) are exactly the 16-lane DPP rows, so
+  // each sum is four DPP adds; lane 0 of a row stores its block.  (G = 32: the foot-foot rows are a second slot.)
+  {
+    constexpr int NSLOT = (S::NCROW + G - 1) / G;
+    const bool any_ff = __builtin_amdgcn_ballot_w64(c_act[2]) != 0;   // wave-uniform
+#pragma unroll
+    for (int t = 0; t < NSLOT; t++) {
+      if (t * G >= 32 && !any_ff) continue;   // foot-foot slot with nothing active anywhere in the wave
+      const int rc = lane + t * G;
+      const bool on = rc < S::NCROW;
+      const int rcl = on ? rc : 0, r = r0c + rcl;
+      float w[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) w[k] = W[6 * rcl + k];
+      const float D = ED[r], jar = JAR[r];
+      const float act = (on && D > 0 && jar < 0) ? D : 0.0f;
+      const float fr = -act * jar;
+      float v[27];
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[k] = fr * w[k];
+      {
+        int q = 6;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+          const float aw = act * w[a];
+#pragma unroll
+          for (int b2 = a; b2 < 6; b2++) v[q++] = aw * w[b2];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 27; q++) {
+        float x = v[q];
+        x += ODK_DPP(x, 0xB1, 0xF); x += ODK_DPP(x, 0x4E, 0xF); x += ODK_DPP(x, 0x141, 0xF); x += ODK_DPP(x, 0x140, 0xF);
+        v[q] = x;
+      }
+      if (on && (lane & 15) == 0) {
+        const int blk = rc >> 4;   // 0 left, 1 right, 2 foot-foot
+        float* FFb = SCR + (blk < 2 ? S::S_FF + 6 * blk : S::S_FFX);
+        float* Kb = SCR + S::S_K + 36 * blk;
+#pragma unroll
+        for (int k = 0; k < 6; k++) FFb[k] = v[k];
+        int q = 6;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+          for (int b2 = a; b2 < 6; b2++) { Kb[6 * a + b2] = v[q]; Kb[6 * b2 + a] = v[q]; q++; }
       }
     }
-    float sx = 0;
-    if (c_act[2]) {
-      for (int rc = 32; rc < 48; rc++) {
-        const int r = r0c + rc;
-        const float act = (ED[r] > 0 && JAR[r] < 0) ? ED[r] : 0.0f;
-        sx += act * W[6 * rc + a] * W[6 * rc + b2];
-      }
+    ODK_SYNC();
+    if (!any_ff) {
+      for (int t2 = lane; t2 < 36; t2 += G) SCR[S::S_K + 72 + t2] = 0.0f;
+    } else {   // rows of the foot-foot pair act on both feet: K_L += K_X, K_R += K_X, FF_L -= FF_X, FF_R += FF_X
+      for (int t2 = lane; t2 < 36; t2 += G) { const float kx = SCR[S::S_K + 72 + t2]; SCR[S::S_K + t2] += kx; SCR[S::S_K + 36 + t2] += kx; }
+      if (lane < 6) { const float fx = SCR[S::S_FFX + lane]; SCR[S::S_FF + lane] -= fx; SCR[S::S_FF + 6 + lane] += fx; }
     }
-    SCR[S::S_K + t] = (blk < 2) ? s + sx : sx;
   }
   ODK_SYNC();
   const bool ff_active = c_act[2] && (SCR[S::S_K + 72 + 21] != 0.0f || SCR[S::S_K + 72 + 28] != 0.0f || SCR[S::S_K + 72 + 35] != 0.0f);
