@@ -668,6 +668,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.F("dof_armature", m.dof_armature, MAXV); B.F("dof_damping", m.dof_damping, MAXV); B.F("dof_frictionloss", m.dof_frictionloss, MAXV);
   B.F("dof_invweight0", m.dof_invweight0, MAXV);
   B.I("k_nM", &m.nM, 1); B.I("k_M_i", m.M_i, MAXNZ); B.I("k_M_j", m.M_j, MAXNZ);
+  B.I("k_nchain", &m.nchain, 1); B.I("k_chain_first", m.chain_first, 3); B.I("k_chain_len", m.chain_len, 3);
   for (int d = 0; d < MAXV; d++) { m.dof_qadr[d] = -1; m.dof_jnt[d] = -1; }
   for (int j = 1; j < m.nj; j++) {
     const int d = m.jnt_dofadr[j];

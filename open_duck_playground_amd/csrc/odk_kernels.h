@@ -29,6 +29,8 @@ namespace odk {
 // One workgroup == one wavefront: DS (LDS) instructions of a wave are issued and serviced in order, so
 // cross-lane hand-offs through LDS need no s_barrier and no s_waitcnt -- only a compiler barrier that keeps
 // the LDS accesses in program order (and stops values being cached in registers across the hand-off).
+// NOTE: never put __restrict__ on an LDS pointer: with noalias the optimiser may treat the barrier as not
+// touching that memory and reuse a value loaded before another lane's store.
 #define ODK_SYNC() asm volatile("" ::: "memory")
 
 constexpr float MINVAL_F = 1e-15f;
@@ -53,6 +55,7 @@ struct Shape {
   static constexpr int DT = DT_;    // max dof depth, kinematic tree
   static constexpr int DV = DV_;    // max dof depth, virtual (Hessian) tree
   static constexpr int NCROW = 48;  // contact rows
+  static constexpr int CL = (NV_ == 20) ? 5 : 0;   // max chain length for the in-register chain solver (0: generic path)
   // persistent over the env step
   static constexpr int O_QPOS = 0;
   static constexpr int O_QVEL = O_QPOS + NQ;
@@ -245,6 +248,7 @@ struct Statics {
   static constexpr int NME = (S::NM + G - 1) / G;   // inertia entries per lane
   static constexpr int NHE = (S::NH + G - 1) / G;   // Hessian entries per lane
   int j_qadr, j_dadr;                    // joint role (sin/cos phase, Euler)
+  int c_len, c_idx, c_n;                 // c_len > 0 on the lane of a chain's first dof (length, chain index); c_n chains
   int d_on, d_body, d_depth, d_Madr, d_ancmask, d_descmask, d_vdepth, d_vMadr, d_vancmask, d_vdescmask;
   int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
   int d_qadr, d_lim_on;                  // hinge qpos address (-1: free joint); has a limit row
@@ -266,6 +270,8 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
     st.j_qadr = on ? m->jnt_qposadr[on ? lane : 0] : -1;
     st.j_dadr = m->jnt_dofadr[on ? lane : 0];
   }
+  st.c_len = 0; st.c_idx = 0; st.c_n = m->nchain;
+  for (int c = 0; c < 3; c++) if (c < m->nchain && lane == m->chain_first[c]) { st.c_len = m->chain_len[c]; st.c_idx = c; }
   const int i = lane < S::NV ? lane : 0;
   st.d_on = lane < S::NV;
   st.d_body = m->dof_body[i];
@@ -328,7 +334,7 @@ __device__ __forceinline__ int load_hent(const DevModel* __restrict__ m, int p, 
 // Sparse L^T D L on the tree layout (row i = [L(i, ancestor at depth 0..d-1), D_i]).  Each lane keeps its
 // own row in registers; at step k lane k publishes its finished row to LDS and the ancestors of k fold it in.
 template <int G, int DMAX, int NVT>
-__device__ __forceinline__ void factor_rows(float* __restrict__ A, int lane, int on, int di, int ai, int descmask, int depth_st, int madr_st) {
+__device__ __forceinline__ void factor_rows(float* A, int lane, int on, int di, int ai, int descmask, int depth_st, int madr_st) {
   // all LDS loads are unconditional (in-bounds of the env's LDS image even when they run past a row) and
   // masked afterwards with selects: a conditional load costs a branch and a full LDS round trip each
   float row[DMAX > 0 ? DMAX : 1];
@@ -367,7 +373,7 @@ __device__ __forceinline__ void factor_rows(float* __restrict__ A, int lane, int
 
 // x <- (L^T D L)^-1 x for the vector whose i-th element is held by lane i (returned the same way)
 template <int G, int NVT>
-__device__ __forceinline__ float solve_rows(const float* __restrict__ A, float xi, int lane, int on, int di, int ai, int ancmask, int descmask,
+__device__ __forceinline__ float solve_rows(const float* A, float xi, int lane, int on, int di, int ai, int ancmask, int descmask,
                                             int depth_st, int madr_st) {
   float Lcol[NVT], Lrow[NVT];
 #pragma unroll
@@ -385,6 +391,145 @@ __device__ __forceinline__ float solve_rows(const float* __restrict__ A, float x
 #pragma unroll
   for (int j = 0; j < NVT - 1; j++) xi -= Lrow[j] * bcast<G>(xi, j);
   return xi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-register solve of (L^T D L) x = b for a "tree of chains" (floating base + up to three serial chains), the
+// shape of this robot.  The matrices are tiny (6 + 5 + 4 + 5), so lane-parallel elimination is bound by ~19
+// dependent hand-offs; instead ONE lane eliminates a whole chain block in its registers (dense, fully unrolled),
+// the three chains run in three lanes at once, lane 0 finishes the 6x6 base block with the chains' Schur
+// complements, and the chains back-substitute.  Two LDS hand-offs in total.  A is the tree layout (read only);
+// VEC holds b on entry and x on exit (LDS); XCH is >= 87 floats of LDS scratch.
+template <class S, int G>
+__device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* XCH,
+                                            const Statics<S, G>& st, int lane) {
+  constexpr int CL = S::CL > 0 ? S::CL : 1;
+  constexpr int NB6 = 6;
+  const bool head = st.c_len > 0;
+  const int d0 = st.d_depth;   // on a chain-head lane: depth of the chain's first dof (= 6)
+  float T[CL][CL], Cb[CL][NB6], y[CL], dinv[CL], Sx[21], rb[NB6];
+  // ---- load the chain block (rows beyond the chain's length are identity padding)
+#pragma unroll
+  for (int p = 0; p < CL; p++) {
+    const bool valid = head && p < st.c_len;
+    const int radr = valid ? st.d_Madr + p * (d0 + 1) + (p * (p - 1)) / 2 : 0;
+#pragma unroll
+    for (int b = 0; b < NB6; b++) { const float v = A[radr + b]; Cb[p][b] = valid ? v : 0.0f; }
+#pragma unroll
+    for (int q = 0; q <= p; q++) { const float v = A[radr + d0 + q]; T[p][q] = valid ? v : (q == p ? 1.0f : 0.0f); }
+    const float bv = VEC[valid ? lane + p : 0];
+    y[p] = valid ? bv : 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < 21; q++) Sx[q] = 0.0f;
+#pragma unroll
+  for (int b = 0; b < NB6; b++) rb[b] = 0.0f;
+  // ---- eliminate the chain from its leaf: L entries replace T / Cb, y <- L^-T b, base gets Schur terms
+#pragma unroll
+  for (int k = CL - 1; k >= 0; k--) {
+    const float inv = __builtin_amdgcn_rcpf(T[k][k]);
+    dinv[k] = inv;
+    const float yk = y[k];
+#pragma unroll
+    for (int i = k - 1; i >= 0; i--) {   // towards the root: row k's entries j <= i are still unscaled
+      const float l = T[k][i] * inv;
+#pragma unroll
+      for (int j = 0; j <= i; j++) T[i][j] = fmaf(-l, T[k][j], T[i][j]);
+#pragma unroll
+      for (int b = 0; b < NB6; b++) Cb[i][b] = fmaf(-l, Cb[k][b], Cb[i][b]);
+      y[i] = fmaf(-l, yk, y[i]);
+      T[k][i] = l;
+    }
+    float lb[NB6];
+#pragma unroll
+    for (int b = 0; b < NB6; b++) lb[b] = Cb[k][b] * inv;
+    {
+      int q = 0;
+#pragma unroll
+      for (int b = 0; b < NB6; b++)
+#pragma unroll
+        for (int b2 = 0; b2 <= b; b2++) { Sx[q] = fmaf(-lb[b], Cb[k][b2], Sx[q]); q++; }
+    }
+#pragma unroll
+    for (int b = 0; b < NB6; b++) { rb[b] = fmaf(-lb[b], yk, rb[b]); Cb[k][b] = lb[b]; }
+  }
+  // ---- hand the Schur complement and rhs contributions to the base lane
+  {
+    const int cidx = st.c_idx;
+    if (head) {
+#pragma unroll
+      for (int q = 0; q < 21; q++) XCH[27 * cidx + q] = Sx[q];
+#pragma unroll
+      for (int b = 0; b < NB6; b++) XCH[27 * cidx + 21 + b] = rb[b];
+    }
+  }
+  ODK_SYNC();
+  // ---- base 6x6 (meaningful on lane 0): B += sum of Schur terms, factor, solve
+  {
+    float Bm[NB6][NB6], bb[NB6], xb[NB6], binv[NB6];
+    const int nch = st.c_n;   // chains per env (uniform)
+    {
+      int q = 0;
+#pragma unroll
+      for (int b = 0; b < NB6; b++) {
+#pragma unroll
+        for (int b2 = 0; b2 <= b; b2++) {
+          float v = A[q];
+#pragma unroll
+          for (int c = 0; c < 3; c++) { const float sx = XCH[27 * c + q]; v += (c < nch) ? sx : 0.0f; }
+          Bm[b][b2] = v;
+          q++;
+        }
+        float r = VEC[b];
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float rx = XCH[27 * c + 21 + b]; r += (c < nch) ? rx : 0.0f; }
+        bb[b] = r;
+      }
+    }
+#pragma unroll
+    for (int k = NB6 - 1; k >= 0; k--) {
+      const float inv = __builtin_amdgcn_rcpf(Bm[k][k]);
+      binv[k] = inv;
+#pragma unroll
+      for (int i = k - 1; i >= 0; i--) {
+        const float l = Bm[k][i] * inv;
+#pragma unroll
+        for (int j = 0; j <= i; j++) Bm[i][j] = fmaf(-l, Bm[k][j], Bm[i][j]);
+        bb[i] = fmaf(-l, bb[k], bb[i]);
+        Bm[k][i] = l;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NB6; k++) {
+      float x = bb[k] * binv[k];
+#pragma unroll
+      for (int i = 0; i < k; i++) x = fmaf(-Bm[k][i], xb[i], x);
+      xb[k] = x;
+    }
+    ODK_SYNC();   // every lane has read b[0..5] and the exchange area before lane 0 overwrites VEC[0..5]
+    if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < NB6; b++) VEC[b] = xb[b];
+    }
+  }
+  ODK_SYNC();
+  // ---- chains back-substitute with the base solution
+  {
+    float xb[NB6], x[CL];
+#pragma unroll
+    for (int b = 0; b < NB6; b++) xb[b] = VEC[b];
+#pragma unroll
+    for (int k = 0; k < CL; k++) {
+      float v = y[k] * dinv[k];
+#pragma unroll
+      for (int b = 0; b < NB6; b++) v = fmaf(-Cb[k][b], xb[b], v);
+#pragma unroll
+      for (int i = 0; i < k; i++) v = fmaf(-T[k][i], x[i], v);
+      x[k] = v;
+      if (head && k < st.c_len) VEC[lane + k] = v;
+    }
+  }
+  ODK_SYNC();
 }
 
 // impedance / stiffness of one constraint row (mjx constraint._row); returns D = 1/R and aref
@@ -414,7 +559,7 @@ __device__ inline void row_params(const float* solref, const float* solimp, floa
 // One mjx.forward for one env (all G lanes of the group call this together).
 //   flags bit0: compute sensordata / debug outputs (last substep only)
 template <class S, int G>
-__device__ __forceinline__ void forward_env(float* __restrict__ L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane, int flags) {
+__device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane, int flags) {
   constexpr int NV = S::NV, NB = S::NB;
   using ST = Statics<S, G>;
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; float* WARM = L + S::O_WARM; float* CTRL = L + S::O_CTRL;
@@ -627,16 +772,27 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
       for (int k = 0; k < 6; k++) v += CDOF[k * NV + j] * BUF6[k * NV + i];
       if (i == j) v += ARM[i];
       M[lane + t * G] = v;
-      HL[lane + t * G] = v;
     }
   }
   ODK_SYNC();
   ODK_PROF(4);
   // ---------------- P5: qacc_smooth = M^-1 qfrc_smooth; dense symmetric row of M into registers
-  factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
-  ODK_PROF(5);
-  const float qas = solve_rows<G, NV>(HL, qfs, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
-  if (st.d_on) QAS[lane] = qas;
+  float qas;
+  if constexpr (S::CL > 0) {
+    if (st.d_on) QAS[lane] = qfs;
+    ODK_SYNC();
+    chain_solve<S, G>(M, QAS, SCR + S::S_K, st, lane);
+    ODK_PROF(5);
+    qas = st.d_on ? QAS[lane] : 0.0f;
+  } else {
+#pragma unroll
+    for (int t = 0; t < ST::NME; t++) { const int p = lane + t * G; if (p < S::NM) HL[p] = M[p]; }
+    ODK_SYNC();
+    factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
+    ODK_PROF(5);
+    qas = solve_rows<G, NV>(HL, qfs, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
+    if (st.d_on) QAS[lane] = qas;
+  }
   float Mrow[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) {
@@ -1001,6 +1157,43 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   }
   ODK_SYNC();
   ODK_PROF(11);
+  const bool any_ffa = __builtin_amdgcn_ballot_w64(ff_active) != 0;   // wave-uniform: some env has an active foot-foot row
+  float search;
+  if (S::CL > 0 && !any_ffa) {
+    // ---- common case: no foot-foot coupling -> the Hessian has the inertia's own tree pattern
+#pragma unroll
+    for (int t = 0; t < ST::NME; t++) {
+      const int p = lane + t * G;
+      if (p < S::NM) {
+        const int i = m->M_i[p], j = m->M_j[p];
+        const int fi = m->foot_dofmask[0][i] | (m->foot_dofmask[1][i] << 1), fj = m->foot_dofmask[0][j] | (m->foot_dofmask[1][j] << 1);
+        float v = M[p];
+        if (i == j) v += JV[i];
+        const int both = fi & fj;
+        if (both) {
+          float cj[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NV + j];
+          if (both & 1) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += cj[k] * BUF6[k * NV + i];
+          }
+          if (both & 2) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += cj[k] * BUF6B[k * NV + i];
+          }
+        }
+        HL[p] = v;
+      }
+    }
+    if (st.d_on) { MA[lane] = grad; GRAD[lane] = grad; }
+    ODK_SYNC();
+    ODK_PROF(12);
+    chain_solve<S, G>(HL, GRAD, SCR + S::S_K, st, lane);
+    ODK_PROF(13);
+    search = st.d_on ? -GRAD[lane] : 0.0f;
+    ODK_PROF(14);
+  } else {
   // Hessian entries on the virtual-tree layout
   int hent[ST::NHE];
 #pragma unroll
@@ -1043,8 +1236,10 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
   ODK_PROF(12);
   factor_rows<G, S::DV, NV>(HL, lane, st.d_on, st.d_vdepth, st.d_vMadr, st.d_vdescmask, st.d_vdepth, st.d_vMadr);
   ODK_PROF(13);
-  const float search = -solve_rows<G, NV>(HL, grad, lane, st.d_on, st.d_vdepth, st.d_vMadr, st.d_vancmask, st.d_vdescmask, st.d_vdepth, st.d_vMadr);
+  search = -solve_rows<G, NV>(HL, grad, lane, st.d_on, st.d_vdepth, st.d_vMadr, st.d_vancmask, st.d_vdescmask, st.d_vdepth, st.d_vMadr);
   ODK_PROF(14);
+
+  }
 
   // ---- line search (mjx solver._linesearch)
   if (st.d_on) GRAD[lane] = search;
@@ -1243,7 +1438,7 @@ __device__ __forceinline__ void forward_env(float* __restrict__ L, const DevMode
 
 // mjx forward.euler (eulerdamp disabled): qvel += dt qacc; qpos integrated with the NEW qvel
 template <class S, int G>
-__device__ __forceinline__ void euler_env(float* __restrict__ L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane) {
+__device__ __forceinline__ void euler_env(float* L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane) {
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; const float* X = L + S::O_X;
   const float dt = m->dt;
   if (lane < S::NV) QVEL[lane] += dt * X[lane];

@@ -44,6 +44,7 @@ struct DevModel {
   float dof_range[MAXV][2];
   float dof_armature[MAXV], dof_damping[MAXV], dof_frictionloss[MAXV], dof_invweight0[MAXV];
   int M_i[MAXNZ], M_j[MAXNZ];
+  int nchain, chain_first[3], chain_len[3];   // tree of chains below the floating base (0 chains: generic tree)
   // virtual tree (Hessian)
   int vdof_depth[MAXV], vdof_anc[MAXV][MAXV], vdof_Madr[MAXV], vdof_anc_adr[MAXV][MAXV];
   int vdof_ndesc[MAXV], vdof_desc[MAXV][MAXV], vdof_desc_adr[MAXV][MAXV];

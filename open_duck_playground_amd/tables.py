@@ -146,6 +146,24 @@ def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     out["k_dof_ndesc"] = true["ndesc"]; out["k_dof_desc"] = true["desc"]; out["k_dof_desc_adr"] = true["desc_adr"]
     out["k_dof_anc_adr"] = true["anc_adr"]
     out["k_dof_ancmask"] = true["ancmask"]; out["k_dof_descmask"] = true["descmask"]
+    # chains: maximal runs of dofs i, i+1, ... with parent(i+1) = i whose first dof hangs off the last base dof.
+    # A "tree of chains" lets one lane factor a whole chain block in registers (csrc chain_solve).
+    chain_first, chain_len = [], []
+    d = 6
+    is_chain_tree = True
+    while d < nv:
+        if parent[d] != 5:
+            is_chain_tree = False
+            break
+        e = d
+        while e + 1 < nv and parent[e + 1] == e:
+            e += 1
+        chain_first.append(d); chain_len.append(e - d + 1)
+        d = e + 1
+    if not is_chain_tree or len(chain_first) > 3:
+        chain_first, chain_len = [], []
+    out["k_chain_first"] = I(chain_first + [0] * (3 - len(chain_first))); out["k_chain_len"] = I(chain_len + [0] * (3 - len(chain_len)))
+    out["k_nchain"] = I([len(chain_first)])
     # velocity prefix (mj_comVel): strict ancestors, except that the free joint's rotational dofs
     # see only its three translational dofs
     prefix = -np.ones((nv, MAXV), np.int32); nprefix = np.zeros(nv, np.int32)
