@@ -122,6 +122,11 @@ int odk_lds_offset(const odk_batch* b, const char* name);
 int odk_batch_record_size(const odk_batch* b);
 int odk_batch_get_records(odk_batch* b, float* host_records);
 
+/* GAE over row-major [B, T] device arrays (brax ppo.losses.compute_gae, reached through common/runner.py:104-118):
+ * vs and advantages out; truncation / termination are 0/1 floats; bootstrap is [B]. */
+int odk_gae(const float* truncation_dev, const float* termination_dev, const float* rewards_dev, const float* values_dev,
+            const float* bootstrap_dev, float* vs_dev, float* adv_dev, int B, int T, float lambda_, float discount, void* stream);
+
 /* live timing of the most recent odk_step launches with HIP events on the launch stream:
  * returns average milliseconds per launch since the last call (and resets the window) */
 int odk_batch_timing(odk_batch* b, int enable, float* avg_ms, int* launches);

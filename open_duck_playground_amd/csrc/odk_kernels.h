@@ -793,15 +793,21 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     qas = solve_rows<G, NV>(HL, qfs, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
     if (st.d_on) QAS[lane] = qas;
   }
-  float Mrow[NV];
+  // y_i = sum_j M(i, j) v_j with the dense symmetric row of M gathered on the fly (unconditional LDS loads + selects);
+  // recomputed at both uses instead of holding NV registers across the whole solver
+  auto mul_M = [&](float v) -> float {
+    float acc = 0.0f;
 #pragma unroll
-  for (int j = 0; j < NV; j++) {
-    const int aj = ubcast(st.d_Madr, j), dj = ubcast(st.d_depth, j);
-    const bool isanc = (st.d_ancmask >> j) & 1, isdesc = (st.d_descmask >> j) & 1;
-    const int adr = isanc ? st.d_Madr + dj : (isdesc ? aj + st.d_depth : st.d_Madr + st.d_depth);
-    const float v = M[adr];
-    Mrow[j] = (isanc || isdesc || j == lane) ? v : 0.0f;
-  }
+    for (int j = 0; j < NV; j++) {
+      const int aj = ubcast(st.d_Madr, j), dj = ubcast(st.d_depth, j);
+      const bool isanc = (st.d_ancmask >> j) & 1, isdesc = (st.d_descmask >> j) & 1;
+      const int adr = isanc ? st.d_Madr + dj : (isdesc ? aj + st.d_depth : st.d_Madr + st.d_depth);
+      const float mij = M[adr];
+      const float vj = bcast<G>(v, j);
+      acc += (isanc || isdesc || j == lane) ? mij * vj : 0.0f;
+    }
+    return acc;
+  };
   ODK_SYNC();
   ODK_PROF(6);
 
@@ -987,9 +993,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     if (lane < 24) SCR[(which ? S::S_VF2 : S::S_VF) + 6 * f + k] = s;
   }
   // M * warmstart from the register row
-  float ma_w = 0.0f;
-#pragma unroll
-  for (int j = 0; j < NV; j++) ma_w += Mrow[j] * bcast<G>(warm, j);
+  const float ma_w = mul_M(warm);
   const float gw = st.d_on ? (ma_w - qfs) * (warm - qas) : 0.0f;
   ODK_SYNC();
   auto contact_jx = [&](int rc, const float* VF) -> float {
@@ -1243,9 +1247,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 
   // ---- line search (mjx solver._linesearch)
   if (st.d_on) GRAD[lane] = search;
-  float mv = 0.0f;
-#pragma unroll
-  for (int j = 0; j < NV; j++) mv += Mrow[j] * bcast<G>(search, j);
+  const float mv = mul_M(search);
   float sn = st.d_on ? search * search : 0.0f, qg1 = st.d_on ? search * (ma - qfs) : 0.0f, qg2 = st.d_on ? 0.5f * search * mv : 0.0f;
   sn = gsum<G>(sn); qg1 = gsum<G>(qg1); qg2 = gsum<G>(qg2);
   ODK_SYNC();

@@ -94,6 +94,7 @@ def load_library() -> C.CDLL:
     L.odk_batch_record_size.argtypes = [P]
     L.odk_batch_get_records.argtypes = [P, FP]
     L.odk_batch_timing.argtypes = [P, C.c_int, FP, C.POINTER(C.c_int)]
+    L.odk_gae.argtypes = [P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_float, P]
     _lib = L
     return L
 
@@ -102,7 +103,7 @@ EXPORTED_SYMBOLS = (
     "odk_last_error", "odk_default_config", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_batch_create",
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
-    "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing")
+    "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae")
 
 
 def _chk(rc: int):
@@ -127,6 +128,17 @@ def _fp(a: np.ndarray):
 
 def _dp(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def gae(truncation, termination, rewards, values, bootstrap, lambda_: float, discount: float):
+    """compute_gae on the device ([B, T] contiguous float32 CUDA tensors) -> (vs, advantages); one HIP kernel."""
+    import torch
+    B, T = rewards.shape
+    args = [t.contiguous().float() for t in (truncation, termination, rewards, values, bootstrap)]
+    vs, adv = torch.empty_like(args[2]), torch.empty_like(args[2])
+    stream = C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
+    _chk(load_library().odk_gae(*[C.c_void_p(a.data_ptr()) for a in args], C.c_void_p(vs.data_ptr()), C.c_void_p(adv.data_ptr()), B, T, lambda_, discount, stream))
+    return vs, adv
 
 
 class Batch:

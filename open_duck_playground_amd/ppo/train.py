@@ -54,10 +54,14 @@ def ppo_loss(net: PPONetworks, mb: Dict[str, torch.Tensor], cfg: Dict):
     bootstrap = net.values(mb["last_priv"])
     rewards = mb["reward"] * cfg["reward_scaling"]
     termination = mb["done"] * (1.0 - mb["truncation"])
-    tm = lambda x: x.transpose(0, 1)
-    vs, adv = compute_gae(tm(mb["truncation"]), tm(termination), tm(rewards), tm(baseline.detach()), bootstrap.detach(),
-                          cfg["gae_lambda"], cfg["discounting"])
-    vs, adv = tm(vs), tm(adv)
+    if rewards.is_cuda:   # one HIP kernel (csrc gae_kernel) instead of ~150 tiny launches
+        from .. import engine
+        vs, adv = engine.gae(mb["truncation"], termination, rewards, baseline.detach(), bootstrap.detach(), cfg["gae_lambda"], cfg["discounting"])
+    else:
+        tm = lambda x: x.transpose(0, 1)
+        vs, adv = compute_gae(tm(mb["truncation"]), tm(termination), tm(rewards), tm(baseline.detach()), bootstrap.detach(),
+                              cfg["gae_lambda"], cfg["discounting"])
+        vs, adv = tm(vs), tm(adv)
     if cfg["normalize_advantage"]:
         adv = (adv - adv.mean()) / (adv.std() + 1e-8)
     logp = tanh_normal_log_prob(loc, scale, mb["raw_action"])
@@ -84,7 +88,63 @@ def _allreduce_grads(params, world: int, group=None):
         off += n
 
 
-def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Generator, world: int = 1, group=None):
+class GraphedSGD:
+    """One clipped-Adam minibatch step captured in HIP graphs (launch-bound otherwise: ~60 small kernels per step,
+    128 steps per training step).  Two graphs -- (zero_grad, loss, backward) and (clip, Adam) -- so that the
+    data-parallel gradient all-reduce can run between them."""
+
+    def __init__(self, net, opt, cfg, example: Dict[str, torch.Tensor], world: int = 1, group=None):
+        self.net, self.opt, self.cfg, self.world, self.group = net, opt, cfg, world, group
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.static = {k: torch.empty_like(v) for k, v in example.items()}
+        for k, v in example.items():
+            self.static[k].copy_(v)
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=self.params[0].device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):   # warm-up outside capture (allocator, Adam state)
+            for _ in range(2):
+                self._fwd_bwd()
+                self._update()
+        torch.cuda.current_stream().wait_stream(side)
+        self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            self.metrics = self._fwd_bwd()
+        with torch.cuda.graph(self.g2):
+            self._update()
+
+    def _fwd_bwd(self):
+        loss, metrics = ppo_loss(self.net, self.static, self.cfg)
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+        loss.backward()
+        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+        return metrics
+
+    def _update(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+        if self.cfg.get("max_grad_norm"):
+            torch.nn.utils.clip_grad_norm_(self.params, self.cfg["max_grad_norm"], foreach=True)
+        self.opt.step()
+
+    def step(self, mb: Dict[str, torch.Tensor]):
+        for k, v in mb.items():
+            self.static[k].copy_(v)
+        self.g1.replay()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat, group=self.group)
+            self.flat /= self.world
+        self.g2.replay()
+        return self.metrics
+
+
+def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Generator, world: int = 1, group=None, graphed=None):
     """num_updates_per_batch x num_minibatches clipped-Adam steps over one rollout ([B, T, ...] per rank)."""
     B = data["reward"].shape[0]
     nmb = cfg["num_minibatches"]
@@ -94,6 +154,9 @@ def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Gen
         perm = torch.randperm(B, generator=gen, device=data["reward"].device)
         for mbi in perm.chunk(nmb):
             mb = {k: v[mbi] for k, v in data.items()}
+            if graphed is not None:
+                metrics = graphed.step(mb)
+                continue
             loss, metrics = ppo_loss(net, mb, cfg)
             opt.zero_grad(set_to_none=False)
             loss.backward()
@@ -103,6 +166,19 @@ def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Gen
                 torch.nn.utils.clip_grad_norm_(params, cfg["max_grad_norm"])
             opt.step()
     return metrics
+
+
+def make_graphed(net, opt, data, cfg, world: int = 1, group=None):
+    """HIP-graph SGD step for CUDA tensors with B divisible by num_minibatches; None (eager path) otherwise."""
+    B = data["reward"].shape[0]
+    if not data["reward"].is_cuda or B % cfg["num_minibatches"] != 0:
+        return None
+    n = B // cfg["num_minibatches"]
+    try:
+        return GraphedSGD(net, opt, cfg, {k: v[:n] for k, v in data.items()}, world, group)
+    except Exception as e:  # graph capture is an optimisation, never a requirement
+        print(f"[ppo] HIP-graph capture unavailable ({type(e).__name__}: {e}); using eager SGD steps")
+        return None
 
 
 @torch.no_grad()
@@ -142,8 +218,9 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
                       nf["policy_hidden_layer_sizes"], nf["value_hidden_layer_sizes"]).to(dev)
     if restore_checkpoint_path:
         net.load_state_dict(torch.load(restore_checkpoint_path, map_location=dev)["networks"])
-    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=cfg["learning_rate"])
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=cfg["learning_rate"], capturable=dev.type == "cuda")
     gen = torch.Generator(device=dev); gen.manual_seed(seed * 1000 + rank)
+    graphed = None
     if randomization_fn is not None:
         randomization_fn(environment)
     state = environment.reset(seed)
@@ -158,7 +235,9 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
         if cfg["normalize_observations"]:
             grp = dist.group.WORLD if world > 1 else None
             net.norm_obs.update(data["obs"], grp); net.norm_priv.update(data["priv"], grp)
-        loss_metrics = sgd_epoch(net, opt, data, cfg, gen, world)
+        if it == 0 and cfg.get("use_graphs", True):
+            graphed = make_graphed(net, opt, data, cfg, world)
+        loss_metrics = sgd_epoch(net, opt, data, cfg, gen, world, graphed=graphed)
         done_steps += steps_per_iter
         if (it + 1) % eval_every == 0 or it == num_iters - 1:
             ep_rew = (data["reward"].sum(1)).mean()
