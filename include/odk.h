@@ -122,10 +122,29 @@ int odk_lds_offset(const odk_batch* b, const char* name);
 int odk_batch_record_size(const odk_batch* b);
 int odk_batch_get_records(odk_batch* b, float* host_records);
 
-/* GAE over row-major [B, T] device arrays (brax ppo.losses.compute_gae, reached through common/runner.py:104-118):
- * vs and advantages out; truncation / termination are 0/1 floats; bootstrap is [B]. */
+/* ---- learner-side kernels (csrc/odk_learner.hip): the element-wise halves of one PPO minibatch step.  The
+ * reference reaches them through brax ppo.train (common/runner.py:104-118): ppo.losses.compute_gae /
+ * compute_ppo_loss and optax.chain(clip_by_global_norm, adam).  All stream-ordered, graph-capturable. ---- */
+
+/* GAE over row-major [B, T] device arrays: vs and advantages out; truncation / termination are 0/1 floats;
+ * bootstrap is [B].  adv_stats (may be NULL) receives {mean, 1/(std+1e-8)} of the advantages (ddof 0). */
 int odk_gae(const float* truncation_dev, const float* termination_dev, const float* rewards_dev, const float* values_dev,
-            const float* bootstrap_dev, float* vs_dev, float* adv_dev, int B, int T, float lambda_, float discount, void* stream);
+            const float* bootstrap_dev, float* vs_dev, float* adv_dev, float* adv_stats_dev, int B, int T, float lambda_,
+            float discount, void* stream);
+
+/* PPO loss head, forward and backward in one launch.  logits [n, 2*action_size] = (loc | raw scale) of the
+ * tanh-normal policy, noise [n, action_size] ~ N(0,1) for the sampled entropy term, adv_stats from odk_gae (NULL:
+ * no advantage normalisation).  Writes grad_scale * dLoss/dlogits and grad_scale * dLoss/dbaseline, and ADDS
+ * (total, policy, value, entropy) loss to losses[0..3] (caller zeroes them). */
+int odk_ppo_head(const float* logits_dev, const float* raw_action_dev, const float* old_log_prob_dev, const float* adv_dev,
+                 const float* adv_stats_dev, const float* vs_dev, const float* baseline_dev, const float* noise_dev,
+                 float* dlogits_dev, float* dbaseline_dev, float* losses_dev, int n, int action_size, float clipping_epsilon,
+                 float entropy_cost, float grad_scale, void* stream);
+
+/* clip_by_global_norm(max_grad_norm; <= 0 disables) + Adam on flat buffers of n floats.  acc_dev[2] is scratch
+ * owned by the caller: acc[0] = squared gradient norm of this call, acc[1] = step count (zero it once). */
+int odk_adam_clip(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr,
+                  float b1, float b2, float eps, float max_grad_norm, void* stream);
 
 /* live timing of the most recent odk_step launches with HIP events on the launch stream:
  * returns average milliseconds per launch since the last call (and resets the window) */

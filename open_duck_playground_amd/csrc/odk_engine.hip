@@ -501,26 +501,6 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
 }
 
 // ================================================================================================
-// GAE (brax ppo.losses.compute_gae): one thread per trajectory, serial in time.  Row-major [B, T] inputs.
-__global__ void gae_kernel(const float* __restrict__ trunc, const float* __restrict__ term, const float* __restrict__ rew,
-                           const float* __restrict__ val, const float* __restrict__ boot, float* __restrict__ vs, float* __restrict__ adv,
-                           int B, int T, float lambda_, float discount) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const size_t o = (size_t)b * T;
-  float acc = 0.0f, v_next = boot[b], vs_next = boot[b];
-  for (int t = T - 1; t >= 0; t--) {
-    const float mask = 1.0f - trunc[o + t], nt = 1.0f - term[o + t], v = val[o + t], r = rew[o + t];
-    const float delta = (r + discount * nt * v_next - v) * mask;
-    acc = delta + discount * nt * mask * lambda_ * acc;
-    const float vs_t = acc + v;
-    adv[o + t] = (r + discount * nt * vs_next - v) * mask;
-    vs[o + t] = vs_t;
-    v_next = v; vs_next = vs_t;
-  }
-}
-
-// ================================================================================================
 // host side
 static thread_local std::string g_err;
 static int fail(int code, const char* fmt, ...) {
@@ -532,6 +512,7 @@ static int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+int odk_fail_(int code, const char* msg) { return fail(code, "%s", msg); }   // for odk_learner.hip
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(ODK_ERR_HIP, "%s: %s", #x, hipGetErrorString(_e)); } while (0)
 
 struct odk_model { DevModel h; int shape; };  // shape: 0 = A, 1 = B
@@ -994,16 +975,6 @@ extern "C" int odk_physics_step(odk_batch* b, const float* ctrl_dev, int n_subst
   a.action = ctrl_dev; a.n_substeps = n_substeps;
   a.dbg_lds = b->d_dbg;
   HIPCHK(launch(b, K_PHYS, a, (hipStream_t)stream));
-  return ODK_OK;
-}
-
-extern "C" int odk_gae(const float* truncation_dev, const float* termination_dev, const float* rewards_dev, const float* values_dev,
-                       const float* bootstrap_dev, float* vs_dev, float* adv_dev, int B, int T, float lambda_, float discount, void* stream) {
-  if (!truncation_dev || !termination_dev || !rewards_dev || !values_dev || !bootstrap_dev || !vs_dev || !adv_dev || B <= 0 || T <= 0)
-    return fail(ODK_ERR_INVALID, "odk_gae: bad arguments");
-  hipLaunchKernelGGL(gae_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, truncation_dev, termination_dev, rewards_dev, values_dev,
-                     bootstrap_dev, vs_dev, adv_dev, B, T, lambda_, discount);
-  HIPCHK(hipGetLastError());
   return ODK_OK;
 }
 

@@ -1,0 +1,200 @@
+// odk_learner.hip -- learner-side kernels of the PPO training step (reference common/runner.py:104-118 ->
+// brax ppo.losses.compute_ppo_loss / compute_gae, optax clip_by_global_norm + adam), gfx950 only.
+//
+// These are the element-wise halves of one minibatch step: everything around the policy/value GEMMs
+// (which stay on hipBLASLt / MFMA).  Each replaces a chain of 50-150 tiny launches by one launch:
+//   gae_kernel        GAE + advantage normalisation statistics          (1 workgroup)
+//   ppo_head_kernel   tanh-normal log-prob, clipped surrogate, value loss, sampled entropy AND their
+//                     gradients w.r.t. the network outputs              (16 lanes per sample)
+//   sqnorm_kernel     global gradient norm                              (flat gradient buffer)
+//   adam_kernel       clip_by_global_norm + Adam on the flat parameter buffer
+// All launches are stream-ordered on the caller's stream and contain no host synchronisation, so they can be
+// captured into a HIP graph together with the GEMMs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/odk.h"
+
+int odk_fail_(int code, const char* msg);   // odk_engine.hip
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {   // sum over an aligned 16-lane group
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ float block_sum(float v, float* sh) {   // blockDim.x multiple of 64, <= 1024
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int i = 0; i < nw; i++) t += sh[i];
+  return t;
+}
+__device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
+__device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// GAE over row-major [B, T]; one thread per trajectory, serial in time (brax compute_gae); then the
+// population mean / std of the advantages (brax: (adv - mean) / (std + 1e-8), jnp.std => ddof 0).
+// stats[0] = mean, stats[1] = 1 / (std + 1e-8).  Single workgroup.
+__global__ void gae_kernel(const float* __restrict__ trunc, const float* __restrict__ term, const float* __restrict__ rew,
+                           const float* __restrict__ val, const float* __restrict__ boot, float* __restrict__ vs,
+                           float* __restrict__ adv, float* __restrict__ stats, int B, int T, float lambda_, float discount) {
+  __shared__ float sh[16];
+  float s = 0.0f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const size_t o = (size_t)b * T;
+    float acc = 0.0f, v_next = boot[b], vs_next = boot[b];
+    for (int t = T - 1; t >= 0; t--) {
+      const float mask = 1.0f - trunc[o + t], nt = 1.0f - term[o + t], v = val[o + t], r = rew[o + t];
+      const float delta = (r + discount * nt * v_next - v) * mask;
+      acc = delta + discount * nt * mask * lambda_ * acc;
+      const float vs_t = acc + v, a = (r + discount * nt * vs_next - v) * mask;
+      adv[o + t] = a;
+      vs[o + t] = vs_t;
+      s += a;
+      v_next = v; vs_next = vs_t;
+    }
+  }
+  if (!stats) return;
+  const float n = (float)B * (float)T;
+  const float mean = block_sum(s, sh) / n;
+  float q = 0.0f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x)
+    for (int t = 0; t < T; t++) { const float d = adv[(size_t)b * T + t] - mean; q += d * d; }   // own writes: visible
+  const float var = block_sum(q, sh) / n;
+  if (threadIdx.x == 0) { stats[0] = mean; stats[1] = 1.0f / (sqrtf(var) + 1e-8f); }
+}
+
+// One 16-lane row per sample, lane j < A = action dimension j.  logits [n, 2A] = (loc | raw_scale).
+// losses[0..3] += (total, policy, value, entropy) contributions (caller zeroes them).
+__global__ void ppo_head_kernel(const float* __restrict__ logits, const float* __restrict__ raw_action, const float* __restrict__ old_logp,
+                                const float* __restrict__ adv, const float* __restrict__ stats, const float* __restrict__ vs,
+                                const float* __restrict__ baseline, const float* __restrict__ noise, float* __restrict__ dlogits,
+                                float* __restrict__ dbaseline, float* __restrict__ losses, int n, int A, float eps, float entropy_cost,
+                                float grad_scale) {
+  const int lane = threadIdx.x & 15;
+  const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool live = s < n, on = live && lane < A;
+  const int sc = live ? s : n - 1;
+  const float inv_n = 1.0f / (float)n;
+  const float HALF_LOG_2PI = 0.91893853320467274f, LOG2 = 0.69314718055994531f;
+  float loc = 0.f, raw = 0.f, a = 0.f, z = 0.f;
+  if (on) { loc = logits[(size_t)sc * 2 * A + lane]; raw = logits[(size_t)sc * 2 * A + A + lane]; a = raw_action[(size_t)sc * A + lane]; z = noise[(size_t)sc * A + lane]; }
+  const float scale = softplus(raw) + 0.001f, inv_scale = 1.0f / scale, lscale = __logf(scale);
+  const float u = (a - loc) * inv_scale;
+  const float ldj_a = 2.0f * (LOG2 - a - softplus(-2.0f * a));
+  const float lp_j = on ? (-0.5f * u * u - lscale - HALF_LOG_2PI - ldj_a) : 0.0f;
+  const float x = loc + scale * z;
+  const float ldj_x = 2.0f * (LOG2 - x - softplus(-2.0f * x));
+  const float ent_j = on ? (0.5f + HALF_LOG_2PI + lscale + ldj_x) : 0.0f;
+  const float logp = row16_sum(lp_j), ent = row16_sum(ent_j);
+  float advn = adv[sc];
+  if (stats) advn = (advn - stats[0]) * stats[1];
+  const float rho = __expf(logp - old_logp[sc]);
+  const float rc = fminf(fmaxf(rho, 1.0f - eps), 1.0f + eps);
+  const float s1 = rho * advn, s2 = rc * advn;
+  const bool inside = rho >= 1.0f - eps && rho <= 1.0f + eps;
+  const float dmin_drho = (inside || s1 < s2) ? advn : 0.0f;   // d min(s1, s2) / d rho (ties split evenly, both branches -> rho)
+  const float dL_dlogp = -dmin_drho * rho * inv_n;
+  const float verr = vs[sc] - baseline[sc];
+  const float th = tanhf(x);
+  const float ce = -entropy_cost * inv_n;
+  if (on) {
+    const float dloc = dL_dlogp * u * inv_scale + ce * (-2.0f * th);
+    const float dscale = dL_dlogp * (u * u - 1.0f) * inv_scale + ce * (inv_scale - 2.0f * th * z);
+    dlogits[(size_t)s * 2 * A + lane] = grad_scale * dloc;
+    dlogits[(size_t)s * 2 * A + A + lane] = grad_scale * dscale * sigmoid(raw);
+  }
+  float lp = 0.f, lv = 0.f, le = 0.f;
+  if (live && lane == 0) {
+    dbaseline[s] = grad_scale * (-0.5f * verr * inv_n);
+    lp = -fminf(s1, s2) * inv_n; lv = 0.25f * verr * verr * inv_n; le = -entropy_cost * ent * inv_n;
+  }
+  lp = wave_sum(lp); lv = wave_sum(lv); le = wave_sum(le);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&losses[0], lp + lv + le); atomicAdd(&losses[1], lp); atomicAdd(&losses[2], lv); atomicAdd(&losses[3], le);
+  }
+}
+
+// acc[0] += sum g^2 (caller zeroes acc); block 0 / thread 0 advances the step counter acc[1].
+__global__ void sqnorm_kernel(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
+  __shared__ float sh[16];
+  float s = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const float v = g[i]; s += v * v; }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], s);
+    if (blockIdx.x == 0) acc[1] += 1.0f;
+  }
+}
+
+// optax.chain(clip_by_global_norm(max_norm), adam(lr)): g *= max_norm / norm when norm >= max_norm;
+// m, v moments with bias correction 1 - b^t, p -= lr * mhat / (sqrt(vhat) + eps).
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ acc, int64_t n, float lr, float b1, float b2, float eps, float max_norm) {
+  const float norm = sqrtf(acc[0]), t = acc[1];
+  const float clip = (max_norm > 0.0f && !(norm < max_norm)) ? max_norm / norm : 1.0f;
+  const float c1 = 1.0f / (1.0f - powf(b1, t)), c2 = 1.0f / (1.0f - powf(b2, t));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * clip;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= lr * (mi * c1) / (sqrtf(vi * c2) + eps);
+  }
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return odk_fail_(ODK_ERR_HIP, what);
+  return ODK_OK;
+}
+
+}  // namespace
+
+extern "C" int odk_gae(const float* truncation_dev, const float* termination_dev, const float* rewards_dev, const float* values_dev,
+                       const float* bootstrap_dev, float* vs_dev, float* adv_dev, float* adv_stats_dev, int B, int T, float lambda_,
+                       float discount, void* stream) {
+  if (!truncation_dev || !termination_dev || !rewards_dev || !values_dev || !bootstrap_dev || !vs_dev || !adv_dev || B <= 0 || T <= 0)
+    return odk_fail_(ODK_ERR_INVALID, "odk_gae: bad arguments");
+  const int threads = B >= 1024 ? 1024 : ((B + 63) / 64) * 64;
+  hipLaunchKernelGGL(gae_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, truncation_dev, termination_dev, rewards_dev, values_dev,
+                     bootstrap_dev, vs_dev, adv_dev, adv_stats_dev, B, T, lambda_, discount);
+  return check_launch("odk_gae: launch failed");
+}
+
+extern "C" int odk_ppo_head(const float* logits_dev, const float* raw_action_dev, const float* old_log_prob_dev, const float* adv_dev,
+                            const float* adv_stats_dev, const float* vs_dev, const float* baseline_dev, const float* noise_dev,
+                            float* dlogits_dev, float* dbaseline_dev, float* losses_dev, int n, int action_size, float clipping_epsilon,
+                            float entropy_cost, float grad_scale, void* stream) {
+  if (!logits_dev || !raw_action_dev || !old_log_prob_dev || !adv_dev || !vs_dev || !baseline_dev || !noise_dev || !dlogits_dev ||
+      !dbaseline_dev || !losses_dev || n <= 0 || action_size <= 0 || action_size > 16)
+    return odk_fail_(ODK_ERR_INVALID, "odk_ppo_head: bad arguments (action_size must be 1..16)");
+  const int threads = 256, per_block = threads / 16;
+  hipLaunchKernelGGL(ppo_head_kernel, dim3((n + per_block - 1) / per_block), dim3(threads), 0, (hipStream_t)stream, logits_dev, raw_action_dev,
+                     old_log_prob_dev, adv_dev, adv_stats_dev, vs_dev, baseline_dev, noise_dev, dlogits_dev, dbaseline_dev, losses_dev, n,
+                     action_size, clipping_epsilon, entropy_cost, grad_scale);
+  return check_launch("odk_ppo_head: launch failed");
+}
+
+extern "C" int odk_adam_clip(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr,
+                             float b1, float b2, float eps, float max_grad_norm, void* stream) {
+  if (!params_dev || !grads_dev || !m_dev || !v_dev || !acc_dev || n <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(acc_dev, 0, sizeof(float), st) != hipSuccess) return odk_fail_(ODK_ERR_HIP, "odk_adam_clip: memset failed");
+  const int threads = 256;
+  int blocks = (int)((n + threads * 4 - 1) / (threads * 4));
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(threads), 0, st, grads_dev, acc_dev, (int64_t)n);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, grads_dev, m_dev, v_dev, acc_dev, (int64_t)n, lr, b1, b2, eps,
+                     max_grad_norm);
+  return check_launch("odk_adam_clip: launch failed");
+}

@@ -94,7 +94,9 @@ def load_library() -> C.CDLL:
     L.odk_batch_record_size.argtypes = [P]
     L.odk_batch_get_records.argtypes = [P, FP]
     L.odk_batch_timing.argtypes = [P, C.c_int, FP, C.POINTER(C.c_int)]
-    L.odk_gae.argtypes = [P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_float, P]
+    L.odk_gae.argtypes = [P, P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_float, P]
+    L.odk_ppo_head.argtypes = [P] * 11 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P]
+    L.odk_adam_clip.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P]
     _lib = L
     return L
 
@@ -103,7 +105,8 @@ EXPORTED_SYMBOLS = (
     "odk_last_error", "odk_default_config", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_batch_create",
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
-    "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae")
+    "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
+    "odk_adam_clip")
 
 
 def _chk(rc: int):
@@ -130,15 +133,49 @@ def _dp(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def gae(truncation, termination, rewards, values, bootstrap, lambda_: float, discount: float):
-    """compute_gae on the device ([B, T] contiguous float32 CUDA tensors) -> (vs, advantages); one HIP kernel."""
+def _stream(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32c(*ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.is_contiguous() and t.dtype.is_floating_point and t.element_size() == 4):
+            raise OdkError("learner kernels take contiguous float32 CUDA tensors")
+
+
+def gae(truncation, termination, rewards, values, bootstrap, lambda_: float, discount: float, vs=None, adv=None, stats=None):
+    """compute_gae on the device ([B, T] contiguous float32 CUDA tensors) -> (vs, advantages); one HIP launch.
+    `stats` (2 floats, optional) receives the advantage mean and 1/(std + 1e-8)."""
     import torch
     B, T = rewards.shape
-    args = [t.contiguous().float() for t in (truncation, termination, rewards, values, bootstrap)]
-    vs, adv = torch.empty_like(args[2]), torch.empty_like(args[2])
-    stream = C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)
-    _chk(load_library().odk_gae(*[C.c_void_p(a.data_ptr()) for a in args], C.c_void_p(vs.data_ptr()), C.c_void_p(adv.data_ptr()), B, T, lambda_, discount, stream))
+    vs = torch.empty_like(rewards) if vs is None else vs
+    adv = torch.empty_like(rewards) if adv is None else adv
+    _f32c(truncation, termination, rewards, values, bootstrap, vs, adv, stats)
+    _chk(load_library().odk_gae(_ptr(truncation), _ptr(termination), _ptr(rewards), _ptr(values), _ptr(bootstrap), _ptr(vs), _ptr(adv),
+                                _ptr(stats), B, T, lambda_, discount, _stream(rewards)))
     return vs, adv
+
+
+def ppo_head(logits, raw_action, old_log_prob, adv, stats, vs, baseline, noise, dlogits, dbaseline, losses, clipping_epsilon: float,
+             entropy_cost: float, grad_scale: float = 1.0):
+    """Fused PPO loss head (forward + gradients w.r.t. logits and baseline); `losses` must be zeroed by the caller."""
+    n, a2 = logits.shape
+    _f32c(logits, raw_action, old_log_prob, adv, stats, vs, baseline, noise, dlogits, dbaseline, losses)
+    _chk(load_library().odk_ppo_head(_ptr(logits), _ptr(raw_action), _ptr(old_log_prob), _ptr(adv), _ptr(stats), _ptr(vs), _ptr(baseline),
+                                     _ptr(noise), _ptr(dlogits), _ptr(dbaseline), _ptr(losses), n, a2 // 2, clipping_epsilon, entropy_cost,
+                                     grad_scale, _stream(logits)))
+
+
+def adam_clip(params, grads, m, v, acc, lr: float, max_grad_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+    """optax clip_by_global_norm + adam on flat float32 buffers; acc = 2-float scratch (acc[1] = step count)."""
+    _f32c(params, grads, m, v, acc)
+    _chk(load_library().odk_adam_clip(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
+                                      max_grad_norm or 0.0, _stream(params)))
 
 
 class Batch:

@@ -1,0 +1,181 @@
+"""Graph-captured PPO minibatch step for the GPU: explicit forward / backward over flat parameter buffers.
+
+brax runs `num_updates_per_batch * num_minibatches` (= 128) clipped-Adam steps per training step
+(reference common/runner.py:104-118 -> brax ppo.train); each is ~10 small GEMMs surrounded by ~300
+element-wise ops, so under an autograd engine it is launch-bound.  Here one step is a single HIP graph of
+
+    7 + 7 forward GEMM/activation launches (hipBLASLt on MFMA, bias fused),
+    1 GAE launch, 1 loss-head launch (forward + gradients, csrc/odk_learner.hip),
+    14 + 14 backward launches writing straight into one flat gradient buffer,
+    [one RCCL all-reduce of that buffer when data-parallel], 2 launches for clip + Adam on the flat buffers.
+
+Parameters live in ONE flat fp32 buffer (the modules' `.data` are views of it, so the rollout policy sees
+every update), gradients in another: the data-parallel exchange is exactly one all-reduce of 1.97 MB.
+The autograd path in `train.py` (`ppo_loss`) is the reference implementation these kernels are tested against.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from .. import engine
+from .networks import PPONetworks
+
+
+class _FlatMLP:
+    """Views of one MLP's weights / gradients inside the flat buffers + explicit forward / backward."""
+
+    def __init__(self, mlp, flat_p, flat_g, off: int):
+        self.W, self.b, self.gW, self.gb = [], [], [], []
+        for lin in mlp.layers:
+            for name in ("weight", "bias"):
+                p = getattr(lin, name)
+                n = p.numel()
+                flat_p[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat_p[off:off + n].view_as(p)
+                (self.W if name == "weight" else self.b).append(p.data)
+                (self.gW if name == "weight" else self.gb).append(flat_g[off:off + n].view_as(p))
+                off += n
+        self.end = off
+
+    def forward(self, x):
+        hs, zs = [x], []
+        for i, (W, b) in enumerate(zip(self.W, self.b)):
+            z = torch.addmm(b, hs[-1], W.t())
+            zs.append(z)
+            if i + 1 < len(self.W):
+                hs.append(F.silu(z))
+        return hs, zs
+
+    def backward(self, dz, hs, zs):
+        for i in range(len(self.W) - 1, -1, -1):
+            torch.mm(dz.t(), hs[i], out=self.gW[i])
+            torch.sum(dz, 0, out=self.gb[i])
+            if i > 0:
+                dz = torch.ops.aten.silu_backward(torch.mm(dz, self.W[i]), zs[i - 1])
+
+
+class FlatLearner:
+    KEYS = ("obs", "priv", "raw_action", "log_prob", "reward", "termination", "truncation")
+
+    def __init__(self, net: PPONetworks, cfg: Dict, B: int, T: int, world: int = 1, group=None, use_graph: bool = True):
+        dev = next(net.parameters()).device
+        if dev.type != "cuda":
+            raise engine.OdkError("FlatLearner runs on the GPU only (the autograd path in train.py is the CPU reference)")
+        self.net, self.cfg, self.B, self.T, self.world, self.group = net, cfg, B, T, world, group
+        A = net.action_size
+        n_par = sum(p.numel() for p in list(net.policy.parameters()) + list(net.value.parameters()))
+        self.flat_p = torch.empty(n_par, device=dev)
+        self.flat_g = torch.zeros(n_par, device=dev)
+        self.m, self.v = torch.zeros(n_par, device=dev), torch.zeros(n_par, device=dev)
+        self.acc = torch.zeros(2, device=dev)       # [sum g^2, step count]
+        self.policy = _FlatMLP(net.policy, self.flat_p, self.flat_g, 0)
+        self.value = _FlatMLP(net.value, self.flat_p, self.flat_g, self.policy.end)
+        assert self.value.end == n_par
+        n = B * T
+        od, pd = net.policy.layers[0].in_features, net.value.layers[0].in_features
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.priv_all = z(n + B, pd)                # minibatch privileged obs, then the bootstrap rows
+        self.static = dict(obs=z(B, T, od), priv=self.priv_all[:n].view(B, T, pd), last_priv=self.priv_all[n:], raw_action=z(B, T, A),
+                           log_prob=z(B, T), reward=z(B, T), termination=z(B, T), truncation=z(B, T))
+        self.noise = z(n, A)
+        self.vs, self.adv, self.stats = z(B, T), z(B, T), z(2)
+        self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
+        self.losses = z(4)
+        self.graph_a = self.graph_b = None
+        self.sample_noise = True                    # plain-launch path only: tests inject self.noise instead
+        if use_graph:
+            self._capture()
+
+    # ---- the step, as plain stream-ordered launches (captured below) ----
+    @torch.no_grad()
+    def _loss_and_grads(self):
+        B, T, n, s, cfg = self.B, self.T, self.B * self.T, self.static, self.cfg
+        hp, zp = self.policy.forward(s["obs"].view(n, -1))
+        hv, zv = self.value.forward(self.priv_all)
+        vals = zv[-1].view(-1)
+        baseline, boot = vals[:n], vals[n:]
+        engine.gae(s["truncation"], s["termination"], s["reward"], baseline.view(B, T), boot, cfg["gae_lambda"], cfg["discounting"],
+                   vs=self.vs, adv=self.adv, stats=self.stats)
+        self.losses.zero_()
+        engine.ppo_head(zp[-1], s["raw_action"].view(n, -1), s["log_prob"].view(n), self.adv.view(n),
+                        self.stats if cfg["normalize_advantage"] else None, self.vs.view(n), baseline, self.noise, self.dlogits,
+                        self.dval_all[:n].view(n), self.losses, cfg["clipping_epsilon"], cfg["entropy_cost"], 1.0 / self.world)
+        self.policy.backward(self.dlogits, hp, zp)
+        self.value.backward(self.dval_all, hv, zv)
+
+    @torch.no_grad()
+    def _draw_noise(self):
+        self.noise.normal_()
+
+    @torch.no_grad()
+    def _update(self):
+        engine.adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0)
+
+    def _capture(self):
+        keep = [t.clone() for t in (self.flat_p, self.m, self.v, self.acc)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):               # warm-up outside capture (hipBLASLt workspaces, allocator)
+            for _ in range(2):
+                self._draw_noise(); self._loss_and_grads(); self._update()
+        torch.cuda.current_stream().wait_stream(side)
+        for t, k in zip((self.flat_p, self.m, self.v, self.acc), keep):
+            t.copy_(k)                              # the warm-up steps must not train
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self._draw_noise(); self._loss_and_grads()
+            if self.world == 1:
+                self._update()
+        if self.world > 1:
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b):
+                self._update()
+
+    # ---- public ----
+    def load_minibatch(self, data: Dict[str, torch.Tensor], idx: torch.Tensor):
+        """Gathers trajectories `idx` of the ([N, T, ...]) rollout tensors into the static buffers."""
+        for k in self.KEYS:
+            torch.index_select(data[k], 0, idx, out=self.static[k])
+        torch.index_select(data["last_priv"], 0, idx, out=self.static["last_priv"])
+
+    def step(self):
+        """One clipped-Adam step on the loaded minibatch; returns the 4 loss scalars (device tensor, no sync)."""
+        if self.graph_a is not None:
+            self.graph_a.replay()
+        else:
+            if self.sample_noise:
+                self._draw_noise()
+            self._loss_and_grads()
+            if self.world == 1:
+                self._update()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat_g, group=self.group)   # gradients were pre-scaled by 1/world in the loss head
+            if self.graph_b is not None:
+                self.graph_b.replay()
+            else:
+                self._update()
+        return self.losses
+
+    def metrics(self):
+        l = self.losses
+        return dict(total_loss=l[0].clone(), policy_loss=l[1].clone(), v_loss=l[2].clone(), entropy_loss=l[3].clone())
+
+    def optimizer_state(self):
+        return dict(m=self.m.clone(), v=self.v.clone(), acc=self.acc.clone())
+
+    def load_optimizer_state(self, st):
+        self.m.copy_(st["m"]); self.v.copy_(st["v"]); self.acc.copy_(st["acc"])
+
+
+@torch.no_grad()
+def prepare_rollout(net: PPONetworks, data: Dict[str, torch.Tensor], cfg: Dict) -> Dict[str, torch.Tensor]:
+    """Per-training-step preprocessing shared by all 128 minibatch steps: observation normalisation (the
+    normaliser is fixed during the SGD epochs, as in brax), reward scaling, termination = done & ~truncation."""
+    return dict(obs=net.norm_obs(data["obs"]), priv=net.norm_priv(data["priv"]), last_priv=net.norm_priv(data["last_priv"]),
+                raw_action=data["raw_action"],
+                log_prob=data["log_prob"], reward=data["reward"] * cfg["reward_scaling"],
+                termination=data["done"] * (1.0 - data["truncation"]), truncation=data["truncation"])

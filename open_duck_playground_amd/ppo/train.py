@@ -47,29 +47,26 @@ def compute_gae(truncation, termination, rewards, values, bootstrap_value, lambd
 
 
 def ppo_loss(net: PPONetworks, mb: Dict[str, torch.Tensor], cfg: Dict):
-    """brax ppo.losses.compute_ppo_loss on a minibatch of trajectories ([B, T, ...] tensors)."""
+    """brax ppo.losses.compute_ppo_loss on a minibatch of trajectories ([B, T, ...] tensors).  Autograd reference
+    of the fused GPU step in ppo/learner.py (and the CPU path)."""
     obs, priv = mb["obs"], mb["priv"]
     loc, scale = net.dist_params(obs)
     baseline = net.values(priv)
     bootstrap = net.values(mb["last_priv"])
     rewards = mb["reward"] * cfg["reward_scaling"]
     termination = mb["done"] * (1.0 - mb["truncation"])
-    if rewards.is_cuda:   # one HIP kernel (csrc gae_kernel) instead of ~150 tiny launches
-        from .. import engine
-        vs, adv = engine.gae(mb["truncation"], termination, rewards, baseline.detach(), bootstrap.detach(), cfg["gae_lambda"], cfg["discounting"])
-    else:
-        tm = lambda x: x.transpose(0, 1)
-        vs, adv = compute_gae(tm(mb["truncation"]), tm(termination), tm(rewards), tm(baseline.detach()), bootstrap.detach(),
-                              cfg["gae_lambda"], cfg["discounting"])
-        vs, adv = tm(vs), tm(adv)
+    tm = lambda x: x.transpose(0, 1)
+    vs, adv = compute_gae(tm(mb["truncation"]), tm(termination), tm(rewards), tm(baseline.detach()), bootstrap.detach(),
+                          cfg["gae_lambda"], cfg["discounting"])
+    vs, adv = tm(vs), tm(adv)
     if cfg["normalize_advantage"]:
-        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        adv = (adv - adv.mean()) / (adv.std(unbiased=False) + 1e-8)   # jnp.std: ddof 0
     logp = tanh_normal_log_prob(loc, scale, mb["raw_action"])
     rho = torch.exp(logp - mb["log_prob"])
     eps = cfg["clipping_epsilon"]
     policy_loss = -torch.min(rho * adv, rho.clamp(1 - eps, 1 + eps) * adv).mean()
     v_loss = ((vs - baseline) ** 2).mean() * 0.5 * 0.5
-    noise = torch.randn_like(loc)
+    noise = mb["noise"] if "noise" in mb else torch.randn_like(loc)   # tests inject the entropy sample
     entropy = tanh_normal_entropy(loc, scale, loc + scale * noise).mean()
     ent_loss = -cfg["entropy_cost"] * entropy
     total = policy_loss + v_loss + ent_loss
@@ -88,97 +85,54 @@ def _allreduce_grads(params, world: int, group=None):
         off += n
 
 
-class GraphedSGD:
-    """One clipped-Adam minibatch step captured in HIP graphs (launch-bound otherwise: ~60 small kernels per step,
-    128 steps per training step).  Two graphs -- (zero_grad, loss, backward) and (clip, Adam) -- so that the
-    data-parallel gradient all-reduce can run between them."""
-
-    def __init__(self, net, opt, cfg, example: Dict[str, torch.Tensor], world: int = 1, group=None):
-        self.net, self.opt, self.cfg, self.world, self.group = net, opt, cfg, world, group
-        self.params = [p for p in net.parameters() if p.requires_grad]
-        self.static = {k: torch.empty_like(v) for k, v in example.items()}
-        for k, v in example.items():
-            self.static[k].copy_(v)
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=self.params[0].device)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):   # warm-up outside capture (allocator, Adam state)
-            for _ in range(2):
-                self._fwd_bwd()
-                self._update()
-        torch.cuda.current_stream().wait_stream(side)
-        self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1):
-            self.metrics = self._fwd_bwd()
-        with torch.cuda.graph(self.g2):
-            self._update()
-
-    def _fwd_bwd(self):
-        loss, metrics = ppo_loss(self.net, self.static, self.cfg)
-        for p in self.params:
-            if p.grad is not None:
-                p.grad.zero_()
-        loss.backward()
-        torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
-        return metrics
-
-    def _update(self):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
-        if self.cfg.get("max_grad_norm"):
-            torch.nn.utils.clip_grad_norm_(self.params, self.cfg["max_grad_norm"], foreach=True)
-        self.opt.step()
-
-    def step(self, mb: Dict[str, torch.Tensor]):
-        for k, v in mb.items():
-            self.static[k].copy_(v)
-        self.g1.replay()
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat, group=self.group)
-            self.flat /= self.world
-        self.g2.replay()
-        return self.metrics
+def clip_by_global_norm(params, max_norm: float):
+    """optax.clip_by_global_norm: g *= max_norm / ||g|| when ||g|| >= max_norm."""
+    grads = [p.grad for p in params if p.grad is not None]
+    norm = torch.sqrt(sum((g.float() ** 2).sum() for g in grads))
+    coef = torch.where(norm < max_norm, torch.ones_like(norm), max_norm / norm)
+    for g in grads:
+        g.mul_(coef)
+    return norm
 
 
-def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Generator, world: int = 1, group=None, graphed=None):
-    """num_updates_per_batch x num_minibatches clipped-Adam steps over one rollout ([B, T, ...] per rank)."""
+def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Generator, world: int = 1, group=None, learner=None):
+    """num_updates_per_batch x num_minibatches clipped-Adam steps over one rollout ([B, T, ...] per rank).
+    With a `learner` (ppo.learner.FlatLearner, GPU) every step is one HIP-graph replay; otherwise autograd."""
     B = data["reward"].shape[0]
     nmb = cfg["num_minibatches"]
+    if learner is not None:
+        from .learner import prepare_rollout
+        prep = prepare_rollout(net, data, cfg)
+        for _ in range(cfg["num_updates_per_batch"]):
+            perm = torch.randperm(B, generator=gen, device=data["reward"].device)
+            for mbi in perm.chunk(nmb):
+                learner.load_minibatch(prep, mbi)
+                learner.step()
+        return learner.metrics()
     params = [p for p in net.parameters() if p.requires_grad]
     metrics = {}
     for _ in range(cfg["num_updates_per_batch"]):
         perm = torch.randperm(B, generator=gen, device=data["reward"].device)
         for mbi in perm.chunk(nmb):
             mb = {k: v[mbi] for k, v in data.items()}
-            if graphed is not None:
-                metrics = graphed.step(mb)
-                continue
             loss, metrics = ppo_loss(net, mb, cfg)
             opt.zero_grad(set_to_none=False)
             loss.backward()
             if world > 1:
                 _allreduce_grads(params, world, group)
             if cfg.get("max_grad_norm"):
-                torch.nn.utils.clip_grad_norm_(params, cfg["max_grad_norm"])
+                clip_by_global_norm(params, cfg["max_grad_norm"])
             opt.step()
     return metrics
 
 
-def make_graphed(net, opt, data, cfg, world: int = 1, group=None):
-    """HIP-graph SGD step for CUDA tensors with B divisible by num_minibatches; None (eager path) otherwise."""
+def make_learner(net, data, cfg, world: int = 1, group=None):
+    """FlatLearner for CUDA rollouts whose trajectory count divides into the minibatches; None (autograd path) otherwise."""
     B = data["reward"].shape[0]
-    if not data["reward"].is_cuda or B % cfg["num_minibatches"] != 0:
+    if not data["reward"].is_cuda or B % cfg["num_minibatches"] != 0 or not cfg.get("use_graphs", True):
         return None
-    n = B // cfg["num_minibatches"]
-    try:
-        return GraphedSGD(net, opt, cfg, {k: v[:n] for k, v in data.items()}, world, group)
-    except Exception as e:  # graph capture is an optimisation, never a requirement
-        print(f"[ppo] HIP-graph capture unavailable ({type(e).__name__}: {e}); using eager SGD steps")
-        return None
+    from .learner import FlatLearner
+    return FlatLearner(net, cfg, B // cfg["num_minibatches"], data["reward"].shape[1], world, group)
 
 
 @torch.no_grad()
@@ -211,8 +165,6 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
     rank = dist.get_rank() if dist.is_initialized() else 0
     dev = environment.batch.obs.device
     nf = cfg["network_factory"]
-    net = PPONetworks(environment.observation_size["state"][0], environment.observation_size["privileged_state"][0], environment.action_size,
-                      nf["policy_hidden_layer_sizes"], nf["value_hidden_layer_sizes"]).to(dev)
     torch.manual_seed(seed)   # identical initial parameters on every rank
     net = PPONetworks(environment.observation_size["state"][0], environment.observation_size["privileged_state"][0], environment.action_size,
                       nf["policy_hidden_layer_sizes"], nf["value_hidden_layer_sizes"]).to(dev)
@@ -220,7 +172,7 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
         net.load_state_dict(torch.load(restore_checkpoint_path, map_location=dev)["networks"])
     opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=cfg["learning_rate"], capturable=dev.type == "cuda")
     gen = torch.Generator(device=dev); gen.manual_seed(seed * 1000 + rank)
-    graphed = None
+    learner = None
     if randomization_fn is not None:
         randomization_fn(environment)
     state = environment.reset(seed)
@@ -235,9 +187,9 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
         if cfg["normalize_observations"]:
             grp = dist.group.WORLD if world > 1 else None
             net.norm_obs.update(data["obs"], grp); net.norm_priv.update(data["priv"], grp)
-        if it == 0 and cfg.get("use_graphs", True):
-            graphed = make_graphed(net, opt, data, cfg, world)
-        loss_metrics = sgd_epoch(net, opt, data, cfg, gen, world, graphed=graphed)
+        if it == 0:
+            learner = make_learner(net, data, cfg, world)
+        loss_metrics = sgd_epoch(net, opt, data, cfg, gen, world, learner=learner)
         done_steps += steps_per_iter
         if (it + 1) % eval_every == 0 or it == num_iters - 1:
             ep_rew = (data["reward"].sum(1)).mean()

@@ -17,7 +17,7 @@ dev = env.batch.obs.device
 torch.manual_seed(0)
 net = PPONetworks(101, 212, 14).to(dev)
 opt = torch.optim.Adam(net.parameters(), lr=cfg["learning_rate"], capturable=True)
-graphed = None
+learner = None
 gen = torch.Generator(device=dev); gen.manual_seed(0)
 state = env.reset(0)
 tr = tl = 0.0
@@ -27,8 +27,8 @@ for it in range(iters + 1):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     net.norm_obs.update(data["obs"]); net.norm_priv.update(data["priv"])
     if it == 0:
-        graphed = T.make_graphed(net, opt, data, cfg)
-    m = T.sgd_epoch(net, opt, data, cfg, gen, graphed=graphed)
+        learner = T.make_learner(net, data, cfg) if os.environ.get("ODK_EAGER_LEARNER") != "1" else None
+    m = T.sgd_epoch(net, opt, data, cfg, gen, learner=learner)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     if it > 0:
         tr += t1 - t0; tl += t2 - t1
