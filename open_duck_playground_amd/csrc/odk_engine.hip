@@ -305,7 +305,9 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   for (int k = lane; k < rec::NINFO; k += G) INFO[k] = rc[R::INFO + k];
   for (int u = lane; u < NU; u += G) ACT[u] = a.action[(size_t)e * NU + u];
   load_params<S, G>(L, m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);  // syncs
+#ifdef ODK_PROFILE
   if (lane < 20) L[S::O_SCR + S::S_PROF + lane] = 0;
+#endif
   Statics<S, G> st;
   load_statics<S, G>(st, m, lane);
   const uint32_t k0 = (uint32_t)f2i(INFO[rec::KEY0]), k1 = (uint32_t)f2i(INFO[rec::KEY1]), ctr = (uint32_t)f2i(INFO[rec::CTR]);
@@ -487,7 +489,9 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   for (int i = lane; i < S::NQ + 2 * S::NV; i += G) L[S::O_QPOS + i] = rc[i];
   for (int u = lane; u < S::NU; u += G) L[S::O_CTRL + u] = a.action[(size_t)e * S::NU + u];
   load_params<S, G>(L, a.m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);
+#ifdef ODK_PROFILE
   if (lane < 20) L[S::O_SCR + S::S_PROF + lane] = 0;
+#endif
   ODK_SYNC();
   Statics<S, G> st;
   load_statics<S, G>(st, a.m, lane);

@@ -93,11 +93,17 @@ struct Shape {
   static constexpr int O_AREF = O_D + NROW;
   static constexpr int O_JAR = O_AREF + NROW;        // J qacc - aref (contact rows)
   static constexpr int O_JV = O_JAR + NROW;          // J search (scratch: candidate Jaref, forces, Hessian diagonal addend)
-  static constexpr int O_W = O_JV + NROW;            // [NCROW][6] contact row wrenches [r x dir; dir]
-  static constexpr int O_CDIST = O_W + 6 * NCROW;    // [12]
+  static constexpr int O_W = O_CFRC;                 // [NCROW][6] contact row wrenches [r x dir; dir]; ALIASES cfrc|crb, which
+                                                     // are dead once the bias forces and M entries exist (P3/P4); W is born in P8
+  static_assert(6 * NCROW <= 16 * NB, "contact wrenches must fit in the cfrc|crb region");
+  static constexpr int O_CDIST = O_JV + NROW;        // [12]
   static constexpr int O_CR = O_CDIST + NCON;        // [12][3] contact position relative to the base origin
   static constexpr int O_SCR = O_CR + 3 * NCON;      // scratch: foot twists, wrenches, 6x6 blocks, sensor inputs
+#ifdef ODK_PROFILE
   static constexpr int N_SCR = 192;
+#else
+  static constexpr int N_SCR = 172;                  // no S_PROF slots outside profile builds
+#endif
   static constexpr int O_SENS = O_SCR + N_SCR;       // sensordata[46]
   static constexpr int O_ACTF = O_SENS + NSENSD;     // actuator_force
   static constexpr int O_QACC = O_X;                 // qacc of the last forward == final iterate
