@@ -132,24 +132,29 @@ struct Shape {
 // Cross-lane all-reduce over the G lanes of one env with DPP (no LDS traffic): xor-1 / xor-2 quad permutes,
 // row_half_mirror, row_mirror give every lane its 16-lane row total; rows are then combined with row_bcast15
 // (/31) and the group total is read back with v_readlane.  MUST be called in uniform control flow.
-#define ODK_DPP(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xF, false))
+// old = 0 with bound_ctrl lets the compiler fold the permute into the consuming VALU op (v_add_f32_dpp ...): one
+// instruction per butterfly stage, no copies, no hazard nops.  (All four patterns read only enabled in-row lanes.)
+#define ODK_DPP(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, true))
 struct OpSum { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
 struct OpMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
 struct OpMin { static __device__ __forceinline__ float f(float a, float b) { return fminf(a, b); } };
+typedef unsigned int odk_u2 __attribute__((ext_vector_type(2)));
 template <int G, class Op> __device__ __forceinline__ float greduce(float v) {
   v = Op::f(v, ODK_DPP(v, 0xB1, 0xF));    // quad_perm [1,0,3,2]
   v = Op::f(v, ODK_DPP(v, 0x4E, 0xF));    // quad_perm [2,3,0,1]
   v = Op::f(v, ODK_DPP(v, 0x141, 0xF));   // row_half_mirror
   v = Op::f(v, ODK_DPP(v, 0x140, 0xF));   // row_mirror: every lane holds its row's total
-  const int iv = __float_as_int(v);
-  if (G == 32) {
-    const float lo = Op::f(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16)));
-    const float hi = Op::f(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
-    return (threadIdx.x & 32) ? hi : lo;
+  // gfx950 v_permlane16_swap: rows (r0 r1 r2 r3),(s0 s1 s2 s3) -> (r0 s0 r2 s2),(r1 s1 r3 s3); with both operands = v the
+  // two results are (x0 x0 x2 x2) and (x1 x1 x3 x3): their combination is the 32-lane group total in every lane.
+  const unsigned iv = __float_as_uint(v);
+  const odk_u2 h = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+  v = Op::f(__uint_as_float(h[0]), __uint_as_float(h[1]));
+  if (G == 64) {   // v_permlane32_swap: halves (lo hi),(lo hi) -> (lo lo),(hi hi)
+    const unsigned iw = __float_as_uint(v);
+    const odk_u2 w = __builtin_amdgcn_permlane32_swap(iw, iw, false, false);
+    v = Op::f(__uint_as_float(w[0]), __uint_as_float(w[1]));
   }
-  const float a = Op::f(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16)));
-  const float b = Op::f(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
-  return Op::f(a, b);
+  return v;
 }
 template <int G> __device__ __forceinline__ float gsum(float v) { return greduce<G, OpSum>(v); }
 template <int G> __device__ __forceinline__ float gmax(float v) { return greduce<G, OpMax>(v); }
