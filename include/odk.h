@@ -38,6 +38,10 @@ enum odk_status {
 
 #define ODK_NOBS 101     /* obs["state"]            joystick.py:570-589 */
 #define ODK_NPRIV 212    /* obs["privileged_state"] joystick.py:596-615 */
+#define ODK_NOBS_STANDING 85    /* standing.py:524-540 */
+#define ODK_NPRIV_STANDING 153  /* standing.py:548-565 */
+#define ODK_ENV_JOYSTICK 0
+#define ODK_ENV_STANDING 1
 #define ODK_NMETRIC 8    /* reward/cost terms (7) + swing_peak, joystick.py:304-311 */
 #define ODK_NU 14
 
@@ -46,7 +50,8 @@ typedef struct {
   float ctrl_dt, action_scale, dof_vel_scale, max_motor_velocity;
   float noise_level, noise_gyro, noise_accelerometer, noise_gravity, noise_joint_vel;
   float qpos_noise_scale[16];
-  float reward_scales[7];  /* tracking_lin_vel, tracking_ang_vel, torques, action_rate, stand_still, alive, imitation */
+  float reward_scales[7];  /* tracking_lin_vel, tracking_ang_vel, torques, action_rate, stand_still, alive, imitation;
+                              Standing: orientation, head_pos, torques, action_rate, stand_still, alive, (unused) */
   float tracking_sigma;
   float push_enable, push_interval_range[2], push_magnitude_range[2];
   float cmd_range[7][2];   /* lin_vel_x, lin_vel_y, ang_vel_yaw, neck_pitch, head_pitch, head_yaw, head_roll */
@@ -55,6 +60,9 @@ typedef struct {
   int32_t episode_length;  /* EpisodeWrapper */
   int32_t n_substeps;      /* ctrl_dt / sim_dt */
   int32_t lanes_per_env;   /* kernel geometry: 32 or 64 (0 = default) */
+  int32_t env_kind;        /* ODK_ENV_JOYSTICK (joystick.py) or ODK_ENV_STANDING (standing.py): selects the obs layout
+                              (101/212 vs 85/153 floats per env -- the output row strides) and the reward table */
+  float reset_base_qvel;   /* half-range of the base velocity noise at reset: joystick.py:253 0.05, standing.py:247 0.5 */
 } odk_env_config;
 
 /* Caller-owned device outputs of reset/step (any pointer may be NULL to skip it). */
@@ -80,6 +88,10 @@ enum odk_param {
 
 const char* odk_last_error(void);
 void odk_default_config(odk_env_config* cfg);
+/* default_config() of reference standing.py:44-100 (incl. USE_IMITATION_REWARD = False, no motor speed limit) */
+void odk_default_config_standing(odk_env_config* cfg);
+/* row strides of the obs / privileged_state outputs for an env kind */
+void odk_obs_sizes(int env_kind, int* nobs, int* npriv);
 
 /* mjx.put_model: parse a ModelBlob (open_duck_playground_amd/model.py) */
 int odk_model_load(const void* blob, uint64_t len, odk_model** out);

@@ -143,7 +143,10 @@ __device__ __forceinline__ void build_obs(float* L, const DevModel* m, const Env
   if (lane < 3) { h0 = INFO[rec::IMU + lane]; h1 = INFO[rec::IMU + 3 + lane]; }
   ODK_SYNC();
   if (lane < 3) { INFO[rec::IMU + lane] = ng; INFO[rec::IMU + 3 + lane] = h0; INFO[rec::IMU + 6 + lane] = h1; }
-  for (int k = lane; k < ODK_NPRIV; k += G) {
+  // Standing (standing.py:524-565) = the Joystick layout minus motor_targets, imitation phase, reference motion, imitation_i
+  const bool standing = c.kind != 0;
+  for (int ks = lane; ks < c.npriv; ks += G) {
+    const int k = !standing ? ks : (ks < 13 + 5 * NU ? ks : (ks < 15 + 5 * NU ? ks + NU : ks + ODK_NOBS - (15 + 5 * NU)));
     float v = 0;
     if (k < 3) v = SENS[m->adr_gyro + k] + (2.0f * rng_uniform(k0, k1, ctr, 4 + k) - 1.0f) * lvl * c.noise_gyro;
     else if (k < 6) v = SENS[m->adr_accelerometer + k - 3] + (2.0f * rng_uniform(k0, k1, ctr, 7 + k - 3) - 1.0f) * lvl * c.noise_accelerometer;
@@ -179,7 +182,7 @@ __device__ __forceinline__ void build_obs(float* L, const DevModel* m, const Env
       else if (q == 66 + 3 * NU) v = (float)imitation_i;
       else v = phase[q - 67 - 3 * NU];
     }
-    P[k] = v;
+    P[ks] = v;
   }
   ODK_SYNC();
 }
@@ -196,8 +199,9 @@ template <class S, int G>
 __device__ __forceinline__ void write_outputs(const KArgs& a, const float* L, int env, float reward, float done, float trunc, const float* metrics, int lane) {
   using E = EnvL<S>;
   const float* P = L + E::O_PRIV;
-  if (a.obs) for (int k = lane; k < ODK_NOBS; k += G) a.obs[(size_t)env * ODK_NOBS + k] = P[k];
-  if (a.priv) for (int k = lane; k < ODK_NPRIV; k += G) a.priv[(size_t)env * ODK_NPRIV + k] = P[k];
+  const int nobs = a.cfg.nobs, npriv = a.cfg.npriv;
+  if (a.obs) for (int k = lane; k < nobs; k += G) a.obs[(size_t)env * nobs + k] = P[k];
+  if (a.priv) for (int k = lane; k < npriv; k += G) a.priv[(size_t)env * npriv + k] = P[k];
   if (lane == 0) {
     if (a.reward) a.reward[env] = reward;
     if (a.done) a.done[env] = done;
@@ -239,12 +243,12 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
     qmul(r, q0, qz);
     for (int k = 0; k < 4; k++) L[S::O_QPOS + 3 + k] = r[k];
   }
-  if (lane >= 3 && lane < 9) L[S::O_QVEL + lane - 3] = -0.05f + rng_uniform(k0, kr, 0, 17 + lane - 3) * 0.1f;
+  if (lane >= 3 && lane < 9) L[S::O_QVEL + lane - 3] = -c.reset_base_qvel + rng_uniform(k0, kr, 0, 17 + lane - 3) * (2.0f * c.reset_base_qvel);
   for (int u = lane; u < S::NU; u += G) {
     const float v = L[S::O_QPOS + m->act_qposadr[u]] * (0.5f + rng_uniform(k0, kr, 0, 3 + u));
     L[S::O_QPOS + m->act_qposadr[u]] = v;
     L[S::O_CTRL + u] = v;
-    INFO[rec::MT + u] = m->key_ctrl[u];
+    INFO[rec::MT + u] = c.kind != 0 ? 0.0f : m->key_ctrl[u];   // standing.py:279 starts from zeros
   }
   if (lane < 7) sample_command(c, k0, kr, 0, 23, lane, INFO[rec::CMD + lane]);
   ODK_SYNC();
@@ -386,9 +390,12 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     t_tq = af * af;
     const float da = ACT[u] - INFO[rec::LAST + u];
     t_ar = da * da;
-    t_pose = fabsf(jq - m->key_ctrl[u]);
-    t_vel = fabsf(jv);
-    if (u < 5 || u >= 9) {  // joints[:5] ++ joints[9:] vs ref[:5] ++ ref[11:16]  (custom_rewards.py:80-88)
+    const bool leg = u < 5 || u >= 9;
+    const bool counted = c.kind == 0 || leg;   // Standing: cost_stand_still(..., ignore_head=True) (standing.py:590-597)
+    t_pose = counted ? fabsf(jq - m->key_ctrl[u]) : 0.0f;
+    t_vel = counted ? fabsf(jv) : 0.0f;
+    if (c.kind != 0 && !leg) { const float dh = jq - INFO[rec::CMD + 3 + (u - 5)]; t_jp = dh * dh; }   // cost_head_pos (rewards.py:131-147)
+    if (c.kind == 0 && leg) {  // joints[:5] ++ joints[9:] vs ref[:5] ++ ref[11:16]  (custom_rewards.py:80-88)
       const int ri = u < 5 ? u : u + 2;
       const float dp = jq - REF[ri], dv = jv - REF[16 + ri];
       t_jp = dp * dp; t_jv = dv * dv;
@@ -408,6 +415,11 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     rew[2] = nan_to_num(t_tq);
     rew[3] = nan_to_num(t_ar);
     const float cn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+    if (c.kind != 0) {   // standing.py:585-606: cost_orientation(upvector), cost_head_pos (gated by the MOVE command norm)
+      const float* up = L + S::O_SENS + m->adr_upvector;
+      rew[0] = nan_to_num(up[0] * up[0] + up[1] * up[1]);
+      rew[1] = nan_to_num(t_jp) * (cn > 0.01f ? 1.0f : 0.0f);
+    }
     rew[4] = nan_to_num(t_pose + t_vel) * (cn < 0.01f ? 1.0f : 0.0f);
     rew[5] = 1.0f;
     rew[6] = 0.0f;
@@ -548,6 +560,21 @@ extern "C" void odk_default_config(odk_env_config* c) {
   const float cr[7][2] = {{-0.15f, 0.15f}, {-0.2f, 0.2f}, {-1.0f, 1.0f}, {-0.34f, 1.1f}, {-0.78f, 0.78f}, {-1.5f, 1.5f}, {-0.5f, 0.5f}};
   memcpy(c->cmd_range, cr, sizeof(cr));
   c->use_imitation = 1; c->use_motor_speed_limits = 1; c->autoreset = 1; c->episode_length = 1000; c->n_substeps = 10; c->lanes_per_env = 0;
+  c->env_kind = ODK_ENV_JOYSTICK; c->reset_base_qvel = 0.05f;
+}
+extern "C" void odk_default_config_standing(odk_env_config* c) {   // reference standing.py:44-100
+  odk_default_config(c);
+  c->env_kind = ODK_ENV_STANDING; c->reset_base_qvel = 0.5f;
+  c->noise_gyro = 0.05f; c->noise_accelerometer = 0.005f;
+  const float rs[7] = {-0.5f, -2.0f, -1.0e-3f, -0.375f, -0.3f, 20.0f, 0.0f};   // orientation, head_pos, torques, action_rate, stand_still, alive
+  memcpy(c->reward_scales, rs, sizeof(rs));
+  for (int k = 0; k < 3; k++) c->cmd_range[k][0] = c->cmd_range[k][1] = 0.0f;   // standing.py:652-654
+  c->cmd_range[5][0] = -2.7f; c->cmd_range[5][1] = 2.7f;
+  c->use_imitation = 0; c->use_motor_speed_limits = 0;
+}
+extern "C" void odk_obs_sizes(int env_kind, int* nobs, int* npriv) {
+  if (nobs) *nobs = env_kind == ODK_ENV_STANDING ? ODK_NOBS_STANDING : ODK_NOBS;
+  if (npriv) *npriv = env_kind == ODK_ENV_STANDING ? ODK_NPRIV_STANDING : ODK_NPRIV;
 }
 
 // ---- blob parsing
@@ -831,6 +858,8 @@ static void to_dev_cfg(const odk_env_config& c, EnvCfg& d) {
   memcpy(d.cmd_range, c.cmd_range, sizeof(d.cmd_range));
   d.use_imitation = c.use_imitation; d.use_motor_speed_limits = c.use_motor_speed_limits; d.autoreset = c.autoreset;
   d.episode_length = c.episode_length; d.n_substeps = c.n_substeps;
+  d.kind = c.env_kind; d.reset_base_qvel = c.reset_base_qvel;
+  odk_obs_sizes(c.env_kind, &d.nobs, &d.npriv);
 }
 
 extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, int nenv, int device, const float* prm_table, const double* dxs, int nx,
@@ -868,6 +897,7 @@ extern "C" void odk_batch_destroy(odk_batch* b) {
 }
 extern "C" int odk_batch_set_config(odk_batch* b, const odk_env_config* cfg) {
   if (!b || !cfg) return fail(ODK_ERR_INVALID, "null");
+  if (cfg->env_kind != b->cfg.env_kind) return fail(ODK_ERR_INVALID, "odk_batch_set_config: env_kind is fixed at creation (it sets the output strides)");
   int g = b->cfg.lanes_per_env;
   b->cfg = *cfg;
   b->cfg.lanes_per_env = g;

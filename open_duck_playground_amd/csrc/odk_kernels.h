@@ -45,6 +45,8 @@ struct EnvCfg {  // device copy of odk_env_config
   float push_enable, push_interval_range[2], push_magnitude_range[2];
   float cmd_range[7][2];
   int use_imitation, use_motor_speed_limits, autoreset, episode_length, n_substeps;
+  int kind, nobs, npriv;   // env kind (0 Joystick, 1 Standing) and its output row strides
+  float reset_base_qvel;
 };
 
 // ------------------------------------------------------------------------------------------------

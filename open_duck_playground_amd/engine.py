@@ -36,7 +36,7 @@ class EnvConfig(C.Structure):
         ("push_enable", C.c_float), ("push_interval_range", C.c_float * 2), ("push_magnitude_range", C.c_float * 2),
         ("cmd_range", (C.c_float * 2) * 7),
         ("use_imitation", C.c_int32), ("use_motor_speed_limits", C.c_int32), ("autoreset", C.c_int32), ("episode_length", C.c_int32),
-        ("n_substeps", C.c_int32), ("lanes_per_env", C.c_int32),
+        ("n_substeps", C.c_int32), ("lanes_per_env", C.c_int32), ("env_kind", C.c_int32), ("reset_base_qvel", C.c_float),
     ]
 
 
@@ -74,6 +74,8 @@ def load_library() -> C.CDLL:
     FP, DP = C.POINTER(C.c_float), C.POINTER(C.c_double)
     L.odk_last_error.restype = C.c_char_p
     L.odk_default_config.argtypes = [C.POINTER(EnvConfig)]
+    L.odk_default_config_standing.argtypes = [C.POINTER(EnvConfig)]
+    L.odk_obs_sizes.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.odk_model_load.argtypes = [C.c_char_p, C.c_uint64, PP]
     L.odk_model_free.argtypes = [P]
     L.odk_model_dims.argtypes = [P] + [C.POINTER(C.c_int)] * 4
@@ -102,7 +104,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "odk_last_error", "odk_default_config", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_batch_create",
+    "odk_last_error", "odk_default_config", "odk_default_config_standing", "odk_obs_sizes", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_batch_create",
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
@@ -114,10 +116,18 @@ def _chk(rc: int):
         raise OdkError(f"odk error {rc}: {load_library().odk_last_error().decode()}")
 
 
-def default_config() -> EnvConfig:
+def default_config(standing: bool = False) -> EnvConfig:
     cfg = EnvConfig()
-    load_library().odk_default_config(C.byref(cfg))
+    L = load_library()
+    (L.odk_default_config_standing if standing else L.odk_default_config)(C.byref(cfg))
     return cfg
+
+
+def obs_sizes(env_kind: int):
+    """(nobs, npriv) row strides of the observation outputs for an env kind (0 Joystick, 1 Standing)."""
+    a, b = C.c_int(0), C.c_int(0)
+    load_library().odk_obs_sizes(int(env_kind), C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def load_prm() -> Dict[str, np.ndarray]:
@@ -202,8 +212,9 @@ class Batch:
                                      len(dys), _dp(dths), len(dths), _dp(ranges), int(prm["nb_steps_in_period"][0]), C.byref(self._b)))
         dev = torch.device("cuda", self.device)
         f32 = dict(dtype=torch.float32, device=dev)
-        self.obs = torch.zeros(self.nenv, NOBS, **f32)
-        self.priv = torch.zeros(self.nenv, NPRIV, **f32)
+        self.nobs, self.npriv = obs_sizes(self.cfg.env_kind)
+        self.obs = torch.zeros(self.nenv, self.nobs, **f32)
+        self.priv = torch.zeros(self.nenv, self.npriv, **f32)
         self.reward = torch.zeros(self.nenv, **f32)
         self.done = torch.zeros(self.nenv, **f32)
         self.truncation = torch.zeros(self.nenv, **f32)

@@ -64,10 +64,16 @@ def _merge(cfg: ConfigDict, overrides: Optional[Dict[str, Any]]) -> ConfigDict:
     return cfg
 
 
-def to_engine_config(cfg: ConfigDict, autoreset: bool = True, lanes_per_env: int = 0) -> engine.EnvConfig:
+REWARD_SLOTS = ("tracking_lin_vel", "tracking_ang_vel", "torques", "action_rate", "stand_still", "alive", "imitation")
+
+
+def to_engine_config(cfg: ConfigDict, autoreset: bool = True, lanes_per_env: int = 0, standing: bool = False,
+                     reward_slots=REWARD_SLOTS, use_imitation: bool = USE_IMITATION_REWARD,
+                     use_motor_speed_limits: bool = USE_MOTOR_SPEED_LIMITS) -> engine.EnvConfig:
     """reference config -> odk_env_config (include/odk.h)."""
-    c = engine.default_config()
-    c.ctrl_dt, c.action_scale, c.dof_vel_scale, c.max_motor_velocity = cfg.ctrl_dt, cfg.action_scale, cfg.dof_vel_scale, cfg.max_motor_velocity
+    c = engine.default_config(standing)
+    c.ctrl_dt, c.action_scale, c.dof_vel_scale = cfg.ctrl_dt, cfg.action_scale, cfg.dof_vel_scale
+    c.max_motor_velocity = cfg.get("max_motor_velocity", 0.0)
     n = cfg.noise_config
     if (n.action_min_delay, n.action_max_delay, n.imu_min_delay, n.imu_max_delay) != (0, 3, 0, 3):
         raise ValueError("the kernels implement the reference's delay ring of depth 3")
@@ -80,21 +86,22 @@ def to_engine_config(cfg: ConfigDict, autoreset: bool = True, lanes_per_env: int
     for i in range(16):
         c.qpos_noise_scale[i] = float(scale[i])
     s = cfg.reward_config.scales
-    for i, k in enumerate(("tracking_lin_vel", "tracking_ang_vel", "torques", "action_rate", "stand_still", "alive", "imitation")):
-        c.reward_scales[i] = float(s[k])
+    for i, k in enumerate(reward_slots):
+        c.reward_scales[i] = float(s[k]) if k is not None else 0.0
     c.tracking_sigma = cfg.reward_config.tracking_sigma
     c.push_enable = 1.0 if cfg.push_config.enable else 0.0
     for i in range(2):
         c.push_interval_range[i] = cfg.push_config.interval_range[i]
         c.push_magnitude_range[i] = cfg.push_config.magnitude_range[i]
     f = cfg.head_range_factor
-    ranges = [cfg.lin_vel_x, cfg.lin_vel_y, cfg.ang_vel_yaw, [cfg.neck_pitch_range[0] * f, cfg.neck_pitch_range[1] * f],
+    zero = [0.0, 0.0]   # Standing has no move command (standing.py:652-654)
+    ranges = [cfg.get("lin_vel_x", zero), cfg.get("lin_vel_y", zero), cfg.get("ang_vel_yaw", zero), [cfg.neck_pitch_range[0] * f, cfg.neck_pitch_range[1] * f],
               [cfg.head_pitch_range[0] * f, cfg.head_pitch_range[1] * f], [cfg.head_yaw_range[0] * f, cfg.head_yaw_range[1] * f],
               [cfg.head_roll_range[0] * f, cfg.head_roll_range[1] * f]]
     for i, r in enumerate(ranges):
         c.cmd_range[i][0], c.cmd_range[i][1] = float(r[0]), float(r[1])
-    c.use_imitation = int(USE_IMITATION_REWARD)
-    c.use_motor_speed_limits = int(USE_MOTOR_SPEED_LIMITS)
+    c.use_imitation = int(use_imitation)
+    c.use_motor_speed_limits = int(use_motor_speed_limits)
     c.autoreset = int(autoreset)
     c.episode_length = int(cfg.episode_length)
     c.n_substeps = int(round(cfg.ctrl_dt / cfg.sim_dt))
@@ -117,14 +124,22 @@ class State:
 class Joystick:
     """Track a joystick command (reference joystick.py:105)."""
 
+    METRIC_NAMES = engine.METRIC_NAMES
+
     def __init__(self, task: str = "flat_terrain", config: Optional[ConfigDict] = None, config_overrides: Optional[Dict[str, Any]] = None,
                  num_envs: int = 8192, device: int = 0, autoreset: bool = True, lanes_per_env: int = 0, env_id_offset: int = 0):
-        self._config = _merge(config if config is not None else default_config(), config_overrides)
+        self._config = _merge(config if config is not None else self._default_config(), config_overrides)
         self._model = constants.task_to_model(task)      # KeyError for unknown task names
         self._task = task
         self.num_envs = int(num_envs)
         self._env_id_offset = int(env_id_offset)
-        self._batch = engine.Batch(self._model, self.num_envs, to_engine_config(self._config, autoreset, lanes_per_env), device=device)
+        self._batch = engine.Batch(self._model, self.num_envs, self._engine_config(autoreset, lanes_per_env), device=device)
+
+    def _default_config(self) -> ConfigDict:
+        return default_config()
+
+    def _engine_config(self, autoreset: bool, lanes_per_env: int) -> engine.EnvConfig:
+        return to_engine_config(self._config, autoreset, lanes_per_env)
 
     # ---- reference accessors (base.py:277-291, MjxEnv)
     @property
@@ -136,7 +151,7 @@ class Joystick:
     @property
     def mjx_model(self): return self._batch
     @property
-    def observation_size(self): return {"state": (engine.NOBS,), "privileged_state": (engine.NPRIV,)}
+    def observation_size(self): return {"state": (self._batch.nobs,), "privileged_state": (self._batch.npriv,)}
     @property
     def dt(self) -> float: return self._config.ctrl_dt
     @property
@@ -157,7 +172,7 @@ class Joystick:
 
     def _state(self) -> State:
         b = self._batch
-        metrics = {name: b.metrics[:, i] for i, name in enumerate(engine.METRIC_NAMES)}
+        metrics = {name: b.metrics[:, i] for i, name in enumerate(self.METRIC_NAMES) if name is not None}
         return State(data=b, obs={"state": b.obs, "privileged_state": b.priv}, reward=b.reward, done=b.done, metrics=metrics,
                      info={"truncation": b.truncation})
 

@@ -17,11 +17,11 @@ class OpenDuckMiniV2Runner:
     def __init__(self, args):
         import torch
         import torch.distributed as dist
-        from . import joystick
+        from . import joystick, standing
         from .ppo import train as ppo_train
         self.args = args
         self.output_dir = os.path.join(os.getcwd(), args.output_dir)
-        available_envs = {"joystick": joystick.Joystick}   # "standing" is the next env to land
+        available_envs = {"joystick": joystick.Joystick, "standing": standing.Standing}   # reference runner.py:14-17
         if args.env not in available_envs:
             raise ValueError(f"Unknown env {args.env}")
         self.world = int(os.environ.get("WORLD_SIZE", "1")); self.rank = int(os.environ.get("RANK", "0"))

@@ -140,6 +140,19 @@ real odko_cost_stand_still(const real* cmd, const real* qpos, const real* qvel, 
   for (int i = 0; i < n; i++) { pc += fabs(qpos[i] - def[i]); vc += fabs(qvel[i]); }
   return nan_to_num(pc + vc) * (cn < 0.01 ? 1.0 : 0.0);
 }
+real odko_cost_stand_still_legs(const real* cmd, const real* qpos, const real* qvel, const real* def, int n) { /* rewards.py:105-117, ignore_head=True */
+  real cn = sqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+  real pc = 0, vc = 0;
+  for (int i = 0; i < n; i++) if (i < 5 || i >= 9) { pc += fabs(qpos[i] - def[i]); vc += fabs(qvel[i]); }
+  return nan_to_num(pc + vc) * (cn < 0.01 ? 1.0 : 0.0);
+}
+real odko_cost_orientation(const real* z) { return nan_to_num(z[0] * z[0] + z[1] * z[1]); } /* rewards.py:45-46 */
+real odko_cost_head_pos(const real* jq, const real* cmd) { /* rewards.py:131-147: gated by the MOVE command norm (> 0.01) */
+  real cn = sqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
+  real e = 0;
+  for (int k = 0; k < 4; k++) e += (jq[5 + k] - cmd[3 + k]) * (jq[5 + k] - cmd[3 + k]);
+  return nan_to_num(e) * (cn > 0.01 ? 1.0 : 0.0);
+}
 real odko_reward_imitation(const real* base_qpos, const real* base_qvel, const real* jq, const real* jv, const real* contacts,
                            const real* ref, const real* cmd) { /* custom_rewards.py:4-148 */
   real cn = sqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
@@ -186,7 +199,21 @@ static void default_cfg(odko_env_cfg* c, int nu) {
   static const real cr[7][2] = {{-0.15, 0.15}, {-0.2, 0.2}, {-1.0, 1.0}, {-0.34, 1.1}, {-0.78, 0.78}, {-1.5, 1.5}, {-0.5, 0.5}};
   memcpy(c->cmd_range, cr, sizeof(cr));
   c->use_imitation = 1; c->use_motor_speed_limits = 1; c->autoreset = 1; c->episode_length = 1000; c->n_substeps = 10;
+  c->env_kind = 0; c->reset_base_qvel = 0.05;
 }
+/* standing.py:44-100 default_config; reward slots: orientation, head_pos, torques, action_rate, stand_still, alive, (unused) */
+void odko_env_set_standing(odko_env* e) {
+  odko_env_cfg* c = &e->cfg;
+  c->env_kind = 1; c->reset_base_qvel = 0.5;
+  c->noise_gyro = 0.05; c->noise_accelerometer = 0.005;
+  static const real rs[7] = {-0.5, -2.0, -1.0e-3, -0.375, -0.3, 20.0, 0.0};
+  memcpy(c->reward_scales, rs, sizeof(rs));
+  for (int k = 0; k < 3; k++) c->cmd_range[k][0] = c->cmd_range[k][1] = 0.0; /* standing.py:652-654: no move command */
+  c->cmd_range[5][0] = -2.7; c->cmd_range[5][1] = 2.7;
+  c->use_imitation = 0; c->use_motor_speed_limits = 0;
+}
+int odko_env_nobs(const odko_env* e) { return e->cfg.env_kind != 0 ? 15 + 5 * e->m->nu : 17 + 6 * e->m->nu; }
+int odko_env_npriv(const odko_env* e) { return odko_env_nobs(e) + 26 + 3 * e->m->nu + (e->cfg.env_kind != 0 ? 0 : 43); }
 
 odko_env* odko_env_new(const odko_model* m, const odko_prm* prm, const odko_env_cfg* cfg) {
   odko_env* e = (odko_env*)calloc(1, sizeof(odko_env));
@@ -220,6 +247,7 @@ real* odko_env_config(odko_env* e, const char* name, int* count) {
   CF(noise_accelerometer, 1) CF(noise_gravity, 1) CF(noise_joint_vel, 1) CF(qpos_noise_scale, ODKO_MAXU) CF(reward_scales, 7)
   CF(tracking_sigma, 1) CF(push_enable, 1) CF(push_interval_range, 2) CF(push_magnitude_range, 2) CF(cmd_range, 14)
   CF(use_imitation, 1) CF(use_motor_speed_limits, 1) CF(autoreset, 1) CF(episode_length, 1) CF(n_substeps, 1)
+  CF(env_kind, 1) CF(reset_base_qvel, 1)
   *count = 0; return NULL;
 }
 #define EF(nm, cnt) if (!strcmp(name, #nm)) { *count = (cnt); return (real*)e->nm; }
@@ -309,9 +337,10 @@ static void get_obs(odko_env* e, const real* contact) {
   for (int u = 0; u < nu; u++) o[p++] = e->last_act[u];
   for (int u = 0; u < nu; u++) o[p++] = e->last_last_act[u];
   for (int u = 0; u < nu; u++) o[p++] = e->last_last_last_act[u];
-  for (int u = 0; u < nu; u++) o[p++] = e->motor_targets[u];
+  const int standing = c->env_kind != 0; /* standing.py:524-540: no motor_targets, empty current_reference_motion */
+  if (!standing) for (int u = 0; u < nu; u++) o[p++] = e->motor_targets[u];
   for (int k = 0; k < 2; k++) o[p++] = contact[k];
-  for (int k = 0; k < 2; k++) o[p++] = e->imitation_phase[k];
+  if (!standing) for (int k = 0; k < 2; k++) o[p++] = e->imitation_phase[k];
   real* q = e->priv;
   int s = 0;
   for (int k = 0; k < p; k++) q[s++] = o[k];
@@ -327,9 +356,13 @@ static void get_obs(odko_env* e, const real* contact) {
   for (int k = 0; k < 2; k++) q[s++] = contact[k];
   for (int f = 0; f < 2; f++) for (int k = 0; k < 3; k++) q[s++] = d->sensordata[e->adr_foot_linvel[f] + k];
   for (int k = 0; k < 2; k++) q[s++] = e->feet_air_time[k];
-  for (int k = 0; k < 40; k++) q[s++] = e->current_reference_motion[k];
-  q[s++] = (real)e->imitation_i;
-  for (int k = 0; k < 2; k++) q[s++] = e->imitation_phase[k];
+  if (!standing) {
+    for (int k = 0; k < 40; k++) q[s++] = e->current_reference_motion[k];
+    q[s++] = (real)e->imitation_i;
+    for (int k = 0; k < 2; k++) q[s++] = e->imitation_phase[k];
+  }
+  for (int k = p; k < ODKO_NOBS; k++) o[k] = 0;
+  for (int k = s; k < ODKO_NPRIV; k++) q[k] = 0;
 }
 
 static void quat_mul_local(real* r, const real* a, const real* b) {
@@ -355,7 +388,7 @@ void odko_env_reset(odko_env* e, uint32_t seed, uint32_t env_id) {
   quat_mul_local(nq, d->qpos + 3, qz);
   memcpy(d->qpos + 3, nq, sizeof(nq));
   for (int u = 0; u < nu; u++) d->qpos[e->act_qposadr[u]] *= 0.5 + UR(e, 3 + u) * 1.0;
-  for (int k = 0; k < 6; k++) d->qvel[k] = -0.05 + UR(e, 17 + k) * 0.1;
+  for (int k = 0; k < 6; k++) d->qvel[k] = -e->cfg.reset_base_qvel + UR(e, 17 + k) * (2 * e->cfg.reset_base_qvel);
   for (int u = 0; u < nu; u++) d->ctrl[u] = d->qpos[e->act_qposadr[u]];
   odko_forward(m, d);
   sample_command(e, 1, 23, e->command);
@@ -366,7 +399,7 @@ void odko_env_reset(odko_env* e, uint32_t seed, uint32_t env_id) {
   e->step = 0; e->push_step = 0; e->imitation_i = 0;
   memset(e->last_act, 0, sizeof(e->last_act)); memset(e->last_last_act, 0, sizeof(e->last_last_act));
   memset(e->last_last_last_act, 0, sizeof(e->last_last_last_act));
-  for (int u = 0; u < nu; u++) e->motor_targets[u] = m->key_ctrl[u];
+  for (int u = 0; u < nu; u++) e->motor_targets[u] = e->cfg.env_kind != 0 ? 0.0 : m->key_ctrl[u]; /* standing.py:279 zeros */
   memset(e->feet_air_time, 0, sizeof(e->feet_air_time)); memset(e->swing_peak, 0, sizeof(e->swing_peak));
   memset(e->push, 0, sizeof(e->push)); memset(e->action_history, 0, sizeof(e->action_history));
   memset(e->imu_history, 0, sizeof(e->imu_history)); memset(e->imitation_phase, 0, sizeof(e->imitation_phase));
@@ -443,11 +476,16 @@ void odko_env_step(odko_env* e, const real* action) {
   /* rewards (:622-669, :440-447) */
   real jq[ODKO_MAXU], jv[ODKO_MAXU], rew[7];
   for (int u = 0; u < nu; u++) { jq[u] = d->qpos[e->act_qposadr[u]]; jv[u] = d->qvel[e->act_dofadr[u]]; }
-  rew[0] = odko_reward_tracking_lin_vel(e->command, d->sensordata + e->adr_local_linvel, c->tracking_sigma);
-  rew[1] = odko_reward_tracking_ang_vel(e->command, d->sensordata + e->adr_gyro, c->tracking_sigma);
+  if (c->env_kind != 0) { /* standing.py:585-606 */
+    rew[0] = odko_cost_orientation(d->sensordata + e->adr_upvector);
+    rew[1] = odko_cost_head_pos(jq, e->command);
+  } else {
+    rew[0] = odko_reward_tracking_lin_vel(e->command, d->sensordata + e->adr_local_linvel, c->tracking_sigma);
+    rew[1] = odko_reward_tracking_ang_vel(e->command, d->sensordata + e->adr_gyro, c->tracking_sigma);
+  }
   rew[2] = odko_cost_torques(d->actuator_force, nu);
   rew[3] = odko_cost_action_rate(action, e->last_act, nu);
-  rew[4] = odko_cost_stand_still(e->command, jq, jv, m->key_ctrl, nu);
+  rew[4] = c->env_kind != 0 ? odko_cost_stand_still_legs(e->command, jq, jv, m->key_ctrl, nu) : odko_cost_stand_still(e->command, jq, jv, m->key_ctrl, nu);
   rew[5] = 1.0;
   rew[6] = c->use_imitation ? odko_reward_imitation(d->qpos, d->qvel, jq, jv, contact, e->current_reference_motion, e->command) : 0.0;
   real total = 0;

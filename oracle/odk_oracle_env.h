@@ -1,9 +1,12 @@
-/* odk_oracle_env.h -- CPU restatement of the Joystick task logic.  TEST INFRASTRUCTURE ONLY.
+/* odk_oracle_env.h -- CPU restatement of the Joystick (and Standing) task logic.  TEST INFRASTRUCTURE ONLY.
  * Follows reference playground/open_duck_mini_v2/joystick.py (reset :206-321, step :323-481,
  * termination :483-485, obs :487-620, reward :622-669, command :671-725), base.py index tables
  * (:63-125,154-231), common/rewards.py, open_duck_mini_v2/custom_rewards.py and
  * common/poly_reference_motion.py, plus the brax EpisodeWrapper / AutoResetWrapper semantics
  * that wrap it during training ([UPSTREAM-MEMORY]).
+ * env_kind = 1 selects the Standing task (reference standing.py: reset :200-314, step :316-430, obs :436-567,
+ * reward :569-608, command :610-660): same skeleton; obs without motor_targets / imitation phase (85 / 153 floats),
+ * rewards orientation / head_pos in slots 0 / 1, stand_still with ignore_head, base-velocity reset range 0.5.
  *
  * Random numbers: the reference uses JAX threefry keys carried in info["rng"]; exact stream parity
  * is unpinned, so the build defines its own counter-based stream (threefry2x32
@@ -33,6 +36,8 @@ typedef struct {
   real push_enable, push_interval_range[2], push_magnitude_range[2];
   real cmd_range[7][2];
   real use_imitation, use_motor_speed_limits, autoreset, episode_length, n_substeps;
+  real env_kind;        /* 0 Joystick, 1 Standing */
+  real reset_base_qvel; /* half-range of the base velocity at reset: joystick.py:253 0.05, standing.py:247 0.5 */
 } odko_env_cfg;
 
 typedef struct odko_env {
@@ -88,6 +93,12 @@ real odko_reward_tracking_ang_vel(const real* cmd, const real* ang_vel, real sig
 real odko_cost_torques(const real* torques, int n);
 real odko_cost_action_rate(const real* act, const real* last_act, int n);
 real odko_cost_stand_still(const real* cmd, const real* qpos, const real* qvel, const real* default_pose, int n);
+real odko_cost_stand_still_legs(const real* cmd, const real* qpos, const real* qvel, const real* default_pose, int n); /* ignore_head=True */
+real odko_cost_orientation(const real* torso_zaxis);
+real odko_cost_head_pos(const real* joints_qpos, const real* cmd);
+void odko_env_set_standing(odko_env* e); /* standing.py default_config on top of the defaults */
+int odko_env_nobs(const odko_env* e);
+int odko_env_npriv(const odko_env* e);
 real odko_reward_imitation(const real* base_qpos, const real* base_qvel, const real* joints_qpos, const real* joints_qvel,
                            const real* contacts, const real* ref, const real* cmd);
 

@@ -60,6 +60,8 @@ class _Lib:
         L.odko_env_int.restype = C.POINTER(C.c_int); L.odko_env_int.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
         L.odko_env_data.restype = P; L.odko_env_data.argtypes = [P]
         L.odko_env_reset.argtypes = [P, C.c_uint32, C.c_uint32]
+        L.odko_env_set_standing.argtypes = [P]; L.odko_env_set_standing.restype = None
+        L.odko_env_nobs.argtypes = [P]; L.odko_env_npriv.argtypes = [P]
         L.odko_env_step.argtypes = [P, RP]
         L.odko_rng_uniform.restype = C.c_float; L.odko_rng_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.odko_env_key.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -69,6 +71,9 @@ class _Lib:
         L.odko_cost_torques.restype = self.real; L.odko_cost_torques.argtypes = [RP, C.c_int]
         L.odko_cost_action_rate.restype = self.real; L.odko_cost_action_rate.argtypes = [RP, RP, C.c_int]
         L.odko_cost_stand_still.restype = self.real; L.odko_cost_stand_still.argtypes = [RP, RP, RP, RP, C.c_int]
+        L.odko_cost_stand_still_legs.restype = self.real; L.odko_cost_stand_still_legs.argtypes = [RP, RP, RP, RP, C.c_int]
+        L.odko_cost_orientation.restype = self.real; L.odko_cost_orientation.argtypes = [RP]
+        L.odko_cost_head_pos.restype = self.real; L.odko_cost_head_pos.argtypes = [RP, RP]
         L.odko_reward_imitation.restype = self.real; L.odko_reward_imitation.argtypes = [RP, RP, RP, RP, RP, RP, RP]
         L.odko_rollout_mt.restype = C.c_double
         L.odko_rollout_mt.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
@@ -207,10 +212,12 @@ class OraclePRM:
 class OracleEnv:
     """One Joystick environment (reference joystick.py) incl. Episode/AutoReset wrappers."""
 
-    def __init__(self, model: OracleModel, prm: OraclePRM):
+    def __init__(self, model: OracleModel, prm: OraclePRM, standing: bool = False):
         self.L = model.L
         self.m, self.prm = model, prm
         self.h = self.L.lib.odko_env_new(model.h, prm.h, None)
+        if standing:   # reference standing.py defaults on top of the Joystick ones
+            self.L.lib.odko_env_set_standing(self.h)
         self.f = _Fields(self.L, self.h, self.L.lib.odko_env_field)
         self.cfg = _Fields(self.L, self.h, self.L.lib.odko_env_config)
         self.data = OracleData(model, _handle=self.L.lib.odko_env_data(self.h), owner=False)
@@ -224,6 +231,14 @@ class OracleEnv:
         if not p:
             raise KeyError(name)
         return np.ctypeslib.as_array(p, shape=(n.value,))
+
+    @property
+    def nobs(self) -> int:
+        return self.L.lib.odko_env_nobs(self.h)
+
+    @property
+    def npriv(self) -> int:
+        return self.L.lib.odko_env_npriv(self.h)
 
     def reset(self, seed: int, env_id: int):
         self.L.lib.odko_env_reset(self.h, seed, env_id)

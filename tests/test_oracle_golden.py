@@ -71,5 +71,12 @@ def test_rewards_match_reference(oracle_mod):
         np.testing.assert_allclose(L.lib.odko_cost_stand_still(p(cmd), p(jq), p(jv), p(dp), 14), g["stand_still"][i], **tol)
         np.testing.assert_allclose(L.lib.odko_reward_imitation(p(bq), p(bv), p(jq), p(jv), p(ct), p(ref), p(cmd)), g["imitation"][i],
                                    rtol=1e-11, atol=1e-11)
+        # Standing terms (reference standing.py:585-606)
+        up, ch = a(g["upvector"][i]), a(g["cmd_head"][i])
+        np.testing.assert_allclose(L.lib.odko_cost_orientation(p(up)), g["orientation"][i], **tol)
+        np.testing.assert_allclose(L.lib.odko_cost_head_pos(p(jq), p(ch)), g["head_pos"][i], **tol)
+        np.testing.assert_allclose(L.lib.odko_cost_stand_still_legs(p(ch), p(jq), p(jv), p(dp), 14), g["stand_still_legs"][i], **tol)
     assert g["alive"][0] == 1.0
+    assert (g["head_pos"][:6] == 0).all() and (g["head_pos"][24:] == 0).all() and (g["head_pos"][12:24] > 0).all()   # move-command gate
+    assert np.isnan(g["upvector"][30]).all() and g["orientation"][30] == 0.0
     assert np.isnan(g["torques"][20]).any() and g["torques_cost"][20] == 0.0  # nan_to_num branch is in the fixture

@@ -79,6 +79,15 @@ with np.errstate(all="ignore"):
     out["alive"] = np.array([R.reward_alive()], dtype=np.float64)
     out["imitation"] = np.array([reward_imitation(base_qpos[i], base_qvel[i], jq[i], jv[i], contacts[i], ref[i], cmd[i], True)
                                  for i in range(N)], dtype=np.float64)
+# Standing terms (reference standing.py:585-606): drawn AFTER everything above so the earlier arrays keep their values
+upvec = rng.normal(0, 0.5, size=(N, 3)); upvec[:, 2] = np.abs(upvec[:, 2])
+upvec[30] = np.nan   # nan_to_num branch
+cmd_head = cmd.copy(); cmd_head[24:, :3] = 0.0   # Standing's own command: no move part -> head_pos gate closed
+out["upvector"] = upvec; out["cmd_head"] = cmd_head
+with np.errstate(all="ignore"):
+    out["orientation"] = np.array([R.cost_orientation(upvec[i]) for i in range(N)], dtype=np.float64)
+    out["head_pos"] = np.array([R.cost_head_pos(jq[i], jv[i], cmd_head[i]) for i in range(N)], dtype=np.float64)
+    out["stand_still_legs"] = np.array([R.cost_stand_still(cmd_head[i], jq[i], jv[i], default_pose, ignore_head=True) for i in range(N)], dtype=np.float64)
 np.savez(os.path.join(OUT, "rewards.npz"), **out)
 print("rewards", {k: v.shape for k, v in out.items() if k in ("imitation", "stand_still", "tracking_lin_vel")})
 print(out["imitation"][:12], out["stand_still"][:8])
