@@ -163,6 +163,11 @@ class Joystick:
     @property
     def batch(self) -> "engine.Batch": return self._batch
 
+    def make_eval_env(self, num_envs: int = 128):
+        """Sibling env for the Evaluator (brax wraps `eval_env or environment` a second time with num_eval_envs)."""
+        return type(self)(task=self._task, config=self._config, num_envs=num_envs, device=self._batch.device, autoreset=True,
+                          env_id_offset=1 << 24)
+
     def randomize(self, rng: np.random.Generator):
         """randomization_fn hook of brax ppo.train (reference runner.py:26, common/runner.py:108)."""
         from . import randomize

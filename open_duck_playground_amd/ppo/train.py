@@ -156,14 +156,19 @@ def rollout(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generat
 
 def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = None, policy_params_fn: Optional[Callable] = None,
           restore_checkpoint_path: Optional[str] = None, seed: int = 0, randomization_fn: Optional[Callable] = None,
-          log_path: Optional[str] = None, **overrides):
-    """Trains on `environment` (a batched Joystick).  Returns (networks, metrics)."""
+          log_path: Optional[str] = None, eval_env=None, **overrides):
+    """Trains on `environment` (a batched Joystick / Standing).  Returns (networks, metrics).
+
+    Epoch structure of brax ppo.train: `num_evals - 1` epochs of `ceil(num_timesteps / (epochs * env_steps_per_iter *
+    num_resets_per_eval))` training steps, the env re-reset `num_resets_per_eval` times per epoch, one evaluation
+    (Evaluator, deterministic policy, `num_eval_envs` envs) before training and after every epoch, then
+    `progress_fn(env_steps, metrics)` and `policy_params_fn(env_steps, networks)` on rank 0."""
     import torch.distributed as dist
     cfg = ppo_config()
     cfg.update({k: v for k, v in overrides.items() if v is not None})
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    dev = environment.batch.obs.device
+    dev = environment.batch.obs.device if hasattr(environment, "batch") else environment.device
     nf = cfg["network_factory"]
     torch.manual_seed(seed)   # identical initial parameters on every rank
     net = PPONetworks(environment.observation_size["state"][0], environment.observation_size["privileged_state"][0], environment.action_size,
@@ -175,37 +180,64 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
     learner = None
     if randomization_fn is not None:
         randomization_fn(environment)
-    state = environment.reset(seed)
     n_local = environment.num_envs
-    steps_per_iter = n_local * world * cfg["unroll_length"]
-    num_iters = max(1, -(-num_timesteps // steps_per_iter))
-    eval_every = max(1, num_iters // max(1, cfg["num_evals"]))
-    t0 = time.time(); done_steps = 0; metrics = {}
+    steps_per_iter = n_local * world * cfg["unroll_length"] * cfg["action_repeat"]
+    num_evals_after_init = max(cfg["num_evals"] - 1, 1)
+    resets = max(cfg["num_resets_per_eval"], 1)
+    iters_per_epoch = max(1, -(-num_timesteps // (num_evals_after_init * steps_per_iter * resets)))
+    evaluator = None
+    if cfg.get("num_eval_envs", 128) and rank == 0:
+        if eval_env is None and hasattr(environment, "make_eval_env"):
+            eval_env = environment.make_eval_env(cfg.get("num_eval_envs", 128))
+            if randomization_fn is not None:
+                randomization_fn(eval_env)
+        if eval_env is not None:
+            from .evaluator import Evaluator
+            evaluator = Evaluator(eval_env, cfg["episode_length"], cfg["action_repeat"])
     log = open(log_path, "a") if (log_path and rank == 0) else None
-    for it in range(num_iters):
-        data, state = rollout(environment, net, state, cfg["unroll_length"], gen)
-        if cfg["normalize_observations"]:
-            grp = dist.group.WORLD if world > 1 else None
-            net.norm_obs.update(data["obs"], grp); net.norm_priv.update(data["priv"], grp)
-        if it == 0:
-            learner = make_learner(net, data, cfg, world)
-        loss_metrics = sgd_epoch(net, opt, data, cfg, gen, world, learner=learner)
-        done_steps += steps_per_iter
-        if (it + 1) % eval_every == 0 or it == num_iters - 1:
-            ep_rew = (data["reward"].sum(1)).mean()
-            m = torch.stack([ep_rew, data["done"].mean()])
-            if world > 1:
-                dist.all_reduce(m); m /= world
-            metrics = {"training/sps": done_steps / (time.time() - t0), "training/walltime": time.time() - t0,
-                       "training/unroll_reward": float(m[0]), "training/done_rate": float(m[1]),
-                       **{f"training/{k}": float(v) for k, v in loss_metrics.items()}}
-            if rank == 0:
-                if log:
-                    log.write(json.dumps({"step": done_steps, **metrics}) + "\n"); log.flush()
-                if progress_fn:
-                    progress_fn(done_steps, metrics)
-                if policy_params_fn:
-                    policy_params_fn(done_steps, net)
+    t0 = time.time(); done_steps = 0; metrics = {}
+
+    def report(training_metrics):
+        m = evaluator.run_evaluation(net, training_metrics, seed=seed + 1) if evaluator is not None else dict(training_metrics)
+        if rank == 0:
+            if log:
+                log.write(json.dumps({"step": done_steps, **m}) + "\n"); log.flush()
+            if progress_fn:
+                progress_fn(done_steps, m)
+        return m
+
+    if cfg["num_evals"] > 1 and evaluator is not None:
+        metrics = report({})
+    state = environment.reset(seed)
+    reset_count = 0
+    for epoch in range(num_evals_after_init):
+        t_epoch = time.time()
+        for _ in range(resets):
+            for _ in range(iters_per_epoch):
+                data, state = rollout(environment, net, state, cfg["unroll_length"], gen)
+                if cfg["normalize_observations"]:
+                    grp = dist.group.WORLD if world > 1 else None
+                    net.norm_obs.update(data["obs"], grp); net.norm_priv.update(data["priv"], grp)
+                if learner is None and done_steps == 0:
+                    learner = make_learner(net, data, cfg, world)
+                loss_metrics = sgd_epoch(net, opt, data, cfg, gen, world, learner=learner)
+                done_steps += steps_per_iter
+            if cfg["num_resets_per_eval"] > 0:
+                reset_count += 1
+                state = environment.reset(seed + 7919 * reset_count)
+        ep_rew = (data["reward"].sum(1)).mean()
+        m = torch.stack([ep_rew, data["done"].mean()])
+        if world > 1:
+            dist.all_reduce(m); m /= world
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        epoch_time = time.time() - t_epoch
+        training_metrics = {"training/sps": iters_per_epoch * resets * steps_per_iter / epoch_time, "training/walltime": time.time() - t0,
+                            "training/unroll_reward": float(m[0]), "training/done_rate": float(m[1]),
+                            **{f"training/{k}": float(v) for k, v in loss_metrics.items()}}
+        metrics = report(training_metrics)
+        if rank == 0 and policy_params_fn:
+            policy_params_fn(done_steps, net)
     if log:
         log.close()
     return net, metrics

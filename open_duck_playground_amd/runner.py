@@ -40,8 +40,12 @@ class OpenDuckMiniV2Runner:
         print(f"Observation size: {self.obs_size}")
 
     def progress_callback(self, num_steps, metrics):
+        for name, value in metrics.items():   # reference common/runner.py:58-60
+            self.writer.add_scalar(name, value, num_steps)
+        self.writer.flush()
         print("-----------")
-        print(f'STEP: {num_steps} reward: {metrics.get("training/unroll_reward")} sps: {metrics.get("training/sps"):.0f}')
+        print(f'STEP: {num_steps} reward: {metrics.get("eval/episode_reward")} reward_std: {metrics.get("eval/episode_reward_std")}'
+              f' sps: {metrics.get("training/sps", 0.0):.0f}')
         print("-----------")
 
     def policy_params_fn(self, current_step, net):
@@ -49,9 +53,13 @@ class OpenDuckMiniV2Runner:
         path = f"{self.output_dir}/{d}_{current_step}.pt"
         print(f"Saving checkpoint (step: {current_step}): {path}")
         self.ppo.save_checkpoint(path, net)
+        from .export_onnx import export_onnx   # reference common/runner.py:77-84
+        export_onnx(net, output_path=f"{self.output_dir}/{d}_{current_step}.onnx")
 
     def train(self):
         os.makedirs(self.output_dir, exist_ok=True)
+        from .tb_writer import SummaryWriter
+        self.writer = SummaryWriter(self.output_dir)   # reference common/runner.py:38-39 (tensorboardX)
         return self.ppo.train(self.env, num_timesteps=self.args.num_timesteps, progress_fn=self.progress_callback,
                               policy_params_fn=self.policy_params_fn, restore_checkpoint_path=self.args.restore_checkpoint_path,
                               seed=self.args.seed, randomization_fn=self.randomizer, log_path=os.path.join(self.output_dir, "metrics.jsonl"),

@@ -1,0 +1,50 @@
+"""ONNX policy export (reference playground/common/export_onnx.py): contract = input "obs" (1, obs_size), output
+"continuous_actions" = tanh(loc) (1, action_size), opset 11."""
+import numpy as np
+import torch
+
+from open_duck_playground_amd import export_onnx as X
+from open_duck_playground_amd.ppo.networks import PPONetworks
+
+
+def test_export_matches_policy_module(tmp_path):
+    torch.manual_seed(0)
+    net = PPONetworks(101, 212, 14)
+    net.norm_obs.update(torch.randn(4096, 101) * 3.0 + 0.5)
+    path = X.export_onnx(net, str(tmp_path / "policy.onnx"))
+    blob = open(path, "rb").read()
+    m = X.load_onnx(blob)
+    assert m["ir_version"] == 6 and m["opset"] == 11                                   # export_onnx.py:177
+    assert m["inputs"] == [("obs", [1, 101])] and m["outputs"] == [("continuous_actions", [1, 14])]   # :170-175
+    ops = [n["op"] for n in m["nodes"]]
+    assert ops == ["Sub", "Div", "Gemm", "Sigmoid", "Mul", "Gemm", "Sigmoid", "Mul", "Gemm", "Sigmoid", "Mul", "Gemm", "Tanh"]
+    assert m["initializers"]["hidden_3/kernel"].shape == (14, 128)                     # loc half only (:71)
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        obs = rng.normal(0, 2, (1, 101)).astype(np.float32)
+        with torch.no_grad():
+            loc, _ = net.dist_params(torch.from_numpy(obs))
+        np.testing.assert_allclose(X.run_onnx(m, obs), torch.tanh(loc).numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_wire_format_is_valid_protobuf():
+    """Independent check of the byte stream with the protobuf runtime: every length-delimited field nests cleanly."""
+    from google.protobuf.internal import decoder
+    blob = X.policy_to_onnx(np.zeros(5, np.float32), np.ones(5, np.float32), [np.eye(4, 5, dtype=np.float32), np.ones((6, 4), np.float32)],
+                            [np.zeros(4, np.float32), np.zeros(6, np.float32)], 3)
+    pos, fields = 0, []
+    while pos < len(blob):
+        tag, pos = decoder._DecodeVarint(blob, pos)
+        field, wire = tag >> 3, tag & 7
+        if wire == 0:
+            _, pos = decoder._DecodeVarint(blob, pos)
+        else:
+            assert wire == 2
+            n, pos = decoder._DecodeVarint(blob, pos)
+            pos += n
+        fields.append(field)
+    assert pos == len(blob) and fields == [1, 2, 3, 7, 8]
+    m = X.load_onnx(blob)
+    out = X.run_onnx(m, np.array([[1, 2, 3, 4, 5]], np.float32))
+    x = np.array([1, 2, 3, 4]) ; h = x / (1 + np.exp(-x)) * 1.0
+    np.testing.assert_allclose(out, np.tanh(np.full((1, 3), h.sum())), rtol=1e-6)

@@ -122,3 +122,67 @@ def test_data_parallel_two_ranks_gloo():
     assert same_params and same_stats
     assert count == 2 * 32 * 8                                   # both shards counted
     assert not np.allclose(local_mean, global_mean, atol=1e-6)   # statistics are global, not rank-local
+
+
+class _ToyEnv:
+    """CPU stand-in with the Joystick surface: reward is high when tanh-action[0] tracks obs[0]."""
+
+    def __init__(self, num_envs=64, seed=0):
+        self.num_envs, self.device = num_envs, torch.device("cpu")
+        self.action_size = 2
+        self.observation_size = {"state": (5,), "privileged_state": (7,)}
+        self.g = torch.Generator().manual_seed(seed)
+        self.resets = 0
+
+    def make_eval_env(self, n):
+        return _ToyEnv(n, seed=99)
+
+    def _state(self, reward, done):
+        from open_duck_playground_amd.joystick import State
+        self.target = torch.rand(self.num_envs, generator=self.g) * 1.6 - 0.8
+        obs = torch.cat([self.target[:, None], torch.randn(self.num_envs, 4, generator=self.g) * 0.1], 1)
+        priv = torch.cat([obs, torch.zeros(self.num_envs, 2)], 1)
+        return State(data=None, obs={"state": obs, "privileged_state": priv}, reward=reward, done=done,
+                     metrics={"reward/track": reward.clone()}, info={"truncation": torch.zeros(self.num_envs)})
+
+    def reset(self, seed):
+        self.resets += 1
+        self.t = torch.zeros(self.num_envs)
+        return self._state(torch.zeros(self.num_envs), torch.zeros(self.num_envs))
+
+    def step(self, state, action):
+        reward = 1.0 - (action[:, 0] - self.target).abs()
+        self.t += 1
+        done = (self.t >= 10).float()
+        self.t = self.t * (1 - done)
+        return self._state(reward, done)
+
+
+def test_train_loop_epochs_evaluator_and_callbacks(tmp_path):
+    env = _ToyEnv(64)
+    seen, saved = [], []
+    net, metrics = T.train(env, num_timesteps=64 * 5 * 12, progress_fn=lambda s, m: seen.append((s, dict(m))),
+                           policy_params_fn=lambda s, n: saved.append(s), seed=0, log_path=str(tmp_path / "m.jsonl"),
+                           num_evals=4, unroll_length=5, num_minibatches=4, num_updates_per_batch=2, episode_length=20, num_eval_envs=16,
+                           learning_rate=3e-3, network_factory=dict(policy_hidden_layer_sizes=(32, 32), value_hidden_layer_sizes=(32, 32)))
+    # brax epoch structure: 1 initial evaluation + (num_evals - 1) epochs of ceil(3840 / (3 * 320)) = 4 training steps
+    assert [s for s, _ in seen] == [0, 1280, 2560, 3840] and saved == [1280, 2560, 3840]
+    assert env.resets == 1 + 3                                  # initial reset + num_resets_per_eval = 1 per epoch
+    first, last = seen[0][1], seen[-1][1]
+    for k in ("eval/episode_reward", "eval/episode_reward_std", "eval/episode_reward/track", "eval/avg_episode_length", "eval/sps"):
+        assert k in first and k in last
+    assert first["eval/avg_episode_length"] == 10.0              # EvalWrapper: only the first episode of each env counts
+    assert abs(first["eval/episode_reward"] - first["eval/episode_reward/track"]) < 1e-5
+    assert "training/sps" in last and "training/total_loss" in last and "training/sps" not in first
+    assert last["eval/episode_reward"] > first["eval/episode_reward"]       # it learns to track
+    import json
+    lines = [json.loads(l) for l in open(tmp_path / "m.jsonl")]
+    assert [l["step"] for l in lines] == [0, 1280, 2560, 3840]
+
+
+def test_tensorboard_writer_round_trip(tmp_path):
+    from open_duck_playground_amd.tb_writer import SummaryWriter, crc32c, read_scalars
+    assert crc32c(b"123456789") == 0xE3069283                   # CRC-32C check value
+    w = SummaryWriter(str(tmp_path))
+    w.add_scalar("eval/episode_reward", 3.5, 100); w.add_scalar("training/sps", 1.0e6, 163840); w.close()
+    assert list(read_scalars(w.path)) == [("eval/episode_reward", 100, 3.5), ("training/sps", 163840, 1.0e6)]
