@@ -221,6 +221,10 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   const bool live = env < a.nenv;
   const int e = live ? env : a.nenv - 1;
   float* L = lds + slot * E::TOTAL;
+#ifdef ODK_POISON_LDS   // debug build: every read of LDS that was not written by this launch surfaces as NaN
+  for (int k = lane; k < E::TOTAL; k += G) L[k] = __int_as_float(0x7fc00000);
+  ODK_SYNC();
+#endif
   const DevModel* m = a.m;
   const EnvCfg& c = a.cfg;
   float* INFO = L + E::O_INFO;
@@ -300,6 +304,10 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   const bool live = env < a.nenv;
   const int e = live ? env : a.nenv - 1;
   float* L = lds + slot * E::TOTAL;
+#ifdef ODK_POISON_LDS   // debug build: every read of LDS that was not written by this launch surfaces as NaN
+  for (int k = lane; k < E::TOTAL; k += G) L[k] = __int_as_float(0x7fc00000);
+  ODK_SYNC();
+#endif
   const DevModel* m = a.m;
   const EnvCfg& c = a.cfg;
   float* INFO = L + E::O_INFO; float* ACT = L + E::O_ACT; float* CTRL = L + S::O_CTRL;
@@ -497,6 +505,10 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   const bool live = env < a.nenv;
   const int e = live ? env : a.nenv - 1;
   float* L = lds + slot * E::TOTAL;
+#ifdef ODK_POISON_LDS   // debug build: every read of LDS that was not written by this launch surfaces as NaN
+  for (int k = lane; k < E::TOTAL; k += G) L[k] = __int_as_float(0x7fc00000);
+  ODK_SYNC();
+#endif
   float* rc = a.recs + (size_t)e * R::SIZE;
   for (int i = lane; i < S::NQ + 2 * S::NV; i += G) L[S::O_QPOS + i] = rc[i];
   for (int u = lane; u < S::NU; u += G) L[S::O_CTRL + u] = a.action[(size_t)e * S::NU + u];

@@ -160,6 +160,7 @@ template <int G, class Op> __device__ __forceinline__ float greduce(float v) {
 }
 template <int G> __device__ __forceinline__ float gsum(float v) { return greduce<G, OpSum>(v); }
 template <int G> __device__ __forceinline__ float gmax(float v) { return greduce<G, OpMax>(v); }
+template <int G> __device__ __forceinline__ float gmin(float v) { return greduce<G, OpMin>(v); }
 // argmax, lowest index wins ties (jnp.argmax semantics): max of the values, then min index among the maxima
 template <int G> __device__ __forceinline__ int gargmax(float v, int i) {
   const float mx = greduce<G, OpMax>(v);
@@ -571,6 +572,134 @@ __device__ inline void row_params(const float* solref, const float* solimp, floa
 // ------------------------------------------------------------------------------------------------
 // One mjx.forward for one env (all G lanes of the group call this together).
 //   flags bit0: compute sensordata / debug outputs (last substep only)
+// mjx collision_convex._manifold_points: 4 support points of approximately maximal area among the vertices within
+// 1e-3 of the deepest one (lane = vertex; `n` = contact normal)
+template <int G>
+__device__ __forceinline__ void select4(const float* w, bool has, float sup, int nvt, const float* n, int* idx, int lane) {
+  const float smax = gmax<G>(sup);
+  const float thr = fmaxf(0.0f, smax - 1e-3f);
+  const float dm = has ? ((sup > thr) ? 0.0f : -1e6f) : -3.0e38f;
+  idx[0] = gargmax<G>(dm, lane);
+  float a[3] = {__shfl(w[0], idx[0], G), __shfl(w[1], idx[0], G), __shfl(w[2], idx[0], G)};
+  float ap[3] = {a[0] - w[0], a[1] - w[1], a[2] - w[2]};
+  idx[1] = gargmax<G>(has ? dot3(ap, ap) + dm : -3.0e38f, lane);
+  float bq[3] = {__shfl(w[0], idx[1], G), __shfl(w[1], idx[1], G), __shfl(w[2], idx[1], G)};
+  float amb[3] = {a[0] - bq[0], a[1] - bq[1], a[2] - bq[2]}, ab[3];
+  cross3(ab, n, amb);
+  idx[2] = gargmax<G>(has ? fabsf(dot3(ap, ab)) + dm : -3.0e38f, lane);
+  float cq[3] = {__shfl(w[0], idx[2], G), __shfl(w[1], idx[2], G), __shfl(w[2], idx[2], G)};
+  float amc[3] = {a[0] - cq[0], a[1] - cq[1], a[2] - cq[2]}, bmc[3] = {bq[0] - cq[0], bq[1] - cq[1], bq[2] - cq[2]}, ac[3], bc[3];
+  cross3(ac, n, amc);
+  cross3(bc, n, bmc);
+  float bp[3] = {bq[0] - w[0], bq[1] - w[1], bq[2] - w[2]};
+  float v1 = fabsf(dot3(bp, bc)) + dm, v2 = fabsf(dot3(ap, ac)) + dm;
+  float vv = v1; int vi = lane;
+  if (v2 > v1) { vv = v2; vi = nvt + lane; }
+  if (!has) { vv = -3.0e38f; vi = 2 * nvt + lane; }
+  idx[3] = gargmax<G>(vv, vi);
+  idx[3] = idx[3] >= nvt ? idx[3] - nvt : idx[3];
+}
+
+// Foot-foot (mesh-mesh) contact manifold: face-normal SAT over both hulls + 4-point manifold, the same restatement as
+// oracle convex_convex.  Called by every lane of the wave; envs whose boxes are separated are masked by `overlap`.
+template <class S, int G>
+__device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict__ m, int lane, bool overlap) {
+  constexpr int NB = S::NB;
+  float* W = L + S::O_W; float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR;
+  const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
+  const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
+  float fR[2][9], fP[2][3];
+  for (int f = 0; f < 2; f++) {
+    const int fb = m->foot_body[f];
+    float q[4];
+    for (int k = 0; k < 4; k++) q[k] = XQUAT[k * NB + fb];
+    for (int k = 0; k < 3; k++) fP[f][k] = XPOS[k * NB + fb];
+    q2mat(fR[f], q);
+  }
+    // Overlapping boxes (feet about to touch, rare): face-normal SAT over both hulls + 4-point manifold, the same
+    // restatement as oracle convex_convex.  Wave-uniform branch; envs whose boxes are separated are masked out.
+    {
+      float* VW = W;   // [2][MAXHV][3] world vertices; the wrench area is free until P8
+      const int n1 = m->foot_nvert[0], n2 = m->foot_nvert[1];
+      float w2[3] = {0, 0, 0};
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        if (lane < m->foot_nvert[f]) {
+          const float vb[3] = {m->foot_vert[f][lane][0], m->foot_vert[f][lane][1], m->foot_vert[f][lane][2]};
+          for (int k = 0; k < 3; k++) {
+            const float x = fP[f][k] + fR[f][3 * k] * vb[0] + fR[f][3 * k + 1] * vb[1] + fR[f][3 * k + 2] * vb[2];
+            VW[(f * MAXHV + lane) * 3 + k] = x;
+            if (f == 1) w2[k] = x;
+          }
+        }
+      }
+      ODK_SYNC();
+      float mybest = -3.0e38f, myax[3] = {0, 0, 1};
+      int myidx = 1 << 20;
+      for (int f = 0; f < 2; f++) {
+        for (int fi = lane; fi < m->foot_nface[f]; fi += G) {
+          const float* v0 = VW + (f * MAXHV + m->foot_face[f][fi][0]) * 3;
+          const float* v1 = VW + (f * MAXHV + m->foot_face[f][fi][1]) * 3;
+          const float* v2 = VW + (f * MAXHV + m->foot_face[f][fi][2]) * 3;
+          const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]}, e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+          float nr[3];
+          cross3(nr, e1, e2);
+          const float nn = sqrtf(dot3(nr, nr));
+          if (nn == 0.0f) continue;
+          nr[0] /= nn; nr[1] /= nn; nr[2] /= nn;
+          float max1 = -3.0e38f, min1 = 3.0e38f, max2 = -3.0e38f, min2 = 3.0e38f;
+          for (int i = 0; i < n1; i++) { const float pr = dot3(VW + i * 3, nr); max1 = fmaxf(max1, pr); min1 = fminf(min1, pr); }
+          for (int i = 0; i < n2; i++) { const float pr = dot3(VW + (MAXHV + i) * 3, nr); max2 = fmaxf(max2, pr); min2 = fminf(min2, pr); }
+          const float sa = min2 - max1, sb = min1 - max2;
+          const float sp = sa > sb ? sa : sb;
+          if (sp > mybest) {
+            mybest = sp; myidx = f * MAXHF + fi;
+            const float sg = sb > sa ? -1.0f : 1.0f;
+            myax[0] = sg * nr[0]; myax[1] = sg * nr[1]; myax[2] = sg * nr[2];
+          }
+        }
+      }
+      const float hsep = gmax<G>(mybest);
+      const int widx = (int)gmin<G>(mybest == hsep ? (float)myidx : 1.0e9f);   // first face in (hull, face) order wins ties
+      ODK_SYNC();
+      if (overlap && myidx == widx) { SCR[S::S_VF] = myax[0]; SCR[S::S_VF + 1] = myax[1]; SCR[S::S_VF + 2] = myax[2]; }
+      ODK_SYNC();
+      const float ax[3] = {SCR[S::S_VF], SCR[S::S_VF + 1], SCR[S::S_VF + 2]};
+      // penetrating: hull 1's support plane along the axis vs the deepest vertices of hull 2
+      const float p1 = (lane < n1) ? dot3(VW + lane * 3, ax) : -3.0e38f;
+      const float max1 = gmax<G>(p1);
+      const bool has2 = lane < n2;
+      const float sup2 = has2 ? max1 - dot3(w2, ax) : -3.0e38f;
+      int idx[4];
+      select4<G>(w2, has2, sup2, n2, ax, idx, lane);
+      const bool pen = overlap && !(hsep > 0.0f);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        bool uniq = true;
+        for (int q = 0; q < k; q++) uniq = uniq && (idx[q] != idx[k]);
+        const int c = 8 + k;
+        if (pen && lane == idx[k]) {
+          const float dist = uniq ? -sup2 : 1.0f;
+          CDIST[c] = dist;
+          for (int t = 0; t < 3; t++) CR[3 * c + t] = w2[t] - 0.5f * dist * ax[t] - ref[t];
+        }
+        if (overlap && !pen && lane == 0) CDIST[c] = k == 0 ? hsep : 1.0f;
+      }
+      if (overlap && lane == 0) {
+        SCR[S::S_MISC] = hsep;
+        // contact frame (make_frame): normal, then a tangent from the less aligned of y / z
+        float b[3] = {0, 0, 0}, cc[3];
+        if (fabsf(ax[1]) < 0.5f) b[1] = 1.0f; else b[2] = 1.0f;
+        const float dtb = dot3(ax, b);
+        b[0] -= dtb * ax[0]; b[1] -= dtb * ax[1]; b[2] -= dtb * ax[2];
+        const float nb = sqrtf(dot3(b, b));
+        b[0] /= nb; b[1] /= nb; b[2] /= nb;
+        cross3(cc, ax, b);
+        for (int t = 0; t < 3; t++) { SCR[S::S_VF + 3 + t] = b[t]; SCR[S::S_VF + 6 + t] = cc[t]; }
+      }
+    }
+  }
+
 template <class S, int G>
 __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane, int flags) {
   constexpr int NV = S::NV, NB = S::NB;
@@ -845,29 +974,8 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
       for (int k = 0; k < 3; k++) w[k] = fP[f][k] + fR[f][3 * k] * vb[0] + fR[f][3 * k + 1] * vb[1] + fR[f][3 * k + 2] * vb[2];
       sup = (m->plane_pos[0] - w[0]) * pn[0] + (m->plane_pos[1] - w[1]) * pn[1] + (m->plane_pos[2] - w[2]) * pn[2];
     }
-    const float smax = gmax<G>(sup);
-    const float thr = fmaxf(0.0f, smax - 1e-3f);
-    const float dm = has ? ((sup > thr) ? 0.0f : -1e6f) : -3.0e38f;
     int idx[4];
-    idx[0] = gargmax<G>(dm, lane);
-    float a[3] = {__shfl(w[0], idx[0], G), __shfl(w[1], idx[0], G), __shfl(w[2], idx[0], G)};
-    float ap[3] = {a[0] - w[0], a[1] - w[1], a[2] - w[2]};
-    idx[1] = gargmax<G>(has ? dot3(ap, ap) + dm : -3.0e38f, lane);
-    float bq[3] = {__shfl(w[0], idx[1], G), __shfl(w[1], idx[1], G), __shfl(w[2], idx[1], G)};
-    float amb[3] = {a[0] - bq[0], a[1] - bq[1], a[2] - bq[2]}, ab[3];
-    cross3(ab, pn, amb);
-    idx[2] = gargmax<G>(has ? fabsf(dot3(ap, ab)) + dm : -3.0e38f, lane);
-    float cq[3] = {__shfl(w[0], idx[2], G), __shfl(w[1], idx[2], G), __shfl(w[2], idx[2], G)};
-    float amc[3] = {a[0] - cq[0], a[1] - cq[1], a[2] - cq[2]}, bmc[3] = {bq[0] - cq[0], bq[1] - cq[1], bq[2] - cq[2]}, ac[3], bc[3];
-    cross3(ac, pn, amc);
-    cross3(bc, pn, bmc);
-    float bp[3] = {bq[0] - w[0], bq[1] - w[1], bq[2] - w[2]};
-    float v1 = fabsf(dot3(bp, bc)) + dm, v2 = fabsf(dot3(ap, ac)) + dm;
-    float vv = v1; int vi = lane;
-    if (v2 > v1) { vv = v2; vi = nvt + lane; }
-    if (!has) { vv = -3.0e38f; vi = 2 * nvt + lane; }
-    idx[3] = gargmax<G>(vv, vi);
-    idx[3] = idx[3] >= nvt ? idx[3] - nvt : idx[3];
+    select4<G>(w, has, sup, nvt, pn, idx, lane);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       bool uniq = true;
@@ -926,12 +1034,15 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     const float best = gmax<G>(sep);
     if (lane < 4) {
       const int c = 8 + lane;
-      // separated boxes -> inactive pair.  Overlapping boxes (feet about to touch) need the full convex-convex
-      // routine, which round 1 does not carry on the GPU: the pair is reported inactive and flagged.
+      // separated boxes -> inactive pair (the box separation bounds the hulls' from below)
       CDIST[c] = (lane == 0 && best > 0) ? best : 1.0f;
       CR[3 * c] = 0; CR[3 * c + 1] = 0; CR[3 * c + 2] = 0;
       if (lane == 0) SCR[S::S_MISC] = best;
     }
+    // Overlapping boxes (feet about to touch; never seen in random-action rollouts): full SAT manifold, kept out of line
+    // so that the hot path's register allocation does not pay for it.  Wave-uniform branch.
+    const bool overlap = !(best > 0.0f);
+    if (__builtin_amdgcn_ballot_w64(overlap) != 0) foot_foot_sat<S, G>(L, m, lane, overlap);
   }
   ODK_SYNC();
   ODK_PROF(8);
@@ -962,7 +1073,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     const float dist = CDIST[c];
     const float mu = m->pair_mu[pair];
     const float fs = (s & 1) ? -mu : mu;
-    const float* fr = m->plane_frame;  // pair 2 (foot-foot) frames come with the convex-convex routine
+    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : m->plane_frame;  // foot-foot frame: left in S_VF by the SAT routine
     const int td = 3 * (1 + (s >> 1));
     const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
     const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};

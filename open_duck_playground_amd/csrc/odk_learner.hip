@@ -125,6 +125,8 @@ __global__ void ppo_head_kernel(const float* __restrict__ logits, const float* _
   }
 }
 
+__global__ void zero1_kernel(float* p) { *p = 0.0f; }
+
 // acc[0] += sum g^2 (caller zeroes acc); block 0 / thread 0 advances the step counter acc[1].
 __global__ void sqnorm_kernel(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
   __shared__ float sh[16];
@@ -189,7 +191,9 @@ extern "C" int odk_adam_clip(float* params_dev, const float* grads_dev, float* m
                              float b1, float b2, float eps, float max_grad_norm, void* stream) {
   if (!params_dev || !grads_dev || !m_dev || !v_dev || !acc_dev || n <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc_dev, 0, sizeof(float), st) != hipSuccess) return odk_fail_(ODK_ERR_HIP, "odk_adam_clip: memset failed");
+  // a kernel, not hipMemsetAsync: a memset NODE in the middle of a captured graph raced with its neighbours on ROCm 7.2
+  // (intermittent non-finite updates, 3 of 12 runs; 0 of 36 with this launch) -- keep the graph kernels-only
+  hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, st, acc_dev);
   const int threads = 256;
   int blocks = (int)((n + threads * 4 - 1) / (threads * 4));
   if (blocks > 1024) blocks = 1024;

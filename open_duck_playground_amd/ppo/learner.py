@@ -20,8 +20,12 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
+import os
+
 from .. import engine
 from .networks import PPONetworks
+
+_DEBUG_NONFINITE = os.environ.get("ODK_DEBUG_NONFINITE") == "1"   # per-step finiteness check (synchronises: debugging only)
 
 
 class _FlatMLP:
@@ -158,7 +162,21 @@ class FlatLearner:
                 self.graph_b.replay()
             else:
                 self._update()
+        if _DEBUG_NONFINITE:
+            self._debug_check()
         return self.losses
+
+    def _debug_check(self):
+        torch.cuda.synchronize()
+        if bool(torch.isfinite(self.losses).all()) or getattr(self, "_reported", False):
+            return
+        self._reported = True
+        print("NONFINITE losses", self.losses.tolist(), "stats", self.stats.tolist(), "acc", self.acc.tolist(), flush=True)
+        for k, v in self.static.items():
+            print("   static", k, bool(torch.isfinite(v).all()), float(v.abs().nan_to_num().max()), flush=True)
+        for nm in ("noise", "vs", "adv", "dlogits", "dval_all", "flat_g", "flat_p", "m", "v"):
+            t = getattr(self, nm)
+            print("   ", nm, bool(torch.isfinite(t).all()), float(t.abs().nan_to_num().max()), flush=True)
 
     def metrics(self):
         l = self.losses

@@ -132,7 +132,8 @@ def make_learner(net, data, cfg, world: int = 1, group=None):
     if not data["reward"].is_cuda or B % cfg["num_minibatches"] != 0 or not cfg.get("use_graphs", True):
         return None
     from .learner import FlatLearner
-    return FlatLearner(net, cfg, B // cfg["num_minibatches"], data["reward"].shape[1], world, group)
+    return FlatLearner(net, cfg, B // cfg["num_minibatches"], data["reward"].shape[1], world, group,
+                       use_graph=os.environ.get("ODK_LEARNER_GRAPH", "1") != "0")
 
 
 @torch.no_grad()

@@ -66,6 +66,8 @@ def test_short_ppo_training_runs():
     seen = []
     net, metrics = T.train(env, num_timesteps=256 * 20 * 3, seed=0, num_minibatches=4, num_updates_per_batch=2, num_evals=3,
                            progress_fn=lambda s, m: seen.append((s, m)))
-    assert len(seen) == 3 and seen[-1][0] == 256 * 20 * 3
+    # brax epoch structure: initial evaluation + (num_evals - 1) epochs of ceil(15360 / (2 * 5120)) = 2 training steps
+    assert [s for s, _ in seen] == [0, 2 * 5120, 4 * 5120]
+    assert "eval/episode_reward" in seen[0][1] and "eval/episode_reward/tracking_lin_vel" in metrics
     assert np.isfinite(metrics["training/unroll_reward"]) and np.isfinite(metrics["training/total_loss"])
     assert metrics["training/sps"] > 0

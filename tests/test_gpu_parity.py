@@ -149,3 +149,63 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, task):
     print(task, "10 substeps: worst rel qpos", wq, "qvel", wv)
     assert wq < 5e-4 and wv < 5e-3
     b.close()
+
+
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+def test_foot_foot_contacts(torch_cuda, oracle_mod, task):
+    """Feet pressed into each other (hip rolls inwards, robot lifted off the floor): the foot-foot SAT manifold,
+    its contact rows and the coupled (virtual-tree) Hessian path against the oracle, one mjx.step."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    torch = torch_cuda
+    model = load_task_model(task)
+    a = model.a
+    from open_duck_playground_amd.tables import build_kernel_tables
+    tabs = build_kernel_tables(a)
+    aq = tabs["k_act_qposadr"]          # actuator order: L hip_yaw, hip_roll, ... (SURVEY A.3)
+    lroll, rroll = int(aq[1]), int(aq[10])
+    rng = np.random.default_rng(5)
+    grid = [(l, r) for l in (0.35, 0.4, 0.45, 0.5, 0.55, 0.6) for r in (-0.6, -0.55, -0.5, -0.45, -0.4, -0.3)]
+    n = len(grid)
+    qpos = np.tile(np.asarray(a["key_qpos"], np.float64), (n, 1)); qvel = np.zeros((n, model.nv))
+    for e, (l, r) in enumerate(grid):
+        qpos[e, 2] = 0.3
+        qpos[e, lroll] = l + rng.uniform(-0.01, 0.01); qpos[e, rroll] = r + rng.uniform(-0.01, 0.01)
+        qvel[e, 6:] = rng.normal(0, 0.5, model.nv - 6)
+    warm = np.zeros((n, model.nv))
+    ctrl = np.stack([qpos[e, aq] for e in range(n)])
+    b = engine.Batch(model, n)
+    b.set_state(qpos, qvel, warm)
+    b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 1)
+    gq, gv, _ = b.get_state()
+    img = b.lds_image()
+    om = oracle_mod.OracleModel(model.blob())
+    o = {k: b.lds_offset(k) for k in ("contact_dist", "efc_D", "qacc")}
+    nv = model.nv
+    n_pen = n_flip = 0
+    worst = dict(dist=0.0, qacc=0.0, qpos=0.0, qvel=0.0)
+    for e in range(n):
+        d = oracle_mod.OracleData(om)
+        d["qpos"][: om.nq] = qpos[e]; d["qvel"][:nv] = qvel[e]; d["ctrl"][:14] = ctrl[e]
+        d.forward()
+        cd_o = np.array(d["contact_dist"][8:12]); cd_g = img[e][o["contact_dist"] + 8: o["contact_dist"] + 12]
+        if (cd_o < 0).any():
+            n_pen += 1
+        if set(np.flatnonzero(cd_o < 0)) != set(np.flatnonzero(cd_g < 0)):
+            n_flip += 1      # fp32 vs fp64 tie in the face / support-point selection
+            continue
+        both = (cd_o < 0)
+        if both.any():
+            worst["dist"] = max(worst["dist"], np.abs(cd_g[both] - cd_o[both]).max())
+        worst["qacc"] = max(worst["qacc"], _rel(img[e][o["qacc"]: o["qacc"] + nv], d["qacc"][:nv], 5.0).max())
+        ds = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 1)
+        worst["qpos"] = max(worst["qpos"], _rel(gq[e], ds["qpos"][: om.nq], 1e-2).max())
+        worst["qvel"] = max(worst["qvel"], _rel(gv[e], ds["qvel"][:nv], 1.0).max())
+    print(task, dict(n=n, penetrating=n_pen, flips=n_flip, **{k: float(f"{v:.3g}") for k, v in worst.items()}))
+    assert n_pen >= 10, "the grid must contain penetrating poses"
+    assert n_flip <= 2
+    assert worst["dist"] < 5e-6
+    assert worst["qacc"] < 5e-3
+    assert worst["qpos"] < RTOL_Q
+    assert worst["qvel"] < 2e-3
+    b.close()
