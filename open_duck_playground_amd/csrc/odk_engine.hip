@@ -56,6 +56,7 @@ struct KArgs {
   float* first;       // [nenv][Rec::FSIZE]
   const float* dr;    // [nenv][NDR] or null
   const float* action;  // [nenv][nu]
+  const float* hfield;  // [nrow][ncol] height-field samples in [0, 1], or null (plane floor)
   float* obs; float* priv; float* reward; float* done; float* trunc; float* metrics;
   float* dbg_lds;     // [nenv][TOTAL] or null: LDS image after the last forward
   int nenv;
@@ -212,7 +213,7 @@ __device__ __forceinline__ void write_outputs(const KArgs& a, const float* L, in
 
 // ================================================================================================
 // Joystick.reset (joystick.py:206-321) + Episode/AutoReset wrapper resets
-template <class S, int G>
+template <class S, int G, bool HF>
 __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   }
   if (lane < 7) sample_command(c, k0, kr, 0, 23, lane, INFO[rec::CMD + lane]);
   ODK_SYNC();
-  forward_env<S, G>(L, m, st, lane, 1);
+  forward_env<S, G, HF>(L, m, a.hfield, st, lane, 1);
   if (a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
   const float pint = c.push_interval_range[0] + rng_uniform(k0, kr, 0, 31) * (c.push_interval_range[1] - c.push_interval_range[0]);
   const int push_interval_steps = (int)rintf(pint / c.ctrl_dt);
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
 
 // ================================================================================================
 // AutoReset.step -> Episode.step -> Joystick.step (joystick.py:323-481), all substeps fused
-template <class S, int G>
+template <class S, int G, bool HF>
 __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   // ---- mjx_env.step: n_substeps x (forward + Euler)   (:420)
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
-    forward_env<S, G>(L, m, st, lane, last ? 1 : 0);
+    forward_env<S, G, HF>(L, m, a.hfield, st, lane, last ? 1 : 0);
     if (last && a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
     euler_env<S, G>(L, m, st, lane);
   }
@@ -496,7 +497,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
 }
 
 // mjx_env.step alone: ctrl = action buffer, no env logic (parity tests)
-template <class S, int G>
+template <class S, int G, bool HF>
 __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
@@ -521,7 +522,7 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   load_statics<S, G>(st, a.m, lane);
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
-    forward_env<S, G>(L, a.m, st, lane, last ? 1 : 0);
+    forward_env<S, G, HF>(L, a.m, a.hfield, st, lane, last ? 1 : 0);
     if (last && a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
     euler_env<S, G>(L, a.m, st, lane);
   }
@@ -543,14 +544,14 @@ static int fail(int code, const char* fmt, ...) {
 int odk_fail_(int code, const char* msg) { return fail(code, "%s", msg); }   // for odk_learner.hip
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(ODK_ERR_HIP, "%s: %s", #x, hipGetErrorString(_e)); } while (0)
 
-struct odk_model { DevModel h; int shape; };  // shape: 0 = A, 1 = B
+struct odk_model { DevModel h; int shape; std::vector<float> hfield; };  // shape: 0 = A, 1 = B; hfield: [nrow][ncol] in [0, 1]
 
 struct odk_batch {
   odk_model model;
   int nenv, device, G;
   odk_env_config cfg;
   DevModel* d_model = nullptr; DevPRM* d_prm = nullptr; float* d_table = nullptr;
-  float* d_recs = nullptr; float* d_first = nullptr; float* d_dr = nullptr; float* d_dbg = nullptr;
+  float* d_recs = nullptr; float* d_first = nullptr; float* d_dr = nullptr; float* d_dbg = nullptr; float* d_hfield = nullptr;
   std::vector<float> h_dr; bool dr_enabled = false;
   int rec_size, frec_size, lds_total, dr_size, env_lds;
   bool timing = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t ev_used = 0;
@@ -802,6 +803,17 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     double n[3] = {pm[2], pm[5], pm[8]};
     for (int k = 0; k < 3; k++) { m.plane_pos[k] = (float)cg_pos[3 * g + k]; m.plane_n[k] = (float)n[k]; }
     make_frame_h(n, m.plane_frame);
+    for (int k = 0; k < 9; k++) m.floor_mat[k] = (float)pm[k];
+    if (!m.floor_is_plane) {   // height field samples + size (scene_rough_terrain_backlash.xml:22)
+      RecHdr hh;
+      const unsigned char* hp = find_rec((const unsigned char*)blob, len, "hfield_data", &hh);
+      double hs[4];
+      if (!hp || hh.dtype != 0 || hh.ndim != 2 || B.D("hfield_size", hs, 4) != 4) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floor without hfield_data / hfield_size"); }
+      m.hfield_nrow = (int)hh.shape[0]; m.hfield_ncol = (int)hh.shape[1];
+      for (int k = 0; k < 4; k++) m.hfield_size[k] = (float)hs[k];
+      mo->hfield.resize((size_t)m.hfield_nrow * m.hfield_ncol);
+      for (size_t i = 0; i < mo->hfield.size(); i++) { double v; memcpy(&v, hp + 8 * i, 8); mo->hfield[i] = (float)v; }
+    }
     // contact parameter mixing (mj_contactParam): pairs 0,1 = floor vs foot, pair 2 = foot vs foot
     for (int pr = 0; pr < 3; pr++) {
       int g1 = pr < 2 ? g : foot_cg[0], g2 = pr < 2 ? foot_cg[pr] : foot_cg[1];
@@ -846,6 +858,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   if (fits(ShapeA::NQ, ShapeA::NV, ShapeA::NB, ShapeA::NU, ShapeA::NJ, ShapeA::NM, ShapeA::NH, ShapeA::NROW, ShapeA::DT, ShapeA::DV)) mo->shape = 0;
   else if (fits(ShapeB::NQ, ShapeB::NV, ShapeB::NB, ShapeB::NU, ShapeB::NJ, ShapeB::NM, ShapeB::NH, ShapeB::NROW, ShapeB::DT, ShapeB::DV)) mo->shape = 1;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
+  if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
   *out = mo;
   return ODK_OK;
 }
@@ -897,13 +910,17 @@ extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, i
   HIPCHK(hipMalloc(&b->d_recs, (size_t)nenv * b->rec_size * sizeof(float))); HIPCHK(hipMemset(b->d_recs, 0, (size_t)nenv * b->rec_size * sizeof(float)));
   HIPCHK(hipMalloc(&b->d_first, (size_t)nenv * b->frec_size * sizeof(float))); HIPCHK(hipMemset(b->d_first, 0, (size_t)nenv * b->frec_size * sizeof(float)));
   HIPCHK(hipMalloc(&b->d_dbg, (size_t)nenv * b->lds_total * sizeof(float))); HIPCHK(hipMemset(b->d_dbg, 0, (size_t)nenv * b->lds_total * sizeof(float)));
+  if (!m->hfield.empty()) {   // shared by all envs, L2-resident (256 KB)
+    HIPCHK(hipMalloc(&b->d_hfield, m->hfield.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(b->d_hfield, m->hfield.data(), m->hfield.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   *out = b;
   return ODK_OK;
 }
 extern "C" void odk_batch_destroy(odk_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  for (void* p : {(void*)b->d_model, (void*)b->d_prm, (void*)b->d_table, (void*)b->d_recs, (void*)b->d_first, (void*)b->d_dr, (void*)b->d_dbg}) (void)hipFree(p);
+  for (void* p : {(void*)b->d_model, (void*)b->d_prm, (void*)b->d_table, (void*)b->d_recs, (void*)b->d_first, (void*)b->d_dr, (void*)b->d_dbg, (void*)b->d_hfield}) (void)hipFree(p);
   for (auto& ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   delete b;
 }
@@ -952,23 +969,26 @@ extern "C" int odk_batch_set_param(odk_batch* b, int param, const float* v, int 
 
 enum { K_RESET = 0, K_STEP = 1, K_PHYS = 2 };
 
-template <class S, int G> static hipError_t launch_sg(int which, const KArgs& a, hipStream_t st) {
+template <class S, int G, bool HF> static hipError_t launch_sg(int which, const KArgs& a, hipStream_t st) {
   const int per_block = 64 / G;
   const int grid = (a.nenv + per_block - 1) / per_block;
   const size_t lds = (size_t)per_block * EnvL<S>::TOTAL * sizeof(float);
-  if (which == K_RESET) hipLaunchKernelGGL((reset_kernel<S, G>), dim3(grid), dim3(64), lds, st, a);
-  else if (which == K_STEP) hipLaunchKernelGGL((step_kernel<S, G>), dim3(grid), dim3(64), lds, st, a);
-  else hipLaunchKernelGGL((physics_kernel<S, G>), dim3(grid), dim3(64), lds, st, a);
+  if (which == K_RESET) hipLaunchKernelGGL((reset_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
+  else if (which == K_STEP) hipLaunchKernelGGL((step_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
+  else hipLaunchKernelGGL((physics_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
   return hipGetLastError();
 }
 static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st) {
-  if (b->model.shape == 0) return b->G == 64 ? launch_sg<ShapeA, 64>(which, a, st) : launch_sg<ShapeA, 32>(which, a, st);
-  return b->G == 64 ? launch_sg<ShapeB, 64>(which, a, st) : launch_sg<ShapeB, 32>(which, a, st);
+  // height-field floors exist only with the backlash model (scene_rough_terrain_backlash.xml) and run 32 lanes per env
+  if (!b->model.h.floor_is_plane) return launch_sg<ShapeB, 32, true>(which, a, st);
+  if (b->model.shape == 0) return b->G == 64 ? launch_sg<ShapeA, 64, false>(which, a, st) : launch_sg<ShapeA, 32, false>(which, a, st);
+  return b->G == 64 ? launch_sg<ShapeB, 64, false>(which, a, st) : launch_sg<ShapeB, 32, false>(which, a, st);
 }
 
 static void base_args(odk_batch* b, KArgs& a, const odk_outputs* o) {
   memset(&a, 0, sizeof(a));
   a.m = b->d_model; a.prm = b->d_prm; a.prm_table = b->d_table; a.recs = b->d_recs; a.first = b->d_first;
+  a.hfield = b->d_hfield;
   a.dr = b->dr_enabled ? b->d_dr : nullptr; a.nenv = b->nenv; a.n_substeps = b->cfg.n_substeps;
   a.dbg_lds = nullptr;
   if (o) { a.obs = o->obs_dev; a.priv = o->priv_dev; a.reward = o->reward_dev; a.done = o->done_dev; a.trunc = o->truncation_dev; a.metrics = o->metrics_dev; }

@@ -574,6 +574,34 @@ __device__ inline void row_params(const float* solref, const float* solimp, floa
 //   flags bit0: compute sensordata / debug outputs (last substep only)
 // mjx collision_convex._manifold_points: 4 support points of approximately maximal area among the vertices within
 // 1e-3 of the deepest one (lane = vertex; `n` = contact normal)
+// Plane of the height-field triangle below world point pw (cell (c, r) split along the (c+1, r)-(c, r+1) diagonal):
+// world position of one of its vertices and its upward unit normal.  Mirrors oracle hfield_plane.
+__device__ __forceinline__ void hfield_plane(const DevModel* __restrict__ m, const float* __restrict__ hf, const float* pw, float* pos_w, float* n_w) {
+  const float* R = m->floor_mat;
+  const float rel[3] = {pw[0] - m->plane_pos[0], pw[1] - m->plane_pos[1], pw[2] - m->plane_pos[2]};
+  const float px = R[0] * rel[0] + R[3] * rel[1] + R[6] * rel[2], py = R[1] * rel[0] + R[4] * rel[1] + R[7] * rel[2];
+  const int nc = m->hfield_ncol, nr = m->hfield_nrow;
+  const float sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+  const float dx = 2.0f * sx / (float)(nc - 1), dy = 2.0f * sy / (float)(nr - 1);
+  const float fx = (px + sx) / dx, fy = (py + sy) / dy;
+  int c = (int)floorf(fx), r = (int)floorf(fy);
+  c = c < 0 ? 0 : (c > nc - 2 ? nc - 2 : c);
+  r = r < 0 ? 0 : (r > nr - 2 ? nr - 2 : r);
+  const float tx = fx - (float)c, ty = fy - (float)r;
+  const float x0 = -sx + (float)c * dx, y0 = -sy + (float)r * dy;
+  const float z00 = hf[r * nc + c] * sz, z10 = hf[r * nc + c + 1] * sz, z01 = hf[(r + 1) * nc + c] * sz, z11 = hf[(r + 1) * nc + c + 1] * sz;
+  float a[3], e1[3], e2[3], nl[3];
+  if (tx + ty <= 1.0f) { a[0] = x0; a[1] = y0; a[2] = z00; e1[0] = dx; e1[1] = 0; e1[2] = z10 - z00; e2[0] = 0; e2[1] = dy; e2[2] = z01 - z00; }
+  else { a[0] = x0 + dx; a[1] = y0 + dy; a[2] = z11; e1[0] = -dx; e1[1] = 0; e1[2] = z01 - z11; e2[0] = 0; e2[1] = -dy; e2[2] = z10 - z11; }
+  cross3(nl, e1, e2);
+  const float inv = 1.0f / sqrtf(dot3(nl, nl));
+  nl[0] *= inv; nl[1] *= inv; nl[2] *= inv;
+  for (int k = 0; k < 3; k++) {
+    n_w[k] = R[3 * k] * nl[0] + R[3 * k + 1] * nl[1] + R[3 * k + 2] * nl[2];
+    pos_w[k] = m->plane_pos[k] + R[3 * k] * a[0] + R[3 * k + 1] * a[1] + R[3 * k + 2] * a[2];
+  }
+}
+
 template <int G>
 __device__ __forceinline__ void select4(const float* w, bool has, float sup, int nvt, const float* n, int* idx, int lane) {
   const float smax = gmax<G>(sup);
@@ -700,8 +728,8 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
     }
   }
 
-template <class S, int G>
-__device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane, int flags) {
+template <class S, int G, bool HF>
+__device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags) {
   constexpr int NV = S::NV, NB = S::NB;
   using ST = Statics<S, G>;
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; float* WARM = L + S::O_WARM; float* CTRL = L + S::O_CTRL;
@@ -963,16 +991,33 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     for (int k = 0; k < 3; k++) fP[f][k] = XPOS[k * NB + fb];
     q2mat(fR[f], q);
   }
-  const float pn[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
+  const float pn0[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
+  constexpr bool flat = !HF;   // plane floor, or height field (rough terrain; its own kernel instantiation)
 #pragma unroll
   for (int f = 0; f < 2; f++) {
     const int nvt = m->foot_nvert[f];
     const bool has = lane < nvt;
     float w[3] = {0, 0, 0}, sup = -3.0e38f;
+    float pn[3] = {pn0[0], pn0[1], pn0[2]}, pp[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
+    if (!flat) {   // terrain under this foot := plane of the height-field triangle below the hull's box centre (oracle hfield_convex)
+      float cw[3];
+      for (int k = 0; k < 3; k++) cw[k] = fP[f][k] + fR[f][3 * k] * m->foot_obb_center[f][0] + fR[f][3 * k + 1] * m->foot_obb_center[f][1] + fR[f][3 * k + 2] * m->foot_obb_center[f][2];
+      hfield_plane(m, hfield, cw, pp, pn);
+      if (lane == 0) {   // contact frame of this pair (make_frame), consumed by P8
+        float b[3] = {0, 0, 0}, cc[3];
+        if (fabsf(pn[1]) < 0.5f) b[1] = 1.0f; else b[2] = 1.0f;
+        const float dtb = dot3(pn, b);
+        b[0] -= dtb * pn[0]; b[1] -= dtb * pn[1]; b[2] -= dtb * pn[2];
+        const float nb = sqrtf(dot3(b, b));
+        b[0] /= nb; b[1] /= nb; b[2] /= nb;
+        cross3(cc, pn, b);
+        for (int t = 0; t < 3; t++) { SCR[S::S_K + 9 * f + t] = pn[t]; SCR[S::S_K + 9 * f + 3 + t] = b[t]; SCR[S::S_K + 9 * f + 6 + t] = cc[t]; }
+      }
+    }
     if (has) {
       const float vb[3] = {m->foot_vert[f][lane][0], m->foot_vert[f][lane][1], m->foot_vert[f][lane][2]};
       for (int k = 0; k < 3; k++) w[k] = fP[f][k] + fR[f][3 * k] * vb[0] + fR[f][3 * k + 1] * vb[1] + fR[f][3 * k + 2] * vb[2];
-      sup = (m->plane_pos[0] - w[0]) * pn[0] + (m->plane_pos[1] - w[1]) * pn[1] + (m->plane_pos[2] - w[2]) * pn[2];
+      sup = (pp[0] - w[0]) * pn[0] + (pp[1] - w[1]) * pn[1] + (pp[2] - w[2]) * pn[2];
     }
     int idx[4];
     select4<G>(w, has, sup, nvt, pn, idx, lane);
@@ -1073,7 +1118,8 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     const float dist = CDIST[c];
     const float mu = m->pair_mu[pair];
     const float fs = (s & 1) ? -mu : mu;
-    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : m->plane_frame;  // foot-foot frame: left in S_VF by the SAT routine
+    // foot-foot frame: left in S_VF by the SAT routine; height-field floor: per-foot frames left in S_K by P7
+    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && HF) ? SCR + S::S_K + 9 * pair : m->plane_frame);
     const int td = 3 * (1 + (s >> 1));
     const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
     const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};

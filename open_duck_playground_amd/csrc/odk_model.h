@@ -67,6 +67,9 @@ struct DevModel {
   float foot_obb_center[2][3], foot_obb_half[2][3], foot_obb_axes[2][9];  // body-frame OBB (columns = axes)
   float plane_pos[3], plane_n[3], plane_frame[9];
   int floor_is_plane;
+  // height-field floor (rough terrain): geom frame = (plane_pos, floor_mat); samples live in HBM (KArgs.hfield)
+  int hfield_nrow, hfield_ncol;
+  float hfield_size[4], floor_mat[9];
   // sites / sensors
   int site_body[MAXSITE], site_imu, site_feet[2];
   float site_pos[MAXSITE][3], site_mat[MAXSITE][9], site_quat[MAXSITE][4];

@@ -180,6 +180,14 @@ odko_model* odko_model_load(const void* blob, uint64_t len) {
   m->nhullvert = load_f(b, len, "hull_vert", (real*)m->hull_vert, ODKO_MAXHV * 3) / 3;
   m->nhullface = load_i(b, len, "hull_face", (int*)m->hull_face, ODKO_MAXHF * 3) / 3;
   if (!ok || m->nsensor < 0 || m->ncgeom < 0) { free(m); return NULL; }
+  { /* optional height field (scene_rough_terrain_backlash.xml:22) */
+    rec_hdr hh;
+    if (find_rec(b, len, "hfield_data", &hh)) {
+      m->hfield_nrow = (int)hh.shape[0]; m->hfield_ncol = (int)hh.shape[1];
+      if (m->hfield_nrow * m->hfield_ncol > ODKO_MAXHFIELD || load_f(b, len, "hfield_data", m->hfield_data, ODKO_MAXHFIELD) < 0 ||
+          load_f(b, len, "hfield_size", m->hfield_size, 4) < 0) { free(m); return NULL; }
+    }
+  }
   /* contact pairs: contype/conaffinity filter, same-body and parent-child(weld) exclusion;
      order: plane/hfield-vs-mesh pairs first (by geom id), then mesh-mesh (MJX groups by type pair) */
   m->npair = 0;
@@ -497,14 +505,13 @@ static void manifold_points(const real (*poly)[3], const int* mask, int n, const
   idx[0] = ai; idx[1] = bi; idx[2] = ci; idx[3] = di;
 }
 
-/* mjx collision_convex.plane_convex; writes 4 contacts starting at slot c0 */
-static void plane_convex(const odko_model* m, odko_data* d, int gp, int gc, int c0) {
+/* mjx collision_convex.plane_convex against the plane (pos_w, pn_w); writes 4 contacts starting at slot c0 */
+static void plane_convex_at(const odko_model* m, odko_data* d, const real* pos_w, const real* pn_w, int gc, int c0) {
   const real (*vert)[3] = &m->hull_vert[m->cgeom_vertadr[gc]];
   int n = m->cgeom_vertnum[gc];
   const real* cm = d->geom_xmat[gc];
-  real pn_w[3] = {d->geom_xmat[gp][2], d->geom_xmat[gp][5], d->geom_xmat[gp][8]};
   real rel[3], plane_pos[3], nl[3];
-  v3_sub(rel, d->geom_xpos[gp], d->geom_xpos[gc]);
+  v3_sub(rel, pos_w, d->geom_xpos[gc]);
   mat_tmulvec(plane_pos, cm, rel);
   mat_tmulvec(nl, cm, pn_w);
   real support[ODKO_MAXHV], smax = -1e30;
@@ -532,6 +539,51 @@ static void plane_convex(const odko_model* m, odko_data* d, int gp, int gc, int 
     v3_copy(d->contact_pos[c0 + k], pw);
     memcpy(d->contact_frame[c0 + k], frame, sizeof(frame));
   }
+}
+static void plane_convex(const odko_model* m, odko_data* d, int gp, int gc, int c0) {
+  real pn_w[3] = {d->geom_xmat[gp][2], d->geom_xmat[gp][5], d->geom_xmat[gp][8]};
+  plane_convex_at(m, d, d->geom_xpos[gp], pn_w, gc, c0);
+}
+
+static void hull_aabb(const odko_model* m, int g, real* c, real* h);
+/* Height field vs convex foot (config "rough_terrain_backlash").  BUILD-DEFINED APPROXIMATION, PARITY UNPINNED: MJX
+ * collides the mesh with the prisms of a sub-grid of cells; here the terrain under the foot is replaced by the plane
+ * of the height-field triangle below the hull's centre (cell (c, r) is split along the (c+1, r)-(c, r+1) diagonal)
+ * and plane_convex runs against that plane.  Exact on flat patches; the terrain's slopes are <= 1 cm per 7.8 cm cell. */
+static void hfield_plane(const odko_model* m, const odko_data* d, int gh, const real* point_w, real* pos_w, real* n_w) {
+  const real* R = d->geom_xmat[gh];
+  real rel[3], p[3];
+  v3_sub(rel, point_w, d->geom_xpos[gh]);
+  mat_tmulvec(p, R, rel);
+  int nc = m->hfield_ncol, nr = m->hfield_nrow;
+  real sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+  real dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
+  real fx = (p[0] + sx) / dx, fy = (p[1] + sy) / dy;
+  int c = (int)floor(fx), r = (int)floor(fy);
+  if (c < 0) c = 0;
+  if (c > nc - 2) c = nc - 2;
+  if (r < 0) r = 0;
+  if (r > nr - 2) r = nr - 2;
+  real tx = fx - c, ty = fy - r;
+  real x0 = -sx + c * dx, y0 = -sy + r * dy;
+  real z00 = m->hfield_data[r * nc + c] * sz, z10 = m->hfield_data[r * nc + c + 1] * sz;
+  real z01 = m->hfield_data[(r + 1) * nc + c] * sz, z11 = m->hfield_data[(r + 1) * nc + c + 1] * sz;
+  real a[3], e1[3], e2[3], nl[3];
+  if (tx + ty <= 1.0) { a[0] = x0; a[1] = y0; a[2] = z00; e1[0] = dx; e1[1] = 0; e1[2] = z10 - z00; e2[0] = 0; e2[1] = dy; e2[2] = z01 - z00; }
+  else { a[0] = x0 + dx; a[1] = y0 + dy; a[2] = z11; e1[0] = -dx; e1[1] = 0; e1[2] = z01 - z11; e2[0] = 0; e2[1] = -dy; e2[2] = z10 - z11; }
+  v3_cross(nl, e1, e2);
+  v3_normalize(nl); /* e1 x e2 points up in both cases */
+  mat_mulvec(n_w, R, nl);
+  mat_mulvec(pos_w, R, a);
+  v3_addscl(pos_w, pos_w, d->geom_xpos[gh], 1);
+}
+static void hfield_convex(const odko_model* m, odko_data* d, int gh, int gc, int c0) {
+  real c[3], h[3], cw[3], pos_w[3], n_w[3];
+  hull_aabb(m, gc, c, h);
+  mat_mulvec(cw, d->geom_xmat[gc], c);
+  v3_addscl(cw, cw, d->geom_xpos[gc], 1);
+  hfield_plane(m, d, gh, cw, pos_w, n_w);
+  plane_convex_at(m, d, pos_w, n_w, gc, c0);
 }
 
 /* Conservative separating test for two convex hulls: projects both vertex sets on the candidate
@@ -568,7 +620,7 @@ static real hull_separation(const odko_model* m, const odko_data* d, int g1, int
 /* Oriented-bounding-box cull (15-axis SAT on the hull AABBs expressed in each geom frame).  A positive
  * return value is a lower bound on the true separation of the two hulls: the pair is then inactive
  * in MJX as well (all dist > 0), so culling is parity-safe. */
-static void hull_aabb(const odko_model* m, int g, real* c, real* h) {
+static void hull_aabb(const odko_model* m, int g, real* c, real* h) { /* (declared above) */
   real lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
   for (int i = 0; i < m->cgeom_vertnum[g]; i++)
     for (int k = 0; k < 3; k++) {
@@ -657,7 +709,8 @@ static void collision(const odko_model* m, odko_data* d) {
     int g1 = m->pair_g1[p], g2 = m->pair_g2[p], c0 = d->ncon;
     if (m->cgeom_type[g1] == ODKO_GEOM_PLANE && m->cgeom_type[g2] == ODKO_GEOM_MESH) plane_convex(m, d, g1, g2, c0);
     else if (m->cgeom_type[g1] == ODKO_GEOM_MESH && m->cgeom_type[g2] == ODKO_GEOM_MESH) convex_convex(m, d, g1, g2, c0);
-    else { /* hfield: not implemented in round 1 -> no contact */
+    else if (m->cgeom_type[g1] == ODKO_GEOM_HFIELD && m->cgeom_type[g2] == ODKO_GEOM_MESH && m->hfield_nrow > 1) hfield_convex(m, d, g1, g2, c0);
+    else { /* unsupported pair type: no contact */
       for (int k = 0; k < 4; k++) { d->contact_dist[c0 + k] = 1.0; v3_zero(d->contact_pos[c0 + k]); real z[3] = {0, 0, 1}; make_frame(d->contact_frame[c0 + k], z); }
     }
     /* friction: higher priority wins, else max (mj_contactParam) */

@@ -44,6 +44,7 @@ typedef ODKO_REAL real;
 
 enum { ODKO_JNT_FREE = 0, ODKO_JNT_HINGE = 3 };
 enum { ODKO_GEOM_PLANE = 0, ODKO_GEOM_HFIELD = 1, ODKO_GEOM_MESH = 7 };
+#define ODKO_MAXHFIELD (256 * 256)
 enum { ODKO_S_GYRO = 0, ODKO_S_VELOCIMETER, ODKO_S_ACCELEROMETER, ODKO_S_FRAMEZAXIS, ODKO_S_FRAMEXAXIS,
        ODKO_S_FRAMELINVEL, ODKO_S_FRAMEANGVEL, ODKO_S_FRAMEPOS, ODKO_S_FRAMEQUAT };
 
@@ -80,6 +81,10 @@ typedef struct {
       cgeom_solimp[ODKO_MAXG][5], cgeom_solmix[ODKO_MAXG];
   real hull_vert[ODKO_MAXHV][3];
   int hull_face[ODKO_MAXHF][3];
+  /* height field of the floor geom (rough terrain): data[row][col] in [0, 1], row <-> y, col <-> x */
+  int hfield_nrow, hfield_ncol;
+  real hfield_size[4];                 /* x half-extent, y half-extent, elevation scale, base thickness */
+  real hfield_data[ODKO_MAXHFIELD];
   /* derived: contact pair list */
   int npair, pair_g1[3], pair_g2[3];
 } odko_model;

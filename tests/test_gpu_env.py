@@ -49,7 +49,7 @@ def test_reset_matches_oracle(oracle_mod, task):
     b.close()
 
 
-@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
 def test_step_sequence_with_resync(oracle_mod, task):
     """60 env steps with random actions.  The physics state is re-synchronised from the oracle before every
     step (fp32-vs-fp64 chaos through contact would otherwise dominate), everything else -- info ring

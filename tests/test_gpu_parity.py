@@ -53,7 +53,7 @@ def _oracle_step(O, om, qpos, qvel, warm, ctrl, nsub):
     return d
 
 
-@pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32)])
+@pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32), ("rough_terrain_backlash", 32)])
 def test_one_substep_stages(torch_cuda, oracle_mod, task, lanes):
     """One mjx.step from random states: every comparable intermediate and the integrated state."""
     from open_duck_playground_amd import engine
@@ -123,7 +123,7 @@ def test_one_substep_stages(torch_cuda, oracle_mod, task, lanes):
     b.close()
 
 
-@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
 def test_env_step_ten_substeps(torch_cuda, oracle_mod, task):
     """mjx_env.step (10 substeps) from standing-ish states: state after one env step within 1e-4 relative."""
     from open_duck_playground_amd import engine
