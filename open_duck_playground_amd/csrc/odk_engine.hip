@@ -78,6 +78,15 @@ __device__ __forceinline__ float nan_to_num(float x) {
   return x;
 }
 
+// Debug image of the env's LDS (parity tests).  Out of line and rolled: unrolled in place, its 79 per-lane 64-bit store
+// addresses were hoisted above the substep loop and parked in scratch (158 dwords per lane, ~400 MB of HBM per launch).
+template <class S, int G>
+__device__ __noinline__ void dump_lds(float* dbg, const float* L, int env, int lane) {
+  float* o = dbg + (size_t)env * S::TOTAL;
+#pragma unroll 1
+  for (int k = lane; k < S::TOTAL; k += G) o[k] = L[k];
+}
+
 // effective per-env model parameters -> LDS
 template <class S, int G>
 __device__ __forceinline__ void load_params(float* L, const DevModel* m, const float* dr, int lane) {
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   if (lane < 7) sample_command(c, k0, kr, 0, 23, lane, INFO[rec::CMD + lane]);
   ODK_SYNC();
   forward_env<S, G, HF>(L, m, a.hfield, st, lane, 1);
-  if (a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
+  if (a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
   const float pint = c.push_interval_range[0] + rng_uniform(k0, kr, 0, 31) * (c.push_interval_range[1] - c.push_interval_range[0]);
   const int push_interval_steps = (int)rintf(pint / c.ctrl_dt);
   if (c.use_imitation) prm_eval<G>(a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], 0, L + E::O_REF, lane);
@@ -368,10 +377,22 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   // ---- mjx_env.step: n_substeps x (forward + Euler)   (:420)
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
-    forward_env<S, G, HF>(L, m, a.hfield, st, lane, last ? 1 : 0);
-    if (last && a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
-    euler_env<S, G>(L, m, st, lane);
+    // The model pointer is made opaque once per substep: the per-lane 64-bit table addresses (and loop-invariant table
+    // loads) would otherwise be hoisted out of the loop and, with 256 VGPRs taken, parked in scratch -- ~150 dwords per
+    // lane, private per wave, evicted to HBM (hundreds of MB per launch) -- while recomputing an address is one VALU op
+    // and the tables themselves are 60 KB shared by every wave (L1 / L2 resident).
+    size_t opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));   // an offset, not the pointer itself: the address space (global) stays known
+    const DevModel* ms = reinterpret_cast<const DevModel*>(reinterpret_cast<const char*>(m) + opaque0);
+    forward_env<S, G, HF>(L, ms, a.hfield, st, lane, last ? 1 : 0);
+    if (last && a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
+    euler_env<S, G>(L, ms, st, lane);
   }
+  // same trick for the epilogue: its table addresses would otherwise be shared (CSE) with the prologue's and carried
+  // across the substep loop in scratch
+  size_t opaque1 = 0;
+  asm volatile("" : "+s"(opaque1));
+  const DevModel* mp = reinterpret_cast<const DevModel*>(reinterpret_cast<const char*>(m) + opaque1);
   for (int u = lane; u < NU; u += G) INFO[rec::MT + u] = CTRL[u];  // info["motor_targets"] (:422)
   // ---- contacts, air time, swing peak (:424-435)
   float contact[2];
@@ -388,20 +409,20 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   float nanflag = 0;
   for (int i = lane; i < S::NQ + S::NV; i += G) nanflag += isnan(L[S::O_QPOS + i]) ? 1.0f : 0.0f;
   nanflag = gsum<G>(nanflag);
-  const bool done_env = (L[S::O_SENS + m->adr_upvector + 2] < 0.0f) || nanflag > 0;
+  const bool done_env = (L[S::O_SENS + mp->adr_upvector + 2] < 0.0f) || nanflag > 0;
   // ---- rewards (:622-669, :440-447); lanes 0..NU-1 hold the per-actuator terms
   float t_tq = 0, t_ar = 0, t_pose = 0, t_vel = 0, t_jp = 0, t_jv = 0;
   const float* REF = L + E::O_REF;
   if (lane < NU) {
     const int u = lane;
-    const float jq = L[S::O_QPOS + m->act_qposadr[u]], jv = L[S::O_QVEL + m->act_dofadr[u]];
+    const float jq = L[S::O_QPOS + mp->act_qposadr[u]], jv = L[S::O_QVEL + mp->act_dofadr[u]];
     const float af = L[S::O_ACTF + u];
     t_tq = af * af;
     const float da = ACT[u] - INFO[rec::LAST + u];
     t_ar = da * da;
     const bool leg = u < 5 || u >= 9;
     const bool counted = c.kind == 0 || leg;   // Standing: cost_stand_still(..., ignore_head=True) (standing.py:590-597)
-    t_pose = counted ? fabsf(jq - m->key_ctrl[u]) : 0.0f;
+    t_pose = counted ? fabsf(jq - mp->key_ctrl[u]) : 0.0f;
     t_vel = counted ? fabsf(jv) : 0.0f;
     if (c.kind != 0 && !leg) { const float dh = jq - INFO[rec::CMD + 3 + (u - 5)]; t_jp = dh * dh; }   // cost_head_pos (rewards.py:131-147)
     if (c.kind == 0 && leg) {  // joints[:5] ++ joints[9:] vs ref[:5] ++ ref[11:16]  (custom_rewards.py:80-88)
@@ -414,8 +435,8 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   float rew[7];
   {
     const float* cmd = INFO + rec::CMD;
-    const float* lv = L + S::O_SENS + m->adr_local_linvel;
-    const float* gy = L + S::O_SENS + m->adr_gyro;
+    const float* lv = L + S::O_SENS + mp->adr_local_linvel;
+    const float* gy = L + S::O_SENS + mp->adr_gyro;
     const float ex = (cmd[0] - lv[0]) * (cmd[0] - lv[0]);
     const float ey = fmaxf(fabsf(lv[1] - cmd[1]) - 0.1f, 0.0f);
     rew[0] = nan_to_num(expf(-(ex + ey * ey) / c.tracking_sigma));
@@ -425,7 +446,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     rew[3] = nan_to_num(t_ar);
     const float cn = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]);
     if (c.kind != 0) {   // standing.py:585-606: cost_orientation(upvector), cost_head_pos (gated by the MOVE command norm)
-      const float* up = L + S::O_SENS + m->adr_upvector;
+      const float* up = L + S::O_SENS + mp->adr_upvector;
       rew[0] = nan_to_num(up[0] * up[0] + up[1] * up[1]);
       rew[1] = nan_to_num(t_jp) * (cn > 0.01f ? 1.0f : 0.0f);
     }
@@ -449,7 +470,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   for (int k = 0; k < 7; k++) { rew[k] *= c.reward_scales[k]; total += rew[k]; }
   const float reward = fminf(fmaxf(total * dt, 0.0f), 10000.0f);
   // ---- obs (uses the pre-shift last_act and the post-increment air time; :437)
-  build_obs<S, G>(L, m, c, contact, k0, k1, ctr, imi, phase, lane);
+  build_obs<S, G>(L, mp, c, contact, k0, k1, ctr, imi, phase, lane);
   // ---- info updates (:449-469)
   step += 1; push_step += 1;
   float la = 0, lla = 0;
@@ -490,8 +511,11 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     // first_obs["state"] == first_priv[:101] by construction; every lane re-reads only what it wrote: no barrier
   }
   if (live) {
-    for (int i = lane; i < S::NQ + 2 * S::NV; i += G) rc[i] = L[S::O_QPOS + i];
-    for (int k = lane; k < rec::NINFO; k += G) rc[R::INFO + k] = INFO[k];
+    // record store addresses recomputed here (opaque offset) instead of being shared with the prologue's loads and
+    // carried across the substep loop: 69 64-bit per-lane pointers = 138 scratch dwords otherwise
+    float* rco = reinterpret_cast<float*>(reinterpret_cast<char*>(rc) + opaque1);
+    for (int i = lane; i < S::NQ + 2 * S::NV; i += G) rco[i] = L[S::O_QPOS + i];
+    for (int k = lane; k < rec::NINFO; k += G) rco[R::INFO + k] = INFO[k];
     write_outputs<S, G>(a, L, env, reward, done_f, trunc, metrics, lane);
   }
 }
@@ -523,7 +547,7 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
     forward_env<S, G, HF>(L, a.m, a.hfield, st, lane, last ? 1 : 0);
-    if (last && a.dbg_lds && live) for (int k = lane; k < S::TOTAL; k += G) a.dbg_lds[(size_t)env * S::TOTAL + k] = L[k];
+    if (last && a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
     euler_env<S, G>(L, a.m, st, lane);
   }
   if (live) for (int i = lane; i < S::NQ + 2 * S::NV; i += G) rc[i] = L[S::O_QPOS + i];

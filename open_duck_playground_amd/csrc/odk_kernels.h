@@ -125,6 +125,9 @@ struct Shape {
 #ifdef ODK_PROFILE
 #define ODK_PROF(i) do { if (lane == 0) { long long _t = clock64(); SCR[S::S_PROF + (i)] += (float)(_t - _tprev); _tprev = _t; } } while (0)
 #define ODK_PROF_BEGIN() long long _tprev = clock64()
+#elif defined(ODK_MARK)   // phase markers in the ISA listing (tools/isa_phase_stats.py): comments only
+#define ODK_PROF(i) asm volatile("; ODK_PHASE_END " #i ::: "memory")
+#define ODK_PROF_BEGIN() asm volatile("; ODK_PHASE_BEGIN" ::: "memory")
 #else
 #define ODK_PROF(i) do { } while (0)
 #define ODK_PROF_BEGIN() do { } while (0)

@@ -175,3 +175,66 @@ def test_against_mjx_golden_if_present(oracle_mod, model_a, model_b, task):
         d.env_physics_step(g["ctrl"][i], 1)
         np.testing.assert_allclose(d["qpos"][: om.nq], g["qpos1"][i], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(d["qvel"][: om.nv], g["qvel1"][i], rtol=1e-3, atol=1e-4)
+
+
+def test_height_field_contacts_follow_the_terrain(oracle_mod):
+    """rough_terrain_backlash: the contact normal under each foot is the normal of the height-field triangle below
+    it (independent numpy evaluation of the same rule), the robot settles on the bumps, and flat patches reduce
+    to the plane case."""
+    from open_duck_playground_amd.model import load_task_model
+    model = load_task_model("rough_terrain_backlash")
+    a = model.a
+    H, size = np.asarray(a["hfield_data"]), np.asarray(a["hfield_size"])
+    assert H.shape == (256, 256) and tuple(size) == (10.0, 10.0, 0.01, 0.1)            # scene_rough_terrain_backlash.xml:22
+    nr, nc = H.shape
+    dx, dy = 2 * size[0] / (nc - 1), 2 * size[1] / (nr - 1)
+
+    def tri_plane(x, y):
+        fx, fy = (x + size[0]) / dx, (y + size[1]) / dy
+        c, r = int(np.clip(np.floor(fx), 0, nc - 2)), int(np.clip(np.floor(fy), 0, nr - 2))
+        z = lambda rr, cc: H[rr, cc] * size[2]
+        if (fx - c) + (fy - r) <= 1.0:
+            p0 = np.array([-size[0] + c * dx, -size[1] + r * dy, z(r, c)])
+            n = np.cross([dx, 0, z(r, c + 1) - z(r, c)], [0, dy, z(r + 1, c) - z(r, c)])
+        else:
+            p0 = np.array([-size[0] + (c + 1) * dx, -size[1] + (r + 1) * dy, z(r + 1, c + 1)])
+            n = np.cross([-dx, 0, z(r + 1, c) - z(r + 1, c + 1)], [0, -dy, z(r, c + 1) - z(r + 1, c + 1)])
+        return p0, n / np.linalg.norm(n)
+
+    rng = np.random.default_rng(0)
+    tilts = []
+    for _ in range(12):
+        q = np.array(a["key_qpos"], dtype=np.float64)
+        q[0:2] = rng.uniform(-4, 4, 2); q[2] = 0.16
+        _om, d = _data(oracle_mod, model, qpos=q)
+        d.forward()
+        frames = np.array(d["contact_frame"][: 8 * 9]).reshape(8, 9)
+        dist = np.array(d["contact_dist"][:8]); pos = np.array(d["contact_pos"][: 8 * 3]).reshape(8, 3)
+        gx = np.array(d["geom_xpos"][:9]).reshape(3, 3); gm = np.array(d["geom_xmat"][:27]).reshape(3, 3, 3)
+        hv = np.asarray(a["hull_vert"])
+        for f in range(2):   # collision geoms: left foot, right foot, floor
+            v = hv[a["cgeom_vertadr"][f]: a["cgeom_vertadr"][f] + a["cgeom_vertnum"][f]]
+            centre = gx[f] + gm[f] @ (0.5 * (v.min(0) + v.max(0)))                   # world centre of the hull's box
+            p0, n = tri_plane(centre[0], centre[1])
+            nrm = frames[4 * f, :3]
+            assert np.allclose(frames[4 * f: 4 * f + 4, :3], nrm)                      # one plane per foot
+            np.testing.assert_allclose(nrm, n, atol=1e-9)
+            wv = gx[f] + v @ gm[f].T
+            depth = (p0 - wv) @ n                                                      # support of every hull vertex
+            live = dist[4 * f: 4 * f + 4] < 0.9
+            assert live[0]
+            for k in range(4):   # manifold points are hull vertices within 1e-3 of the deepest one (_manifold_points mask)
+                if live[k]:
+                    assert np.abs(depth + dist[4 * f + k]).min() < 1e-12 and -dist[4 * f + k] > depth.max() - 1e-3 - 1e-12
+            for k in range(4):
+                if live[k]:   # contact point = vertex - dist/2 * n: it sits dist/2 off the plane along n
+                    assert abs((pos[4 * f + k] - p0) @ n - 0.5 * dist[4 * f + k]) < 1e-9
+            tilts.append(np.degrees(np.arccos(nrm[2])))
+    assert 0.05 < max(tilts) < 10.0 and min(tilts) >= 0.0                                # gentle bumps: <= 1 cm per 7.8 cm cell
+    # settles on the terrain
+    _om, d = _data(oracle_mod, model, qpos=np.array(a["key_qpos"], dtype=np.float64))
+    ctrl = np.asarray(a["key_ctrl"], dtype=np.float64)
+    for _ in range(40):
+        d.env_physics_step(ctrl, 10)
+    ground = H[nr // 2 - 2: nr // 2 + 2, nc // 2 - 2: nc // 2 + 2].mean() * size[2]
+    assert 0.14 + ground - 0.01 < d["qpos"][2] < 0.18 + ground and d["sensordata"][11] > 0.99
