@@ -384,6 +384,9 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     size_t opaque0 = 0;
     asm volatile("" : "+s"(opaque0));   // an offset, not the pointer itself: the address space (global) stays known
     const DevModel* ms = reinterpret_cast<const DevModel*>(reinterpret_cast<const char*>(m) + opaque0);
+    // per-lane row addresses derived from the statics are one add away: keep the statics, not the derived values, alive
+    // across the loop (the derived ones were hoisted and spilled: +4 % when recomputed)
+    asm volatile("" : "+v"(st.d_Madr), "+v"(st.d_vMadr), "+v"(st.d_depth), "+v"(st.d_vdepth), "+v"(st.d_body), "+v"(st.d_qadr), "+v"(st.j_qadr), "+v"(st.j_dadr));
     forward_env<S, G, HF>(L, ms, a.hfield, st, lane, last ? 1 : 0);
     if (last && a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
     euler_env<S, G>(L, ms, st, lane);
