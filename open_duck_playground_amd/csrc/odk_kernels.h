@@ -1037,52 +1037,67 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     }
   }
   ODK_PROF(7);
-  // foot-foot: oriented-box cull, 15 axes on 15 lanes (a positive box separation bounds the hulls' from below)
+  // foot-foot: bounding spheres first (a positive gap already means "inactive pair"); only when the spheres of some env
+  // in the wave touch: oriented-box cull, 15 axes on 15 lanes (a positive box separation bounds the hulls' from below)
   {
     float sep = -3.0e38f;
-    if (lane < 15) {
-      float c1[3], c2[3], A1[9], A2[9], tt[3];
-#pragma unroll
-      for (int f = 0; f < 2; f++) {
-        float* cc = f ? c2 : c1; float* AA = f ? A2 : A1;
-        for (int k = 0; k < 3; k++) cc[k] = fP[f][k] + fR[f][3 * k] * m->foot_obb_center[f][0] + fR[f][3 * k + 1] * m->foot_obb_center[f][1] + fR[f][3 * k + 2] * m->foot_obb_center[f][2];
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 3; j++) AA[3 * i + j] = fR[f][3 * i] * m->foot_obb_axes[f][j] + fR[f][3 * i + 1] * m->foot_obb_axes[f][3 + j] + fR[f][3 * i + 2] * m->foot_obb_axes[f][6 + j];
-      }
-      for (int k = 0; k < 3; k++) tt[k] = c2[k] - c1[k];
-      // axis of this lane: 0-2 faces of box 1, 3-5 faces of box 2, 6-14 edge x edge
-      const int ia = lane < 3 ? lane : (lane < 6 ? 0 : (lane - 6) / 3), ib = lane < 3 ? 0 : (lane < 6 ? lane - 3 : (lane - 6) % 3);
-      float e1[3], e2[3], ax[3];
-#pragma unroll
+    float sph;
+    {
+      float dc[3];
       for (int k = 0; k < 3; k++) {
-        e1[k] = ia == 0 ? A1[3 * k] : (ia == 1 ? A1[3 * k + 1] : A1[3 * k + 2]);
-        e2[k] = ib == 0 ? A2[3 * k] : (ib == 1 ? A2[3 * k + 1] : A2[3 * k + 2]);
+        const float a1 = fP[0][k] + fR[0][3 * k] * m->foot_obb_center[0][0] + fR[0][3 * k + 1] * m->foot_obb_center[0][1] + fR[0][3 * k + 2] * m->foot_obb_center[0][2];
+        const float a2 = fP[1][k] + fR[1][3 * k] * m->foot_obb_center[1][0] + fR[1][3 * k + 1] * m->foot_obb_center[1][1] + fR[1][3 * k + 2] * m->foot_obb_center[1][2];
+        dc[k] = a2 - a1;
       }
-      bool ok = true;
-      if (lane < 3) { ax[0] = e1[0]; ax[1] = e1[1]; ax[2] = e1[2]; }
-      else if (lane < 6) { ax[0] = e2[0]; ax[1] = e2[1]; ax[2] = e2[2]; }
-      else {
-        cross3(ax, e1, e2);
-        const float n = sqrtf(dot3(ax, ax));
-        ok = n >= 1e-6f;
-        const float inv = ok ? 1.0f / n : 0.0f;
-        ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
-      }
-      if (ok) {
-        float r1 = 0, r2 = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const float b1[3] = {A1[k], A1[3 + k], A1[6 + k]}, b2[3] = {A2[k], A2[3 + k], A2[6 + k]};
-          r1 += m->foot_obb_half[0][k] * fabsf(dot3(ax, b1));
-          r2 += m->foot_obb_half[1][k] * fabsf(dot3(ax, b2));
+      const float r1 = sqrtf(dot3(m->foot_obb_half[0], m->foot_obb_half[0])), r2 = sqrtf(dot3(m->foot_obb_half[1], m->foot_obb_half[1]));
+      sph = sqrtf(dot3(dc, dc)) - r1 - r2;
+    }
+    if (__builtin_amdgcn_ballot_w64(!(sph > 0.0f)) != 0) {
+      if (lane < 15) {
+        float c1[3], c2[3], A1[9], A2[9], tt[3];
+  #pragma unroll
+        for (int f = 0; f < 2; f++) {
+          float* cc = f ? c2 : c1; float* AA = f ? A2 : A1;
+          for (int k = 0; k < 3; k++) cc[k] = fP[f][k] + fR[f][3 * k] * m->foot_obb_center[f][0] + fR[f][3 * k + 1] * m->foot_obb_center[f][1] + fR[f][3 * k + 2] * m->foot_obb_center[f][2];
+          for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) AA[3 * i + j] = fR[f][3 * i] * m->foot_obb_axes[f][j] + fR[f][3 * i + 1] * m->foot_obb_axes[f][3 + j] + fR[f][3 * i + 2] * m->foot_obb_axes[f][6 + j];
         }
-        sep = fabsf(dot3(tt, ax)) - r1 - r2;
+        for (int k = 0; k < 3; k++) tt[k] = c2[k] - c1[k];
+        // axis of this lane: 0-2 faces of box 1, 3-5 faces of box 2, 6-14 edge x edge
+        const int ia = lane < 3 ? lane : (lane < 6 ? 0 : (lane - 6) / 3), ib = lane < 3 ? 0 : (lane < 6 ? lane - 3 : (lane - 6) % 3);
+        float e1[3], e2[3], ax[3];
+  #pragma unroll
+        for (int k = 0; k < 3; k++) {
+          e1[k] = ia == 0 ? A1[3 * k] : (ia == 1 ? A1[3 * k + 1] : A1[3 * k + 2]);
+          e2[k] = ib == 0 ? A2[3 * k] : (ib == 1 ? A2[3 * k + 1] : A2[3 * k + 2]);
+        }
+        bool ok = true;
+        if (lane < 3) { ax[0] = e1[0]; ax[1] = e1[1]; ax[2] = e1[2]; }
+        else if (lane < 6) { ax[0] = e2[0]; ax[1] = e2[1]; ax[2] = e2[2]; }
+        else {
+          cross3(ax, e1, e2);
+          const float n = sqrtf(dot3(ax, ax));
+          ok = n >= 1e-6f;
+          const float inv = ok ? 1.0f / n : 0.0f;
+          ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
+        }
+        if (ok) {
+          float r1 = 0, r2 = 0;
+  #pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const float b1[3] = {A1[k], A1[3 + k], A1[6 + k]}, b2[3] = {A2[k], A2[3 + k], A2[6 + k]};
+            r1 += m->foot_obb_half[0][k] * fabsf(dot3(ax, b1));
+            r2 += m->foot_obb_half[1][k] * fabsf(dot3(ax, b2));
+          }
+          sep = fabsf(dot3(tt, ax)) - r1 - r2;
+        }
       }
     }
-    const float best = gmax<G>(sep);
+    const float boxsep = gmax<G>(sep);   // unconditional: cross-lane ops stay in uniform control flow
+    const float best = sph > 0.0f ? sph : boxsep;
     if (lane < 4) {
       const int c = 8 + lane;
-      // separated boxes -> inactive pair (the box separation bounds the hulls' from below)
+      // separated spheres / boxes -> inactive pair
       CDIST[c] = (lane == 0 && best > 0) ? best : 1.0f;
       CR[3 * c] = 0; CR[3 * c + 1] = 0; CR[3 * c + 2] = 0;
       if (lane == 0) SCR[S::S_MISC] = best;

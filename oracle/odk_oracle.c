@@ -637,6 +637,10 @@ static real obb_separation(const odko_model* m, const odko_data* d, int g1, int 
   mat_mulvec(w1, R1, c1); v3_addscl(w1, w1, d->geom_xpos[g1], 1);
   mat_mulvec(w2, R2, c2); v3_addscl(w2, w2, d->geom_xpos[g2], 1);
   v3_sub(t, w2, w1);
+  { /* bounding spheres first: a positive gap already makes the pair inactive (and is what the kernels report) */
+    real sph = sqrt(v3_dot(t, t)) - sqrt(v3_dot(h1, h1)) - sqrt(v3_dot(h2, h2));
+    if (sph > 0) return sph;
+  }
   real ax[15][3];
   int na = 0;
   for (int k = 0; k < 3; k++) { ax[na][0] = R1[k]; ax[na][1] = R1[3 + k]; ax[na][2] = R1[6 + k]; na++; }
