@@ -51,7 +51,7 @@ class OdkError(RuntimeError):
 
 def build_library(force: bool = False) -> str:
     """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("odk_engine.hip", "odk_kernels.h", "odk_model.h", "Makefile")]
+    srcs = [os.path.join(_CSRC, f) for f in ("odk_engine.hip", "odk_learner.hip", "odk_kernels.h", "odk_model.h", "Makefile")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "odk.h"))
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return LIB_PATH
