@@ -71,3 +71,57 @@ def test_short_ppo_training_runs():
     assert "eval/episode_reward" in seen[0][1] and "eval/episode_reward/tracking_lin_vel" in metrics
     assert np.isfinite(metrics["training/unroll_reward"]) and np.isfinite(metrics["training/total_loss"])
     assert metrics["training/sps"] > 0
+
+
+def test_env_sharding_is_invisible():
+    """Multi-GPU partition: rank r owns envs [r N, (r+1) N) via env_id_offset.  Two half-batches with
+    offsets 0 / 24 must reproduce one 48-env batch bit for bit (same per-env RNG streams, no cross-env coupling);
+    also covers an env count that is not a multiple of the 2 envs per workgroup."""
+    import torch
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    model = load_task_model("flat_terrain")
+    whole = engine.Batch(model, 49)
+    parts = [engine.Batch(model, 24), engine.Batch(model, 25)]
+    whole.reset(seed=7, env_id_offset=0)
+    parts[0].reset(seed=7, env_id_offset=0); parts[1].reset(seed=7, env_id_offset=24)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(12):
+        act = torch.empty(49, 14, device="cuda").uniform_(-1, 1, generator=g)
+        whole.step(act)
+        parts[0].step(act[:24].contiguous()); parts[1].step(act[24:].contiguous())
+    for name in ("obs", "priv", "reward", "done", "truncation", "metrics"):
+        w = getattr(whole, name)
+        p = torch.cat([getattr(parts[0], name), getattr(parts[1], name)])
+        assert torch.equal(w, p), name
+    qw = whole.get_state(); qp = [b.get_state() for b in parts]
+    for k in range(3):
+        assert np.array_equal(qw[k], np.concatenate([qp[0][k], qp[1][k]]))
+    for b in [whole] + parts:
+        b.close()
+
+
+def test_nan_state_terminates_and_resets_cleanly():
+    """joystick.py:483-485: NaN in qpos/qvel => done; the auto-reset then hands back the first state, and no NaN
+    reaches obs / reward (rewards.py nan_to_num)."""
+    import torch
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    model = load_task_model("flat_terrain")
+    b = engine.Batch(model, 8)
+    b.reset(seed=1)
+    first_obs = b.obs.clone()
+    b.step(torch.zeros(8, 14, device="cuda"))
+    qpos, qvel, warm = b.get_state()
+    qvel[3, 7] = np.nan; qpos[5, 9] = np.nan
+    b.set_state(qpos, qvel, warm)
+    b.step(torch.zeros(8, 14, device="cuda"))
+    done = b.done.cpu().numpy()
+    assert done[3] == 1 and done[5] == 1 and done[[0, 1, 2, 4, 6, 7]].sum() == 0
+    assert torch.isfinite(b.obs).all() and torch.isfinite(b.priv).all() and torch.isfinite(b.reward).all()
+    assert torch.equal(b.obs[3], first_obs[3]) and torch.equal(b.obs[5], first_obs[5])     # AutoReset: obs <- first_obs
+    q2, v2, _ = b.get_state()
+    assert np.isfinite(q2).all() and np.isfinite(v2).all()
+    b.step(torch.zeros(8, 14, device="cuda"))
+    assert float(b.done.sum()) == 0 and torch.isfinite(b.obs).all()
+    b.close()
