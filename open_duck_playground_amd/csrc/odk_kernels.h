@@ -1351,7 +1351,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   ODK_PROF(11);
   const bool any_ffa = __builtin_amdgcn_ballot_w64(ff_active) != 0;   // wave-uniform: some env has an active foot-foot row
   float search;
-  if (S::CL > 0 && !any_ffa) {
+  if (!any_ffa) {
     // ---- common case: no foot-foot coupling -> the Hessian has the inertia's own tree pattern
 #pragma unroll
     for (int t = 0; t < ST::NME; t++) {
@@ -1381,9 +1381,15 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     if (st.d_on) { MA[lane] = grad; GRAD[lane] = grad; }
     ODK_SYNC();
     ODK_PROF(12);
-    chain_solve<S, G>(HL, GRAD, SCR + S::S_K, st, lane);
-    ODK_PROF(13);
-    search = st.d_on ? -GRAD[lane] : 0.0f;
+    if constexpr (S::CL > 0) {
+      chain_solve<S, G>(HL, GRAD, SCR + S::S_K, st, lane);
+      ODK_PROF(13);
+      search = st.d_on ? -GRAD[lane] : 0.0f;
+    } else {   // generic tree: the inertia's own (shallower) row layout instead of the virtual tree's
+      factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
+      ODK_PROF(13);
+      search = -solve_rows<G, NV>(HL, grad, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
+    }
     ODK_PROF(14);
   } else {
   // Hessian entries on the virtual-tree layout
