@@ -153,8 +153,11 @@ int odk_ppo_head(const float* logits_dev, const float* raw_action_dev, const flo
                  float* dlogits_dev, float* dbaseline_dev, float* losses_dev, int n, int action_size, float clipping_epsilon,
                  float entropy_cost, float grad_scale, void* stream);
 
-/* clip_by_global_norm(max_grad_norm; <= 0 disables) + Adam on flat buffers of n floats.  acc_dev[2] is scratch
- * owned by the caller: acc[0] = squared gradient norm of this call, acc[1] = step count (zero it once). */
+/* clip_by_global_norm(max_grad_norm; <= 0 disables) + Adam on flat buffers of n floats.  acc_dev[ODK_ADAM_ACC_FLOATS]
+ * is scratch owned by the caller: acc[0] = squared gradient norm of this call, acc[1] = step count (zero it once),
+ * acc[2..] = per-block partial sums (the norm is reduced in a fixed order: data-parallel replicas stay bit-identical). */
+#define ODK_ADAM_MAX_PARTIALS 1024
+#define ODK_ADAM_ACC_FLOATS (2 + ODK_ADAM_MAX_PARTIALS)
 int odk_adam_clip(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr,
                   float b1, float b2, float eps, float max_grad_norm, void* stream);
 

@@ -125,18 +125,22 @@ __global__ void ppo_head_kernel(const float* __restrict__ logits, const float* _
   }
 }
 
-__global__ void zero1_kernel(float* p) { *p = 0.0f; }
-
-// acc[0] += sum g^2 (caller zeroes acc); block 0 / thread 0 advances the step counter acc[1].
+// Deterministic global gradient norm (data-parallel replicas must apply bit-identical updates, so no float atomics):
+// block b writes its partial sum to acc[2 + b]; one block then folds the partials in a fixed order into acc[0] and
+// advances the step counter acc[1].
 __global__ void sqnorm_kernel(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
   __shared__ float sh[16];
   float s = 0.0f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const float v = g[i]; s += v * v; }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) {
-    atomicAdd(&acc[0], s);
-    if (blockIdx.x == 0) acc[1] += 1.0f;
-  }
+  if (threadIdx.x == 0) acc[2 + blockIdx.x] = s;
+}
+__global__ void sqnorm_final_kernel(float* __restrict__ acc, int nblocks) {
+  __shared__ float sh[16];
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += acc[2 + i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) { acc[0] = s; acc[1] += 1.0f; }
 }
 
 // optax.chain(clip_by_global_norm(max_norm), adam(lr)): g *= max_norm / norm when norm >= max_norm;
@@ -191,13 +195,13 @@ extern "C" int odk_adam_clip(float* params_dev, const float* grads_dev, float* m
                              float b1, float b2, float eps, float max_grad_norm, void* stream) {
   if (!params_dev || !grads_dev || !m_dev || !v_dev || !acc_dev || n <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  // a kernel, not hipMemsetAsync: a memset NODE in the middle of a captured graph raced with its neighbours on ROCm 7.2
-  // (intermittent non-finite updates, 3 of 12 runs; 0 of 36 with this launch) -- keep the graph kernels-only
-  hipLaunchKernelGGL(zero1_kernel, dim3(1), dim3(1), 0, st, acc_dev);
+  // kernels only (no hipMemsetAsync): a memset NODE in the middle of a captured graph raced with its neighbours on
+  // ROCm 7.2 (intermittent non-finite updates, 3 of 12 runs; 0 of 36 without it)
   const int threads = 256;
   int blocks = (int)((n + threads * 4 - 1) / (threads * 4));
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > ODK_ADAM_MAX_PARTIALS) blocks = ODK_ADAM_MAX_PARTIALS;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(threads), 0, st, grads_dev, acc_dev, (int64_t)n);
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, acc_dev, blocks);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, grads_dev, m_dev, v_dev, acc_dev, (int64_t)n, lr, b1, b2, eps,
                      max_grad_norm);
   return check_launch("odk_adam_clip: launch failed");

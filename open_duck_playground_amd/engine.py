@@ -20,6 +20,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("ODK_LIB", os.path.join(_CSRC, "libodk.so"))  # ODK_LIB: e.g. the -DODK_PROFILE build
 
 NOBS, NPRIV, NMETRIC, NU = 101, 212, 8, 14
+ADAM_ACC_FLOATS = 2 + 1024   # ODK_ADAM_ACC_FLOATS (include/odk.h)
 METRIC_NAMES = ("reward/tracking_lin_vel", "reward/tracking_ang_vel", "cost/torques", "cost/action_rate", "cost/stand_still",
                 "reward/alive", "reward/imitation", "swing_peak")
 
@@ -182,8 +183,10 @@ def ppo_head(logits, raw_action, old_log_prob, adv, stats, vs, baseline, noise, 
 
 
 def adam_clip(params, grads, m, v, acc, lr: float, max_grad_norm: float = 0.0, b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
-    """optax clip_by_global_norm + adam on flat float32 buffers; acc = 2-float scratch (acc[1] = step count)."""
+    """optax clip_by_global_norm + adam on flat float32 buffers; acc = ADAM_ACC_FLOATS scratch (acc[1] = step count)."""
     _f32c(params, grads, m, v, acc)
+    if acc.numel() < ADAM_ACC_FLOATS:
+        raise OdkError("adam_clip: acc needs ADAM_ACC_FLOATS floats")
     _chk(load_library().odk_adam_clip(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
                                       max_grad_norm or 0.0, _stream(params)))
 

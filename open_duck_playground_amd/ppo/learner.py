@@ -74,7 +74,7 @@ class FlatLearner:
         self.flat_p = torch.empty(n_par, device=dev)
         self.flat_g = torch.zeros(n_par, device=dev)
         self.m, self.v = torch.zeros(n_par, device=dev), torch.zeros(n_par, device=dev)
-        self.acc = torch.zeros(2, device=dev)       # [sum g^2, step count]
+        self.acc = torch.zeros(engine.ADAM_ACC_FLOATS, device=dev)   # [sum g^2, step count, per-block partials...]
         self.policy = _FlatMLP(net.policy, self.flat_p, self.flat_g, 0)
         self.value = _FlatMLP(net.value, self.flat_p, self.flat_g, self.policy.end)
         assert self.value.end == n_par

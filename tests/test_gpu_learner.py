@@ -115,3 +115,47 @@ def test_flat_learner_training_step_matches_eager_and_graph_replays():
     assert float(learners[0].acc[1]) == 3.0
     # the module parameters ARE the flat buffer (rollout policy sees the update)
     assert nets[0].policy.layers[0].weight.data_ptr() == learners[0].flat_p.data_ptr()
+
+
+def _dp_worker(rank, world, port, out):
+    """Two ranks on one GPU over gloo (RCCL refuses two ranks per device): the data-parallel FlatLearner path --
+    graph (loss + grads), all-reduce of the flat gradient, graph (clip + Adam)."""
+    import os
+    import torch.distributed as dist
+    from open_duck_playground_amd.ppo import train as T
+    from open_duck_playground_amd.ppo.learner import FlatLearner, prepare_rollout
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    net = PPONetworks(101, 212, 14).to(dev)
+    data = _fake_rollout(32, 20, dev, seed=10 + rank)          # each rank has its own shard
+    net.norm_obs.update(data["obs"], dist.group.WORLD); net.norm_priv.update(data["priv"], dist.group.WORLD)
+    cfg = T.ppo_config(); cfg.update(num_minibatches=2, num_updates_per_batch=2)
+    before = torch.cat([p.detach().reshape(-1).clone() for p in list(net.policy.parameters()) + list(net.value.parameters())])
+    lr = FlatLearner(net, cfg, 16, 20, world=world, group=dist.group.WORLD)
+    assert lr.graph_b is not None
+    m = T.sgd_epoch(net, None, data, cfg, torch.Generator(device=dev).manual_seed(3), world=world, learner=lr)
+    torch.cuda.synchronize()
+    flat = lr.flat_p.detach().cpu()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out.put((bool(torch.equal(gathered[0], gathered[1])), float((flat - before.cpu()).abs().max()), bool(torch.isfinite(flat).all()),
+                 float(lr.acc[1]), float(m["total_loss"])))
+    dist.destroy_process_group()
+
+
+def test_flat_learner_data_parallel_two_ranks():
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    same, moved, finite, steps, loss = q.get(timeout=300)
+    for p in procs: p.join(timeout=60)
+    assert same, "ranks diverged: the flat gradient all-reduce must make the updates identical"
+    assert finite and moved > 1e-5 and steps == 4.0 and loss == loss
