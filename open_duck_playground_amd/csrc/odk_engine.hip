@@ -396,6 +396,10 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   size_t opaque1 = 0;
   asm volatile("" : "+s"(opaque1));
   const DevModel* mp = reinterpret_cast<const DevModel*>(reinterpret_cast<const char*>(m) + opaque1);
+  // ... and for the RNG key / counter: everything derived from them (threefry key schedules of the observation-noise
+  // draws) is recomputed here instead of riding through the loop in scratch
+  uint32_t k0e = k0, k1e = k1, ctre = ctr;
+  asm volatile("" : "+v"(k0e), "+v"(k1e), "+v"(ctre));
   for (int u = lane; u < NU; u += G) INFO[rec::MT + u] = CTRL[u];  // info["motor_targets"] (:422)
   // ---- contacts, air time, swing peak (:424-435)
   float contact[2];
@@ -473,14 +477,14 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   for (int k = 0; k < 7; k++) { rew[k] *= c.reward_scales[k]; total += rew[k]; }
   const float reward = fminf(fmaxf(total * dt, 0.0f), 10000.0f);
   // ---- obs (uses the pre-shift last_act and the post-increment air time; :437)
-  build_obs<S, G>(L, mp, c, contact, k0, k1, ctr, imi, phase, lane);
+  build_obs<S, G>(L, mp, c, contact, k0e, k1e, ctre, imi, phase, lane);
   // ---- info updates (:449-469)
   step += 1; push_step += 1;
   float la = 0, lla = 0;
   for (int u = lane; u < NU; u += G) { la = INFO[rec::LAST + u]; lla = INFO[rec::LAST2 + u]; }
   ODK_SYNC();
   for (int u = lane; u < NU; u += G) { INFO[rec::LAST3 + u] = lla; INFO[rec::LAST2 + u] = la; INFO[rec::LAST + u] = ACT[u]; }
-  if (step > 500 && lane < 7) sample_command(c, k0, k1, ctr, 41, lane, INFO[rec::CMD + lane]);
+  if (step > 500 && lane < 7) sample_command(c, k0e, k1e, ctre, 41, lane, INFO[rec::CMD + lane]);
   if (done_env || step > 500) step = 0;
   int lcon_new = 0;
   for (int f = 0; f < 2; f++) {
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     INFO[rec::EPSTEPS] = ep_steps; INFO[rec::TRUNC] = trunc; INFO[rec::DONE] = done_f;
     INFO[rec::EPSUM] = (INFO[rec::EPSUM] + reward) * keep; INFO[rec::EPLEN] = (INFO[rec::EPLEN] + 1.0f) * keep;
     for (int k = 0; k < ODK_NMETRIC; k++) INFO[rec::EPMET + k] = (INFO[rec::EPMET + k] + metrics[k]) * keep;
-    INFO[rec::CTR] = i2f((int)(ctr + 1)); INFO[rec::STEP] = i2f(step); INFO[rec::PSTEP] = i2f(push_step);
+    INFO[rec::CTR] = i2f((int)(ctre + 1)); INFO[rec::STEP] = i2f(step); INFO[rec::PSTEP] = i2f(push_step);
     INFO[rec::IMI] = i2f(imi); INFO[rec::LCON] = i2f(lcon_new);
   }
   ODK_SYNC();
