@@ -274,7 +274,7 @@ struct Statics {
 // Phase-local statics: fetched from the model (L1/L2-resident, one batch of loads per phase and substep)
 // right where they are used, so they do not occupy registers for the rest of the substep.
 struct BodySt {
-  int level, parent, nchild, child[3], njnt, jd[2], jj[2];
+  int level, parent, nchild, child[3], njnt, jd[2], jj[2], pathmask, is_path;
   float pos[3], quat[4], ipos[3], inertia[6], ax[2][3];
 };
 struct ActSt { float bias2, clo, chi, flo, fhi; int climited, flimited; };
@@ -310,6 +310,8 @@ __device__ __forceinline__ void load_body(BodySt& b, const DevModel* __restrict_
   b.level = lane < S::NB ? m->body_level[bi] : -2;
   b.parent = m->body_parent[bi];
   b.nchild = lane < S::NB ? m->body_nchild[bi] : 0;
+  b.pathmask = lane < S::NB ? m->body_pathmask[bi] : 0;
+  b.is_path = lane < S::NB ? m->body_is_path[bi] : 0;
   for (int k = 0; k < 3; k++) b.child[k] = m->body_children[bi][k];
   b.njnt = (lane < S::NB && b.level > 0) ? m->body_jntnum[bi] : 0;
   for (int k = 0; k < 2; k++) {
@@ -827,6 +829,9 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
       }
       ODK_SYNC();
     }
+    float acc[16];   // cinert (10) | local bias force (6) of this lane's body, then their subtree sums
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = 0.0f;
     if (lane < NB) {
       if (bs.level < 0) {
 #pragma unroll
@@ -870,16 +875,32 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
       fr[3] += a3[0]; fr[4] += a3[1]; fr[5] += a3[2];
       const bool dyn = bs.level >= 0;
 #pragma unroll
-      for (int k = 0; k < 10; k++) CRB[k * NB + lane] = dyn ? ci[k] : 0.0f;
+      for (int k = 0; k < 10; k++) acc[k] = dyn ? ci[k] : 0.0f;
 #pragma unroll
-      for (int k = 0; k < 6; k++) CFRC[k * NB + lane] = dyn ? fr[k] : 0.0f;
+      for (int k = 0; k < 6; k++) acc[10 + k] = dyn ? fr[k] : 0.0f;
+    }
+    ODK_PROF(1);
+    // ---------------- P2: composite inertia and subtree bias force.  Serial body chains (legs, head): suffix sums
+    // over neighbouring lanes, three cross-lane steps in registers; the few bodies above them: one level per step.
+#pragma unroll
+    for (int si = 0; si < 3; si++) {
+      const bool ok = (bs.pathmask >> si) & 1;
+      float t[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) t[k] = __shfl_down(acc[k], 1 << si, G);
+#pragma unroll
+      for (int k = 0; k < 16; k++) acc[k] += ok ? t[k] : 0.0f;
+    }
+    if (lane < NB) {
+#pragma unroll
+      for (int k = 0; k < 10; k++) CRB[k * NB + lane] = acc[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) CFRC[k * NB + lane] = acc[10 + k];
     }
     ODK_SYNC();
   }
-  ODK_PROF(1);
-  // ---------------- P2: bottom-up sweep: composite inertia and subtree bias force
-  for (int lvl = m->max_level - 1; lvl >= 0; lvl--) {
-    if (bs.level == lvl && bs.nchild > 0) {
+  for (int lvl = m->max_nonpath_level; lvl >= 0; lvl--) {
+    if (bs.level == lvl && bs.nchild > 0 && !bs.is_path) {
       float acc[16];
 #pragma unroll
       for (int k = 0; k < 10; k++) acc[k] = CRB[k * NB + lane];

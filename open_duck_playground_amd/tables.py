@@ -131,6 +131,27 @@ def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
                 children[p_, nchild[p_]] = b; nchild[p_] += 1
     out["k_body_level"] = level; out["k_body_children"] = children; out["k_body_nchild"] = nchild
     out["k_max_level"] = I([int(level.max())])
+    # "path" bodies: the subtree below (and including) the body is a serial chain with consecutive ids, so subtree
+    # sums are suffix sums over neighbouring lanes (3 Hillis-Steele steps) instead of one tree level per step.
+    # bit s of pathmask[b]: body b + 2^s belongs to b's chain below it.
+    is_path = np.zeros(nb, np.int32)
+    for b in range(nb - 1, 0, -1):
+        if in_tree[b] and (nchild[b] == 0 or (nchild[b] == 1 and children[b, 0] == b + 1 and is_path[b + 1])):
+            is_path[b] = 1
+    plen = np.zeros(nb, np.int32)   # bodies in the chain from b downwards
+    for b in range(nb - 1, 0, -1):
+        if is_path[b]:
+            plen[b] = 1 + (plen[b + 1] if nchild[b] == 1 else 0)
+    if plen.max() > 8:
+        raise ValueError("serial body chain longer than 8")
+    pathmask = np.zeros(nb, np.int32)
+    for b in range(nb):
+        for si in range(3):
+            if is_path[b] and (1 << si) < plen[b]:
+                pathmask[b] |= 1 << si
+    out["k_body_pathmask"] = pathmask; out["k_body_is_path"] = is_path
+    nonpath_levels = [int(level[b]) for b in range(nb) if in_tree[b] and not is_path[b] and nchild[b] > 0]
+    out["k_max_nonpath_level"] = I([max(nonpath_levels) if nonpath_levels else -1])
     sub = -np.ones((nb, MAXB), np.int32); nsub = np.zeros(nb, np.int32)
     for c in range(1, nb):
         b = c
