@@ -988,8 +988,9 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     if (st.d_on) QAS[lane] = qas;
   }
   // y_i = sum_j M(i, j) v_j with the dense symmetric row of M gathered on the fly (unconditional LDS loads + selects);
-  // recomputed at both uses instead of holding NV registers across the whole solver
-  auto mul_M = [&](float v) -> float {
+  // recomputed at both uses instead of holding NV registers across the whole solver.  v is read from its LDS vector
+  // with uniform addresses (broadcast reads on the LDS pipe) instead of 2 x v_readlane + select per element on the VALU.
+  auto mul_M = [&](const float* V) -> float {
     float acc = 0.0f;
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -997,7 +998,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
       const bool isanc = (st.d_ancmask >> j) & 1, isdesc = (st.d_descmask >> j) & 1;
       const int adr = isanc ? st.d_Madr + dj : (isdesc ? aj + st.d_depth : st.d_Madr + st.d_depth);
       const float mij = M[adr];
-      const float vj = bcast<G>(v, j);
+      const float vj = V[j];
       acc += (isanc || isdesc || j == lane) ? mij * vj : 0.0f;
     }
     return acc;
@@ -1196,13 +1197,13 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 #pragma unroll
     for (int d = 0; d < NV; d++) {
       const int fm = ubcast(st.d_foot, d);
-      const float vq = bcast<G>(qas, d), vw = bcast<G>(warm, d);
+      const float vq = QAS[d], vw = WARM[d];   // uniform addresses: LDS broadcast reads
       if ((fm >> f) & 1) s += CDOF[k * NV + d] * (which ? vw : vq);
     }
     if (lane < 24) SCR[(which ? S::S_VF2 : S::S_VF) + 6 * f + k] = s;
   }
   // M * warmstart from the register row
-  const float ma_w = mul_M(warm);
+  const float ma_w = mul_M(WARM);
   const float gw = st.d_on ? (ma_w - qfs) * (warm - qas) : 0.0f;
   ODK_SYNC();
   auto contact_jx = [&](int rc, const float* VF) -> float {
@@ -1462,7 +1463,8 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 
   // ---- line search (mjx solver._linesearch)
   if (st.d_on) GRAD[lane] = search;
-  const float mv = mul_M(search);
+  ODK_SYNC();
+  const float mv = mul_M(GRAD);
   float sn = st.d_on ? search * search : 0.0f, qg1 = st.d_on ? search * (ma - qfs) : 0.0f, qg2 = st.d_on ? 0.5f * search * mv : 0.0f;
   sn = gsum<G>(sn); qg1 = gsum<G>(qg1); qg2 = gsum<G>(qg2);
   ODK_SYNC();
@@ -1472,7 +1474,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 #pragma unroll
     for (int d = 0; d < NV; d++) {
       const int fm = ubcast(st.d_foot, d);
-      const float sd = bcast<G>(search, d);
+      const float sd = GRAD[d];
       if ((fm >> f) & 1) s += CDOF[k * NV + d] * sd;
     }
     if (lane < 12) SCR[S::S_VF + lane] = s;
