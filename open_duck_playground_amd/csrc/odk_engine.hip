@@ -727,6 +727,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I("k_max_level", &m.max_level, 1); B.I("k_body_level", m.body_level, MAXB); B.I2("k_body_children", &m.body_children[0][0], MAXB, 3);
   B.I("k_body_nchild", m.body_nchild, MAXB);
   B.I("k_max_nonpath_level", &m.max_nonpath_level, 1); B.I("k_body_pathmask", m.body_pathmask, MAXB); B.I("k_body_is_path", m.body_is_path, MAXB);
+  B.I("k_body_upmask", m.body_upmask, MAXB); B.I("k_body_path_head", m.body_path_head, MAXB);
   B.F("body_pos", &m.body_pos[0][0], MAXB * 3); B.F("body_quat", &m.body_quat[0][0], MAXB * 4); B.F("body_ipos", &m.body_ipos[0][0], MAXB * 3);
   B.F("body_mass", m.body_mass, MAXB); B.F("body_inertia_full", &m.body_inertia[0][0], MAXB * 6);
   // joints

@@ -274,7 +274,7 @@ struct Statics {
 // Phase-local statics: fetched from the model (L1/L2-resident, one batch of loads per phase and substep)
 // right where they are used, so they do not occupy registers for the rest of the substep.
 struct BodySt {
-  int level, parent, nchild, child[3], njnt, jd[2], jj[2], pathmask, is_path;
+  int level, parent, nchild, child[3], njnt, jd[2], jj[2], pathmask, is_path, upmask, path_head;
   float pos[3], quat[4], ipos[3], inertia[6], ax[2][3];
 };
 struct ActSt { float bias2, clo, chi, flo, fhi; int climited, flimited; };
@@ -312,6 +312,8 @@ __device__ __forceinline__ void load_body(BodySt& b, const DevModel* __restrict_
   b.nchild = lane < S::NB ? m->body_nchild[bi] : 0;
   b.pathmask = lane < S::NB ? m->body_pathmask[bi] : 0;
   b.is_path = lane < S::NB ? m->body_is_path[bi] : 0;
+  b.upmask = lane < S::NB ? m->body_upmask[bi] : 0;
+  b.path_head = lane < S::NB ? m->body_path_head[bi] : 0;
   for (int k = 0; k < 3; k++) b.child[k] = m->body_children[bi][k];
   b.njnt = (lane < S::NB && b.level > 0) ? m->body_jntnum[bi] : 0;
   for (int k = 0; k < 2; k++) {
@@ -768,8 +770,9 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
       for (int k = 0; k < 3; k++) p[k] = bs.pos[k];
       for (int k = 0; k < 4; k++) q[k] = bs.quat[k];
     }
-    for (int lvl = 0; lvl <= m->max_level; lvl++) {
-      if (bs.level == lvl) {
+    // bodies above the serial chains (world side of the tree: base, trunk): one tree level per step
+    for (int lvl = 0; lvl <= m->max_nonpath_level; lvl++) {
+      if (bs.level == lvl && !bs.is_path) {
         if (lvl == 0) {  // floating base: free joint (mj_comVel free-joint rule)
           for (int k = 0; k < 3; k++) p[k] = ref[k];
           for (int k = 0; k < 4; k++) q[k] = QPOS[3 + k];
@@ -826,6 +829,132 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
         for (int k = 0; k < 4; k++) XQUAT[k * NB + lane] = q[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) { CVEL[k * NB + lane] = cvel[k]; CACC[k * NB + lane] = cacc[k]; }
+      }
+      ODK_SYNC();
+    }
+    // serial body chains (legs, head): pose, velocity and bias acceleration as three prefix scans over neighbouring
+    // lanes (Hillis-Steele from the chain head, 3 cross-lane steps each) instead of one dependent LDS round trip per
+    // tree level.  Every lane runs the shuffles (uniform control flow); only chain bodies use the results.
+    {
+      const bool isp = bs.is_path != 0, head = bs.path_head != 0;
+      // local transform of the body relative to its parent, and the frames in which its joint axes are given
+      float ql[4] = {bs.quat[0], bs.quat[1], bs.quat[2], bs.quat[3]}, qb[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) qb[jj][k] = ql[k];
+        if (jj < bs.njnt) {
+          const float s = SC[2 * bs.jj[jj]], c = SC[2 * bs.jj[jj] + 1];
+          const float qj[4] = {c, s * bs.ax[jj][0], s * bs.ax[jj][1], s * bs.ax[jj][2]};
+          qmul(ql, ql, qj);
+        }
+      }
+      float tp[3] = {bs.pos[0], bs.pos[1], bs.pos[2]}, tq[4] = {ql[0], ql[1], ql[2], ql[3]};
+      float ppq[4] = {1, 0, 0, 0}, pcv[6] = {0, 0, 0, 0, 0, 0}, pca[6] = {0, 0, 0, 0, 0, 0};   // parent's world q, cvel, cacc
+      if (isp && head) {   // chain head: its parent is one of the bodies done above
+        const int pb = bs.parent;
+        float pp[3], t[3];
+        for (int k = 0; k < 3; k++) pp[k] = XPOS[k * NB + pb];
+        for (int k = 0; k < 4; k++) ppq[k] = XQUAT[k * NB + pb];
+        for (int k = 0; k < 6; k++) { pcv[k] = CVEL[k * NB + pb]; pca[k] = CACC[k * NB + pb]; }
+        qrot(t, ppq, tp);
+        tp[0] = pp[0] + t[0]; tp[1] = pp[1] + t[1]; tp[2] = pp[2] + t[2];
+        qmul(tq, ppq, tq);
+      }
+#pragma unroll
+      for (int si = 0; si < 3; si++) {   // world pose: T[b] <- T[b - 2^si] o T[b]
+        float up[3], uq[4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) up[k] = __shfl_up(tp[k], 1 << si, G);
+#pragma unroll
+        for (int k = 0; k < 4; k++) uq[k] = __shfl_up(tq[k], 1 << si, G);
+        if ((bs.upmask >> si) & 1) {
+          float t[3];
+          qrot(t, uq, tp);
+          tp[0] = up[0] + t[0]; tp[1] = up[1] + t[1]; tp[2] = up[2] + t[2];
+          qmul(tq, uq, tq);
+        }
+      }
+      {   // parent's world orientation: the lane above, except for chain heads (read from LDS above)
+        float uq[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) uq[k] = __shfl_up(tq[k], 1, G);
+        if (isp && !head) { ppq[0] = uq[0]; ppq[1] = uq[1]; ppq[2] = uq[2]; ppq[3] = uq[3]; }
+      }
+      // joint twists about the base origin and the body's own velocity / acceleration increments
+      float cd[2][6], qv[2] = {0, 0}, cinc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int jj = 0; jj < 2; jj++) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cd[jj][k] = 0.0f;
+        if (isp && jj < bs.njnt) {
+          float qw[4], axw[3];
+          qmul(qw, ppq, qb[jj]);
+          qrot(axw, qw, bs.ax[jj]);
+          const float off[3] = {ref[0] - tp[0], ref[1] - tp[1], ref[2] - tp[2]};
+          cd[jj][0] = axw[0]; cd[jj][1] = axw[1]; cd[jj][2] = axw[2];
+          cross3(cd[jj] + 3, axw, off);
+          const int d = bs.jd[jj];
+#pragma unroll
+          for (int k = 0; k < 6; k++) CDOF[k * NV + d] = cd[jj][k];
+          qv[jj] = QVEL[d];
+#pragma unroll
+          for (int k = 0; k < 6; k++) cinc[k] += cd[jj][k] * qv[jj];
+        }
+      }
+      float cv[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cv[k] = cinc[k] + pcv[k];   // heads start from their parent's velocity
+#pragma unroll
+      for (int si = 0; si < 3; si++) {
+        float u[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) u[k] = __shfl_up(cv[k], 1 << si, G);
+        const bool ok = (bs.upmask >> si) & 1;
+#pragma unroll
+        for (int k = 0; k < 6; k++) cv[k] += ok ? u[k] : 0.0f;
+      }
+      {   // velocity of the parent (= velocity before this body's first joint)
+        float u[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) u[k] = __shfl_up(cv[k], 1, G);
+        if (isp && !head) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) pcv[k] = u[k];
+        }
+      }
+      float ca[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) ca[k] = pca[k];
+      if (isp) {
+        float vb[6] = {pcv[0], pcv[1], pcv[2], pcv[3], pcv[4], pcv[5]};
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          if (jj < bs.njnt) {
+            float dot[6];
+            cross_motion(dot, vb, cd[jj]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) { ca[k] += dot[k] * qv[jj]; vb[k] += cd[jj][k] * qv[jj]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int si = 0; si < 3; si++) {
+        float u[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) u[k] = __shfl_up(ca[k], 1 << si, G);
+        const bool ok = (bs.upmask >> si) & 1;
+#pragma unroll
+        for (int k = 0; k < 6; k++) ca[k] += ok ? u[k] : 0.0f;
+      }
+      if (isp) {
+        qnormalize(tq);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { p[k] = tp[k]; XPOS[k * NB + lane] = tp[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { q[k] = tq[k]; XQUAT[k * NB + lane] = tq[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cvel[k] = cv[k]; cacc[k] = ca[k]; CVEL[k * NB + lane] = cv[k]; CACC[k * NB + lane] = ca[k]; }
       }
       ODK_SYNC();
     }

@@ -26,7 +26,7 @@ struct DevModel {
   // bodies
   int base_body, body_in_tree[MAXB], body_parent[MAXB], body_jntadr[MAXB], body_jntnum[MAXB];
   int max_level, body_level[MAXB], body_children[MAXB][3], body_nchild[MAXB];
-  int max_nonpath_level, body_pathmask[MAXB], body_is_path[MAXB];   // serial body chains (tables.py)
+  int max_nonpath_level, body_pathmask[MAXB], body_is_path[MAXB], body_upmask[MAXB], body_path_head[MAXB];   // serial body chains (tables.py)
   int body_chain[MAXB][MAXCHAIN], body_chain_len[MAXB];
   int body_ancdof[MAXB][MAXV], body_nancdof[MAXB];
   int body_sub[MAXB][MAXB], body_nsub[MAXB];

@@ -149,6 +149,19 @@ def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
         for si in range(3):
             if is_path[b] and (1 << si) < plen[b]:
                 pathmask[b] |= 1 << si
+    # upward masks for prefix scans from the chain head: bit s: body b - 2^s is in b's chain above it
+    head = np.zeros(nb, np.int32); upmask = np.zeros(nb, np.int32); is_head = np.zeros(nb, np.int32)
+    for b in range(1, nb):
+        if is_path[b]:
+            par = bparent[b]
+            if is_path[par] and par == b - 1:
+                head[b] = head[par]
+            else:
+                head[b] = b; is_head[b] = 1
+            for si in range(3):
+                if b - (1 << si) >= head[b]:
+                    upmask[b] |= 1 << si
+    out["k_body_upmask"] = upmask; out["k_body_path_head"] = is_head
     out["k_body_pathmask"] = pathmask; out["k_body_is_path"] = is_path
     nonpath_levels = [int(level[b]) for b in range(nb) if in_tree[b] and not is_path[b] and nchild[b] > 0]
     out["k_max_nonpath_level"] = I([max(nonpath_levels) if nonpath_levels else -1])
