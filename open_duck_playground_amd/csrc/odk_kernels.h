@@ -266,6 +266,7 @@ struct Statics {
   static constexpr int NHE = (S::NH + G - 1) / G;   // Hessian entries per lane
   int j_qadr, j_dadr;                    // joint role (sin/cos phase, Euler)
   int c_len, c_idx, c_n;                 // c_len > 0 on the lane of a chain's first dof (length, chain index); c_n chains
+  int ch_first, ch_len;                  // the serial dof chain this lane's dof belongs to (ch_len 0: base dof / no chain)
   int d_on, d_body, d_depth, d_Madr, d_ancmask, d_descmask, d_vdepth, d_vMadr, d_vancmask, d_vdescmask;
   int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
   int d_qadr, d_lim_on;                  // hinge qpos address (-1: free joint); has a limit row
@@ -289,6 +290,9 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
   }
   st.c_len = 0; st.c_idx = 0; st.c_n = m->nchain;
   for (int c = 0; c < 3; c++) if (c < m->nchain && lane == m->chain_first[c]) { st.c_len = m->chain_len[c]; st.c_idx = c; }
+  st.ch_first = 0; st.ch_len = 0;
+  for (int c = 0; c < 3; c++)
+    if (c < m->nchain && lane >= m->chain_first[c] && lane < m->chain_first[c] + m->chain_len[c]) { st.ch_first = m->chain_first[c]; st.ch_len = m->chain_len[c]; }
   const int i = lane < S::NV ? lane : 0;
   st.d_on = lane < S::NV;
   st.d_body = m->dof_body[i];
@@ -389,6 +393,99 @@ __device__ __forceinline__ void factor_rows(float* A, int lane, int on, int di, 
     ODK_SYNC();
   }
   if (on) A[ai + di] = diag;  // rows at depth 0 were never published
+  ODK_SYNC();
+}
+
+// Same factorisation for a "floating base + serial dof chains" tree (this robot with backlash joints: 6 + 10 + 4 + 10):
+// the chains are independent of each other, so their pivots at equal distance from the leaf are eliminated in the
+// same step (MAXLEN steps instead of NV - 1), each chain lane folding only its own chain's pivot row; the base block
+// receives the chains' Schur complement afterwards and is finished with the generic loop (NBASE - 1 steps).
+// Produces the same LDS image as factor_rows (row k = scaled L entries, then D_k).
+template <int G, int DMAX, int NVT, int MAXLEN, int NBASE>
+__device__ __forceinline__ void factor_chains(float* A, int lane, int on, int di, int ai, int ch_first, int ch_len, int descmask,
+                                              int depth_st, int madr_st) {
+  float row[DMAX > 0 ? DMAX : 1];
+#pragma unroll
+  for (int c = 0; c < DMAX; c++) row[c] = A[ai + c];
+  float diag = A[ai + di];
+  if (!on) diag = 1.0f;
+  const int a_loc = lane - ch_first;
+  for (int s = 0; s < MAXLEN; s++) {
+    const int kl = ch_len - 1 - s;              // local index of this chain's pivot in step s
+    const int t = kl - a_loc;                   // pivot dof = lane + t
+    const bool act = ch_len > 0 && kl >= 0;
+    if (act && t == 0) {                        // the pivot publishes its finished row
+      const float inv = __builtin_amdgcn_rcpf(diag);
+#pragma unroll
+      for (int c = 0; c < DMAX; c++)
+        if (c < di) { row[c] *= inv; A[ai + c] = row[c]; }
+      A[ai + di] = diag;
+    }
+    ODK_SYNC();
+    {
+      const bool anc = act && t > 0;            // this lane's dof is above the pivot in the same chain
+      const int tk = anc ? t : 0;
+      const int ak = ai + tk * (di + 1) + (tk * (tk - 1)) / 2, Dk = di + tk;   // consecutive dofs: rows are adjacent, one entry longer each
+      float rk[DMAX > 0 ? DMAX : 1];
+#pragma unroll
+      for (int c = 0; c < DMAX; c++) rk[c] = A[ak + c];
+      const float Lki = A[ak + di], dk = A[ak + Dk];
+      const float tt = anc ? Lki * dk : 0.0f;
+#pragma unroll
+      for (int c = 0; c < DMAX; c++) row[c] = anc ? fmaf(-tt, rk[c], row[c]) : row[c];
+      diag = anc ? fmaf(-tt, Lki, diag) : diag;
+    }
+    ODK_SYNC();
+  }
+  // Schur complement of the chains on the base block: lane e < NBASE (NBASE + 1) / 2 owns entry (a, b), b <= a
+  {
+    int a = 0, b = lane;
+#pragma unroll
+    for (int r = 0; r < NBASE; r++)
+      if (b > a) { b -= a + 1; a++; }
+    const bool mine = lane < (NBASE * (NBASE + 1)) / 2;
+    const int ac = mine ? a : 0, bc = mine ? b : 0;
+    float acc = 0.0f;
+    for (int k = NBASE; k < NVT; k++) {
+      const int adr = ubcast(madr_st, k), Dk = ubcast(depth_st, k);
+      const float la = A[adr + ac], lb = A[adr + bc], dk = A[adr + Dk];
+      acc = fmaf(la * dk, lb, acc);
+    }
+    const int ra = ubcast(madr_st, 0);   // rows of the base dofs start at madr(a) = a (a + 1) / 2 + madr(0)
+    ODK_SYNC();
+    if (mine) A[ra + (ac * (ac + 1)) / 2 + bc] -= acc;
+  }
+  ODK_SYNC();
+  // base block: reload the updated rows and finish as in factor_rows
+  if (lane < NBASE) {
+#pragma unroll
+    for (int c = 0; c < DMAX; c++) row[c] = A[ai + c];
+    diag = A[ai + di];
+  }
+  for (int k = NBASE - 1; k > 0; k--) {
+    const int Dk = ubcast(depth_st, k), ak = ubcast(madr_st, k);
+    if (lane == k) {
+      const float inv = __builtin_amdgcn_rcpf(diag);
+#pragma unroll
+      for (int c = 0; c < DMAX; c++)
+        if (c < Dk) { row[c] *= inv; A[ak + c] = row[c]; }
+      A[ak + Dk] = diag;
+    }
+    ODK_SYNC();
+    {
+      const bool anc = lane < k;
+      float rk[NBASE];
+#pragma unroll
+      for (int c = 0; c < NBASE; c++) rk[c] = A[ak + c];
+      const float Lki = A[ak + di], dk = A[ak + Dk];
+      const float tt = anc ? Lki * dk : 0.0f;
+#pragma unroll
+      for (int c = 0; c < NBASE; c++) row[c] = anc ? fmaf(-tt, rk[c], row[c]) : row[c];
+      diag = anc ? fmaf(-tt, Lki, diag) : diag;
+    }
+    ODK_SYNC();
+  }
+  if (lane == 0) A[ai + di] = diag;
   ODK_SYNC();
 }
 
@@ -1111,7 +1208,10 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 #pragma unroll
     for (int t = 0; t < ST::NME; t++) { const int p = lane + t * G; if (p < S::NM) HL[p] = M[p]; }
     ODK_SYNC();
-    factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
+    if (m->nchain > 0 && m->chain_first[0] == 6)   // floating base + serial chains: chain-parallel elimination
+      factor_chains<G, S::DT, NV, S::DT - 5, 6>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.ch_first, st.ch_len, st.d_descmask, st.d_depth, st.d_Madr);
+    else
+      factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
     ODK_PROF(5);
     qas = solve_rows<G, NV>(HL, qfs, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
     if (st.d_on) QAS[lane] = qas;
@@ -1537,6 +1637,9 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
       ODK_PROF(13);
       search = st.d_on ? -GRAD[lane] : 0.0f;
     } else {   // generic tree: the inertia's own (shallower) row layout instead of the virtual tree's
+      if (m->nchain > 0 && m->chain_first[0] == 6)   // floating base + serial chains: chain-parallel elimination
+      factor_chains<G, S::DT, NV, S::DT - 5, 6>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.ch_first, st.ch_len, st.d_descmask, st.d_depth, st.d_Madr);
+    else
       factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
       ODK_PROF(13);
       search = -solve_rows<G, NV>(HL, grad, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
