@@ -119,8 +119,11 @@ __global__ void ppo_head_kernel(const float* __restrict__ logits, const float* _
     dbaseline[s] = grad_scale * (-0.5f * verr * inv_n);
     lp = -fminf(s1, s2) * inv_n; lv = 0.25f * verr * verr * inv_n; le = -entropy_cost * ent * inv_n;
   }
-  lp = wave_sum(lp); lv = wave_sum(lv); le = wave_sum(le);
-  if ((threadIdx.x & 63) == 0) {
+  // block totals first: one atomic per loss and workgroup (1 280 wave-level float atomics on four addresses serialised
+  // into ~50 us; these sums are reporting only, the gradients above do not depend on them)
+  __shared__ float sh[16];
+  lp = block_sum(lp, sh); lv = block_sum(lv, sh); le = block_sum(le, sh);
+  if (threadIdx.x == 0) {
     atomicAdd(&losses[0], lp + lv + le); atomicAdd(&losses[1], lp); atomicAdd(&losses[2], lv); atomicAdd(&losses[3], le);
   }
 }

@@ -21,11 +21,39 @@ import torch
 import torch.nn.functional as F
 
 import os
+import tempfile
 
 from .. import engine
 from .networks import PPONetworks
 
 _DEBUG_NONFINITE = os.environ.get("ODK_DEBUG_NONFINITE") == "1"   # per-step finiteness check (synchronises: debugging only)
+
+
+def _tunable(tuning: bool) -> bool:
+    """hipBLASLt / rocBLAS kernel selection measured on this GPU for the learner's 30 GEMM shapes (PyTorch TunableOp):
+    the library heuristics pick stream-K 32x32 tiles for the K = 5120 weight-gradient GEMMs (30-36 us each); the tuned
+    choices run 17-24 us (-150 us per minibatch step).  Tuning happens during the warm-up steps only."""
+    try:
+        import torch.cuda.tunable as tn
+    except Exception as e:                          # optional speed-up, never a requirement
+        print(f"[ppo] GEMM tuning unavailable ({type(e).__name__}: {e})")
+        return False
+    try:
+        if tuning:
+            tn.set_max_tuning_duration(30)          # ms per candidate kernel
+            tn.set_max_tuning_iterations(20)
+            # results go to $ODK_TUNABLEOP_FILE when set, else to a per-process scratch file (TunableOp writes one on exit)
+            tn.set_filename(os.environ.get("ODK_TUNABLEOP_FILE") or os.path.join(tempfile.gettempdir(), f"odk_tunableop_{os.getpid()}.csv"))
+        tn.enable(True)
+        tn.tuning_enable(tuning)
+        return True
+    except Exception as e:
+        print(f"[ppo] GEMM tuning unavailable ({type(e).__name__}: {e})")
+        try:
+            tn.tuning_enable(False)
+        except Exception:
+            pass
+        return False
 
 
 class _FlatMLP:
@@ -122,10 +150,13 @@ class FlatLearner:
         keep = [t.clone() for t in (self.flat_p, self.m, self.v, self.acc)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):               # warm-up outside capture (hipBLASLt workspaces, allocator)
+        tuned = _tunable(True) if self.cfg.get("tune_gemms", True) else False
+        with torch.cuda.stream(side):               # warm-up outside capture (hipBLASLt workspaces, allocator, GEMM tuning)
             for _ in range(2):
                 self._draw_noise(); self._loss_and_grads(); self._update()
         torch.cuda.current_stream().wait_stream(side)
+        if tuned:
+            _tunable(False)                         # keep the selected kernels, never tune inside a capture
         for t, k in zip((self.flat_p, self.m, self.v, self.acc), keep):
             t.copy_(k)                              # the warm-up steps must not train
         self.graph_a = torch.cuda.CUDAGraph()
