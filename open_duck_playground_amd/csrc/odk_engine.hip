@@ -700,6 +700,19 @@ static void row_consts(const double* solref, const double* solimp, double dt, do
   *bb = b;
 }
 
+// mju impedance constants of one constraint row (the same float arithmetic the kernels used to repeat per row and substep)
+static void pack_imp(const float* solref, const float* solimp, float dt, float* P) {
+  const float timeconst = fmaxf(solref[0], 2.0f * dt), dampratio = solref[1];
+  const float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
+  const float width = fmaxf(solimp[2], 1e-15f), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(solimp[4], 1.0f);
+  float k = 1.0f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  float b = 2.0f / (dmax * timeconst);
+  if (solref[0] <= 0) k = -solref[0] / (dmax * dmax);
+  if (solref[1] <= 0) b = -solref[1] / dmax;
+  P[0] = k; P[1] = b; P[2] = dmin; P[3] = dmax; P[4] = 1.0f / width; P[5] = mid; P[6] = power;
+  P[7] = 1.0f / powf(mid, power - 1.0f); P[8] = 1.0f / powf(1.0f - mid, power - 1.0f);
+}
+
 extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   if (!blob || !out || len < 16 || memcmp(blob, "ODKM", 4) != 0) return fail(ODK_ERR_INVALID, "odk_model_load: not an ODKM blob");
   Blob B{(const unsigned char*)blob, len};
@@ -791,6 +804,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     if (jnt_margin[j] != 0) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "joint margin"); }
     for (int k = 0; k < 2; k++) m.lim_solref[r][k] = (float)jnt_solref[2 * j + k];
     for (int k = 0; k < 5; k++) m.lim_solimp[r][k] = (float)jnt_solimp[5 * j + k];
+    pack_imp(m.lim_solref[r], m.lim_solimp[r], m.dt, m.lim_imp[r]);
     m.lim_invweight[r] = (float)dof_iw[m.jnt_dofadr[j]];
   }
   // geoms: feet + floor
@@ -855,6 +869,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       else { double s1 = cg_solmix[g1], s2 = cg_solmix[g2]; mix = (s1 >= 1e-15 && s2 >= 1e-15) ? s1 / (s1 + s2) : ((s1 < 1e-15 && s2 < 1e-15) ? 0.5 : (s1 < 1e-15 ? 0.0 : 1.0)); }
       for (int k = 0; k < 2; k++) m.pair_solref[pr][k] = (float)(mix * cg_solref[2 * g1 + k] + (1 - mix) * cg_solref[2 * g2 + k]);
       for (int k = 0; k < 5; k++) m.pair_solimp[pr][k] = (float)(mix * cg_solimp[5 * g1 + k] + (1 - mix) * cg_solimp[5 * g2 + k]);
+      pack_imp(m.pair_solref[pr], m.pair_solimp[pr], m.dt, m.pair_imp[pr]);
       double mu = cg_prio[g1] > cg_prio[g2] ? cg_fric[3 * g1] : (cg_prio[g2] > cg_prio[g1] ? cg_fric[3 * g2] : fmax(cg_fric[3 * g1], cg_fric[3 * g2]));
       m.pair_mu[pr] = (float)mu;
       double t = biw[2 * cg_body[g1]] + biw[2 * cg_body[g2]];

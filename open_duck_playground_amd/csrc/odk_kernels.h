@@ -651,25 +651,20 @@ __device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* X
 }
 
 // impedance / stiffness of one constraint row (mjx constraint._row); returns D = 1/R and aref
-__device__ inline void row_params(const float* solref, const float* solimp, float dt, float pos, float invweight, float vel, float& D,
-                                  float& aref) {
-  float timeconst = fmaxf(solref[0], 2.0f * dt), dampratio = solref[1];
-  float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
-  float width = fmaxf(solimp[2], MINVAL_F), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(solimp[4], 1.0f);
-  float k = 1.0f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
-  float b = 2.0f / (dmax * timeconst);
-  if (solref[0] <= 0) k = -solref[0] / (dmax * dmax);
-  if (solref[1] <= 0) b = -solref[1] / dmax;
-  float x = fabsf(pos) / width, y;
+// efc_D and efc_aref of one active row from the constants packed at load (DevModel::*_imp): impedance sigmoid of
+// |pos| / width, R = invweight (1 - imp) / imp, aref = -b vel - k imp pos  (mjx constraint._efc_row / mju_makeImpedance)
+__device__ __forceinline__ void row_params(const float* P, float pos, float invweight, float vel, float& D, float& aref) {
+  const float k = P[0], b = P[1], dmin = P[2], dmax = P[3], mid = P[5], power = P[6];
+  const float x = fabsf(pos) * P[4];
+  float y;
   if (power == 2.0f) {
-    y = x < mid ? x * x / mid : 1.0f - (1.0f - x) * (1.0f - x) / (1.0f - mid);
+    y = x < mid ? x * x * P[7] : 1.0f - (1.0f - x) * (1.0f - x) * P[8];
   } else {
-    y = x < mid ? powf(x, power) / powf(mid, power - 1.0f) : 1.0f - powf(1.0f - x, power) / powf(1.0f - mid, power - 1.0f);
+    y = x < mid ? powf(x, power) * P[7] : 1.0f - powf(1.0f - x, power) * P[8];
   }
   float imp = fminf(fmaxf(dmin + y * (dmax - dmin), dmin), dmax);
   if (x > 1.0f) imp = dmax;
-  float R = fmaxf(invweight * (1.0f - imp) / imp, MINVAL_F);
-  D = 1.0f / R;
+  D = imp / fmaxf(invweight * (1.0f - imp), MINVAL_F * imp);   // = 1 / max(invweight (1 - imp) / imp, MINVAL)
   aref = -b * vel - k * imp * pos;
 }
 
@@ -1379,7 +1374,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     const float pos = fminf(dlo, dhi);
     lim_sgn = dlo < dhi ? 1.0f : -1.0f;
     float D = 0, aref = 0;
-    if (pos < 0) row_params(m->lim_solref[st.d_limrow], m->lim_solimp[st.d_limrow], dt, pos, m->lim_invweight[st.d_limrow], lim_sgn * QVEL[lane], D, aref);
+    if (pos < 0) row_params(m->lim_imp[st.d_limrow], pos, m->lim_invweight[st.d_limrow], lim_sgn * QVEL[lane], D, aref);
     ED[r] = D; AREF[r] = aref;
   }
   for (int rc = lane; rc < S::NCROW; rc += G) {
@@ -1407,7 +1402,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 #pragma unroll
         for (int k = 0; k < 6; k++) vel -= wr[k] * CVEL[k * NB + b1];
       }
-      row_params(m->pair_solref[pair], m->pair_solimp[pair], dt, dist, m->pair_invweight[pair], vel, D, aref);
+      row_params(m->pair_imp[pair], dist, m->pair_invweight[pair], vel, D, aref);
     }
     ED[r] = D;
     AREF[r] = aref;

@@ -61,6 +61,9 @@ struct DevModel {
   float fl_D[MAXV], fl_R[MAXV], fl_b[MAXV];             // friction-loss rows: pos = 0 -> constant impedance
   float lim_solref[MAXJ][2], lim_solimp[MAXJ][5], lim_invweight[MAXJ];
   float pair_solref[3][2], pair_solimp[3][5], pair_mu[3], pair_invweight[3];  // pairs: Lfoot-floor, Rfoot-floor, Lfoot-Rfoot
+  // solref / solimp folded into per-row constants at load (odk_engine.hip: pack_imp): k, b, dmin, dmax, 1/width, mid,
+  // power, 1/mid^(power-1), 1/(1-mid)^(power-1)
+  float lim_imp[MAXJ][9], pair_imp[3][9];
   // feet / floor
   int foot_body[2], foot_nvert[2], foot_nface[2], foot_dofmask[2][MAXV];
   float foot_vert[2][MAXHV][3];  // hull vertices in the BODY frame (geom pos/quat folded in)
