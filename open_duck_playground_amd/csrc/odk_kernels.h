@@ -192,10 +192,10 @@ __device__ __forceinline__ void qmul(float* r, const float* a, const float* b) {
   float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
   r[0] = w; r[1] = x; r[2] = y; r[3] = z;
 }
-__device__ __forceinline__ void qnormalize(float* q) {
-  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n < MINVAL_F) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
-  float inv = 1.0f / n;
+__device__ __forceinline__ void qnormalize(float* q) {   // v_rsq_f32 (1 ulp) instead of IEEE sqrt + division (~20 instructions)
+  const float n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (n2 < MINVAL_F * MINVAL_F) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  const float inv = __builtin_amdgcn_rsqf(n2);
   q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 __device__ __forceinline__ void qrot(float* r, const float* q, const float* v) {  // r = R(q) v
@@ -1766,7 +1766,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
       d1[a] = 2.0f * t2 + (t2 == 0.0f ? MINVAL_F : 0.0f);
     }
   };
-  auto sdiv = [](float a, float b) { return b == 0.0f ? 0.0f : a / b; };
+  auto sdiv = [](float a, float b) { return b == 0.0f ? 0.0f : a * __builtin_amdgcn_rcpf(b); };   // Newton step of the 1-D search: 1 ulp is plenty
   float al[3] = {0, 0, 0}, cs[3], e0[3], e1[3];
   ls_eval3(al, cs, e0, e1);
   const float p0_cost = cs[0], p0_d0 = e0[0], p0_d1 = e1[0];
