@@ -162,13 +162,32 @@ template <int G, class Op> __device__ __forceinline__ float greduce(float v) {
   return v;
 }
 template <int G> __device__ __forceinline__ float gsum(float v) { return greduce<G, OpSum>(v); }
-template <int G> __device__ __forceinline__ float gmax(float v) { return greduce<G, OpMax>(v); }
-template <int G> __device__ __forceinline__ float gmin(float v) { return greduce<G, OpMin>(v); }
+// max / min / argmax run on order-preserving unsigned keys: integer v_max_u32 / v_min_u32 fold the DPP permute into the
+// op (float max needs a canonicalising v_max x, x per stage under IEEE mode, and then the permute stays a separate mov)
+__device__ __forceinline__ unsigned fkey(float v) { const unsigned b = __float_as_uint(v); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu)); }
+#define ODK_DPPU(v, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, 0xF, 0xF, true))
+template <int G, bool MAX> __device__ __forceinline__ unsigned greduce_u(unsigned v) {
+  auto op = [](unsigned a, unsigned b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  v = op(v, ODK_DPPU(v, 0xB1));
+  v = op(v, ODK_DPPU(v, 0x4E));
+  v = op(v, ODK_DPPU(v, 0x141));
+  v = op(v, ODK_DPPU(v, 0x140));
+  const odk_u2 h = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = op(h[0], h[1]);
+  if (G == 64) {
+    const odk_u2 w = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    v = op(w[0], w[1]);
+  }
+  return v;
+}
+template <int G> __device__ __forceinline__ float gmax(float v) { return fkey_inv(greduce_u<G, true>(fkey(v))); }
+template <int G> __device__ __forceinline__ float gmin(float v) { return fkey_inv(greduce_u<G, false>(fkey(v))); }
 // argmax, lowest index wins ties (jnp.argmax semantics): max of the values, then min index among the maxima
 template <int G> __device__ __forceinline__ int gargmax(float v, int i) {
-  const float mx = greduce<G, OpMax>(v);
-  const float cand = (v == mx) ? (float)i : 1.0e9f;
-  return (int)greduce<G, OpMin>(cand);
+  const unsigned k = fkey(v);
+  const unsigned mx = greduce_u<G, true>(k);
+  return (int)greduce_u<G, false>(k == mx ? (unsigned)i : 0x7FFFFFFFu);
 }
 // value held by lane j (uniform j < G) of this env's lane group, via v_readlane (no LDS)
 template <int G> __device__ __forceinline__ float bcast(float v, int j) {
