@@ -161,6 +161,16 @@ int odk_ppo_head(const float* logits_dev, const float* raw_action_dev, const flo
 int odk_adam_clip(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr,
                   float b1, float b2, float eps, float max_grad_norm, void* stream);
 
+/* dz = dh * silu'(z) over row-major [n, w] and colsum[c] = sum_r dz[r, c] (the bias gradient of the layer below), fixed
+ * summation order.  partial_dev: scratch of ceil(n / 64) * w floats. */
+int odk_silu_bwd_colsum(const float* dh_dev, const float* z_dev, float* dz_dev, float* colsum_dev, float* partial_dev, int n, int w,
+                        void* stream);
+
+/* dst[f][b, :] = src[f][idx[b], :] for up to 8 row-major float fields in one launch (minibatch gather of the rollout).
+ * src_dev / dst_dev / row_floats are HOST arrays of device pointers / row lengths; idx_dev is int64 on the device. */
+int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, int nfields, const long long* idx_dev,
+                    int nrows, void* stream);
+
 /* live timing of the most recent odk_step launches with HIP events on the launch stream:
  * returns average milliseconds per launch since the last call (and resets the window) */
 int odk_batch_timing(odk_batch* b, int enable, float* avg_ms, int* launches);

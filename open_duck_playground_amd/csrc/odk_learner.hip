@@ -161,6 +161,54 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// dz = dh * silu'(z) and per-tile column sums of dz in one pass (bias gradient).  Tile = 64 rows x 64 columns, 256
+// threads = 64 columns x 4 row phases (coalesced 256 B rows); partial[tile_row][c]; colsum_final_kernel folds the
+// partials in a fixed order (again 64 columns x 4 phases per workgroup).
+constexpr int SB_ROWS = 64;
+__global__ void silu_bwd_colsum_kernel(const float* __restrict__ dh, const float* __restrict__ z, float* __restrict__ dz,
+                                       float* __restrict__ partial, int n, int w) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * SB_ROWS, r1 = min(n, r0 + SB_ROWS);
+  float s = 0.0f;
+  if (c < w) {
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += 4) {
+      const size_t o = (size_t)r * w + c;
+      const float x = z[o], sg = 1.0f / (1.0f + __expf(-x));
+      const float g = dh[o] * sg * (1.0f + x * (1.0f - sg));   // d/dx x sigmoid(x)
+      dz[o] = g;
+      s += g;
+    }
+  }
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < w) partial[(size_t)blockIdx.y * w + c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int w) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float s = 0.0f;
+  if (c < w)
+    for (int b = ty; b < nblk; b += 4) s += partial[(size_t)b * w + c];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < w) out[c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+}
+
+// Minibatch gather: trajectory idx[b] of up to 8 row-major [N, row_floats] sources -> row b of the matching static
+// buffers, one launch (blockIdx.x = trajectory, blockIdx.y = field).
+struct GatherArgs { const float* src[8]; float* dst[8]; int row[8]; int nfields; };
+__global__ void gather_rows_kernel(GatherArgs a, const long long* __restrict__ idx) {
+  const int f = blockIdx.y;
+  const int n = a.row[f];
+  const float* s = a.src[f] + (size_t)idx[blockIdx.x] * n;
+  float* d = a.dst[f] + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return odk_fail_(ODK_ERR_HIP, what);
@@ -208,4 +256,24 @@ extern "C" int odk_adam_clip(float* params_dev, const float* grads_dev, float* m
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, grads_dev, m_dev, v_dev, acc_dev, (int64_t)n, lr, b1, b2, eps,
                      max_grad_norm);
   return check_launch("odk_adam_clip: launch failed");
+}
+
+extern "C" int odk_silu_bwd_colsum(const float* dh_dev, const float* z_dev, float* dz_dev, float* colsum_dev, float* partial_dev, int n,
+                                   int w, void* stream) {
+  if (!dh_dev || !z_dev || !dz_dev || !colsum_dev || !partial_dev || n <= 0 || w <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_silu_bwd_colsum: bad arguments");
+  const int nblk = (n + SB_ROWS - 1) / SB_ROWS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(silu_bwd_colsum_kernel, dim3((w + 63) / 64, nblk), dim3(256), 0, st, dh_dev, z_dev, dz_dev, partial_dev, n, w);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((w + 63) / 64), dim3(256), 0, st, partial_dev, colsum_dev, nblk, w);
+  return check_launch("odk_silu_bwd_colsum: launch failed");
+}
+
+extern "C" int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, int nfields, const long long* idx_dev,
+                               int nrows, void* stream) {
+  if (!src_dev || !dst_dev || !row_floats || !idx_dev || nfields <= 0 || nfields > 8 || nrows <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_gather_rows: bad arguments");
+  GatherArgs a;
+  a.nfields = nfields;
+  for (int f = 0; f < 8; f++) { a.src[f] = f < nfields ? src_dev[f] : nullptr; a.dst[f] = f < nfields ? dst_dev[f] : nullptr; a.row[f] = f < nfields ? row_floats[f] : 0; }
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows, nfields), dim3(256), 0, (hipStream_t)stream, a, idx_dev);
+  return check_launch("odk_gather_rows: launch failed");
 }

@@ -100,6 +100,8 @@ def load_library() -> C.CDLL:
     L.odk_gae.argtypes = [P, P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_float, P]
     L.odk_ppo_head.argtypes = [P] * 11 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P]
     L.odk_adam_clip.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P]
+    L.odk_silu_bwd_colsum.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
+    L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, P, C.c_int, P]
     _lib = L
     return L
 
@@ -109,7 +111,7 @@ EXPORTED_SYMBOLS = (
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
-    "odk_adam_clip")
+    "odk_adam_clip", "odk_silu_bwd_colsum", "odk_gather_rows")
 
 
 def _chk(rc: int):
@@ -189,6 +191,33 @@ def adam_clip(params, grads, m, v, acc, lr: float, max_grad_norm: float = 0.0, b
         raise OdkError("adam_clip: acc needs ADAM_ACC_FLOATS floats")
     _chk(load_library().odk_adam_clip(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
                                       max_grad_norm or 0.0, _stream(params)))
+
+
+def silu_bwd_colsum(dh, z, dz, colsum, partial):
+    """dz = dh * silu'(z) ([n, w]) and colsum = dz.sum(0) in one pass; partial: scratch of ceil(n / 64) * w floats."""
+    n, w = z.shape
+    _f32c(dh, z, dz, colsum, partial)
+    if partial.numel() < ((n + 63) // 64) * w:
+        raise OdkError("silu_bwd_colsum: partial scratch too small")
+    _chk(load_library().odk_silu_bwd_colsum(_ptr(dh), _ptr(z), _ptr(dz), _ptr(colsum), _ptr(partial), n, w, _stream(z)))
+
+
+class RowGather:
+    """dst[f][b] = src[f][idx[b]] for a fixed set of (src, dst) float32 tensors in one launch (`odk_gather_rows`)."""
+
+    def __init__(self, pairs):
+        n = len(pairs)
+        self.n = n
+        self.keep = pairs
+        for s_, d_ in pairs:
+            _f32c(s_, d_)
+        self.src = (C.c_void_p * n)(*[s_.data_ptr() for s_, _ in pairs])
+        self.dst = (C.c_void_p * n)(*[d_.data_ptr() for _, d_ in pairs])
+        self.rows = (C.c_int * n)(*[int(s_[0].numel()) for s_, _ in pairs])
+        self.nrows = int(pairs[0][1].shape[0])
+
+    def __call__(self, idx):
+        _chk(load_library().odk_gather_rows(self.src, self.dst, self.rows, self.n, _ptr(idx), self.nrows, _stream(idx)))
 
 
 class Batch:

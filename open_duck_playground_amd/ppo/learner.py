@@ -61,6 +61,7 @@ class _FlatMLP:
 
     def __init__(self, mlp, flat_p, flat_g, off: int):
         self.W, self.b, self.gW, self.gb = [], [], [], []
+        self.partial = None   # scratch of the fused SiLU-backward + column-sum kernel
         for lin in mlp.layers:
             for name in ("weight", "bias"):
                 p = getattr(lin, name)
@@ -82,11 +83,18 @@ class _FlatMLP:
         return hs, zs
 
     def backward(self, dz, hs, zs):
-        for i in range(len(self.W) - 1, -1, -1):
+        """Gradients straight into the flat buffer.  Below the top layer, dz and its column sums (the bias gradient)
+        come out of one fused pass (csrc silu_bwd_colsum) instead of silu_backward + a separate reduction."""
+        top = len(self.W) - 1
+        torch.sum(dz, 0, out=self.gb[top])
+        for i in range(top, -1, -1):
             torch.mm(dz.t(), hs[i], out=self.gW[i])
-            torch.sum(dz, 0, out=self.gb[i])
             if i > 0:
-                dz = torch.ops.aten.silu_backward(torch.mm(dz, self.W[i]), zs[i - 1])
+                dh = torch.mm(dz, self.W[i])
+                dz = torch.empty_like(dh)
+                if self.partial is None or self.partial.numel() < ((dh.shape[0] + 63) // 64) * max(w.shape[0] for w in self.W):
+                    self.partial = torch.empty(((dh.shape[0] + 63) // 64) * max(w.shape[0] for w in self.W), device=dh.device)
+                engine.silu_bwd_colsum(dh, zs[i - 1], dz, self.gb[i - 1], self.partial)
 
 
 class FlatLearner:
@@ -117,6 +125,7 @@ class FlatLearner:
         self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
         self.losses = z(4)
         self.graph_a = self.graph_b = None
+        self._gather = None; self._gather_src = ()
         self.sample_noise = True                    # plain-launch path only: tests inject self.noise instead
         if use_graph:
             self._capture()
@@ -171,10 +180,14 @@ class FlatLearner:
 
     # ---- public ----
     def load_minibatch(self, data: Dict[str, torch.Tensor], idx: torch.Tensor):
-        """Gathers trajectories `idx` of the ([N, T, ...]) rollout tensors into the static buffers."""
-        for k in self.KEYS:
-            torch.index_select(data[k], 0, idx, out=self.static[k])
-        torch.index_select(data["last_priv"], 0, idx, out=self.static["last_priv"])
+        """Gathers trajectories `idx` of the ([N, T, ...]) rollout tensors into the static buffers: one launch for all
+        eight fields (`odk_gather_rows`)."""
+        keys = self.KEYS + ("last_priv",)
+        srcs = tuple(data[k] for k in keys)
+        if self._gather is None or any(a is not b for a, b in zip(self._gather_src, srcs)):
+            self._gather = engine.RowGather([(data[k], self.static[k]) for k in keys])
+            self._gather_src = srcs
+        self._gather(idx)
 
     def step(self):
         """One clipped-Adam step on the loaded minibatch; returns the 4 loss scalars (device tensor, no sync)."""
