@@ -456,23 +456,26 @@ __device__ __forceinline__ void factor_chains(float* A, int lane, int on, int di
     }
     ODK_SYNC();
   }
-  // Schur complement of the chains on the base block: lane e < NBASE (NBASE + 1) / 2 owns entry (a, b), b <= a
+  // Schur complement of the chains on the base block: every chain dof still holds its finished row in registers
+  // (scaled entries of the NBASE base columns, D_k), so entry (a, b) is a group sum of row[a] D row[b] over the chain
+  // lanes -- 21 register reductions, no LDS reads; lane q = a (a + 1) / 2 + b applies entry q.
   {
-    int a = 0, b = lane;
+    const bool chain = on && ch_len > 0;
+    float mine = 0.0f;
+    int q = 0;
 #pragma unroll
-    for (int r = 0; r < NBASE; r++)
-      if (b > a) { b -= a + 1; a++; }
-    const bool mine = lane < (NBASE * (NBASE + 1)) / 2;
-    const int ac = mine ? a : 0, bc = mine ? b : 0;
-    float acc = 0.0f;
-    for (int k = NBASE; k < NVT; k++) {
-      const int adr = ubcast(madr_st, k), Dk = ubcast(depth_st, k);
-      const float la = A[adr + ac], lb = A[adr + bc], dk = A[adr + Dk];
-      acc = fmaf(la * dk, lb, acc);
+    for (int a = 0; a < NBASE; a++) {
+      const float la = chain ? row[a] * diag : 0.0f;
+#pragma unroll
+      for (int b2 = 0; b2 <= a; b2++) {
+        const float sq = gsum<G>(la * row[b2]);
+        mine = lane == q ? sq : mine;
+        q++;
+      }
     }
-    const int ra = ubcast(madr_st, 0);   // rows of the base dofs start at madr(a) = a (a + 1) / 2 + madr(0)
+    const int ra = ubcast(madr_st, 0);   // base rows are stored first: entry q of the packed lower triangle is at ra + q
     ODK_SYNC();
-    if (mine) A[ra + (ac * (ac + 1)) / 2 + bc] -= acc;
+    if (lane < (NBASE * (NBASE + 1)) / 2) A[ra + lane] -= mine;
   }
   ODK_SYNC();
   // base block: reload the updated rows and finish as in factor_rows
