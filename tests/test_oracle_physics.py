@@ -238,3 +238,64 @@ def test_height_field_contacts_follow_the_terrain(oracle_mod):
         d.env_physics_step(ctrl, 10)
     ground = H[nr // 2 - 2: nr // 2 + 2, nc // 2 - 2: nc // 2 + 2].mean() * size[2]
     assert 0.14 + ground - 0.01 < d["qpos"][2] < 0.18 + ground and d["sensordata"][11] > 0.99
+
+
+def test_actuator_force_clamp_and_pd_law(oracle_mod, model_a):
+    """Position actuators (open_duck_mini_v2.xml:45-50): force = kp (ctrl - q) (kv = 0), clamped to forcerange +-3.23;
+    ctrl itself is clamped to the joint range (inheritrange)."""
+    a = model_a.a
+    q = np.array(a["key_qpos"], float); q[2] = 1.0
+    ctrl = np.array(a["key_ctrl"], float)
+    ctrl[3] += 0.1          # left knee: small error -> linear regime
+    ctrl[12] += 5.0         # right knee: far outside its range -> ctrl clamp (ctrlrange = joint range)
+    jr = int(a["actuator_trnid"][10]); lo, hi = a["jnt_range"][jr]
+    q[7 + 10] = lo + 0.01   # right hip roll at its lower stop, target at the upper one -> force clamp
+    ctrl[10] = hi
+    om, d = _data(oracle_mod, model_a, qpos=q, ctrl=ctrl)
+    d.forward()
+    f = np.array(d["actuator_force"][:14])
+    kp = float(a["actuator_gainprm0"][3])
+    assert kp == pytest.approx(13.37)
+    assert f[3] == pytest.approx(kp * 0.1, rel=1e-9)
+    khi = a["jnt_range"][int(a["actuator_trnid"][12])][1]
+    assert f[12] == pytest.approx(kp * (khi - q[7 + 12]), rel=1e-9)      # ctrl clamped to the joint range first
+    assert kp * (hi - lo - 0.01) > 3.23 and f[10] == pytest.approx(3.23, rel=1e-12)   # forcerange
+    others = [u for u in range(14) if u not in (3, 10, 12)]
+    np.testing.assert_allclose(f[others], 0.0, atol=1e-12)              # ctrl == q at the keyframe
+    # generalized force = gear * force on the actuated dof only
+    qa = np.array(d["qfrc_actuator"][: om.nv])
+    assert qa[6 + 3] == pytest.approx(f[3]) and np.abs(qa[:6]).max() == 0.0
+
+
+def test_sliding_friction_opposes_motion_within_the_cone(oracle_mod, model_a):
+    """Standing robot pushed sideways: the tangential contact force opposes the sliding velocity and stays inside the
+    friction pyramid (mu = 0.6: floor priority 1, scene_flat_terrain.xml:35-36)."""
+    om, d = _data(oracle_mod, model_a)
+    for _ in range(300):                      # settle
+        d.env_physics_step(model_a.a["key_ctrl"], 1)
+    d["qvel"][0] = 0.5                        # base slides along +x
+    d.forward()
+    J, f = d.J(), np.array(d["efc_force"][:76])
+    nf, nl = d.i("nf"), d.i("nl")
+    Jc, fc = J[nf + nl:], f[nf + nl:]
+    F = Jc.T @ fc                             # generalized contact force; rows 0..2 = world force on the floating base
+    assert F[2] > 0.5 * MASS * G              # feet still carry the robot
+    assert F[0] < 0                           # friction opposes +x sliding
+    assert abs(F[0]) <= 0.6 * F[2] * 1.0001 and abs(F[1]) <= 0.6 * F[2] * 1.0001
+    assert (fc >= 0).all()
+
+
+def test_frictionloss_holds_a_joint_against_small_torque(oracle_mod, model_a):
+    """dof frictionloss 0.068 (sts3215 class): an actuator torque below it, with the robot in free fall, leaves the
+    joint acceleration ~0 (the friction-loss row cancels it); a torque well above it accelerates the joint."""
+    a = model_a.a
+    q = np.array(a["key_qpos"], float); q[2] = 1.0
+    kp = float(a["actuator_gainprm0"][7])
+    accs = []
+    for torque in (0.03, 1.0):
+        ctrl = np.array(a["key_ctrl"], float); ctrl[7] += torque / kp       # head_yaw: light distal link
+        om, d = _data(oracle_mod, model_a, qpos=q, ctrl=ctrl)
+        d.forward()
+        accs.append(abs(d["qacc"][6 + 7]))
+        assert d["actuator_force"][7] == pytest.approx(torque, rel=1e-9)
+    assert accs[0] < 0.05 * accs[1] and accs[1] > 1.0
