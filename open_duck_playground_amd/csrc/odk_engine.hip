@@ -819,6 +819,11 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   int nhv = B.D("hull_vert", hv, 64 * 3) / 3; int nhf = B.I("hull_face", hf, 128 * 3) / 3;
   B.D("body_invweight0", biw, MAXB * 2);
   B.I("k_foot_body", m.foot_body, 2); B.I2("k_foot_dofmask", &m.foot_dofmask[0][0], 2, MAXV);
+  for (int p = 0; p < m.nM && p < MAXNZ; p++) {
+    const int i = m.M_i[p], j = m.M_j[p];
+    const int fi = m.foot_dofmask[0][i] | (m.foot_dofmask[1][i] << 1), fj = m.foot_dofmask[0][j] | (m.foot_dofmask[1][j] << 1);
+    m.M_ent[p] = i | (j << 5) | (fi << 10) | (fj << 12);
+  }
   if (!B.ok || ncg != 3) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   (void)nhv; (void)nhf;
   for (int f = 0; f < 2; f++) {

@@ -1625,8 +1625,8 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     for (int t = 0; t < ST::NME; t++) {
       const int p = lane + t * G;
       if (p < S::NM) {
-        const int i = m->M_i[p], j = m->M_j[p];
-        const int fi = m->foot_dofmask[0][i] | (m->foot_dofmask[1][i] << 1), fj = m->foot_dofmask[0][j] | (m->foot_dofmask[1][j] << 1);
+        const int e = m->M_ent[p];   // one packed load instead of M_i, M_j and four foot-mask loads chained behind them
+        const int i = e & 31, j = (e >> 5) & 31, fi = (e >> 10) & 3, fj = (e >> 12) & 3;
         float v = M[p];
         if (i == j) v += JV[i];
         const int both = fi & fj;

@@ -45,6 +45,7 @@ struct DevModel {
   float dof_range[MAXV][2];
   float dof_armature[MAXV], dof_damping[MAXV], dof_frictionloss[MAXV], dof_invweight0[MAXV];
   int M_i[MAXNZ], M_j[MAXNZ];
+  int M_ent[MAXNZ];   // packed entry: i | j << 5 | feet moved by dof i << 10 | feet moved by dof j << 12
   int nchain, chain_first[3], chain_len[3];   // tree of chains below the floating base (0 chains: generic tree)
   // virtual tree (Hessian)
   int vdof_depth[MAXV], vdof_anc[MAXV][MAXV], vdof_Madr[MAXV], vdof_anc_adr[MAXV][MAXV];
