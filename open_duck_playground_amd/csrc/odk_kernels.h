@@ -429,7 +429,8 @@ __device__ __forceinline__ void factor_chains(float* A, int lane, int on, int di
   float diag = A[ai + di];
   if (!on) diag = 1.0f;
   const int a_loc = lane - ch_first;
-  for (int s = 0; s < MAXLEN; s++) {
+#pragma unroll
+  for (int s = 0; s < MAXLEN; s++) {            // unrolled: in step s no pivot is deeper than DMAX - s, rows shrink with s
     const int kl = ch_len - 1 - s;              // local index of this chain's pivot in step s
     const int t = kl - a_loc;                   // pivot dof = lane + t
     const bool act = ch_len > 0 && kl >= 0;
@@ -437,7 +438,7 @@ __device__ __forceinline__ void factor_chains(float* A, int lane, int on, int di
       const float inv = __builtin_amdgcn_rcpf(diag);
 #pragma unroll
       for (int c = 0; c < DMAX; c++)
-        if (c < di) { row[c] *= inv; A[ai + c] = row[c]; }
+        if (c < DMAX - s && c < di) { row[c] *= inv; A[ai + c] = row[c]; }
       A[ai + di] = diag;
     }
     ODK_SYNC();
@@ -447,11 +448,13 @@ __device__ __forceinline__ void factor_chains(float* A, int lane, int on, int di
       const int ak = ai + tk * (di + 1) + (tk * (tk - 1)) / 2, Dk = di + tk;   // consecutive dofs: rows are adjacent, one entry longer each
       float rk[DMAX > 0 ? DMAX : 1];
 #pragma unroll
-      for (int c = 0; c < DMAX; c++) rk[c] = A[ak + c];
+      for (int c = 0; c < DMAX; c++)
+        if (c < DMAX - s - 1) rk[c] = A[ak + c];   // an ancestor's own row is at least one entry shorter than the pivot's
       const float Lki = A[ak + di], dk = A[ak + Dk];
       const float tt = anc ? Lki * dk : 0.0f;
 #pragma unroll
-      for (int c = 0; c < DMAX; c++) row[c] = anc ? fmaf(-tt, rk[c], row[c]) : row[c];
+      for (int c = 0; c < DMAX; c++)
+        if (c < DMAX - s - 1) row[c] = anc ? fmaf(-tt, rk[c], row[c]) : row[c];
       diag = anc ? fmaf(-tt, Lki, diag) : diag;
     }
     ODK_SYNC();
