@@ -1415,8 +1415,12 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     if (pos < 0) row_params(m->lim_imp[st.d_limrow], pos, m->lim_invweight[st.d_limrow], lim_sgn * QVEL[lane], D, aref);
     ED[r] = D; AREF[r] = aref;
   }
+  // foot-foot rows (32..47) are skipped wave-wide unless some env has a penetrating foot-foot contact (D = 0 rows
+  // are never read again: the solver gates on D > 0 and on the same wave-uniform flag)
+  const bool ff_rows = __builtin_amdgcn_ballot_w64(fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0.0f) != 0;
   for (int rc = lane; rc < S::NCROW; rc += G) {
     const int r = r0c + rc, c = rc >> 2, s = rc & 3, pair = c >> 2;
+    if (rc >= 32 && !ff_rows) { ED[r] = 0.0f; AREF[r] = 0.0f; continue; }
     const float dist = CDIST[c];
     const float mu = m->pair_mu[pair];
     const float fs = (s & 1) ? -mu : mu;
