@@ -4,7 +4,8 @@ brax runs `num_updates_per_batch * num_minibatches` (= 128) clipped-Adam steps p
 (reference common/runner.py:104-118 -> brax ppo.train); each is ~10 small GEMMs surrounded by ~300
 element-wise ops, so under an autograd engine it is launch-bound.  Here one step is a single HIP graph of
 
-    7 + 7 forward GEMM/activation launches (hipBLASLt on MFMA, bias fused),
+    7 + 7 forward GEMM/activation launches (hipBLASLt on MFMA, bias fused; policy and value networks are two
+    parallel branches of the graph, forward and backward),
     1 GAE launch, 1 loss-head launch (forward + gradients, csrc/odk_learner.hip),
     14 + 14 backward launches writing straight into one flat gradient buffer,
     [one RCCL all-reduce of that buffer when data-parallel], 2 launches for clip + Adam on the flat buffers.
@@ -126,6 +127,7 @@ class FlatLearner:
         self.losses = z(4)
         self.graph_a = self.graph_b = None
         self._gather = None; self._gather_src = ()
+        self.side = torch.cuda.Stream() if os.environ.get("ODK_LEARNER_BRANCHES", "1") == "1" else None   # policy || value
         self.sample_noise = True                    # plain-launch path only: tests inject self.noise instead
         if use_graph:
             self._capture()
@@ -134,8 +136,17 @@ class FlatLearner:
     @torch.no_grad()
     def _loss_and_grads(self):
         B, T, n, s, cfg = self.B, self.T, self.B * self.T, self.static, self.cfg
-        hp, zp = self.policy.forward(s["obs"].view(n, -1))
-        hv, zv = self.value.forward(self.priv_all)
+        # policy and value networks are independent until the loss head: two branches of the captured graph
+        cur = torch.cuda.current_stream()
+        if self.side is not None:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                hv, zv = self.value.forward(self.priv_all)
+            hp, zp = self.policy.forward(s["obs"].view(n, -1))
+            cur.wait_stream(self.side)
+        else:
+            hp, zp = self.policy.forward(s["obs"].view(n, -1))
+            hv, zv = self.value.forward(self.priv_all)
         vals = zv[-1].view(-1)
         baseline, boot = vals[:n], vals[n:]
         engine.gae(s["truncation"], s["termination"], s["reward"], baseline.view(B, T), boot, cfg["gae_lambda"], cfg["discounting"],
@@ -144,8 +155,15 @@ class FlatLearner:
         engine.ppo_head(zp[-1], s["raw_action"].view(n, -1), s["log_prob"].view(n), self.adv.view(n),
                         self.stats if cfg["normalize_advantage"] else None, self.vs.view(n), baseline, self.noise, self.dlogits,
                         self.dval_all[:n].view(n), self.losses, cfg["clipping_epsilon"], cfg["entropy_cost"], 1.0 / self.world)
-        self.policy.backward(self.dlogits, hp, zp)
-        self.value.backward(self.dval_all, hv, zv)
+        if self.side is not None:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.value.backward(self.dval_all, hv, zv)
+            self.policy.backward(self.dlogits, hp, zp)
+            cur.wait_stream(self.side)
+        else:
+            self.policy.backward(self.dlogits, hp, zp)
+            self.value.backward(self.dval_all, hv, zv)
 
     @torch.no_grad()
     def _draw_noise(self):
