@@ -752,6 +752,70 @@ __device__ __forceinline__ void select4(const float* w, bool has, float sup, int
   idx[3] = idx[3] >= nvt ? idx[3] - nvt : idx[3];
 }
 
+// 16-lane row reductions on unsigned keys (the first four butterfly stages of greduce_u: every lane ends with its row's value)
+template <bool MAX> __device__ __forceinline__ unsigned rreduce_u(unsigned v) {
+  auto op = [](unsigned a, unsigned b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  v = op(v, ODK_DPPU(v, 0xB1));
+  v = op(v, ODK_DPPU(v, 0x4E));
+  v = op(v, ODK_DPPU(v, 0x141));
+  v = op(v, ODK_DPPU(v, 0x140));
+  return v;
+}
+// _manifold_points for BOTH feet at once: foot f lives in the 16-lane row f (lane = 16 f + vertex, vertices 0..15) and
+// every lane of the row also carries the hull's 17th vertex (index 16) itself, so all arg-max steps are row-local DPP
+// reductions and the two feet share every instruction.  we / supe: the extra vertex (has_e: the hull has one).
+__device__ __forceinline__ void select4_rows(const float* w, bool has, float sup, const float* we, bool has_e, float supe, int nvt,
+                                             const float* n, int* idx, int lane) {
+  const int j = lane & 15, rowbase = lane & ~15;
+  auto amax = [&](float v, int i, float ve, int ie) -> int {   // lowest index among the maxima of {(v, i) over the row} + (ve, ie)
+    const unsigned k = fkey(v), ke = fkey(ve);
+    const unsigned rm = rreduce_u<true>(k);
+    const unsigned mx = rm > ke ? rm : ke;
+    const unsigned ri = rreduce_u<false>(k == mx ? (unsigned)i : 0x7FFFFFFFu);
+    const unsigned ei = ke == mx ? (unsigned)ie : 0x7FFFFFFFu;
+    return (int)(ri < ei ? ri : ei);
+  };
+  auto fetch = [&](int id, float* o) {   // position of vertex id of this row's hull
+    const int src = rowbase + (id & 15);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const float t = __shfl(w[k], src, 32); o[k] = id == 16 ? we[k] : t; }   // src: relative to the env's 32 lanes
+  };
+  const unsigned ksm = rreduce_u<true>(fkey(sup)), kse = fkey(supe);
+  const float smax = fkey_inv(ksm > kse ? ksm : kse);
+  const float thr = fmaxf(0.0f, smax - 1e-3f);
+  const float dm = has ? ((sup > thr) ? 0.0f : -1e6f) : -3.0e38f;
+  const float dme = has_e ? ((supe > thr) ? 0.0f : -1e6f) : -3.0e38f;
+  idx[0] = amax(dm, j, dme, 16);
+  float a[3];
+  fetch(idx[0], a);
+  const float ap[3] = {a[0] - w[0], a[1] - w[1], a[2] - w[2]}, ape[3] = {a[0] - we[0], a[1] - we[1], a[2] - we[2]};
+  idx[1] = amax(has ? dot3(ap, ap) + dm : -3.0e38f, j, has_e ? dot3(ape, ape) + dme : -3.0e38f, 16);
+  float bq[3];
+  fetch(idx[1], bq);
+  const float amb[3] = {a[0] - bq[0], a[1] - bq[1], a[2] - bq[2]};
+  float ab[3];
+  cross3(ab, n, amb);
+  idx[2] = amax(has ? fabsf(dot3(ap, ab)) + dm : -3.0e38f, j, has_e ? fabsf(dot3(ape, ab)) + dme : -3.0e38f, 16);
+  float cq[3];
+  fetch(idx[2], cq);
+  const float amc[3] = {a[0] - cq[0], a[1] - cq[1], a[2] - cq[2]}, bmc[3] = {bq[0] - cq[0], bq[1] - cq[1], bq[2] - cq[2]};
+  float ac[3], bc[3];
+  cross3(ac, n, amc);
+  cross3(bc, n, bmc);
+  auto last = [&](const float* x, const float* apx, float dmx, bool hx, int ix, float& vv, int& vi) {
+    const float bp[3] = {bq[0] - x[0], bq[1] - x[1], bq[2] - x[2]};
+    const float v1 = fabsf(dot3(bp, bc)) + dmx, v2 = fabsf(dot3(apx, ac)) + dmx;
+    vv = v1; vi = ix;
+    if (v2 > v1) { vv = v2; vi = nvt + ix; }
+    if (!hx) { vv = -3.0e38f; vi = 2 * nvt + ix; }
+  };
+  float vv, vve; int vi, vie;
+  last(w, ap, dm, has, j, vv, vi);
+  last(we, ape, dme, has_e, 16, vve, vie);
+  idx[3] = amax(vv, vi, vve, vie);
+  idx[3] = idx[3] >= nvt ? idx[3] - nvt : idx[3];
+}
+
 // Foot-foot (mesh-mesh) contact manifold: face-normal SAT over both hulls + 4-point manifold, the same restatement as
 // oracle convex_convex.  Called by every lane of the wave; envs whose boxes are separated are masked by `overlap`.
 template <class S, int G>
@@ -1280,17 +1344,23 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   }
   const float pn0[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
   constexpr bool flat = !HF;   // plane floor, or height field (rough terrain; its own kernel instantiation)
-#pragma unroll
-  for (int f = 0; f < 2; f++) {
+  {
+    // both feet at once: foot f = 16-lane row f of the env's lanes (vertices 0..15), the 17th vertex rides along in every lane
+    const int f = (lane >> 4) & 1, j = lane & 15;
     const int nvt = m->foot_nvert[f];
-    const bool has = lane < nvt;
-    float w[3] = {0, 0, 0}, sup = -3.0e38f;
+    const bool inrow = lane < 32;                    // G = 64: rows 2, 3 idle
+    const bool has = inrow && j < nvt, has_e = inrow && nvt > 16;
     float pn[3] = {pn0[0], pn0[1], pn0[2]}, pp[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
+    float Rf[9], Pf[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rf[k] = f ? fR[1][k] : fR[0][k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) Pf[k] = f ? fP[1][k] : fP[0][k];
     if (!flat) {   // terrain under this foot := plane of the height-field triangle below the hull's box centre (oracle hfield_convex)
       float cw[3];
-      for (int k = 0; k < 3; k++) cw[k] = fP[f][k] + fR[f][3 * k] * m->foot_obb_center[f][0] + fR[f][3 * k + 1] * m->foot_obb_center[f][1] + fR[f][3 * k + 2] * m->foot_obb_center[f][2];
+      for (int k = 0; k < 3; k++) cw[k] = Pf[k] + Rf[3 * k] * m->foot_obb_center[f][0] + Rf[3 * k + 1] * m->foot_obb_center[f][1] + Rf[3 * k + 2] * m->foot_obb_center[f][2];
       hfield_plane(m, hfield, cw, pp, pn);
-      if (lane == 0) {   // contact frame of this pair (make_frame), consumed by P8
+      if (inrow && j == 0) {   // contact frame of this pair (make_frame), consumed by P8
         float b[3] = {0, 0, 0}, cc[3];
         if (fabsf(pn[1]) < 0.5f) b[1] = 1.0f; else b[2] = 1.0f;
         const float dtb = dot3(pn, b);
@@ -1301,22 +1371,33 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
         for (int t = 0; t < 3; t++) { SCR[S::S_K + 9 * f + t] = pn[t]; SCR[S::S_K + 9 * f + 3 + t] = b[t]; SCR[S::S_K + 9 * f + 6 + t] = cc[t]; }
       }
     }
-    if (has) {
-      const float vb[3] = {m->foot_vert[f][lane][0], m->foot_vert[f][lane][1], m->foot_vert[f][lane][2]};
-      for (int k = 0; k < 3; k++) w[k] = fP[f][k] + fR[f][3 * k] * vb[0] + fR[f][3 * k + 1] * vb[1] + fR[f][3 * k + 2] * vb[2];
-      sup = (pp[0] - w[0]) * pn[0] + (pp[1] - w[1]) * pn[1] + (pp[2] - w[2]) * pn[2];
+    float w[3] = {0, 0, 0}, we[3] = {0, 0, 0}, sup = -3.0e38f, supe = -3.0e38f;
+    {
+      const int jv = has ? j : 0;
+      const float vb[3] = {m->foot_vert[f][jv][0], m->foot_vert[f][jv][1], m->foot_vert[f][jv][2]};
+      const float ve[3] = {m->foot_vert[f][16][0], m->foot_vert[f][16][1], m->foot_vert[f][16][2]};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        w[k] = Pf[k] + Rf[3 * k] * vb[0] + Rf[3 * k + 1] * vb[1] + Rf[3 * k + 2] * vb[2];
+        we[k] = Pf[k] + Rf[3 * k] * ve[0] + Rf[3 * k + 1] * ve[1] + Rf[3 * k + 2] * ve[2];
+      }
+      const float s0 = (pp[0] - w[0]) * pn[0] + (pp[1] - w[1]) * pn[1] + (pp[2] - w[2]) * pn[2];
+      const float s1 = (pp[0] - we[0]) * pn[0] + (pp[1] - we[1]) * pn[1] + (pp[2] - we[2]) * pn[2];
+      sup = has ? s0 : -3.0e38f; supe = has_e ? s1 : -3.0e38f;
     }
     int idx[4];
-    select4<G>(w, has, sup, nvt, pn, idx, lane);
+    select4_rows(w, has, sup, we, has_e, supe, nvt, pn, idx, lane);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       bool uniq = true;
       for (int q = 0; q < k; q++) uniq = uniq && (idx[q] != idx[k]);
-      if (lane == idx[k]) {
-        const float dist = uniq ? -sup : 1.0f;
+      const bool ext = idx[k] == 16;
+      if (inrow && j == (ext ? 0 : idx[k])) {   // the vertex's own lane writes (lane 0 of the row for the 17th vertex)
+        const float sv = ext ? supe : sup;
+        const float dist = uniq ? -sv : 1.0f;
         const int c = 4 * f + k;
         CDIST[c] = dist;
-        for (int t = 0; t < 3; t++) CR[3 * c + t] = w[t] - 0.5f * dist * pn[t] - ref[t];
+        for (int t = 0; t < 3; t++) CR[3 * c + t] = (ext ? we[t] : w[t]) - 0.5f * dist * pn[t] - ref[t];
       }
     }
   }
