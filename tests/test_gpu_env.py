@@ -117,11 +117,12 @@ def test_free_running_rollout_stays_close(oracle_mod):
     b.close()
 
 
-def test_standing_env_matches_oracle(oracle_mod):
+@pytest.mark.parametrize("task", ["flat_terrain", "rough_terrain_backlash"])
+def test_standing_env_matches_oracle(oracle_mod, task):
     """Standing (reference standing.py): reset + 40 resynchronised steps; obs rows are 85 / 153 floats wide."""
     def edit(cfg):
         cfg.episode_length = 25
-    torch, model, b, envs, keep = _mk(oracle_mod, "flat_terrain", 32, edit, standing=True)
+    torch, model, b, envs, keep = _mk(oracle_mod, task, 32, edit, standing=True)
     n = len(envs)
     assert tuple(b.obs.shape) == (n, 85) and tuple(b.priv.shape) == (n, 153)
     b.reset(seed=11)
