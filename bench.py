@@ -71,9 +71,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_api.py): run the multi-rank path on a one-GPU box -- RCCL refuses two ranks per device,
+    # gloo does not; the driver's runs use neither variable
+    backend = os.environ.get("ODK_BENCH_BACKEND", "nccl")
+    local_rank = int(os.environ.get("ODK_BENCH_DEVICE", local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists for the env engine)")
     torch.cuda.set_device(local_rank)

@@ -125,3 +125,23 @@ def test_nan_state_terminates_and_resets_cleanly():
     b.step(torch.zeros(8, 14, device="cuda"))
     assert float(b.done.sum()) == 0 and torch.isfinite(b.obs).all()
     b.close()
+
+
+def test_bench_multi_rank_launch_path():
+    """bench.py under the driver's launcher with 2 ranks (both on GPU 0 over gloo, because RCCL wants one rank per
+    device): barrier + max-over-ranks timing, rank 0 prints one JSON line with the whole-job throughput."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ODK_BENCH_BACKEND="gloo", ODK_BENCH_DEVICE="0")
+    port = 29600 + os.getpid() % 300
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5", "--envs", "2048"],
+                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 5 and d["scaling"] == "weak" and d["unit"] == "env-steps/s"
+    assert d["config"]["global_envs"] == 4096 and "cpu_baseline" not in d
+    assert abs(d["value"] - 4096 * 40 / (d["ms_per_step"] * 40 / 1e3)) / d["value"] < 1e-3
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
