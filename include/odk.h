@@ -5,6 +5,7 @@
  *     mjx.put_model(mj_model)                                  playground/open_duck_mini_v2/base.py:61
  *     Joystick.reset(rng) -> State                              playground/open_duck_mini_v2/joystick.py:206
  *     Joystick.step(State, action) -> State                     playground/open_duck_mini_v2/joystick.py:323
+ *     Standing.reset / Standing.step (env_kind = ODK_ENV_STANDING) playground/open_duck_mini_v2/standing.py:200,316
  *       (which calls mjx_env.init :258 and mjx_env.step(model, data, motor_targets, n_substeps) :420)
  *     randomize.domain_randomize(model, rng) -> batched fields  playground/common/randomize.py:26-146
  *     wrapper.wrap_for_brax_training (Vmap/Episode/AutoReset)   playground/common/runner.py:117

@@ -4,7 +4,11 @@ brax ppo.train, common/runner.py:104-118; its progress_fn prints `eval/episode_r
 
 One evaluation = reset `num_eval_envs` envs, run the DETERMINISTIC policy (action = tanh(loc)) for
 `episode_length` steps, and sum reward / metrics over each env's FIRST episode only
-(`episode_metrics += metrics * active; active *= 1 - done`)."""
+(`episode_metrics += metrics * active; active *= 1 - done`).
+
+On the GPU one evaluation step (policy inference, the fused env-step launch, the accumulator updates: ~45 small
+launches) is captured once as a HIP graph and replayed `episode_length` times: with 128 envs the step is launch
+bound, not compute bound."""
 from __future__ import annotations
 
 import time
@@ -14,41 +18,75 @@ import torch
 
 
 class Evaluator:
-    def __init__(self, eval_env, episode_length: int, action_repeat: int = 1):
+    def __init__(self, eval_env, episode_length: int, action_repeat: int = 1, use_graph: bool = True):
         self.env, self.episode_length, self.action_repeat = eval_env, int(episode_length), int(action_repeat)
+        self.use_graph = use_graph
         self._steps_per_unroll = self.episode_length * eval_env.num_envs
         self._eval_walltime = 0.0
+        self._acc = None              # persistent accumulators (the captured graph updates them in place)
+        self._graph = None
+        self._graph_key = None
+
+    def _one_step(self, net):
+        st = self._state
+        loc, _ = net.dist_params(st.obs["state"])
+        st = self.env.step(st, torch.tanh(loc).contiguous())
+        a = self._acc
+        a["sums"]["reward"] += st.reward * a["active"]
+        for k, v in st.metrics.items():
+            a["sums"][k] += v * a["active"]
+        a["steps"] += a["active"]
+        a["active"] *= (1.0 - st.done)
+        self._state = st
 
     @torch.no_grad()
     def run_evaluation(self, net, training_metrics: Dict[str, float], seed: int = 0, aggregate_episodes: bool = True) -> Dict[str, float]:
         t0 = time.time()
-        state = self.env.reset(seed)
+        self._state = self.env.reset(seed)
         n = self.env.num_envs
-        dev = state.reward.device
-        active = torch.ones(n, device=dev)
-        sums = {"reward": torch.zeros(n, device=dev), **{k: torch.zeros(n, device=dev) for k in state.metrics}}
-        steps = torch.zeros(n, device=dev)
-        for _ in range(self.episode_length // self.action_repeat):
-            loc, _ = net.dist_params(state.obs["state"])
-            state = self.env.step(state, torch.tanh(loc).contiguous())
-            sums["reward"] += state.reward * active
-            for k, v in state.metrics.items():
-                sums[k] += v * active
-            steps += active
-            active = active * (1.0 - state.done)
+        dev = self._state.reward.device
+        if self._acc is None:
+            z = lambda: torch.zeros(n, device=dev)
+            self._acc = dict(active=z(), steps=z(), sums={"reward": z(), **{k: z() for k in self._state.metrics}})
+        a = self._acc
+        a["active"].fill_(1.0); a["steps"].zero_()
+        for v in a["sums"].values():
+            v.zero_()
+        nsteps = self.episode_length // self.action_repeat
+        if dev.type == "cuda" and self.use_graph:
+            # the env's outputs are persistent buffers and the accumulators are updated in place, so one step replays as
+            # a graph; re-captured when the parameters move (FlatLearner re-homes them in its flat buffer)
+            key = tuple(p.data_ptr() for p in net.policy.parameters())
+            done = 0
+            if self._graph is None or self._graph_key != key:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._one_step(net)                          # warm-up: this IS step 1 of the evaluation
+                torch.cuda.current_stream().wait_stream(side)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._one_step(net)                          # captured, not executed
+                self._graph_key = key
+                done = 1
+            for _ in range(nsteps - done):
+                self._graph.replay()
+        else:
+            for _ in range(nsteps):
+                self._one_step(net)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         dt = time.time() - t0
         self._eval_walltime += dt
         out = {}
-        for name, v in sums.items():
+        for name, v in a["sums"].items():
             if aggregate_episodes:
                 out[f"eval/episode_{name}"] = float(v.mean())
                 out[f"eval/episode_{name}_std"] = float(v.std(unbiased=False))
             else:
                 out[f"eval/episode_{name}"] = v.cpu().numpy()
-        out["eval/avg_episode_length"] = float(steps.mean())
-        out["eval/std_episode_length"] = float(steps.std(unbiased=False))
+        out["eval/avg_episode_length"] = float(a["steps"].mean())
+        out["eval/std_episode_length"] = float(a["steps"].std(unbiased=False))
         out["eval/epoch_eval_time"] = dt
         out["eval/sps"] = self._steps_per_unroll / dt
         out["eval/walltime"] = self._eval_walltime

@@ -145,3 +145,25 @@ def test_bench_multi_rank_launch_path():
     assert d["config"]["global_envs"] == 4096 and "cpu_baseline" not in d
     assert abs(d["value"] - 4096 * 40 / (d["ms_per_step"] * 40 / 1e3)) / d["value"] < 1e-3
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+
+
+def test_evaluator_graph_replay_matches_plain_launches():
+    """The evaluation step captured as a HIP graph (policy + fused env step + first-episode accumulators) reproduces the
+    plain-launch evaluation, also when re-used for a second evaluation and after the parameters move."""
+    import torch
+    from open_duck_playground_amd import joystick
+    from open_duck_playground_amd.ppo.evaluator import Evaluator
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    torch.manual_seed(0)
+    net = PPONetworks(101, 212, 14).cuda()
+    env = joystick.Joystick(task="flat_terrain", num_envs=64)
+    g, p = Evaluator(env, 60, use_graph=True), Evaluator(env, 60, use_graph=False)
+    for rnd in range(3):
+        if rnd == 2:      # parameters re-homed (what FlatLearner does): the graph must be re-captured
+            for prm in net.policy.parameters():
+                prm.data = prm.data.clone().mul_(1.05)
+        a = g.run_evaluation(net, {}, seed=5 + rnd)
+        b = p.run_evaluation(net, {}, seed=5 + rnd)
+        for k in ("eval/episode_reward", "eval/episode_reward_std", "eval/avg_episode_length", "eval/episode_reward/alive", "eval/episode_cost/torques"):
+            assert a[k] == pytest.approx(b[k], rel=1e-5, abs=1e-6), (rnd, k, a[k], b[k])
+    assert a["eval/avg_episode_length"] <= 60 and a["eval/episode_reward"] > 0
