@@ -609,6 +609,7 @@ extern "C" void odk_default_config(odk_env_config* c) {
 extern "C" void odk_default_config_standing(odk_env_config* c) {   // reference standing.py:44-100
   odk_default_config(c);
   c->env_kind = ODK_ENV_STANDING; c->reset_base_qvel = 0.5f;
+  c->max_motor_velocity = 0.0f;   // standing.py has no speed limit (and no such config key)
   c->noise_gyro = 0.05f; c->noise_accelerometer = 0.005f;
   const float rs[7] = {-0.5f, -2.0f, -1.0e-3f, -0.375f, -0.3f, 20.0f, 0.0f};   // orientation, head_pos, torques, action_rate, stand_still, alive
   memcpy(c->reward_scales, rs, sizeof(rs));

@@ -112,3 +112,39 @@ def test_domain_randomize_host_mirror(model_b):
     assert (np.abs(f["body_mass"][:, 1]) <= 0.1).all() and (f["body_mass"][:, 1] < 0).any()   # BUG-COMPAT: massless base gets +-0.1 kg
     np.testing.assert_allclose(f["actuator_biasprm"], -f["actuator_gainprm"])
     assert (np.abs(f["qpos0"]) <= 0.03 + 1e-12).all()
+
+
+def test_standing_config_matches_reference_defaults():
+    """odk_default_config_standing / standing.default_config == reference standing.py:44-100 (+ :42, :377-380, :652-654)."""
+    from open_duck_playground_amd import engine, joystick, standing
+    c = engine.default_config(standing=True)
+    assert c.env_kind == 1 and c.reset_base_qvel == pytest.approx(0.5)
+    assert (c.noise_gyro, c.noise_accelerometer) == pytest.approx((0.05, 0.005))
+    assert list(c.reward_scales) == pytest.approx([-0.5, -2.0, -1e-3, -0.375, -0.3, 20.0, 0.0])   # orientation, head_pos, torques, action_rate, stand_still, alive
+    assert c.use_imitation == 0 and c.use_motor_speed_limits == 0
+    assert [list(r) for r in c.cmd_range][:3] == [[0.0, 0.0]] * 3 and list(c.cmd_range[5]) == pytest.approx([-2.7, 2.7])
+    assert engine.obs_sizes(1) == (85, 153) and engine.obs_sizes(0) == (101, 212)
+    cfg = standing.default_config()
+    assert set(cfg.reward_config.scales) == {"orientation", "torques", "action_rate", "stand_still", "alive", "head_pos"}
+    assert "max_motor_velocity" not in cfg and "lin_vel_x" not in cfg and cfg.head_yaw_range == [-2.7, 2.7]
+    e = joystick.to_engine_config(cfg, standing=True, reward_slots=standing.REWARD_SLOTS, use_imitation=False, use_motor_speed_limits=False)
+    for name, _t in engine.EnvConfig._fields_:
+        a, b = getattr(e, name), getattr(c, name)
+        flat = lambda v: [y for x in v for y in (x if hasattr(x, "__len__") else [x])] if hasattr(v, "__len__") else [v]
+        assert flat(a) == pytest.approx(flat(b)), name   # the Python config and the C default agree field by field
+
+
+@pytest.mark.parametrize("task,xml", [("flat_terrain", "scene_flat_terrain.xml"), ("flat_terrain_backlash", "scene_flat_terrain_backlash.xml")])
+def test_shipped_assets_are_what_the_compiler_makes_from_the_reference_xml(task, xml):
+    """The shipped assets/<task>.npz are data compiled from the reference's MJCF (tools/compile_models.py); where the
+    reference is mounted (build container only) the compiler must reproduce them."""
+    path = os.path.join("/root/reference/playground/open_duck_mini_v2/xmls", xml)
+    if not os.path.exists(path):
+        pytest.skip("reference not mounted (GPU box)")
+    from open_duck_playground_amd import mjcf
+    from open_duck_playground_amd.model import load_task_model
+    fresh = mjcf.compile_mjcf(path, sim_dt=0.002)
+    shipped = load_task_model(task).a
+    for k in ("nq", "nv", "body_mass", "body_pos", "body_quat", "body_ipos", "jnt_axis", "jnt_range", "dof_armature", "dof_damping", "dof_frictionloss",
+              "dof_invweight0", "body_invweight0", "hull_vert", "hull_face", "key_qpos", "actuator_gainprm0", "actuator_biasprm", "sensor_adr", "site_pos"):
+        np.testing.assert_allclose(np.asarray(fresh[k], dtype=np.float64), np.asarray(shipped[k], dtype=np.float64), rtol=1e-12, atol=1e-14, err_msg=k)
