@@ -16,13 +16,12 @@ The autograd path in `train.py` (`ppo_loss`) is the reference implementation the
 """
 from __future__ import annotations
 
+import os
+import tempfile
 from typing import Dict
 
 import torch
 import torch.nn.functional as F
-
-import os
-import tempfile
 
 from .. import engine
 from .networks import PPONetworks
