@@ -234,6 +234,13 @@ int odko_model_int(const odko_model* m, const char* name) {
   return -1;
 }
 
+/* solver options only (tests drive the Newton solver to convergence to check its fixed point) */
+int odko_model_set_int(odko_model* m, const char* name, int value) {
+  if (!strcmp(name, "iterations")) { m->iterations = value; return 0; }
+  if (!strcmp(name, "ls_iterations")) { m->ls_iterations = value; return 0; }
+  return -1;
+}
+
 odko_data* odko_data_new(void) { return (odko_data*)calloc(1, sizeof(odko_data)); }
 void odko_data_free(odko_data* d) { free(d); }
 

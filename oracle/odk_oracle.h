@@ -129,6 +129,7 @@ odko_model* odko_model_copy(const odko_model* m);
 /* named access for tests / domain randomisation: returns pointer + element count, NULL if unknown */
 real* odko_model_field(odko_model* m, const char* name, int* count);
 int odko_model_int(const odko_model* m, const char* name);
+int odko_model_set_int(odko_model* m, const char* name, int value); /* "iterations" / "ls_iterations" */
 
 /* physics */
 odko_data* odko_data_new(void);

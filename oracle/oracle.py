@@ -37,6 +37,7 @@ class _Lib:
         L.odko_model_copy.restype = P; L.odko_model_copy.argtypes = [P]
         L.odko_model_field.restype = RP; L.odko_model_field.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
         L.odko_model_int.restype = C.c_int; L.odko_model_int.argtypes = [P, C.c_char_p]
+        L.odko_model_set_int.restype = C.c_int; L.odko_model_set_int.argtypes = [P, C.c_char_p, C.c_int]
         L.odko_data_new.restype = P
         L.odko_data_free.argtypes = [P]
         for fn in ("odko_make_data", "odko_forward", "odko_step"):
@@ -120,6 +121,11 @@ class OracleModel:
         self.f = _Fields(self.L, self.h, self.L.lib.odko_model_field)
         for k in ("nq", "nv", "nu", "nbody", "njnt", "nsite", "nsensordata", "ncgeom", "npair"):
             setattr(self, k, self.L.lib.odko_model_int(self.h, k.encode()))
+
+    def set_int(self, name: str, value: int):
+        if self.L.lib.odko_model_set_int(self.h, name.encode(), int(value)) != 0:
+            raise KeyError(name)
+        setattr(self, name, int(value))
 
     def copy(self) -> "OracleModel":
         return OracleModel(b"", self.L.f32, _handle=self.L.lib.odko_model_copy(self.h))

@@ -299,3 +299,35 @@ def test_frictionloss_holds_a_joint_against_small_torque(oracle_mod, model_a):
         accs.append(abs(d["qacc"][6 + 7]))
         assert d["actuator_force"][7] == pytest.approx(torque, rel=1e-9)
     assert accs[0] < 0.05 * accs[1] and accs[1] > 1.0
+
+
+def test_newton_solver_converges_to_the_stationary_point(oracle_mod, model_a):
+    """MuJoCo's soft-constraint dynamics are the minimiser of a convex cost; at the minimum
+    M qacc = qfrc_smooth + J^T f(qacc).  The model runs ONE Newton iteration per step (iterations=1); driving the same
+    solver code to convergence must reach that fixed point, and the one-iteration answer must lie between the
+    warm start and it.  Pins gradient / Hessian / line search against each other, independently of MJX."""
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for trial in range(6):
+        q = np.array(model_a.a["key_qpos"], float)
+        q[2] = 0.148 + 0.004 * trial                      # feet a few mm into the floor: contacts active
+        q[7:] += rng.uniform(-0.15, 0.15, 14)
+        q[10] = 1.62 if trial % 2 else q[10]              # a knee beyond its limit on odd trials
+        qv = rng.normal(0, 0.5, 20)
+        om, d = _data(oracle_mod, model_a, qpos=q, qvel=qv)
+        d.forward()
+        cost_1 = d["solver_cost1"][0]
+        qacc_1 = np.array(d["qacc"][:20])
+        om.set_int("iterations", 60); om.set_int("ls_iterations", 60)
+        d2 = oracle_mod.OracleData(om)
+        d2["qpos"][:21] = q; d2["qvel"][:20] = qv; d2["ctrl"][:14] = model_a.a["key_ctrl"]
+        d2.forward()
+        qacc = np.array(d2["qacc"][:20])
+        M = d2.M()
+        resid = M @ qacc - np.array(d2["qfrc_smooth"][:20]) - np.array(d2["qfrc_constraint"][:20])
+        scale = np.abs(M @ qacc).max() + np.abs(np.array(d2["qfrc_smooth"][:20])).max()
+        worst = max(worst, np.abs(resid).max() / scale)
+        assert d2["solver_cost1"][0] <= cost_1 + 1e-9 * abs(cost_1)          # more iterations never cost more
+        assert d2.i("nefc") == 76 and (np.array(d2["efc_force"][28:76]) >= 0).all()
+        assert np.linalg.norm(qacc_1 - qacc) < np.linalg.norm(np.array(d["qacc_smooth"][:20]) - qacc) + 1e-9   # one step moves towards it
+    assert worst < 1e-6, worst
