@@ -331,3 +331,39 @@ def test_newton_solver_converges_to_the_stationary_point(oracle_mod, model_a):
         assert d2.i("nefc") == 76 and (np.array(d2["efc_force"][28:76]) >= 0).all()
         assert np.linalg.norm(qacc_1 - qacc) < np.linalg.norm(np.array(d["qacc_smooth"][:20]) - qacc) + 1e-9   # one step moves towards it
     assert worst < 1e-6, worst
+
+
+def test_yaw_equivariance(oracle_mod, model_a):
+    """Rotating the whole state about the vertical axis rotates the base's linear acceleration and leaves everything
+    else unchanged (free-joint angular velocity is body-frame).  Airborne: any angle.  On the floor: 90 degrees, under
+    which the friction pyramid's axes map onto themselves."""
+    rng = np.random.default_rng(8)
+
+    def run(q, v):
+        om, d = _data(oracle_mod, model_a, qpos=q, qvel=v)
+        d.forward()
+        return np.array(d["qacc"][:20]), np.array(d["sensordata"][:46])
+
+    for z, ang in ((0.6, 0.7), (0.6, 2.1), (0.15, np.pi / 2), (0.146, -np.pi / 2)):
+        q = np.array(model_a.a["key_qpos"], float)
+        q[0:2] = rng.uniform(-0.3, 0.3, 2); q[2] = z
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); tilt = 0.2
+        q[3:7] = np.concatenate([[np.cos(tilt / 2)], np.sin(tilt / 2) * ax])
+        q[7:] += rng.uniform(-0.2, 0.2, 14)
+        v = np.concatenate([rng.normal(0, 0.3, 3), rng.normal(0, 0.5, 3), rng.normal(0, 1.0, 14)])
+        c, s = np.cos(ang), np.sin(ang)
+        Rz = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+        qz = np.array([np.cos(ang / 2), 0, 0, np.sin(ang / 2)])
+        w1, x1, y1, z1 = qz; w2, x2, y2, z2 = q[3:7]
+        q2 = q.copy(); v2 = v.copy()
+        q2[0:3] = Rz @ q[0:3]
+        q2[3:7] = [w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                   w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2]
+        v2[0:3] = Rz @ v[0:3]
+        a1, s1 = run(q, v)
+        a2, s2 = run(q2, v2)
+        scale = np.abs(a1).max()
+        np.testing.assert_allclose(a2[0:3], Rz @ a1[0:3], atol=1e-8 * scale + 1e-9)
+        np.testing.assert_allclose(a2[3:], a1[3:], atol=1e-8 * scale + 1e-9)
+        np.testing.assert_allclose(s2[0:9], s1[0:9], atol=1e-8 * np.abs(s1).max())     # gyro, local linvel, accelerometer are body-frame
+        np.testing.assert_allclose(s2[9:12], Rz @ s1[9:12], atol=1e-9)                  # upvector = site z axis in the WORLD frame
