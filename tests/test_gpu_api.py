@@ -192,3 +192,37 @@ def test_lanes64_geometry_matches_default():
     torch.testing.assert_close(a[1], c[1], rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(a[2], c[2], rtol=2e-3, atol=1e-3)
     assert np.abs(a[4] - c[4]).max() < 2e-4
+
+
+def test_full_size_rollout_properties():
+    """BASELINE size (8192 envs, flat_terrain, noise and pushes on): size-independent properties of a 60-step
+    random-action rollout -- everything finite, rewards inside the clip range, alive reward constant, terminations
+    happen but stay a minority, truncation only ever together with done, and a second batch with the same seed
+    reproduces the run bit for bit."""
+    import torch
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    model = load_task_model("flat_terrain")
+    n = 8192
+    runs = []
+    for rep in range(2):
+        cfg = engine.default_config(); cfg.episode_length = 40
+        b = engine.Batch(model, n, cfg)
+        b.reset(seed=21)
+        g = torch.Generator(device="cuda").manual_seed(5)
+        dones = torch.zeros(n, device="cuda"); truncs = torch.zeros(n, device="cuda")
+        for t in range(60):
+            b.step(torch.empty(n, 14, device="cuda").uniform_(-1, 1, generator=g))
+            assert torch.isfinite(b.obs).all() and torch.isfinite(b.priv).all() and torch.isfinite(b.metrics).all()
+            assert float(b.reward.min()) >= 0.0 and float(b.reward.max()) <= 1.0e4
+            assert bool(((b.truncation == 0) | (b.done == 1)).all())
+            dones += b.done; truncs += b.truncation
+        assert float(b.metrics[:, 5].min()) == 20.0 and float(b.metrics[:, 5].max()) == 20.0     # reward/alive
+        frac = float((dones > 0).float().mean())
+        assert 0.2 < frac <= 1.0                       # episode_length 40 < 60 steps: every surviving env is truncated once
+        assert float(truncs.sum()) > 0.5 * n
+        q, v, w = b.get_state()
+        assert np.isfinite(q).all() and np.isfinite(v).all() and np.abs(q[:, 2]).max() < 2.0
+        runs.append((b.obs.clone(), b.reward.clone(), q))
+        b.close()
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
