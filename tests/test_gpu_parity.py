@@ -209,3 +209,48 @@ def test_foot_foot_contacts(torch_cuda, oracle_mod, task):
     assert worst["qpos"] < RTOL_Q
     assert worst["qvel"] < 2e-3
     b.close()
+
+
+def test_yaw_equivariance_full_size(torch_cuda):
+    """8192 envs, size-independent property of the HIP path itself (no oracle): rotating every state by 90 degrees about
+    the vertical axis (under which the friction pyramid maps onto itself) rotates base position / linear velocity after
+    an env step of 10 substeps and leaves the joint state unchanged, to fp32 accuracy."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    torch = torch_cuda
+    model = load_task_model("flat_terrain")
+    n = 8192
+    rng = np.random.default_rng(3)
+    qpos, qvel = _random_states(model, 256, rng, airborne_frac=0.2)
+    reps = n // 256
+    qpos = np.tile(qpos, (reps, 1)); qvel = np.tile(qvel, (reps, 1)) * 0.3
+    qpos[:, 0:2] += rng.uniform(-0.2, 0.2, (n, 2))
+    ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.2, 0.2, (n, 14))
+    Rz = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    qz = np.array([np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    q2 = qpos.copy(); v2 = qvel.copy()
+    q2[:, 0:3] = qpos[:, 0:3] @ Rz.T
+    w1, x1, y1, z1 = qz
+    w2, x2, y2, z2 = qpos[:, 3], qpos[:, 4], qpos[:, 5], qpos[:, 6]
+    q2[:, 3] = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2; q2[:, 4] = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2
+    q2[:, 5] = w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2; q2[:, 6] = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2
+    v2[:, 0:3] = qvel[:, 0:3] @ Rz.T
+    outs = []
+    for q, v in ((qpos, qvel), (q2, v2)):
+        b = engine.Batch(model, n)
+        b.set_state(q, v, np.zeros((n, model.nv)))
+        b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 10)
+        outs.append(b.get_state())
+        b.close()
+    (qa, va, _), (qb, vb, _) = outs
+    ok = np.isfinite(qa).all(axis=1) & np.isfinite(qb).all(axis=1)
+    assert ok.mean() > 0.999
+    qa, va, qb, vb = qa[ok], va[ok], qb[ok], vb[ok]
+    err_p = np.abs(qb[:, 0:3] - qa[:, 0:3] @ Rz.T).max(axis=1)
+    err_j = np.abs(qb[:, 7:] - qa[:, 7:]).max(axis=1)
+    err_v = np.abs(vb[:, 0:3] - va[:, 0:3] @ Rz.T).max(axis=1)
+    err_w = np.abs(vb[:, 3:] - va[:, 3:]).max(axis=1)
+    # contact-manifold ties can flip between the two orientations in a handful of envs: judge the bulk
+    assert np.quantile(err_p, 0.99) < 2e-5 and np.quantile(err_j, 0.99) < 2e-4, (np.quantile(err_p, 0.99), np.quantile(err_j, 0.99))
+    assert np.quantile(err_v, 0.99) < 2e-3 and np.quantile(err_w, 0.99) < 2e-2, (np.quantile(err_v, 0.99), np.quantile(err_w, 0.99))
+    assert np.median(err_j) < 2e-6 and np.median(err_p) < 1e-6
