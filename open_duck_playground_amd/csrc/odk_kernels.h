@@ -7,18 +7,23 @@
 // restated in oracle/odk_oracle.c; the reference reaches it through mjx_env.step at
 // playground/open_duck_mini_v2/joystick.py:420.
 //
-// What makes it fast (all exact in real arithmetic):
-//  * NO table loads inside the substep loop: everything a lane needs about "its" body / dof / row /
-//    matrix entries is read once per launch into registers (struct Statics); per-step uniform scalars
-//    are pulled out of those registers with v_readlane;
-//  * kinematics, velocities and bias accelerations in ONE top-down level sweep of the body tree,
-//    composite inertias and bias forces in one bottom-up sweep;
+// What makes it fast (all exact in real arithmetic; DESIGN.md 4.1 has the measurements):
+//  * occupancy by construction: 256 VGPRs => 2 waves/SIMD = 8 workgroups/CU, and the LDS image is sized so that 8
+//    workgroups fit (shape A: 2 412 floats/env) => 8192 envs are exactly two rounds;
+//  * per-lane statics (a lane's dof depth, row address, ancestor / descendant masks...) are read once per launch into
+//    registers (struct Statics); phase-local constants are re-fetched from the L2-resident model where they are used;
+//    the model pointer is made opaque once per substep so that table addresses are not hoisted into scratch;
+//  * the body recursions (pose, cvel, cacc top-down; composite inertia, bias force bottom-up) are cross-lane prefix /
+//    suffix scans over the serial chains of the tree (3 ds_bpermute steps each), not one LDS round trip per level;
 //  * spatial quantities are expressed about the floating-base origin instead of the subtree COM;
 //  * contact Jacobian rows are never formed: J_r = w_r . cdof[d] for dofs d above the foot, with the
 //    6-vector w_r = [r x dir; dir], so J x, J^T f and J^T D J collapse to 6-vector / 6x6 algebra;
-//  * inertia and Newton Hessian share a tree-sparse row layout (row i = its ancestors by depth) and a
-//    fill-free L^T D L whose rows live in registers; triangular solves and M*v run on dense per-lane
-//    rows in registers with v_readlane broadcasts (no LDS round trips in the dependent chain).
+//  * both feet's plane-convex manifolds run in one pass, one 16-lane DPP row per foot;
+//  * inertia and Newton Hessian share a tree-sparse row layout (row i = its ancestors by depth) and a fill-free
+//    L^T D L: shape A eliminates each serial dof chain in ONE lane's registers (chain_solve), shape B eliminates the
+//    three chains' pivots together (factor_chains);
+//  * group reductions are fused v_add_f32_dpp / v_max_u32_dpp butterflies + gfx950 v_permlane16/32_swap; whole-vector
+//    broadcasts are LDS broadcast reads (the VALU is the busy unit, the LDS pipe is not).
 #pragma once
 #include <hip/hip_runtime.h>
 
