@@ -364,6 +364,14 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   const float gate = (((push_step + 1) % push_int) == 0 ? 1.0f : 0.0f) * c.push_enable;
   const float push[2] = {cosf(theta) * gate, sinf(theta) * gate};
   if (lane < 2) L[S::O_QVEL + lane] += push[lane] * mag;
+  // values only the epilogue needs go back to LDS now instead of riding through the substep loop in scratch:
+  // info["push"], the imitation counter, its phase (two spare floats behind the action), the episode step counter
+  if (lane == 0) {
+    INFO[rec::PUSH] = push[0]; INFO[rec::PUSH + 1] = push[1];
+    INFO[rec::IMI] = i2f(imi);
+    ACT[NU] = phase[0]; ACT[NU + 1] = phase[1];
+    INFO[rec::EPSTEPS] = ep_steps;
+  }
   // ---- motor targets with speed limit (:404-417)
   for (int u = lane; u < NU; u += G) {
     float mt = m->key_ctrl[u] + INFO[rec::AHIST + aidx * NU + u] * c.action_scale;
@@ -398,8 +406,12 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   const DevModel* mp = reinterpret_cast<const DevModel*>(reinterpret_cast<const char*>(m) + opaque1);
   // ... and for the RNG key / counter: everything derived from them (threefry key schedules of the observation-noise
   // draws) is recomputed here instead of riding through the loop in scratch
-  uint32_t k0e = k0, k1e = k1, ctre = ctr;
-  asm volatile("" : "+v"(k0e), "+v"(k1e), "+v"(ctre));
+  const uint32_t k0e = (uint32_t)f2i(INFO[rec::KEY0]), k1e = (uint32_t)f2i(INFO[rec::KEY1]), ctre = (uint32_t)f2i(INFO[rec::CTR]);
+  const int imi_e = f2i(INFO[rec::IMI]);
+  const float phase_e[2] = {ACT[NU], ACT[NU + 1]};
+  int step_e = f2i(INFO[rec::STEP]), push_step_e = f2i(INFO[rec::PSTEP]);
+  float ep_steps_e = INFO[rec::EPSTEPS];
+  const float prev_done_e = INFO[rec::DONE];
   for (int u = lane; u < NU; u += G) INFO[rec::MT + u] = CTRL[u];  // info["motor_targets"] (:422)
   // ---- contacts, air time, swing peak (:424-435)
   float contact[2];
@@ -477,15 +489,15 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   for (int k = 0; k < 7; k++) { rew[k] *= c.reward_scales[k]; total += rew[k]; }
   const float reward = fminf(fmaxf(total * dt, 0.0f), 10000.0f);
   // ---- obs (uses the pre-shift last_act and the post-increment air time; :437)
-  build_obs<S, G>(L, mp, c, contact, k0e, k1e, ctre, imi, phase, lane);
+  build_obs<S, G>(L, mp, c, contact, k0e, k1e, ctre, imi_e, phase_e, lane);
   // ---- info updates (:449-469)
-  step += 1; push_step += 1;
+  step_e += 1; push_step_e += 1;
   float la = 0, lla = 0;
   for (int u = lane; u < NU; u += G) { la = INFO[rec::LAST + u]; lla = INFO[rec::LAST2 + u]; }
   ODK_SYNC();
   for (int u = lane; u < NU; u += G) { INFO[rec::LAST3 + u] = lla; INFO[rec::LAST2 + u] = la; INFO[rec::LAST + u] = ACT[u]; }
-  if (step > 500 && lane < 7) sample_command(c, k0e, k1e, ctre, 41, lane, INFO[rec::CMD + lane]);
-  if (done_env || step > 500) step = 0;
+  if (step_e > 500 && lane < 7) sample_command(c, k0e, k1e, ctre, 41, lane, INFO[rec::CMD + lane]);
+  if (done_env || step_e > 500) step_e = 0;
   int lcon_new = 0;
   for (int f = 0; f < 2; f++) {
     if (contact[f] != 0.0f) { air[f] = 0; peak[f] = 0; lcon_new |= (1 << f); }
@@ -495,19 +507,18 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   for (int k = 0; k < 7; k++) metrics[k] = c.reward_scales[k] > 0 ? rew[k] : -rew[k];
   metrics[7] = 0.5f * (peak[0] + peak[1]);
   // ---- EpisodeWrapper.step
-  ep_steps += 1.0f;
+  ep_steps_e += 1.0f;
   float done_f = done_env ? 1.0f : 0.0f, trunc = 0.0f;
-  if (ep_steps >= (float)c.episode_length) { trunc = 1.0f - done_f; done_f = 1.0f; }
-  const float keep = 1.0f - prev_done;  // info['episode_done'] of the previous step
+  if (ep_steps_e >= (float)c.episode_length) { trunc = 1.0f - done_f; done_f = 1.0f; }
+  const float keep = 1.0f - prev_done_e;  // info['episode_done'] of the previous step
   ODK_SYNC();
   if (lane == 0) {
     INFO[rec::AIR] = air[0]; INFO[rec::AIR + 1] = air[1]; INFO[rec::PEAK] = peak[0]; INFO[rec::PEAK + 1] = peak[1];
-    INFO[rec::PUSH] = push[0]; INFO[rec::PUSH + 1] = push[1];
-    INFO[rec::EPSTEPS] = ep_steps; INFO[rec::TRUNC] = trunc; INFO[rec::DONE] = done_f;
+    INFO[rec::EPSTEPS] = ep_steps_e; INFO[rec::TRUNC] = trunc; INFO[rec::DONE] = done_f;
     INFO[rec::EPSUM] = (INFO[rec::EPSUM] + reward) * keep; INFO[rec::EPLEN] = (INFO[rec::EPLEN] + 1.0f) * keep;
     for (int k = 0; k < ODK_NMETRIC; k++) INFO[rec::EPMET + k] = (INFO[rec::EPMET + k] + metrics[k]) * keep;
-    INFO[rec::CTR] = i2f((int)(ctre + 1)); INFO[rec::STEP] = i2f(step); INFO[rec::PSTEP] = i2f(push_step);
-    INFO[rec::IMI] = i2f(imi); INFO[rec::LCON] = i2f(lcon_new);
+    INFO[rec::CTR] = i2f((int)(ctre + 1)); INFO[rec::STEP] = i2f(step_e); INFO[rec::PSTEP] = i2f(push_step_e);
+    INFO[rec::LCON] = i2f(lcon_new);
   }
   ODK_SYNC();
   // ---- AutoReset.step epilogue: data, obs <- first_* where done (info is NOT reset)

