@@ -395,9 +395,14 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     // per-lane row addresses derived from the statics are one add away: keep the statics, not the derived values, alive
     // across the loop (the derived ones were hoisted and spilled: +4 % when recomputed)
     asm volatile("" : "+v"(st.d_Madr), "+v"(st.d_vMadr), "+v"(st.d_depth), "+v"(st.d_vdepth), "+v"(st.d_body), "+v"(st.d_qadr), "+v"(st.j_qadr), "+v"(st.j_dadr));
-    forward_env<S, G, HF>(L, ms, a.hfield, st, lane, last ? 1 : 0);
+    // ... and so is the lane id: every lane-derived LDS address and predicate is a handful of VALU ops to rebuild, while
+    // hoisted above the loop they sat in scratch (the range assumption keeps the 24-bit multiply / known-bits folds)
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+    __builtin_assume(lane_s >= 0 && lane_s < 64);
+    forward_env<S, G, HF>(L, ms, a.hfield, st, lane_s, last ? 1 : 0);
     if (last && a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
-    euler_env<S, G>(L, ms, st, lane);
+    euler_env<S, G>(L, ms, st, lane_s);
   }
   // same trick for the epilogue: its table addresses would otherwise be shared (CSE) with the prologue's and carried
   // across the substep loop in scratch

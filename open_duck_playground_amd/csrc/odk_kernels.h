@@ -1577,10 +1577,12 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     return 0.0f;
   };
   auto fl_cost = [&](float jar, float& force) -> float {
-    if (jar <= -fl_rf) { force = fl_f; return -0.5f * fl_rf * fl_f - fl_f * jar; }
-    if (jar >= fl_rf) { force = -fl_f; return -0.5f * fl_rf * fl_f + fl_f * jar; }
-    force = -fs.D * jar;
-    return 0.5f * fs.D * jar * jar;
+    // select form of the three-zone cost (linear outside +-R*f): as branches the two candidates were packed into
+    // v_pk_mul pairs whose constant halves were hoisted above the substep loop and parked in scratch
+    const float aj = fabsf(jar);
+    const bool lin = aj >= fl_rf;
+    force = lin ? (jar > 0 ? -fl_f : fl_f) : -fs.D * jar;
+    return lin ? fl_f * (aj - 0.5f * fl_rf) : 0.5f * fs.D * jar * jar;
   };
   // Jaref and cost of both candidates; rows owned by this lane: friction row `lane`, limit row of dof `lane`, contact rows
   float cost_s = 0, cost_w = 0, jar_fl_s = 0, jar_fl_w = 0, jar_lim_s = 0, jar_lim_w = 0, fo;
