@@ -392,9 +392,6 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     size_t opaque0 = 0;
     asm volatile("" : "+s"(opaque0));   // an offset, not the pointer itself: the address space (global) stays known
     const DevModel* ms = reinterpret_cast<const DevModel*>(reinterpret_cast<const char*>(m) + opaque0);
-    // per-lane row addresses derived from the statics are one add away: keep the statics, not the derived values, alive
-    // across the loop (the derived ones were hoisted and spilled: +4 % when recomputed)
-    asm volatile("" : "+v"(st.d_Madr), "+v"(st.d_vMadr), "+v"(st.d_depth), "+v"(st.d_vdepth), "+v"(st.d_body), "+v"(st.d_qadr), "+v"(st.j_qadr), "+v"(st.j_dadr));
     // ... and so is the lane id: every lane-derived LDS address and predicate is a handful of VALU ops to rebuild, while
     // hoisted above the loop they sat in scratch (the range assumption keeps the 24-bit multiply / known-bits folds)
     int lane_s = lane;
