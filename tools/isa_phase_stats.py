@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 shape = sys.argv[1] if len(sys.argv) > 1 else "A"
 key = "ILi21E" if shape == "A" else "ILi31E"
 out = os.path.join(tempfile.gettempdir(), "odk_mark.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-DODK_MARK", *sys.argv[2:], "-S", "--cuda-device-only", "-o", out,
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-load-store-vectorizer=0", "-DODK_MARK", *sys.argv[2:], "-S", "--cuda-device-only", "-o", out,
                        os.path.join(ROOT, "open_duck_playground_amd/csrc/odk_engine.hip")], stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_Z11step_kernel") and key in l and "Li32ELb0E" in l)
