@@ -62,6 +62,7 @@ class _FlatMLP:
     def __init__(self, mlp, flat_p, flat_g, off: int):
         self.W, self.b, self.gW, self.gb = [], [], [], []
         self.partial = None   # scratch of the fused SiLU-backward + column-sum kernel
+        self.dzs = self.dhs = None
         for lin in mlp.layers:
             for name in ("weight", "bias"):
                 p = getattr(lin, name)
@@ -84,16 +85,21 @@ class _FlatMLP:
 
     def backward(self, dz, hs, zs):
         """Gradients straight into the flat buffer.  Below the top layer, dz and its column sums (the bias gradient)
-        come out of one fused pass (csrc silu_bwd_colsum) instead of silu_backward + a separate reduction."""
+        come out of one fused pass (csrc silu_bwd_colsum) instead of silu_backward + a separate reduction.
+        (Measured and dropped: the weight-gradient GEMMs as a further parallel branch beside the dz -> dh chain made the
+        step 10 % slower -- the small GEMMs already share the CUs with the other network's branch -- and a branch forked
+        from a branch crashes hipStreamEndCapture on ROCm 7.2.)"""
         top = len(self.W) - 1
+        if self.dzs is None:   # persistent dh / dz buffers per hidden layer (shapes are fixed for the learner's lifetime)
+            self.dzs = [torch.empty(dz.shape[0], w.shape[0], device=dz.device) for w in self.W[:-1]]
+            self.dhs = [torch.empty_like(t) for t in self.dzs]
+            self.partial = torch.empty(((dz.shape[0] + 63) // 64) * max(w.shape[0] for w in self.W), device=dz.device)
         torch.sum(dz, 0, out=self.gb[top])
         for i in range(top, -1, -1):
             torch.mm(dz.t(), hs[i], out=self.gW[i])
             if i > 0:
-                dh = torch.mm(dz, self.W[i])
-                dz = torch.empty_like(dh)
-                if self.partial is None or self.partial.numel() < ((dh.shape[0] + 63) // 64) * max(w.shape[0] for w in self.W):
-                    self.partial = torch.empty(((dh.shape[0] + 63) // 64) * max(w.shape[0] for w in self.W), device=dh.device)
+                dh = torch.mm(dz, self.W[i], out=self.dhs[i - 1])
+                dz = self.dzs[i - 1]
                 engine.silu_bwd_colsum(dh, zs[i - 1], dz, self.gb[i - 1], self.partial)
 
 
