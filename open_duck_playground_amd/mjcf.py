@@ -412,8 +412,17 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
             key[k.attrib.get("name", "")] = dict(
                 qpos=_floats(k.attrib.get("qpos"), nq, qpos0), ctrl=_floats(k.attrib.get("ctrl"), nu, [0] * nu))
 
+    # ---- sections that would change the physics but have no counterpart in the kernels: refuse, never ignore
+    for tag in ("equality", "tendon", "contact"):
+        if any(len(e) for e in root.findall(tag)):
+            raise NotImplementedError(f"<{tag}> is not supported by this engine (Open Duck scenes have none)")
+
     # ---- collision geoms (everything with contype|conaffinity != 0)
     col = [g for g in geoms if (g["contype"] or g["conaffinity"])]
+    for g in col:
+        if g["type"] not in ("plane", "hfield", "mesh"):
+            raise NotImplementedError(f"colliding geom '{g['name']}' of type {g['type']}: only plane / hfield floors and convex meshes "
+                                      "collide in this engine (give visual primitives contype=conaffinity=0)")
     col_ids = [i for i, g in enumerate(geoms) if (g["contype"] or g["conaffinity"])]
     geom_name2id = {g["name"]: i for i, g in enumerate(geoms) if g["name"]}
 

@@ -178,3 +178,33 @@ def test_env_kernels_have_no_scratch_and_fit_two_waves_per_simd(tmp_path):
     for k, v in env.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
         assert v["vgpr_count"] <= 256, (k, v)      # 2 waves per SIMD (launch bounds 64, 2)
+
+
+@pytest.mark.parametrize("extra, what", [
+    ("<equality><weld body1='a' body2='b'/></equality>", "equality"),
+    ("<tendon><fixed name='t'><joint joint='j' coef='1'/></fixed></tendon>", "tendon"),
+    ("<contact><exclude body1='a' body2='b'/></contact>", "contact"),
+])
+def test_compiler_refuses_sections_the_kernels_do_not_model(tmp_path, extra, what):
+    """Data-format boundary: MJCF features that would change the physics are refused, not silently dropped."""
+    from open_duck_playground_amd import mjcf
+    xml = f"""<mujoco><compiler angle="radian"/><worldbody>
+      <body name="a"><freejoint/><inertial pos="0 0 0" mass="1" fullinertia="1 1 1 0 0 0"/>
+        <body name="b" pos="0 0 0.1"><joint name="j" type="hinge" axis="0 1 0"/><inertial pos="0 0 0" mass="1" fullinertia="1 1 1 0 0 0"/></body>
+      </body></worldbody>{extra}</mujoco>"""
+    path = tmp_path / "m.xml"
+    path.write_text(xml)
+    with pytest.raises(NotImplementedError, match=what):
+        mjcf.compile_mjcf(str(path))
+
+
+def test_compiler_refuses_colliding_primitives(tmp_path):
+    from open_duck_playground_amd import mjcf
+    xml = """<mujoco><compiler angle="radian"/><worldbody>
+      <geom name="floor" type="plane" size="0 0 0.01"/>
+      <body name="a"><freejoint/><inertial pos="0 0 0" mass="1" fullinertia="1 1 1 0 0 0"/><geom name="ball" type="sphere" size="0.1"/></body>
+      </worldbody></mujoco>"""
+    path = tmp_path / "m.xml"
+    path.write_text(xml)
+    with pytest.raises(NotImplementedError, match="ball"):
+        mjcf.compile_mjcf(str(path))
