@@ -163,9 +163,14 @@ int odk_adam_clip(float* params_dev, const float* grads_dev, float* m_dev, float
                   float b1, float b2, float eps, float max_grad_norm, void* stream);
 
 /* dz = dh * silu'(z) over row-major [n, w] and colsum[c] = sum_r dz[r, c] (the bias gradient of the layer below), fixed
- * summation order.  partial_dev: scratch of ceil(n / 64) * w floats. */
+ * summation order.  partial_dev: scratch of ceil(n / 64) * w floats.  colsum_dev may be NULL: the per-tile partial sums
+ * then stay in partial_dev for odk_colsum_finalize. */
 int odk_silu_bwd_colsum(const float* dh_dev, const float* z_dev, float* dz_dev, float* colsum_dev, float* partial_dev, int n, int w,
                         void* stream);
+
+/* colsum[f][c] = sum over the ceil(n / 64) tile rows of partial[f][tile, c] for up to 8 layers in ONE launch (same fixed
+ * order as odk_silu_bwd_colsum's own fold).  partial_dev / colsum_dev / widths are HOST arrays. */
+int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_dev, const int* widths, int count, int n, void* stream);
 
 /* dst[f][b, :] = src[f][idx[b], :] for up to 8 row-major float fields in one launch (minibatch gather of the rollout).
  * src_dev / dst_dev / row_floats are HOST arrays of device pointers / row lengths; idx_dev is int64 on the device. */

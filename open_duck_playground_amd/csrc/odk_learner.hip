@@ -198,6 +198,23 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
   if (ty == 0 && c < w) out[c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
 }
 
+// The same fold for up to 8 layers in one launch (blockIdx.y = layer): the bias gradients are only needed by the clip + Adam
+// step, so the per-layer finalisations leave the dz -> dh -> dz chain of the backward pass.
+struct ColsumArgs { const float* partial[8]; float* out[8]; int w[8]; };
+__global__ void colsum_final_multi_kernel(ColsumArgs a, int nblk) {
+  __shared__ float sh[4][64];
+  const int f = blockIdx.y, w = a.w[f];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const float* partial = a.partial[f];
+  float s = 0.0f;
+  if (c < w)
+    for (int b = ty; b < nblk; b += 4) s += partial[(size_t)b * w + c];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < w) a.out[f][c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+}
+
 // Minibatch gather: trajectory idx[b] of up to 8 row-major [N, row_floats] sources -> row b of the matching static
 // buffers, one launch (blockIdx.x = trajectory, blockIdx.y = field).
 struct GatherArgs { const float* src[8]; float* dst[8]; int row[8]; int nfields; };
@@ -260,12 +277,26 @@ extern "C" int odk_adam_clip(float* params_dev, const float* grads_dev, float* m
 
 extern "C" int odk_silu_bwd_colsum(const float* dh_dev, const float* z_dev, float* dz_dev, float* colsum_dev, float* partial_dev, int n,
                                    int w, void* stream) {
-  if (!dh_dev || !z_dev || !dz_dev || !colsum_dev || !partial_dev || n <= 0 || w <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_silu_bwd_colsum: bad arguments");
+  if (!dh_dev || !z_dev || !dz_dev || !partial_dev || n <= 0 || w <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_silu_bwd_colsum: bad arguments");
   const int nblk = (n + SB_ROWS - 1) / SB_ROWS;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(silu_bwd_colsum_kernel, dim3((w + 63) / 64, nblk), dim3(256), 0, st, dh_dev, z_dev, dz_dev, partial_dev, n, w);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((w + 63) / 64), dim3(256), 0, st, partial_dev, colsum_dev, nblk, w);
+  if (colsum_dev)   // null: the caller folds the partials later with odk_colsum_finalize
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((w + 63) / 64), dim3(256), 0, st, partial_dev, colsum_dev, nblk, w);
   return check_launch("odk_silu_bwd_colsum: launch failed");
+}
+
+extern "C" int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_dev, const int* widths, int count, int n, void* stream) {
+  if (!partial_dev || !colsum_dev || !widths || count <= 0 || count > 8 || n <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_colsum_finalize: bad arguments");
+  ColsumArgs a;
+  int wmax = 0;
+  for (int f = 0; f < 8; f++) {
+    a.partial[f] = f < count ? partial_dev[f] : nullptr; a.out[f] = f < count ? colsum_dev[f] : nullptr; a.w[f] = f < count ? widths[f] : 0;
+    if (f < count && (!partial_dev[f] || !colsum_dev[f] || widths[f] <= 0)) return odk_fail_(ODK_ERR_INVALID, "odk_colsum_finalize: bad layer arguments");
+    if (a.w[f] > wmax) wmax = a.w[f];
+  }
+  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((wmax + 63) / 64, count), dim3(256), 0, (hipStream_t)stream, a, (n + SB_ROWS - 1) / SB_ROWS);
+  return check_launch("odk_colsum_finalize: launch failed");
 }
 
 extern "C" int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, int nfields, const long long* idx_dev,

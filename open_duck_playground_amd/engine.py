@@ -101,6 +101,7 @@ def load_library() -> C.CDLL:
     L.odk_ppo_head.argtypes = [P] * 11 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P]
     L.odk_adam_clip.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P]
     L.odk_silu_bwd_colsum.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
+    L.odk_colsum_finalize.argtypes = [PP, PP, C.POINTER(C.c_int), C.c_int, C.c_int, P]
     L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, P, C.c_int, P]
     _lib = L
     return L
@@ -111,7 +112,7 @@ EXPORTED_SYMBOLS = (
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
-    "odk_adam_clip", "odk_silu_bwd_colsum", "odk_gather_rows")
+    "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_finalize", "odk_gather_rows")
 
 
 def _chk(rc: int):
@@ -194,12 +195,31 @@ def adam_clip(params, grads, m, v, acc, lr: float, max_grad_norm: float = 0.0, b
 
 
 def silu_bwd_colsum(dh, z, dz, colsum, partial):
-    """dz = dh * silu'(z) ([n, w]) and colsum = dz.sum(0) in one pass; partial: scratch of ceil(n / 64) * w floats."""
+    """dz = dh * silu'(z) ([n, w]) and colsum = dz.sum(0) in one pass; partial: scratch of ceil(n / 64) * w floats.
+    colsum=None leaves the per-tile sums in `partial` for a later `ColsumFinalize` (one launch for several layers)."""
     n, w = z.shape
     _f32c(dh, z, dz, colsum, partial)
     if partial.numel() < ((n + 63) // 64) * w:
         raise OdkError("silu_bwd_colsum: partial scratch too small")
     _chk(load_library().odk_silu_bwd_colsum(_ptr(dh), _ptr(z), _ptr(dz), _ptr(colsum), _ptr(partial), n, w, _stream(z)))
+
+
+class ColsumFinalize:
+    """colsum[f] = fold of partial[f] for a fixed set of layers in one launch (`odk_colsum_finalize`); `n` = rows of dz."""
+
+    def __init__(self, pairs, n: int):
+        k = len(pairs)
+        self.k, self.n, self.keep = k, int(n), pairs
+        for p_, o_ in pairs:
+            _f32c(p_, o_)
+            if p_.numel() < ((n + 63) // 64) * o_.numel():
+                raise OdkError("ColsumFinalize: partial scratch too small")
+        self.partial = (C.c_void_p * k)(*[p_.data_ptr() for p_, _ in pairs])
+        self.out = (C.c_void_p * k)(*[o_.data_ptr() for _, o_ in pairs])
+        self.w = (C.c_int * k)(*[int(o_.numel()) for _, o_ in pairs])
+
+    def __call__(self):
+        _chk(load_library().odk_colsum_finalize(self.partial, self.out, self.w, self.k, self.n, _stream(self.keep[0][0])))
 
 
 class RowGather:
