@@ -1,7 +1,8 @@
-"""First-contact GPU debug: per-stage max errors of the HIP forward pass vs the oracle (prints, no asserts)."""
+"""Parity debugging aid (test infrastructure, not collected by pytest): per-stage max errors of the HIP forward pass vs the
+oracle (prints, no asserts).  `python tests/debug_gpu_stages.py` on a GPU box."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))  # ROOT = repo root (this file lives in tests/)
 import numpy as np, torch
 import oracle as O
 from open_duck_playground_amd import engine
