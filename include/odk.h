@@ -168,6 +168,10 @@ int odk_adam_clip(float* params_dev, const float* grads_dev, float* m_dev, float
 int odk_silu_bwd_colsum(const float* dh_dev, const float* z_dev, float* dz_dev, float* colsum_dev, float* partial_dev, int n, int w,
                         void* stream);
 
+/* partial[tile, c] = sum of x[r, c] over the 64 rows of the tile (x row-major [n, w]): the first half of a column sum whose
+ * second half is odk_colsum_finalize. */
+int odk_colsum_partial(const float* x_dev, float* partial_dev, int n, int w, void* stream);
+
 /* colsum[f][c] = sum over the ceil(n / 64) tile rows of partial[f][tile, c] for up to 8 layers in ONE launch (same fixed
  * order as odk_silu_bwd_colsum's own fold).  partial_dev / colsum_dev / widths are HOST arrays. */
 int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_dev, const int* widths, int count, int n, void* stream);

@@ -74,6 +74,50 @@ __global__ void gae_kernel(const float* __restrict__ trunc, const float* __restr
   if (threadIdx.x == 0) { stats[0] = mean; stats[1] = 1.0f / (sqrtf(var) + 1e-8f); }
 }
 
+// Same arithmetic, in the same order, for T <= TT and B <= blockDim.x: the recursion is serial in time, so in the
+// kernel above every one of its T steps waits for four strided global loads (20 us for 256 x 20).  Here a thread first
+// issues all 4 T loads of its trajectory (independent, all in flight together), then runs the recursion and the
+// variance pass out of registers.
+template <int TT>
+__global__ void gae_kernel_reg(const float* __restrict__ trunc, const float* __restrict__ term, const float* __restrict__ rew,
+                               const float* __restrict__ val, const float* __restrict__ boot, float* __restrict__ vs,
+                               float* __restrict__ adv, float* __restrict__ stats, int B, int T, float lambda_, float discount) {
+  __shared__ float sh[16];
+  const int b = threadIdx.x;
+  const bool live = b < B;
+  const size_t o = (size_t)(live ? b : 0) * T;
+  float mk[TT], nt[TT], v[TT], r[TT];
+#pragma unroll
+  for (int t = 0; t < TT; t++) {
+    const bool on = live && t < T;
+    const size_t i = on ? o + t : 0;
+    mk[t] = 1.0f - trunc[i]; nt[t] = 1.0f - term[i]; v[t] = val[i]; r[t] = rew[i];
+  }
+  float acc = 0.0f, v_next = live ? boot[b] : 0.0f, vs_next = v_next, s = 0.0f;
+#pragma unroll
+  for (int t = TT - 1; t >= 0; t--) {
+    if (live && t < T) {
+      const float delta = (r[t] + discount * nt[t] * v_next - v[t]) * mk[t];
+      acc = delta + discount * nt[t] * mk[t] * lambda_ * acc;
+      const float vs_t = acc + v[t], a = (r[t] + discount * nt[t] * vs_next - v[t]) * mk[t];
+      adv[o + t] = a;
+      vs[o + t] = vs_t;
+      s += a;
+      v_next = v[t]; vs_next = vs_t;
+      r[t] = a;   // kept for the variance pass
+    }
+  }
+  if (!stats) return;
+  const float n = (float)B * (float)T;
+  const float mean = block_sum(s, sh) / n;
+  float q = 0.0f;
+#pragma unroll
+  for (int t = 0; t < TT; t++)
+    if (live && t < T) { const float d = r[t] - mean; q += d * d; }
+  const float var = block_sum(q, sh) / n;
+  if (threadIdx.x == 0) { stats[0] = mean; stats[1] = 1.0f / (sqrtf(var) + 1e-8f); }
+}
+
 // One 16-lane row per sample, lane j < A = action dimension j.  logits [n, 2A] = (loc | raw_scale).
 // losses[0..3] += (total, policy, value, entropy) contributions (caller zeroes them).
 __global__ void ppo_head_kernel(const float* __restrict__ logits, const float* __restrict__ raw_action, const float* __restrict__ old_logp,
@@ -186,6 +230,19 @@ __global__ void silu_bwd_colsum_kernel(const float* __restrict__ dh, const float
   __syncthreads();
   if (ty == 0 && c < w) partial[(size_t)blockIdx.y * w + c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
 }
+// Tile sums of a plain [n, w] matrix in the same layout (the top layer's bias gradient: dz needs no activation derivative)
+__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int n, int w) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * SB_ROWS, r1 = min(n, r0 + SB_ROWS);
+  float s = 0.0f;
+  if (c < w)
+    for (int r = r0 + ty; r < r1; r += 4) s += x[(size_t)r * w + c];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < w) partial[(size_t)blockIdx.y * w + c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+}
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int w) {
   __shared__ float sh[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -240,8 +297,12 @@ extern "C" int odk_gae(const float* truncation_dev, const float* termination_dev
   if (!truncation_dev || !termination_dev || !rewards_dev || !values_dev || !bootstrap_dev || !vs_dev || !adv_dev || B <= 0 || T <= 0)
     return odk_fail_(ODK_ERR_INVALID, "odk_gae: bad arguments");
   const int threads = B >= 1024 ? 1024 : ((B + 63) / 64) * 64;
-  hipLaunchKernelGGL(gae_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, truncation_dev, termination_dev, rewards_dev, values_dev,
-                     bootstrap_dev, vs_dev, adv_dev, adv_stats_dev, B, T, lambda_, discount);
+  if (B <= 1024 && T <= 32)
+    hipLaunchKernelGGL(gae_kernel_reg<32>, dim3(1), dim3(threads), 0, (hipStream_t)stream, truncation_dev, termination_dev, rewards_dev,
+                       values_dev, bootstrap_dev, vs_dev, adv_dev, adv_stats_dev, B, T, lambda_, discount);
+  else
+    hipLaunchKernelGGL(gae_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, truncation_dev, termination_dev, rewards_dev, values_dev,
+                       bootstrap_dev, vs_dev, adv_dev, adv_stats_dev, B, T, lambda_, discount);
   return check_launch("odk_gae: launch failed");
 }
 
@@ -252,7 +313,7 @@ extern "C" int odk_ppo_head(const float* logits_dev, const float* raw_action_dev
   if (!logits_dev || !raw_action_dev || !old_log_prob_dev || !adv_dev || !vs_dev || !baseline_dev || !noise_dev || !dlogits_dev ||
       !dbaseline_dev || !losses_dev || n <= 0 || action_size <= 0 || action_size > 16)
     return odk_fail_(ODK_ERR_INVALID, "odk_ppo_head: bad arguments (action_size must be 1..16)");
-  const int threads = 256, per_block = threads / 16;
+  const int threads = 1024, per_block = threads / 16;   // 64 samples per workgroup: 4 loss atomics per 64 samples
   hipLaunchKernelGGL(ppo_head_kernel, dim3((n + per_block - 1) / per_block), dim3(threads), 0, (hipStream_t)stream, logits_dev, raw_action_dev,
                      old_log_prob_dev, adv_dev, adv_stats_dev, vs_dev, baseline_dev, noise_dev, dlogits_dev, dbaseline_dev, losses_dev, n,
                      action_size, clipping_epsilon, entropy_cost, grad_scale);
@@ -284,6 +345,12 @@ extern "C" int odk_silu_bwd_colsum(const float* dh_dev, const float* z_dev, floa
   if (colsum_dev)   // null: the caller folds the partials later with odk_colsum_finalize
     hipLaunchKernelGGL(colsum_final_kernel, dim3((w + 63) / 64), dim3(256), 0, st, partial_dev, colsum_dev, nblk, w);
   return check_launch("odk_silu_bwd_colsum: launch failed");
+}
+
+extern "C" int odk_colsum_partial(const float* x_dev, float* partial_dev, int n, int w, void* stream) {
+  if (!x_dev || !partial_dev || n <= 0 || w <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_colsum_partial: bad arguments");
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((w + 63) / 64, (n + SB_ROWS - 1) / SB_ROWS), dim3(256), 0, (hipStream_t)stream, x_dev, partial_dev, n, w);
+  return check_launch("odk_colsum_partial: launch failed");
 }
 
 extern "C" int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_dev, const int* widths, int count, int n, void* stream) {

@@ -101,6 +101,7 @@ def load_library() -> C.CDLL:
     L.odk_ppo_head.argtypes = [P] * 11 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P]
     L.odk_adam_clip.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P]
     L.odk_silu_bwd_colsum.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
+    L.odk_colsum_partial.argtypes = [P, P, C.c_int, C.c_int, P]
     L.odk_colsum_finalize.argtypes = [PP, PP, C.POINTER(C.c_int), C.c_int, C.c_int, P]
     L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, P, C.c_int, P]
     _lib = L
@@ -112,7 +113,7 @@ EXPORTED_SYMBOLS = (
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
-    "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_finalize", "odk_gather_rows")
+    "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows")
 
 
 def _chk(rc: int):
@@ -202,6 +203,15 @@ def silu_bwd_colsum(dh, z, dz, colsum, partial):
     if partial.numel() < ((n + 63) // 64) * w:
         raise OdkError("silu_bwd_colsum: partial scratch too small")
     _chk(load_library().odk_silu_bwd_colsum(_ptr(dh), _ptr(z), _ptr(dz), _ptr(colsum), _ptr(partial), n, w, _stream(z)))
+
+
+def colsum_partial(x, partial):
+    """Tile sums of x ([n, w]) for a later `ColsumFinalize` (partial: ceil(n / 64) * w floats)."""
+    n, w = x.shape
+    _f32c(x, partial)
+    if partial.numel() < ((n + 63) // 64) * w:
+        raise OdkError("colsum_partial: partial scratch too small")
+    _chk(load_library().odk_colsum_partial(_ptr(x), _ptr(partial), n, w, _stream(x)))
 
 
 class ColsumFinalize:

@@ -110,17 +110,16 @@ class _FlatMLP:
             self.dhs = [torch.empty_like(t) for t in self.dzs]
             # per-layer tile sums of dz; folded into the bias gradients by ONE launch after the chain (the bias gradients
             # are first read by the clip + Adam step, so their finalisation need not sit between the GEMMs)
-            self.partials = [torch.empty(((n + 63) // 64) * w.shape[0], device=dz.device) for w in self.W[:-1]]
-            self.fold = engine.ColsumFinalize([(p, self.gb[i]) for i, p in enumerate(self.partials)], n) if self.partials else None
-        torch.sum(dz, 0, out=self.gb[top])
+            self.partials = [torch.empty(((n + 63) // 64) * w.shape[0], device=dz.device) for w in self.W]
+            self.fold = engine.ColsumFinalize([(p, self.gb[i]) for i, p in enumerate(self.partials)], n)
+        engine.colsum_partial(dz, self.partials[top])   # (a torch.sum over the tall [n, <=28] matrix takes 22-28 us)
         for i in range(top, -1, -1):
             torch.mm(dz.t(), hs[i], out=self.gW[i])
             if i > 0:
                 dh = torch.mm(dz, self.W[i], out=self.dhs[i - 1])
                 dz = self.dzs[i - 1]
                 engine.silu_bwd_colsum(dh, zs[i - 1], dz, None, self.partials[i - 1])
-        if self.fold is not None:
-            self.fold()
+        self.fold()
 
 
 class FlatLearner:
