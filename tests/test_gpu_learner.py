@@ -16,11 +16,11 @@ def _fake_rollout(N, T, dev, seed=0):
                 done=done, truncation=trunc, last_priv=r(N, 212))
 
 
-def test_gae_kernel_matches_torch_reference():
+@pytest.mark.parametrize("B, Tn", [(256, 20), (37, 5), (300, 20), (1200, 40)])   # LDS-staged, register-staged and generic kernels
+def test_gae_kernel_matches_torch_reference(B, Tn):
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.ppo import train as T
     g = torch.Generator(device="cuda").manual_seed(0)
-    B, Tn = 300, 20
     rew, val = torch.randn(B, Tn, device="cuda", generator=g), torch.randn(B, Tn, device="cuda", generator=g)
     boot = torch.randn(B, device="cuda", generator=g)
     term = (torch.rand(B, Tn, device="cuda", generator=g) < 0.1).float()
