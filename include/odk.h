@@ -157,6 +157,12 @@ int odk_ppo_head(const float* logits_dev, const float* raw_action_dev, const flo
 /* clip_by_global_norm(max_grad_norm; <= 0 disables) + Adam on flat buffers of n floats.  acc_dev[ODK_ADAM_ACC_FLOATS]
  * is scratch owned by the caller: acc[0] = squared gradient norm of this call, acc[1] = step count (zero it once),
  * acc[2..] = per-block partial sums (the norm is reduced in a fixed order: data-parallel replicas stay bit-identical). */
+/* Rollout sampling of the tanh-normal policy (brax NormalTanhDistribution, as odk_ppo_head): logits [n, 2A] = (loc | raw_scale),
+ * noise [n, A] standard normal (zeros: the mode).  raw_action = loc + (softplus(raw_scale) + 0.001) noise, action = tanh(raw_action),
+ * log_prob[n] = log density of the action.  One launch instead of ~15 element-wise ones per rollout step. */
+int odk_policy_sample(const float* logits_dev, const float* noise_dev, float* raw_action_dev, float* action_dev, float* log_prob_dev, int n,
+                      int action_size, void* stream);
+
 #define ODK_ADAM_MAX_PARTIALS 1024
 #define ODK_ADAM_ACC_FLOATS (2 + ODK_ADAM_MAX_PARTIALS)
 int odk_adam_clip(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr,

@@ -214,6 +214,27 @@ __global__ void ppo_head_kernel(const float* __restrict__ logits, const float* _
   }
 }
 
+// Rollout side of the same distribution: raw = loc + scale z, action = tanh(raw), log_prob = sum_j log N(raw; loc, scale) -
+// log |d tanh / d raw| (brax NormalTanhDistribution; scale = softplus(raw_scale) + 0.001).  One 16-lane row per sample.
+__global__ void policy_sample_kernel(const float* __restrict__ logits, const float* __restrict__ noise, float* __restrict__ raw_out,
+                                     float* __restrict__ action_out, float* __restrict__ logp_out, int n, int A) {
+  const int lane = threadIdx.x & 15;
+  const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool live = s < n, on = live && lane < A;
+  const int sc = live ? s : n - 1;
+  const float HALF_LOG_2PI = 0.91893853320467274f, LOG2 = 0.69314718055994531f;
+  float loc = 0.f, rs = 0.f, z = 0.f;
+  if (on) { loc = logits[(size_t)sc * 2 * A + lane]; rs = logits[(size_t)sc * 2 * A + A + lane]; z = noise[(size_t)sc * A + lane]; }
+  const float scale = softplus(rs) + 0.001f;
+  const float raw = loc + scale * z;
+  const float u = (raw - loc) / scale;
+  const float ldj = 2.0f * (LOG2 - raw - softplus(-2.0f * raw));
+  const float lp_j = on ? (-0.5f * u * u - __logf(scale) - HALF_LOG_2PI - ldj) : 0.0f;
+  const float logp = row16_sum(lp_j);
+  if (on) { raw_out[(size_t)s * A + lane] = raw; action_out[(size_t)s * A + lane] = tanhf(raw); }
+  if (live && lane == 0) logp_out[s] = logp;
+}
+
 // Deterministic global gradient norm (data-parallel replicas must apply bit-identical updates, so no float atomics):
 // block b writes its partial sum to acc[2 + b]; one block then folds the partials in a fixed order into acc[0] and
 // advances the step counter acc[1].
@@ -363,6 +384,16 @@ extern "C" int odk_ppo_head(const float* logits_dev, const float* raw_action_dev
                      old_log_prob_dev, adv_dev, adv_stats_dev, vs_dev, baseline_dev, noise_dev, dlogits_dev, dbaseline_dev, losses_dev, n,
                      action_size, clipping_epsilon, entropy_cost, grad_scale);
   return check_launch("odk_ppo_head: launch failed");
+}
+
+extern "C" int odk_policy_sample(const float* logits_dev, const float* noise_dev, float* raw_action_dev, float* action_dev, float* log_prob_dev,
+                                 int n, int action_size, void* stream) {
+  if (!logits_dev || !noise_dev || !raw_action_dev || !action_dev || !log_prob_dev || n <= 0 || action_size <= 0 || action_size > 16)
+    return odk_fail_(ODK_ERR_INVALID, "odk_policy_sample: bad arguments (action_size must be 1..16)");
+  const int threads = 256, per_block = threads / 16;
+  hipLaunchKernelGGL(policy_sample_kernel, dim3((n + per_block - 1) / per_block), dim3(threads), 0, (hipStream_t)stream, logits_dev, noise_dev,
+                     raw_action_dev, action_dev, log_prob_dev, n, action_size);
+  return check_launch("odk_policy_sample: launch failed");
 }
 
 extern "C" int odk_adam_clip(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr,

@@ -99,6 +99,7 @@ def load_library() -> C.CDLL:
     L.odk_batch_timing.argtypes = [P, C.c_int, FP, C.POINTER(C.c_int)]
     L.odk_gae.argtypes = [P, P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_float, P]
     L.odk_ppo_head.argtypes = [P] * 11 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P]
+    L.odk_policy_sample.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
     L.odk_adam_clip.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P]
     L.odk_silu_bwd_colsum.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
     L.odk_colsum_partial.argtypes = [P, P, C.c_int, C.c_int, P]
@@ -113,7 +114,7 @@ EXPORTED_SYMBOLS = (
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
-    "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows")
+    "odk_policy_sample", "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows")
 
 
 def _chk(rc: int):
@@ -193,6 +194,16 @@ def adam_clip(params, grads, m, v, acc, lr: float, max_grad_norm: float = 0.0, b
         raise OdkError("adam_clip: acc needs ADAM_ACC_FLOATS floats")
     _chk(load_library().odk_adam_clip(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
                                       max_grad_norm or 0.0, _stream(params)))
+
+
+def policy_sample(logits, noise):
+    """(raw_action, action, log_prob) of the tanh-normal policy for logits [n, 2A] and standard-normal noise [n, A]."""
+    import torch
+    n, A = noise.shape
+    _f32c(logits, noise)
+    raw, act, logp = torch.empty_like(noise), torch.empty_like(noise), torch.empty(n, device=noise.device)
+    _chk(load_library().odk_policy_sample(_ptr(logits), _ptr(noise), _ptr(raw), _ptr(act), _ptr(logp), n, A, _stream(noise)))
+    return raw, act, logp
 
 
 def silu_bwd_colsum(dh, z, dz, colsum, partial):

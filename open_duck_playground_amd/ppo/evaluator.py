@@ -29,7 +29,7 @@ class Evaluator:
 
     def _one_step(self, net):
         st = self._state
-        loc, _ = net.dist_params(st.obs["state"])
+        loc = net.policy(net.norm_obs(st.obs["state"]))[..., : net.action_size]   # the mode needs no scale (softplus skipped)
         st = self.env.step(st, torch.tanh(loc).contiguous())
         a = self._acc
         if a["matrix"] is not None:

@@ -143,10 +143,17 @@ def rollout(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generat
     buf = {k: [] for k in keys}
     for _ in range(unroll_length):
         obs, priv = state.obs["state"].clone(), state.obs["privileged_state"].clone()
-        loc, scale = net.dist_params(obs)
-        raw = loc if deterministic else loc + scale * torch.randn(loc.shape, generator=gen, device=loc.device)
-        logp = tanh_normal_log_prob(loc, scale, raw)
-        action = torch.tanh(raw).contiguous()
+        if obs.is_cuda:   # one launch for softplus / sample / tanh / log-density (csrc policy_sample_kernel)
+            from .. import engine
+            logits = net.policy(net.norm_obs(obs))
+            A = net.action_size
+            z = torch.zeros(obs.shape[0], A, device=obs.device) if deterministic else torch.randn(obs.shape[0], A, generator=gen, device=obs.device)
+            raw, action, logp = engine.policy_sample(logits, z)
+        else:
+            loc, scale = net.dist_params(obs)
+            raw = loc if deterministic else loc + scale * torch.randn(loc.shape, generator=gen, device=loc.device)
+            logp = tanh_normal_log_prob(loc, scale, raw)
+            action = torch.tanh(raw).contiguous()
         state = env.step(state, action)
         buf["obs"].append(obs); buf["priv"].append(priv); buf["raw_action"].append(raw); buf["log_prob"].append(logp)
         buf["reward"].append(state.reward.clone()); buf["done"].append(state.done.clone()); buf["truncation"].append(state.info["truncation"].clone())

@@ -160,3 +160,20 @@ def test_flat_learner_data_parallel_two_ranks():
     for p in procs: p.join(timeout=60)
     assert same, "ranks diverged: the flat gradient all-reduce must make the updates identical"
     assert finite and moved > 1e-5 and steps == 4.0 and loss == loss
+
+
+def test_policy_sample_kernel_matches_the_torch_distribution():
+    """raw action, tanh action and log-density of the fused rollout sampler == the torch formulas the CPU path uses."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.ppo.networks import tanh_normal_log_prob
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, A = 1000, 14                                        # n not a multiple of the 16 samples per workgroup
+    logits = 2.0 * torch.randn(n, 2 * A, device="cuda", generator=g)
+    for z in (torch.randn(n, A, device="cuda", generator=g), torch.zeros(n, A, device="cuda")):
+        raw, act, logp = engine.policy_sample(logits, z)
+        loc, scale = logits[:, :A], F.softplus(logits[:, A:]) + 0.001
+        raw_ref = loc + scale * z
+        torch.testing.assert_close(raw, raw_ref, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(act, torch.tanh(raw_ref), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(logp, tanh_normal_log_prob(loc, scale, raw_ref), rtol=1e-4, atol=2e-3)
