@@ -153,6 +153,7 @@ class FlatLearner:
         self._gather = None; self._gather_src = ()
         self.side = torch.cuda.Stream() if os.environ.get("ODK_LEARNER_BRANCHES", "1") == "1" else None   # policy || value
         self.sample_noise = True                    # plain-launch path only: tests inject self.noise instead
+        self._pool, self._pool_k = None, 0
         if use_graph:
             self._capture()
 
@@ -193,6 +194,20 @@ class FlatLearner:
     def _draw_noise(self):
         self.noise.normal_()
 
+    NOISE_POOL = 128   # minibatch steps per refill (= steps per training step in the reference configuration)
+
+    @torch.no_grad()
+    def _next_noise(self):
+        """Entropy-sample noise for the captured step: inside a graph `normal_` costs three launches per replay (the
+        generator's seed / offset fills + the kernel); one refill per 128 steps and one slice copy per step cost one."""
+        if self._pool is None or self._pool_k >= self.NOISE_POOL:
+            if self._pool is None:
+                self._pool = torch.empty(self.NOISE_POOL, *self.noise.shape, device=self.noise.device)
+            self._pool.normal_()
+            self._pool_k = 0
+        self.noise.copy_(self._pool[self._pool_k])
+        self._pool_k += 1
+
     @torch.no_grad()
     def _update(self):
         engine.adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0)
@@ -212,7 +227,7 @@ class FlatLearner:
             t.copy_(k)                              # the warm-up steps must not train
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
-            self._draw_noise(); self._loss_and_grads()
+            self._loss_and_grads()                  # the noise buffer is filled before each replay (_next_noise)
             if self.world == 1:
                 self._update()
         if self.world > 1:
@@ -234,6 +249,7 @@ class FlatLearner:
     def step(self):
         """One clipped-Adam step on the loaded minibatch; returns the 4 loss scalars (device tensor, no sync)."""
         if self.graph_a is not None:
+            self._next_noise()
             self.graph_a.replay()
         else:
             if self.sample_noise:
