@@ -71,6 +71,24 @@ def _tunable(tuning: bool) -> bool:
         return False
 
 
+@torch.no_grad()
+def tune_inference_shapes(net: PPONetworks, rows) -> None:
+    """Library kernel selection for the policy-inference GEMMs of the rollout (rows = envs per GPU) and of the evaluator
+    (rows = eval envs): without it the 128-row evaluator GEMMs run 256x128 macro-tiles (61 us for a 128 x 101 x 512
+    product).  The shipped selection file covers the reference sizes (8192 / 128 rows), so this usually tunes nothing."""
+    dev = next(net.parameters()).device
+    if dev.type != "cuda" or not _tunable(True):
+        return
+    try:
+        for r in rows:
+            x = torch.zeros(int(r), net.policy.layers[0].in_features, device=dev)
+            for _ in range(2):
+                net.policy(net.norm_obs(x))
+        torch.cuda.synchronize(dev)
+    finally:
+        _tunable(False)
+
+
 class _FlatMLP:
     """Views of one MLP's weights / gradients inside the flat buffers + explicit forward / backward."""
 

@@ -202,6 +202,9 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
         if eval_env is not None:
             from .evaluator import Evaluator
             evaluator = Evaluator(eval_env, cfg["episode_length"], cfg["action_repeat"])
+    if dev.type == "cuda" and cfg.get("tune_gemms", True):
+        from .learner import tune_inference_shapes
+        tune_inference_shapes(net, [n_local] + ([cfg.get("num_eval_envs", 128)] if evaluator is not None else []))
     log = open(log_path, "a") if (log_path and rank == 0) else None
     t0 = time.time(); done_steps = 0; metrics = {}
 
