@@ -37,12 +37,13 @@ def _tunable(tuning: bool) -> bool:
     the library heuristics pick stream-K 32x32 tiles for the K = 5120 weight-gradient GEMMs (30-36 us each); the tuned
     choices run 17-24 us (-150 us per minibatch step).
 
-    The selections for the reference PPO configuration (batch 256 x unroll 20, both duck observation sizes) ship in
-    `assets/tunableop_gfx950.csv`: candidates timed alone are within noise of each other and what matters is the step time
-    with the policy / value branches overlapping, so the shipped file is the best of 8 tuning runs measured on the whole
-    minibatch step (55.9 vs 55.9-58.0 ms per training step).  TunableOp checks the file's version validators (PyTorch,
-    HIP, hipBLASLt, rocBLAS, arch) and ignores it on a mismatch; shapes it does not list are tuned during the warm-up
-    steps as before.  $ODK_TUNABLEOP_FILE overrides the file (TunableOp rewrites it on exit)."""
+    The selections for the reference PPO configuration (batch 256 x unroll 20, the duck's observation sizes; also the
+    policy-inference GEMMs of an 8192-env rollout and a 128-env evaluator) ship in `assets/tunableop_gfx950.csv`:
+    candidates timed alone are within noise of each other and what matters is the step time with the policy / value
+    branches overlapping, so the shipped learner entries are the best of 18 tuning runs measured on the whole minibatch
+    step (53.9 vs 54.1-58.3 ms per training step at the time).  TunableOp checks the file's version validators
+    (PyTorch, HIP, hipBLASLt, rocBLAS, arch) and ignores it on a mismatch; shapes it does not list are tuned during the
+    warm-up steps as before.  $ODK_TUNABLEOP_FILE overrides the file (TunableOp rewrites it on exit)."""
     try:
         import torch.cuda.tunable as tn
     except Exception as e:                          # optional speed-up, never a requirement
