@@ -139,7 +139,8 @@ int odk_batch_get_records(odk_batch* b, float* host_records);
  * reference reaches them through brax ppo.train (common/runner.py:104-118): ppo.losses.compute_gae /
  * compute_ppo_loss and optax.chain(clip_by_global_norm, adam).  All stream-ordered, graph-capturable. ---- */
 
-/* GAE over row-major [B, T] device arrays: vs and advantages out; truncation / termination are 0/1 floats;
+/* GAE over row-major [B, T] device arrays: vs and advantages out; truncation / termination are flags (0 = clear, any
+ * other value = set);
  * bootstrap is [B].  adv_stats (may be NULL) receives {mean, 1/(std+1e-8)} of the advantages (ddof 0). */
 int odk_gae(const float* truncation_dev, const float* termination_dev, const float* rewards_dev, const float* values_dev,
             const float* bootstrap_dev, float* vs_dev, float* adv_dev, float* adv_stats_dev, int B, int T, float lambda_,
@@ -148,7 +149,8 @@ int odk_gae(const float* truncation_dev, const float* termination_dev, const flo
 /* PPO loss head, forward and backward in one launch.  logits [n, 2*action_size] = (loc | raw scale) of the
  * tanh-normal policy, noise [n, action_size] ~ N(0,1) for the sampled entropy term, adv_stats from odk_gae (NULL:
  * no advantage normalisation).  Writes grad_scale * dLoss/dlogits and grad_scale * dLoss/dbaseline, and ADDS
- * (total, policy, value, entropy) loss to losses[0..3] (caller zeroes them). */
+ * (total, policy, value, entropy) loss to losses[0..3]: the caller zeroes them, per step or -- for the mean over an
+ * epoch of steps -- once per epoch. */
 int odk_ppo_head(const float* logits_dev, const float* raw_action_dev, const float* old_log_prob_dev, const float* adv_dev,
                  const float* adv_stats_dev, const float* vs_dev, const float* baseline_dev, const float* noise_dev,
                  float* dlogits_dev, float* dbaseline_dev, float* losses_dev, int n, int action_size, float clipping_epsilon,
@@ -183,9 +185,11 @@ int odk_colsum_partial(const float* x_dev, float* partial_dev, int n, int w, voi
 int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_dev, const int* widths, int count, int n, void* stream);
 
 /* dst[f][b, :] = src[f][idx[b], :] for up to 8 row-major float fields in one launch (minibatch gather of the rollout).
- * src_dev / dst_dev / row_floats are HOST arrays of device pointers / row lengths; idx_dev is int64 on the device. */
+ * src_dev / dst_dev / row_floats are HOST arrays of device pointers / row lengths; idx_dev is int64 on the device, nrows
+ * entries; every source has src_rows rows.  An index outside [0, src_rows) is never dereferenced: its destination rows
+ * are filled with NaN. */
 int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, int nfields, const long long* idx_dev,
-                    int nrows, void* stream);
+                    int nrows, long long src_rows, void* stream);
 
 /* live timing of the most recent odk_step launches with HIP events on the launch stream:
  * returns average milliseconds per launch since the last call (and resets the window) */

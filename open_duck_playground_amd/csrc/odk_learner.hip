@@ -42,7 +42,8 @@ __device__ float block_sum(float v, float* sh) {   // blockDim.x multiple of 64,
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
 __device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-// GAE over row-major [B, T]; one thread per trajectory, serial in time (brax compute_gae); then the
+// GAE over row-major [B, T]; one thread per trajectory, serial in time (brax compute_gae); truncation / termination are
+// FLAGS (any non-zero value counts as 1, in all three kernels); then the
 // population mean / std of the advantages (brax: (adv - mean) / (std + 1e-8), jnp.std => ddof 0).
 // stats[0] = mean, stats[1] = 1 / (std + 1e-8).  Single workgroup.
 __global__ void gae_kernel(const float* __restrict__ trunc, const float* __restrict__ term, const float* __restrict__ rew,
@@ -54,7 +55,7 @@ __global__ void gae_kernel(const float* __restrict__ trunc, const float* __restr
     const size_t o = (size_t)b * T;
     float acc = 0.0f, v_next = boot[b], vs_next = boot[b];
     for (int t = T - 1; t >= 0; t--) {
-      const float mask = 1.0f - trunc[o + t], nt = 1.0f - term[o + t], v = val[o + t], r = rew[o + t];
+      const float mask = trunc[o + t] != 0.0f ? 0.0f : 1.0f, nt = term[o + t] != 0.0f ? 0.0f : 1.0f, v = val[o + t], r = rew[o + t];
       const float delta = (r + discount * nt * v_next - v) * mask;
       acc = delta + discount * nt * mask * lambda_ * acc;
       const float vs_t = acc + v, a = (r + discount * nt * vs_next - v) * mask;
@@ -91,7 +92,7 @@ __global__ void gae_kernel_reg(const float* __restrict__ trunc, const float* __r
   for (int t = 0; t < TT; t++) {
     const bool on = live && t < T;
     const size_t i = on ? o + t : 0;
-    mk[t] = 1.0f - trunc[i]; nt[t] = 1.0f - term[i]; v[t] = val[i]; r[t] = rew[i];
+    mk[t] = trunc[i] != 0.0f ? 0.0f : 1.0f; nt[t] = term[i] != 0.0f ? 0.0f : 1.0f; v[t] = val[i]; r[t] = rew[i];
   }
   float acc = 0.0f, v_next = live ? boot[b] : 0.0f, vs_next = v_next, s = 0.0f;
 #pragma unroll
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(1024) gae_kernel_lds(const float* __restrict__
   __shared__ float s_r[GAE_LDS_N], s_v[GAE_LDS_N], s_f[GAE_LDS_N];   // s_f = trunc + 2 * term (both are 0 / 1 flags)
   __shared__ float sh[16];
   const int N = B * T;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) { s_r[i] = rew[i]; s_v[i] = val[i]; s_f[i] = trunc[i] + 2.0f * term[i]; }
+  for (int i = threadIdx.x; i < N; i += blockDim.x) { s_r[i] = rew[i]; s_v[i] = val[i]; s_f[i] = (trunc[i] != 0.0f ? 1.0f : 0.0f) + (term[i] != 0.0f ? 2.0f : 0.0f); }
   __syncthreads();
   float s = 0.0f;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
@@ -338,11 +339,16 @@ __global__ void colsum_final_multi_kernel(ColsumArgs a, int nblk) {
 // Minibatch gather: trajectory idx[b] of up to 8 row-major [N, row_floats] sources -> row b of the matching static
 // buffers, one launch (blockIdx.x = trajectory, blockIdx.y = field).
 struct GatherArgs { const float* src[8]; float* dst[8]; int row[8]; int nfields; };
-__global__ void gather_rows_kernel(GatherArgs a, const long long* __restrict__ idx) {
+__global__ void gather_rows_kernel(GatherArgs a, const long long* __restrict__ idx, long long src_rows) {
   const int f = blockIdx.y;
   const int n = a.row[f];
-  const float* s = a.src[f] + (size_t)idx[blockIdx.x] * n;
+  const long long j = idx[blockIdx.x];
   float* d = a.dst[f] + (size_t)blockIdx.x * n;
+  if (j < 0 || j >= src_rows) {   // never read out of bounds: the row becomes NaN and the step's losses say so
+    for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = __builtin_nanf("");
+    return;
+  }
+  const float* s = a.src[f] + (size_t)j * n;
   for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
 }
 
@@ -443,11 +449,12 @@ extern "C" int odk_colsum_finalize(const float* const* partial_dev, float* const
 }
 
 extern "C" int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, int nfields, const long long* idx_dev,
-                               int nrows, void* stream) {
-  if (!src_dev || !dst_dev || !row_floats || !idx_dev || nfields <= 0 || nfields > 8 || nrows <= 0) return odk_fail_(ODK_ERR_INVALID, "odk_gather_rows: bad arguments");
+                               int nrows, long long src_rows, void* stream) {
+  if (!src_dev || !dst_dev || !row_floats || !idx_dev || nfields <= 0 || nfields > 8 || nrows <= 0 || src_rows <= 0)
+    return odk_fail_(ODK_ERR_INVALID, "odk_gather_rows: bad arguments");
   GatherArgs a;
   a.nfields = nfields;
   for (int f = 0; f < 8; f++) { a.src[f] = f < nfields ? src_dev[f] : nullptr; a.dst[f] = f < nfields ? dst_dev[f] : nullptr; a.row[f] = f < nfields ? row_floats[f] : 0; }
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows, nfields), dim3(256), 0, (hipStream_t)stream, a, idx_dev);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows, nfields), dim3(256), 0, (hipStream_t)stream, a, idx_dev, src_rows);
   return check_launch("odk_gather_rows: launch failed");
 }

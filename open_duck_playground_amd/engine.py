@@ -104,7 +104,7 @@ def load_library() -> C.CDLL:
     L.odk_silu_bwd_colsum.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
     L.odk_colsum_partial.argtypes = [P, P, C.c_int, C.c_int, P]
     L.odk_colsum_finalize.argtypes = [PP, PP, C.POINTER(C.c_int), C.c_int, C.c_int, P]
-    L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, P, C.c_int, P]
+    L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, P, C.c_int, C.c_longlong, P]
     _lib = L
     return L
 
@@ -166,6 +166,7 @@ def _f32c(*ts):
 
 def gae(truncation, termination, rewards, values, bootstrap, lambda_: float, discount: float, vs=None, adv=None, stats=None):
     """compute_gae on the device ([B, T] contiguous float32 CUDA tensors) -> (vs, advantages); one HIP launch.
+    `truncation` / `termination` are flags: 0 = clear, anything else = set.
     `stats` (2 floats, optional) receives the advantage mean and 1/(std + 1e-8)."""
     import torch
     B, T = rewards.shape
@@ -256,9 +257,20 @@ class RowGather:
         self.dst = (C.c_void_p * n)(*[d_.data_ptr() for _, d_ in pairs])
         self.rows = (C.c_int * n)(*[int(s_[0].numel()) for s_, _ in pairs])
         self.nrows = int(pairs[0][1].shape[0])
+        self.src_rows = int(pairs[0][0].shape[0])
+        for s_, d_ in pairs:
+            if int(s_.shape[0]) != self.src_rows or int(d_.shape[0]) != self.nrows or s_[0].numel() != d_[0].numel():
+                raise OdkError("RowGather: every source needs the same row count, every destination the same row count, and "
+                               "matching row lengths")
 
     def __call__(self, idx):
-        _chk(load_library().odk_gather_rows(self.src, self.dst, self.rows, self.n, _ptr(idx), self.nrows, _stream(idx)))
+        """`idx`: contiguous int64 CUDA tensor of `nrows` source-row numbers (values outside the source are not read: those
+        destination rows become NaN)."""
+        import torch
+        if not (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == self.nrows):
+            raise OdkError(f"RowGather: idx must be a contiguous int64 CUDA tensor of {self.nrows} entries "
+                           f"(got {idx.dtype}, {idx.device}, contiguous={idx.is_contiguous()}, {idx.numel()} entries)")
+        _chk(load_library().odk_gather_rows(self.src, self.dst, self.rows, self.n, _ptr(idx), self.nrows, self.src_rows, _stream(idx)))
 
 
 class Batch:

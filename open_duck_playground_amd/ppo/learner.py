@@ -32,6 +32,61 @@ _DEBUG_NONFINITE = os.environ.get("ODK_DEBUG_NONFINITE") == "1"   # per-step fin
 _TUNED_ASSET = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "tunableop_gfx950.csv")
 
 
+_scratch_files = []
+_reported_validators = False
+
+
+def _cleanup_tunableop():
+    """TunableOp rewrites its results file from a static destructor at process exit: point it at /dev/null and delete the
+    per-process scratch copy, so that a run leaves no /tmp/odk_tunableop_<pid>.csv behind."""
+    try:
+        import torch.cuda.tunable as tn
+        if _scratch_files:
+            tn.set_filename(os.devnull)
+            tn.tuning_enable(False)
+    except Exception:
+        pass
+    for f in _scratch_files:
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
+
+
+def _report_validators(tn, path: str) -> None:
+    """Says once whether the shipped selections apply: TunableOp silently ignores a file whose validators (PyTorch, HIP,
+    hipBLASLt, rocBLAS builds, arch) differ from the running stack and tunes from scratch instead."""
+    global _reported_validators
+    if _reported_validators:
+        return
+    _reported_validators = True
+    try:
+        mine = {str(k): str(v) for k, v in tn.get_validators()}
+        theirs = {}
+        with open(path) as f:
+            for line in f:
+                c = line.rstrip("\n").split(",", 2)
+                if c[0] == "Validator" and len(c) == 3:
+                    theirs[c[1]] = c[2]
+        bad = {k: (v, mine.get(k)) for k, v in theirs.items() if mine.get(k) != v}
+        if bad:
+            print(f"[ppo] shipped GEMM selections NOT applied (validator mismatch {bad}): tuning during warm-up instead")
+        else:
+            print(f"[ppo] shipped GEMM selections applied ({os.path.basename(path)}, validators match)")
+    except Exception as e:
+        print(f"[ppo] could not compare GEMM selection validators ({type(e).__name__}: {e})")
+
+
+def tunable_off() -> None:
+    """Turns TunableOp off again (it is process-wide): called when the learner / training loop is torn down."""
+    try:
+        import torch.cuda.tunable as tn
+        tn.tuning_enable(False)
+        tn.enable(False)
+    except Exception:
+        pass
+
+
 def _tunable(tuning: bool) -> bool:
     """hipBLASLt / rocBLAS kernel selection measured on this GPU for the learner's 30 GEMM shapes (PyTorch TunableOp):
     the library heuristics pick stream-K 32x32 tiles for the K = 5120 weight-gradient GEMMs (30-36 us each); the tuned
@@ -56,9 +111,15 @@ def _tunable(tuning: bool) -> bool:
             path = os.environ.get("ODK_TUNABLEOP_FILE")
             if not path:                            # per-process scratch copy: the shipped asset is never written to
                 path = os.path.join(tempfile.gettempdir(), f"odk_tunableop_{os.getpid()}.csv")
+                if path not in _scratch_files:
+                    import atexit
+                    if not _scratch_files:
+                        atexit.register(_cleanup_tunableop)
+                    _scratch_files.append(path)
                 if os.path.exists(_TUNED_ASSET) and os.environ.get("ODK_TUNABLEOP_PRETUNED", "1") == "1":
                     import shutil
                     shutil.copyfile(_TUNED_ASSET, path)
+                    _report_validators(tn, path)
             tn.set_filename(path)
         tn.enable(True)
         tn.tuning_enable(tuning)
@@ -144,7 +205,10 @@ class _FlatMLP:
 class FlatLearner:
     KEYS = ("obs", "priv", "raw_action", "log_prob", "reward", "termination", "truncation")
 
-    def __init__(self, net: PPONetworks, cfg: Dict, B: int, T: int, world: int = 1, group=None, use_graph: bool = True):
+    def __init__(self, net: PPONetworks, cfg: Dict, B: int, T: int, world: int = 1, group=None, use_graph: bool = True,
+                 split_update=None):
+        """`split_update` (default: world > 1) runs the step as graph A (loss + gradients) -> all-reduce of the flat gradient
+        -> graph B (clip + Adam); tests force it at world size 1 to drive the RCCL stream hand-over on one GPU."""
         dev = next(net.parameters()).device
         if dev.type != "cuda":
             raise engine.OdkError("FlatLearner runs on the GPU only (the autograd path in train.py is the CPU reference)")
@@ -167,7 +231,9 @@ class FlatLearner:
         self.noise = z(n, A)
         self.vs, self.adv, self.stats = z(B, T), z(B, T), z(2)
         self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
-        self.losses = z(4)
+        self.losses = z(4)                          # running SUMS of (total, policy, value, entropy) over the steps since metrics()
+        self.nsteps = 0
+        self.split_update = world > 1 if split_update is None else bool(split_update)
         self.graph_a = self.graph_b = None
         self._gather = None; self._gather_src = ()
         self.side = torch.cuda.Stream() if os.environ.get("ODK_LEARNER_BRANCHES", "1") == "1" else None   # policy || value
@@ -195,7 +261,6 @@ class FlatLearner:
         baseline, boot = vals[:n], vals[n:]
         engine.gae(s["truncation"], s["termination"], s["reward"], baseline.view(B, T), boot, cfg["gae_lambda"], cfg["discounting"],
                    vs=self.vs, adv=self.adv, stats=self.stats)
-        self.losses.zero_()
         engine.ppo_head(zp[-1], s["raw_action"].view(n, -1), s["log_prob"].view(n), self.adv.view(n),
                         self.stats if cfg["normalize_advantage"] else None, self.vs.view(n), baseline, self.noise, self.dlogits,
                         self.dval_all[:n].view(n), self.losses, cfg["clipping_epsilon"], cfg["entropy_cost"], 1.0 / self.world)
@@ -244,12 +309,13 @@ class FlatLearner:
             _tunable(False)                         # keep the selected kernels, never tune inside a capture
         for t, k in zip((self.flat_p, self.m, self.v, self.acc), keep):
             t.copy_(k)                              # the warm-up steps must not train
+        self.losses.zero_()
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self._loss_and_grads()                  # the noise buffer is filled before each replay (_next_noise)
-            if self.world == 1:
+            if not self.split_update:
                 self._update()
-        if self.world > 1:
+        if self.split_update:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b):
                 self._update()
@@ -266,7 +332,8 @@ class FlatLearner:
         self._gather(idx)
 
     def step(self):
-        """One clipped-Adam step on the loaded minibatch; returns the 4 loss scalars (device tensor, no sync)."""
+        """One clipped-Adam step on the loaded minibatch.  The loss head ADDS this step's (total, policy, value, entropy)
+        to `self.losses` (no sync); `metrics()` turns the sums into means."""
         if self.graph_a is not None:
             self._next_noise()
             self.graph_a.replay()
@@ -274,15 +341,20 @@ class FlatLearner:
             if self.sample_noise:
                 self._draw_noise()
             self._loss_and_grads()
-            if self.world == 1:
+            if not self.split_update:
                 self._update()
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat_g, group=self.group)   # gradients were pre-scaled by 1/world in the loss head
+        if self.split_update:
+            if self.world > 1 or self.group is not None:
+                import torch.distributed as dist
+                # RCCL: the collective runs on the process group's own stream; c10d makes that stream wait for the current
+                # one (graph A) before it starts and, for a blocking call, the current stream wait for it afterwards, so
+                # graph B is ordered behind the reduced gradient without any host synchronisation.
+                dist.all_reduce(self.flat_g, group=self.group)   # gradients were pre-scaled by 1/world in the loss head
             if self.graph_b is not None:
                 self.graph_b.replay()
             else:
                 self._update()
+        self.nsteps += 1
         if _DEBUG_NONFINITE:
             self._debug_check()
         return self.losses
@@ -299,9 +371,23 @@ class FlatLearner:
             t = getattr(self, nm)
             print("   ", nm, bool(torch.isfinite(t).all()), float(t.abs().nan_to_num().max()), flush=True)
 
-    def metrics(self):
-        l = self.losses
-        return dict(total_loss=l[0].clone(), policy_loss=l[1].clone(), v_loss=l[2].clone(), entropy_loss=l[3].clone())
+    def metrics(self, reset: bool = True):
+        """Mean of the four losses over every minibatch step since the last reset, averaged over the data-parallel ranks
+        (brax reports the mean over all num_updates_per_batch x num_minibatches steps of the epoch and pmean's it)."""
+        l = self.losses / float(max(self.nsteps, 1))
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(l, group=self.group)
+            l /= self.world
+        if reset:
+            self.losses.zero_()
+            self.nsteps = 0
+        return dict(total_loss=l[0], policy_loss=l[1], v_loss=l[2], entropy_loss=l[3])
+
+    def close(self):
+        """Drops the captured graphs and turns the process-wide TunableOp switch off again."""
+        self.graph_a = self.graph_b = None
+        tunable_off()
 
     def optimizer_state(self):
         return dict(m=self.m.clone(), v=self.v.clone(), acc=self.acc.clone())

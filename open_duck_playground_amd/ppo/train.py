@@ -95,9 +95,40 @@ def clip_by_global_norm(params, max_norm: float):
     return norm
 
 
-def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Generator, world: int = 1, group=None, learner=None):
+class LossMeter:
+    """Mean of the loss scalars over every SGD step since the last reset (brax returns the metrics of all
+    num_updates_per_batch x num_minibatches steps of every training step of the epoch and averages them; with several
+    ranks they are pmean'ed as well)."""
+    KEYS = ("total_loss", "policy_loss", "v_loss", "entropy_loss")
+
+    def __init__(self):
+        self.sum, self.n = None, 0
+
+    def add(self, metrics: Dict[str, torch.Tensor]):
+        v = torch.stack([metrics[k].detach().float() for k in self.KEYS])
+        self.sum = v if self.sum is None else self.sum + v
+        self.n += 1
+
+    def mean(self, world: int = 1, group=None, reset: bool = True) -> Dict[str, torch.Tensor]:
+        if self.sum is None:
+            return {}
+        v = self.sum / float(self.n)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(v, group=group)
+            v = v / world
+        if reset:
+            self.sum, self.n = None, 0
+        return {k: v[i] for i, k in enumerate(self.KEYS)}
+
+
+def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Generator, world: int = 1, group=None, learner=None,
+              meter: Optional[LossMeter] = None):
     """num_updates_per_batch x num_minibatches clipped-Adam steps over one rollout ([B, T, ...] per rank).
-    With a `learner` (ppo.learner.FlatLearner, GPU) every step is one HIP-graph replay; otherwise autograd."""
+    With a `learner` (ppo.learner.FlatLearner, GPU) every step is one HIP-graph replay; otherwise autograd.
+    Returns the mean losses over this call's steps (averaged over the ranks).  With a `meter` nothing is reduced or returned:
+    the sums keep running (in the meter, or in the learner) until the caller asks for the mean -- `train` does so once per
+    epoch, like brax."""
     B = data["reward"].shape[0]
     nmb = cfg["num_minibatches"]
     if learner is not None:
@@ -108,9 +139,10 @@ def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Gen
             for mbi in perm.chunk(nmb):
                 learner.load_minibatch(prep, mbi)
                 learner.step()
-        return learner.metrics()
+        return learner.metrics() if meter is None else None
     params = [p for p in net.parameters() if p.requires_grad]
-    metrics = {}
+    own = meter is None
+    meter = LossMeter() if own else meter
     for _ in range(cfg["num_updates_per_batch"]):
         perm = torch.randperm(B, generator=gen, device=data["reward"].device)
         for mbi in perm.chunk(nmb):
@@ -123,7 +155,8 @@ def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Gen
             if cfg.get("max_grad_norm"):
                 clip_by_global_norm(params, cfg["max_grad_norm"])
             opt.step()
-    return metrics
+            meter.add(metrics)
+    return meter.mean(world, group) if own else None
 
 
 def make_learner(net, data, cfg, world: int = 1, group=None):
@@ -187,7 +220,7 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
     gen = torch.Generator(device=dev); gen.manual_seed(seed * 1000 + rank)
     learner = None
     if randomization_fn is not None:
-        randomization_fn(environment)
+        _randomize(randomization_fn, environment, 0)
     n_local = environment.num_envs
     steps_per_iter = n_local * world * cfg["unroll_length"] * cfg["action_repeat"]
     num_evals_after_init = max(cfg["num_evals"] - 1, 1)
@@ -198,7 +231,7 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
         if eval_env is None and hasattr(environment, "make_eval_env"):
             eval_env = environment.make_eval_env(cfg.get("num_eval_envs", 128))
             if randomization_fn is not None:
-                randomization_fn(eval_env)
+                _randomize(randomization_fn, eval_env, 1)    # its own draws, not a copy of the first training envs'
         if eval_env is not None:
             from .evaluator import Evaluator
             evaluator = Evaluator(eval_env, cfg["episode_length"], cfg["action_repeat"])
@@ -208,8 +241,13 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
     log = open(log_path, "a") if (log_path and rank == 0) else None
     t0 = time.time(); done_steps = 0; metrics = {}
 
+    eval_count = 0
+
     def report(training_metrics):
-        m = evaluator.run_evaluation(net, training_metrics, seed=seed + 1) if evaluator is not None else dict(training_metrics)
+        nonlocal eval_count
+        # brax's Evaluator splits its key on every run: each evaluation gets fresh initial states, commands and pushes
+        m = evaluator.run_evaluation(net, training_metrics, seed=seed + 1 + eval_count) if evaluator is not None else dict(training_metrics)
+        eval_count += 1
         if rank == 0:
             if log:
                 log.write(json.dumps({"step": done_steps, **m}) + "\n"); log.flush()
@@ -221,21 +259,25 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
         metrics = report({})
     state = environment.reset(seed)
     reset_count = 0
+    meter = LossMeter()
+    grp = dist.group.WORLD if world > 1 else None
     for epoch in range(num_evals_after_init):
         t_epoch = time.time()
         for _ in range(resets):
             for _ in range(iters_per_epoch):
                 data, state = rollout(environment, net, state, cfg["unroll_length"], gen)
                 if cfg["normalize_observations"]:
-                    grp = dist.group.WORLD if world > 1 else None
                     net.norm_obs.update(data["obs"], grp); net.norm_priv.update(data["priv"], grp)
                 if learner is None and done_steps == 0:
                     learner = make_learner(net, data, cfg, world)
-                loss_metrics = sgd_epoch(net, opt, data, cfg, gen, world, learner=learner)
+                sgd_epoch(net, opt, data, cfg, gen, world, grp, learner=learner, meter=meter)
                 done_steps += steps_per_iter
             if cfg["num_resets_per_eval"] > 0:
                 reset_count += 1
                 state = environment.reset(seed + 7919 * reset_count)
+        loss_metrics = learner.metrics() if learner is not None else meter.mean(world, grp)
+        if world > 1:
+            assert_replicas_identical(net, grp)
         ep_rew = (data["reward"].sum(1)).mean()
         m = torch.stack([ep_rew, data["done"].mean()])
         if world > 1:
@@ -251,7 +293,36 @@ def train(environment, num_timesteps: int, progress_fn: Optional[Callable] = Non
             policy_params_fn(done_steps, net)
     if log:
         log.close()
+    if learner is not None:
+        learner.close()
     return net, metrics
+
+
+def _randomize(randomization_fn: Callable, env, stream: int):
+    """`randomization_fn(env, stream)`: stream 0 = the training envs, 1 = the evaluation envs (distinct draws).  One-argument
+    callables are still accepted."""
+    import inspect
+    try:
+        two = len(inspect.signature(randomization_fn).parameters) >= 2
+    except (TypeError, ValueError):
+        two = False
+    return randomization_fn(env, stream) if two else randomization_fn(env)
+
+
+@torch.no_grad()
+def assert_replicas_identical(net: PPONetworks, group=None):
+    """Data-parallel invariant: parameters and normaliser statistics are BIT-identical on every rank (same initial values,
+    all-reduced gradients and moments, fixed-order reductions).  Two all-reduces (min / max of the bit patterns) of ~2 MB
+    once per epoch; raises on the first divergence instead of training replicas that silently drift apart."""
+    import torch.distributed as dist
+    flat = torch.cat([t.detach().reshape(-1).float() for t in list(net.parameters()) + [b for b in net.buffers() if b.dtype == torch.float32]])
+    bits = flat.view(torch.int32)
+    lo, hi = bits.clone(), bits.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    bad = int((lo != hi).sum())
+    if bad:
+        raise RuntimeError(f"data-parallel replicas diverged: {bad} of {bits.numel()} parameter / normaliser words differ across ranks")
 
 
 def save_checkpoint(path: str, net: PPONetworks):

@@ -35,11 +35,12 @@ class OpenDuckMiniV2Runner:
         self.env = available_envs[args.env](task=args.task, num_envs=n_local, device=device, env_id_offset=self.rank * n_local)
         self.action_size = self.env.action_size
         self.obs_size = int(self.env.observation_size["state"][0])
-        self.randomizer = None if args.no_randomize else (lambda env: env.randomize(np.random.default_rng(args.seed + 7919 * self.rank)))
+        # one generator per (seed, rank, stream): stream 0 = training envs, 1 = evaluation envs (ppo/train.py)
+        self.randomizer = None if args.no_randomize else (lambda env, stream=0: env.randomize(np.random.default_rng([args.seed, self.rank, stream])))
         self.ppo = ppo_train
         print(f"Observation size: {self.obs_size}")
 
-    def progress_callback(self, num_steps, metrics):
+    def progress_callback(self, num_steps, metrics):   # rank 0 only (ppo/train.py)
         for name, value in metrics.items():   # reference common/runner.py:58-60
             self.writer.add_scalar(name, value, num_steps)
         self.writer.flush()
@@ -57,13 +58,24 @@ class OpenDuckMiniV2Runner:
         export_onnx(net, output_path=f"{self.output_dir}/{d}_{current_step}.onnx")
 
     def train(self):
-        os.makedirs(self.output_dir, exist_ok=True)
-        from .tb_writer import SummaryWriter
-        self.writer = SummaryWriter(self.output_dir)   # reference common/runner.py:38-39 (tensorboardX)
-        return self.ppo.train(self.env, num_timesteps=self.args.num_timesteps, progress_fn=self.progress_callback,
-                              policy_params_fn=self.policy_params_fn, restore_checkpoint_path=self.args.restore_checkpoint_path,
-                              seed=self.args.seed, randomization_fn=self.randomizer, log_path=os.path.join(self.output_dir, "metrics.jsonl"),
-                              num_envs=self.args.num_envs)
+        self.writer = None
+        if self.rank == 0:   # one writer, one output directory: the other ranks only train
+            os.makedirs(self.output_dir, exist_ok=True)
+            from .tb_writer import SummaryWriter
+            self.writer = SummaryWriter(self.output_dir)   # reference common/runner.py:38-39 (tensorboardX)
+        try:
+            return self.ppo.train(self.env, num_timesteps=self.args.num_timesteps, progress_fn=self.progress_callback,
+                                  policy_params_fn=self.policy_params_fn, restore_checkpoint_path=self.args.restore_checkpoint_path,
+                                  seed=self.args.seed, randomization_fn=self.randomizer, log_path=os.path.join(self.output_dir, "metrics.jsonl"),
+                                  num_envs=self.args.num_envs)
+        finally:
+            if self.writer is not None:
+                self.writer.close()
+
+    def close(self):
+        import torch.distributed as dist
+        if self.world > 1 and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def main():
@@ -79,7 +91,10 @@ def main():
     parser.add_argument("--no_randomize", action="store_true")
     args = parser.parse_args()
     runner = OpenDuckMiniV2Runner(args)
-    runner.train()
+    try:
+        runner.train()
+    finally:
+        runner.close()
 
 
 if __name__ == "__main__":

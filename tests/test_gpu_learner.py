@@ -177,3 +177,105 @@ def test_policy_sample_kernel_matches_the_torch_distribution():
         torch.testing.assert_close(raw, raw_ref, rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(act, torch.tanh(raw_ref), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(logp, tanh_normal_log_prob(loc, scale, raw_ref), rtol=1e-4, atol=2e-3)
+
+
+def test_learner_metrics_are_means_over_all_steps_since_the_last_call():
+    """brax reports the mean loss over all SGD steps of an epoch: the loss head adds into running sums, metrics() divides
+    by the step count and resets."""
+    from open_duck_playground_amd.ppo import train as T
+    from open_duck_playground_amd.ppo.learner import FlatLearner, prepare_rollout
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    dev = torch.device("cuda")
+    torch.manual_seed(2)
+    net = PPONetworks(101, 212, 14).to(dev)
+    cfg = T.ppo_config(); cfg["tune_gemms"] = False
+    data = _fake_rollout(64, 20, dev, seed=4)
+    net.norm_obs.update(data["obs"]); net.norm_priv.update(data["priv"])
+    lr = FlatLearner(net, cfg, 16, 20, use_graph=True)
+    assert float(lr.losses.abs().sum()) == 0.0                 # the capture warm-up steps leave no loss behind
+    prep = prepare_rollout(net, data, cfg)
+    per_step = []
+    for k in range(4):
+        lr.load_minibatch(prep, torch.arange(k * 16, k * 16 + 16, device=dev))
+        before = lr.losses.clone()
+        lr.step()
+        per_step.append(lr.losses - before)
+    m = lr.metrics()
+    ref = torch.stack(per_step).mean(0)
+    got = torch.stack([m["total_loss"], m["policy_loss"], m["v_loss"], m["entropy_loss"]])
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
+    assert lr.nsteps == 0 and float(lr.losses.abs().sum()) == 0.0
+    assert torch.stack(per_step)[:, 2].std() > 0               # the steps differ, so a mean is not the last step's value
+
+
+def test_split_update_over_rccl_matches_the_single_graph_step():
+    """The data-parallel step (graph A: loss + gradients -> RCCL all-reduce of the flat gradient on the process group's
+    stream -> graph B: clip + Adam) on the real `nccl` backend.  One GPU admits one rank, so the group has world size 1
+    (the all-reduce is the identity): what is pinned is the stream hand-over graph -> collective -> graph without host
+    synchronisation -- parameters after 6 steps are bit-identical to the single-graph learner fed the same noise."""
+    import os
+    import torch.distributed as dist
+    from open_duck_playground_amd.ppo import train as T
+    from open_duck_playground_amd.ppo.learner import FlatLearner, prepare_rollout
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    dev = torch.device("cuda", 0)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(32500 + os.getpid() % 2000)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = T.ppo_config(); cfg["tune_gemms"] = False
+        data = _fake_rollout(64, 20, dev, seed=6)
+        nets = []
+        for _ in range(2):
+            torch.manual_seed(3)
+            n = PPONetworks(101, 212, 14).to(dev)
+            n.norm_obs.update(data["obs"], dist.group.WORLD); n.norm_priv.update(data["priv"], dist.group.WORLD)
+            nets.append(n)
+        one = FlatLearner(nets[0], cfg, 16, 20)
+        two = FlatLearner(nets[1], cfg, 16, 20, world=1, group=dist.group.WORLD, split_update=True)
+        assert one.graph_b is None and two.graph_b is not None
+        prep = prepare_rollout(nets[0], data, cfg)
+        for k in range(6):
+            idx = torch.arange((k % 4) * 16, (k % 4) * 16 + 16, device=dev)
+            for lr in (one, two):
+                lr.load_minibatch(prep, idx)
+            one.step()
+            two._pool, two._pool_k = one._pool, one._pool_k - 1        # same entropy noise
+            two.step()
+        T.assert_replicas_identical(nets[1], dist.group.WORLD)
+        torch.cuda.synchronize()
+        assert torch.equal(one.flat_p, two.flat_p) and torch.equal(one.m, two.m)
+        assert float(two.acc[1]) == 6.0 and torch.isfinite(two.flat_p).all()
+        m1, m2 = one.metrics(), two.metrics()
+        assert abs(float(m1["v_loss"]) - float(m2["v_loss"])) < 1e-6
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_gather_refuses_bad_indices():
+    from open_duck_playground_amd import engine
+    src = torch.arange(40, dtype=torch.float32, device="cuda").view(10, 4)
+    dst = torch.zeros(3, 4, device="cuda")
+    g = engine.RowGather([(src, dst)])
+    g(torch.tensor([7, 0, 9], device="cuda"))
+    assert dst.tolist() == [src[7].tolist(), src[0].tolist(), src[9].tolist()]
+    for bad in (torch.tensor([7, 0, 9], device="cuda", dtype=torch.int32), torch.tensor([7, 0, 9]), torch.tensor([1, 2], device="cuda"),
+                torch.arange(6, device="cuda")[::2]):
+        with pytest.raises(engine.OdkError):
+            g(bad)
+    g(torch.tensor([1, 10, -1], device="cuda"))                # out of range: NaN rows, never an out-of-bounds read
+    assert dst[0].tolist() == src[1].tolist() and torch.isnan(dst[1:]).all()
+    with pytest.raises(engine.OdkError):
+        engine.RowGather([(src, dst), (torch.zeros(9, 4, device="cuda"), torch.zeros(3, 4, device="cuda"))])
+
+
+def test_gae_treats_any_nonzero_flag_as_set_in_every_kernel():
+    from open_duck_playground_amd import engine
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for B, Tn in ((256, 20), (300, 20), (1200, 40)):           # LDS-staged, register-staged, generic
+        rew, val = torch.randn(B, Tn, device="cuda", generator=g), torch.randn(B, Tn, device="cuda", generator=g)
+        boot = torch.randn(B, device="cuda", generator=g)
+        term = (torch.rand(B, Tn, device="cuda", generator=g) < 0.1).float()
+        trunc = (torch.rand(B, Tn, device="cuda", generator=g) < 0.05).float() * (1 - term)
+        a = engine.gae(trunc, term, rew, val, boot, 0.95, 0.97)
+        b = engine.gae(trunc * 3.0, term * 0.25, rew, val, boot, 0.95, 0.97)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

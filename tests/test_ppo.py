@@ -94,7 +94,21 @@ def _dist_worker(rank, world, port, out):
     net.norm_obs.update(data["obs"], dist.group.WORLD); net.norm_priv.update(data["priv"], dist.group.WORLD)
     cfg = T.ppo_config(); cfg.update(num_minibatches=4, num_updates_per_batch=2)
     opt = torch.optim.Adam(net.parameters(), 1e-3)
-    T.sgd_epoch(net, opt, data, cfg, torch.Generator().manual_seed(7), world=world)
+    m = T.sgd_epoch(net, opt, data, cfg, torch.Generator().manual_seed(7), world=world, group=dist.group.WORLD)
+    T.assert_replicas_identical(net, dist.group.WORLD)          # passes: gradients and moments were all-reduced
+    ml = [torch.zeros(()) for _ in range(world)]
+    dist.all_gather(ml, m["total_loss"])
+    assert torch.equal(ml[0], ml[1])                            # the reported losses are means over the ranks
+    if rank == 1:
+        net.policy.layers[0].bias.data[0] += 1e-3
+    try:
+        T.assert_replicas_identical(net, dist.group.WORLD)
+        diverged = False
+    except RuntimeError:
+        diverged = True
+    assert diverged                                             # ... and a drifting replica is caught on every rank
+    if rank == 1:
+        net.policy.layers[0].bias.data[0] -= 1e-3
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -178,6 +192,40 @@ def test_train_loop_epochs_evaluator_and_callbacks(tmp_path):
     import json
     lines = [json.loads(l) for l in open(tmp_path / "m.jsonl")]
     assert [l["step"] for l in lines] == [0, 1280, 2560, 3840]
+
+
+def test_loss_meter_and_sgd_epoch_report_means_over_all_steps():
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(0)
+    net = PPONetworks(101, 212, 14, (32, 16), (32, 16))
+    data = _fake_rollout(32, 6, gen)
+    cfg = T.ppo_config(); cfg.update(num_minibatches=4, num_updates_per_batch=2)
+    opt = torch.optim.Adam(net.parameters(), 1e-3)
+    meter = T.LossMeter()
+    assert T.sgd_epoch(net, opt, data, cfg, gen, meter=meter) is None and meter.n == 8     # sums keep running in the meter
+    T.sgd_epoch(net, opt, data, cfg, gen, meter=meter)
+    assert meter.n == 16
+    m = meter.mean()
+    assert set(m) == set(T.LossMeter.KEYS) and meter.n == 0 and meter.mean() == {}
+    torch.testing.assert_close(m["total_loss"], m["policy_loss"] + m["v_loss"] + m["entropy_loss"], rtol=1e-5, atol=1e-6)
+    own = T.sgd_epoch(net, opt, data, cfg, gen)                 # without a meter: the mean over this call's 8 steps
+    assert set(own) == set(T.LossMeter.KEYS)
+
+
+def test_every_evaluation_gets_its_own_seed_and_the_eval_envs_their_own_randomisation():
+    env = _ToyEnv(32)
+    seeds, streams = [], []
+    ev = _ToyEnv(8, seed=99)
+    real_reset = ev.reset
+    ev.reset = lambda seed: (seeds.append(seed), real_reset(seed))[1]
+    T.train(env, num_timesteps=32 * 5 * 6, seed=11, eval_env=None, num_evals=4, unroll_length=5, num_minibatches=4, num_updates_per_batch=1,
+            episode_length=10, num_eval_envs=8, randomization_fn=lambda e, stream: streams.append((e.num_envs, stream)),
+            network_factory=dict(policy_hidden_layer_sizes=(8,), value_hidden_layer_sizes=(8,)))
+    assert streams == [(32, 0), (8, 1)]                         # training envs: stream 0, evaluation envs: stream 1
+    env2 = _ToyEnv(32)
+    T.train(env2, num_timesteps=32 * 5 * 6, seed=11, eval_env=ev, num_evals=4, unroll_length=5, num_minibatches=4, num_updates_per_batch=1,
+            episode_length=10, num_eval_envs=8, network_factory=dict(policy_hidden_layer_sizes=(8,), value_hidden_layer_sizes=(8,)))
+    assert seeds == [12, 13, 14, 15]                            # seed + 1 + evaluation index
 
 
 def test_tensorboard_writer_round_trip(tmp_path):
