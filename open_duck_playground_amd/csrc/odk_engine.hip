@@ -727,6 +727,65 @@ static void pack_imp(const float* solref, const float* solimp, float dt, float* 
   P[7] = 1.0f / powf(mid, power - 1.0f); P[8] = 1.0f / powf(1.0f - mid, power - 1.0f);
 }
 
+// Twin-dof detection and the reduced (twins merged) tree layout -- see DevModel::paired.  Called after the dof / joint /
+// foot tables are in place.  Leaves m.paired = 0 when the model has no twins or does not have the "floating base + up to
+// three serial chains of <= 5 reduced dofs" form the in-register chain solver is built for.
+static void build_reduced_tables(DevModel& m) {
+  m.paired = 0; m.nvr = m.nv; m.nMr = 0; m.nrchain = 0;
+  int ntwin = 0;
+  for (int d = 0; d < MAXV; d++) { m.dof_twin[d] = -1; m.dof_tkind[d] = 0; m.dof_red[d] = -1; }
+  for (int v = 7; v < m.nv; v++) {
+    const int u = v - 1, ju = m.dof_jnt[u], jv = m.dof_jnt[v];
+    if (ju < 0 || jv < 0 || m.dof_tkind[u] != 0) continue;
+    const bool same = m.dof_body[u] == m.dof_body[v] && m.dof_anc[v][1] == u && m.jnt_axis[ju][0] == m.jnt_axis[jv][0] &&
+                      m.jnt_axis[ju][1] == m.jnt_axis[jv][1] && m.jnt_axis[ju][2] == m.jnt_axis[jv][2];   // jnt_pos == 0 for every hinge (checked by the caller)
+    if (!same) continue;
+    m.dof_twin[u] = v; m.dof_twin[v] = u; m.dof_tkind[u] = 1; m.dof_tkind[v] = 2; ntwin++;
+  }
+  if (ntwin == 0) return;
+  int nr = 0;
+  for (int d = 0; d < m.nv; d++) {
+    if (m.dof_tkind[d] == 2) { m.dof_red[d] = m.dof_red[m.dof_twin[d]]; continue; }
+    m.dof_red[d] = nr; m.red_main[nr] = d; m.red_twin[nr] = m.dof_tkind[d] == 1 ? m.dof_twin[d] : -1; nr++;
+  }
+  m.nvr = nr;
+  int rparent[MAXV], n = 0;
+  for (int r = 0; r < nr; r++) {
+    const int p = m.dof_anc[m.red_main[r]][1];   // -1 at the root
+    rparent[r] = p < 0 ? -1 : m.dof_red[p];
+    m.red_depth[r] = rparent[r] < 0 ? 0 : m.red_depth[rparent[r]] + 1;
+    m.red_Madr[r] = n;
+    n += m.red_depth[r] + 1;
+  }
+  if (n > MAXNZ) return;
+  m.nMr = n;
+  for (int r = 0; r < nr; r++) {
+    const int u = m.red_main[r];
+    const int fi = m.foot_dofmask[0][u] | (m.foot_dofmask[1][u] << 1);
+    int a = r;
+    for (int c = m.red_depth[r]; c >= 0; c--, a = rparent[a]) {   // column = reduced ancestor at depth c
+      const int ua = m.red_main[a];
+      const int fj = m.foot_dofmask[0][ua] | (m.foot_dofmask[1][ua] << 1);
+      const bool diag = a == r, pair = diag && m.red_twin[r] >= 0;
+      const int src = pair ? m.dof_Madr[m.red_twin[r]] + m.dof_depth[u] : m.dof_Madr[u] + m.dof_depth[ua];
+      m.R_ent[m.red_Madr[r] + c] = src | (u << 9) | (ua << 14) | (fi << 19) | (fj << 21) | ((int)diag << 23) | ((int)pair << 24);
+    }
+  }
+  // reduced chains below the floating base
+  int d = 6;
+  bool ok = nr > 6;
+  for (int r = 0; r < 6 && ok; r++) ok = rparent[r] == r - 1;
+  while (ok && d < nr) {
+    if (rparent[d] != 5 || m.nrchain == 3) { ok = false; break; }
+    int e = d;
+    while (e + 1 < nr && rparent[e + 1] == e) e++;
+    m.rchain_first[m.nrchain] = d; m.rchain_len[m.nrchain] = e - d + 1; m.nrchain++;
+    if (e - d + 1 > 5) ok = false;
+    d = e + 1;
+  }
+  m.paired = ok ? 1 : 0;
+}
+
 extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   if (!blob || !out || len < 16 || memcmp(blob, "ODKM", 4) != 0) return fail(ODK_ERR_INVALID, "odk_model_load: not an ODKM blob");
   Blob B{(const unsigned char*)blob, len};
@@ -839,6 +898,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     m.M_ent[p] = i | (j << 5) | (fi << 10) | (fj << 12);
   }
   if (!B.ok || ncg != 3) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
+  build_reduced_tables(m);
   (void)nhv; (void)nhf;
   for (int f = 0; f < 2; f++) {
     int g = foot_cg[f];
@@ -926,6 +986,11 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   else if (fits(ShapeB::NQ, ShapeB::NV, ShapeB::NB, ShapeB::NU, ShapeB::NJ, ShapeB::NM, ShapeB::NH, ShapeB::NROW, ShapeB::DT, ShapeB::DV)) mo->shape = 1;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
+  if (mo->shape == 1 && !(m.paired && m.nvr == ShapeB::NVR && m.nMr == ShapeB::NMR)) {
+    delete mo;
+    return fail(ODK_ERR_UNSUPPORTED, "the 30-dof kernels expect backlash twins (same body, anchor and axis as their joint) over the 20-dof tree");
+  }
+  if (mo->shape == 0 && m.paired) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "twin dofs in a model of the 20-dof shape"); }
   *out = mo;
   return ODK_OK;
 }
@@ -1046,6 +1111,13 @@ template <class S, int G, bool HF> static hipError_t launch_sg(int which, const 
   return hipGetLastError();
 }
 static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st) {
+#if defined(ODK_DEV_B32)   // development builds: one instantiation only (make libodk_devB.so / libodk_devA.so: ~25 s instead of 2 min)
+  if (b->model.shape == 1 && b->model.h.floor_is_plane && b->G == 32) return launch_sg<ShapeB, 32, false>(which, a, st);
+  return hipErrorNotSupported;
+#elif defined(ODK_DEV_A32)
+  if (b->model.shape == 0 && b->G == 32) return launch_sg<ShapeA, 32, false>(which, a, st);
+  return hipErrorNotSupported;
+#endif
   // height-field floors exist only with the backlash model (scene_rough_terrain_backlash.xml) and run 32 lanes per env
   if (!b->model.h.floor_is_plane) return launch_sg<ShapeB, 32, true>(which, a, st);
   if (b->model.shape == 0) return b->G == 64 ? launch_sg<ShapeA, 64, false>(which, a, st) : launch_sg<ShapeA, 32, false>(which, a, st);

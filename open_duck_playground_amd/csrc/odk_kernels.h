@@ -62,7 +62,12 @@ struct Shape {
   static constexpr int DT = DT_;    // max dof depth, kinematic tree
   static constexpr int DV = DV_;    // max dof depth, virtual (Hessian) tree
   static constexpr int NCROW = 48;  // contact rows
-  static constexpr int CL = (NV_ == 20) ? 5 : 0;   // max chain length for the in-register chain solver (0: generic path)
+  // Twin dofs (the backlash model, nv 30): solves run on the reduced tree -- twins merged into their main dof, which is
+  // the 20-dof robot's own tree (DevModel::paired; reduced_rhs / reduced_expand below).
+  static constexpr bool PAIRED = (NV_ == 30);
+  static constexpr int NVR = PAIRED ? 20 : NV_;    // reduced dofs
+  static constexpr int NMR = PAIRED ? 145 : NM_;   // entries of the reduced tree layout
+  static constexpr int CL = (NV_ == 20 || PAIRED) ? 5 : 0;   // max (reduced) chain length for the in-register chain solver (0: generic path)
   // persistent over the env step
   static constexpr int O_QPOS = 0;
   static constexpr int O_QVEL = O_QPOS + NQ;
@@ -294,6 +299,7 @@ struct Statics {
   int d_on, d_body, d_depth, d_Madr, d_ancmask, d_descmask, d_vdepth, d_vMadr, d_vancmask, d_vdescmask;
   int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
   int d_qadr, d_lim_on;                  // hinge qpos address (-1: free joint); has a limit row
+  int d_tkind, d_red;                    // twin dofs (DevModel::paired): 0 unpaired / 1 main (twin = dof + 1) / 2 twin; reduced dof
   float d_damping, d_lo, d_hi;           // joint range of the dof's hinge
 };
 // Phase-local statics: fetched from the model (L1/L2-resident, one batch of loads per phase and substep)
@@ -331,6 +337,8 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
   st.d_lim_on = st.d_limrow >= 0;
   st.d_qadr = m->dof_qadr[i];
   st.d_lo = m->dof_range[i][0]; st.d_hi = m->dof_range[i][1];
+  st.d_tkind = (S::PAIRED && st.d_on) ? m->dof_tkind[i] : 0;
+  st.d_red = S::PAIRED ? m->dof_red[i] : i;
 }
 template <class S>
 __device__ __forceinline__ void load_body(BodySt& b, const DevModel* __restrict__ m, int lane) {
@@ -548,9 +556,9 @@ __device__ __forceinline__ float solve_rows(const float* A, float xi, int lane, 
 // the three chains run in three lanes at once, lane 0 finishes the 6x6 base block with the chains' Schur
 // complements, and the chains back-substitute.  Two LDS hand-offs in total.  A is the tree layout (read only);
 // VEC holds b on entry and x on exit (LDS); XCH is >= 87 floats of LDS scratch.
+struct ChainSt { int c_len, c_idx, c_n, d_depth, d_Madr; };   // c_len > 0 on the lane of a chain's first dof; its depth / row address
 template <class S, int G>
-__device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* XCH,
-                                            const Statics<S, G>& st, int lane) {
+__device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* XCH, const ChainSt& st, int lane) {
   constexpr int CL = S::CL > 0 ? S::CL : 1;
   constexpr int NB6 = 6;
   const bool head = st.c_len > 0;
@@ -678,6 +686,50 @@ __device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* X
     }
   }
   ODK_SYNC();
+}
+
+// Solve (P Hr P^T + diag(d)) x = g for a model with twin dofs (DevModel::paired), d_i = ARM[i] (+ DX[i]):
+// with z = P^T x (one entry per reduced dof), E = P^T diag(1/d) P = diag(1/d_u + 1/d_v) and s = P^T diag(1/d) g,
+//     (Hr + E^-1) z = E^-1 s      -- the 20-dof robot's own system with the pair's series stiffness d_u d_v / (d_u + d_v) on
+//                                    the diagonal: ONE in-register chain solve instead of a 30-dof factorisation,
+//     x_i = (g_i - t_r) / d_i,  t = E^-1 (s - z)   (unpaired dofs: x = z).
+// HR: reduced matrix in the reduced tree layout with E^-1 already on the twin diagonals (LDS); GV: g per dof (LDS);
+// RV: NVR floats of LDS scratch; returns x of this lane's dof.
+template <class S, int G>
+__device__ __forceinline__ float paired_solve(const float* HR, const float* GV, float gi, const float* ARM, const float* DX, float* RV, float* XCH,
+                                              const DevModel* __restrict__ m, const Statics<S, G>& st, int lane) {
+  auto pair_terms = [&](int u, float& rhs, float& einv, float& du, float& dv) {   // twin = u + 1 (build_reduced_tables)
+    du = ARM[u] + (DX ? DX[u] : 0.0f); dv = ARM[u + 1] + (DX ? DX[u + 1] : 0.0f);
+    const float inv = __builtin_amdgcn_rcpf(du + dv);
+    rhs = (GV[u] * dv + GV[u + 1] * du) * inv;
+    einv = du * dv * inv;
+  };
+  ChainSt cst{0, 0, m->nrchain, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; c++) if (c < m->nrchain && lane == m->rchain_first[c]) { cst.c_len = m->rchain_len[c]; cst.c_idx = c; }
+  const int rl = lane < S::NVR ? lane : 0;
+  cst.d_depth = m->red_depth[rl]; cst.d_Madr = m->red_Madr[rl];
+  if (lane < S::NVR) {
+    const int u = m->red_main[lane];
+    float rhs = GV[u];
+    if (m->red_twin[lane] >= 0) { float einv, du, dv; pair_terms(u, rhs, einv, du, dv); }
+    RV[lane] = rhs;
+  }
+  ODK_SYNC();
+  chain_solve<S, G>(HR, RV, XCH, cst, lane);
+  float x = 0.0f;
+  if (st.d_on) {
+    const float z = RV[st.d_red];
+    x = z;
+    if (st.d_tkind != 0) {
+      const int u = st.d_tkind == 1 ? lane : lane - 1;
+      float rhs, einv, du, dv;
+      pair_terms(u, rhs, einv, du, dv);
+      const float t = rhs - einv * z;
+      x = (gi - t) * __builtin_amdgcn_rcpf(st.d_tkind == 1 ? du : dv);
+    }
+  }
+  return x;
 }
 
 // impedance / stiffness of one constraint row (mjx constraint._row); returns D = 1/R and aref
@@ -1300,10 +1352,26 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   ODK_PROF(4);
   // ---------------- P5: qacc_smooth = M^-1 qfrc_smooth; dense symmetric row of M into registers
   float qas;
-  if constexpr (S::CL > 0) {
+  if constexpr (S::PAIRED) {
+    // reduced inertia (twins merged) in the reduced tree layout: HL[0 .. NMR)
+#pragma unroll
+    for (int t = 0; t < (S::NMR + G - 1) / G; t++) {
+      const int p = lane + t * G;
+      if (p < S::NMR) {
+        const int e = m->R_ent[p];
+        float v = M[e & 511];
+        if ((e >> 24) & 1) { const int u = (e >> 9) & 31; const float du = ARM[u], dv = ARM[u + 1]; v += du * dv * __builtin_amdgcn_rcpf(du + dv); }
+        HL[p] = v;
+      }
+    }
+    ODK_SYNC();
+    ODK_PROF(5);
+    qas = paired_solve<S, G>(HL, QFS, qfs, ARM, nullptr, GRAD, SCR + S::S_K, m, st, lane);
+    if (st.d_on) QAS[lane] = qas;
+  } else if constexpr (S::CL > 0) {
     if (st.d_on) QAS[lane] = qfs;
     ODK_SYNC();
-    chain_solve<S, G>(M, QAS, SCR + S::S_K, st, lane);
+    chain_solve<S, G>(M, QAS, SCR + S::S_K, ChainSt{st.c_len, st.c_idx, st.c_n, st.d_depth, st.d_Madr}, lane);
     ODK_PROF(5);
     qas = st.d_on ? QAS[lane] : 0.0f;
   } else {
@@ -1727,7 +1795,44 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   ODK_PROF(11);
   const bool any_ffa = __builtin_amdgcn_ballot_w64(ff_active) != 0;   // wave-uniform: some env has an active foot-foot row
   float search;
-  if (!any_ffa) {
+  if (S::PAIRED && !any_ffa) {
+    // ---- common case, model with twin dofs: reduced Hessian (twins merged) on the reduced tree, one chain solve
+#pragma unroll
+    for (int t = 0; t < (S::NMR + G - 1) / G; t++) {
+      const int p = lane + t * G;
+      if (p < S::NMR) {
+        const int e = m->R_ent[p];
+        const int i = (e >> 9) & 31, j = (e >> 14) & 31, fi = (e >> 19) & 3, fj = (e >> 21) & 3;
+        float v = M[e & 511];
+        if ((e >> 23) & 1) {
+          if ((e >> 24) & 1) { const float du = ARM[i] + JV[i], dv = ARM[i + 1] + JV[i + 1]; v += du * dv * __builtin_amdgcn_rcpf(du + dv); }
+          else v += JV[i];
+        }
+        const int both = fi & fj;
+        if (both) {
+          float cj[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NV + j];
+          if (both & 1) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += cj[k] * BUF6[k * NV + i];
+          }
+          if (both & 2) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) v += cj[k] * BUF6B[k * NV + i];
+          }
+        }
+        HL[p] = v;
+      }
+    }
+    if (st.d_on) { MA[lane] = grad; GRAD[lane] = grad; }
+    ODK_SYNC();
+    ODK_PROF(12);
+    search = -paired_solve<S, G>(HL, GRAD, grad, ARM, JV, MV, SCR + S::S_K, m, st, lane);
+    ODK_PROF(13);
+    ODK_SYNC();   // every lane has read its GRAD / JV inputs before the line search overwrites them
+    ODK_PROF(14);
+  } else if (!any_ffa) {
     // ---- common case: no foot-foot coupling -> the Hessian has the inertia's own tree pattern
 #pragma unroll
     for (int t = 0; t < ST::NME; t++) {
@@ -1758,7 +1863,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     ODK_SYNC();
     ODK_PROF(12);
     if constexpr (S::CL > 0) {
-      chain_solve<S, G>(HL, GRAD, SCR + S::S_K, st, lane);
+      chain_solve<S, G>(HL, GRAD, SCR + S::S_K, ChainSt{st.c_len, st.c_idx, st.c_n, st.d_depth, st.d_Madr}, lane);
       ODK_PROF(13);
       search = st.d_on ? -GRAD[lane] : 0.0f;
     } else {   // generic tree: the inertia's own (shallower) row layout instead of the virtual tree's

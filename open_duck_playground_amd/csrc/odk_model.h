@@ -47,6 +47,20 @@ struct DevModel {
   int M_i[MAXNZ], M_j[MAXNZ];
   int M_ent[MAXNZ];   // packed entry: i | j << 5 | feet moved by dof i << 10 | feet moved by dof j << 12
   int nchain, chain_first[3], chain_len[3];   // tree of chains below the floating base (0 chains: generic tree)
+  // Twin dofs (backlash joints): a hinge v declared right after hinge u on the same body, same anchor, same axis, has the
+  // same motion column, cdof_v == cdof_u, so M = P Mr P^T + diag(armature) with P copying each reduced column onto the
+  // pair (and likewise the Newton Hessian: contact rows see the pair through the same column, friction-loss / limit rows are
+  // diagonal).  The kernels then solve on the REDUCED tree (twins merged into their main dof; odk_engine.hip:
+  // build_reduced_tables, odk_kernels.h: reduced_solve).  paired = 0: no twins / structure not recognised.
+  int paired, nvr, nMr;
+  int dof_twin[MAXV];        // partner dof (-1: none)
+  int dof_tkind[MAXV];       // 0: unpaired, 1: main dof of a pair, 2: twin
+  int dof_red[MAXV];         // reduced dof of this dof (a twin shares its main dof's)
+  int red_main[MAXV], red_twin[MAXV], red_depth[MAXV], red_Madr[MAXV];
+  int nrchain, rchain_first[3], rchain_len[3];
+  int R_ent[MAXNZ];          // reduced entry p: address in M (9 bits; twin diagonals: entry (twin, main), which carries no
+                             // armature) | main dof i << 9 | main dof j << 14 | feet of i << 19 | feet of j << 21 |
+                             // diagonal << 23 | pair << 24
   // virtual tree (Hessian)
   int vdof_depth[MAXV], vdof_anc[MAXV][MAXV], vdof_Madr[MAXV], vdof_anc_adr[MAXV][MAXV];
   int vdof_ndesc[MAXV], vdof_desc[MAXV][MAXV], vdof_desc_adr[MAXV][MAXV];
