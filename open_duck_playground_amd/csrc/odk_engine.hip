@@ -42,7 +42,7 @@ template <class S> struct EnvL {
   static constexpr int O_ACT = O_REF + 40;         // [16] this step's action
   static constexpr int O_PRIV = S::O_M;            // [212] aliases M|HL (dead after the last forward)
   static constexpr int TOTAL = O_ACT + 16;
-  static_assert(S::NM + S::NH >= ODK_NPRIV, "privileged obs must fit in the M|HL region");
+  static_assert(S::NMR + S::NHR >= ODK_NPRIV, "privileged obs must fit in the M|HL region");
 };
 
 using ShapeA = Shape<21, 20, 18, 14, 15, 145, 170, 76, 10, 15>;   // flat_terrain
@@ -727,48 +727,84 @@ static void pack_imp(const float* solref, const float* solimp, float dt, float* 
   P[7] = 1.0f / powf(mid, power - 1.0f); P[8] = 1.0f / powf(1.0f - mid, power - 1.0f);
 }
 
-// Twin-dof detection and the reduced (twins merged) tree layout -- see DevModel::paired.  Called after the dof / joint /
-// foot tables are in place.  Leaves m.paired = 0 when the model has no twins or does not have the "floating base + up to
-// three serial chains of <= 5 reduced dofs" form the in-register chain solver is built for.
-static void build_reduced_tables(DevModel& m) {
-  m.paired = 0; m.nvr = m.nv; m.nMr = 0; m.nrchain = 0;
+// Twin-dof detection and the reduced (twins merged) tree layouts -- see DevModel::paired.  Called after the dof / joint /
+// foot tables are in place.  Returns false when the reduced tree is not "floating base + up to three serial chains of <= 5
+// dofs" (the form the in-register chain solver is built for).
+namespace {
+struct SparseLayout { int depth[MAXV], adr[MAXV], ancmask[MAXV], descmask[MAXV], anc_at[MAXV][MAXV], nnz; };
+// rows in dof order; row i = entries for i's ancestors by depth (c = depth[i]: the diagonal) -- tables.py _sparse_layout
+void sparse_layout(const int* parent, int n, SparseLayout& L) {
+  L.nnz = 0;
+  for (int i = 0; i < n; i++) {
+    L.depth[i] = parent[i] < 0 ? 0 : L.depth[parent[i]] + 1;
+    L.adr[i] = L.nnz; L.nnz += L.depth[i] + 1;
+    L.ancmask[i] = 0; L.descmask[i] = 0;
+  }
+  for (int i = 0; i < n; i++) {
+    int a = i;
+    for (int c = L.depth[i]; c >= 0; c--, a = parent[a]) {
+      L.anc_at[i][c] = a;
+      if (a != i) { L.ancmask[i] |= 1 << a; L.descmask[a] |= 1 << i; }
+    }
+  }
+}
+}  // namespace
+static bool build_reduced_tables(DevModel& m) {
+  m.paired = 0; m.nrchain = 0;
   int ntwin = 0;
-  for (int d = 0; d < MAXV; d++) { m.dof_twin[d] = -1; m.dof_tkind[d] = 0; m.dof_red[d] = -1; }
+  for (int d = 0; d < MAXV; d++) { m.dof_tkind[d] = 0; m.dof_red[d] = 0; m.red_main[d] = 0; m.red_twin[d] = -1; }
   for (int v = 7; v < m.nv; v++) {
     const int u = v - 1, ju = m.dof_jnt[u], jv = m.dof_jnt[v];
     if (ju < 0 || jv < 0 || m.dof_tkind[u] != 0) continue;
     const bool same = m.dof_body[u] == m.dof_body[v] && m.dof_anc[v][1] == u && m.jnt_axis[ju][0] == m.jnt_axis[jv][0] &&
                       m.jnt_axis[ju][1] == m.jnt_axis[jv][1] && m.jnt_axis[ju][2] == m.jnt_axis[jv][2];   // jnt_pos == 0 for every hinge (checked by the caller)
     if (!same) continue;
-    m.dof_twin[u] = v; m.dof_twin[v] = u; m.dof_tkind[u] = 1; m.dof_tkind[v] = 2; ntwin++;
+    m.dof_tkind[u] = 1; m.dof_tkind[v] = 2; ntwin++;
   }
-  if (ntwin == 0) return;
+  m.paired = ntwin > 0;
   int nr = 0;
   for (int d = 0; d < m.nv; d++) {
-    if (m.dof_tkind[d] == 2) { m.dof_red[d] = m.dof_red[m.dof_twin[d]]; continue; }
-    m.dof_red[d] = nr; m.red_main[nr] = d; m.red_twin[nr] = m.dof_tkind[d] == 1 ? m.dof_twin[d] : -1; nr++;
+    if (m.dof_tkind[d] == 2) { m.dof_red[d] = m.dof_red[d - 1]; continue; }
+    m.dof_red[d] = nr; m.red_main[nr] = d; m.red_twin[nr] = m.dof_tkind[d] == 1 ? d + 1 : -1; nr++;
   }
   m.nvr = nr;
-  int rparent[MAXV], n = 0;
+  int rparent[MAXV], rvparent[MAXV];
   for (int r = 0; r < nr; r++) {
     const int p = m.dof_anc[m.red_main[r]][1];   // -1 at the root
     rparent[r] = p < 0 ? -1 : m.dof_red[p];
-    m.red_depth[r] = rparent[r] < 0 ? 0 : m.red_depth[rparent[r]] + 1;
-    m.red_Madr[r] = n;
-    n += m.red_depth[r] + 1;
-  }
-  if (n > MAXNZ) return;
-  m.nMr = n;
-  for (int r = 0; r < nr; r++) {
+    rvparent[r] = rparent[r];
     const int u = m.red_main[r];
-    const int fi = m.foot_dofmask[0][u] | (m.foot_dofmask[1][u] << 1);
-    int a = r;
-    for (int c = m.red_depth[r]; c >= 0; c--, a = rparent[a]) {   // column = reduced ancestor at depth c
-      const int ua = m.red_main[a];
-      const int fj = m.foot_dofmask[0][ua] | (m.foot_dofmask[1][ua] << 1);
-      const bool diag = a == r, pair = diag && m.red_twin[r] >= 0;
-      const int src = pair ? m.dof_Madr[m.red_twin[r]] + m.dof_depth[u] : m.dof_Madr[u] + m.dof_depth[ua];
-      m.R_ent[m.red_Madr[r] + c] = src | (u << 9) | (ua << 14) | (fi << 19) | (fj << 21) | ((int)diag << 23) | ((int)pair << 24);
+    m.red_foot[r] = m.foot_dofmask[0][u] | (m.foot_dofmask[1][u] << 1);
+  }
+  // virtual tree (tables.py): the second leg hangs below the first foot's last dof
+  {
+    int l_last = -1, r_first = -1;
+    for (int r = 0; r < nr; r++) {
+      if (m.red_foot[r] & 1) l_last = r;
+      if ((m.red_foot[r] & 2) && !(m.red_foot[r] & 1) && r_first < 0) r_first = r;
+    }
+    if (l_last >= 0 && r_first > l_last) rvparent[r_first] = l_last;
+  }
+  static SparseLayout T, V;   // model loading is not re-entrant anyway (thread-local error string aside)
+  sparse_layout(rparent, nr, T);
+  sparse_layout(rvparent, nr, V);
+  if (T.nnz > MAXNZ || V.nnz > MAXNZ) return false;
+  m.nMr = T.nnz; m.nHr = V.nnz;
+  for (int r = 0; r < nr; r++) {
+    m.red_depth[r] = T.depth[r]; m.red_Madr[r] = T.adr[r]; m.red_ancmask[r] = T.ancmask[r]; m.red_descmask[r] = T.descmask[r];
+    m.rv_depth[r] = V.depth[r]; m.rv_Madr[r] = V.adr[r]; m.rv_ancmask[r] = V.ancmask[r]; m.rv_descmask[r] = V.descmask[r];
+  }
+  auto pack = [&](int r, int a) {
+    const bool diag = a == r, pair = diag && m.red_twin[r] >= 0;
+    return r | (a << 5) | (m.red_foot[r] << 10) | (m.red_foot[a] << 12) | ((int)diag << 14) | ((int)pair << 15) | (m.red_main[r] << 16);
+  };
+  for (int r = 0; r < nr; r++) {
+    for (int c = 0; c <= T.depth[r]; c++) m.R_ent[T.adr[r] + c] = pack(r, T.anc_at[r][c]);
+    for (int c = 0; c <= V.depth[r]; c++) {
+      const int a = V.anc_at[r][c];
+      int src = -1;   // address of (r, a) in the true reduced layout, if a is a true ancestor (or r itself)
+      if (a == r || ((T.ancmask[r] >> a) & 1)) src = T.adr[r] + T.depth[a];
+      m.RH_ent[V.adr[r] + c] = pack(r, a) | ((src + 1) << 21);
     }
   }
   // reduced chains below the floating base
@@ -783,7 +819,15 @@ static void build_reduced_tables(DevModel& m) {
     if (e - d + 1 > 5) ok = false;
     d = e + 1;
   }
-  m.paired = ok ? 1 : 0;
+  if (ok && !m.paired) {   // a model without twins reduces to itself: the tables above must be the blob's own (tables.py)
+    ok = m.nMr == m.nM && m.nHr == m.nH;
+    for (int r = 0; r < nr && ok; r++)
+      ok = m.red_depth[r] == m.dof_depth[r] && m.red_Madr[r] == m.dof_Madr[r] && m.red_ancmask[r] == m.dof_ancmask[r] && m.red_descmask[r] == m.dof_descmask[r] &&
+           m.rv_depth[r] == m.vdof_depth[r] && m.rv_Madr[r] == m.vdof_Madr[r] && m.rv_ancmask[r] == m.vdof_ancmask[r] && m.rv_descmask[r] == m.vdof_descmask[r];
+    for (int p = 0; p < m.nM && ok; p++) ok = (m.R_ent[p] & 31) == m.M_i[p] && ((m.R_ent[p] >> 5) & 31) == m.M_j[p];
+    for (int p = 0; p < m.nH && ok; p++) ok = (m.RH_ent[p] & 31) == m.H_i[p] && ((m.RH_ent[p] >> 5) & 31) == m.H_j[p] && (m.RH_ent[p] >> 21) - 1 == m.H_src[p];
+  }
+  return ok;
 }
 
 extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
@@ -898,7 +942,6 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     m.M_ent[p] = i | (j << 5) | (fi << 10) | (fj << 12);
   }
   if (!B.ok || ncg != 3) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
-  build_reduced_tables(m);
   (void)nhv; (void)nhf;
   for (int f = 0; f < 2; f++) {
     int g = foot_cg[f];
@@ -977,6 +1020,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     bool ok = (b == m.base_body) || (b == m.foot_body[0]) || (b == m.foot_body[1]);
     if (!ok || ((m.sensor_type[s] == 2 || m.sensor_type[s] == 8) && b != m.base_body)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "sensor %d placement", s); }
   }
+  if (!build_reduced_tables(m)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "dof tree is not a floating base with up to three serial chains of <= 5 (twin-merged) dofs"); }
   int dt_max = 0, dv_max = 0;
   for (int d = 0; d < m.nv; d++) { dt_max = m.dof_depth[d] > dt_max ? m.dof_depth[d] : dt_max; dv_max = m.vdof_depth[d] > dv_max ? m.vdof_depth[d] : dv_max; }
   auto fits = [&](int nq, int nv, int nb, int nu, int nj, int nM, int nH, int nrow, int DT, int DV) {
@@ -986,7 +1030,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   else if (fits(ShapeB::NQ, ShapeB::NV, ShapeB::NB, ShapeB::NU, ShapeB::NJ, ShapeB::NM, ShapeB::NH, ShapeB::NROW, ShapeB::DT, ShapeB::DV)) mo->shape = 1;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
-  if (mo->shape == 1 && !(m.paired && m.nvr == ShapeB::NVR && m.nMr == ShapeB::NMR)) {
+  if (mo->shape == 1 && !(m.paired && m.nvr == ShapeB::NVR && m.nMr == ShapeB::NMR && m.nHr == ShapeB::NHR)) {
     delete mo;
     return fail(ODK_ERR_UNSUPPORTED, "the 30-dof kernels expect backlash twins (same body, anchor and axis as their joint) over the 20-dof tree");
   }
@@ -1001,6 +1045,9 @@ extern "C" int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int
   return ODK_OK;
 }
 
+// occupancy by construction: 2 waves / SIMD = 8 single-wave workgroups per CU need <= 160 KiB / 8 of LDS per workgroup (2 envs)
+static_assert(2 * EnvL<ShapeA>::TOTAL * sizeof(float) <= 20480, "shape A: LDS image too large for 8 workgroups per CU");
+static_assert(2 * EnvL<ShapeB>::TOTAL * sizeof(float) <= 20480, "shape B: LDS image too large for 8 workgroups per CU");
 template <class S> static void fill_sizes(odk_batch* b) {
   b->rec_size = Rec<S>::SIZE; b->frec_size = Rec<S>::FSIZE; b->lds_total = S::TOTAL; b->dr_size = DRL<S>::SIZE; b->env_lds = EnvL<S>::TOTAL;
 }

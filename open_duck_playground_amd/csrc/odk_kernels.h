@@ -67,6 +67,8 @@ struct Shape {
   static constexpr bool PAIRED = (NV_ == 30);
   static constexpr int NVR = PAIRED ? 20 : NV_;    // reduced dofs
   static constexpr int NMR = PAIRED ? 145 : NM_;   // entries of the reduced tree layout
+  static constexpr int NHR = PAIRED ? 170 : NH_;   // entries of the reduced virtual-tree layout
+  static constexpr int DVR = PAIRED ? 15 : DV_;    // max dof depth, reduced virtual tree
   static constexpr int CL = (NV_ == 20 || PAIRED) ? 5 : 0;   // max (reduced) chain length for the in-register chain solver (0: generic path)
   // persistent over the env step
   static constexpr int O_QPOS = 0;
@@ -87,14 +89,14 @@ struct Shape {
   static constexpr int O_CACC = O_CVEL + 6 * NB;     // [6][NB] velocity-dependent part of cacc (gravity folded in)
   static constexpr int O_CFRC = O_CACC + 6 * NB;     // [6][NB] local then subtree-accumulated bias force
   static constexpr int O_CRB = O_CFRC + 6 * NB;      // [10][NB] cinert then composite inertia
-  static constexpr int O_SC = O_CRB + 10 * NB;       // [2][NJ] sin/cos of the half joint angles
-  static constexpr int O_CDOF = O_SC + 2 * NJ;       // [6][NV]
-  static constexpr int O_BUF6 = O_CDOF + 6 * NV;     // [6][NV] crb*cdof -> K_L*cdof
-  static constexpr int O_BUF6B = O_BUF6 + 6 * NV;    // [6][NV] K_R*cdof
-  static constexpr int O_M = O_BUF6B + 6 * NV;       // [NM] sparse inertia (rows by ancestor depth)
-  static constexpr int O_HL = O_M + NM;              // [NH] L^T D L of M, then Hessian and its factor
+  // matrix work runs on the REDUCED dofs (twins merged, DevModel::paired): one motion column per reduced dof
+  static constexpr int O_CDOF = O_CRB + 10 * NB;     // [6][NVR]
+  static constexpr int O_BUF6 = O_CDOF + 6 * NVR;    // [6][NVR] crb*cdof -> K_L*cdof
+  static constexpr int O_BUF6B = O_BUF6 + 6 * NVR;   // [6][NVR] K_R*cdof
+  static constexpr int O_M = O_BUF6B + 6 * NVR;      // [NMR] sparse reduced inertia (rows by ancestor depth; twin pairs: no armature)
+  static constexpr int O_HL = O_M + NMR;             // [NHR] reduced inertia / Hessian with the diagonal terms, and its factor
   // dof vectors
-  static constexpr int O_QFS = O_HL + NH;            // qfrc_smooth
+  static constexpr int O_QFS = O_HL + NHR;           // qfrc_smooth
   static constexpr int O_QAS = O_QFS + NV;           // qacc_smooth
   static constexpr int O_X = O_QAS + NV;             // current qacc iterate
   static constexpr int O_MA = O_X + NV;              // scratch: per-dof friction-row hand-over
@@ -105,6 +107,8 @@ struct Shape {
   static constexpr int O_AREF = O_D + NROW;
   static constexpr int O_JAR = O_AREF + NROW;        // J qacc - aref (contact rows)
   static constexpr int O_JV = O_JAR + NROW;          // J search (scratch: candidate Jaref, forces, Hessian diagonal addend)
+  static constexpr int O_SC = O_JAR;                 // [2][NJ] sin/cos of the half joint angles: P0 -> P1 only, ALIASES jar (born in P9)
+  static_assert(2 * NJ <= NROW, "sin/cos must fit in the jar rows");
   static constexpr int O_W = O_CFRC;                 // [NCROW][6] contact row wrenches [r x dir; dir]; ALIASES cfrc|crb, which
                                                      // are dead once the bias forces and M entries exist (P3/P4); W is born in P8
   static_assert(6 * NCROW <= 16 * NB, "contact wrenches must fit in the cfrc|crb region");
@@ -291,12 +295,15 @@ __device__ __forceinline__ int randint3(float u) { int i = (int)(u * 3.0f); retu
 // decides whether two wavefronts fit on a SIMD).
 template <class S, int G>
 struct Statics {
-  static constexpr int NME = (S::NM + G - 1) / G;   // inertia entries per lane
-  static constexpr int NHE = (S::NH + G - 1) / G;   // Hessian entries per lane
+  static constexpr int NME = (S::NMR + G - 1) / G;  // reduced inertia entries per lane
+  static constexpr int NHE = (S::NHR + G - 1) / G;  // reduced virtual-tree Hessian entries per lane
   int j_qadr, j_dadr;                    // joint role (sin/cos phase, Euler)
-  int c_len, c_idx, c_n;                 // c_len > 0 on the lane of a chain's first dof (length, chain index); c_n chains
-  int ch_first, ch_len;                  // the serial dof chain this lane's dof belongs to (ch_len 0: base dof / no chain)
-  int d_on, d_body, d_depth, d_Madr, d_ancmask, d_descmask, d_vdepth, d_vMadr, d_vancmask, d_vdescmask;
+  // reduced-dof role (lane = reduced dof, DevModel::paired; a model without twins: reduced dof = dof)
+  int c_len, c_idx, c_n;                 // c_len > 0 on the lane of a reduced chain's first dof (length, chain index); c_n chains
+  int ch_first, ch_len;                  // the serial chain this lane's reduced dof belongs to (ch_len 0: base dof / no chain)
+  int r_on, r_depth, r_Madr, r_ancmask, r_descmask, r_foot;   // reduced tree layout (virtual-tree statics: fetched in the rare path)
+  // dof role (lane = dof)
+  int d_on, d_body;
   int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
   int d_qadr, d_lim_on;                  // hinge qpos address (-1: free joint); has a limit row
   int d_tkind, d_red;                    // twin dofs (DevModel::paired): 0 unpaired / 1 main (twin = dof + 1) / 2 twin; reduced dof
@@ -305,7 +312,7 @@ struct Statics {
 // Phase-local statics: fetched from the model (L1/L2-resident, one batch of loads per phase and substep)
 // right where they are used, so they do not occupy registers for the rest of the substep.
 struct BodySt {
-  int level, parent, nchild, child[3], njnt, jd[2], jj[2], pathmask, is_path, upmask, path_head;
+  int level, parent, nchild, child[3], njnt, jd[2], jj[2], jr[2], pathmask, is_path, upmask, path_head;   // jr: CDOF column of the joint's dof (-1: twin, its main dof's column is the same vector)
   float pos[3], quat[4], ipos[3], inertia[6], ax[2][3];
 };
 struct ActSt { float bias2, clo, chi, flo, fhi; int climited, flimited; };
@@ -318,17 +325,21 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
     st.j_qadr = on ? m->jnt_qposadr[on ? lane : 0] : -1;
     st.j_dadr = m->jnt_dofadr[on ? lane : 0];
   }
-  st.c_len = 0; st.c_idx = 0; st.c_n = m->nchain;
-  for (int c = 0; c < 3; c++) if (c < m->nchain && lane == m->chain_first[c]) { st.c_len = m->chain_len[c]; st.c_idx = c; }
+  st.c_len = 0; st.c_idx = 0; st.c_n = m->nrchain;
+  for (int c = 0; c < 3; c++) if (c < m->nrchain && lane == m->rchain_first[c]) { st.c_len = m->rchain_len[c]; st.c_idx = c; }
   st.ch_first = 0; st.ch_len = 0;
   for (int c = 0; c < 3; c++)
-    if (c < m->nchain && lane >= m->chain_first[c] && lane < m->chain_first[c] + m->chain_len[c]) { st.ch_first = m->chain_first[c]; st.ch_len = m->chain_len[c]; }
+    if (c < m->nrchain && lane >= m->rchain_first[c] && lane < m->rchain_first[c] + m->rchain_len[c]) { st.ch_first = m->rchain_first[c]; st.ch_len = m->rchain_len[c]; }
+  {
+    const int r = lane < S::NVR ? lane : 0;
+    st.r_on = lane < S::NVR;
+    st.r_depth = m->red_depth[r]; st.r_Madr = m->red_Madr[r]; st.r_ancmask = m->red_ancmask[r]; st.r_descmask = m->red_descmask[r];
+    st.r_foot = st.r_on ? m->red_foot[r] : 0;
+    if (!st.r_on) { st.r_ancmask = 0; st.r_descmask = 0; st.r_depth = 0; }
+  }
   const int i = lane < S::NV ? lane : 0;
   st.d_on = lane < S::NV;
   st.d_body = m->dof_body[i];
-  st.d_depth = m->dof_depth[i]; st.d_Madr = m->dof_Madr[i]; st.d_ancmask = m->dof_ancmask[i]; st.d_descmask = m->dof_descmask[i];
-  st.d_vdepth = m->vdof_depth[i]; st.d_vMadr = m->vdof_Madr[i]; st.d_vancmask = m->vdof_ancmask[i]; st.d_vdescmask = m->vdof_descmask[i];
-  if (!st.d_on) { st.d_ancmask = 0; st.d_descmask = 0; st.d_vancmask = 0; st.d_vdescmask = 0; st.d_depth = 0; st.d_vdepth = 0; }
   st.d_act = st.d_on ? m->dof_act[i] : -1;
   st.d_flrow = st.d_on ? m->dof_flrow[i] : -1;
   st.d_limrow = st.d_on ? m->dof_limrow[i] : -1;
@@ -338,7 +349,7 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
   st.d_qadr = m->dof_qadr[i];
   st.d_lo = m->dof_range[i][0]; st.d_hi = m->dof_range[i][1];
   st.d_tkind = (S::PAIRED && st.d_on) ? m->dof_tkind[i] : 0;
-  st.d_red = S::PAIRED ? m->dof_red[i] : i;
+  st.d_red = S::PAIRED ? m->dof_red[i] : i;   // column of this dof's motion vector in CDOF / BUF6
 }
 template <class S>
 __device__ __forceinline__ void load_body(BodySt& b, const DevModel* __restrict__ m, int lane) {
@@ -357,6 +368,7 @@ __device__ __forceinline__ void load_body(BodySt& b, const DevModel* __restrict_
     const int j = on ? m->body_jntadr[bi] + k : 0;
     b.jj[k] = j;
     b.jd[k] = m->jnt_dofadr[j];
+    b.jr[k] = (S::PAIRED && m->dof_tkind[b.jd[k]] == 2) ? -1 : m->dof_red[b.jd[k]];
     for (int c = 0; c < 3; c++) b.ax[k][c] = on ? m->jnt_axis[j][c] : 0.0f;
   }
   for (int c = 0; c < 3; c++) { b.pos[c] = m->body_pos[bi][c]; b.ipos[c] = m->body_ipos[bi][c]; }
@@ -373,19 +385,9 @@ __device__ __forceinline__ void load_fl(FlSt& f, const DevModel* __restrict__ m,
   const int r = lane < m->nfl ? lane : 0;
   f.D = m->fl_D[r]; f.R = m->fl_R[r]; f.b = m->fl_b[r]; f.dof = m->fl_dof[r];
 }
-// matrix entries of this lane: i | j << 5 (| foot bits of i << 10 | foot bits of j << 12 | (src + 1) << 14 for H)
-__device__ __forceinline__ int load_ment(const DevModel* __restrict__ m, int p, int nm) {
-  const int q = p < nm ? p : 0;
-  const int e = m->M_i[q] | (m->M_j[q] << 5);
-  return p < nm ? e : -1;
-}
-__device__ __forceinline__ int load_hent(const DevModel* __restrict__ m, int p, int nh) {
-  const int q = p < nh ? p : 0;
-  const int hi = m->H_i[q], hj = m->H_j[q];
-  const int fi = m->foot_dofmask[0][hi] | (m->foot_dofmask[1][hi] << 1), fj = m->foot_dofmask[0][hj] | (m->foot_dofmask[1][hj] << 1);
-  const int e = hi | (hj << 5) | (fi << 10) | (fj << 12) | ((m->H_src[q] + 1) << 14);
-  return p < nh ? e : -1;
-}
+// packed entries of the reduced layouts (DevModel::R_ent / RH_ent), -1 beyond the layout
+__device__ __forceinline__ int load_rent(const DevModel* __restrict__ m, int p, int n) { const int e = m->R_ent[p < n ? p : 0]; return p < n ? e : -1; }
+__device__ __forceinline__ int load_rhent(const DevModel* __restrict__ m, int p, int n) { const int e = m->RH_ent[p < n ? p : 0]; return p < n ? e : -1; }
 
 // ------------------------------------------------------------------------------------------------
 // Sparse L^T D L on the tree layout (row i = [L(i, ancestor at depth 0..d-1), D_i]).  Each lane keeps its
@@ -688,48 +690,58 @@ __device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* X
   ODK_SYNC();
 }
 
-// Solve (P Hr P^T + diag(d)) x = g for a model with twin dofs (DevModel::paired), d_i = ARM[i] (+ DX[i]):
-// with z = P^T x (one entry per reduced dof), E = P^T diag(1/d) P = diag(1/d_u + 1/d_v) and s = P^T diag(1/d) g,
-//     (Hr + E^-1) z = E^-1 s      -- the 20-dof robot's own system with the pair's series stiffness d_u d_v / (d_u + d_v) on
-//                                    the diagonal: ONE in-register chain solve instead of a 30-dof factorisation,
-//     x_i = (g_i - t_r) / d_i,  t = E^-1 (s - z)   (unpaired dofs: x = z).
-// HR: reduced matrix in the reduced tree layout with E^-1 already on the twin diagonals (LDS); GV: g per dof (LDS);
-// RV: NVR floats of LDS scratch; returns x of this lane's dof.
-template <class S, int G>
-__device__ __forceinline__ float paired_solve(const float* HR, const float* GV, float gi, const float* ARM, const float* DX, float* RV, float* XCH,
-                                              const DevModel* __restrict__ m, const Statics<S, G>& st, int lane) {
-  auto pair_terms = [&](int u, float& rhs, float& einv, float& du, float& dv) {   // twin = u + 1 (build_reduced_tables)
-    du = ARM[u] + (DX ? DX[u] : 0.0f); dv = ARM[u + 1] + (DX ? DX[u + 1] : 0.0f);
-    const float inv = __builtin_amdgcn_rcpf(du + dv);
-    rhs = (GV[u] * dv + GV[u + 1] * du) * inv;
-    einv = du * dv * inv;
-  };
-  ChainSt cst{0, 0, m->nrchain, 0, 0};
-#pragma unroll
-  for (int c = 0; c < 3; c++) if (c < m->nrchain && lane == m->rchain_first[c]) { cst.c_len = m->rchain_len[c]; cst.c_idx = c; }
-  const int rl = lane < S::NVR ? lane : 0;
-  cst.d_depth = m->red_depth[rl]; cst.d_Madr = m->red_Madr[rl];
+// Twin dofs (DevModel::paired): solving (P Hr P^T + diag(d)) x = g, with P copying each reduced column onto its pair.
+// With z = P^T x (one entry per reduced dof), E = P^T diag(1/d) P = diag(1/d_u + 1/d_v) and s = P^T diag(1/d) g:
+//     (Hr + E^-1) z = E^-1 s      -- the twin-free robot's own system with the pair's series stiffness d_u d_v / (d_u + d_v)
+//                                    on the diagonal (pair_einv) and the right-hand side pair_rhs,
+//     x_i = (g_i - t_r) / d_i,  t = E^-1 s - E^-1 z     (unpaired dofs: x = z)   -- pair_expand.
+// d_i = ARM[i] (+ DX[i]: the Newton Hessian's diagonal rows); the twin of main dof u is u + 1 (build_reduced_tables).
+__device__ __forceinline__ void pair_terms(const float* GV, const float* ARM, const float* DX, int u, float& rhs, float& einv, float& du, float& dv) {
+  du = ARM[u] + (DX ? DX[u] : 0.0f); dv = ARM[u + 1] + (DX ? DX[u + 1] : 0.0f);
+  const float inv = __builtin_amdgcn_rcpf(du + dv);
+  rhs = (GV[u] * dv + GV[u + 1] * du) * inv;
+  einv = du * dv * inv;
+}
+__device__ __forceinline__ float pair_einv(const float* ARM, const float* DX, int u) {
+  const float du = ARM[u] + (DX ? DX[u] : 0.0f), dv = ARM[u + 1] + (DX ? DX[u + 1] : 0.0f);
+  return du * dv * __builtin_amdgcn_rcpf(du + dv);
+}
+// right-hand side of the reduced system for reduced dof `lane` (GV: g per dof, LDS)
+template <class S>
+__device__ __forceinline__ float pair_rhs(const float* GV, const float* ARM, const float* DX, const DevModel* __restrict__ m, int lane) {
+  float rhs = 0.0f;
   if (lane < S::NVR) {
     const int u = m->red_main[lane];
-    float rhs = GV[u];
-    if (m->red_twin[lane] >= 0) { float einv, du, dv; pair_terms(u, rhs, einv, du, dv); }
-    RV[lane] = rhs;
+    rhs = GV[u];
+    if (m->red_twin[lane] >= 0) { float einv, du, dv; pair_terms(GV, ARM, DX, u, rhs, einv, du, dv); }
   }
-  ODK_SYNC();
-  chain_solve<S, G>(HR, RV, XCH, cst, lane);
+  return rhs;
+}
+// x of this lane's dof from the reduced solution Z (LDS, one entry per reduced dof); gi = g of this dof
+template <class S, int G>
+__device__ __forceinline__ float pair_expand(const float* Z, const float* GV, float gi, const float* ARM, const float* DX, const Statics<S, G>& st, int lane) {
   float x = 0.0f;
   if (st.d_on) {
-    const float z = RV[st.d_red];
+    const float z = Z[st.d_red];
     x = z;
     if (st.d_tkind != 0) {
-      const int u = st.d_tkind == 1 ? lane : lane - 1;
       float rhs, einv, du, dv;
-      pair_terms(u, rhs, einv, du, dv);
-      const float t = rhs - einv * z;
-      x = (gi - t) * __builtin_amdgcn_rcpf(st.d_tkind == 1 ? du : dv);
+      pair_terms(GV, ARM, DX, st.d_tkind == 1 ? lane : lane - 1, rhs, einv, du, dv);
+      x = (gi - (rhs - einv * z)) * __builtin_amdgcn_rcpf(st.d_tkind == 1 ? du : dv);
     }
   }
   return x;
+}
+// P^T v for reduced dof `lane`: v_u (+ v_twin)
+template <class S>
+__device__ __forceinline__ float pair_sum(const float* V, const DevModel* __restrict__ m, int lane) {
+  float r = 0.0f;
+  if (lane < S::NVR) {
+    const int u = m->red_main[lane];
+    r = V[u];
+    if (m->red_twin[lane] >= 0) r += V[u + 1];
+  }
+  return r;
 }
 
 // impedance / stiffness of one constraint row (mjx constraint._row); returns D = 1/R and aref
@@ -975,7 +987,7 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
 
 template <class S, int G, bool HF>
 __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags) {
-  constexpr int NV = S::NV, NB = S::NB;
+  constexpr int NV = S::NV, NB = S::NB, NR = S::NVR;   // NR: reduced dofs = columns of CDOF / BUF6 / BUF6B
   using ST = Statics<S, G>;
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; float* WARM = L + S::O_WARM; float* CTRL = L + S::O_CTRL;
   float* Q0 = L + S::O_Q0; float* MASS = L + S::O_MASS; float* ARM = L + S::O_ARM; float* FRL = L + S::O_FRL; float* KP = L + S::O_KP;
@@ -1035,9 +1047,9 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
           for (int k = 0; k < 3; k++) ww[k] = R[3 * k] * wl[0] + R[3 * k + 1] * wl[1] + R[3 * k + 2] * wl[2];
           const float v[3] = {QVEL[0], QVEL[1], QVEL[2]};
           for (int k = 0; k < 3; k++) {
-            for (int c = 0; c < 6; c++) CDOF[c * NV + k] = (c == 3 + k) ? 1.0f : 0.0f;
-            CDOF[0 * NV + 3 + k] = R[k]; CDOF[1 * NV + 3 + k] = R[3 + k]; CDOF[2 * NV + 3 + k] = R[6 + k];
-            CDOF[3 * NV + 3 + k] = 0; CDOF[4 * NV + 3 + k] = 0; CDOF[5 * NV + 3 + k] = 0;
+            for (int c = 0; c < 6; c++) CDOF[c * NR + k] = (c == 3 + k) ? 1.0f : 0.0f;
+            CDOF[0 * NR + 3 + k] = R[k]; CDOF[1 * NR + 3 + k] = R[3 + k]; CDOF[2 * NR + 3 + k] = R[6 + k];
+            CDOF[3 * NR + 3 + k] = 0; CDOF[4 * NR + 3 + k] = 0; CDOF[5 * NR + 3 + k] = 0;
           }
           float vxw[3];
           cross3(vxw, v, ww);
@@ -1060,9 +1072,11 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
               const float off[3] = {ref[0] - p[0], ref[1] - p[1], ref[2] - p[2]};
               cd[0] = axw[0]; cd[1] = axw[1]; cd[2] = axw[2];
               cross3(cd + 3, axw, off);
-              const int d = bs.jd[jj];
+              const int d = bs.jd[jj], col = bs.jr[jj];
+              if (col >= 0) {
 #pragma unroll
-              for (int k = 0; k < 6; k++) CDOF[k * NV + d] = cd[k];
+                for (int k = 0; k < 6; k++) CDOF[k * NR + col] = cd[k];
+              }
               const float qv = QVEL[d];
               cross_motion(dot, cvel, cd);
 #pragma unroll
@@ -1145,9 +1159,11 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
           const float off[3] = {ref[0] - tp[0], ref[1] - tp[1], ref[2] - tp[2]};
           cd[jj][0] = axw[0]; cd[jj][1] = axw[1]; cd[jj][2] = axw[2];
           cross3(cd[jj] + 3, axw, off);
-          const int d = bs.jd[jj];
+          const int d = bs.jd[jj], col = bs.jr[jj];
+          if (col >= 0) {   // a twin's motion vector is its main dof's: one column
 #pragma unroll
-          for (int k = 0; k < 6; k++) CDOF[k * NV + d] = cd[jj][k];
+            for (int k = 0; k < 6; k++) CDOF[k * NR + col] = cd[jj][k];
+          }
           qv[jj] = QVEL[d];
 #pragma unroll
           for (int k = 0; k < 6; k++) cinc[k] += cd[jj][k] * qv[jj];
@@ -1312,10 +1328,12 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 #pragma unroll
     for (int k = 0; k < 10; k++) crb[k] = CRB[k * NB + b];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { cd[k] = CDOF[k * NV + i]; bias += cd[k] * CFRC[k * NB + b]; }
+    for (int k = 0; k < 6; k++) { cd[k] = CDOF[k * NR + st.d_red]; bias += cd[k] * CFRC[k * NB + b]; }
     inert_mul(buf, crb, cd);
+    if (st.d_tkind != 2) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) BUF6[k * NV + i] = buf[k];
+      for (int k = 0; k < 6; k++) BUF6[k * NR + st.d_red] = buf[k];
+    }
     const float qv = QVEL[i];
     float frc = -st.d_damping * qv - bias;
     const int u = st.d_act;
@@ -1335,16 +1353,17 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   }
   ODK_SYNC();
   ODK_PROF(3);
-  // ---------------- P4: sparse inertia entries (lane = entry), mirrored into HL for the factorisation
+  // ---------------- P4: sparse reduced inertia entries (lane = entry): cdof_j . (crb cdof_i), armature on the unpaired
+  // diagonals only (a pair's armatures enter the solves as the series term pair_einv, and M v as ARM[i] v_i)
 #pragma unroll
   for (int t = 0; t < ST::NME; t++) {
-    const int e = load_ment(m, lane + t * G, S::NM);
+    const int e = load_rent(m, lane + t * G, S::NMR);
     if (e >= 0) {
       const int i = e & 31, j = (e >> 5) & 31;
       float v = 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) v += CDOF[k * NV + j] * BUF6[k * NV + i];
-      if (i == j) v += ARM[i];
+      for (int k = 0; k < 6; k++) v += CDOF[k * NR + j] * BUF6[k * NR + i];
+      if (((e >> 14) & 3) == 1) v += ARM[(e >> 16) & 31];   // diagonal of an unpaired dof
       M[lane + t * G] = v;
     }
   }
@@ -1352,53 +1371,63 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   ODK_PROF(4);
   // ---------------- P5: qacc_smooth = M^-1 qfrc_smooth; dense symmetric row of M into registers
   float qas;
+  const ChainSt cst{st.c_len, st.c_idx, st.c_n, st.r_depth, st.r_Madr};
   if constexpr (S::PAIRED) {
-    // reduced inertia (twins merged) in the reduced tree layout: HL[0 .. NMR)
+    // M = P Mr P^T + diag(armature): reduced system with the pairs' series armature on the diagonal (HL), one chain solve
 #pragma unroll
-    for (int t = 0; t < (S::NMR + G - 1) / G; t++) {
+    for (int t = 0; t < ST::NME; t++) {
       const int p = lane + t * G;
       if (p < S::NMR) {
         const int e = m->R_ent[p];
-        float v = M[e & 511];
-        if ((e >> 24) & 1) { const int u = (e >> 9) & 31; const float du = ARM[u], dv = ARM[u + 1]; v += du * dv * __builtin_amdgcn_rcpf(du + dv); }
+        float v = M[p];
+        if ((e >> 15) & 1) v += pair_einv(ARM, nullptr, (e >> 16) & 31);
         HL[p] = v;
       }
     }
+    if (st.r_on) GRAD[lane] = pair_rhs<S>(QFS, ARM, nullptr, m, lane);
     ODK_SYNC();
     ODK_PROF(5);
-    qas = paired_solve<S, G>(HL, QFS, qfs, ARM, nullptr, GRAD, SCR + S::S_K, m, st, lane);
+    chain_solve<S, G>(HL, GRAD, SCR + S::S_K, cst, lane);
+    qas = pair_expand<S, G>(GRAD, QFS, qfs, ARM, nullptr, st, lane);
     if (st.d_on) QAS[lane] = qas;
   } else if constexpr (S::CL > 0) {
     if (st.d_on) QAS[lane] = qfs;
     ODK_SYNC();
-    chain_solve<S, G>(M, QAS, SCR + S::S_K, ChainSt{st.c_len, st.c_idx, st.c_n, st.d_depth, st.d_Madr}, lane);
+    chain_solve<S, G>(M, QAS, SCR + S::S_K, cst, lane);
     ODK_PROF(5);
     qas = st.d_on ? QAS[lane] : 0.0f;
   } else {
 #pragma unroll
-    for (int t = 0; t < ST::NME; t++) { const int p = lane + t * G; if (p < S::NM) HL[p] = M[p]; }
+    for (int t = 0; t < ST::NME; t++) { const int p = lane + t * G; if (p < S::NMR) HL[p] = M[p]; }
     ODK_SYNC();
-    if (m->nchain > 0 && m->chain_first[0] == 6)   // floating base + serial chains: chain-parallel elimination
-      factor_chains<G, S::DT, NV, S::DT - 5, 6>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.ch_first, st.ch_len, st.d_descmask, st.d_depth, st.d_Madr);
+    if (m->nrchain > 0 && m->rchain_first[0] == 6)   // floating base + serial chains: chain-parallel elimination
+      factor_chains<G, S::DT, NV, S::DT - 5, 6>(HL, lane, st.r_on, st.r_depth, st.r_Madr, st.ch_first, st.ch_len, st.r_descmask, st.r_depth, st.r_Madr);
     else
-      factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
+      factor_rows<G, S::DT, NV>(HL, lane, st.r_on, st.r_depth, st.r_Madr, st.r_descmask, st.r_depth, st.r_Madr);
     ODK_PROF(5);
-    qas = solve_rows<G, NV>(HL, qfs, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
+    qas = solve_rows<G, NV>(HL, qfs, lane, st.r_on, st.r_depth, st.r_Madr, st.r_ancmask, st.r_descmask, st.r_depth, st.r_Madr);
     if (st.d_on) QAS[lane] = qas;
   }
-  // y_i = sum_j M(i, j) v_j with the dense symmetric row of M gathered on the fly (unconditional LDS loads + selects);
-  // recomputed at both uses instead of holding NV registers across the whole solver.  v is read from its LDS vector
-  // with uniform addresses (broadcast reads on the LDS pipe) instead of 2 x v_readlane + select per element on the VALU.
-  auto mul_M = [&](const float* V) -> float {
+  // y = M v with the dense symmetric row of the reduced M gathered on the fly (unconditional LDS loads + selects);
+  // recomputed at both uses instead of holding NR registers across the whole solver.  VB = P^T v (LDS, one entry per reduced
+  // dof; v itself without twins) is read with uniform addresses (broadcast reads on the LDS pipe) instead of 2 x v_readlane
+  // + select per element on the VALU.  Twin dofs: y_i = (Mr P^T v)_r(i) + ARM[i] v_i, handed from the reduced-dof lanes to
+  // the dof lanes through YB (LDS, NR floats); vi = v of this lane's dof.
+  auto mul_M = [&](const float* VB, float* YB, float vi) -> float {
     float acc = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-      const int aj = ubcast(st.d_Madr, j), dj = ubcast(st.d_depth, j);
-      const bool isanc = (st.d_ancmask >> j) & 1, isdesc = (st.d_descmask >> j) & 1;
-      const int adr = isanc ? st.d_Madr + dj : (isdesc ? aj + st.d_depth : st.d_Madr + st.d_depth);
+    for (int j = 0; j < NR; j++) {
+      const int aj = ubcast(st.r_Madr, j), dj = ubcast(st.r_depth, j);
+      const bool isanc = (st.r_ancmask >> j) & 1, isdesc = (st.r_descmask >> j) & 1;
+      const int adr = isanc ? st.r_Madr + dj : (isdesc ? aj + st.r_depth : st.r_Madr + st.r_depth);
       const float mij = M[adr];
-      const float vj = V[j];
+      const float vj = VB[j];
       acc += (isanc || isdesc || j == lane) ? mij * vj : 0.0f;
+    }
+    if constexpr (S::PAIRED) {
+      if (st.r_on) YB[lane] = acc;
+      ODK_SYNC();
+      acc = st.d_on ? YB[st.d_red] + (st.d_tkind != 0 ? ARM[lane] * vi : 0.0f) : 0.0f;
     }
     return acc;
   };
@@ -1611,19 +1640,27 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   // foot twists of both candidates: VF = sum_{d above foot} cdof[d] qacc_smooth[d], VF2 likewise for the warmstart.
   // NOTE: v_readlane (ubcast / bcast) must stay in uniform control flow -- inside a divergent branch the source
   // lanes may be inactive and hold stale (e.g. un-reloaded spill) registers.
+  // Twin dofs: the columns are per reduced dof, so the vectors enter as P^T v (pair sums): P^T qacc_smooth -> X (free until
+  // the line search ends), P^T warmstart -> MA (free until the forces of the chosen point).
+  const float* VBQ = QAS; const float* VBW = WARM;
+  if constexpr (S::PAIRED) {
+    if (st.r_on) { X[lane] = pair_sum<S>(QAS, m, lane); MA[lane] = pair_sum<S>(WARM, m, lane); }
+    ODK_SYNC();
+    VBQ = X; VBW = MA;
+  }
   {
     const int which = (lane / 12) & 1, f = (lane / 6) & 1, k = lane % 6;
     float s = 0;
 #pragma unroll
-    for (int d = 0; d < NV; d++) {
-      const int fm = ubcast(st.d_foot, d);
-      const float vq = QAS[d], vw = WARM[d];   // uniform addresses: LDS broadcast reads
-      if ((fm >> f) & 1) s += CDOF[k * NV + d] * (which ? vw : vq);
+    for (int d = 0; d < NR; d++) {
+      const int fm = ubcast(st.r_foot, d);
+      const float vq = VBQ[d], vw = VBW[d];   // uniform addresses: LDS broadcast reads
+      if ((fm >> f) & 1) s += CDOF[k * NR + d] * (which ? vw : vq);
     }
     if (lane < 24) SCR[(which ? S::S_VF2 : S::S_VF) + 6 * f + k] = s;
   }
   // M * warmstart from the register row
-  const float ma_w = mul_M(WARM);
+  const float ma_w = mul_M(VBW, MV, warm);
   const float gw = st.d_on ? (ma_w - qfs) * (warm - qas) : 0.0f;
   ODK_SYNC();
   auto contact_jx = [&](int rc, const float* VF) -> float {
@@ -1766,7 +1803,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     if (st.d_lim_on) { qc += lim_sgn * f_lim; if (lim_D > 0 && jar_lim < 0) hdiag_extra += lim_D; }
     float cd[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) cd[k] = CDOF[k * NV + i];
+    for (int k = 0; k < 6; k++) cd[k] = CDOF[k * NR + st.d_red];
 #pragma unroll
     for (int f = 0; f < 2; f++)
       if ((st.d_foot >> f) & 1) {
@@ -1774,19 +1811,21 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
         for (int k = 0; k < 6; k++) qc += cd[k] * SCR[S::S_FF + 6 * f + k];
       }
     grad = ma - qfs - qc;
-    // T_f[i] = K_f cdof[i]
+    // T_f[column] = K_f cdof[column] (a twin shares its main dof's column)
+    if (st.d_tkind != 2) {
 #pragma unroll
-    for (int f = 0; f < 2; f++) {
-      float* T = f ? BUF6B : BUF6;
-      const bool on = ((st.d_foot >> f) & 1) && (c_act[f] || c_act[2]);
+      for (int f = 0; f < 2; f++) {
+        float* T = f ? BUF6B : BUF6;
+        const bool on = ((st.d_foot >> f) & 1) && (c_act[f] || c_act[2]);
 #pragma unroll
-      for (int a = 0; a < 6; a++) {
-        float s = 0;
-        if (on) {
+        for (int a = 0; a < 6; a++) {
+          float s = 0;
+          if (on) {
 #pragma unroll
-          for (int b2 = 0; b2 < 6; b2++) s += SCR[S::S_K + 36 * f + 6 * a + b2] * cd[b2];
+            for (int b2 = 0; b2 < 6; b2++) s += SCR[S::S_K + 36 * f + 6 * a + b2] * cd[b2];
+          }
+          T[a * NR + st.d_red] = s;
         }
-        T[a * NV + i] = s;
       }
     }
     JV[i] = hdiag_extra;  // JV[0..NV) lies below the contact rows: free scratch for the per-dof diagonal addend
@@ -1794,150 +1833,128 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   ODK_SYNC();
   ODK_PROF(11);
   const bool any_ffa = __builtin_amdgcn_ballot_w64(ff_active) != 0;   // wave-uniform: some env has an active foot-foot row
-  float search;
-  if (S::PAIRED && !any_ffa) {
-    // ---- common case, model with twin dofs: reduced Hessian (twins merged) on the reduced tree, one chain solve
+  // contact / diagonal terms of one reduced Hessian entry e (packed: DevModel::R_ent) on top of the inertia value v
+  auto hess_entry = [&](int e, float v) -> float {
+    const int i = e & 31, j = (e >> 5) & 31, fi = (e >> 10) & 3, fj = (e >> 12) & 3;
+    if ((e >> 14) & 1) {   // diagonal: friction-loss / limit rows; a pair's two diagonals enter as their series term
+      const int u = (e >> 16) & 31;
+      v += (S::PAIRED && ((e >> 15) & 1)) ? pair_einv(ARM, JV, u) : JV[u];
+    }
+    const int both = fi & fj;
+    if (both) {
+      float cj[6];
 #pragma unroll
-    for (int t = 0; t < (S::NMR + G - 1) / G; t++) {
-      const int p = lane + t * G;
-      if (p < S::NMR) {
-        const int e = m->R_ent[p];
-        const int i = (e >> 9) & 31, j = (e >> 14) & 31, fi = (e >> 19) & 3, fj = (e >> 21) & 3;
-        float v = M[e & 511];
-        if ((e >> 23) & 1) {
-          if ((e >> 24) & 1) { const float du = ARM[i] + JV[i], dv = ARM[i + 1] + JV[i + 1]; v += du * dv * __builtin_amdgcn_rcpf(du + dv); }
-          else v += JV[i];
-        }
-        const int both = fi & fj;
-        if (both) {
-          float cj[6];
+      for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NR + j];
+      if (both & 1) {
 #pragma unroll
-          for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NV + j];
-          if (both & 1) {
+        for (int k = 0; k < 6; k++) v += cj[k] * BUF6[k * NR + i];
+      }
+      if (both & 2) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) v += cj[k] * BUF6[k * NV + i];
-          }
-          if (both & 2) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) v += cj[k] * BUF6B[k * NV + i];
-          }
-        }
-        HL[p] = v;
+        for (int k = 0; k < 6; k++) v += cj[k] * BUF6B[k * NR + i];
       }
     }
-    if (st.d_on) { MA[lane] = grad; GRAD[lane] = grad; }
+    return v;
+  };
+  if (st.d_on) { MA[lane] = grad; GRAD[lane] = grad; }   // MA: kept for the debug image (gradient at the starting point)
+  // right-hand side of the reduced system on the reduced-dof lanes (twin-free model: the gradient itself)
+  float rhs = grad;
+  if constexpr (S::PAIRED) {
     ODK_SYNC();
-    ODK_PROF(12);
-    search = -paired_solve<S, G>(HL, GRAD, grad, ARM, JV, MV, SCR + S::S_K, m, st, lane);
-    ODK_PROF(13);
-    ODK_SYNC();   // every lane has read its GRAD / JV inputs before the line search overwrites them
-    ODK_PROF(14);
-  } else if (!any_ffa) {
-    // ---- common case: no foot-foot coupling -> the Hessian has the inertia's own tree pattern
+    rhs = pair_rhs<S>(GRAD, ARM, JV, m, lane);
+  }
+  float search;
+  if (!any_ffa) {
+    // ---- common case: no foot-foot coupling -> the Hessian has the reduced inertia's own tree pattern
 #pragma unroll
     for (int t = 0; t < ST::NME; t++) {
       const int p = lane + t * G;
-      if (p < S::NM) {
-        const int e = m->M_ent[p];   // one packed load instead of M_i, M_j and four foot-mask loads chained behind them
-        const int i = e & 31, j = (e >> 5) & 31, fi = (e >> 10) & 3, fj = (e >> 12) & 3;
-        float v = M[p];
-        if (i == j) v += JV[i];
-        const int both = fi & fj;
-        if (both) {
-          float cj[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NV + j];
-          if (both & 1) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) v += cj[k] * BUF6[k * NV + i];
-          }
-          if (both & 2) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) v += cj[k] * BUF6B[k * NV + i];
-          }
-        }
-        HL[p] = v;
-      }
+      if (p < S::NMR) HL[p] = hess_entry(m->R_ent[p], M[p]);   // one packed load per entry
     }
-    if (st.d_on) { MA[lane] = grad; GRAD[lane] = grad; }
+    if constexpr (S::PAIRED) { if (st.r_on) MV[lane] = rhs; }
     ODK_SYNC();
     ODK_PROF(12);
-    if constexpr (S::CL > 0) {
-      chain_solve<S, G>(HL, GRAD, SCR + S::S_K, ChainSt{st.c_len, st.c_idx, st.c_n, st.d_depth, st.d_Madr}, lane);
+    if constexpr (S::PAIRED) {
+      chain_solve<S, G>(HL, MV, SCR + S::S_K, cst, lane);
+      ODK_PROF(13);
+      search = -pair_expand<S, G>(MV, GRAD, grad, ARM, JV, st, lane);
+    } else if constexpr (S::CL > 0) {
+      chain_solve<S, G>(HL, GRAD, SCR + S::S_K, cst, lane);
       ODK_PROF(13);
       search = st.d_on ? -GRAD[lane] : 0.0f;
     } else {   // generic tree: the inertia's own (shallower) row layout instead of the virtual tree's
-      if (m->nchain > 0 && m->chain_first[0] == 6)   // floating base + serial chains: chain-parallel elimination
-      factor_chains<G, S::DT, NV, S::DT - 5, 6>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.ch_first, st.ch_len, st.d_descmask, st.d_depth, st.d_Madr);
-    else
-      factor_rows<G, S::DT, NV>(HL, lane, st.d_on, st.d_depth, st.d_Madr, st.d_descmask, st.d_depth, st.d_Madr);
+      if (m->nrchain > 0 && m->rchain_first[0] == 6)   // floating base + serial chains: chain-parallel elimination
+        factor_chains<G, S::DT, NV, S::DT - 5, 6>(HL, lane, st.r_on, st.r_depth, st.r_Madr, st.ch_first, st.ch_len, st.r_descmask, st.r_depth, st.r_Madr);
+      else
+        factor_rows<G, S::DT, NV>(HL, lane, st.r_on, st.r_depth, st.r_Madr, st.r_descmask, st.r_depth, st.r_Madr);
       ODK_PROF(13);
-      search = -solve_rows<G, NV>(HL, grad, lane, st.d_on, st.d_depth, st.d_Madr, st.d_ancmask, st.d_descmask, st.d_depth, st.d_Madr);
+      search = -solve_rows<G, NV>(HL, grad, lane, st.r_on, st.r_depth, st.r_Madr, st.r_ancmask, st.r_descmask, st.r_depth, st.r_Madr);
     }
     ODK_PROF(14);
   } else {
-  // Hessian entries on the virtual-tree layout
-  int hent[ST::NHE];
+    // ---- an env of the wave has an active foot-foot row: Hessian on the reduced VIRTUAL tree (second leg below the first
+    // foot), whose statics are fetched here (rare path: they do not occupy registers elsewhere)
+    const int rl = st.r_on ? lane : 0;
+    const int v_depth = st.r_on ? m->rv_depth[rl] : 0, v_Madr = m->rv_Madr[rl];
+    const int v_ancmask = st.r_on ? m->rv_ancmask[rl] : 0, v_descmask = st.r_on ? m->rv_descmask[rl] : 0;
+    int hent[ST::NHE];
 #pragma unroll
-  for (int t = 0; t < ST::NHE; t++) hent[t] = load_hent(m, lane + t * G, S::NH);
+    for (int t = 0; t < ST::NHE; t++) hent[t] = load_rhent(m, lane + t * G, S::NHR);
 #pragma unroll
-  for (int t = 0; t < ST::NHE; t++) {
-    const int e = hent[t];
-    if (e >= 0) {
-      const int i = e & 31, j = (e >> 5) & 31, fi = (e >> 10) & 3, fj = (e >> 12) & 3, src = (e >> 14) - 1;
-      float v = src >= 0 ? M[src] : 0.0f;
-      if (i == j) v += JV[i];
-      const int both = fi & fj;
-      if (both) {
-        float cj[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NV + j];
-        if (both & 1) {
-#pragma unroll
-          for (int k = 0; k < 6; k++) v += cj[k] * BUF6[k * NV + i];
+    for (int t = 0; t < ST::NHE; t++) {
+      const int e = hent[t];
+      if (e >= 0) {
+        const int i = e & 31, j = (e >> 5) & 31, fi = (e >> 10) & 3, fj = (e >> 12) & 3, src = (e >> 21) - 1;
+        float v = hess_entry(e, src >= 0 ? M[src] : 0.0f);
+        if (ff_active) {  // cross terms -(A_R^T K_X A_L + A_L^T K_X A_R); rare
+          const float wgt = (float)(((fi >> 1) & 1) && (fj & 1)) + (float)((fi & 1) && ((fj >> 1) & 1));
+          if (wgt != 0.0f) {
+            float sx = 0;
+            for (int a2 = 0; a2 < 6; a2++)
+              for (int b2 = 0; b2 < 6; b2++) sx += CDOF[a2 * NR + i] * SCR[S::S_K + 72 + 6 * a2 + b2] * CDOF[b2 * NR + j];
+            v -= wgt * sx;
+          }
         }
-        if (both & 2) {
-#pragma unroll
-          for (int k = 0; k < 6; k++) v += cj[k] * BUF6B[k * NV + i];
-        }
+        HL[lane + t * G] = v;
       }
-      if (ff_active) {  // cross terms -(A_R^T K_X A_L + A_L^T K_X A_R); rare
-        const float wgt = (float)(((fi >> 1) & 1) && (fj & 1)) + (float)((fi & 1) && ((fj >> 1) & 1));
-        if (wgt != 0.0f) {
-          float s = 0;
-          for (int a = 0; a < 6; a++)
-            for (int b2 = 0; b2 < 6; b2++) s += CDOF[a * NV + i] * SCR[S::S_K + 72 + 6 * a + b2] * CDOF[b2 * NV + j];
-          v -= wgt * s;
-        }
-      }
-      HL[lane + t * G] = v;
     }
-  }
-  ODK_SYNC();
-  if (st.d_on) MA[lane] = grad;  // kept for the debug image (gradient at the starting point)
-  ODK_PROF(12);
-  factor_rows<G, S::DV, NV>(HL, lane, st.d_on, st.d_vdepth, st.d_vMadr, st.d_vdescmask, st.d_vdepth, st.d_vMadr);
-  ODK_PROF(13);
-  search = -solve_rows<G, NV>(HL, grad, lane, st.d_on, st.d_vdepth, st.d_vMadr, st.d_vancmask, st.d_vdescmask, st.d_vdepth, st.d_vMadr);
-  ODK_PROF(14);
-
+    ODK_SYNC();
+    ODK_PROF(12);
+    factor_rows<G, S::DVR, NR>(HL, lane, st.r_on, v_depth, v_Madr, v_descmask, v_depth, v_Madr);
+    ODK_PROF(13);
+    const float z = solve_rows<G, NR>(HL, rhs, lane, st.r_on, v_depth, v_Madr, v_ancmask, v_descmask, v_depth, v_Madr);
+    if constexpr (S::PAIRED) {
+      if (st.r_on) MV[lane] = z;
+      ODK_SYNC();
+      search = -pair_expand<S, G>(MV, GRAD, grad, ARM, JV, st, lane);
+    } else {
+      search = -z;
+    }
+    ODK_PROF(14);
   }
 
   // ---- line search (mjx solver._linesearch)
+  ODK_SYNC();   // every lane has read its GRAD / JV inputs
   if (st.d_on) GRAD[lane] = search;
   ODK_SYNC();
-  const float mv = mul_M(GRAD);
+  const float* VBS = GRAD;   // P^T search (twin dofs: pair sums in X, free until the step is taken)
+  if constexpr (S::PAIRED) {
+    if (st.r_on) X[lane] = pair_sum<S>(GRAD, m, lane);
+    ODK_SYNC();
+    VBS = X;
+  }
+  const float mv = mul_M(VBS, MV, search);
   float sn = st.d_on ? search * search : 0.0f, qg1 = st.d_on ? search * (ma - qfs) : 0.0f, qg2 = st.d_on ? 0.5f * search * mv : 0.0f;
   sn = gsum<G>(sn); qg1 = gsum<G>(qg1); qg2 = gsum<G>(qg2);
   ODK_SYNC();
-  {  // foot twists of the search direction, straight from registers
+  {  // foot twists of the search direction
     const int f = (lane / 6) & 1, k = lane % 6;
     float s = 0;
 #pragma unroll
-    for (int d = 0; d < NV; d++) {
-      const int fm = ubcast(st.d_foot, d);
-      const float sd = GRAD[d];
-      if ((fm >> f) & 1) s += CDOF[k * NV + d] * sd;
+    for (int d = 0; d < NR; d++) {
+      const int fm = ubcast(st.r_foot, d);
+      const float sd = VBS[d];
+      if ((fm >> f) & 1) s += CDOF[k * NR + d] * sd;
     }
     if (lane < 12) SCR[S::S_VF + lane] = s;
   }
@@ -2075,7 +2092,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
         for (int k = 0; k < 6; k++) ca[k] = CACC[k * NB + b];
         for (int d = 0; d < 6; d++) {
           const float qa = X[d];
-          for (int k = 0; k < 6; k++) ca[k] += CDOF[k * NV + d] * qa;
+          for (int k = 0; k < 6; k++) ca[k] += CDOF[k * NR + d] * qa;   // base dofs: reduced column = dof
         }
         float al3[3], wl[3], vl[3], corr[3], acc[3];
         cross3(t, dif, ca);

@@ -50,17 +50,18 @@ struct DevModel {
   // Twin dofs (backlash joints): a hinge v declared right after hinge u on the same body, same anchor, same axis, has the
   // same motion column, cdof_v == cdof_u, so M = P Mr P^T + diag(armature) with P copying each reduced column onto the
   // pair (and likewise the Newton Hessian: contact rows see the pair through the same column, friction-loss / limit rows are
-  // diagonal).  The kernels then solve on the REDUCED tree (twins merged into their main dof; odk_engine.hip:
-  // build_reduced_tables, odk_kernels.h: reduced_solve).  paired = 0: no twins / structure not recognised.
-  int paired, nvr, nMr;
-  int dof_twin[MAXV];        // partner dof (-1: none)
-  int dof_tkind[MAXV];       // 0: unpaired, 1: main dof of a pair, 2: twin
+  // diagonal).  All matrix work of the kernels runs on the REDUCED tree (twins merged into their main dof); a model without
+  // twins reduces to itself.  Built at load (odk_engine.hip: build_reduced_tables); kernel side: odk_kernels.h.
+  int paired, nvr, nMr, nHr;
+  int dof_tkind[MAXV];       // 0: unpaired, 1: main dof of a pair (its twin is dof + 1), 2: twin
   int dof_red[MAXV];         // reduced dof of this dof (a twin shares its main dof's)
-  int red_main[MAXV], red_twin[MAXV], red_depth[MAXV], red_Madr[MAXV];
-  int nrchain, rchain_first[3], rchain_len[3];
-  int R_ent[MAXNZ];          // reduced entry p: address in M (9 bits; twin diagonals: entry (twin, main), which carries no
-                             // armature) | main dof i << 9 | main dof j << 14 | feet of i << 19 | feet of j << 21 |
-                             // diagonal << 23 | pair << 24
+  int red_main[MAXV], red_twin[MAXV];                                  // per reduced dof: main dof, twin dof (-1: none)
+  int red_depth[MAXV], red_Madr[MAXV], red_ancmask[MAXV], red_descmask[MAXV], red_foot[MAXV];   // reduced tree layout (as dof_*); feet moved (bit f)
+  int rv_depth[MAXV], rv_Madr[MAXV], rv_ancmask[MAXV], rv_descmask[MAXV];                     // reduced VIRTUAL tree (as vdof_*)
+  int nrchain, rchain_first[3], rchain_len[3];                         // serial chains of the reduced tree below the floating base
+  // packed entries of the reduced layouts: ri | rj << 5 | feet of ri << 10 | feet of rj << 12 | diagonal << 14 | pair << 15 |
+  // main dof of ri << 16; virtual tree: | (address in the reduced M + 1) << 21 (0: structurally zero in M)
+  int R_ent[MAXNZ], RH_ent[MAXNZ];
   // virtual tree (Hessian)
   int vdof_depth[MAXV], vdof_anc[MAXV][MAXV], vdof_Madr[MAXV], vdof_anc_adr[MAXV][MAXV];
   int vdof_ndesc[MAXV], vdof_desc[MAXV][MAXV], vdof_desc_adr[MAXV][MAXV];

@@ -79,6 +79,39 @@ def _sparse_layout(parent: np.ndarray):
                 ancd=ancd, ancmask=to_i32(ancmask), descmask=to_i32(descmask))
 
 
+def reduced_layout(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Python mirror of csrc/odk_engine.hip build_reduced_tables (twin dofs merged into their main dof): used by the
+    parity tests to address the kernels' reduced inertia `M`.  A twin is a hinge declared right after another hinge on
+    the same body with the same axis (backlash joints): identical motion column, so the kernels keep one column per
+    pair and work on the twin-free tree.  Returns `main`, `twin` (-1: none) per reduced dof and, per entry of the
+    reduced row layout (row r = r's ancestors by depth), the pair of FULL dof indices (`ei`, `ej`) whose inertia
+    element the entry holds -- for a pair's diagonal that is (twin, main), the element without armature."""
+    nv, nj = int(a["nv"][0]), int(a["njnt"][0])
+    parent = np.asarray(a["dof_parentid"], np.int64)
+    dof_jnt = -np.ones(nv, np.int64)
+    for j in range(1, nj):
+        dof_jnt[a["jnt_dofadr"][j]] = j
+    kind = np.zeros(nv, np.int64)
+    for v in range(7, nv):
+        u = v - 1
+        ju, jv = dof_jnt[u], dof_jnt[v]
+        if ju < 0 or jv < 0 or kind[u] != 0:
+            continue
+        if a["dof_bodyid"][u] == a["dof_bodyid"][v] and parent[v] == u and np.array_equal(a["jnt_axis"][ju], a["jnt_axis"][jv]):
+            kind[u], kind[v] = 1, 2
+    red = np.zeros(nv, np.int64); main, twin = [], []
+    for d in range(nv):
+        if kind[d] == 2:
+            red[d] = red[d - 1]
+            continue
+        red[d] = len(main); main.append(d); twin.append(d + 1 if kind[d] == 1 else -1)
+    rparent = np.array([-1 if parent[u] < 0 else red[parent[u]] for u in main], np.int32)
+    lay = _sparse_layout(rparent)
+    ei = np.array([twin[i] if (i == j and twin[i] >= 0) else main[i] for i, j in zip(lay["ei"], lay["ej"])], np.int64)
+    ej = np.array([main[j] for j in lay["ej"]], np.int64)
+    return dict(main=np.array(main), twin=np.array(twin), red=red, kind=kind, ei=ei, ej=ej, nnz=lay["nnz"])
+
+
 def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     nv, nb, nj, nu = int(a["nv"][0]), int(a["nbody"][0]), int(a["njnt"][0]), int(a["nu"][0])
     if nv > MAXV or nb > MAXB:

@@ -75,9 +75,14 @@ def test_one_substep_stages(torch_cuda, oracle_mod, task, lanes):
     nv, nb = model.nv, model.nbody
     worst = dict(xpos=0, M=0, qfs=0, qas=0, dist=0, D=0, aref=0, qacc=0, qpos=0, qvel=0, sens=0)
     o = {k: b.lds_offset(k) for k in ("xpos", "M", "qfrc_smooth", "qacc_smooth", "contact_dist", "efc_D", "efc_aref", "qacc", "sensordata", "actuator_force")}
-    from open_duck_playground_amd.tables import build_kernel_tables
+    from open_duck_playground_amd.tables import build_kernel_tables, reduced_layout
     tabs = build_kernel_tables(model.a)
-    Mi, Mj = tabs["k_M_i"], tabs["k_M_j"]
+    red = reduced_layout(model.a)     # the kernels keep the inertia on the reduced (backlash twins merged) tree
+    Mi, Mj = red["ei"], red["ej"]
+    if task == "flat_terrain":
+        assert np.array_equal(Mi, tabs["k_M_i"]) and np.array_equal(Mj, tabs["k_M_j"])   # no twins: the model's own layout
+    else:
+        assert len(Mi) == 145 and (red["twin"] >= 0).sum() == 10
     nfl, nlim = len(tabs["k_fl_dof"]), len(tabs["k_lim_jnt"])
     for e in range(n):
         d = oracle_mod.OracleData(om)
