@@ -819,6 +819,17 @@ static bool build_reduced_tables(DevModel& m) {
     if (e - d + 1 > 5) ok = false;
     d = e + 1;
   }
+  // the reduced dofs above a foot must be exactly the six base dofs + one whole chain (foot_twist in odk_kernels.h)
+  for (int f = 0; f < 2 && ok; f++) {
+    int c = -1;
+    for (int k = 0; k < m.nrchain; k++) if ((m.red_foot[m.rchain_first[k]] >> f) & 1) c = k;
+    ok = c >= 0;
+    for (int r = 0; r < nr && ok; r++) {
+      const bool want = r < 6 || (r >= m.rchain_first[c] && r < m.rchain_first[c] + m.rchain_len[c]);
+      ok = (((m.red_foot[r] >> f) & 1) != 0) == want;
+    }
+    if (ok) { m.foot_rchain_first[f] = m.rchain_first[c]; m.foot_rchain_len[f] = m.rchain_len[c]; }
+  }
   if (ok && !m.paired) {   // a model without twins reduces to itself: the tables above must be the blob's own (tables.py)
     ok = m.nMr == m.nM && m.nHr == m.nH;
     for (int r = 0; r < nr && ok; r++)

@@ -1648,15 +1648,31 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     ODK_SYNC();
     VBQ = X; VBW = MA;
   }
+  // component k of foot f's twist for the reduced vector V (LDS): the dofs above a foot are the six base dofs and the foot's
+  // own serial chain (DevModel::foot_rchain, checked at load), so the sum is 6 + chain-length terms with compile-time
+  // offsets -- no per-dof foot mask (a v_readlane each), no predicate.  Generic trees keep the masked loop over all dofs.
+  auto foot_twist = [&](const float* V, int k, int f) -> float {
+    float s = 0;
+    if constexpr (S::CL > 0) {
+      const int c0 = f ? m->foot_rchain_first[1] : m->foot_rchain_first[0], cl = f ? m->foot_rchain_len[1] : m->foot_rchain_len[0];
+      const float* cd = CDOF + k * NR;
+#pragma unroll
+      for (int t = 0; t < 6; t++) s += cd[t] * V[t];
+#pragma unroll
+      for (int t = 0; t < S::CL; t++) { const float a = cd[c0 + t] * V[c0 + t]; s += t < cl ? a : 0.0f; }   // in-bounds of the LDS image even past the chain
+    } else {
+#pragma unroll
+      for (int d = 0; d < NR; d++) {
+        const int fm = ubcast(st.r_foot, d);
+        const float vd = V[d];
+        if ((fm >> f) & 1) s += CDOF[k * NR + d] * vd;
+      }
+    }
+    return s;
+  };
   {
     const int which = (lane / 12) & 1, f = (lane / 6) & 1, k = lane % 6;
-    float s = 0;
-#pragma unroll
-    for (int d = 0; d < NR; d++) {
-      const int fm = ubcast(st.r_foot, d);
-      const float vq = VBQ[d], vw = VBW[d];   // uniform addresses: LDS broadcast reads
-      if ((fm >> f) & 1) s += CDOF[k * NR + d] * (which ? vw : vq);
-    }
+    const float s = foot_twist(which ? VBW : VBQ, k, f);
     if (lane < 24) SCR[(which ? S::S_VF2 : S::S_VF) + 6 * f + k] = s;
   }
   // M * warmstart from the register row
@@ -1948,14 +1964,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   sn = gsum<G>(sn); qg1 = gsum<G>(qg1); qg2 = gsum<G>(qg2);
   ODK_SYNC();
   {  // foot twists of the search direction
-    const int f = (lane / 6) & 1, k = lane % 6;
-    float s = 0;
-#pragma unroll
-    for (int d = 0; d < NR; d++) {
-      const int fm = ubcast(st.r_foot, d);
-      const float sd = VBS[d];
-      if ((fm >> f) & 1) s += CDOF[k * NR + d] * sd;
-    }
+    const float s = foot_twist(VBS, lane % 6, (lane / 6) & 1);
     if (lane < 12) SCR[S::S_VF + lane] = s;
   }
   ODK_SYNC();

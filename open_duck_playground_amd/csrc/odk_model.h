@@ -59,6 +59,7 @@ struct DevModel {
   int red_depth[MAXV], red_Madr[MAXV], red_ancmask[MAXV], red_descmask[MAXV], red_foot[MAXV];   // reduced tree layout (as dof_*); feet moved (bit f)
   int rv_depth[MAXV], rv_Madr[MAXV], rv_ancmask[MAXV], rv_descmask[MAXV];                     // reduced VIRTUAL tree (as vdof_*)
   int nrchain, rchain_first[3], rchain_len[3];                         // serial chains of the reduced tree below the floating base
+  int foot_rchain_first[2], foot_rchain_len[2];                        // the chain that carries foot f: the reduced dofs above the foot are 0..5 + this chain
   // packed entries of the reduced layouts: ri | rj << 5 | feet of ri << 10 | feet of rj << 12 | diagonal << 14 | pair << 15 |
   // main dof of ri << 16; virtual tree: | (address in the reduced M + 1) << 21 (0: structurally zero in M)
   int R_ent[MAXNZ], RH_ent[MAXNZ];
