@@ -137,9 +137,20 @@ __device__ inline void sample_command(const EnvCfg& c, uint32_t k0, uint32_t k1,
   out = (z < 0.1f) ? 0.0f : c.cmd_range[k][0] + u * (c.cmd_range[k][1] - c.cmd_range[k][0]);
 }
 
-// _get_obs (joystick.py:487-620): builds privileged_state[212] (whose first 101 entries are `state`) in LDS
+// Draws 4 .. 49 of stream (k0, k1, ctr) in ONE threefry evaluation: lane l < 23 computes block l + 2, whose two words are
+// draws 4 + 2 l and 5 + 2 l; NZ[i - 4] = draw i.  (The observation noise and the command resampling used to call the
+// generator from inside divergent branches: ~8 serial threefry evaluations per env step.)
+constexpr int ODK_NDRAW = 46;
+__device__ __forceinline__ void draw_block(uint32_t k0, uint32_t k1, uint32_t ctr, float* NZ, int lane) {
+  uint32_t a, b;
+  threefry2x32(k0, k1, ctr, (uint32_t)(lane + 2), a, b);
+  if (lane < ODK_NDRAW / 2) { NZ[2 * lane] = (float)(a >> 8) * (1.0f / 16777216.0f); NZ[2 * lane + 1] = (float)(b >> 8) * (1.0f / 16777216.0f); }
+  ODK_SYNC();
+}
+
+// _get_obs (joystick.py:487-620): builds privileged_state[212] (whose first 101 entries are `state`) in LDS; NZ: draw_block
 template <class S, int G>
-__device__ __forceinline__ void build_obs(float* L, const DevModel* m, const EnvCfg& c, const float* contact, uint32_t k0, uint32_t k1, uint32_t ctr,
+__device__ __forceinline__ void build_obs(float* L, const DevModel* m, const EnvCfg& c, const float* contact, const float* NZ,
                           int imitation_i, const float* phase, int lane) {
   using E = EnvL<S>;
   float* P = L + E::O_PRIV; float* INFO = L + E::O_INFO; const float* SENS = L + S::O_SENS; const float* SCR = L + S::O_SCR;
@@ -148,7 +159,7 @@ __device__ __forceinline__ void build_obs(float* L, const DevModel* m, const Env
   constexpr int NU = S::NU;
   // imu history ring (noisy gravity, never emitted: joystick.py:522-530)
   float ng = 0;
-  if (lane < 3) ng = SCR[S::S_MISC + 10 + lane] + (2.0f * rng_uniform(k0, k1, ctr, 10 + lane) - 1.0f) * lvl * c.noise_gravity;
+  if (lane < 3) ng = SCR[S::S_MISC + 10 + lane] + (2.0f * NZ[10 - 4 + lane] - 1.0f) * lvl * c.noise_gravity;
   float h0 = 0, h1 = 0;
   if (lane < 3) { h0 = INFO[rec::IMU + lane]; h1 = INFO[rec::IMU + 3 + lane]; }
   ODK_SYNC();
@@ -158,16 +169,16 @@ __device__ __forceinline__ void build_obs(float* L, const DevModel* m, const Env
   for (int ks = lane; ks < c.npriv; ks += G) {
     const int k = !standing ? ks : (ks < 13 + 5 * NU ? ks : (ks < 15 + 5 * NU ? ks + NU : ks + ODK_NOBS - (15 + 5 * NU)));
     float v = 0;
-    if (k < 3) v = SENS[m->adr_gyro + k] + (2.0f * rng_uniform(k0, k1, ctr, 4 + k) - 1.0f) * lvl * c.noise_gyro;
-    else if (k < 6) v = SENS[m->adr_accelerometer + k - 3] + (2.0f * rng_uniform(k0, k1, ctr, 7 + k - 3) - 1.0f) * lvl * c.noise_accelerometer;
+    if (k < 3) v = SENS[m->adr_gyro + k] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_gyro;
+    else if (k < 6) v = SENS[m->adr_accelerometer + k - 3] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_accelerometer;
     else if (k < 13) v = INFO[rec::CMD + k - 6];
     else if (k < 13 + NU) {
       const int u = k - 13, bq = m->act_backlash_qposadr[u];
       const float ja = QPOS[m->act_qposadr[u]] + (bq >= 0 ? QPOS[bq] : 0.0f);
-      v = ja + (2.0f * rng_uniform(k0, k1, ctr, 13 + u) - 1.0f) * lvl * c.qpos_noise_scale[u] - m->key_ctrl[u];
+      v = ja + (2.0f * NZ[13 - 4 + u] - 1.0f) * lvl * c.qpos_noise_scale[u] - m->key_ctrl[u];
     } else if (k < 13 + 2 * NU) {
       const int u = k - 13 - NU;
-      v = (QVEL[m->act_dofadr[u]] + (2.0f * rng_uniform(k0, k1, ctr, 27 + u) - 1.0f) * lvl * c.noise_joint_vel) * c.dof_vel_scale;
+      v = (QVEL[m->act_dofadr[u]] + (2.0f * NZ[27 - 4 + u] - 1.0f) * lvl * c.noise_joint_vel) * c.dof_vel_scale;
     } else if (k < 13 + 3 * NU) v = INFO[rec::LAST + k - 13 - 2 * NU];
     else if (k < 13 + 4 * NU) v = INFO[rec::LAST2 + k - 13 - 3 * NU];
     else if (k < 13 + 5 * NU) v = INFO[rec::LAST3 + k - 13 - 4 * NU];
@@ -277,7 +288,8 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   foot_contact_flags(L + S::O_CDIST, contact);
   const float phase[2] = {0, 0};
   // stash state before the obs overwrites the M|HL region?  (qpos/qvel/warm live elsewhere: safe)
-  build_obs<S, G>(L, m, c, contact, k0, k1, 0u, 0, phase, lane);
+  draw_block(k0, k1, 0u, L + S::O_BUF6, lane);   // the motion-column buffers are dead after the forward pass
+  build_obs<S, G>(L, m, c, contact, L + S::O_BUF6, 0, phase, lane);
   if (lane == 0) {
     INFO[rec::KEY0] = i2f((int)k0); INFO[rec::KEY1] = i2f((int)k1); INFO[rec::CTR] = i2f(1);
     INFO[rec::STEP] = i2f(0); INFO[rec::PSTEP] = i2f(0); INFO[rec::PINT] = i2f(push_interval_steps);
@@ -357,10 +369,13 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   ODK_SYNC();
   for (int u = lane; u < NU; u += G) { INFO[rec::AHIST + u] = ACT[u]; INFO[rec::AHIST + NU + u] = h0; INFO[rec::AHIST + 2 * NU + u] = h1; }
   ODK_SYNC();
-  const int aidx = randint3(rng_uniform(k0, k1, ctr, 0));
+  uint32_t w0, w1, w2, w3;   // draws 0 | 1 (unused) and 2 | 3: two generator blocks
+  threefry2x32(k0, k1, ctr, 0u, w0, w1);
+  threefry2x32(k0, k1, ctr, 1u, w2, w3);
+  const int aidx = randint3((float)(w0 >> 8) * (1.0f / 16777216.0f));
   // ---- push (:381-398)
-  const float theta = rng_uniform(k0, k1, ctr, 2) * (2.0f * PI_F);
-  const float mag = c.push_magnitude_range[0] + rng_uniform(k0, k1, ctr, 3) * (c.push_magnitude_range[1] - c.push_magnitude_range[0]);
+  const float theta = (float)(w2 >> 8) * (1.0f / 16777216.0f) * (2.0f * PI_F);
+  const float mag = c.push_magnitude_range[0] + (float)(w3 >> 8) * (1.0f / 16777216.0f) * (c.push_magnitude_range[1] - c.push_magnitude_range[0]);
   const float gate = (((push_step + 1) % push_int) == 0 ? 1.0f : 0.0f) * c.push_enable;
   const float push[2] = {cosf(theta) * gate, sinf(theta) * gate};
   if (lane < 2) L[S::O_QVEL + lane] += push[lane] * mag;
@@ -415,6 +430,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   float ep_steps_e = INFO[rec::EPSTEPS];
   const float prev_done_e = INFO[rec::DONE];
   for (int u = lane; u < NU; u += G) INFO[rec::MT + u] = CTRL[u];  // info["motor_targets"] (:422)
+  draw_block(k0e, k1e, ctre, L + S::O_BUF6, lane);   // the motion-column buffers are dead after the last forward pass
   // ---- contacts, air time, swing peak (:424-435)
   float contact[2];
   foot_contact_flags(L + S::O_CDIST, contact);
@@ -491,14 +507,18 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   for (int k = 0; k < 7; k++) { rew[k] *= c.reward_scales[k]; total += rew[k]; }
   const float reward = fminf(fmaxf(total * dt, 0.0f), 10000.0f);
   // ---- obs (uses the pre-shift last_act and the post-increment air time; :437)
-  build_obs<S, G>(L, mp, c, contact, k0e, k1e, ctre, imi_e, phase_e, lane);
+  const float* NZ = L + S::O_BUF6;   // this step's draws 4 .. 49 (drawn above, before the reward block)
+  build_obs<S, G>(L, mp, c, contact, NZ, imi_e, phase_e, lane);
   // ---- info updates (:449-469)
   step_e += 1; push_step_e += 1;
   float la = 0, lla = 0;
   for (int u = lane; u < NU; u += G) { la = INFO[rec::LAST + u]; lla = INFO[rec::LAST2 + u]; }
   ODK_SYNC();
   for (int u = lane; u < NU; u += G) { INFO[rec::LAST3 + u] = lla; INFO[rec::LAST2 + u] = la; INFO[rec::LAST + u] = ACT[u]; }
-  if (step_e > 500 && lane < 7) sample_command(c, k0e, k1e, ctre, 41, lane, INFO[rec::CMD + lane]);
+  if (step_e > 500 && lane < 7) {   // sample_command (joystick.py:671-725) on draws 41 .. 48 of this step
+    const float z = NZ[41 + 7 - 4], u = NZ[41 - 4 + lane];
+    INFO[rec::CMD + lane] = (z < 0.1f) ? 0.0f : c.cmd_range[lane][0] + u * (c.cmd_range[lane][1] - c.cmd_range[lane][0]);
+  }
   if (done_env || step_e > 500) step_e = 0;
   int lcon_new = 0;
   for (int f = 0; f < 2; f++) {

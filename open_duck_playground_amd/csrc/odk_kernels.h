@@ -176,6 +176,26 @@ template <int G, class Op> __device__ __forceinline__ float greduce(float v) {
   return v;
 }
 template <int G> __device__ __forceinline__ float gsum(float v) { return greduce<G, OpSum>(v); }
+// N sums at once (G = 32): the four in-row butterfly stages on the VALU as above, then the two rows are exchanged by
+// ds_swizzle (xor 16 inside each 32-lane group: the LDS crossbar, no memory access and no VALU slot) instead of
+// v_permlane16_swap (~8 cycles of VALU issue each); the N swizzles are in flight together, so their latency is paid once.
+template <int G, int N> __device__ __forceinline__ void gsum_n(float* v) {
+  if constexpr (G == 32) {
+    float o[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      float x = v[i];
+      x += ODK_DPP(x, 0xB1, 0xF); x += ODK_DPP(x, 0x4E, 0xF); x += ODK_DPP(x, 0x141, 0xF); x += ODK_DPP(x, 0x140, 0xF);
+      v[i] = x;
+      o[i] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));   // bit mode: and 0x1F, or 0, xor 0x10
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += o[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = gsum<G>(v[i]);
+  }
+}
 // max / min / argmax run on order-preserving unsigned keys: integer v_max_u32 / v_min_u32 fold the DPP permute into the
 // op (float max needs a canonicalising v_max x, x per stage under IEEE mode, and then the permute stays a separate mov)
 __device__ __forceinline__ unsigned fkey(float v) { const unsigned b = __float_as_uint(v); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
@@ -1731,9 +1751,8 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     }
     JAR[r] = js; JV[r] = jw;
   }
-  cost_s = gsum<G>(cost_s);
-  const float gauss_w = 0.5f * gsum<G>(gw);
-  cost_w = gsum<G>(cost_w) + gauss_w;
+  float gauss_w;
+  { float r3[3] = {cost_s, gw, cost_w}; gsum_n<G, 3>(r3); cost_s = r3[0]; gauss_w = 0.5f * r3[1]; cost_w = r3[2] + gauss_w; }
   const bool use_warm = cost_w < cost_s;
   const float gauss = use_warm ? gauss_w : 0.0f;
   const float x = use_warm ? warm : qas;
@@ -1961,7 +1980,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   }
   const float mv = mul_M(VBS, MV, search);
   float sn = st.d_on ? search * search : 0.0f, qg1 = st.d_on ? search * (ma - qfs) : 0.0f, qg2 = st.d_on ? 0.5f * search * mv : 0.0f;
-  sn = gsum<G>(sn); qg1 = gsum<G>(qg1); qg2 = gsum<G>(qg2);
+  { float r3[3] = {sn, qg1, qg2}; gsum_n<G, 3>(r3); sn = r3[0]; qg1 = r3[1]; qg2 = r3[2]; }
   ODK_SYNC();
   {  // foot twists of the search direction
     const float s = foot_twist(VBS, lane % 6, (lane / 6) & 1);
@@ -2017,8 +2036,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
           if (jar + al[a] * jv < 0) { acc[3 * a] += q0; acc[3 * a + 1] += q1; acc[3 * a + 2] += q2; }
       }
     }
-#pragma unroll
-    for (int k = 0; k < 9; k++) acc[k] = gsum<G>(acc[k]);
+    gsum_n<G, 9>(acc);
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const float t0 = acc[3 * a] + gauss, t1 = acc[3 * a + 1] + qg1, t2 = acc[3 * a + 2] + qg2;
