@@ -99,6 +99,15 @@ int odk_model_load(const void* blob, uint64_t len, odk_model** out);
 void odk_model_free(odk_model* m);
 int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int* nbody);
 
+/* Twin dofs (backlash joints: a hinge declared right after another hinge on the same body, same anchor and axis) share
+ * their motion column, so the kernels keep the inertia / Newton Hessian on the REDUCED tree with the twins merged
+ * (csrc/odk_model.h DevModel::paired).  Reports that reduction: paired (0 / 1), reduced dof count, entries of the reduced
+ * tree layout and of its virtual (Hessian) tree, and per reduced dof the main dof and the twin dof (-1: none); arrays of
+ * >= 32 ints, any pointer may be NULL.  Host-only (no GPU needed). */
+int odk_model_reduced(const odk_model* m, int* paired, int* nvr, int* nMr, int* nHr, int* red_main, int* red_twin);
+/* floats of LDS one env occupies in the fused step kernel (8 single-wave workgroups of two envs per CU need <= 2560) */
+int odk_model_env_lds_floats(const odk_model* m);
+
 /* One batch of `nenv` environments resident on HIP device `device`.  `prm_table` is the host
  * [nx,ny,nth,40,16] float32 reference-motion table (poly_reference_motion.py), grids in float64. */
 int odk_batch_create(const odk_model* m, const odk_env_config* cfg, int nenv, int device, const float* prm_table,

@@ -1079,6 +1079,17 @@ extern "C" int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int
 // occupancy by construction: 2 waves / SIMD = 8 single-wave workgroups per CU need <= 160 KiB / 8 of LDS per workgroup (2 envs)
 static_assert(2 * EnvL<ShapeA>::TOTAL * sizeof(float) <= 20480, "shape A: LDS image too large for 8 workgroups per CU");
 static_assert(2 * EnvL<ShapeB>::TOTAL * sizeof(float) <= 20480, "shape B: LDS image too large for 8 workgroups per CU");
+extern "C" int odk_model_reduced(const odk_model* m, int* paired, int* nvr, int* nMr, int* nHr, int* red_main, int* red_twin) {
+  if (!m) return fail(ODK_ERR_INVALID, "null model");
+  if (paired) *paired = m->h.paired; if (nvr) *nvr = m->h.nvr; if (nMr) *nMr = m->h.nMr; if (nHr) *nHr = m->h.nHr;
+  for (int r = 0; r < m->h.nvr; r++) { if (red_main) red_main[r] = m->h.red_main[r]; if (red_twin) red_twin[r] = m->h.red_twin[r]; }
+  return ODK_OK;
+}
+extern "C" int odk_model_env_lds_floats(const odk_model* m) {
+  if (!m) return -1;
+  return m->shape == 0 ? EnvL<ShapeA>::TOTAL : EnvL<ShapeB>::TOTAL;
+}
+
 template <class S> static void fill_sizes(odk_batch* b) {
   b->rec_size = Rec<S>::SIZE; b->frec_size = Rec<S>::FSIZE; b->lds_total = S::TOTAL; b->dr_size = DRL<S>::SIZE; b->env_lds = EnvL<S>::TOTAL;
 }

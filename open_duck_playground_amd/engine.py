@@ -80,6 +80,8 @@ def load_library() -> C.CDLL:
     L.odk_model_load.argtypes = [C.c_char_p, C.c_uint64, PP]
     L.odk_model_free.argtypes = [P]
     L.odk_model_dims.argtypes = [P] + [C.POINTER(C.c_int)] * 4
+    L.odk_model_reduced.argtypes = [P] + [C.POINTER(C.c_int)] * 6
+    L.odk_model_env_lds_floats.argtypes = [P]
     L.odk_batch_create.argtypes = [P, C.POINTER(EnvConfig), C.c_int, C.c_int, FP, DP, C.c_int, DP, C.c_int, DP, C.c_int, DP, C.c_int, PP]
     L.odk_batch_destroy.argtypes = [P]
     L.odk_batch_set_config.argtypes = [P, C.POINTER(EnvConfig)]
@@ -110,7 +112,8 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "odk_last_error", "odk_default_config", "odk_default_config_standing", "odk_obs_sizes", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_batch_create",
+    "odk_last_error", "odk_default_config", "odk_default_config_standing", "odk_obs_sizes", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_model_reduced",
+    "odk_model_env_lds_floats", "odk_batch_create",
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
@@ -134,6 +137,23 @@ def obs_sizes(env_kind: int):
     a, b = C.c_int(0), C.c_int(0)
     load_library().odk_obs_sizes(int(env_kind), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def model_reduction(model: Model) -> Dict:
+    """The twin-dof reduction the kernels use for `model` (odk_model_reduced) + its LDS footprint; host-only, no GPU."""
+    L = load_library()
+    blob = model.blob()
+    h = C.c_void_p()
+    _chk(L.odk_model_load(blob, len(blob), C.byref(h)))
+    try:
+        ints = [C.c_int(0) for _ in range(4)]
+        main, twin = (C.c_int * 32)(), (C.c_int * 32)()
+        _chk(L.odk_model_reduced(h, *[C.byref(i) for i in ints], main, twin))
+        nvr = ints[1].value
+        return dict(paired=ints[0].value, nvr=nvr, nMr=ints[2].value, nHr=ints[3].value, main=list(main)[:nvr], twin=list(twin)[:nvr],
+                    env_lds_floats=L.odk_model_env_lds_floats(h))
+    finally:
+        L.odk_model_free(h)
 
 
 def load_prm() -> Dict[str, np.ndarray]:

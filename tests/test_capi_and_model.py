@@ -94,6 +94,26 @@ def test_blob_roundtrip_and_tables(model_a, model_b):
         assert (t["k_foot_dofmask"].sum(axis=1) == [6 + (nv - 6 - 4) // 2] * 2).all()
 
 
+def test_twin_dof_reduction_of_the_loader_matches_the_python_mirror(model_a, model_b):
+    """csrc build_reduced_tables (host side of the kernels' reduced tree) == tables.reduced_layout; the backlash model
+    reduces to the 20-dof robot's own tree (145 / 170 entries) and both LDS images fit 8 workgroups per CU."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.tables import build_kernel_tables, reduced_layout
+    for m, paired in ((model_a, 0), (model_b, 1)):
+        got, ref = engine.model_reduction(m), reduced_layout(m.a)
+        assert got["paired"] == paired and got["nvr"] == 20 and got["nMr"] == ref["nnz"] == 145 and got["nHr"] == 170
+        assert got["main"] == list(ref["main"]) and got["twin"] == list(ref["twin"])
+        assert got["env_lds_floats"] * 4 * 2 <= 160 * 1024 // 8          # two envs per single-wave workgroup, 8 workgroups per CU
+    ref_b = reduced_layout(model_b.a)
+    assert list(ref_b["twin"][6:11]) == [7, 9, 11, 13, 15] and list(ref_b["twin"][11:15]) == [-1] * 4   # legs have twins, the head has none
+    # reduced entries address the inertia element of the main dofs; a pair's diagonal is the (twin, main) element (no armature)
+    ta = build_kernel_tables(model_a.a)
+    ref_a = reduced_layout(model_a.a)
+    assert np.array_equal(ref_a["ei"], ta["k_M_i"]) and np.array_equal(ref_a["ej"], ta["k_M_j"])
+    for p, (i, j) in enumerate(zip(ref_b["ei"], ref_b["ej"])):
+        assert ref_b["kind"][j] != 2 and (ref_b["kind"][i] != 2 or i == j + 1)
+
+
 def test_unknown_task_and_env_errors():
     from open_duck_playground_amd import constants
     with pytest.raises(KeyError):     # reference constants.py:28-34

@@ -194,6 +194,42 @@ def test_train_loop_epochs_evaluator_and_callbacks(tmp_path):
     assert [l["step"] for l in lines] == [0, 1280, 2560, 3840]
 
 
+def _train_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    env = _ToyEnv(32, seed=10 + rank)                             # every rank steps its own env shard
+    seen = []
+    net, metrics = T.train(env, num_timesteps=2 * 32 * 5 * 6, progress_fn=lambda s, m: seen.append((s, dict(m))), seed=0, num_evals=3,
+                           unroll_length=5, num_minibatches=4, num_updates_per_batch=2, episode_length=20, num_eval_envs=8, learning_rate=3e-3,
+                           network_factory=dict(policy_hidden_layer_sizes=(16,), value_hidden_layer_sizes=(16,)))
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [net.norm_obs.mean, net.norm_obs.std])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    out.put((rank, [s for s, _ in seen], bool(torch.equal(gathered[0], gathered[1])), float(net.norm_obs.count),
+             sorted(k for k in metrics if k.startswith("training/"))))
+    dist.destroy_process_group()
+
+
+def test_train_loop_two_ranks_gloo():
+    """The whole training loop under data parallelism (what `torchrun ... runner` runs per GPU, with gloo instead of RCCL):
+    env shards per rank, all-reduced gradients / normaliser moments / loss means, evaluation and callbacks on rank 0 only,
+    and the per-epoch replica check (train.assert_replicas_identical) passing on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs: p.join(timeout=60)
+    (r0, steps0, same0, count0, keys0), (r1, steps1, same1, count1, keys1) = res
+    assert (r0, r1) == (0, 1) and same0 and same1
+    assert steps0 == [0, 960, 1920] and steps1 == []              # progress / evaluation on rank 0 only; env steps count both shards
+    assert count0 == count1 == 1920                               # normaliser statistics cover both ranks' rollouts
+    assert "training/total_loss" in keys0 and "training/sps" in keys0
+
+
 def test_loss_meter_and_sgd_epoch_report_means_over_all_steps():
     torch.manual_seed(0)
     gen = torch.Generator().manual_seed(0)
