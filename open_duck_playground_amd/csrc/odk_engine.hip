@@ -38,12 +38,31 @@ template <class S> struct Rec {
 // extra LDS used by the env logic, placed after the physics arrays
 template <class S> struct EnvL {
   static constexpr int O_INFO = S::TOTAL;          // [144]
-  static constexpr int O_REF = O_INFO + 144;       // [40] current_reference_motion
-  static constexpr int O_ACT = O_REF + 40;         // [16] this step's action
+  static constexpr int O_ACT = O_INFO + 144;       // [16] this step's action
+  // epilogue only, on top of the motion-column buffers (dead after the last forward pass): this step's random draws and the
+  // reference motion (evaluated in the epilogue: reward and privileged obs are its only readers)
+  static constexpr int O_NZ = S::O_BUF6;           // [46] draw_block
+  static constexpr int O_REF = S::O_BUF6 + 48;     // [40] current_reference_motion
+  static_assert(48 + 40 <= 6 * S::NVR, "draws + reference motion must fit in BUF6");
   static constexpr int O_PRIV = S::O_M;            // [212] aliases M|HL (dead after the last forward)
   static constexpr int TOTAL = O_ACT + 16;
   static_assert(S::NMR + S::NHR >= ODK_NPRIV, "privileged obs must fit in the M|HL region");
+  // per WORKGROUP, behind the envs' images: static tables shared by the envs of the workgroup
+  static constexpr int SHARED = S::SHARED;       // DevModel::R_ent | contact-row constants (forward_env: RT, CT)
+  static constexpr int wg_floats(int envs) { return envs * TOTAL + SHARED; }
 };
+// the workgroup's copy of the shared tables (call with all 64 lanes; followed by a hand-off barrier at the caller)
+template <class S> __device__ __forceinline__ const int* load_shared(float* lds, int envs, const DevModel* m) {
+  int* RT = reinterpret_cast<int*>(lds + envs * EnvL<S>::TOTAL);
+  for (int k = threadIdx.x; k < S::NMR; k += 64) RT[k] = m->R_ent[k];
+  float* SH = reinterpret_cast<float*>(RT);
+  float* CT = SH + S::SH_CT;
+  const int k = threadIdx.x;
+  if (k < 3) { CT[k] = m->pair_mu[k]; CT[3 + k] = m->pair_invweight[k]; }
+  if (k < 27) CT[6 + k] = m->pair_imp[k / 9][k % 9];
+  if (k < 9) CT[33 + k] = m->plane_frame[k];
+  return RT;
+}
 
 using ShapeA = Shape<21, 20, 18, 14, 15, 145, 170, 76, 10, 15>;   // flat_terrain
 using ShapeB = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25>;   // *_backlash
@@ -128,6 +147,23 @@ __device__ __forceinline__ void prm_eval(const DevPRM* p, const float* table, fl
     for (int q = 1; q < 16; q++) yv = fmaf(yv, t, c[k * 16 + q]);
     out[k] = yv;
   }
+}
+// the same evaluation into two registers per lane (dims lane and lane + 32; G = 32 or 64): the step kernel evaluates the
+// reference motion in its prologue, where the table loads overlap the state loads, and parks it in LDS only in the epilogue
+template <int G>
+__device__ __forceinline__ void prm_eval_regs(const DevPRM* p, const float* table, float dx, float dy, float dth, int i, float& r0, float& r1, int lane) {
+  const float x = fminf(fmaxf(dx, p->ranges[0]), p->ranges[1]);
+  const float y = fminf(fmaxf(dy, p->ranges[2]), p->ranges[3]);
+  const float t3 = fminf(fmaxf(dth, p->ranges[4]), p->ranges[5]);
+  const int ix = prm_nearest(p->dxs, p->nx, x), iy = prm_nearest(p->dys, p->ny, y), it = prm_nearest(p->dths, p->nth, t3);
+  float t = (float)(i % p->nsteps) / (float)p->nsteps;
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  const float* c = table + ((size_t)((ix * p->ny + iy) * p->nth + it)) * 640;
+  const int k0 = lane < 40 ? lane : 0, k1 = lane + 32 < 40 ? lane + 32 : 0;
+  float a = c[k0 * 16], b = c[k1 * 16];
+#pragma unroll
+  for (int q = 1; q < 16; q++) { a = fmaf(a, t, c[k0 * 16 + q]); b = fmaf(b, t, c[k1 * 16 + q]); }
+  r0 = a; r1 = b;
 }
 
 // sample_command (joystick.py:671-725); draws base..base+7 of stream (k0,k1,ctr)
@@ -242,6 +278,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   const bool live = env < a.nenv;
   const int e = live ? env : a.nenv - 1;
   float* L = lds + slot * E::TOTAL;
+  const int* RT = load_shared<S>(lds, 64 / G, a.m);   // ordered before its first use by the ODK_SYNCs below
 #ifdef ODK_POISON_LDS   // debug build: every read of LDS that was not written by this launch surfaces as NaN
   for (int k = lane; k < E::TOTAL; k += G) L[k] = __int_as_float(0x7fc00000);
   ODK_SYNC();
@@ -277,7 +314,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   }
   if (lane < 7) sample_command(c, k0, kr, 0, 23, lane, INFO[rec::CMD + lane]);
   ODK_SYNC();
-  forward_env<S, G, HF>(L, m, a.hfield, st, lane, 1);
+  forward_env<S, G, HF>(L, RT, m, a.hfield, st, lane, 1);
   if (a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
   const float pint = c.push_interval_range[0] + rng_uniform(k0, kr, 0, 31) * (c.push_interval_range[1] - c.push_interval_range[0]);
   const int push_interval_steps = (int)rintf(pint / c.ctrl_dt);
@@ -288,8 +325,8 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   foot_contact_flags(L + S::O_CDIST, contact);
   const float phase[2] = {0, 0};
   // stash state before the obs overwrites the M|HL region?  (qpos/qvel/warm live elsewhere: safe)
-  draw_block(k0, k1, 0u, L + S::O_BUF6, lane);   // the motion-column buffers are dead after the forward pass
-  build_obs<S, G>(L, m, c, contact, L + S::O_BUF6, 0, phase, lane);
+  draw_block(k0, k1, 0u, L + E::O_NZ, lane);   // the motion-column buffers are dead after the forward pass
+  build_obs<S, G>(L, m, c, contact, L + E::O_NZ, 0, phase, lane);
   if (lane == 0) {
     INFO[rec::KEY0] = i2f((int)k0); INFO[rec::KEY1] = i2f((int)k1); INFO[rec::CTR] = i2f(1);
     INFO[rec::STEP] = i2f(0); INFO[rec::PSTEP] = i2f(0); INFO[rec::PINT] = i2f(push_interval_steps);
@@ -326,6 +363,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   const bool live = env < a.nenv;
   const int e = live ? env : a.nenv - 1;
   float* L = lds + slot * E::TOTAL;
+  const int* RT = load_shared<S>(lds, 64 / G, a.m);   // ordered before its first use by the ODK_SYNCs below
 #ifdef ODK_POISON_LDS   // debug build: every read of LDS that was not written by this launch surfaces as NaN
   for (int k = lane; k < E::TOTAL; k += G) L[k] = __int_as_float(0x7fc00000);
   ODK_SYNC();
@@ -354,14 +392,14 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   const float dt = c.ctrl_dt;
   // ---- imitation phase + reference motion (:325-355)
   float phase[2] = {0, 0};
+  float ref0 = 0.0f, ref1 = 0.0f;   // current_reference_motion[lane], [lane + 32]: two registers across the substeps
   if (c.use_imitation) {
     imi = (imi + 1) % a.prm->nsteps;
     const float ph = ((float)imi / (float)a.prm->nsteps) * 2.0f * PI_F;
     phase[0] = cosf(ph); phase[1] = sinf(ph);
-    prm_eval<G>(a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], imi, L + E::O_REF, lane);
+    prm_eval_regs<G>(a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], imi, ref0, ref1, lane);   // (:347-353)
   } else {
     imi = 0;
-    for (int k = lane; k < 40; k += G) L[E::O_REF + k] = 0;
   }
   // ---- action delay ring (:362-376): roll by nu, newest first
   float h0 = 0, h1 = 0;
@@ -412,7 +450,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     int lane_s = lane;
     asm volatile("" : "+v"(lane_s));
     __builtin_assume(lane_s >= 0 && lane_s < 64);
-    forward_env<S, G, HF>(L, ms, a.hfield, st, lane_s, last ? 1 : 0);
+    forward_env<S, G, HF>(L, RT, ms, a.hfield, st, lane_s, last ? 1 : 0);
     if (last && a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
     euler_env<S, G>(L, ms, st, lane_s);
   }
@@ -430,7 +468,11 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   float ep_steps_e = INFO[rec::EPSTEPS];
   const float prev_done_e = INFO[rec::DONE];
   for (int u = lane; u < NU; u += G) INFO[rec::MT + u] = CTRL[u];  // info["motor_targets"] (:422)
-  draw_block(k0e, k1e, ctre, L + S::O_BUF6, lane);   // the motion-column buffers are dead after the last forward pass
+  draw_block(k0e, k1e, ctre, L + E::O_NZ, lane);   // the motion-column buffers are dead after the last forward pass
+  // reference motion of this step: evaluated in the prologue, parked here (reward and privileged obs are its only readers)
+  if (lane < 40) L[E::O_REF + lane] = ref0;
+  if (lane < 8) L[E::O_REF + 32 + lane] = ref1;
+  ODK_SYNC();
   // ---- contacts, air time, swing peak (:424-435)
   float contact[2];
   foot_contact_flags(L + S::O_CDIST, contact);
@@ -507,7 +549,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   for (int k = 0; k < 7; k++) { rew[k] *= c.reward_scales[k]; total += rew[k]; }
   const float reward = fminf(fmaxf(total * dt, 0.0f), 10000.0f);
   // ---- obs (uses the pre-shift last_act and the post-increment air time; :437)
-  const float* NZ = L + S::O_BUF6;   // this step's draws 4 .. 49 (drawn above, before the reward block)
+  const float* NZ = L + E::O_NZ;   // this step's draws 4 .. 49 (drawn above, before the reward block)
   build_obs<S, G>(L, mp, c, contact, NZ, imi_e, phase_e, lane);
   // ---- info updates (:449-469)
   step_e += 1; push_step_e += 1;
@@ -570,6 +612,7 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   const bool live = env < a.nenv;
   const int e = live ? env : a.nenv - 1;
   float* L = lds + slot * E::TOTAL;
+  const int* RT = load_shared<S>(lds, 64 / G, a.m);   // ordered before its first use by the ODK_SYNCs below
 #ifdef ODK_POISON_LDS   // debug build: every read of LDS that was not written by this launch surfaces as NaN
   for (int k = lane; k < E::TOTAL; k += G) L[k] = __int_as_float(0x7fc00000);
   ODK_SYNC();
@@ -586,7 +629,7 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   load_statics<S, G>(st, a.m, lane);
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
-    forward_env<S, G, HF>(L, a.m, a.hfield, st, lane, last ? 1 : 0);
+    forward_env<S, G, HF>(L, RT, a.m, a.hfield, st, lane, last ? 1 : 0);
     if (last && a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
     euler_env<S, G>(L, a.m, st, lane);
   }
@@ -1051,6 +1094,23 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     bool ok = (b == m.base_body) || (b == m.foot_body[0]) || (b == m.foot_body[1]);
     if (!ok || ((m.sensor_type[s] == 2 || m.sensor_type[s] == 8) && b != m.base_body)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "sensor %d placement", s); }
   }
+  // bodies above the serial chains that have children: flattened source lists for the one-step subtree fold (P2)
+  m.np_count = 0;
+  for (int b2 = 0; b2 < m.nb; b2++) {
+    if (!(m.body_level[b2] >= 0 && m.body_nchild[b2] > 0 && !m.body_is_path[b2])) continue;
+    if (m.np_count == 4) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "more than four branching bodies above the serial chains"); }
+    const int i = m.np_count++;
+    m.np_body[i] = b2; m.np_nsrc[i] = 0;
+    for (int c2 = 0; c2 < m.nb; c2++) {   // c2 in the subtree of b2 (or b2 itself) and either not a chain body, or a chain head
+      bool below = false;
+      for (int a2 = c2; a2 > 0; a2 = m.body_parent[a2]) if (a2 == b2) { below = true; break; }
+      if (!below || m.body_level[c2] < 0) continue;
+      if (!m.body_is_path[c2] || m.body_path_head[c2]) {
+        if (m.np_nsrc[i] == 6) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "more than six sources in a subtree fold"); }
+        m.np_src[i][m.np_nsrc[i]++] = c2;
+      }
+    }
+  }
   if (!build_reduced_tables(m)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "dof tree is not a floating base with up to three serial chains of <= 5 (twin-merged) dofs"); }
   int dt_max = 0, dv_max = 0;
   for (int d = 0; d < m.nv; d++) { dt_max = m.dof_depth[d] > dt_max ? m.dof_depth[d] : dt_max; dv_max = m.vdof_depth[d] > dv_max ? m.vdof_depth[d] : dv_max; }
@@ -1077,8 +1137,8 @@ extern "C" int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int
 }
 
 // occupancy by construction: 2 waves / SIMD = 8 single-wave workgroups per CU need <= 160 KiB / 8 of LDS per workgroup (2 envs)
-static_assert(2 * EnvL<ShapeA>::TOTAL * sizeof(float) <= 20480, "shape A: LDS image too large for 8 workgroups per CU");
-static_assert(2 * EnvL<ShapeB>::TOTAL * sizeof(float) <= 20480, "shape B: LDS image too large for 8 workgroups per CU");
+static_assert(EnvL<ShapeA>::wg_floats(2) * sizeof(float) <= 20480, "shape A: LDS image too large for 8 workgroups per CU");
+static_assert(EnvL<ShapeB>::wg_floats(2) * sizeof(float) <= 20480, "shape B: LDS image too large for 8 workgroups per CU");
 extern "C" int odk_model_reduced(const odk_model* m, int* paired, int* nvr, int* nMr, int* nHr, int* red_main, int* red_twin) {
   if (!m) return fail(ODK_ERR_INVALID, "null model");
   if (paired) *paired = m->h.paired; if (nvr) *nvr = m->h.nvr; if (nMr) *nMr = m->h.nMr; if (nHr) *nHr = m->h.nHr;
@@ -1193,7 +1253,7 @@ enum { K_RESET = 0, K_STEP = 1, K_PHYS = 2 };
 template <class S, int G, bool HF> static hipError_t launch_sg(int which, const KArgs& a, hipStream_t st) {
   const int per_block = 64 / G;
   const int grid = (a.nenv + per_block - 1) / per_block;
-  const size_t lds = (size_t)per_block * EnvL<S>::TOTAL * sizeof(float);
+  const size_t lds = (size_t)EnvL<S>::wg_floats(per_block) * sizeof(float);
   if (which == K_RESET) hipLaunchKernelGGL((reset_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
   else if (which == K_STEP) hipLaunchKernelGGL((step_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
   else hipLaunchKernelGGL((physics_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);

@@ -69,6 +69,10 @@ struct Shape {
   static constexpr int NMR = PAIRED ? 145 : NM_;   // entries of the reduced tree layout
   static constexpr int NHR = PAIRED ? 170 : NH_;   // entries of the reduced virtual-tree layout
   static constexpr int DVR = PAIRED ? 15 : DV_;    // max dof depth, reduced virtual tree
+  // workgroup-shared LDS tables behind the envs' images (odk_engine.hip load_shared): the packed reduced entries and the
+  // contact-row constants.  (Friction-loss rows, actuator constants and the foot hull were tried there too: no gain, their
+  // loads from the L2-resident model are already covered.)
+  static constexpr int SH_CT = NMR, SHARED = SH_CT + 42;
   static constexpr int CL = (NV_ == 20 || PAIRED) ? 5 : 0;   // max (reduced) chain length for the in-register chain solver (0: generic path)
   // persistent over the env step
   static constexpr int O_QPOS = 0;
@@ -120,8 +124,9 @@ struct Shape {
 #else
   static constexpr int N_SCR = 172;                  // no S_PROF slots outside profile builds
 #endif
-  static constexpr int O_SENS = O_SCR + N_SCR;       // sensordata[46]
-  static constexpr int O_ACTF = O_SENS + NSENSD;     // actuator_force
+  static constexpr int O_SENS = O_JV;                // sensordata[46]: born after the line search (P10, last substep only), ALIASES jv
+  static_assert(NSENSD <= NROW, "sensordata must fit in the jv rows");
+  static constexpr int O_ACTF = O_SCR + N_SCR;       // actuator_force
   static constexpr int O_QACC = O_X;                 // qacc of the last forward == final iterate
   static constexpr int TOTAL = ((O_ACTF + NU + 3) / 4) * 4;
   // scratch sub-offsets
@@ -1006,7 +1011,12 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
   }
 
 template <class S, int G, bool HF>
-__device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags) {
+__device__ __forceinline__ void forward_env(float* L, const int* RT, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags) {
+  // RT: the packed reduced entries (DevModel::R_ent) in LDS, one copy per workgroup (load_shared): every substep reads them
+  // twice (inertia, Hessian), and a table load from the L2-resident model right behind a phase hand-off is ~300 exposed cycles.
+  // Behind them (SH_CT): the contact-row constants -- pair_mu[3] | pair_invweight[3] | pair_imp[3][9] | plane_frame[9].
+  const float* SH = reinterpret_cast<const float*>(RT);
+  const float* CT = SH + S::SH_CT;
   constexpr int NV = S::NV, NB = S::NB, NR = S::NVR;   // NR: reduced dofs = columns of CDOF / BUF6 / BUF6B
   using ST = Statics<S, G>;
   float* QPOS = L + S::O_QPOS; float* QVEL = L + S::O_QVEL; float* WARM = L + S::O_WARM; float* CTRL = L + S::O_CTRL;
@@ -1315,27 +1325,35 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     }
     ODK_SYNC();
   }
-  for (int lvl = m->max_nonpath_level; lvl >= 0; lvl--) {
-    if (bs.level == lvl && bs.nchild > 0 && !bs.is_path) {
-      float acc[16];
+  // bodies above the serial chains (base, trunk): body i's subtree sum = its own value + the own values of the non-chain
+  // bodies below it + the (final) sums of the chain heads below it -- a host-built source list (DevModel::np_src), so every
+  // such body is folded in ONE step, 16 lanes per body (lane = component: cfrc | crb are contiguous, component q of body b
+  // is at q * NB + b), instead of one dependent LDS round trip per tree level
+  {
+    float* ACC = CFRC;
+    static_assert(S::O_CRB == S::O_CFRC + 6 * NB, "cfrc | crb must be contiguous");
+    const int nnp = m->np_count;          // <= 2 * (G / 16), checked at load
+    const int slot = lane >> 4, q = lane & 15;
+    float t[2] = {0.0f, 0.0f};
 #pragma unroll
-      for (int k = 0; k < 10; k++) acc[k] = CRB[k * NB + lane];
+    for (int pass = 0; pass < 2; pass++) {
+      const int i = pass * (G / 16) + slot;
+      if (i < nnp) {   // (skipped wave-wide for pass 1 when there are at most G / 16 such bodies)
+        const int ns = m->np_nsrc[i];
+        int src[6];    // all list loads in flight together, then all LDS reads (np_nsrc <= 6, checked at load)
 #pragma unroll
-      for (int k = 0; k < 6; k++) acc[10 + k] = CFRC[k * NB + lane];
+        for (int c = 0; c < 6; c++) src[c] = m->np_src[i][c];
+        float x = 0.0f;
 #pragma unroll
-      for (int cidx = 0; cidx < 3; cidx++) {
-        if (cidx < bs.nchild) {
-          const int c = bs.child[cidx];
-#pragma unroll
-          for (int k = 0; k < 10; k++) acc[k] += CRB[k * NB + c];
-#pragma unroll
-          for (int k = 0; k < 6; k++) acc[10 + k] += CFRC[k * NB + c];
-        }
+        for (int c = 0; c < 6; c++) { const float y = ACC[q * NB + src[c]]; x += c < ns ? y : 0.0f; }
+        t[pass] = x;
       }
+    }
+    ODK_SYNC();   // all own values read before any is replaced by its sum
 #pragma unroll
-      for (int k = 0; k < 10; k++) CRB[k * NB + lane] = acc[k];
-#pragma unroll
-      for (int k = 0; k < 6; k++) CFRC[k * NB + lane] = acc[10 + k];
+    for (int pass = 0; pass < 2; pass++) {
+      const int i = pass * (G / 16) + slot;
+      if (i < nnp) ACC[q * NB + m->np_body[i]] = t[pass];
     }
     ODK_SYNC();
   }
@@ -1377,7 +1395,8 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
   // diagonals only (a pair's armatures enter the solves as the series term pair_einv, and M v as ARM[i] v_i)
 #pragma unroll
   for (int t = 0; t < ST::NME; t++) {
-    const int e = load_rent(m, lane + t * G, S::NMR);
+    const int pq = lane + t * G;
+    const int e = pq < S::NMR ? RT[pq] : -1;
     if (e >= 0) {
       const int i = e & 31, j = (e >> 5) & 31;
       float v = 0;
@@ -1398,7 +1417,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     for (int t = 0; t < ST::NME; t++) {
       const int p = lane + t * G;
       if (p < S::NMR) {
-        const int e = m->R_ent[p];
+        const int e = RT[p];
         float v = M[p];
         if ((e >> 15) & 1) v += pair_einv(ARM, nullptr, (e >> 16) & 31);
         HL[p] = v;
@@ -1625,10 +1644,10 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
     const int r = r0c + rc, c = rc >> 2, s = rc & 3, pair = c >> 2;
     if (rc >= 32 && !ff_rows) { ED[r] = 0.0f; AREF[r] = 0.0f; continue; }
     const float dist = CDIST[c];
-    const float mu = m->pair_mu[pair];
+    const float mu = CT[pair];
     const float fs = (s & 1) ? -mu : mu;
     // foot-foot frame: left in S_VF by the SAT routine; height-field floor: per-foot frames left in S_K by P7
-    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && HF) ? SCR + S::S_K + 9 * pair : m->plane_frame);
+    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && HF) ? SCR + S::S_K + 9 * pair : CT + 33);
     const int td = 3 * (1 + (s >> 1));
     const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
     const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};
@@ -1647,7 +1666,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 #pragma unroll
         for (int k = 0; k < 6; k++) vel -= wr[k] * CVEL[k * NB + b1];
       }
-      row_params(m->pair_imp[pair], dist, m->pair_invweight[pair], vel, D, aref);
+      row_params(CT + 6 + 9 * pair, dist, CT[3 + pair], vel, D, aref);
     }
     ED[r] = D;
     AREF[r] = aref;
@@ -1904,7 +1923,7 @@ __device__ __forceinline__ void forward_env(float* L, const DevModel* __restrict
 #pragma unroll
     for (int t = 0; t < ST::NME; t++) {
       const int p = lane + t * G;
-      if (p < S::NMR) HL[p] = hess_entry(m->R_ent[p], M[p]);   // one packed load per entry
+      if (p < S::NMR) HL[p] = hess_entry(RT[p], M[p]);
     }
     if constexpr (S::PAIRED) { if (st.r_on) MV[lane] = rhs; }
     ODK_SYNC();

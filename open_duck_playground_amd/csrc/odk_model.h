@@ -27,6 +27,9 @@ struct DevModel {
   int base_body, body_in_tree[MAXB], body_parent[MAXB], body_jntadr[MAXB], body_jntnum[MAXB];
   int max_level, body_level[MAXB], body_children[MAXB][3], body_nchild[MAXB];
   int max_nonpath_level, body_pathmask[MAXB], body_is_path[MAXB], body_upmask[MAXB], body_path_head[MAXB];   // serial body chains (tables.py)
+  // bodies above the serial chains that have children: the subtree sum of np_body[i] = sum over np_src[i][0 .. np_nsrc) of
+  // own values (itself, non-chain bodies below it) and chain-head sums (chain heads below it)
+  int np_count, np_body[4], np_nsrc[4], np_src[4][MAXB];
   int body_chain[MAXB][MAXCHAIN], body_chain_len[MAXB];
   int body_ancdof[MAXB][MAXV], body_nancdof[MAXB];
   int body_sub[MAXB][MAXB], body_nsub[MAXB];
