@@ -193,12 +193,24 @@ int odk_colsum_partial(const float* x_dev, float* partial_dev, int n, int w, voi
  * order as odk_silu_bwd_colsum's own fold).  partial_dev / colsum_dev / widths are HOST arrays. */
 int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_dev, const int* widths, int count, int n, void* stream);
 
-/* dst[f][b, :] = src[f][idx[b], :] for up to 8 row-major float fields in one launch (minibatch gather of the rollout).
+/* Weight gradients of up to 4 dense layers in one launch on the f32 matrix cores (v_mfma_f32_32x32x2_f32):
+ *   out[out_off[l] + i * n_in[l] + j] = sum over the nrows minibatch rows r of dz[l][r, i] * h[l][r, j]      (= dz^T h, torch Linear weight layout)
+ * dz[l] is [nrows, n_out[l]], h[l] is [nrows, n_in[l]], both row-major; out_dev is the flat gradient buffer.  The rows are
+ * split into kslices slices (a multiple of 8; nrows divisible by 16 * kslices); ws_dev is a workspace of kslices * ws_stride
+ * floats laid out like out_dev (ws_stride >= every out_off + n_out * n_in, a multiple of 4; every out_off and n_out * n_in a
+ * multiple of 4; ws_dev and out_dev 16-byte aligned); the slices are folded in a fixed order, so the result is
+ * bit-reproducible.  dz_dev / h_dev / n_out / n_in / out_off are HOST arrays. */
+int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int* n_out, const int* n_in, const long long* out_off, int nlayers,
+                int nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, void* stream);
+
+/* dst[f][b, :] = src[f][idx[b], :] for up to 10 row-major float fields in one launch (minibatch gather of the rollout).
  * src_dev / dst_dev / row_floats are HOST arrays of device pointers / row lengths; idx_dev is int64 on the device, nrows
- * entries; every source has src_rows rows.  An index outside [0, src_rows) is never dereferenced: its destination rows
- * are filled with NaN. */
-int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, int nfields, const long long* idx_dev,
-                    int nrows, long long src_rows, void* stream);
+ * entries; every indexed source has src_rows rows.  An index outside [0, src_rows) is never dereferenced: its destination
+ * rows are filled with NaN.  direct_base (HOST array, may be NULL): direct_base[f] >= 0 makes field f a plain block copy,
+ * dst[f][b, :] = src[f][direct_base[f] + b, :] (no index; e.g. this step's slice of a noise pool) -- the caller guarantees
+ * the range.  Buffers of fields whose row length is a multiple of 4 must be 16-byte aligned. */
+int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, const long long* direct_base, int nfields,
+                    const long long* idx_dev, int nrows, long long src_rows, void* stream);
 
 /* live timing of the most recent odk_step launches with HIP events on the launch stream:
  * returns average milliseconds per launch since the last call (and resets the window) */

@@ -336,20 +336,131 @@ __global__ void colsum_final_multi_kernel(ColsumArgs a, int nblk) {
   if (ty == 0 && c < w) a.out[f][c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
 }
 
-// Minibatch gather: trajectory idx[b] of up to 8 row-major [N, row_floats] sources -> row b of the matching static
-// buffers, one launch (blockIdx.x = trajectory, blockIdx.y = field).
-struct GatherArgs { const float* src[8]; float* dst[8]; int row[8]; int nfields; };
+// Minibatch gather: row idx[b] (or, for a "direct" field, row base + b) of up to 10 row-major [N, row_floats] sources -> row b
+// of the matching static buffers, one launch: blockIdx.x = destination row, .y = field, .z = 1024-float chunk of the row
+// (16-byte copies when the row length is a multiple of 4: every field of the PPO minibatch is).
+constexpr int GATHER_MAX = 10;
+struct GatherArgs { const float* src[GATHER_MAX]; float* dst[GATHER_MAX]; int row[GATHER_MAX]; long long base[GATHER_MAX]; int direct[GATHER_MAX]; int nfields; };
 __global__ void gather_rows_kernel(GatherArgs a, const long long* __restrict__ idx, long long src_rows) {
   const int f = blockIdx.y;
   const int n = a.row[f];
-  const long long j = idx[blockIdx.x];
+  const int c0 = blockIdx.z * 1024;
+  if (c0 >= n) return;
+  const int c1 = min(n, c0 + 1024);
+  const bool direct = a.direct[f] != 0;
+  const long long j = direct ? a.base[f] + blockIdx.x : idx[blockIdx.x];
   float* d = a.dst[f] + (size_t)blockIdx.x * n;
-  if (j < 0 || j >= src_rows) {   // never read out of bounds: the row becomes NaN and the step's losses say so
-    for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = __builtin_nanf("");
+  if (!direct && (j < 0 || j >= src_rows)) {   // never read out of bounds: the row becomes NaN and the step's losses say so
+    for (int i = c0 + threadIdx.x; i < c1; i += blockDim.x) d[i] = __builtin_nanf("");
     return;
   }
   const float* s = a.src[f] + (size_t)j * n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+  if ((n & 3) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(s); float4* d4 = reinterpret_cast<float4*>(d);
+    for (int i = (c0 >> 2) + threadIdx.x; i < (c1 >> 2); i += blockDim.x) d4[i] = s4[i];
+  } else {
+    for (int i = c0 + threadIdx.x; i < c1; i += blockDim.x) d[i] = s[i];
+  }
+}
+
+// ---- weight gradients of an MLP: dW_l = dz_l^T h_{l-1} for up to 4 layers in ONE launch, on the f32 matrix cores.
+// These are the learner's worst-shaped GEMMs (K = 5 120 minibatch rows deep, outputs as small as 28 x 128): the library runs
+// them at ~30 TFLOP/s.  Here both operands are K-major ([rows, n_out] and [rows, n_in] row-major), which is exactly the
+// v_mfma_f32_32x32x2_f32 fragment order -- lane l feeds A[m = l % 32][k = l / 32] = dz[k0 + l / 32][i0 + l % 32], likewise B
+// from h -- so fragments are plain coalesced global loads (two 128-byte row segments per instruction), no LDS, no
+// transposes.  One wave = one 64 x 64 output tile (2 x 2 MFMA blocks, 64 accumulator registers) over one slice of the rows
+// (split-K); partial tiles go to a workspace laid out like the flat gradient buffer, and dw_reduce_kernel folds the slices
+// in a fixed order (data-parallel replicas must stay bit-identical: no float atomics).  Block b runs on XCD b % 8: the
+// blocks of an XCD share the same row slices, so each XCD's L2 reads its part of dz / h once and serves all tiles from it.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct DwLayer { const float* dz; const float* h; int n_out, n_in, tj, tile0; long long out_off; };
+struct DwArgs { DwLayer L[4]; int nlayers, ntiles, nrows, kslices; float* ws; long long ws_stride; };
+
+__global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
+  const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
+  const int per_xcd = a.kslices >> 3;                 // kslices is a multiple of 8
+  const int slice = xcd * per_xcd + q / a.ntiles, tile = q % a.ntiles;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < 4; k++) if (k < a.nlayers && tile >= a.L[k].tile0) l = k;
+  const DwLayer& Ly = a.L[l];
+  const int n_out = Ly.n_out, n_in = Ly.n_in;
+  const int t = tile - Ly.tile0, i0 = (t / Ly.tj) * 64, j0 = (t % Ly.tj) * 64;
+  const int lane = threadIdx.x, r = lane >> 5, c = lane & 31;
+  const int rows = a.nrows / a.kslices;               // even (checked by the host)
+  const size_t k0 = (size_t)slice * rows + r;
+  const bool ma0 = i0 + c < n_out, ma1 = i0 + 32 + c < n_out, mb0 = j0 + c < n_in, mb1 = j0 + 32 + c < n_in;
+  // out-of-range columns read column 0 of the tile row (always valid) and are zeroed by the select: no divergent loads
+  const float* pa0 = Ly.dz + k0 * n_out + (ma0 ? i0 + c : 0);
+  const float* pa1 = Ly.dz + k0 * n_out + (ma1 ? i0 + 32 + c : 0);
+  const float* pb0 = Ly.h + k0 * n_in + (mb0 ? j0 + c : 0);
+  const float* pb1 = Ly.h + k0 * n_in + (mb1 ? j0 + 32 + c : 0);
+  const size_t sa = (size_t)2 * n_out, sb = (size_t)2 * n_in;
+  f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+  const bool two_i = i0 + 32 < n_out, two_j = j0 + 32 < n_in;   // wave-uniform: skip the empty halves of edge tiles
+  // Out-of-range columns are NOT zeroed: entry (i, j) depends on column i of dz and column j of h only, so whatever the
+  // clamped loads bring into the padding never reaches a stored element -- and a select behind every load would make the
+  // wave wait for the load it just issued.  U k-pairs per batch; the NEXT batch's 4 U loads are in flight under this
+  // batch's MFMAs (two batches per trip: the register arrays swap roles without copies); the host guarantees that the
+  // slice is a whole number of trips.
+  constexpr int U = 4;
+  const int npair = rows >> 1;
+  float fa0[U], fa1[U], fb0[U], fb1[U], ga0[U], ga1[U], gb0[U], gb1[U];
+  auto fetch = [&](int kk, float* xa0, float* xa1, float* xb0, float* xb1) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const size_t o = (size_t)(kk + u);
+      xa0[u] = pa0[o * sa]; xa1[u] = pa1[o * sa]; xb0[u] = pb0[o * sb]; xb1[u] = pb1[o * sb];
+    }
+  };
+  auto mma = [&](const float* xa0, const float* xa1, const float* xb0, const float* xb1) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[u], xb0[u], c00, 0, 0, 0);
+      if (two_j) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[u], xb1[u], c01, 0, 0, 0);
+      if (two_i) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[u], xb0[u], c10, 0, 0, 0);
+      if (two_i && two_j) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[u], xb1[u], c11, 0, 0, 0);
+    }
+  };
+  fetch(0, fa0, fa1, fb0, fb1);
+  for (int kk = 0; kk < npair; kk += 2 * U) {
+    fetch(kk + U, ga0, ga1, gb0, gb1);
+    mma(fa0, fa1, fb0, fb1);
+    fetch(kk + 2 * U < npair ? kk + 2 * U : 0, fa0, fa1, fb0, fb1);   // (the last trip re-reads batch 0: in bounds, unused)
+    mma(ga0, ga1, gb0, gb1);
+  }
+  // C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* w = a.ws + (size_t)slice * a.ws_stride + Ly.out_off;
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int row = (v & 3) + 8 * (v >> 2) + 4 * r;
+    if (i0 + row < n_out) {
+      if (mb0) w[(size_t)(i0 + row) * n_in + j0 + c] = c00[v];
+      if (mb1) w[(size_t)(i0 + row) * n_in + j0 + 32 + c] = c01[v];
+    }
+    if (i0 + 32 + row < n_out) {
+      if (mb0) w[(size_t)(i0 + 32 + row) * n_in + j0 + c] = c10[v];
+      if (mb1) w[(size_t)(i0 + 32 + row) * n_in + j0 + 32 + c] = c11[v];
+    }
+  }
+}
+// out[off + e] = sum over the row slices, in slice order, for the weight ranges of the layers (e < count); four consecutive
+// elements per thread (offsets, counts and the slice stride are multiples of 4: checked by the host)
+struct DwRanges { long long off[4], count[4]; int n; };
+__global__ void dw_reduce_kernel(const float* __restrict__ ws, long long ws_stride, int kslices, DwRanges rg, float* __restrict__ out) {
+  long long total = 0;
+  for (int k = 0; k < rg.n; k++) total += rg.count[k];
+  for (long long i = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x); i < total; i += 4 * (long long)gridDim.x * blockDim.x) {
+    long long e = i, off = rg.off[0];
+#pragma unroll
+    for (int k = 0; k < 3; k++) if (k + 1 < rg.n && e >= rg.count[k]) { e -= rg.count[k]; off = rg.off[k + 1]; } else break;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int sl = 0; sl < kslices; sl++) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)sl * ws_stride + off + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + off + e) = s;
+  }
 }
 
 int check_launch(const char* what) {
@@ -448,13 +559,53 @@ extern "C" int odk_colsum_finalize(const float* const* partial_dev, float* const
   return check_launch("odk_colsum_finalize: launch failed");
 }
 
-extern "C" int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, int nfields, const long long* idx_dev,
-                               int nrows, long long src_rows, void* stream) {
-  if (!src_dev || !dst_dev || !row_floats || !idx_dev || nfields <= 0 || nfields > 8 || nrows <= 0 || src_rows <= 0)
+extern "C" int odk_gather_rows(const float* const* src_dev, float* const* dst_dev, const int* row_floats, const long long* direct_base, int nfields,
+                               const long long* idx_dev, int nrows, long long src_rows, void* stream) {
+  if (!src_dev || !dst_dev || !row_floats || !idx_dev || nfields <= 0 || nfields > GATHER_MAX || nrows <= 0 || src_rows <= 0)
     return odk_fail_(ODK_ERR_INVALID, "odk_gather_rows: bad arguments");
   GatherArgs a;
   a.nfields = nfields;
-  for (int f = 0; f < 8; f++) { a.src[f] = f < nfields ? src_dev[f] : nullptr; a.dst[f] = f < nfields ? dst_dev[f] : nullptr; a.row[f] = f < nfields ? row_floats[f] : 0; }
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows, nfields), dim3(256), 0, (hipStream_t)stream, a, idx_dev, src_rows);
+  int maxrow = 0;
+  for (int f = 0; f < GATHER_MAX; f++) {
+    a.src[f] = f < nfields ? src_dev[f] : nullptr; a.dst[f] = f < nfields ? dst_dev[f] : nullptr; a.row[f] = f < nfields ? row_floats[f] : 0;
+    a.direct[f] = (f < nfields && direct_base && direct_base[f] >= 0) ? 1 : 0;
+    a.base[f] = a.direct[f] ? direct_base[f] : 0;
+    if (a.row[f] > maxrow) maxrow = a.row[f];
+    if (f < nfields && (a.row[f] & 3) == 0 && ((((uintptr_t)a.src[f]) | ((uintptr_t)a.dst[f])) & 15) != 0) return odk_fail_(ODK_ERR_INVALID, "odk_gather_rows: 16-byte aligned buffers expected");
+  }
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nrows, nfields, (maxrow + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, a, idx_dev, src_rows);
   return check_launch("odk_gather_rows: launch failed");
+}
+
+extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int* n_out, const int* n_in, const long long* out_off,
+                           int nlayers, int nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, void* stream) {
+  if (!dz_dev || !h_dev || !n_out || !n_in || !out_off || !ws_dev || !out_dev || nlayers <= 0 || nlayers > 4 || nrows <= 0 || kslices <= 0 ||
+      (kslices & 7) != 0 || nrows % (16 * kslices) != 0 || (ws_stride & 3) != 0 || ((uintptr_t)ws_dev & 15) != 0 || ((uintptr_t)out_dev & 15) != 0)
+    return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad arguments (1..4 layers, kslices a multiple of 8, rows divisible by 16 * kslices, "
+                                      "ws_stride a multiple of 4, 16-byte aligned buffers)");
+  DwArgs a;
+  DwRanges rg;
+  a.nlayers = nlayers; a.nrows = nrows; a.kslices = kslices; a.ws = ws_dev; a.ws_stride = ws_stride; a.ntiles = 0; rg.n = nlayers;
+  for (int l = 0; l < 4; l++) {
+    DwLayer& L = a.L[l];
+    if (l < nlayers) {
+      if (!dz_dev[l] || !h_dev[l] || n_out[l] <= 0 || n_in[l] <= 0 || out_off[l] < 0 || out_off[l] + (long long)n_out[l] * n_in[l] > ws_stride ||
+          (out_off[l] & 3) != 0 || (((long long)n_out[l] * n_in[l]) & 3) != 0)
+        return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad layer (offset and element count must be multiples of 4)");
+      L.dz = dz_dev[l]; L.h = h_dev[l]; L.n_out = n_out[l]; L.n_in = n_in[l]; L.out_off = out_off[l];
+      L.tj = (n_in[l] + 63) / 64; L.tile0 = a.ntiles;
+      a.ntiles += ((n_out[l] + 63) / 64) * L.tj;
+      rg.off[l] = out_off[l]; rg.count[l] = (long long)n_out[l] * n_in[l];
+    } else {
+      L.dz = L.h = nullptr; L.n_out = L.n_in = L.tj = 0; L.tile0 = 1 << 30; L.out_off = 0; rg.off[l] = 0; rg.count[l] = 0;
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dw_gemm_kernel, dim3(a.ntiles * kslices), dim3(64), 0, st, a);
+  long long total = 0;
+  for (int l = 0; l < nlayers; l++) total += rg.count[l];
+  int blocks = (int)((total / 4 + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws_dev, ws_stride, kslices, rg, out_dev);
+  return check_launch("odk_dw_gemm: launch failed");
 }

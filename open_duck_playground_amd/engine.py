@@ -106,7 +106,8 @@ def load_library() -> C.CDLL:
     L.odk_silu_bwd_colsum.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
     L.odk_colsum_partial.argtypes = [P, P, C.c_int, C.c_int, P]
     L.odk_colsum_finalize.argtypes = [PP, PP, C.POINTER(C.c_int), C.c_int, C.c_int, P]
-    L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, P, C.c_int, C.c_longlong, P]
+    L.odk_dw_gemm.argtypes = [PP, PP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, C.c_int, C.c_int, P, C.c_longlong, P, P]
+    L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, P, C.c_int, C.c_longlong, P]
     _lib = L
     return L
 
@@ -117,7 +118,7 @@ EXPORTED_SYMBOLS = (
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
-    "odk_policy_sample", "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows")
+    "odk_policy_sample", "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows", "odk_dw_gemm")
 
 
 def _chk(rc: int):
@@ -264,33 +265,85 @@ class ColsumFinalize:
         _chk(load_library().odk_colsum_finalize(self.partial, self.out, self.w, self.k, self.n, _stream(self.keep[0][0])))
 
 
-class RowGather:
-    """dst[f][b] = src[f][idx[b]] for a fixed set of (src, dst) float32 tensors in one launch (`odk_gather_rows`)."""
+class DwGemm:
+    """Weight gradients out[off_l : off_l + n_out n_in] = dz_l^T h_l of up to 4 layers in one launch (`odk_dw_gemm`, f32
+    matrix cores, split over `kslices` row slices folded in a fixed order).  `layers`: [(dz [n, n_out], h [n, n_in], offset in
+    `flat_out`)]; `workspace`: kslices * flat_out.numel() floats (shared by several DwGemm objects with disjoint offsets)."""
 
-    def __init__(self, pairs):
-        n = len(pairs)
-        self.n = n
-        self.keep = pairs
-        for s_, d_ in pairs:
+    def __init__(self, layers, flat_out, workspace, kslices: int = 16):
+        k = len(layers)
+        n = int(layers[0][0].shape[0])
+        _f32c(flat_out, workspace, *[t for dz, h, _ in layers for t in (dz, h)])
+        if any(int(dz.shape[0]) != n or int(h.shape[0]) != n for dz, h, _ in layers):
+            raise OdkError("DwGemm: every dz / h needs the same row count")
+        if n % (16 * kslices) != 0 or kslices % 8 != 0:
+            raise OdkError("DwGemm: rows must be divisible by 16 * kslices, kslices by 8")
+        stride = self.workspace_stride(flat_out.numel())
+        if workspace.numel() < kslices * stride:
+            raise OdkError("DwGemm: workspace too small (kslices * workspace_stride(flat_out.numel()) floats)")
+        if any(int(o) % 4 or (int(dz.shape[1]) * int(h.shape[1])) % 4 for dz, h, o in layers):
+            raise OdkError("DwGemm: offsets and element counts must be multiples of 4")
+        self.keep = (layers, flat_out, workspace)
+        self.k, self.n, self.kslices, self.stride = k, n, int(kslices), stride
+        self.dz = (C.c_void_p * k)(*[dz.data_ptr() for dz, _, _ in layers])
+        self.h = (C.c_void_p * k)(*[h.data_ptr() for _, h, _ in layers])
+        self.n_out = (C.c_int * k)(*[int(dz.shape[1]) for dz, _, _ in layers])
+        self.n_in = (C.c_int * k)(*[int(h.shape[1]) for _, h, _ in layers])
+        self.off = (C.c_longlong * k)(*[int(o) for _, _, o in layers])
+
+    @staticmethod
+    def workspace_stride(numel: int) -> int:
+        return (int(numel) + 3) // 4 * 4
+
+    def __call__(self):
+        _, flat_out, ws = self.keep
+        _chk(load_library().odk_dw_gemm(self.dz, self.h, self.n_out, self.n_in, self.off, self.k, self.n, self.kslices, _ptr(ws), self.stride,
+                                        _ptr(flat_out), _stream(flat_out)))
+
+
+class RowGather:
+    """dst[f][b] = src[f][idx[b]] for a fixed set of (src, dst) float32 tensors in one launch (`odk_gather_rows`).
+    `direct`: further (src, dst) pairs copied as plain blocks, dst[b] = src[base + b] with `base` given per call (the
+    learner's slice of its noise pool rides along with the minibatch gather instead of being a launch of its own)."""
+
+    def __init__(self, pairs, direct=()):
+        allp = list(pairs) + list(direct)
+        n = len(allp)
+        if n > 10:
+            raise OdkError("RowGather: at most 10 fields")
+        self.n, self.nidx = n, len(pairs)
+        self.keep = allp
+        for s_, d_ in allp:
             _f32c(s_, d_)
-        self.src = (C.c_void_p * n)(*[s_.data_ptr() for s_, _ in pairs])
-        self.dst = (C.c_void_p * n)(*[d_.data_ptr() for _, d_ in pairs])
-        self.rows = (C.c_int * n)(*[int(s_[0].numel()) for s_, _ in pairs])
+        self.src = (C.c_void_p * n)(*[s_.data_ptr() for s_, _ in allp])
+        self.dst = (C.c_void_p * n)(*[d_.data_ptr() for _, d_ in allp])
+        self.rows = (C.c_int * n)(*[int(s_[0].numel()) for s_, _ in allp])
+        self.base = (C.c_longlong * n)(*([-1] * n))
         self.nrows = int(pairs[0][1].shape[0])
         self.src_rows = int(pairs[0][0].shape[0])
         for s_, d_ in pairs:
             if int(s_.shape[0]) != self.src_rows or int(d_.shape[0]) != self.nrows or s_[0].numel() != d_[0].numel():
                 raise OdkError("RowGather: every source needs the same row count, every destination the same row count, and "
                                "matching row lengths")
+        for s_, d_ in direct:
+            if int(d_.shape[0]) != self.nrows or s_[0].numel() != d_[0].numel():
+                raise OdkError("RowGather: a direct field needs the destinations' row count and matching row lengths")
 
-    def __call__(self, idx):
+    def __call__(self, idx, direct_base=()):
         """`idx`: contiguous int64 CUDA tensor of `nrows` source-row numbers (values outside the source are not read: those
-        destination rows become NaN)."""
+        destination rows become NaN); `direct_base`: first source row of every direct field."""
         import torch
         if not (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == self.nrows):
             raise OdkError(f"RowGather: idx must be a contiguous int64 CUDA tensor of {self.nrows} entries "
                            f"(got {idx.dtype}, {idx.device}, contiguous={idx.is_contiguous()}, {idx.numel()} entries)")
-        _chk(load_library().odk_gather_rows(self.src, self.dst, self.rows, self.n, _ptr(idx), self.nrows, self.src_rows, _stream(idx)))
+        if len(direct_base) != self.n - self.nidx:
+            raise OdkError("RowGather: one base row per direct field")
+        for k, b in enumerate(direct_base):
+            s_ = self.keep[self.nidx + k][0]
+            if b < 0 or b + self.nrows > int(s_.shape[0]):
+                raise OdkError("RowGather: direct block out of range")
+            self.base[self.nidx + k] = int(b)
+        _chk(load_library().odk_gather_rows(self.src, self.dst, self.rows, self.base, self.n, _ptr(idx), self.nrows, self.src_rows, _stream(idx)))
 
 
 class Batch:

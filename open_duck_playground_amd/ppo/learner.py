@@ -151,12 +151,17 @@ def tune_inference_shapes(net: PPONetworks, rows) -> None:
         _tunable(False)
 
 
+_DW_GEMM = os.environ.get("ODK_LEARNER_DW", "1") == "1"   # weight gradients on csrc dw_gemm_kernel (0: torch.mm, the library GEMMs)
+
+
 class _FlatMLP:
-    """Views of one MLP's weights / gradients inside the flat buffers + explicit forward / backward."""
+    """Views of one MLP's weights / gradients inside the flat buffers + explicit forward / backward over persistent
+    activation buffers (`bind`): fixed addresses, so the weight-gradient launch is prepared once and nothing is allocated
+    inside the step."""
 
     def __init__(self, mlp, flat_p, flat_g, off: int):
-        self.W, self.b, self.gW, self.gb = [], [], [], []
-        self.dzs = self.dhs = self.partials = self.fold = None
+        self.W, self.b, self.gW, self.gb, self.goff = [], [], [], [], []
+        self.zs = self.hs = self.dzs = self.dhs = self.partials = self.fold = self.dw = None
         for lin in mlp.layers:
             for name in ("weight", "bias"):
                 p = getattr(lin, name)
@@ -165,41 +170,56 @@ class _FlatMLP:
                 p.data = flat_p[off:off + n].view_as(p)
                 (self.W if name == "weight" else self.b).append(p.data)
                 (self.gW if name == "weight" else self.gb).append(flat_g[off:off + n].view_as(p))
+                if name == "weight":
+                    self.goff.append(off)
                 off += n
         self.end = off
 
-    def forward(self, x):
-        hs, zs = [x], []
-        for i, (W, b) in enumerate(zip(self.W, self.b)):
-            z = torch.addmm(b, hs[-1], W.t())
-            zs.append(z)
-            if i + 1 < len(self.W):
-                hs.append(F.silu(z))
-        return hs, zs
+    def bind(self, x, dz_top, flat_g, workspace, kslices: int = 16):
+        """Fixes the step's tensors: x [n, in] (network input), dz_top [n, out] (gradient w.r.t. the output, written by the loss
+        head), and allocates z / h per layer, dz / dh per hidden layer and the bias-gradient tile sums."""
+        n, dev = x.shape[0], x.device
+        self.x, self.dz_top = x, dz_top
+        self.zs = [torch.empty(n, w.shape[0], device=dev) for w in self.W]
+        self.hs = [x] + [torch.empty(n, w.shape[0], device=dev) for w in self.W[:-1]]
+        self.dzs = [torch.empty(n, w.shape[0], device=dev) for w in self.W[:-1]]
+        self.dhs = [torch.empty_like(t) for t in self.dzs]
+        # per-layer tile sums of dz; folded into the bias gradients by ONE launch after the chain (the bias gradients
+        # are first read by the clip + Adam step, so their finalisation need not sit between the GEMMs)
+        self.partials = [torch.empty(((n + 63) // 64) * w.shape[0], device=dev) for w in self.W]
+        self.fold = engine.ColsumFinalize([(p, self.gb[i]) for i, p in enumerate(self.partials)], n)
+        dz_of = self.dzs + [dz_top]
+        ok = _DW_GEMM and len(self.W) <= 4 and n % (16 * kslices) == 0 and all(o % 4 == 0 and w.numel() % 4 == 0 for o, w in zip(self.goff, self.W))
+        # dW_l = dz_l^T h_{l-1} of all layers in one launch on the f32 matrix cores (the library runs these K = n deep,
+        # small-output GEMMs at ~30 TFLOP/s: 175 us of the minibatch step for the two networks, 100 us here)
+        self.dw = engine.DwGemm([(dz_of[i], self.hs[i], self.goff[i]) for i in range(len(self.W))], flat_g, workspace, kslices) if ok else None
 
-    def backward(self, dz, hs, zs):
+    def forward(self):
+        for i, (W, b) in enumerate(zip(self.W, self.b)):
+            torch.addmm(b, self.hs[i], W.t(), out=self.zs[i])
+            if i + 1 < len(self.W):
+                torch.ops.aten.silu.out(self.zs[i], out=self.hs[i + 1])
+        return self.zs[-1]
+
+    def backward(self):
         """Gradients straight into the flat buffer.  Below the top layer, dz and its column sums (the bias gradient)
-        come out of one fused pass (csrc silu_bwd_colsum) instead of silu_backward + a separate reduction.
-        (Measured and dropped: the weight-gradient GEMMs as a further parallel branch beside the dz -> dh chain made the
-        step 10 % slower -- the small GEMMs already share the CUs with the other network's branch -- and a branch forked
-        from a branch crashes hipStreamEndCapture on ROCm 7.2.)"""
+        come out of one fused pass (csrc silu_bwd_colsum) instead of silu_backward + a separate reduction; the weight
+        gradients of all layers follow in one launch (csrc dw_gemm_kernel) once every dz exists.
+        (Measured and dropped with the library GEMMs: the weight-gradient GEMMs as a further parallel branch beside the
+        dz -> dh chain made the step 10 % slower, and a branch forked from a branch crashes hipStreamEndCapture on ROCm 7.2.)"""
         top = len(self.W) - 1
-        if self.dzs is None:   # persistent dh / dz buffers per hidden layer (shapes are fixed for the learner's lifetime)
-            n = dz.shape[0]
-            self.dzs = [torch.empty(n, w.shape[0], device=dz.device) for w in self.W[:-1]]
-            self.dhs = [torch.empty_like(t) for t in self.dzs]
-            # per-layer tile sums of dz; folded into the bias gradients by ONE launch after the chain (the bias gradients
-            # are first read by the clip + Adam step, so their finalisation need not sit between the GEMMs)
-            self.partials = [torch.empty(((n + 63) // 64) * w.shape[0], device=dz.device) for w in self.W]
-            self.fold = engine.ColsumFinalize([(p, self.gb[i]) for i, p in enumerate(self.partials)], n)
+        dz = self.dz_top
         engine.colsum_partial(dz, self.partials[top])   # (a torch.sum over the tall [n, <=28] matrix takes 22-28 us)
         for i in range(top, -1, -1):
-            torch.mm(dz.t(), hs[i], out=self.gW[i])
+            if self.dw is None:
+                torch.mm(dz.t(), self.hs[i], out=self.gW[i])
             if i > 0:
                 dh = torch.mm(dz, self.W[i], out=self.dhs[i - 1])
                 dz = self.dzs[i - 1]
-                engine.silu_bwd_colsum(dh, zs[i - 1], dz, None, self.partials[i - 1])
+                engine.silu_bwd_colsum(dh, self.zs[i - 1], dz, None, self.partials[i - 1])
         self.fold()
+        if self.dw is not None:
+            self.dw()
 
 
 class FlatLearner:
@@ -231,6 +251,10 @@ class FlatLearner:
         self.noise = z(n, A)
         self.vs, self.adv, self.stats = z(B, T), z(B, T), z(2)
         self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
+        kslices = 16
+        self.dw_ws = torch.empty(kslices * engine.DwGemm.workspace_stride(n_par), device=dev)   # split-K partial weight gradients
+        self.policy.bind(self.static["obs"].view(n, -1), self.dlogits, self.flat_g, self.dw_ws, kslices)
+        self.value.bind(self.priv_all, self.dval_all, self.flat_g, self.dw_ws, kslices)
         self.losses = z(4)                          # running SUMS of (total, policy, value, entropy) over the steps since metrics()
         self.nsteps = 0
         self.split_update = world > 1 if split_update is None else bool(split_update)
@@ -251,28 +275,28 @@ class FlatLearner:
         if self.side is not None:
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                hv, zv = self.value.forward(self.priv_all)
-            hp, zp = self.policy.forward(s["obs"].view(n, -1))
+                zv = self.value.forward()
+            zp = self.policy.forward()
             cur.wait_stream(self.side)
         else:
-            hp, zp = self.policy.forward(s["obs"].view(n, -1))
-            hv, zv = self.value.forward(self.priv_all)
-        vals = zv[-1].view(-1)
+            zp = self.policy.forward()
+            zv = self.value.forward()
+        vals = zv.view(-1)
         baseline, boot = vals[:n], vals[n:]
         engine.gae(s["truncation"], s["termination"], s["reward"], baseline.view(B, T), boot, cfg["gae_lambda"], cfg["discounting"],
                    vs=self.vs, adv=self.adv, stats=self.stats)
-        engine.ppo_head(zp[-1], s["raw_action"].view(n, -1), s["log_prob"].view(n), self.adv.view(n),
+        engine.ppo_head(zp, s["raw_action"].view(n, -1), s["log_prob"].view(n), self.adv.view(n),
                         self.stats if cfg["normalize_advantage"] else None, self.vs.view(n), baseline, self.noise, self.dlogits,
                         self.dval_all[:n].view(n), self.losses, cfg["clipping_epsilon"], cfg["entropy_cost"], 1.0 / self.world)
         if self.side is not None:
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
-                self.value.backward(self.dval_all, hv, zv)
-            self.policy.backward(self.dlogits, hp, zp)
+                self.value.backward()
+            self.policy.backward()
             cur.wait_stream(self.side)
         else:
-            self.policy.backward(self.dlogits, hp, zp)
-            self.value.backward(self.dval_all, hv, zv)
+            self.policy.backward()
+            self.value.backward()
 
     @torch.no_grad()
     def _draw_noise(self):
@@ -281,16 +305,21 @@ class FlatLearner:
     NOISE_POOL = 128   # minibatch steps per refill (= steps per training step in the reference configuration)
 
     @torch.no_grad()
-    def _next_noise(self):
+    def _noise_block(self):
         """Entropy-sample noise for the captured step: inside a graph `normal_` costs three launches per replay (the
-        generator's seed / offset fills + the kernel); one refill per 128 steps and one slice copy per step cost one."""
-        if self._pool is None or self._pool_k >= self.NOISE_POOL:
-            if self._pool is None:
-                self._pool = torch.empty(self.NOISE_POOL, *self.noise.shape, device=self.noise.device)
+        generator's seed / offset fills + the kernel); a pool refilled once per 128 steps costs none -- this step's slice is
+        copied into the static noise buffer by the minibatch gather launch itself (a "direct" field of `odk_gather_rows`).
+        Returns the slice's first row in the pool viewed as [NOISE_POOL * B, T * A]."""
+        if self._pool is None:
+            self._pool = torch.empty(self.NOISE_POOL, *self.noise.shape, device=self.noise.device)
+            self._pool_k = self.NOISE_POOL
+            self._gather = None
+        if self._pool_k >= self.NOISE_POOL:
             self._pool.normal_()
             self._pool_k = 0
-        self.noise.copy_(self._pool[self._pool_k])
+        k = self._pool_k
         self._pool_k += 1
+        return k * self.B
 
     @torch.no_grad()
     def _update(self):
@@ -312,7 +341,7 @@ class FlatLearner:
         self.losses.zero_()
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
-            self._loss_and_grads()                  # the noise buffer is filled before each replay (_next_noise)
+            self._loss_and_grads()                  # the noise buffer is filled before each replay (load_minibatch)
             if not self.split_update:
                 self._update()
         if self.split_update:
@@ -325,18 +354,19 @@ class FlatLearner:
         """Gathers trajectories `idx` of the ([N, T, ...]) rollout tensors into the static buffers: one launch for all
         eight fields (`odk_gather_rows`)."""
         keys = self.KEYS + ("last_priv",)
-        srcs = tuple(data[k] for k in keys)
-        if self._gather is None or any(a is not b for a, b in zip(self._gather_src, srcs)):
-            self._gather = engine.RowGather([(data[k], self.static[k]) for k in keys])
+        base = [self._noise_block()] if self.graph_a is not None else []     # (may replace the pool: before the gather is built)
+        srcs = tuple(data[k] for k in keys) + ((self._pool,) if base else ())
+        if self._gather is None or len(srcs) != len(self._gather_src) or any(a is not b for a, b in zip(self._gather_src, srcs)):
+            direct = [(self._pool.view(self.NOISE_POOL * self.B, -1), self.noise.view(self.B, -1))] if base else []
+            self._gather = engine.RowGather([(data[k], self.static[k]) for k in keys], direct)
             self._gather_src = srcs
-        self._gather(idx)
+        self._gather(idx, base)
 
     def step(self):
         """One clipped-Adam step on the loaded minibatch.  The loss head ADDS this step's (total, policy, value, entropy)
         to `self.losses` (no sync); `metrics()` turns the sums into means."""
         if self.graph_a is not None:
-            self._next_noise()
-            self.graph_a.replay()
+            self.graph_a.replay()                       # (its entropy noise came with load_minibatch)
         else:
             if self.sample_noise:
                 self._draw_noise()

@@ -35,8 +35,36 @@ def test_gae_kernel_matches_torch_reference(B, Tn):
     torch.testing.assert_close(stats[1], 1.0 / (adv_ref.std(unbiased=False) + 1e-8), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("normalize_advantage", [True, False])
-def test_flat_learner_gradients_match_autograd(normalize_advantage):
+def test_dw_gemm_matches_torch_mm_and_is_reproducible():
+    """odk_dw_gemm (weight gradients dz^T h of several layers, split-K on the f32 matrix cores) vs float64 torch; edge tiles
+    (28, 1, 101, 212 columns), offsets into a flat buffer, bit-identical repeats (fixed-order fold of the row slices)."""
+    from open_duck_playground_amd import engine
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for n, shapes, ks in ((1280, [(512, 101), (256, 512), (128, 256), (28, 128)], 8), (768, [(512, 212), (1, 128)], 16), (256, [(36, 70), (64, 33)], 8)):
+        tot = sum((o * i + 7) // 4 * 4 for o, i in shapes) + 12
+        flat = torch.full((tot,), 7.0, device="cuda")
+        ws = torch.empty(ks * engine.DwGemm.workspace_stride(tot), device="cuda")
+        layers, off = [], 8
+        for o, i in shapes:
+            layers.append((torch.randn(n, o, device="cuda", generator=g), torch.randn(n, i, device="cuda", generator=g), off))
+            off += (o * i + 7) // 4 * 4
+        op = engine.DwGemm(layers, flat, ws, ks)
+        op()
+        first = flat.clone()
+        for dz, h, o in layers:
+            ref = dz.double().t() @ h.double()
+            got = flat[o:o + ref.numel()].view_as(ref).double()
+            assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+        assert float(flat[:8].min()) == 7.0 and float(flat[off:].min()) == 7.0          # nothing outside the layers' ranges is touched
+        ws.fill_(float("nan")); op()
+        assert torch.equal(flat, first)
+    with pytest.raises(engine.OdkError):
+        engine.DwGemm([(torch.zeros(100, 8, device="cuda"), torch.zeros(100, 8, device="cuda"), 0)], torch.zeros(64, device="cuda"),
+                      torch.zeros(8 * 64, device="cuda"), 8)                              # rows not divisible by 16 * kslices
+
+
+@pytest.mark.parametrize("normalize_advantage, N", [(True, 64), (False, 64), (True, 1024)])   # N = 1024: 256 x 20 rows, the dW kernel's path
+def test_flat_learner_gradients_match_autograd(normalize_advantage, N):
     """loss scalars and every parameter gradient of the fused step == autograd of ppo_loss (same entropy noise)."""
     from open_duck_playground_amd.ppo import train as T
     from open_duck_playground_amd.ppo.learner import FlatLearner, prepare_rollout
@@ -45,13 +73,14 @@ def test_flat_learner_gradients_match_autograd(normalize_advantage):
     torch.manual_seed(0)
     net = PPONetworks(101, 212, 14).to(dev)
     cfg = T.ppo_config(); cfg["normalize_advantage"] = normalize_advantage
-    N, Tn, nmb = 64, 20, 4
+    Tn, nmb = 20, 4
     data = _fake_rollout(N, Tn, dev)
     net.norm_obs.update(data["obs"]); net.norm_priv.update(data["priv"])
     ref = copy.deepcopy(net)
     lr = FlatLearner(net, cfg, N // nmb, Tn, use_graph=False)
     idx = torch.arange(3, 3 + N // nmb, device=dev)
     lr.load_minibatch(prepare_rollout(net, data, cfg), idx)
+    assert (lr.policy.dw is not None) == (N == 1024)            # 5 120 rows divide into the dW kernel's slices, 320 do not
     lr._draw_noise(); lr._loss_and_grads()
     mb = {k: v[idx] for k, v in data.items()}
     mb["noise"] = lr.noise.view(N // nmb, Tn, 14).clone()
@@ -236,10 +265,10 @@ def test_split_update_over_rccl_matches_the_single_graph_step():
         prep = prepare_rollout(nets[0], data, cfg)
         for k in range(6):
             idx = torch.arange((k % 4) * 16, (k % 4) * 16 + 16, device=dev)
-            for lr in (one, two):
-                lr.load_minibatch(prep, idx)
+            one.load_minibatch(prep, idx)
+            two.load_minibatch(prep, idx)
+            two.noise.copy_(one.noise)                                   # same entropy noise
             one.step()
-            two._pool, two._pool_k = one._pool, one._pool_k - 1        # same entropy noise
             two.step()
         T.assert_replicas_identical(nets[1], dist.group.WORLD)
         torch.cuda.synchronize()
@@ -264,6 +293,15 @@ def test_row_gather_refuses_bad_indices():
             g(bad)
     g(torch.tensor([1, 10, -1], device="cuda"))                # out of range: NaN rows, never an out-of-bounds read
     assert dst[0].tolist() == src[1].tolist() and torch.isnan(dst[1:]).all()
+    # rows longer than one 1024-float chunk, odd row lengths (no 16-byte path), and a direct (un-indexed) block field
+    big, odd, pool = torch.randn(9, 2500, device="cuda"), torch.randn(9, 7, device="cuda"), torch.randn(12, 40, device="cuda")
+    dbig, dodd, dpool = torch.zeros(3, 2500, device="cuda"), torch.zeros(3, 7, device="cuda"), torch.zeros(3, 40, device="cuda")
+    g2 = engine.RowGather([(big, dbig), (odd, dodd)], [(pool, dpool)])
+    pick = torch.tensor([8, 2, 5], device="cuda")
+    g2(pick, [6])
+    assert torch.equal(dbig, big[pick]) and torch.equal(dodd, odd[pick]) and torch.equal(dpool, pool[6:9])
+    with pytest.raises(engine.OdkError):
+        g2(pick, [10])                                         # direct block past the end of its source
     with pytest.raises(engine.OdkError):
         engine.RowGather([(src, dst), (torch.zeros(9, 4, device="cuda"), torch.zeros(3, 4, device="cuda"))])
 

@@ -1,5 +1,6 @@
-import sys, time, torch
-sys.path.insert(0, '.')
+"""Per-substep cost vs per-env-step overhead of the fused step kernel (n_substeps = 1, 2, 10):  python tools/gpu_substep_scan.py"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from open_duck_playground_amd import engine
 from open_duck_playground_amd.model import load_task_model
 for task in ("flat_terrain", "flat_terrain_backlash"):
