@@ -124,7 +124,7 @@ def main():
 
     if rank == 0:
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r2", "traffic.json")
         if args.task == "flat_terrain" and args.envs == 8192 and os.path.exists(tpath):
             # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, profiles/README.md)
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
