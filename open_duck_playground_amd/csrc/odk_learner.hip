@@ -6,7 +6,7 @@
 //   gae_kernel        GAE + advantage normalisation statistics          (1 workgroup)
 //   ppo_head_kernel   tanh-normal log-prob, clipped surrogate, value loss, sampled entropy AND their
 //                     gradients w.r.t. the network outputs              (16 lanes per sample)
-//   sqnorm_kernel     global gradient norm                              (flat gradient buffer)
+//   sqnorm_kernel     per-block partial sums of the squared gradient norm (flat gradient buffer; folded by adam_kernel)
 //   adam_kernel       clip_by_global_norm + Adam on the flat parameter buffer
 // All launches are stream-ordered on the caller's stream and contain no host synchronisation, so they can be
 // captured into a HIP graph together with the GEMMs.
@@ -244,21 +244,22 @@ __global__ void sqnorm_kernel(const float* __restrict__ g, float* __restrict__ a
   float s = 0.0f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const float v = g[i]; s += v * v; }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) acc[2 + blockIdx.x] = s;
-}
-__global__ void sqnorm_final_kernel(float* __restrict__ acc, int nblocks) {
-  __shared__ float sh[16];
-  float s = 0.0f;
-  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += acc[2 + i];
-  s = block_sum(s, sh);
-  if (threadIdx.x == 0) { acc[0] = s; acc[1] += 1.0f; }
+  if (threadIdx.x == 0) { acc[2 + blockIdx.x] = s; if (blockIdx.x == 0) acc[1] += 1.0f; }   // block 0 also advances the step counter
 }
 
 // optax.chain(clip_by_global_norm(max_norm), adam(lr)): g *= max_norm / norm when norm >= max_norm;
 // m, v moments with bias correction 1 - b^t, p -= lr * mhat / (sqrt(vhat) + eps).
+// Every block folds the per-block partial sums of the squared norm itself, in the same fixed order (so every block -- and
+// every data-parallel replica -- gets the same bits): one launch less than a separate final-reduction kernel.  Block 0
+// leaves the total in acc[0] for the caller.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            const float* __restrict__ acc, int64_t n, float lr, float b1, float b2, float eps, float max_norm) {
-  const float norm = sqrtf(acc[0]), t = acc[1];
+                            float* __restrict__ acc, int nblocks, int64_t n, float lr, float b1, float b2, float eps, float max_norm) {
+  __shared__ float sh[16];
+  float sq = 0.0f;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) sq += acc[2 + i];
+  sq = block_sum(sq, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) acc[0] = sq;
+  const float norm = sqrtf(sq), t = acc[1];
   const float clip = (max_norm > 0.0f && !(norm < max_norm)) ? max_norm / norm : 1.0f;
   const float c1 = 1.0f / (1.0f - powf(b1, t)), c2 = 1.0f / (1.0f - powf(b2, t));
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -477,8 +478,8 @@ extern "C" int odk_gae(const float* truncation_dev, const float* termination_dev
   if (!truncation_dev || !termination_dev || !rewards_dev || !values_dev || !bootstrap_dev || !vs_dev || !adv_dev || B <= 0 || T <= 0)
     return odk_fail_(ODK_ERR_INVALID, "odk_gae: bad arguments");
   const int threads = B >= 1024 ? 1024 : ((B + 63) / 64) * 64;
-  if ((long long)B * T <= GAE_LDS_N)
-    hipLaunchKernelGGL(gae_kernel_lds, dim3(1), dim3(threads), 0, (hipStream_t)stream, truncation_dev, termination_dev, rewards_dev,
+  if ((long long)B * T <= GAE_LDS_N)   // 1024 threads: the staging loops are latency-bound (5 trips of 4 loads instead of 20), the recursion uses B of them
+    hipLaunchKernelGGL(gae_kernel_lds, dim3(1), dim3(1024), 0, (hipStream_t)stream, truncation_dev, termination_dev, rewards_dev,
                        values_dev, bootstrap_dev, vs_dev, adv_dev, adv_stats_dev, B, T, lambda_, discount);
   else if (B <= 1024 && T <= 32)
     hipLaunchKernelGGL(gae_kernel_reg<32>, dim3(1), dim3(threads), 0, (hipStream_t)stream, truncation_dev, termination_dev, rewards_dev,
@@ -523,8 +524,7 @@ extern "C" int odk_adam_clip(float* params_dev, const float* grads_dev, float* m
   int blocks = (int)((n + threads * 4 - 1) / (threads * 4));
   if (blocks > ODK_ADAM_MAX_PARTIALS) blocks = ODK_ADAM_MAX_PARTIALS;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks), dim3(threads), 0, st, grads_dev, acc_dev, (int64_t)n);
-  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, acc_dev, blocks);
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, grads_dev, m_dev, v_dev, acc_dev, (int64_t)n, lr, b1, b2, eps,
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, grads_dev, m_dev, v_dev, acc_dev, blocks, (int64_t)n, lr, b1, b2, eps,
                      max_grad_norm);
   return check_launch("odk_adam_clip: launch failed");
 }
