@@ -1,5 +1,8 @@
 """Parity debugging aid (test infrastructure, not collected by pytest): per-stage max errors of the HIP forward pass vs the
-oracle (prints, no asserts).  `python tests/debug_gpu_stages.py` on a GPU box."""
+oracle (prints, no asserts).  `python tests/debug_gpu_stages.py` on a GPU box.
+NOTE (round 2): in the image of a forward pass that computed the sensors (the last substep), the first 46 floats of the
+"jv" rows hold sensordata (csrc Shape::O_SENS aliases O_JV) and the first 2 * njnt floats of "jar" held sin/cos during
+P0 / P1; "M" / "HL" / "cdof" are on the reduced (backlash twins merged) dof tree -- see tables.reduced_layout."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))  # ROOT = repo root (this file lives in tests/)
