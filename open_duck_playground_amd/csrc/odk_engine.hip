@@ -54,7 +54,14 @@ template <class S> struct EnvL {
 // the workgroup's copy of the shared tables (call with all 64 lanes; followed by a hand-off barrier at the caller)
 template <class S> __device__ __forceinline__ const int* load_shared(float* lds, int envs, const DevModel* m) {
   int* RT = reinterpret_cast<int*>(lds + envs * EnvL<S>::TOTAL);
-  for (int k = threadIdx.x; k < S::NMR; k += 64) RT[k] = m->R_ent[k];
+  {
+    constexpr int T = (S::NMR + 63) / 64;
+    int v[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) { const int k = threadIdx.x + 64 * t; v[t] = m->R_ent[k < S::NMR ? k : 0]; }
+#pragma unroll
+    for (int t = 0; t < T; t++) { const int k = threadIdx.x + 64 * t; if (k < S::NMR) RT[k] = v[t]; }
+  }
   float* SH = reinterpret_cast<float*>(RT);
   float* CT = SH + S::SH_CT;
   const int k = threadIdx.x;
@@ -69,7 +76,7 @@ using ShapeB = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25>;   // *_backlash
 
 struct KArgs {
   const DevModel* m;
-  const DevPRM* prm;
+  DevPRM prm;         // by value (232 bytes of kernel arguments): the grid searches read scalar registers, not 20 dependent loads
   const float* prm_table;
   float* recs;        // [nenv][Rec::SIZE]
   float* first;       // [nenv][Rec::FSIZE]
@@ -106,34 +113,66 @@ __device__ __noinline__ void dump_lds(float* dbg, const float* L, int env, int l
   for (int k = lane; k < S::TOTAL; k += G) o[k] = L[k];
 }
 
-// effective per-env model parameters -> LDS
+// Global -> LDS copies of the prologue.  Written as "all loads, then all stores" with compile-time trip counts: as
+// `for (i = lane; i < N; i += G) dst[i] = src[i]` every trip was its own load -> s_waitcnt vmcnt(0) -> ds_write round trip
+// (~25 serialised global round trips per env step: most of the 40 us a zero-substep launch took).
+template <int N, int G> struct G2L {
+  static constexpr int T = (N + G - 1) / G;
+  float v[T];
+  __device__ __forceinline__ void load(const float* __restrict__ src, int lane) {
+#pragma unroll
+    for (int t = 0; t < T; t++) { const int i = lane + t * G; v[t] = src[i < N ? i : 0]; }
+  }
+  __device__ __forceinline__ void store(float* dst, int lane) const {
+#pragma unroll
+    for (int t = 0; t < T; t++) { const int i = lane + t * G; if (i < N) dst[i] = v[t]; }
+  }
+};
+
+// effective per-env model parameters -> LDS: nominal values from the model, domain-randomised ones (dr != null) on top
 template <class S, int G>
-__device__ __forceinline__ void load_params(float* L, const DevModel* m, const float* dr, int lane) {
-  for (int i = lane; i < S::NQ; i += G) L[S::O_Q0 + i] = m->qpos0[i];
-  for (int i = lane; i < S::NB; i += G) L[S::O_MASS + i] = dr ? dr[DRL<S>::MASS + i] : m->body_mass[i];
-  for (int i = lane; i < S::NV; i += G) { L[S::O_ARM + i] = m->dof_armature[i]; L[S::O_FRL + i] = m->dof_frictionloss[i]; }
-  for (int i = lane; i < S::NU; i += G) L[S::O_KP + i] = dr ? dr[DRL<S>::KP + i] : m->act_kp[i];
-  if (lane < 3) L[S::O_IPOS1 + lane] = dr ? dr[DRL<S>::IPOS + lane] : m->body_ipos[1][lane];
-  ODK_SYNC();
-  if (dr) {
-    for (int u = lane; u < S::NU; u += G) {
-      L[S::O_Q0 + m->act_qposadr[u]] = dr[DRL<S>::Q0 + u];
-      L[S::O_ARM + m->act_dofadr[u]] = dr[DRL<S>::ARM + u];
-      L[S::O_FRL + m->act_dofadr[u]] = dr[DRL<S>::FRL + u];
-    }
+struct ParamLoad {
+  float q0, mass, arm, frl, kp, ipos, dq0, darm, dfrl;
+  int qadr, dadr;
+  __device__ __forceinline__ void load(const DevModel* __restrict__ m, const float* __restrict__ dr, int lane) {
+    static_assert(S::NQ <= G && S::NV <= G && S::NB <= G && S::NU <= G, "one parameter of each kind per lane");
+    const int iq = lane < S::NQ ? lane : 0, ib = lane < S::NB ? lane : 0, iv = lane < S::NV ? lane : 0, iu = lane < S::NU ? lane : 0, i3 = lane < 3 ? lane : 0;
+    q0 = m->qpos0[iq];
+    mass = dr ? dr[DRL<S>::MASS + ib] : m->body_mass[ib];
+    arm = m->dof_armature[iv]; frl = m->dof_frictionloss[iv];
+    kp = dr ? dr[DRL<S>::KP + iu] : m->act_kp[iu];
+    ipos = dr ? dr[DRL<S>::IPOS + i3] : m->body_ipos[1][i3];
+    qadr = m->act_qposadr[iu]; dadr = m->act_dofadr[iu];
+    dq0 = dr ? dr[DRL<S>::Q0 + iu] : 0.0f; darm = dr ? dr[DRL<S>::ARM + iu] : 0.0f; dfrl = dr ? dr[DRL<S>::FRL + iu] : 0.0f;
+  }
+  __device__ __forceinline__ void store(float* L, bool has_dr, int lane) const {
+    if (lane < S::NQ) L[S::O_Q0 + lane] = q0;
+    if (lane < S::NB) L[S::O_MASS + lane] = mass;
+    if (lane < S::NV) { L[S::O_ARM + lane] = arm; L[S::O_FRL + lane] = frl; }
+    if (lane < S::NU) L[S::O_KP + lane] = kp;
+    if (lane < 3) L[S::O_IPOS1 + lane] = ipos;
+    ODK_SYNC();   // the actuated joints' randomised values go on top of the nominal ones written by other lanes
+    if (has_dr && lane < S::NU) { L[S::O_Q0 + qadr] = dq0; L[S::O_ARM + dadr] = darm; L[S::O_FRL + dadr] = dfrl; }
     ODK_SYNC();
   }
+};
+template <class S, int G>
+__device__ __forceinline__ void load_params(float* L, const DevModel* m, const float* dr, int lane) {
+  ParamLoad<S, G> p;
+  p.load(m, dr, lane);
+  p.store(L, dr != nullptr, lane);
 }
 
 // PolyReferenceMotion.get_reference_motion (reference poly_reference_motion.py:148-168): float32 fma Horner
-__device__ inline int prm_nearest(const float* grid, int n, float v) {
+__device__ __forceinline__ int prm_nearest(const float* grid, int n, float v) {   // grid: kernel-argument array, fully unrolled
   int best = 0;
   float bd = fabsf(grid[0] - v);
-  for (int i = 1; i < n; i++) { const float d = fabsf(grid[i] - v); if (d < bd) { bd = d; best = i; } }
+#pragma unroll
+  for (int i = 1; i < 16; i++) { const float d = fabsf(grid[i] - v); if (i < n && d < bd) { bd = d; best = i; } }
   return best;
 }
 template <int G>
-__device__ __forceinline__ void prm_eval(const DevPRM* p, const float* table, float dx, float dy, float dth, int i, float* out, int lane) {
+__device__ __forceinline__ void prm_eval(const DevPRM* __restrict__ p, const float* table, float dx, float dy, float dth, int i, float* out, int lane) {
   const float x = fminf(fmaxf(dx, p->ranges[0]), p->ranges[1]);
   const float y = fminf(fmaxf(dy, p->ranges[2]), p->ranges[3]);
   const float t3 = fminf(fmaxf(dth, p->ranges[4]), p->ranges[5]);
@@ -318,7 +357,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   if (a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
   const float pint = c.push_interval_range[0] + rng_uniform(k0, kr, 0, 31) * (c.push_interval_range[1] - c.push_interval_range[0]);
   const int push_interval_steps = (int)rintf(pint / c.ctrl_dt);
-  if (c.use_imitation) prm_eval<G>(a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], 0, L + E::O_REF, lane);
+  if (c.use_imitation) prm_eval<G>(&a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], 0, L + E::O_REF, lane);
   else for (int k = lane; k < 40; k += G) L[E::O_REF + k] = 0;
   ODK_SYNC();
   float contact[2];
@@ -372,11 +411,19 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   const EnvCfg& c = a.cfg;
   float* INFO = L + E::O_INFO; float* ACT = L + E::O_ACT; float* CTRL = L + S::O_CTRL;
   float* rc = a.recs + (size_t)e * R::SIZE;
-  // ---- load state record (coalesced: the group's lanes read consecutive floats)
-  for (int i = lane; i < S::NQ + 2 * S::NV; i += G) L[S::O_QPOS + i] = rc[i];  // qpos|qvel|warm are contiguous in LDS too
-  for (int k = lane; k < rec::NINFO; k += G) INFO[k] = rc[R::INFO + k];
-  for (int u = lane; u < NU; u += G) ACT[u] = a.action[(size_t)e * NU + u];
-  load_params<S, G>(L, m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);  // syncs
+  // ---- state record, action, parameters, per-lane statics: ONE batch of global loads (coalesced: the group's lanes read
+  // consecutive floats), then the LDS stores
+  {
+    G2L<S::NQ + 2 * S::NV, G> g_state;   // qpos|qvel|warm are contiguous in LDS too
+    G2L<rec::NINFO, G> g_info;
+    G2L<NU, G> g_act;
+    ParamLoad<S, G> g_par;
+    const float* drp = a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr;
+    g_state.load(rc, lane); g_info.load(rc + R::INFO, lane); g_act.load(a.action + (size_t)e * NU, lane);
+    g_par.load(m, drp, lane);
+    g_state.store(L + S::O_QPOS, lane); g_info.store(INFO, lane); g_act.store(ACT, lane);
+    g_par.store(L, drp != nullptr, lane);   // syncs
+  }
 #ifdef ODK_PROFILE
   if (lane < 20) L[S::O_SCR + S::S_PROF + lane] = 0;
 #endif
@@ -394,10 +441,10 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   float phase[2] = {0, 0};
   float ref0 = 0.0f, ref1 = 0.0f;   // current_reference_motion[lane], [lane + 32]: two registers across the substeps
   if (c.use_imitation) {
-    imi = (imi + 1) % a.prm->nsteps;
-    const float ph = ((float)imi / (float)a.prm->nsteps) * 2.0f * PI_F;
+    imi = (imi + 1) % a.prm.nsteps;
+    const float ph = ((float)imi / (float)a.prm.nsteps) * 2.0f * PI_F;
     phase[0] = cosf(ph); phase[1] = sinf(ph);
-    prm_eval_regs<G>(a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], imi, ref0, ref1, lane);   // (:347-353)
+    prm_eval_regs<G>(&a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], imi, ref0, ref1, lane);   // (:347-353)
   } else {
     imi = 0;
   }
@@ -657,7 +704,7 @@ struct odk_batch {
   odk_model model;
   int nenv, device, G;
   odk_env_config cfg;
-  DevModel* d_model = nullptr; DevPRM* d_prm = nullptr; float* d_table = nullptr;
+  DevModel* d_model = nullptr; DevPRM h_prm; float* d_table = nullptr;
   float* d_recs = nullptr; float* d_first = nullptr; float* d_dr = nullptr; float* d_dbg = nullptr; float* d_hfield = nullptr;
   std::vector<float> h_dr; bool dr_enabled = false;
   int rec_size, frec_size, lds_total, dr_size, env_lds;
@@ -1188,7 +1235,7 @@ extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, i
   for (int i = 0; i < 6; i++) hp.ranges[i] = (float)ranges6[i];
   size_t tbytes = (size_t)nx * ny * nth * 640 * sizeof(float);
   HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel))); HIPCHK(hipMemcpy(b->d_model, &m->h, sizeof(DevModel), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&b->d_prm, sizeof(DevPRM))); HIPCHK(hipMemcpy(b->d_prm, &hp, sizeof(DevPRM), hipMemcpyHostToDevice));
+  b->h_prm = hp;
   HIPCHK(hipMalloc(&b->d_table, tbytes)); HIPCHK(hipMemcpy(b->d_table, prm_table, tbytes, hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&b->d_recs, (size_t)nenv * b->rec_size * sizeof(float))); HIPCHK(hipMemset(b->d_recs, 0, (size_t)nenv * b->rec_size * sizeof(float)));
   HIPCHK(hipMalloc(&b->d_first, (size_t)nenv * b->frec_size * sizeof(float))); HIPCHK(hipMemset(b->d_first, 0, (size_t)nenv * b->frec_size * sizeof(float)));
@@ -1203,7 +1250,7 @@ extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, i
 extern "C" void odk_batch_destroy(odk_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
-  for (void* p : {(void*)b->d_model, (void*)b->d_prm, (void*)b->d_table, (void*)b->d_recs, (void*)b->d_first, (void*)b->d_dr, (void*)b->d_dbg, (void*)b->d_hfield}) (void)hipFree(p);
+  for (void* p : {(void*)b->d_model, (void*)b->d_table, (void*)b->d_recs, (void*)b->d_first, (void*)b->d_dr, (void*)b->d_dbg, (void*)b->d_hfield}) (void)hipFree(p);
   for (auto& ev : b->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   delete b;
 }
@@ -1277,7 +1324,7 @@ static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st
 
 static void base_args(odk_batch* b, KArgs& a, const odk_outputs* o) {
   memset(&a, 0, sizeof(a));
-  a.m = b->d_model; a.prm = b->d_prm; a.prm_table = b->d_table; a.recs = b->d_recs; a.first = b->d_first;
+  a.m = b->d_model; a.prm = b->h_prm; a.prm_table = b->d_table; a.recs = b->d_recs; a.first = b->d_first;
   a.hfield = b->d_hfield;
   a.dr = b->dr_enabled ? b->d_dr : nullptr; a.nenv = b->nenv; a.n_substeps = b->cfg.n_substeps;
   a.dbg_lds = nullptr;

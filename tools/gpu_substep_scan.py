@@ -6,7 +6,7 @@ from open_duck_playground_amd.model import load_task_model
 for task in ("flat_terrain", "flat_terrain_backlash"):
     model = load_task_model(task)
     res = {}
-    for ns in (1, 2, 10):
+    for ns in (0, 1, 2, 10):
         cfg = engine.default_config(); cfg.noise_level = 0.0; cfg.push_enable = 0.0; cfg.n_substeps = ns
         b = engine.Batch(model, 8192, cfg); b.reset(0)
         act = torch.empty(64, 8192, 14, device="cuda").uniform_(-1, 1)
