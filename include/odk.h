@@ -193,15 +193,69 @@ int odk_colsum_partial(const float* x_dev, float* partial_dev, int n, int w, voi
  * order as odk_silu_bwd_colsum's own fold).  partial_dev / colsum_dev / widths are HOST arrays. */
 int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_dev, const int* widths, int count, int n, void* stream);
 
-/* Weight gradients of up to 4 dense layers in one launch on the f32 matrix cores (v_mfma_f32_32x32x2_f32):
- *   out[out_off[l] + i * n_in[l] + j] = sum over the nrows minibatch rows r of dz[l][r, i] * h[l][r, j]      (= dz^T h, torch Linear weight layout)
- * dz[l] is [nrows, n_out[l]], h[l] is [nrows, n_in[l]], both row-major; out_dev is the flat gradient buffer.  The rows are
- * split into kslices slices (a multiple of 8; nrows divisible by 16 * kslices); ws_dev is a workspace of kslices * ws_stride
- * floats laid out like out_dev (ws_stride >= every out_off + n_out * n_in, a multiple of 4; every out_off and n_out * n_in a
- * multiple of 4; ws_dev and out_dev 16-byte aligned); the slices are folded in a fixed order, so the result is
- * bit-reproducible.  dz_dev / h_dev / n_out / n_in / out_off are HOST arrays. */
+/* Weight gradients of up to 8 dense layers in one launch on the f32 matrix cores (v_mfma_f32_32x32x2_f32):
+ *   out[out_off[l] + i * n_in[l] + j] = sum over the nrows[l] minibatch rows s of dz[l](s, i) * h[l](s, j)      (= dz^T h, torch Linear weight layout)
+ * dz[l] / h[l] are in the QUAD-ROW layout the fused network kernels write: [nrows / 4][width][4], element (s, f) at
+ * ((s / 4) * width + f) * 4 + s % 4 (16-byte aligned; nrows[l] a multiple of 8 and >= 8 * kslices; rows past the batch hold zeros
+ * in at least one of the two operands).  out_dev is the flat gradient buffer.  The rows are split into kslices slices (a
+ * multiple of 8); ws_dev is a workspace of kslices * ws_stride floats laid out like out_dev (ws_stride >= every out_off +
+ * n_out * n_in, a multiple of 4; every out_off and n_out * n_in a multiple of 4; ws_dev and out_dev 16-byte aligned); the slices
+ * are folded in a fixed order, so the result is bit-reproducible.  dz_dev / h_dev / n_out / n_in / out_off / nrows are HOST arrays. */
 int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int* n_out, const int* n_in, const long long* out_off, int nlayers,
-                int nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, void* stream);
+                const int* nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, void* stream);
+
+/* ---- fused policy / value networks (csrc/odk_mlp.hip): a swish MLP  n_in -> 512 -> 256 -> 128 -> n_out  (brax ppo.networks as
+ * configured by the reference, common/runner.py:86-118) forward in ONE launch and its backward-data chain in ONE launch, on the
+ * f32 matrix cores; a workgroup keeps a tile of 32 samples in LDS for all layers.  One or two networks per launch (policy and
+ * value side by side).  Everything row-major float32 on the device.
+ * The kernels read the weights from PACKED copies (16-byte pieces of four consecutive reduction indices per column):
+ *   forward copy of W [n_out, n_in]:  [pad8(n_in) / 4][n_out][4],  element (o, i) at ((i / 4) * n_out + o) * 4 + i % 4
+ *   backward copy:                    [pad8(n_out) / 4][n_in][4],  element (o, i) at ((o / 4) * n_in + i) * 4 + o % 4
+ * with pad8(k) = k rounded up to a multiple of 8 and the padding zero (the caller zeroes the buffers once; odk_pack_weights /
+ * odk_adam_clip_packed write the weights' elements only). */
+#define ODK_MLP_H1 512
+#define ODK_MLP_H2 256
+#define ODK_MLP_H3 128
+#define ODK_MLP_MAX_IN 224
+typedef struct odk_mlp_desc {
+  const float* x;            /* [n, n_in] network input */
+  const float* wf[4];        /* forward-packed weights of the four layers (16-byte aligned) */
+  const float* wb[4];        /* backward-packed weights (wb[0] is not read: the input's gradient is never formed) */
+  const float* b[4];         /* biases */
+  /* training buffers, all in the QUAD-ROW layout [np / 4][width][4] with np = n rounded up to a multiple of 32 (element (s, f) at
+   * ((s / 4) * width + f) * 4 + s % 4; the operand layout of odk_dw_gemm); rows n .. np - 1 are written as zeros in h / g / dz / doutp */
+  float* xp;                 /* forward out: quad-row copy of x, width n_in (rows past n: copies of row n - 1) */
+  float* h[3];               /* forward out: swish(z_l), width H_l; all of xp / h / g NULL: inference only, nothing but `out` is written */
+  float* g[3];               /* forward out / backward in: swish'(z_l) */
+  float* out;                /* forward out: [n, n_out] row-major */
+  const float* dout;         /* backward in: dLoss/dout [n, n_out] row-major */
+  float* doutp;              /* backward out: quad-row copy of dout, width n_out */
+  float* dz[3];              /* backward out: dLoss/dz_l, width H_l */
+  float* bias_partial[4];    /* backward out: per-tile column sums of dz_l (l = 3: of dout), [ceil(n / 32), width_l]; odk_colsum_fold finishes them */
+  int n, n_in, n_out;        /* n_in <= ODK_MLP_MAX_IN, n_out <= 32 */
+} odk_mlp_desc;
+int odk_mlp_forward(const odk_mlp_desc* nets, int count, void* stream);
+int odk_mlp_backward(const odk_mlp_desc* nets, int count, void* stream);
+/* tools: device buffer of 32 int64 receiving the forward kernel's phase timestamps (shader clock, workgroup 0); NULL: off */
+void odk_mlp_set_profile(long long* stamps_dev);
+/* Where up to 8 weight matrices sit in a flat parameter buffer (float offset `off`, torch layout [rows = n_out, cols = n_in]) and
+ * in the packed buffers (float offsets, multiples of 4; bwd_off < 0: no backward copy of that weight). */
+typedef struct odk_weight_table {
+  int count;
+  long long off[8];
+  int rows[8], cols[8];
+  long long fwd_off[8], bwd_off[8];
+} odk_weight_table;
+/* (re)builds the packed copies from the parameters */
+int odk_pack_weights(const float* params_dev, long long n, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
+                     const odk_weight_table* table, void* stream);
+/* odk_adam_clip that also keeps the packed copies current (every updated weight is written to all of its places) */
+int odk_adam_clip_packed(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
+                         float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
+                         const odk_weight_table* table, void* stream);
+/* colsum[f][c] = sum over the nblk[f] tile rows of partial[f][tile, c] for up to 8 layers in one launch (fixed order);
+ * partial_dev / colsum_dev / widths / nblk are HOST arrays */
+int odk_colsum_fold(const float* const* partial_dev, float* const* colsum_dev, const int* widths, const int* nblk, int count, void* stream);
 
 /* dst[f][b, :] = src[f][idx[b], :] for up to 10 row-major float fields in one launch (minibatch gather of the rollout).
  * src_dev / dst_dev / row_floats are HOST arrays of device pointers / row lengths; idx_dev is int64 on the device, nrows

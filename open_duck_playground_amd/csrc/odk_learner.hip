@@ -364,18 +364,23 @@ __global__ void gather_rows_kernel(GatherArgs a, const long long* __restrict__ i
   }
 }
 
-// ---- weight gradients of an MLP: dW_l = dz_l^T h_{l-1} for up to 4 layers in ONE launch, on the f32 matrix cores.
+// ---- weight gradients of an MLP: dW_l = dz_l^T h_{l-1} for up to 8 layers (two networks) in ONE launch, on the f32 matrix cores.
 // These are the learner's worst-shaped GEMMs (K = 5 120 minibatch rows deep, outputs as small as 28 x 128): the library runs
-// them at ~30 TFLOP/s.  Here both operands are K-major ([rows, n_out] and [rows, n_in] row-major), which is exactly the
-// v_mfma_f32_32x32x2_f32 fragment order -- lane l feeds A[m = l % 32][k = l / 32] = dz[k0 + l / 32][i0 + l % 32], likewise B
-// from h -- so fragments are plain coalesced global loads (two 128-byte row segments per instruction), no LDS, no
-// transposes.  One wave = one 64 x 64 output tile (2 x 2 MFMA blocks, 64 accumulator registers) over one slice of the rows
-// (split-K); partial tiles go to a workspace laid out like the flat gradient buffer, and dw_reduce_kernel folds the slices
-// in a fixed order (data-parallel replicas must stay bit-identical: no float atomics).  Block b runs on XCD b % 8: the
-// blocks of an XCD share the same row slices, so each XCD's L2 reads its part of dz / h once and serves all tiles from it.
+// them at ~30 TFLOP/s.  Both operands arrive in the quad-row layout the fused network kernels write (csrc/odk_mlp.hip:
+// [rows / 4][width][4], four consecutive rows of one column = 16 bytes), so that a lane's piece of four reduction indices is ONE
+// global_load_dwordx4 and the wave reads two contiguous 512-byte runs per operand block: lane l (r = l / 32, c = l % 32) of
+// row group G takes rows 8 G + 4 r + {0..3} of column i0 + c (dz) / j0 + c (h), and the group's MFMAs j = 0..3 use component j
+// of both (v_mfma_f32_32x32x2_f32: A[m = c][k = r], B[k = r][n = c]).  No LDS, no transposes, 4 loads per 16 MFMAs (with one
+// 4-byte load per lane and MFMA -- the first version -- the CU's address unit was the limit: ~30 % of the matrix pipe).
+// One wave = one 64 x 64 output tile (2 x 2 MFMA blocks, 64 accumulator registers) over one slice of the rows (split-K);
+// partial tiles go to a workspace laid out like the flat gradient buffer, and dw_reduce_kernel folds the slices in a fixed
+// order (data-parallel replicas must stay bit-identical: no float atomics).  Block b runs on XCD b % 8: the blocks of an XCD
+// share the same row slices, so each XCD's L2 reads its part of dz / h once and serves all tiles from it.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-struct DwLayer { const float* dz; const float* h; int n_out, n_in, tj, tile0; long long out_off; };
-struct DwArgs { DwLayer L[4]; int nlayers, ntiles, nrows, kslices; float* ws; long long ws_stride; };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DW_MAX = 8;
+struct DwLayer { const float* dz; const float* h; int n_out, n_in, tj, tile0, ngroups; long long out_off; };   // ngroups = rows / 8
+struct DwArgs { DwLayer L[DW_MAX]; int nlayers, ntiles, kslices; float* ws; long long ws_stride; };
 
 __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
   const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
@@ -383,52 +388,48 @@ __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
   const int slice = xcd * per_xcd + q / a.ntiles, tile = q % a.ntiles;
   int l = 0;
 #pragma unroll
-  for (int k = 1; k < 4; k++) if (k < a.nlayers && tile >= a.L[k].tile0) l = k;
+  for (int k = 1; k < DW_MAX; k++) if (k < a.nlayers && tile >= a.L[k].tile0) l = k;
   const DwLayer& Ly = a.L[l];
   const int n_out = Ly.n_out, n_in = Ly.n_in;
   const int t = tile - Ly.tile0, i0 = (t / Ly.tj) * 64, j0 = (t % Ly.tj) * 64;
   const int lane = threadIdx.x, r = lane >> 5, c = lane & 31;
-  const int rows = a.nrows / a.kslices;               // even (checked by the host)
-  const size_t k0 = (size_t)slice * rows + r;
+  const int g_lo = (int)((long long)slice * Ly.ngroups / a.kslices), g_hi = (int)((long long)(slice + 1) * Ly.ngroups / a.kslices);
   const bool ma0 = i0 + c < n_out, ma1 = i0 + 32 + c < n_out, mb0 = j0 + c < n_in, mb1 = j0 + 32 + c < n_in;
-  // out-of-range columns read column 0 of the tile row (always valid) and are zeroed by the select: no divergent loads
-  const float* pa0 = Ly.dz + k0 * n_out + (ma0 ? i0 + c : 0);
-  const float* pa1 = Ly.dz + k0 * n_out + (ma1 ? i0 + 32 + c : 0);
-  const float* pb0 = Ly.h + k0 * n_in + (mb0 ? j0 + c : 0);
-  const float* pb1 = Ly.h + k0 * n_in + (mb1 ? j0 + 32 + c : 0);
-  const size_t sa = (size_t)2 * n_out, sb = (size_t)2 * n_in;
+  // Out-of-range columns read column 0 of the tile (always valid) and are NOT zeroed: entry (i, j) depends on column i of dz and
+  // column j of h only, so whatever the clamped loads bring into the padding never reaches a stored element.
+  const f32x4* pa0 = reinterpret_cast<const f32x4*>(Ly.dz) + (size_t)r * n_out + (ma0 ? i0 + c : i0);
+  const f32x4* pa1 = reinterpret_cast<const f32x4*>(Ly.dz) + (size_t)r * n_out + (ma1 ? i0 + 32 + c : i0);
+  const f32x4* pb0 = reinterpret_cast<const f32x4*>(Ly.h) + (size_t)r * n_in + (mb0 ? j0 + c : j0);
+  const f32x4* pb1 = reinterpret_cast<const f32x4*>(Ly.h) + (size_t)r * n_in + (mb1 ? j0 + 32 + c : j0);
+  const size_t sa = (size_t)2 * n_out, sb = (size_t)2 * n_in;   // one row group = two row quads
   f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
   const bool two_i = i0 + 32 < n_out, two_j = j0 + 32 < n_in;   // wave-uniform: skip the empty halves of edge tiles
-  // Out-of-range columns are NOT zeroed: entry (i, j) depends on column i of dz and column j of h only, so whatever the
-  // clamped loads bring into the padding never reaches a stored element -- and a select behind every load would make the
-  // wave wait for the load it just issued.  U k-pairs per batch; the NEXT batch's 4 U loads are in flight under this
-  // batch's MFMAs (two batches per trip: the register arrays swap roles without copies); the host guarantees that the
-  // slice is a whole number of trips.
-  constexpr int U = 4;
-  const int npair = rows >> 1;
-  float fa0[U], fa1[U], fb0[U], fb1[U], ga0[U], ga1[U], gb0[U], gb1[U];
-  auto fetch = [&](int kk, float* xa0, float* xa1, float* xb0, float* xb1) {
+  f32x4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
+  auto fetch = [&](int g, f32x4& xa0, f32x4& xa1, f32x4& xb0, f32x4& xb1) {
+    const size_t o = (size_t)(g < g_hi ? g : g_lo);   // past the slice: re-read its first group (in bounds, unused)
+    xa0 = pa0[o * sa]; xa1 = pa1[o * sa]; xb0 = pb0[o * sb]; xb1 = pb1[o * sb];
+  };
+  auto mma = [&](const f32x4& xa0, const f32x4& xa1, const f32x4& xb0, const f32x4& xb1) {
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const size_t o = (size_t)(kk + u);
-      xa0[u] = pa0[o * sa]; xa1[u] = pa1[o * sa]; xb0[u] = pb0[o * sb]; xb1[u] = pb1[o * sb];
+    for (int j = 0; j < 4; j++) {
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[j], xb0[j], c00, 0, 0, 0);
+      if (two_j) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[j], xb1[j], c01, 0, 0, 0);
+      if (two_i) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[j], xb0[j], c10, 0, 0, 0);
+      if (two_i && two_j) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[j], xb1[j], c11, 0, 0, 0);
     }
   };
-  auto mma = [&](const float* xa0, const float* xa1, const float* xb0, const float* xb1) {
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[u], xb0[u], c00, 0, 0, 0);
-      if (two_j) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[u], xb1[u], c01, 0, 0, 0);
-      if (two_i) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[u], xb0[u], c10, 0, 0, 0);
-      if (two_i && two_j) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[u], xb1[u], c11, 0, 0, 0);
-    }
-  };
-  fetch(0, fa0, fa1, fb0, fb1);
-  for (int kk = 0; kk < npair; kk += 2 * U) {
-    fetch(kk + U, ga0, ga1, gb0, gb1);
+  // the NEXT group's four loads are in flight under this group's 16 MFMAs (two groups per trip: the registers swap roles
+  // without copies); sched_barrier keeps the scheduler from sinking the loads down to their MFMAs
+  fetch(g_lo, fa0, fa1, fb0, fb1);
+  for (int g = g_lo; g < g_hi; g += 2) {
+    fetch(g + 1, ga0, ga1, gb0, gb1);
+    __builtin_amdgcn_sched_barrier(0);
     mma(fa0, fa1, fb0, fb1);
-    fetch(kk + 2 * U < npair ? kk + 2 * U : 0, fa0, fa1, fb0, fb1);   // (the last trip re-reads batch 0: in bounds, unused)
-    mma(ga0, ga1, gb0, gb1);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(g + 2, fa0, fa1, fb0, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < g_hi) mma(ga0, ga1, gb0, gb1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float* w = a.ws + (size_t)slice * a.ws_stride + Ly.out_off;
@@ -447,14 +448,14 @@ __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
 }
 // out[off + e] = sum over the row slices, in slice order, for the weight ranges of the layers (e < count); four consecutive
 // elements per thread (offsets, counts and the slice stride are multiples of 4: checked by the host)
-struct DwRanges { long long off[4], count[4]; int n; };
+struct DwRanges { long long off[DW_MAX], count[DW_MAX]; int n; };
 __global__ void dw_reduce_kernel(const float* __restrict__ ws, long long ws_stride, int kslices, DwRanges rg, float* __restrict__ out) {
   long long total = 0;
   for (int k = 0; k < rg.n; k++) total += rg.count[k];
   for (long long i = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x); i < total; i += 4 * (long long)gridDim.x * blockDim.x) {
     long long e = i, off = rg.off[0];
 #pragma unroll
-    for (int k = 0; k < 3; k++) if (k + 1 < rg.n && e >= rg.count[k]) { e -= rg.count[k]; off = rg.off[k + 1]; } else break;
+    for (int k = 0; k < DW_MAX - 1; k++) if (k + 1 < rg.n && e >= rg.count[k]) { e -= rg.count[k]; off = rg.off[k + 1]; } else break;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int sl = 0; sl < kslices; sl++) {
       const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)sl * ws_stride + off + e);
@@ -578,26 +579,26 @@ extern "C" int odk_gather_rows(const float* const* src_dev, float* const* dst_de
 }
 
 extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int* n_out, const int* n_in, const long long* out_off,
-                           int nlayers, int nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, void* stream) {
-  if (!dz_dev || !h_dev || !n_out || !n_in || !out_off || !ws_dev || !out_dev || nlayers <= 0 || nlayers > 4 || nrows <= 0 || kslices <= 0 ||
-      (kslices & 7) != 0 || nrows % (16 * kslices) != 0 || (ws_stride & 3) != 0 || ((uintptr_t)ws_dev & 15) != 0 || ((uintptr_t)out_dev & 15) != 0)
-    return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad arguments (1..4 layers, kslices a multiple of 8, rows divisible by 16 * kslices, "
-                                      "ws_stride a multiple of 4, 16-byte aligned buffers)");
+                           int nlayers, const int* nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, void* stream) {
+  if (!dz_dev || !h_dev || !n_out || !n_in || !out_off || !ws_dev || !out_dev || nlayers <= 0 || nlayers > DW_MAX || !nrows || kslices <= 0 ||
+      (kslices & 7) != 0 || (ws_stride & 3) != 0 || ((uintptr_t)ws_dev & 15) != 0 || ((uintptr_t)out_dev & 15) != 0)
+    return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad arguments (1..8 layers, kslices a multiple of 8, ws_stride a multiple of 4, 16-byte aligned buffers)");
   DwArgs a;
   DwRanges rg;
-  a.nlayers = nlayers; a.nrows = nrows; a.kslices = kslices; a.ws = ws_dev; a.ws_stride = ws_stride; a.ntiles = 0; rg.n = nlayers;
-  for (int l = 0; l < 4; l++) {
+  a.nlayers = nlayers; a.kslices = kslices; a.ws = ws_dev; a.ws_stride = ws_stride; a.ntiles = 0; rg.n = nlayers;
+  for (int l = 0; l < DW_MAX; l++) {
     DwLayer& L = a.L[l];
     if (l < nlayers) {
-      if (!dz_dev[l] || !h_dev[l] || n_out[l] <= 0 || n_in[l] <= 0 || out_off[l] < 0 || out_off[l] + (long long)n_out[l] * n_in[l] > ws_stride ||
-          (out_off[l] & 3) != 0 || (((long long)n_out[l] * n_in[l]) & 3) != 0)
-        return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad layer (offset and element count must be multiples of 4)");
-      L.dz = dz_dev[l]; L.h = h_dev[l]; L.n_out = n_out[l]; L.n_in = n_in[l]; L.out_off = out_off[l];
+      if (!dz_dev[l] || !h_dev[l] || n_out[l] <= 0 || n_in[l] <= 0 || nrows[l] <= 0 || (nrows[l] & 7) != 0 || nrows[l] / 8 < kslices || out_off[l] < 0 || out_off[l] + (long long)n_out[l] * n_in[l] > ws_stride ||
+          (out_off[l] & 3) != 0 || (((long long)n_out[l] * n_in[l]) & 3) != 0 || ((((uintptr_t)dz_dev[l]) | ((uintptr_t)h_dev[l])) & 15) != 0)
+        return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad layer (rows a multiple of 8 and >= 8 * kslices, offset and element count multiples of 4, "
+                                          "16-byte aligned operands)");
+      L.dz = dz_dev[l]; L.h = h_dev[l]; L.n_out = n_out[l]; L.n_in = n_in[l]; L.out_off = out_off[l]; L.ngroups = nrows[l] / 8;
       L.tj = (n_in[l] + 63) / 64; L.tile0 = a.ntiles;
       a.ntiles += ((n_out[l] + 63) / 64) * L.tj;
       rg.off[l] = out_off[l]; rg.count[l] = (long long)n_out[l] * n_in[l];
     } else {
-      L.dz = L.h = nullptr; L.n_out = L.n_in = L.tj = 0; L.tile0 = 1 << 30; L.out_off = 0; rg.off[l] = 0; rg.count[l] = 0;
+      L.dz = L.h = nullptr; L.n_out = L.n_in = L.tj = L.ngroups = 0; L.tile0 = 1 << 30; L.out_off = 0; rg.off[l] = 0; rg.count[l] = 0;
     }
   }
   hipStream_t st = (hipStream_t)stream;

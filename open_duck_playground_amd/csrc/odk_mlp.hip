@@ -1,0 +1,588 @@
+// odk_mlp.hip -- the policy / value networks of the PPO learner as two launches: every layer of a swish MLP
+// (in -> 512 -> 256 -> 128 -> out, brax ppo.networks as configured by reference common/runner.py:86-118) forward in ONE
+// kernel, and the whole backward-data chain in ONE kernel, on the f32 matrix cores (v_mfma_f32_32x32x2_f32).  gfx950 only.
+//
+// Why: a minibatch is 5 120 samples and the layers are at most 512 wide, so as separate GEMMs every layer is a ~10 us
+// launch that under-fills the chip, with a 5 us element-wise launch (bias + swish, swish' + bias-gradient sums) between two
+// of them: ~25 launches per network and minibatch step, 128 steps per training step.  Here a workgroup owns a tile of 32
+// samples for ALL layers: the tile's activations stay in LDS, the weights stream from the L2 (both networks together are
+// 2 MB: resident in every XCD's 4 MB L2), and the epilogues (bias, swish, swish', the bias gradients' tile sums) run on the
+// accumulator registers.
+//
+// Operands.  A wave-wide load instruction costs the address unit ~16 cycles whatever its width, and a 32x32x2 MFMA takes 64
+// cycles per SIMD: with one 4-byte load per lane and MFMA the four SIMDs of a CU saturate the address unit (the first version
+// of these kernels ran at 25 % of the matrix pipe that way).  So both operands come in 16-byte pieces holding FOUR consecutive
+// reduction indices: lane l (r = l / 32, c = l % 32) of k-group G takes k = 8 G + 4 r + {0, 1, 2, 3},
+//   A = act[sample c][k .. k + 3]   one ds_read_b128 from the tile in LDS (row pitch = 4 mod 8 floats: conflict-free),
+//   B = Wp[k / 4][col0 + c][0 .. 3]  one global_load_dwordx4 from a PACKED copy of the weights, [K / 4][N][4]: the wave reads two
+//                                   contiguous 512-byte runs,
+// and the group's four MFMAs use component j of both (MFMA j: lanes r = 0 / 1 supply k = 8 G + j and 8 G + 4 + j).  The packed
+// copies -- one with the input index as reduction index for the forward pass, one with the output index for the backward
+// pass, zero-padded to a multiple of 8 -- live next to the torch-layout parameters and are kept current by the Adam launch
+// (odk_adam_clip_packed; odk_pack_weights rebuilds them).
+// Accumulator fragment: col = c, row = (v & 3) + 8 (v >> 2) + 4 r for register v.
+//
+// Forward, per workgroup (4 waves): layer 1 is produced in four 128-column chunks (wave w: one 32 x 32 block per chunk) and
+// each chunk is consumed at once as a K-slice of layer 2 (wave w: 64 columns, accumulators live across the chunks), so the
+// 512-wide activation never exists in LDS: X 29 KB + chunk 16.5 KB + layer-2 output 32.5 KB = 78 KB => two workgroups per
+// CU (all 328 tiles of the two networks resident at once).  Layer 3: one block per wave; output layer (<= 32 columns): K
+// split over the four waves, partial blocks folded through LDS.
+// Backward: dz_top (from the loss head) -> dh3 = dz_top W4 -> dz3 = dh3 * swish'(z3) -> ... -> dz1, each dz written once to
+// global memory (the weight-gradient launch reads it) and kept in LDS as the next layer's A operand; per-tile column sums
+// of every dz (the bias gradients' first half, folded by odk_colsum_fold in a fixed order).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/odk.h"
+
+int odk_fail_(int code, const char* msg);   // odk_engine.hip
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H1 = ODK_MLP_H1, H2 = ODK_MLP_H2, H3 = ODK_MLP_H3;
+constexpr int TM = 32;                 // samples per workgroup
+constexpr int CH = 128;                // layer-1 chunk width = K-slice of layer 2
+constexpr int KIN_MAX = ODK_MLP_MAX_IN, NOUT_MAX = 32;
+constexpr int PC = CH + 4, P2 = H2 + 4, P3 = H3 + 4, P4 = NOUT_MAX + 4;   // LDS row pitches: multiples of 4 (16-byte reads), = 4 mod 8
+constexpr int PX_MAX = KIN_MAX + 4;
+constexpr int SLACK = 64;              // the k loops fetch (never use) up to two batches past a row's end
+static_assert(KIN_MAX % 8 == 0, "padded input width");
+// forward LDS (floats): X | chunk | layer-2 output | slack;  the layer-3 output aliases X, the output layer's partial blocks alias the chunk
+constexpr int F_X = 0, F_C = F_X + TM * PX_MAX, F_H2 = F_C + TM * PC, F_TOTAL = F_H2 + TM * P2 + SLACK;
+static_assert(TM * P3 <= TM * PX_MAX, "layer-3 output must fit in the X region");
+static_assert(3 * 16 * 64 <= TM * PC, "output-layer partial blocks must fit in the chunk region");
+static_assert(F_TOTAL * 4 <= 80 * 1024, "two forward workgroups per CU");
+// backward LDS: dz_top | dz3 | dz2 | slack
+constexpr int B_D4 = 0, B_D3 = B_D4 + TM * P4, B_D2 = B_D3 + TM * P3, B_TOTAL = B_D2 + TM * P2 + SLACK;
+
+__host__ __device__ constexpr int pad8(int k) { return (k + 7) & ~7; }
+
+struct Net {
+  const float* x; const float* wf[4]; const float* wb[4]; const float* b[4];
+  float* h[3]; float* g[3]; float* out; float* xp;
+  const float* dout; float* dz[3]; float* doutp; float* bias_partial[4];
+  int n, n_in, n_out, tile0;
+};
+struct Args { Net net[2]; int nnets; long long* prof; };   // prof: phase timestamps of workgroup 0, wave 0 (tools only)
+#define ODK_STAMP(i) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[i] = clock64(); } while (0)
+
+// One GEMM phase of a wave: acc[blk] += A (32 samples x K, LDS) * Bp (packed [K / 4][N][4], columns col0 + 32 blk + c), over ng
+// k-groups of 8.  U groups per batch, register double-buffered: while a batch's MFMAs run (4 U NBLK MFMAs = 1 024 cycles of the
+// matrix pipe in every phase) the next batch's loads are in flight.  The FIRST batch of weights is fetched by prefetch(), which
+// the caller issues before the previous phase's epilogue and barrier (weights do not depend on them), so a phase starts with
+// its operands already on the way; A comes from LDS after the barrier.  __builtin_amdgcn_sched_barrier pins the order: left
+// alone, the scheduler sinks every load down to its MFMA (minimum register pressure = one exposed L2 round trip per MFMA).
+// Groups >= ng are fetched from group 0 (in bounds) and skipped.
+#define ODK_PIN() __builtin_amdgcn_sched_barrier(0)
+template <int NBLK, int U>
+struct Phase {
+  f32x4 fb[U][NBLK];
+  const f32x4* B; unsigned lane_off; int N2, ng;
+  __device__ __forceinline__ void load_b(int G0, f32x4 (*xb)[NBLK]) const {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int G = G0 + u;
+      const f32x4* bp = B + (size_t)(G < ng ? G : 0) * N2;   // wave-uniform base, 32-bit lane offset
+#pragma unroll
+      for (int k = 0; k < NBLK; k++) xb[u][k] = bp[lane_off + 32 * k];
+    }
+  }
+  // Bp: the packed weight, ncols columns; this lane's first column col; ng groups starting at group g0
+  __device__ __forceinline__ void prefetch(const float* __restrict__ Bp, int ncols, int col, int r, int g0, int ng_) {
+    B = reinterpret_cast<const f32x4*>(Bp) + (size_t)(2 * g0) * ncols;
+    lane_off = (unsigned)(r * ncols + col); N2 = 2 * ncols; ng = ng_;
+    load_b(0, fb);
+    ODK_PIN();
+  }
+  // A: LDS address of act[sample c][4 r] (16-byte aligned)
+  __device__ __forceinline__ void run(f32x16 (&acc)[NBLK], const float* A) {
+    f32x4 fa[U], ga[U], gb[U][NBLK];
+    auto load_a = [&](int G0, f32x4* xa) {
+#pragma unroll
+      for (int u = 0; u < U; u++) xa[u] = *reinterpret_cast<const f32x4*>(A + 8 * (G0 + u));   // in bounds of the LDS image (SLACK)
+    };
+    auto mma = [&](int G0, const f32x4* xa, const f32x4 (*xb)[NBLK]) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (G0 + u < ng) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < NBLK; k++) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][j], xb[u][k][j], acc[k], 0, 0, 0);
+        }
+      }
+    };
+    load_a(0, fa);
+    ODK_PIN();
+    for (int G0 = 0; G0 < ng; G0 += 2 * U) {
+      load_b(G0 + U, gb); load_a(G0 + U, ga);
+      ODK_PIN();
+      mma(G0, fa, fb);
+      ODK_PIN();
+      load_b(G0 + 2 * U, fb); load_a(G0 + 2 * U, fa);
+      ODK_PIN();
+      mma(G0 + U, ga, gb);
+      ODK_PIN();
+    }
+  }
+};
+
+__device__ __forceinline__ int frag_row(int v, int r) { return (v & 3) + 8 * (v >> 2) + 4 * r; }
+__device__ __forceinline__ void zero(f32x16& a) {
+#pragma unroll
+  for (int v = 0; v < 16; v++) a[v] = 0.0f;
+}
+
+// bias + swish on one accumulator block: h -> LDS (next layer's A operand, row-major) and, when the buffers exist, h and
+// swish'(z) -> global memory in the quad-row layout [rows / 4][width][4] (the four rows a lane holds per register quad are one
+// 16-byte store; rows past the end of the batch are written as zeros, so the weight-gradient launch may read whole tiles).
+// hq / gq: this lane's column in the tile's first row quad.
+__device__ __forceinline__ void fwd_epilogue(const f32x16& acc, float bias, float* Ls, int P, float* hq, float* gq, int width, int r, int rows_valid) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    f32x4 hv, gv;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int v = 4 * q + t, row = frag_row(v, r);
+      const float z = acc[v] + bias;
+      const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+      const float h = z * sg;
+      Ls[row * P] = h;
+      const bool live = row < rows_valid;
+      hv[t] = live ? h : 0.0f;
+      gv[t] = live ? sg + (h - h * sg) : 0.0f;   // swish'(z) = s + z s (1 - s)
+    }
+    if (hq) {
+      const size_t o = (size_t)(2 * q + r) * width * 4;
+      *reinterpret_cast<f32x4*>(hq + o) = hv;
+      *reinterpret_cast<f32x4*>(gq + o) = gv;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int bid = blockIdx.x;
+  const Net& N = a.net[(a.nnets > 1 && bid >= a.net[1].tile0) ? 1 : 0];
+  const int m0 = (bid - N.tile0) * TM;
+  const int rows_valid = N.n - m0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane >> 5, c = lane & 31;
+  const int kin = N.n_in, k8 = pad8(kin), PX = k8 + 4;
+  float* X = lds + F_X; float* C1 = lds + F_C; float* H2s = lds + F_H2; float* H3s = lds + F_X;
+  Phase<1, 4> p1;     // layer 1 (one 32-column block of the current chunk), layer 3, output layer
+  Phase<2, 2> p2;     // layer 2, K-slice = the chunk, 64 columns
+  ODK_STAMP(0);
+  p1.prefetch(N.wf[0], H1, w * 32 + c, r, 0, k8 >> 3);
+  const int nout = N.n_out, colc = c < nout ? c : nout - 1;
+  // this lane's biases: fetched now, used by the epilogues (a load there is an exposed round trip per block)
+  float bias1[H1 / CH], bias2[2];
+#pragma unroll
+  for (int ch = 0; ch < H1 / CH; ch++) bias1[ch] = N.b[0][ch * CH + w * 32 + c];
+#pragma unroll
+  for (int k = 0; k < 2; k++) bias2[k] = N.b[1][w * 64 + 32 * k + c];
+  const float bias3 = N.b[2][w * 32 + c], bias4 = N.b[3][colc];
+  // ---- the tile's input rows, zero-padded to a multiple of 8 columns (rows past the end repeat the last one): all loads
+  // first, then the LDS stores (one exposed round trip instead of one per row)
+  {
+    constexpr int T = (KIN_MAX + 63) / 64;
+    float xv[TM / 4][T];
+#pragma unroll
+    for (int i = 0; i < TM / 4; i++) {
+      const int rr = w + 4 * i, row = m0 + rr < N.n ? m0 + rr : N.n - 1;
+      const float* src = N.x + (size_t)row * kin;
+#pragma unroll
+      for (int t = 0; t < T; t++) { const int k = lane + 64 * t; xv[i][t] = src[k < kin ? k : 0]; }
+    }
+    ODK_PIN();
+#pragma unroll
+    for (int i = 0; i < TM / 4; i++)
+#pragma unroll
+      for (int t = 0; t < T; t++) { const int k = lane + 64 * t; if (k < k8) X[(w + 4 * i) * PX + k] = k < kin ? xv[i][t] : 0.0f; }
+  }
+  __syncthreads();
+  ODK_STAMP(1);
+  const bool store = N.h[0] != nullptr;
+  const size_t q0 = (size_t)(m0 >> 2);   // the tile's first row quad
+  if (store) {   // quad-row copy of the input (the weight-gradient launch's operand)
+    for (int k = threadIdx.x; k < kin; k += 256)
+#pragma unroll
+      for (int q = 0; q < TM / 4; q++) {
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[t] = X[(4 * q + t) * PX + k];
+        *reinterpret_cast<f32x4*>(N.xp + ((q0 + q) * kin + k) * 4) = v;
+      }
+  }
+  f32x16 acc2[2];
+  zero(acc2[0]); zero(acc2[1]);
+#pragma unroll
+  for (int ch = 0; ch < H1 / CH; ch++) {
+    f32x16 acc1[1];
+    zero(acc1[0]);
+    const int col = ch * CH + w * 32 + c;
+    p1.run(acc1, X + c * PX + 4 * r);
+    ODK_STAMP(2 + 5 * ch);
+    p2.prefetch(N.wf[1], H2, w * 64 + c, r, ch * (CH / 8), CH / 8);
+    fwd_epilogue(acc1[0], bias1[ch], C1 + w * 32 + c, PC, store ? N.h[0] + (q0 * H1 + col) * 4 : nullptr,
+                 store ? N.g[0] + (q0 * H1 + col) * 4 : nullptr, H1, r, rows_valid);
+    ODK_STAMP(3 + 5 * ch);
+    __syncthreads();
+    ODK_STAMP(4 + 5 * ch);
+    p2.run(acc2, C1 + c * PC + 4 * r);
+    ODK_STAMP(5 + 5 * ch);
+    if (ch + 1 < H1 / CH) p1.prefetch(N.wf[0], H1, col + CH, r, 0, k8 >> 3);
+    else p1.prefetch(N.wf[2], H3, w * 32 + c, r, 0, H2 / 8);
+    __syncthreads();
+    ODK_STAMP(6 + 5 * ch);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int col = w * 64 + 32 * k + c;
+    fwd_epilogue(acc2[k], bias2[k], H2s + col, P2, store ? N.h[1] + (q0 * H2 + col) * 4 : nullptr,
+                 store ? N.g[1] + (q0 * H2 + col) * 4 : nullptr, H2, r, rows_valid);
+  }
+  ODK_STAMP(22);
+  __syncthreads();
+  ODK_STAMP(23);
+  {  // layer 3, columns w * 32 .. + 31
+    f32x16 acc3[1];
+    zero(acc3[0]);
+    const int col = w * 32 + c;
+    p1.run(acc3, H2s + c * P2 + 4 * r);
+    ODK_STAMP(24);
+    // output layer (<= 32 columns): wave w reduces k in [32 w, 32 w + 32)
+    p1.prefetch(N.wf[3], nout, colc, r, w * (H3 / 32), H3 / 32);
+    fwd_epilogue(acc3[0], bias3, H3s + col, P3, store ? N.h[2] + (q0 * H3 + col) * 4 : nullptr,
+                 store ? N.g[2] + (q0 * H3 + col) * 4 : nullptr, H3, r, rows_valid);   // X is dead: every wave passed two barriers since its last read
+  }
+  ODK_STAMP(25);
+  __syncthreads();
+  ODK_STAMP(26);
+  {  // partial blocks of the output layer folded by wave 0
+    f32x16 acc4[1];
+    zero(acc4[0]);
+    p1.run(acc4, H3s + c * P3 + 32 * w + 4 * r);
+    ODK_STAMP(27);
+    float* R = C1;
+    if (w > 0) {
+#pragma unroll
+      for (int v = 0; v < 16; v++) R[((w - 1) * 16 + v) * 64 + lane] = acc4[0][v];
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const int row = frag_row(v, r);
+        const float z = ((acc4[0][v] + R[v * 64 + lane]) + (R[(16 + v) * 64 + lane] + R[(32 + v) * 64 + lane])) + bias4;
+        if (c < nout && row < rows_valid) N.out[(size_t)(m0 + row) * nout + c] = z;
+      }
+    }
+  }
+  ODK_STAMP(28);
+}
+
+// dz = dh * swish'(z) on NBLK accumulator blocks (columns col0 + 32 k): -> global in the quad-row layout (the weight-gradient
+// launch reads it), -> LDS (next layer's A operand, row-major; may be null), and each block's column sums over the tile's 32
+// rows -> partial[col].  swish' is zero in the rows past the end of the batch (the forward pass wrote it so), hence so is dz.
+// gq / dzq: this lane's first column in the tile's first row quad.  All swish' loads are issued before the first use.
+template <int NBLK>
+__device__ __forceinline__ void bwd_epilogue(const f32x16 (&acc)[NBLK], const float* __restrict__ gq, float* dzq, int width, float* Ls, int P, float* partial, int r) {
+  f32x4 gv[NBLK][4];
+#pragma unroll
+  for (int k = 0; k < NBLK; k++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) gv[k][q] = *reinterpret_cast<const f32x4*>(gq + ((size_t)(2 * q + r) * width + 32 * k) * 4);
+  ODK_PIN();
+#pragma unroll
+  for (int k = 0; k < NBLK; k++) {
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      f32x4 dv;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int v = 4 * q + t;
+        const float dz = acc[k][v] * gv[k][q][t];
+        dv[t] = dz;
+        if (Ls) Ls[frag_row(v, r) * P + 32 * k] = dz;
+        s += dz;
+      }
+      *reinterpret_cast<f32x4*>(dzq + ((size_t)(2 * q + r) * width + 32 * k) * 4) = dv;
+    }
+    s += __shfl_xor(s, 32);
+    if (r == 0) partial[32 * k] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) mlp_bwd_kernel(Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int bid = blockIdx.x;
+  const Net& N = a.net[(a.nnets > 1 && bid >= a.net[1].tile0) ? 1 : 0];
+  const int tile = bid - N.tile0, m0 = tile * TM;
+  const int rows_valid = N.n - m0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane >> 5, c = lane & 31;
+  const int nout = N.n_out;
+  float* D4 = lds + B_D4; float* D3 = lds + B_D3; float* D2 = lds + B_D2;
+  Phase<1, 4> p3;     // dh3 = dout W4: columns w * 32 .. + 31, K = n_out
+  Phase<2, 2> p2;     // dh2 = dz3 W3: columns w * 64 .. + 63, K = 128
+  Phase<4, 1> p1;     // dh1 = dz2 W2: columns w * 128 .. + 127, K = 256
+  p3.prefetch(N.wb[3], H3, w * 32 + c, r, 0, pad8(nout) >> 3);
+  // ---- the tile of dLoss/dout, zero beyond the tile's rows / the layer's columns
+  for (int e = threadIdx.x; e < TM * NOUT_MAX; e += 256) {
+    const int rr = e >> 5, k = e & 31;
+    D4[rr * P4 + k] = (rr < rows_valid && k < nout) ? N.dout[(size_t)(m0 + rr) * nout + k] : 0.0f;
+  }
+  __syncthreads();
+  const size_t q0 = (size_t)(m0 >> 2);   // the tile's first row quad
+  if (threadIdx.x < nout) {   // output layer's bias gradient: tile sums of dout
+    float s = 0.0f;
+    for (int rr = 0; rr < TM; rr++) s += D4[rr * P4 + threadIdx.x];
+    N.bias_partial[3][(size_t)tile * nout + threadIdx.x] = s;
+  }
+  for (int e = threadIdx.x; e < (TM / 4) * nout; e += 256) {   // quad-row copy of dout (the weight-gradient launch's operand)
+    const int q = e / nout, k = e - q * nout;
+    f32x4 v;
+#pragma unroll
+    for (int t = 0; t < 4; t++) v[t] = D4[(4 * q + t) * P4 + k];
+    *reinterpret_cast<f32x4*>(N.doutp + ((q0 + q) * nout + k) * 4) = v;
+  }
+  {
+    f32x16 acc[1];
+    zero(acc[0]);
+    const int col = w * 32 + c;
+    p3.run(acc, D4 + c * P4 + 4 * r);
+    p2.prefetch(N.wb[2], H2, w * 64 + c, r, 0, H3 / 8);
+    bwd_epilogue<1>(acc, N.g[2] + (q0 * H3 + col) * 4, N.dz[2] + (q0 * H3 + col) * 4, H3, D3 + col, P3, N.bias_partial[2] + (size_t)tile * H3 + col, r);
+  }
+  __syncthreads();
+  {
+    f32x16 acc[2];
+    zero(acc[0]); zero(acc[1]);
+    const int col = w * 64 + c;
+    p2.run(acc, D3 + c * P3 + 4 * r);
+    p1.prefetch(N.wb[1], H1, w * 128 + c, r, 0, H2 / 8);
+    bwd_epilogue<2>(acc, N.g[1] + (q0 * H2 + col) * 4, N.dz[1] + (q0 * H2 + col) * 4, H2, D2 + col, P2, N.bias_partial[1] + (size_t)tile * H2 + col, r);
+  }
+  __syncthreads();
+  {
+    f32x16 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) zero(acc[k]);
+    const int col = w * 128 + c;
+    p1.run(acc, D2 + c * P2 + 4 * r);
+    bwd_epilogue<4>(acc, N.g[0] + (q0 * H1 + col) * 4, N.dz[0] + (q0 * H1 + col) * 4, H1, nullptr, 0, N.bias_partial[0] + (size_t)tile * H1 + col, r);
+  }
+}
+
+// ---- parameters -> packed weight copies.  Weight k: params[off .. off + rows * cols), torch layout [rows = n_out][cols = n_in];
+// forward copy at fwd_off: [pad8(cols) / 4][rows][4] (reduction over the input index), backward copy at bwd_off (< 0: none):
+// [pad8(rows) / 4][cols][4] (reduction over the output index).  Padding elements are never written: the caller zeroes the
+// buffers once.
+struct WeightTable { long long off[8], fwd[8], bwd[8]; int rows[8], cols[8]; int n; };
+
+__device__ __forceinline__ void packed_store(const WeightTable& t, long long i, float v, float* __restrict__ pf, float* __restrict__ pb) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k < t.n) {
+      const long long e = i - t.off[k];
+      if (e >= 0 && e < (long long)t.rows[k] * t.cols[k]) {
+        const int o = (int)(e / t.cols[k]), in = (int)(e - (long long)o * t.cols[k]);
+        pf[t.fwd[k] + ((long long)(in >> 2) * t.rows[k] + o) * 4 + (in & 3)] = v;
+        if (t.bwd[k] >= 0) pb[t.bwd[k] + ((long long)(o >> 2) * t.cols[k] + in) * 4 + (o & 3)] = v;
+        return;
+      }
+    }
+  }
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ p, float* __restrict__ pf, float* __restrict__ pb, long long n, WeightTable t) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) packed_store(t, i, p[i], pf, pb);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int i = 0; i < nw; i++) t += sh[i];
+  return t;
+}
+// adam_kernel of odk_learner.hip (same arithmetic, same fixed-order norm fold) that also writes every updated weight to its
+// places in the packed copies
+__global__ void adam_packed_kernel(float* __restrict__ p, float* __restrict__ pf, float* __restrict__ pb, const float* __restrict__ g, float* __restrict__ m,
+                                   float* __restrict__ v, float* __restrict__ acc, int nblocks, int64_t n, float lr, float b1, float b2, float eps,
+                                   float max_norm, WeightTable t) {
+  __shared__ float sh[16];
+  float sq = 0.0f;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) sq += acc[2 + i];
+  sq = block_sum(sq, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) acc[0] = sq;
+  const float norm = sqrtf(sq), tt = acc[1];
+  const float clip = (max_norm > 0.0f && !(norm < max_norm)) ? max_norm / norm : 1.0f;
+  const float c1 = 1.0f / (1.0f - powf(b1, tt)), c2 = 1.0f / (1.0f - powf(b2, tt));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * clip;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float pi = p[i] - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
+    p[i] = pi;
+    packed_store(t, i, pi, pf, pb);
+  }
+}
+__global__ void sqnorm_p_kernel(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
+  __shared__ float sh[16];
+  float s = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { const float v = g[i]; s += v * v; }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) { acc[2 + blockIdx.x] = s; if (blockIdx.x == 0) acc[1] += 1.0f; }
+}
+
+// colsum[f][c] = sum over nblk[f] tile rows of partial[f][tile, c], up to 8 layers in one launch, fixed order
+struct FoldArgs { const float* partial[8]; float* out[8]; int w[8], nblk[8]; };
+__global__ void __launch_bounds__(1024) colsum_fold_kernel(FoldArgs a) {   // 64 columns x 16 row phases per workgroup
+  __shared__ float sh[16][64];
+  const int f = blockIdx.y, w = a.w[f], nblk = a.nblk[f];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  if (blockIdx.x * 64 >= w) return;
+  const float* partial = a.partial[f];
+  float s = 0.0f;
+  if (c < w)
+    for (int b = ty; b < nblk; b += 16) s += partial[(size_t)b * w + c];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < w) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += sh[k][tx];
+    a.out[f][c] = t;
+  }
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return odk_fail_(ODK_ERR_HIP, what);
+  return ODK_OK;
+}
+
+long long* g_prof = nullptr;
+
+int fill_args(Args& a, const odk_mlp_desc* nets, int count, bool backward, int& tiles, const char*& err) {
+  a.nnets = count; tiles = 0; a.prof = backward ? nullptr : g_prof;
+  for (int k = 0; k < 2; k++) {
+    Net& N = a.net[k];
+    if (k >= count) { N = a.net[0]; N.tile0 = 1 << 30; continue; }
+    const odk_mlp_desc& d = nets[k];
+    if (d.n <= 0 || d.n_in <= 0 || d.n_in > KIN_MAX || d.n_out <= 0 || d.n_out > NOUT_MAX) { err = "n_in must be 1..ODK_MLP_MAX_IN, n_out 1..32, n > 0"; return 1; }
+    for (int l = 0; l < 4; l++) {
+      const float* wp = backward ? d.wb[l] : d.wf[l];
+      if ((!backward && (!d.b[l] || !wp)) || (backward && l > 0 && !wp)) { err = "missing packed weights / biases"; return 1; }
+      if (((uintptr_t)wp & 15) != 0) { err = "packed weights must be 16-byte aligned"; return 1; }
+    }
+    const bool has_act = d.h[0] && d.h[1] && d.h[2] && d.g[0] && d.g[1] && d.g[2] && d.xp;
+    if (!backward) {
+      if (!d.x || !d.out) { err = "missing x / out"; return 1; }
+      if (!has_act && (d.h[0] || d.h[1] || d.h[2] || d.g[0] || d.g[1] || d.g[2] || d.xp)) { err = "xp / h / g buffers: all seven or none"; return 1; }
+    } else {
+      if (!d.dout || !d.doutp || !d.g[0] || !d.g[1] || !d.g[2] || !d.dz[0] || !d.dz[1] || !d.dz[2] || !d.bias_partial[0] || !d.bias_partial[1] ||
+          !d.bias_partial[2] || !d.bias_partial[3]) { err = "backward needs dout, doutp, g, dz and bias_partial"; return 1; }
+    }
+    N.x = d.x; N.out = d.out; N.dout = d.dout; N.xp = d.xp; N.doutp = d.doutp; N.n = d.n; N.n_in = d.n_in; N.n_out = d.n_out; N.tile0 = tiles;
+    for (int l = 0; l < 4; l++) { N.wf[l] = d.wf[l]; N.wb[l] = d.wb[l]; N.b[l] = d.b[l]; N.bias_partial[l] = d.bias_partial[l]; }
+    for (int l = 0; l < 3; l++) { N.h[l] = has_act ? d.h[l] : nullptr; N.g[l] = d.g[l]; N.dz[l] = d.dz[l]; }
+    if (!backward && !has_act) for (int l = 0; l < 3; l++) N.g[l] = nullptr;
+    tiles += (d.n + TM - 1) / TM;
+  }
+  return 0;
+}
+
+int fill_table(WeightTable& t, const odk_weight_table* h, long long n, long long nf, long long nb) {
+  if (!h || h->count < 0 || h->count > 8) return 1;
+  t.n = h->count;
+  for (int k = 0; k < 8; k++) {
+    const bool on = k < h->count;
+    t.off[k] = on ? h->off[k] : 0; t.fwd[k] = on ? h->fwd_off[k] : 0; t.bwd[k] = on ? h->bwd_off[k] : -1;
+    t.rows[k] = on ? h->rows[k] : 0; t.cols[k] = on ? h->cols[k] : 1;
+    if (!on) continue;
+    const long long rc = (long long)t.rows[k] * t.cols[k];
+    if (t.off[k] < 0 || t.rows[k] <= 0 || t.cols[k] <= 0 || t.off[k] + rc > n) return 1;
+    if (t.fwd[k] < 0 || (t.fwd[k] & 3) || t.fwd[k] + (long long)pad8(t.cols[k]) * t.rows[k] > nf) return 1;
+    if (t.bwd[k] >= 0 && ((t.bwd[k] & 3) || t.bwd[k] + (long long)pad8(t.rows[k]) * t.cols[k] > nb)) return 1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// tools: device buffer of 32 int64 that receives the forward kernel's phase timestamps (workgroup 0); NULL switches it off
+extern "C" void odk_mlp_set_profile(long long* stamps_dev) { g_prof = stamps_dev; }
+
+extern "C" int odk_mlp_forward(const odk_mlp_desc* nets, int count, void* stream) {
+  if (!nets || count < 1 || count > 2) return odk_fail_(ODK_ERR_INVALID, "odk_mlp_forward: 1 or 2 networks");
+  Args a; int tiles; const char* err = nullptr;
+  if (fill_args(a, nets, count, false, tiles, err)) return odk_fail_(ODK_ERR_INVALID, err);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_TOTAL * 4); attr = true; }
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(tiles), dim3(256), F_TOTAL * 4, (hipStream_t)stream, a);
+  return check_launch("odk_mlp_forward: launch failed");
+}
+
+extern "C" int odk_mlp_backward(const odk_mlp_desc* nets, int count, void* stream) {
+  if (!nets || count < 1 || count > 2) return odk_fail_(ODK_ERR_INVALID, "odk_mlp_backward: 1 or 2 networks");
+  Args a; int tiles; const char* err = nullptr;
+  if (fill_args(a, nets, count, true, tiles, err)) return odk_fail_(ODK_ERR_INVALID, err);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B_TOTAL * 4); attr = true; }
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(tiles), dim3(256), B_TOTAL * 4, (hipStream_t)stream, a);
+  return check_launch("odk_mlp_backward: launch failed");
+}
+
+extern "C" int odk_pack_weights(const float* params_dev, long long n, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
+                                const odk_weight_table* table, void* stream) {
+  WeightTable t;
+  if (!params_dev || !fwd_packed_dev || !bwd_packed_dev || n <= 0 || fill_table(t, table, n, n_fwd, n_bwd))
+    return odk_fail_(ODK_ERR_INVALID, "odk_pack_weights: bad arguments (at most 8 weights inside the buffers, packed offsets multiples of 4)");
+  int blocks = (int)((n + 1023) / 1024);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params_dev, fwd_packed_dev, bwd_packed_dev, n, t);
+  return check_launch("odk_pack_weights: launch failed");
+}
+
+extern "C" int odk_adam_clip_packed(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
+                                    float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
+                                    const odk_weight_table* table, void* stream) {
+  WeightTable t;
+  if (!params_dev || !fwd_packed_dev || !bwd_packed_dev || !grads_dev || !m_dev || !v_dev || !acc_dev || n <= 0 || fill_table(t, table, n, n_fwd, n_bwd))
+    return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip_packed: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int threads = 256;
+  int blocks = (int)((n + threads * 4 - 1) / (threads * 4));
+  if (blocks > ODK_ADAM_MAX_PARTIALS) blocks = ODK_ADAM_MAX_PARTIALS;
+  hipLaunchKernelGGL(sqnorm_p_kernel, dim3(blocks), dim3(threads), 0, st, grads_dev, acc_dev, (int64_t)n);
+  hipLaunchKernelGGL(adam_packed_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, fwd_packed_dev, bwd_packed_dev, grads_dev, m_dev, v_dev, acc_dev, blocks,
+                     (int64_t)n, lr, b1, b2, eps, max_grad_norm, t);
+  return check_launch("odk_adam_clip_packed: launch failed");
+}
+
+extern "C" int odk_colsum_fold(const float* const* partial_dev, float* const* colsum_dev, const int* widths, const int* nblk, int count, void* stream) {
+  if (!partial_dev || !colsum_dev || !widths || !nblk || count <= 0 || count > 8) return odk_fail_(ODK_ERR_INVALID, "odk_colsum_fold: bad arguments");
+  FoldArgs a;
+  int wmax = 0;
+  for (int f = 0; f < 8; f++) {
+    a.partial[f] = f < count ? partial_dev[f] : nullptr; a.out[f] = f < count ? colsum_dev[f] : nullptr; a.w[f] = f < count ? widths[f] : 0; a.nblk[f] = f < count ? nblk[f] : 0;
+    if (f < count && (!partial_dev[f] || !colsum_dev[f] || widths[f] <= 0 || nblk[f] <= 0)) return odk_fail_(ODK_ERR_INVALID, "odk_colsum_fold: bad layer arguments");
+    if (a.w[f] > wmax) wmax = a.w[f];
+  }
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((wmax + 63) / 64, count), dim3(1024), 0, (hipStream_t)stream, a);
+  return check_launch("odk_colsum_fold: launch failed");
+}

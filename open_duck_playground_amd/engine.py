@@ -46,13 +46,30 @@ class Outputs(C.Structure):
                 ("truncation_dev", C.c_void_p), ("metrics_dev", C.c_void_p)]
 
 
+class MlpDesc(C.Structure):
+    """odk_mlp_desc (include/odk.h)."""
+    _fields_ = [("x", C.c_void_p), ("wf", C.c_void_p * 4), ("wb", C.c_void_p * 4), ("b", C.c_void_p * 4), ("xp", C.c_void_p), ("h", C.c_void_p * 3),
+                ("g", C.c_void_p * 3), ("out", C.c_void_p), ("dout", C.c_void_p), ("doutp", C.c_void_p), ("dz", C.c_void_p * 3),
+                ("bias_partial", C.c_void_p * 4), ("n", C.c_int), ("n_in", C.c_int), ("n_out", C.c_int)]
+
+
+class WeightTableC(C.Structure):
+    """odk_weight_table (include/odk.h)."""
+    _fields_ = [("count", C.c_int), ("off", C.c_longlong * 8), ("rows", C.c_int * 8), ("cols", C.c_int * 8), ("fwd_off", C.c_longlong * 8),
+                ("bwd_off", C.c_longlong * 8)]
+
+
+MLP_HIDDEN = (512, 256, 128)     # ODK_MLP_H1..3: the hidden widths the fused network kernels are built for
+MLP_MAX_IN, MLP_MAX_OUT, MLP_TILE = 224, 32, 32
+
+
 class OdkError(RuntimeError):
     pass
 
 
 def build_library(force: bool = False) -> str:
     """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("odk_engine.hip", "odk_learner.hip", "odk_kernels.h", "odk_model.h", "Makefile")]
+    srcs = [os.path.join(_CSRC, f) for f in ("odk_engine.hip", "odk_learner.hip", "odk_mlp.hip", "odk_kernels.h", "odk_model.h", "Makefile")]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "odk.h"))
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -106,7 +123,15 @@ def load_library() -> C.CDLL:
     L.odk_silu_bwd_colsum.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
     L.odk_colsum_partial.argtypes = [P, P, C.c_int, C.c_int, P]
     L.odk_colsum_finalize.argtypes = [PP, PP, C.POINTER(C.c_int), C.c_int, C.c_int, P]
-    L.odk_dw_gemm.argtypes = [PP, PP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, C.c_int, C.c_int, P, C.c_longlong, P, P]
+    L.odk_dw_gemm.argtypes = [PP, PP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int), C.c_int, P, C.c_longlong, P, P]
+    IP, LP = C.POINTER(C.c_int), C.POINTER(C.c_longlong)
+    L.odk_mlp_forward.argtypes = [C.POINTER(MlpDesc), C.c_int, P]
+    L.odk_mlp_backward.argtypes = [C.POINTER(MlpDesc), C.c_int, P]
+    L.odk_mlp_set_profile.argtypes = [P]
+    L.odk_mlp_set_profile.restype = None
+    L.odk_pack_weights.argtypes = [P, C.c_longlong, P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), P]
+    L.odk_adam_clip_packed.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), P]
+    L.odk_colsum_fold.argtypes = [PP, PP, IP, IP, C.c_int, P]
     L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, P, C.c_int, C.c_longlong, P]
     _lib = L
     return L
@@ -118,7 +143,8 @@ EXPORTED_SYMBOLS = (
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
-    "odk_policy_sample", "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows", "odk_dw_gemm")
+    "odk_policy_sample", "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows", "odk_dw_gemm",
+    "odk_mlp_forward", "odk_mlp_backward", "odk_mlp_set_profile", "odk_pack_weights", "odk_adam_clip_packed", "odk_colsum_fold")
 
 
 def _chk(rc: int):
@@ -265,31 +291,56 @@ class ColsumFinalize:
         _chk(load_library().odk_colsum_finalize(self.partial, self.out, self.w, self.k, self.n, _stream(self.keep[0][0])))
 
 
+def quad_rows(n: int) -> int:
+    """Rows of a quad-row buffer for n samples: n rounded up to whole 32-sample tiles."""
+    return (int(n) + MLP_TILE - 1) // MLP_TILE * MLP_TILE
+
+
+def quad_pack(t):
+    """[n, width] -> the quad-row layout [np / 4][width][4] the fused network / weight-gradient kernels use (flat tensor, rows
+    past n zero).  Plain torch ops: tests and tools."""
+    import torch
+    n, w = t.shape
+    full = torch.zeros(quad_rows(n), w, device=t.device, dtype=t.dtype)
+    full[:n] = t
+    return full.view(-1, 4, w).permute(0, 2, 1).contiguous().reshape(-1)
+
+
+def quad_unpack(buf, n: int, width: int):
+    """Inverse of `quad_pack`: the first n rows as [n, width]."""
+    return buf.view(-1, width, 4).permute(0, 2, 1).reshape(-1, width)[:n]
+
+
 class DwGemm:
-    """Weight gradients out[off_l : off_l + n_out n_in] = dz_l^T h_l of up to 4 layers in one launch (`odk_dw_gemm`, f32
-    matrix cores, split over `kslices` row slices folded in a fixed order).  `layers`: [(dz [n, n_out], h [n, n_in], offset in
-    `flat_out`)]; `workspace`: kslices * flat_out.numel() floats (shared by several DwGemm objects with disjoint offsets)."""
+    """Weight gradients out[off_l : off_l + n_out n_in] = dz_l^T h_l of up to 8 layers in one launch (`odk_dw_gemm`, f32
+    matrix cores, split over `kslices` row slices folded in a fixed order).  `layers`: [(dz, h, n_out, n_in, offset in
+    `flat_out`)] with dz / h flat QUAD-ROW buffers ([np / 4][width][4], `quad_pack`; np a multiple of 8, >= 8 * kslices);
+    `workspace`: kslices * workspace_stride(flat_out.numel()) floats."""
 
     def __init__(self, layers, flat_out, workspace, kslices: int = 16):
         k = len(layers)
-        n = int(layers[0][0].shape[0])
-        _f32c(flat_out, workspace, *[t for dz, h, _ in layers for t in (dz, h)])
-        if any(int(dz.shape[0]) != n or int(h.shape[0]) != n for dz, h, _ in layers):
-            raise OdkError("DwGemm: every dz / h needs the same row count")
-        if n % (16 * kslices) != 0 or kslices % 8 != 0:
-            raise OdkError("DwGemm: rows must be divisible by 16 * kslices, kslices by 8")
+        _f32c(flat_out, workspace, *[t for dz, h, _, _, _ in layers for t in (dz, h)])
+        if k > 8 or kslices % 8 != 0:
+            raise OdkError("DwGemm: at most 8 layers, kslices a multiple of 8")
+        rows = []
+        for dz, h, no, ni, o in layers:
+            np_ = dz.numel() // int(no)
+            if dz.numel() != np_ * no or h.numel() != np_ * ni or np_ % 8 or np_ // 8 < kslices:
+                raise OdkError("DwGemm: dz / h must be quad-row buffers of the same row count (a multiple of 8, >= 8 * kslices)")
+            if int(o) % 4 or (int(no) * int(ni)) % 4:
+                raise OdkError("DwGemm: offsets and element counts must be multiples of 4")
+            rows.append(np_)
         stride = self.workspace_stride(flat_out.numel())
         if workspace.numel() < kslices * stride:
             raise OdkError("DwGemm: workspace too small (kslices * workspace_stride(flat_out.numel()) floats)")
-        if any(int(o) % 4 or (int(dz.shape[1]) * int(h.shape[1])) % 4 for dz, h, o in layers):
-            raise OdkError("DwGemm: offsets and element counts must be multiples of 4")
         self.keep = (layers, flat_out, workspace)
-        self.k, self.n, self.kslices, self.stride = k, n, int(kslices), stride
-        self.dz = (C.c_void_p * k)(*[dz.data_ptr() for dz, _, _ in layers])
-        self.h = (C.c_void_p * k)(*[h.data_ptr() for _, h, _ in layers])
-        self.n_out = (C.c_int * k)(*[int(dz.shape[1]) for dz, _, _ in layers])
-        self.n_in = (C.c_int * k)(*[int(h.shape[1]) for _, h, _ in layers])
-        self.off = (C.c_longlong * k)(*[int(o) for _, _, o in layers])
+        self.k, self.kslices, self.stride = k, int(kslices), stride
+        self.n = (C.c_int * k)(*rows)
+        self.dz = (C.c_void_p * k)(*[l[0].data_ptr() for l in layers])
+        self.h = (C.c_void_p * k)(*[l[1].data_ptr() for l in layers])
+        self.n_out = (C.c_int * k)(*[int(l[2]) for l in layers])
+        self.n_in = (C.c_int * k)(*[int(l[3]) for l in layers])
+        self.off = (C.c_longlong * k)(*[int(l[4]) for l in layers])
 
     @staticmethod
     def workspace_stride(numel: int) -> int:
@@ -299,6 +350,154 @@ class DwGemm:
         _, flat_out, ws = self.keep
         _chk(load_library().odk_dw_gemm(self.dz, self.h, self.n_out, self.n_in, self.off, self.k, self.n, self.kslices, _ptr(ws), self.stride,
                                         _ptr(flat_out), _stream(flat_out)))
+
+
+def _pad8(k: int) -> int:
+    return (int(k) + 7) // 8 * 8
+
+
+class WeightTable:
+    """Where the weight matrices sit inside a flat parameter buffer -- [(float offset, rows = n_out, cols = n_in, backward copy?)],
+    at most 8 -- and inside the two packed buffers the fused network kernels read (layouts: include/odk.h, odk_mlp_desc).
+    `fwd_size` / `bwd_size`: floats to allocate (zero-initialised) for the packed buffers."""
+
+    def __init__(self, entries):
+        if len(entries) > 8:
+            raise OdkError("WeightTable: at most 8 weights")
+        self.entries = [(int(o), int(r), int(c), bool(bw)) for o, r, c, bw in entries]
+        t = WeightTableC()
+        t.count = len(entries)
+        fo = bo = 0
+        self.fwd, self.bwd = [], []
+        for k, (o, r, c, bw) in enumerate(self.entries):
+            t.off[k], t.rows[k], t.cols[k] = o, r, c
+            t.fwd_off[k] = fo; self.fwd.append((fo, _pad8(c) * r)); fo += _pad8(c) * r
+            if bw:
+                t.bwd_off[k] = bo; self.bwd.append((bo, _pad8(r) * c)); bo += _pad8(r) * c
+            else:
+                t.bwd_off[k] = -1; self.bwd.append(None)
+        self.c, self.fwd_size, self.bwd_size = t, fo, max(bo, 4)
+
+    def fwd_view(self, buf, k):
+        o, n = self.fwd[k]
+        return buf[o:o + n]
+
+    def bwd_view(self, buf, k):
+        if self.bwd[k] is None:
+            return None
+        o, n = self.bwd[k]
+        return buf[o:o + n]
+
+
+def pack_weights(params, fwd_packed, bwd_packed, table: WeightTable):
+    """(Re)builds the packed weight copies from the flat parameter buffer (`odk_pack_weights`); padding is left untouched."""
+    _f32c(params, fwd_packed, bwd_packed)
+    if fwd_packed.numel() < table.fwd_size or bwd_packed.numel() < table.bwd_size:
+        raise OdkError("pack_weights: packed buffers too small")
+    _chk(load_library().odk_pack_weights(_ptr(params), params.numel(), _ptr(fwd_packed), fwd_packed.numel(), _ptr(bwd_packed), bwd_packed.numel(),
+                                         C.byref(table.c), _stream(params)))
+
+
+def adam_clip_packed(params, grads, m, v, acc, fwd_packed, bwd_packed, table: WeightTable, lr: float, max_grad_norm: float = 0.0, b1: float = 0.9,
+                     b2: float = 0.999, eps: float = 1e-8):
+    """`adam_clip` that also writes every updated weight to its places in the packed copies (`odk_adam_clip_packed`)."""
+    _f32c(params, grads, m, v, acc, fwd_packed, bwd_packed)
+    if acc.numel() < ADAM_ACC_FLOATS or fwd_packed.numel() < table.fwd_size or bwd_packed.numel() < table.bwd_size:
+        raise OdkError("adam_clip_packed: acc needs ADAM_ACC_FLOATS floats, the packed buffers table.fwd_size / bwd_size")
+    _chk(load_library().odk_adam_clip_packed(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
+                                             max_grad_norm or 0.0, _ptr(fwd_packed), fwd_packed.numel(), _ptr(bwd_packed), bwd_packed.numel(),
+                                             C.byref(table.c), _stream(params)))
+
+
+class ColsumFold:
+    """colsum[f] = sum over the nblk[f] tile rows of partial[f] ([nblk[f], width]) for up to 8 layers in one launch (`odk_colsum_fold`)."""
+
+    def __init__(self, pairs, nblk):
+        k = len(pairs)
+        self.k, self.keep = k, pairs
+        nblk = [int(nblk)] * k if isinstance(nblk, int) else [int(b) for b in nblk]
+        for (p_, o_), nb in zip(pairs, nblk):
+            _f32c(p_, o_)
+            if p_.numel() < nb * o_.numel():
+                raise OdkError("ColsumFold: partial buffer too small")
+        self.nblk = (C.c_int * k)(*nblk)
+        self.partial = (C.c_void_p * k)(*[p_.data_ptr() for p_, _ in pairs])
+        self.out = (C.c_void_p * k)(*[o_.data_ptr() for _, o_ in pairs])
+        self.w = (C.c_int * k)(*[int(o_.numel()) for _, o_ in pairs])
+
+    def __call__(self):
+        _chk(load_library().odk_colsum_fold(self.partial, self.out, self.w, self.nblk, self.k, _stream(self.keep[0][0])))
+
+
+class FusedMLP:
+    """One or two swish MLPs (n_in -> 512 -> 256 -> 128 -> n_out) whose forward pass is ONE launch and whose backward-data chain is
+    ONE launch (`odk_mlp_forward` / `odk_mlp_backward`, csrc/odk_mlp.hip).  Each net is a dict of tensors:
+      x [n, n_in], wf[4] (forward-packed weights: `WeightTable.fwd_view`), b[4], out [n, n_out]; for training also wb[4]
+      (backward-packed, wb[0] may be None), dout [n, n_out], bias_partial[4] ([ceil(n / 32), width]) and the flat QUAD-ROW
+      buffers (`quad_rows(n)` x width floats, layout of `quad_pack`) xp (copy of x), h[3], g[3] (activations, swish'), dz[3],
+      doutp (copy of dout) -- `train_buffers` allocates them."""
+
+    @staticmethod
+    def train_buffers(n: int, n_in: int, n_out: int, device):
+        import torch
+        np_, tiles = quad_rows(n), quad_rows(n) // MLP_TILE
+        E = lambda k: torch.empty(k, device=device)
+        return dict(xp=E(np_ * n_in), h=[E(np_ * w) for w in MLP_HIDDEN], g=[E(np_ * w) for w in MLP_HIDDEN], dz=[E(np_ * w) for w in MLP_HIDDEN],
+                    doutp=E(np_ * n_out), bias_partial=[E(tiles * w) for w in MLP_HIDDEN + (n_out,)])
+
+    def __init__(self, nets):
+        if not 1 <= len(nets) <= 2:
+            raise OdkError("FusedMLP: one or two networks")
+        self.k = len(nets)
+        self.keep = nets
+        self.desc = (MlpDesc * self.k)()
+        self.train = []
+        for d, nt in zip(self.desc, nets):
+            x, out = nt["x"], nt["out"]
+            n, n_in = x.shape
+            n_out = out.shape[1]
+            widths = (n_in,) + MLP_HIDDEN + (n_out,)
+            if n_in > MLP_MAX_IN or n_out > MLP_MAX_OUT or out.shape[0] != n:
+                raise OdkError("FusedMLP: n_in <= 224, n_out <= 32")
+            _f32c(x, out, *nt["wf"], *nt["b"])
+            for l in range(4):
+                if nt["wf"][l].numel() != _pad8(widths[l]) * widths[l + 1] or nt["b"][l].numel() != widths[l + 1]:
+                    raise OdkError(f"FusedMLP: layer {l} is not {widths[l]} -> {widths[l + 1]} (hidden widths are fixed at {MLP_HIDDEN})")
+            d.x, d.out, d.n, d.n_in, d.n_out = x.data_ptr(), out.data_ptr(), int(n), int(n_in), int(n_out)
+            for l in range(4):
+                d.wf[l], d.b[l] = nt["wf"][l].data_ptr(), nt["b"][l].data_ptr()
+            train = "h" in nt
+            self.train.append(train)
+            if train:
+                tiles, np_ = (n + MLP_TILE - 1) // MLP_TILE, quad_rows(n)
+                _f32c(nt["dout"], nt["xp"], nt["doutp"], *nt["h"], *nt["g"], *nt["dz"], *nt["bias_partial"], *nt["wb"][1:])
+                if nt["xp"].numel() != np_ * n_in or nt["doutp"].numel() != np_ * n_out:
+                    raise OdkError("FusedMLP: xp / doutp must be quad-row buffers of quad_rows(n) rows")
+                d.xp, d.doutp = nt["xp"].data_ptr(), nt["doutp"].data_ptr()
+                for l in range(1, 4):
+                    if nt["wb"][l].numel() != _pad8(widths[l + 1]) * widths[l]:
+                        raise OdkError(f"FusedMLP: backward-packed weight {l} has the wrong size")
+                    d.wb[l] = nt["wb"][l].data_ptr()
+                for l in range(3):
+                    for key in ("h", "g", "dz"):
+                        if nt[key][l].numel() != np_ * MLP_HIDDEN[l]:
+                            raise OdkError(f"FusedMLP: {key}[{l}] must be a quad-row buffer of {np_} x {MLP_HIDDEN[l]} floats")
+                    d.h[l], d.g[l], d.dz[l] = nt["h"][l].data_ptr(), nt["g"][l].data_ptr(), nt["dz"][l].data_ptr()
+                if tuple(nt["dout"].shape) != (n, n_out):
+                    raise OdkError("FusedMLP: dout must match out")
+                d.dout = nt["dout"].data_ptr()
+                for l in range(4):
+                    if nt["bias_partial"][l].numel() < tiles * widths[l + 1]:
+                        raise OdkError("FusedMLP: bias_partial too small")
+                    d.bias_partial[l] = nt["bias_partial"][l].data_ptr()
+
+    def forward(self):
+        _chk(load_library().odk_mlp_forward(self.desc, self.k, _stream(self.keep[0]["x"])))
+
+    def backward(self):
+        if not all(self.train):
+            raise OdkError("FusedMLP.backward: built without training buffers")
+        _chk(load_library().odk_mlp_backward(self.desc, self.k, _stream(self.keep[0]["x"])))
 
 
 class RowGather:

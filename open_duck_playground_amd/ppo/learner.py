@@ -151,7 +151,7 @@ def tune_inference_shapes(net: PPONetworks, rows) -> None:
         _tunable(False)
 
 
-_DW_GEMM = os.environ.get("ODK_LEARNER_DW", "1") == "1"   # weight gradients on csrc dw_gemm_kernel (0: torch.mm, the library GEMMs)
+_FUSED_MLP = os.environ.get("ODK_LEARNER_FUSED", "1") == "1"   # whole-network forward / backward-data launches (csrc/odk_mlp.hip; 0: one library GEMM per layer)
 
 
 class _FlatMLP:
@@ -161,7 +161,7 @@ class _FlatMLP:
 
     def __init__(self, mlp, flat_p, flat_g, off: int):
         self.W, self.b, self.gW, self.gb, self.goff = [], [], [], [], []
-        self.zs = self.hs = self.dzs = self.dhs = self.partials = self.fold = self.dw = None
+        self.zs = self.hs = self.dzs = self.dhs = self.partials = self.fold = None
         for lin in mlp.layers:
             for name in ("weight", "bias"):
                 p = getattr(lin, name)
@@ -175,12 +175,15 @@ class _FlatMLP:
                 off += n
         self.end = off
 
-    def bind(self, x, dz_top, flat_g, workspace, kslices: int = 16):
+    def bind(self, x, dz_top, fused: bool):
         """Fixes the step's tensors: x [n, in] (network input), dz_top [n, out] (gradient w.r.t. the output, written by the loss
-        head), and allocates z / h per layer, dz / dh per hidden layer and the bias-gradient tile sums."""
+        head).  Library path (`fused` false: one GEMM per layer): allocates z / h per layer, dz / dh per hidden layer and the
+        bias-gradient tile sums; the fused path (csrc/odk_mlp.hip) needs only the output buffer here, see `fused_desc`."""
         n, dev = x.shape[0], x.device
         self.x, self.dz_top = x, dz_top
-        self.zs = [torch.empty(n, w.shape[0], device=dev) for w in self.W]
+        self.zs = [torch.empty(n, w.shape[0], device=dev) if (not fused or i == len(self.W) - 1) else None for i, w in enumerate(self.W)]
+        if fused:
+            return
         self.hs = [x] + [torch.empty(n, w.shape[0], device=dev) for w in self.W[:-1]]
         self.dzs = [torch.empty(n, w.shape[0], device=dev) for w in self.W[:-1]]
         self.dhs = [torch.empty_like(t) for t in self.dzs]
@@ -188,11 +191,23 @@ class _FlatMLP:
         # are first read by the clip + Adam step, so their finalisation need not sit between the GEMMs)
         self.partials = [torch.empty(((n + 63) // 64) * w.shape[0], device=dev) for w in self.W]
         self.fold = engine.ColsumFinalize([(p, self.gb[i]) for i, p in enumerate(self.partials)], n)
-        dz_of = self.dzs + [dz_top]
-        ok = _DW_GEMM and len(self.W) <= 4 and n % (16 * kslices) == 0 and all(o % 4 == 0 and w.numel() % 4 == 0 for o, w in zip(self.goff, self.W))
-        # dW_l = dz_l^T h_{l-1} of all layers in one launch on the f32 matrix cores (the library runs these K = n deep,
-        # small-output GEMMs at ~30 TFLOP/s: 175 us of the minibatch step for the two networks, 100 us here)
-        self.dw = engine.DwGemm([(dz_of[i], self.hs[i], self.goff[i]) for i in range(len(self.W))], flat_g, workspace, kslices) if ok else None
+
+    def fused_ok(self) -> bool:
+        """The shapes csrc/odk_mlp.hip is built for: in -> 512 -> 256 -> 128 -> out with in <= 224, out <= 32."""
+        return (_FUSED_MLP and len(self.W) == 4 and tuple(w.shape[0] for w in self.W[:3]) == engine.MLP_HIDDEN
+                and self.W[0].shape[1] <= engine.MLP_MAX_IN and self.W[3].shape[0] <= engine.MLP_MAX_OUT)
+
+    def fused_desc(self, table, k0, packed_f, packed_b):
+        """This network for `engine.FusedMLP`: the bound buffers + swish' buffers, bias-gradient tile sums (32-row tiles) and the
+        views of its weights (entries k0 .. k0 + 3 of `table`) inside the packed buffers."""
+        n, n_in, n_out = self.x.shape[0], self.x.shape[1], self.W[-1].shape[0]
+        tb = engine.FusedMLP.train_buffers(n, n_in, n_out, self.x.device)
+        self.tile_sums, self.tiles = tb["bias_partial"], engine.quad_rows(n) // engine.MLP_TILE
+        # weight gradients dW_l = dz_l^T h_{l-1}: (dz, h, n_out, n_in, offset in the flat gradient buffer), quad-row operands
+        acts, dzs = [tb["xp"]] + tb["h"], tb["dz"] + [tb["doutp"]]
+        self.dw_layers = [(dzs[l], acts[l], w.shape[0], w.shape[1], self.goff[l]) for l, w in enumerate(self.W)]
+        return dict(x=self.x, wf=[table.fwd_view(packed_f, k0 + l) for l in range(4)], wb=[table.bwd_view(packed_b, k0 + l) for l in range(4)],
+                    b=self.b, out=self.zs[-1], dout=self.dz_top, **tb)
 
     def forward(self):
         for i, (W, b) in enumerate(zip(self.W, self.b)):
@@ -202,24 +217,20 @@ class _FlatMLP:
         return self.zs[-1]
 
     def backward(self):
-        """Gradients straight into the flat buffer.  Below the top layer, dz and its column sums (the bias gradient)
-        come out of one fused pass (csrc silu_bwd_colsum) instead of silu_backward + a separate reduction; the weight
-        gradients of all layers follow in one launch (csrc dw_gemm_kernel) once every dz exists.
-        (Measured and dropped with the library GEMMs: the weight-gradient GEMMs as a further parallel branch beside the
-        dz -> dh chain made the step 10 % slower, and a branch forked from a branch crashes hipStreamEndCapture on ROCm 7.2.)"""
+        """Library path: gradients straight into the flat buffer.  Below the top layer, dz and its column sums (the bias
+        gradient) come out of one fused pass (csrc silu_bwd_colsum) instead of silu_backward + a separate reduction.
+        (Measured and dropped: the weight-gradient GEMMs as a further parallel branch beside the dz -> dh chain made the step
+        10 % slower, and a branch forked from a branch crashes hipStreamEndCapture on ROCm 7.2.)"""
         top = len(self.W) - 1
         dz = self.dz_top
         engine.colsum_partial(dz, self.partials[top])   # (a torch.sum over the tall [n, <=28] matrix takes 22-28 us)
         for i in range(top, -1, -1):
-            if self.dw is None:
-                torch.mm(dz.t(), self.hs[i], out=self.gW[i])
+            torch.mm(dz.t(), self.hs[i], out=self.gW[i])
             if i > 0:
                 dh = torch.mm(dz, self.W[i], out=self.dhs[i - 1])
                 dz = self.dzs[i - 1]
                 engine.silu_bwd_colsum(dh, self.zs[i - 1], dz, None, self.partials[i - 1])
         self.fold()
-        if self.dw is not None:
-            self.dw()
 
 
 class FlatLearner:
@@ -251,10 +262,23 @@ class FlatLearner:
         self.noise = z(n, A)
         self.vs, self.adv, self.stats = z(B, T), z(B, T), z(2)
         self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
-        kslices = 16
-        self.dw_ws = torch.empty(kslices * engine.DwGemm.workspace_stride(n_par), device=dev)   # split-K partial weight gradients
-        self.policy.bind(self.static["obs"].view(n, -1), self.dlogits, self.flat_g, self.dw_ws, kslices)
-        self.value.bind(self.priv_all, self.dval_all, self.flat_g, self.dw_ws, kslices)
+        fused = self.policy.fused_ok() and self.value.fused_ok()
+        self.policy.bind(self.static["obs"].view(n, -1), self.dlogits, fused)
+        self.value.bind(self.priv_all, self.dval_all, fused)
+        # whole-network launches (csrc/odk_mlp.hip): forward of both networks = 1 launch, backward-data of both = 1 launch, the
+        # bias gradients' fold = 1, the weight gradients of all 8 layers = 1 (+ its slice fold); the kernels read the weights
+        # from packed copies (16-byte pieces along the reduction index) that the Adam launch keeps current
+        self.fused = None
+        if fused:
+            kslices = 16
+            self.dw_ws = torch.empty(kslices * engine.DwGemm.workspace_stride(n_par), device=dev)   # split-K partial weight gradients
+            nets = (self.policy, self.value)
+            self.wtable = engine.WeightTable([(o, w.shape[0], w.shape[1], l > 0) for f in nets for l, (o, w) in enumerate(zip(f.goff, f.W))])
+            self.packed_f, self.packed_b = z(self.wtable.fwd_size), z(self.wtable.bwd_size)
+            self.fused = engine.FusedMLP([f.fused_desc(self.wtable, 4 * k, self.packed_f, self.packed_b) for k, f in enumerate(nets)])
+            self.fold = engine.ColsumFold([(t, f.gb[i]) for f in nets for i, t in enumerate(f.tile_sums)], [f.tiles for f in nets for _ in f.W])
+            self.dw_all = engine.DwGemm([l for f in nets for l in f.dw_layers], self.flat_g, self.dw_ws, kslices)
+            self.sync_weights()
         self.losses = z(4)                          # running SUMS of (total, policy, value, entropy) over the steps since metrics()
         self.nsteps = 0
         self.split_update = world > 1 if split_update is None else bool(split_update)
@@ -270,6 +294,19 @@ class FlatLearner:
     @torch.no_grad()
     def _loss_and_grads(self):
         B, T, n, s, cfg = self.B, self.T, self.B * self.T, self.static, self.cfg
+        if self.fused is not None:
+            self.fused.forward()
+            zp, vals = self.policy.zs[-1], self.value.zs[-1].view(-1)
+            baseline, boot = vals[:n], vals[n:]
+            engine.gae(s["truncation"], s["termination"], s["reward"], baseline.view(B, T), boot, cfg["gae_lambda"], cfg["discounting"],
+                       vs=self.vs, adv=self.adv, stats=self.stats)
+            engine.ppo_head(zp, s["raw_action"].view(n, -1), s["log_prob"].view(n), self.adv.view(n),
+                            self.stats if cfg["normalize_advantage"] else None, self.vs.view(n), baseline, self.noise, self.dlogits,
+                            self.dval_all[:n].view(n), self.losses, cfg["clipping_epsilon"], cfg["entropy_cost"], 1.0 / self.world)
+            self.fused.backward()
+            self.fold()
+            self.dw_all()
+            return
         # policy and value networks are independent until the loss head: two branches of the captured graph
         cur = torch.cuda.current_stream()
         if self.side is not None:
@@ -323,7 +360,18 @@ class FlatLearner:
 
     @torch.no_grad()
     def _update(self):
-        engine.adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0)
+        if self.fused is not None:
+            engine.adam_clip_packed(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.packed_f, self.packed_b, self.wtable,
+                                    self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0)
+        else:
+            engine.adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0)
+
+    @torch.no_grad()
+    def sync_weights(self):
+        """Rebuilds the packed weight copies from the flat parameter buffer.  The Adam launch keeps them current; call this after
+        writing parameters from outside (checkpoint restore, tests) -- `sgd_epoch` does so once per training step."""
+        if self.fused is not None:
+            engine.pack_weights(self.flat_p, self.packed_f, self.packed_b, self.wtable)
 
     def _capture(self):
         keep = [t.clone() for t in (self.flat_p, self.m, self.v, self.acc)]
@@ -338,6 +386,7 @@ class FlatLearner:
             _tunable(False)                         # keep the selected kernels, never tune inside a capture
         for t, k in zip((self.flat_p, self.m, self.v, self.acc), keep):
             t.copy_(k)                              # the warm-up steps must not train
+        self.sync_weights()
         self.losses.zero_()
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
@@ -424,6 +473,7 @@ class FlatLearner:
 
     def load_optimizer_state(self, st):
         self.m.copy_(st["m"]); self.v.copy_(st["v"]); self.acc.copy_(st["acc"])
+        self.sync_weights()
 
 
 @torch.no_grad()

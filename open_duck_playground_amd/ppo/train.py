@@ -134,6 +134,7 @@ def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Gen
     if learner is not None:
         from .learner import prepare_rollout
         prep = prepare_rollout(net, data, cfg)
+        learner.sync_weights()                        # (parameters written from outside since the last step, e.g. a restored checkpoint)
         for _ in range(cfg["num_updates_per_batch"]):
             perm = torch.randperm(B, generator=gen, device=data["reward"].device)
             for mbi in perm.chunk(nmb):

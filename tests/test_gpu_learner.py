@@ -36,22 +36,26 @@ def test_gae_kernel_matches_torch_reference(B, Tn):
 
 
 def test_dw_gemm_matches_torch_mm_and_is_reproducible():
-    """odk_dw_gemm (weight gradients dz^T h of several layers, split-K on the f32 matrix cores) vs float64 torch; edge tiles
-    (28, 1, 101, 212 columns), offsets into a flat buffer, bit-identical repeats (fixed-order fold of the row slices)."""
+    """odk_dw_gemm (weight gradients dz^T h of several layers, split-K on the f32 matrix cores, quad-row operands) vs float64
+    torch; edge tiles (28, 1, 101, 212 columns), ragged row counts (slices of unequal length), offsets into a flat buffer,
+    bit-identical repeats (fixed-order fold of the row slices)."""
     from open_duck_playground_amd import engine
     g = torch.Generator(device="cuda").manual_seed(0)
-    for n, shapes, ks in ((1280, [(512, 101), (256, 512), (128, 256), (28, 128)], 8), (768, [(512, 212), (1, 128)], 16), (256, [(36, 70), (64, 33)], 8)):
+    for n, shapes, ks in ((1280, [(512, 101), (256, 512), (128, 256), (28, 128)], 8), (777, [(512, 212), (1, 128)], 16), (200, [(36, 70), (64, 33)], 8)):
         tot = sum((o * i + 7) // 4 * 4 for o, i in shapes) + 12
         flat = torch.full((tot,), 7.0, device="cuda")
         ws = torch.empty(ks * engine.DwGemm.workspace_stride(tot), device="cuda")
-        layers, off = [], 8
+        layers, dense, off = [], [], 8
         for o, i in shapes:
-            layers.append((torch.randn(n, o, device="cuda", generator=g), torch.randn(n, i, device="cuda", generator=g), off))
+            dz, h = torch.randn(n, o, device="cuda", generator=g), torch.randn(n, i, device="cuda", generator=g)
+            dense.append((dz, h, off))
+            layers.append((engine.quad_pack(dz), engine.quad_pack(h), o, i, off))
+            assert torch.equal(engine.quad_unpack(layers[-1][0], n, o), dz)
             off += (o * i + 7) // 4 * 4
         op = engine.DwGemm(layers, flat, ws, ks)
         op()
         first = flat.clone()
-        for dz, h, o in layers:
+        for dz, h, o in dense:
             ref = dz.double().t() @ h.double()
             got = flat[o:o + ref.numel()].view_as(ref).double()
             assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
@@ -59,8 +63,141 @@ def test_dw_gemm_matches_torch_mm_and_is_reproducible():
         ws.fill_(float("nan")); op()
         assert torch.equal(flat, first)
     with pytest.raises(engine.OdkError):
-        engine.DwGemm([(torch.zeros(100, 8, device="cuda"), torch.zeros(100, 8, device="cuda"), 0)], torch.zeros(64, device="cuda"),
-                      torch.zeros(8 * 64, device="cuda"), 8)                              # rows not divisible by 16 * kslices
+        engine.DwGemm([(torch.zeros(32 * 8, device="cuda"), torch.zeros(32 * 8, device="cuda"), 8, 8, 0)], torch.zeros(64, device="cuda"),
+                      torch.zeros(8 * 64, device="cuda"), 8)                              # fewer row groups than slices
+
+
+def _mlp_params(n_in, n_out, g):
+    """Random swish MLP n_in -> 512 -> 256 -> 128 -> n_out as the learner keeps it: one flat buffer (W1 b1 W2 b2 ...), the weight
+    table, and the two packed copies built by odk_pack_weights."""
+    from open_duck_playground_amd import engine
+    widths = (n_in,) + engine.MLP_HIDDEN + (n_out,)
+    W = [torch.randn(widths[l + 1], widths[l], device="cuda", generator=g) * (1.5 / widths[l] ** 0.5) for l in range(4)]
+    b = [0.3 * torch.randn(widths[l + 1], device="cuda", generator=g) for l in range(4)]
+    offs, off = [], 0
+    for l in range(4):
+        offs.append(off); off += W[l].numel() + b[l].numel()
+    flat = torch.cat([t.reshape(-1) for l in range(4) for t in (W[l], b[l])])
+    table = engine.WeightTable([(offs[l], widths[l + 1], widths[l], l > 0) for l in range(4)])
+    pf, pb = torch.zeros(table.fwd_size, device="cuda"), torch.zeros(table.bwd_size, device="cuda")
+    engine.pack_weights(flat, pf, pb, table)
+    return widths, W, b, flat, table, pf, pb
+
+
+def _packed_reference(Wk):
+    """[K, N] matrix (reduction index first) -> the packed layout [pad8(K) / 4][N][4], zero padding."""
+    K, N = Wk.shape
+    K8 = (K + 7) // 8 * 8
+    full = torch.zeros(K8, N, device=Wk.device)
+    full[:K] = Wk
+    return full.view(K8 // 4, 4, N).permute(0, 2, 1).contiguous().reshape(-1)
+
+
+@pytest.mark.parametrize("n, n_in, n_out", [(320, 101, 28), (336, 212, 1), (5120, 85, 28), (77, 153, 1)])   # whole / ragged tiles, odd and even K, Joystick and Standing sizes
+def test_fused_mlp_matches_torch(n, n_in, n_out):
+    """odk_mlp_forward / odk_mlp_backward (one launch per direction for the whole swish MLP) vs float64 torch: output, hidden
+    activations, swish', every dz, and the bias gradients through odk_colsum_fold; inference-only mode writes `out` alone;
+    the packed weight copies against their definition."""
+    from open_duck_playground_amd import engine
+    g = torch.Generator(device="cuda").manual_seed(n + n_in)
+    widths, W, b, flat, table, pf, pb = _mlp_params(n_in, n_out, g)
+    for l in range(4):
+        assert torch.equal(table.fwd_view(pf, l), _packed_reference(W[l].t()))
+        if l > 0:
+            assert torch.equal(table.bwd_view(pb, l), _packed_reference(W[l]))
+    assert table.bwd_view(pb, 0) is None
+    x = torch.randn(n, n_in, device="cuda", generator=g)
+    dout = torch.randn(n, n_out, device="cuda", generator=g)
+    tiles = (n + 31) // 32
+    buf = lambda w: torch.full((n, w), float("nan"), device="cuda")
+    wf, wb = [table.fwd_view(pf, l) for l in range(4)], [table.bwd_view(pb, l) for l in range(4)]
+    tb = engine.FusedMLP.train_buffers(n, n_in, n_out, "cuda")
+    for t in [tb["xp"], tb["doutp"]] + tb["h"] + tb["g"] + tb["dz"] + tb["bias_partial"]:
+        t.fill_(float("nan"))
+    raw = dict(x=x, wf=wf, wb=wb, b=b, out=buf(n_out), dout=dout, **tb)
+    op = engine.FusedMLP([raw])
+    op.forward(); op.backward()
+    # quad-row buffers: rows past the batch are zeros (the weight-gradient launch reads whole tiles); unpack the rest
+    np_ = engine.quad_rows(n)
+    for key in ("h", "g", "dz"):
+        for l, w in enumerate(engine.MLP_HIDDEN):
+            assert float(engine.quad_unpack(raw[key][l], np_, w)[n:].abs().sum()) == 0.0
+    assert torch.equal(engine.quad_unpack(raw["xp"], n, n_in), x) and torch.equal(engine.quad_unpack(raw["doutp"], n, n_out), dout)
+    assert float(engine.quad_unpack(raw["doutp"], np_, n_out)[n:].abs().sum()) == 0.0
+    net = dict(out=raw["out"], bias_partial=raw["bias_partial"], **{key: [engine.quad_unpack(raw[key][l], n, w) for l, w in enumerate(engine.MLP_HIDDEN)]
+                                                                    for key in ("h", "g", "dz")})
+    # float64 reference
+    zs, hs = [], [x.double()]
+    for l in range(4):
+        z = hs[-1] @ W[l].double().t() + b[l].double()
+        zs.append(z)
+        if l < 3:
+            hs.append(z * torch.sigmoid(z))
+    rel = lambda a, ref: float((a.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    assert rel(net["out"], zs[3]) < 2e-6
+    dz_ref, dzl = [None] * 3, dout.double()
+    for l in (2, 1, 0):
+        sg = torch.sigmoid(zs[l])
+        gref = sg * (1 + zs[l] * (1 - sg))
+        assert rel(net["h"][l], hs[l + 1]) < 2e-6 and rel(net["g"][l], gref) < 2e-6
+        dzl = (dzl @ W[l + 1].double()) * gref
+        dz_ref[l] = dzl
+        assert rel(net["dz"][l], dzl) < 3e-6
+    gb = [torch.empty(w, device="cuda") for w in widths[1:]]
+    engine.ColsumFold([(net["bias_partial"][l], gb[l]) for l in range(4)], tiles)()
+    for l in range(3):
+        assert rel(gb[l], dz_ref[l].sum(0)) < 3e-6
+    assert rel(gb[3], dout.double().sum(0)) < 3e-6
+    # inference only: nothing but `out`
+    inf = dict(x=x, wf=wf, b=b, out=buf(n_out))
+    engine.FusedMLP([inf]).forward()
+    assert torch.equal(inf["out"], net["out"])
+    with pytest.raises(engine.OdkError):
+        engine.FusedMLP([dict(x=torch.zeros(8, 300, device="cuda"), wf=wf, b=b, out=buf(n_out)[:8])])
+
+
+def test_fused_mlp_two_networks_one_launch_and_adam_keeps_the_packed_copies():
+    """Policy and value side by side in one launch == each alone; odk_adam_clip_packed == odk_adam_clip + a fresh packing."""
+    from open_duck_playground_amd import engine
+    g = torch.Generator(device="cuda").manual_seed(5)
+    nets = []
+    for n, n_in, n_out in ((320, 101, 28), (336, 212, 1)):
+        widths, W, b, flat, table, pf, pb = _mlp_params(n_in, n_out, g)
+        tiles = (n + 31) // 32
+        x, dout = torch.randn(n, n_in, device="cuda", generator=g), torch.randn(n, n_out, device="cuda", generator=g)
+        mk = lambda: dict(x=x, wf=[table.fwd_view(pf, l) for l in range(4)], wb=[table.bwd_view(pb, l) for l in range(4)], b=b,
+                          out=torch.empty(n, n_out, device="cuda"), dout=dout, **engine.FusedMLP.train_buffers(n, n_in, n_out, "cuda"))
+        nets.append((mk(), mk()))
+    pair = engine.FusedMLP([nets[0][0], nets[1][0]])
+    pair.forward(); pair.backward()
+    for k in range(2):
+        one = engine.FusedMLP([nets[k][1]])
+        one.forward(); one.backward()
+        for key in ("h", "g", "dz", "bias_partial"):
+            assert all(torch.equal(a, b_) for a, b_ in zip(nets[k][0][key], nets[k][1][key]))
+        for key in ("out", "xp", "doutp"):
+            assert torch.equal(nets[k][0][key], nets[k][1][key])
+    # Adam with the packed copies: a 64 x 64 weight (both copies), a bias, a 40 x 21 weight (forward copy only), a bias
+    npar = 4096 + 64 + 40 * 21 + 40
+    table = engine.WeightTable([(0, 64, 64, True), (4096 + 64, 40, 21, False)])
+    p = torch.randn(npar, device="cuda", generator=g); gr = torch.randn(npar, device="cuda", generator=g)
+    p2 = p.clone()
+    pf, pb = torch.zeros(table.fwd_size, device="cuda"), torch.zeros(table.bwd_size, device="cuda")
+    m1, v1, a1 = torch.zeros(npar, device="cuda"), torch.zeros(npar, device="cuda"), torch.zeros(engine.ADAM_ACC_FLOATS, device="cuda")
+    m2, v2, a2 = m1.clone(), v1.clone(), a1.clone()
+    for _ in range(3):
+        engine.adam_clip(p, gr, m1, v1, a1, 3e-4, 1.0)
+        engine.adam_clip_packed(p2, gr, m2, v2, a2, pf, pb, table, 3e-4, 1.0)
+    # (two compilations of the same arithmetic: fused multiply-adds may differ in the last bit -- every replica runs the same one)
+    for got, ref in ((p2, p), (m2, m1), (v2, v1)):
+        torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-7)
+    assert torch.equal(a1[:2], a2[:2])
+    rf, rb = torch.zeros_like(pf), torch.zeros_like(pb)
+    engine.pack_weights(p2, rf, rb, table)
+    assert torch.equal(pf, rf) and torch.equal(pb, rb)
+    assert torch.equal(table.fwd_view(pf, 0), _packed_reference(p2[:4096].view(64, 64).t()))
+    assert torch.equal(table.bwd_view(pb, 0), _packed_reference(p2[:4096].view(64, 64)))
+    assert torch.equal(table.fwd_view(pf, 1), _packed_reference(p2[4160:4160 + 840].view(40, 21).t()))
 
 
 @pytest.mark.parametrize("normalize_advantage, N", [(True, 64), (False, 64), (True, 1024)])   # N = 1024: 256 x 20 rows, the dW kernel's path
@@ -80,7 +217,7 @@ def test_flat_learner_gradients_match_autograd(normalize_advantage, N):
     lr = FlatLearner(net, cfg, N // nmb, Tn, use_graph=False)
     idx = torch.arange(3, 3 + N // nmb, device=dev)
     lr.load_minibatch(prepare_rollout(net, data, cfg), idx)
-    assert (lr.policy.dw is not None) == (N == 1024)            # 5 120 rows divide into the dW kernel's slices, 320 do not
+    assert lr.fused is not None                                 # the reference architecture runs on the fused network kernels
     lr._draw_noise(); lr._loss_and_grads()
     mb = {k: v[idx] for k, v in data.items()}
     mb["noise"] = lr.noise.view(N // nmb, Tn, 14).clone()

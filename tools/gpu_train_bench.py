@@ -21,7 +21,8 @@ learner = None
 gen = torch.Generator(device=dev); gen.manual_seed(0)
 state = env.reset(0)
 tr = tl = 0.0
-for it in range(iters + 1):
+WARM = 2   # untimed: learner construction, library handles, selection file
+for it in range(iters + WARM):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     data, state = T.rollout(env, net, state, cfg["unroll_length"], gen)
     torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -30,7 +31,7 @@ for it in range(iters + 1):
         learner = T.make_learner(net, data, cfg) if os.environ.get("ODK_EAGER_LEARNER") != "1" else None
     m = T.sgd_epoch(net, opt, data, cfg, gen, learner=learner)
     torch.cuda.synchronize(); t2 = time.perf_counter()
-    if it > 0:
+    if it >= WARM:
         tr += t1 - t0; tl += t2 - t1
 steps = iters * 8192 * cfg["unroll_length"]
 print(json.dumps({"task": task, "iters": iters, "env_steps_per_s_total": steps / (tr + tl), "rollout_env_steps_per_s": steps / tr,

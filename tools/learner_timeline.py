@@ -6,7 +6,7 @@ d = sys.argv[1]; which = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+adam = [i for i, r in enumerate(rows) if "adam_" in r["Kernel_Name"] and "sqnorm" not in r["Kernel_Name"]]
 a, b = adam[which], adam[which + 1]
 t0 = int(rows[a]["End_Timestamp"])
 busy = 0
