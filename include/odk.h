@@ -206,17 +206,18 @@ int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int
 
 /* ---- fused policy / value networks (csrc/odk_mlp.hip): a swish MLP  n_in -> 512 -> 256 -> 128 -> n_out  (brax ppo.networks as
  * configured by the reference, common/runner.py:86-118) forward in ONE launch and its backward-data chain in ONE launch, on the
- * f32 matrix cores; a workgroup keeps a tile of 32 samples in LDS for all layers.  One or two networks per launch (policy and
+ * f32 matrix cores; a workgroup keeps a tile of 16 samples in LDS for all layers.  One or two networks per launch (policy and
  * value side by side).  Everything row-major float32 on the device.
  * The kernels read the weights from PACKED copies (16-byte pieces of four consecutive reduction indices per column):
- *   forward copy of W [n_out, n_in]:  [pad8(n_in) / 4][n_out][4],  element (o, i) at ((i / 4) * n_out + o) * 4 + i % 4
- *   backward copy:                    [pad8(n_out) / 4][n_in][4],  element (o, i) at ((o / 4) * n_in + i) * 4 + o % 4
- * with pad8(k) = k rounded up to a multiple of 8 and the padding zero (the caller zeroes the buffers once; odk_pack_weights /
+ *   forward copy of W [n_out, n_in]:  [pad16(n_in) / 4][n_out][4],  element (o, i) at ((i / 4) * n_out + o) * 4 + i % 4
+ *   backward copy:                    [pad16(n_out) / 4][n_in][4],  element (o, i) at ((o / 4) * n_in + i) * 4 + o % 4
+ * with pad16(k) = k rounded up to a multiple of 16 and the padding zero (the caller zeroes the buffers once; odk_pack_weights /
  * odk_adam_clip_packed write the weights' elements only). */
 #define ODK_MLP_H1 512
 #define ODK_MLP_H2 256
 #define ODK_MLP_H3 128
 #define ODK_MLP_MAX_IN 224
+#define ODK_MLP_TILE 16        /* samples per workgroup */
 typedef struct odk_mlp_desc {
   const float* x;            /* [n, n_in] network input */
   const float* wf[4];        /* forward-packed weights of the four layers (16-byte aligned) */
@@ -231,7 +232,7 @@ typedef struct odk_mlp_desc {
   const float* dout;         /* backward in: dLoss/dout [n, n_out] row-major */
   float* doutp;              /* backward out: quad-row copy of dout, width n_out */
   float* dz[3];              /* backward out: dLoss/dz_l, width H_l */
-  float* bias_partial[4];    /* backward out: per-tile column sums of dz_l (l = 3: of dout), [ceil(n / 32), width_l]; odk_colsum_fold finishes them */
+  float* bias_partial[4];    /* backward out: per-tile column sums of dz_l (l = 3: of dout), [ceil(n / 16), width_l]; odk_colsum_fold finishes them */
   int n, n_in, n_out;        /* n_in <= ODK_MLP_MAX_IN, n_out <= 32 */
 } odk_mlp_desc;
 int odk_mlp_forward(const odk_mlp_desc* nets, int count, void* stream);

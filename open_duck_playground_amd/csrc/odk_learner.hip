@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/odk.h"
 
 int odk_fail_(int code, const char* msg);   // odk_engine.hip
@@ -379,6 +381,9 @@ __global__ void gather_rows_kernel(GatherArgs a, const long long* __restrict__ i
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DW_MAX = 8;
+#ifndef DW_AHEAD
+#define DW_AHEAD 2
+#endif
 struct DwLayer { const float* dz; const float* h; int n_out, n_in, tj, tile0, ngroups; long long out_off; };   // ngroups = rows / 8
 struct DwArgs { DwLayer L[DW_MAX]; int nlayers, ntiles, kslices; float* ws; long long ws_stride; };
 
@@ -404,33 +409,40 @@ __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
   const size_t sa = (size_t)2 * n_out, sb = (size_t)2 * n_in;   // one row group = two row quads
   f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
   const bool two_i = i0 + 32 < n_out, two_j = j0 + 32 < n_in;   // wave-uniform: skip the empty halves of edge tiles
-  f32x4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
-  auto fetch = [&](int g, f32x4& xa0, f32x4& xa1, f32x4& xb0, f32x4& xb1) {
+  struct Ops { f32x4 a0, a1, b0, b1; };
+  auto fetch = [&](int g, Ops& x) {
     const size_t o = (size_t)(g < g_hi ? g : g_lo);   // past the slice: re-read its first group (in bounds, unused)
-    xa0 = pa0[o * sa]; xa1 = pa1[o * sa]; xb0 = pb0[o * sb]; xb1 = pb1[o * sb];
+    x.a0 = pa0[o * sa]; x.a1 = pa1[o * sa]; x.b0 = pb0[o * sb]; x.b1 = pb1[o * sb];
   };
-  auto mma = [&](const f32x4& xa0, const f32x4& xa1, const f32x4& xb0, const f32x4& xb1) {
+  // the loads of the next DW_AHEAD groups are in flight under a group's 16 MFMAs (a ring of register sets, the trip unrolled so
+  // that the sets swap roles without copies); sched_barrier keeps the scheduler from sinking the loads down to their MFMAs.
+  // The loop exists twice: whole tiles (no branch between the MFMAs) and edge tiles (the empty halves skipped).
+  constexpr int AH = DW_AHEAD;
+  Ops ring[AH + 1];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[j], xb0[j], c00, 0, 0, 0);
-      if (two_j) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa0[j], xb1[j], c01, 0, 0, 0);
-      if (two_i) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[j], xb0[j], c10, 0, 0, 0);
-      if (two_i && two_j) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa1[j], xb1[j], c11, 0, 0, 0);
+  for (int k = 0; k < AH; k++) fetch(g_lo + k, ring[k]);
+  auto sweep = [&](auto full) {
+    constexpr bool FULL = decltype(full)::value;
+    for (int g = g_lo; g < g_hi; g += AH + 1) {
+#pragma unroll
+      for (int k = 0; k <= AH; k++) {
+        fetch(g + k + AH, ring[(k + AH) % (AH + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + k < g_hi) {
+          const Ops& x = ring[k];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a0[j], x.b0[j], c00, 0, 0, 0);
+            if (FULL || two_j) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a0[j], x.b1[j], c01, 0, 0, 0);
+            if (FULL || two_i) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a1[j], x.b0[j], c10, 0, 0, 0);
+            if (FULL || (two_i && two_j)) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a1[j], x.b1[j], c11, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
-  // the NEXT group's four loads are in flight under this group's 16 MFMAs (two groups per trip: the registers swap roles
-  // without copies); sched_barrier keeps the scheduler from sinking the loads down to their MFMAs
-  fetch(g_lo, fa0, fa1, fb0, fb1);
-  for (int g = g_lo; g < g_hi; g += 2) {
-    fetch(g + 1, ga0, ga1, gb0, gb1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma(fa0, fa1, fb0, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(g + 2, fa0, fa1, fb0, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (g + 1 < g_hi) mma(ga0, ga1, gb0, gb1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  if (two_i && two_j) sweep(std::true_type{}); else sweep(std::false_type{});
   // C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float* w = a.ws + (size_t)slice * a.ws_stride + Ly.out_off;
 #pragma unroll

@@ -39,26 +39,25 @@ int odk_fail_(int code, const char* msg);   // odk_engine.hip
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int H1 = ODK_MLP_H1, H2 = ODK_MLP_H2, H3 = ODK_MLP_H3;
-constexpr int TM = 32;                 // samples per workgroup
+constexpr int TM = ODK_MLP_TILE;       // samples per workgroup
 constexpr int CH = 128;                // layer-1 chunk width = K-slice of layer 2
 constexpr int KIN_MAX = ODK_MLP_MAX_IN, NOUT_MAX = 32;
 constexpr int PC = CH + 4, P2 = H2 + 4, P3 = H3 + 4, P4 = NOUT_MAX + 4;   // LDS row pitches: multiples of 4 (16-byte reads), = 4 mod 8
 constexpr int PX_MAX = KIN_MAX + 4;
 constexpr int SLACK = 64;              // the k loops fetch (never use) up to two batches past a row's end
-static_assert(KIN_MAX % 8 == 0, "padded input width");
+static_assert(TM == 16 && KIN_MAX % 16 == 0, "tile = one 16-row MFMA block, padded input width");
 // forward LDS (floats): X | chunk | layer-2 output | slack;  the layer-3 output aliases X, the output layer's partial blocks alias the chunk
 constexpr int F_X = 0, F_C = F_X + TM * PX_MAX, F_H2 = F_C + TM * PC, F_TOTAL = F_H2 + TM * P2 + SLACK;
 static_assert(TM * P3 <= TM * PX_MAX, "layer-3 output must fit in the X region");
-static_assert(3 * 16 * 64 <= TM * PC, "output-layer partial blocks must fit in the chunk region");
-static_assert(F_TOTAL * 4 <= 80 * 1024, "two forward workgroups per CU");
+static_assert(3 * 2 * 4 * 64 <= TM * PC, "output-layer partial blocks must fit in the chunk region");
+static_assert(F_TOTAL * 4 <= 40 * 1024, "four forward workgroups per CU");
 // backward LDS: dz_top | dz3 | dz2 | slack
 constexpr int B_D4 = 0, B_D3 = B_D4 + TM * P4, B_D2 = B_D3 + TM * P3, B_TOTAL = B_D2 + TM * P2 + SLACK;
 
-__host__ __device__ constexpr int pad8(int k) { return (k + 7) & ~7; }
+__host__ __device__ constexpr int pad16(int k) { return (k + 15) & ~15; }
 
 struct Net {
   const float* x; const float* wf[4]; const float* wb[4]; const float* b[4];
@@ -69,40 +68,42 @@ struct Net {
 struct Args { Net net[2]; int nnets; long long* prof; };   // prof: phase timestamps of workgroup 0, wave 0 (tools only)
 #define ODK_STAMP(i) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[i] = clock64(); } while (0)
 
-// One GEMM phase of a wave: acc[blk] += A (32 samples x K, LDS) * Bp (packed [K / 4][N][4], columns col0 + 32 blk + c), over ng
-// k-groups of 8.  U groups per batch, register double-buffered: while a batch's MFMAs run (4 U NBLK MFMAs = 1 024 cycles of the
-// matrix pipe in every phase) the next batch's loads are in flight.  The FIRST batch of weights is fetched by prefetch(), which
-// the caller issues before the previous phase's epilogue and barrier (weights do not depend on them), so a phase starts with
-// its operands already on the way; A comes from LDS after the barrier.  __builtin_amdgcn_sched_barrier pins the order: left
-// alone, the scheduler sinks every load down to its MFMA (minimum register pressure = one exposed L2 round trip per MFMA).
-// Groups >= ng are fetched from group 0 (in bounds) and skipped.
+// One GEMM phase of a wave: acc[blk] += A (16 samples x K, LDS) * Bp (packed [K / 4][N][4], columns col0 + 16 blk + c), over ng
+// k-groups of 16 (lane (q, c): k = 16 G + 4 q + {0..3}; the group's MFMAs j = 0..3 use component j of both pieces).  U groups
+// per batch, register double-buffered: while a batch's MFMAs run (4 U NBLK MFMAs of 32 cycles) the next batch's loads are in
+// flight.  The FIRST batch of weights is fetched by prefetch(), which the caller issues before the previous phase's epilogue
+// and barrier (weights do not depend on them), so a phase starts with its operands already on the way; A comes from LDS after
+// the barrier.  __builtin_amdgcn_sched_barrier pins the order: left alone, the scheduler sinks every load down to its MFMA
+// (minimum register pressure = one exposed L2 round trip per MFMA).  Groups >= ng are fetched from group 0 (in bounds) and
+// skipped.  NBLK >= 2 everywhere: a 16x16x4 MFMA has 40 cycles of dependent latency for 32 of issue.
 #define ODK_PIN() __builtin_amdgcn_sched_barrier(0)
 template <int NBLK, int U>
 struct Phase {
   f32x4 fb[U][NBLK];
-  const f32x4* B; unsigned lane_off; int N2, ng;
+  const f32x4* B; unsigned lane_off, blk_off; int N4, ng;
   __device__ __forceinline__ void load_b(int G0, f32x4 (*xb)[NBLK]) const {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int G = G0 + u;
-      const f32x4* bp = B + (size_t)(G < ng ? G : 0) * N2;   // wave-uniform base, 32-bit lane offset
+      const f32x4* bp = B + (size_t)(G < ng ? G : 0) * N4;   // wave-uniform base, 32-bit lane offset
 #pragma unroll
-      for (int k = 0; k < NBLK; k++) xb[u][k] = bp[lane_off + 32 * k];
+      for (int k = 0; k < NBLK; k++) xb[u][k] = bp[lane_off + blk_off * k];
     }
   }
-  // Bp: the packed weight, ncols columns; this lane's first column col; ng groups starting at group g0
-  __device__ __forceinline__ void prefetch(const float* __restrict__ Bp, int ncols, int col, int r, int g0, int ng_) {
-    B = reinterpret_cast<const f32x4*>(Bp) + (size_t)(2 * g0) * ncols;
-    lane_off = (unsigned)(r * ncols + col); N2 = 2 * ncols; ng = ng_;
+  // Bp: the packed weight, ncols columns; this lane's column in block k: col + blk * k (blk = 16; the output layer, narrower
+  // than its blocks, passes clamped columns); ng groups starting at group g0
+  __device__ __forceinline__ void prefetch(const float* __restrict__ Bp, int ncols, int col, int q, int g0, int ng_, unsigned blk = 16) {
+    B = reinterpret_cast<const f32x4*>(Bp) + (size_t)(4 * g0) * ncols;
+    lane_off = (unsigned)(q * ncols + col); blk_off = blk; N4 = 4 * ncols; ng = ng_;
     load_b(0, fb);
     ODK_PIN();
   }
-  // A: LDS address of act[sample c][4 r] (16-byte aligned)
-  __device__ __forceinline__ void run(f32x16 (&acc)[NBLK], const float* A) {
+  // A: LDS address of act[sample c][4 q] (16-byte aligned)
+  __device__ __forceinline__ void run(f32x4 (&acc)[NBLK], const float* A) {
     f32x4 fa[U], ga[U], gb[U][NBLK];
     auto load_a = [&](int G0, f32x4* xa) {
 #pragma unroll
-      for (int u = 0; u < U; u++) xa[u] = *reinterpret_cast<const f32x4*>(A + 8 * (G0 + u));   // in bounds of the LDS image (SLACK)
+      for (int u = 0; u < U; u++) xa[u] = *reinterpret_cast<const f32x4*>(A + 16 * (G0 + u));   // in bounds of the LDS image (SLACK)
     };
     auto mma = [&](int G0, const f32x4* xa, const f32x4 (*xb)[NBLK]) {
 #pragma unroll
@@ -111,7 +112,7 @@ struct Phase {
 #pragma unroll
           for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int k = 0; k < NBLK; k++) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][j], xb[u][k][j], acc[k], 0, 0, 0);
+            for (int k = 0; k < NBLK; k++) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][j], xb[u][k][j], acc[k], 0, 0, 0);
         }
       }
     };
@@ -130,61 +131,66 @@ struct Phase {
   }
 };
 
-__device__ __forceinline__ int frag_row(int v, int r) { return (v & 3) + 8 * (v >> 2) + 4 * r; }
-__device__ __forceinline__ void zero(f32x16& a) {
+template <int N> __device__ __forceinline__ void zero(f32x4 (&a)[N]) {
 #pragma unroll
-  for (int v = 0; v < 16; v++) a[v] = 0.0f;
+  for (int k = 0; k < N; k++) a[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 }
 
-// bias + swish on one accumulator block: h -> LDS (next layer's A operand, row-major) and, when the buffers exist, h and
-// swish'(z) -> global memory in the quad-row layout [rows / 4][width][4] (the four rows a lane holds per register quad are one
-// 16-byte store; rows past the end of the batch are written as zeros, so the weight-gradient launch may read whole tiles).
-// hq / gq: this lane's column in the tile's first row quad.
-__device__ __forceinline__ void fwd_epilogue(const f32x16& acc, float bias, float* Ls, int P, float* hq, float* gq, int width, int r, int rows_valid) {
+// bias + swish on NBLK accumulator blocks (columns col0 + 16 k; accumulator register v = row 4 q + v): h -> LDS (next layer's A
+// operand, row-major) and, when the buffers exist, h and swish'(z) -> global memory in the quad-row layout [rows / 4][width][4]
+// (a lane's four rows are one 16-byte store; rows past the end of the batch are written as zeros, so the weight-gradient launch
+// may read whole tiles).  hq / gq: this lane's first column in ITS row quad.
+template <int NBLK>
+__device__ __forceinline__ void fwd_epilogue(const f32x4 (&acc)[NBLK], const float* bias, float* Ls, int P, float* hq, float* gq, int q, int rows_valid) {
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
+  for (int k = 0; k < NBLK; k++) {
     f32x4 hv, gv;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      const int v = 4 * q + t, row = frag_row(v, r);
-      const float z = acc[v] + bias;
+      const int row = 4 * q + t;
+      const float z = acc[k][t] + bias[k];
       const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
       const float h = z * sg;
-      Ls[row * P] = h;
+      Ls[row * P + 16 * k] = h;
       const bool live = row < rows_valid;
       hv[t] = live ? h : 0.0f;
       gv[t] = live ? sg + (h - h * sg) : 0.0f;   // swish'(z) = s + z s (1 - s)
     }
     if (hq) {
-      const size_t o = (size_t)(2 * q + r) * width * 4;
-      *reinterpret_cast<f32x4*>(hq + o) = hv;
-      *reinterpret_cast<f32x4*>(gq + o) = gv;
+      *reinterpret_cast<f32x4*>(hq + 64 * k) = hv;
+      *reinterpret_cast<f32x4*>(gq + 64 * k) = gv;
     }
   }
 }
 
-__global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(Args a) {
+__global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bid = blockIdx.x;
   const Net& N = a.net[(a.nnets > 1 && bid >= a.net[1].tile0) ? 1 : 0];
   const int m0 = (bid - N.tile0) * TM;
   const int rows_valid = N.n - m0;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane >> 5, c = lane & 31;
-  const int kin = N.n_in, k8 = pad8(kin), PX = k8 + 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
+  const int kin = N.n_in, k16 = pad16(kin), PX = k16 + 4;
   float* X = lds + F_X; float* C1 = lds + F_C; float* H2s = lds + F_H2; float* H3s = lds + F_X;
-  Phase<1, 4> p1;     // layer 1 (one 32-column block of the current chunk), layer 3, output layer
-  Phase<2, 2> p2;     // layer 2, K-slice = the chunk, 64 columns
+  Phase<2, 2> p1;     // layer 1 (32 columns of the current chunk), layer 3, output layer
+  Phase<4, 1> p2;     // layer 2, K-slice = the chunk, 64 columns
   ODK_STAMP(0);
-  p1.prefetch(N.wf[0], H1, w * 32 + c, r, 0, k8 >> 3);
-  const int nout = N.n_out, colc = c < nout ? c : nout - 1;
+  p1.prefetch(N.wf[0], H1, w * 32 + c, q, 0, k16 >> 4);
+  const int nout = N.n_out;
+  int colc[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) colc[k] = 16 * k + c < nout ? 16 * k + c : nout - 1;
   // this lane's biases: fetched now, used by the epilogues (a load there is an exposed round trip per block)
-  float bias1[H1 / CH], bias2[2];
+  float bias1[H1 / CH][2], bias2[4], bias3[2], bias4[2];
 #pragma unroll
-  for (int ch = 0; ch < H1 / CH; ch++) bias1[ch] = N.b[0][ch * CH + w * 32 + c];
+  for (int ch = 0; ch < H1 / CH; ch++)
 #pragma unroll
-  for (int k = 0; k < 2; k++) bias2[k] = N.b[1][w * 64 + 32 * k + c];
-  const float bias3 = N.b[2][w * 32 + c], bias4 = N.b[3][colc];
-  // ---- the tile's input rows, zero-padded to a multiple of 8 columns (rows past the end repeat the last one): all loads
+    for (int k = 0; k < 2; k++) bias1[ch][k] = N.b[0][ch * CH + w * 32 + 16 * k + c];
+#pragma unroll
+  for (int k = 0; k < 4; k++) bias2[k] = N.b[1][w * 64 + 16 * k + c];
+#pragma unroll
+  for (int k = 0; k < 2; k++) { bias3[k] = N.b[2][w * 32 + 16 * k + c]; bias4[k] = N.b[3][colc[k]]; }
+  // ---- the tile's input rows, zero-padded to a multiple of 16 columns (rows past the end repeat the last one): all loads
   // first, then the LDS stores (one exposed round trip instead of one per row)
   {
     constexpr int T = (KIN_MAX + 63) / 64;
@@ -200,7 +206,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(Args a) {
 #pragma unroll
     for (int i = 0; i < TM / 4; i++)
 #pragma unroll
-      for (int t = 0; t < T; t++) { const int k = lane + 64 * t; if (k < k8) X[(w + 4 * i) * PX + k] = k < kin ? xv[i][t] : 0.0f; }
+      for (int t = 0; t < T; t++) { const int k = lane + 64 * t; if (k < k16) X[(w + 4 * i) * PX + k] = k < kin ? xv[i][t] : 0.0f; }
   }
   __syncthreads();
   ODK_STAMP(1);
@@ -209,177 +215,175 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(Args a) {
   if (store) {   // quad-row copy of the input (the weight-gradient launch's operand)
     for (int k = threadIdx.x; k < kin; k += 256)
 #pragma unroll
-      for (int q = 0; q < TM / 4; q++) {
+      for (int qq = 0; qq < TM / 4; qq++) {
         f32x4 v;
 #pragma unroll
-        for (int t = 0; t < 4; t++) v[t] = X[(4 * q + t) * PX + k];
-        *reinterpret_cast<f32x4*>(N.xp + ((q0 + q) * kin + k) * 4) = v;
+        for (int t = 0; t < 4; t++) v[t] = X[(4 * qq + t) * PX + k];
+        *reinterpret_cast<f32x4*>(N.xp + ((q0 + qq) * kin + k) * 4) = v;
       }
   }
-  f32x16 acc2[2];
-  zero(acc2[0]); zero(acc2[1]);
+  const size_t ql = q0 + q;              // this lane's row quad
+  f32x4 acc2[4];
+  zero(acc2);
 #pragma unroll
   for (int ch = 0; ch < H1 / CH; ch++) {
-    f32x16 acc1[1];
-    zero(acc1[0]);
+    f32x4 acc1[2];
+    zero(acc1);
     const int col = ch * CH + w * 32 + c;
-    p1.run(acc1, X + c * PX + 4 * r);
+    p1.run(acc1, X + c * PX + 4 * q);
     ODK_STAMP(2 + 5 * ch);
-    p2.prefetch(N.wf[1], H2, w * 64 + c, r, ch * (CH / 8), CH / 8);
-    fwd_epilogue(acc1[0], bias1[ch], C1 + w * 32 + c, PC, store ? N.h[0] + (q0 * H1 + col) * 4 : nullptr,
-                 store ? N.g[0] + (q0 * H1 + col) * 4 : nullptr, H1, r, rows_valid);
+    p2.prefetch(N.wf[1], H2, w * 64 + c, q, ch * (CH / 16), CH / 16);
+    fwd_epilogue<2>(acc1, bias1[ch], C1 + w * 32 + c, PC, store ? N.h[0] + (ql * H1 + col) * 4 : nullptr, store ? N.g[0] + (ql * H1 + col) * 4 : nullptr, q,
+                    rows_valid);
     ODK_STAMP(3 + 5 * ch);
     __syncthreads();
     ODK_STAMP(4 + 5 * ch);
-    p2.run(acc2, C1 + c * PC + 4 * r);
+    p2.run(acc2, C1 + c * PC + 4 * q);
     ODK_STAMP(5 + 5 * ch);
-    if (ch + 1 < H1 / CH) p1.prefetch(N.wf[0], H1, col + CH, r, 0, k8 >> 3);
-    else p1.prefetch(N.wf[2], H3, w * 32 + c, r, 0, H2 / 8);
+    if (ch + 1 < H1 / CH) p1.prefetch(N.wf[0], H1, col + CH, q, 0, k16 >> 4);
+    else p1.prefetch(N.wf[2], H3, w * 32 + c, q, 0, H2 / 16);
     __syncthreads();
     ODK_STAMP(6 + 5 * ch);
   }
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int col = w * 64 + 32 * k + c;
-    fwd_epilogue(acc2[k], bias2[k], H2s + col, P2, store ? N.h[1] + (q0 * H2 + col) * 4 : nullptr,
-                 store ? N.g[1] + (q0 * H2 + col) * 4 : nullptr, H2, r, rows_valid);
+  {
+    const int col = w * 64 + c;
+    fwd_epilogue<4>(acc2, bias2, H2s + col, P2, store ? N.h[1] + (ql * H2 + col) * 4 : nullptr, store ? N.g[1] + (ql * H2 + col) * 4 : nullptr, q, rows_valid);
   }
   ODK_STAMP(22);
   __syncthreads();
   ODK_STAMP(23);
   {  // layer 3, columns w * 32 .. + 31
-    f32x16 acc3[1];
-    zero(acc3[0]);
+    f32x4 acc3[2];
+    zero(acc3);
     const int col = w * 32 + c;
-    p1.run(acc3, H2s + c * P2 + 4 * r);
+    p1.run(acc3, H2s + c * P2 + 4 * q);
     ODK_STAMP(24);
-    // output layer (<= 32 columns): wave w reduces k in [32 w, 32 w + 32)
-    p1.prefetch(N.wf[3], nout, colc, r, w * (H3 / 32), H3 / 32);
-    fwd_epilogue(acc3[0], bias3, H3s + col, P3, store ? N.h[2] + (q0 * H3 + col) * 4 : nullptr,
-                 store ? N.g[2] + (q0 * H3 + col) * 4 : nullptr, H3, r, rows_valid);   // X is dead: every wave passed two barriers since its last read
+    // output layer (<= 32 columns): wave w reduces k in [32 w, 32 w + 32); a lane whose column is past n_out reads the last
+    // column instead (its results are never stored)
+    p1.prefetch(N.wf[3], nout, colc[0], q, w * (H3 / 64), H3 / 64, (unsigned)(colc[1] - colc[0]));
+    fwd_epilogue<2>(acc3, bias3, H3s + col, P3, store ? N.h[2] + (ql * H3 + col) * 4 : nullptr, store ? N.g[2] + (ql * H3 + col) * 4 : nullptr, q,
+                    rows_valid);   // X is dead: every wave passed two barriers since its last read
   }
   ODK_STAMP(25);
   __syncthreads();
   ODK_STAMP(26);
   {  // partial blocks of the output layer folded by wave 0
-    f32x16 acc4[1];
-    zero(acc4[0]);
-    p1.run(acc4, H3s + c * P3 + 32 * w + 4 * r);
+    f32x4 acc4[2];
+    zero(acc4);
+    p1.run(acc4, H3s + c * P3 + 32 * w + 4 * q);
     ODK_STAMP(27);
     float* R = C1;
     if (w > 0) {
 #pragma unroll
-      for (int v = 0; v < 16; v++) R[((w - 1) * 16 + v) * 64 + lane] = acc4[0][v];
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) R[((w - 1) * 8 + 4 * k + t) * 64 + lane] = acc4[k][t];
     }
     __syncthreads();
     if (w == 0) {
 #pragma unroll
-      for (int v = 0; v < 16; v++) {
-        const int row = frag_row(v, r);
-        const float z = ((acc4[0][v] + R[v * 64 + lane]) + (R[(16 + v) * 64 + lane] + R[(32 + v) * 64 + lane])) + bias4;
-        if (c < nout && row < rows_valid) N.out[(size_t)(m0 + row) * nout + c] = z;
-      }
+      for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int row = 4 * q + t, e = 4 * k + t;
+          const float z = ((acc4[k][t] + R[e * 64 + lane]) + (R[(8 + e) * 64 + lane] + R[(16 + e) * 64 + lane])) + bias4[k];
+          if (16 * k + c < nout && row < rows_valid) N.out[(size_t)(m0 + row) * nout + 16 * k + c] = z;
+        }
     }
   }
   ODK_STAMP(28);
 }
 
-// dz = dh * swish'(z) on NBLK accumulator blocks (columns col0 + 32 k): -> global in the quad-row layout (the weight-gradient
-// launch reads it), -> LDS (next layer's A operand, row-major; may be null), and each block's column sums over the tile's 32
+// dz = dh * swish'(z) on NBLK accumulator blocks (columns col0 + 16 k): -> global in the quad-row layout (the weight-gradient
+// launch reads it), -> LDS (next layer's A operand, row-major; may be null), and each block's column sums over the tile's 16
 // rows -> partial[col].  swish' is zero in the rows past the end of the batch (the forward pass wrote it so), hence so is dz.
-// gq / dzq: this lane's first column in the tile's first row quad.  All swish' loads are issued before the first use.
+// gq / dzq: this lane's first column in ITS row quad.  All swish' loads are issued before the first use.
 template <int NBLK>
-__device__ __forceinline__ void bwd_epilogue(const f32x16 (&acc)[NBLK], const float* __restrict__ gq, float* dzq, int width, float* Ls, int P, float* partial, int r) {
-  f32x4 gv[NBLK][4];
+__device__ __forceinline__ void bwd_epilogue(const f32x4 (&acc)[NBLK], const float* __restrict__ gq, float* dzq, float* Ls, int P, float* partial, int q) {
+  f32x4 gv[NBLK];
 #pragma unroll
-  for (int k = 0; k < NBLK; k++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) gv[k][q] = *reinterpret_cast<const f32x4*>(gq + ((size_t)(2 * q + r) * width + 32 * k) * 4);
+  for (int k = 0; k < NBLK; k++) gv[k] = *reinterpret_cast<const f32x4*>(gq + 64 * k);
   ODK_PIN();
 #pragma unroll
   for (int k = 0; k < NBLK; k++) {
+    f32x4 dv;
     float s = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      f32x4 dv;
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int v = 4 * q + t;
-        const float dz = acc[k][v] * gv[k][q][t];
-        dv[t] = dz;
-        if (Ls) Ls[frag_row(v, r) * P + 32 * k] = dz;
-        s += dz;
-      }
-      *reinterpret_cast<f32x4*>(dzq + ((size_t)(2 * q + r) * width + 32 * k) * 4) = dv;
+    for (int t = 0; t < 4; t++) {
+      const float dz = acc[k][t] * gv[k][t];
+      dv[t] = dz;
+      if (Ls) Ls[(4 * q + t) * P + 16 * k] = dz;
+      s += dz;
     }
+    *reinterpret_cast<f32x4*>(dzq + 64 * k) = dv;
+    s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (r == 0) partial[32 * k] = s;
+    if (q == 0) partial[16 * k] = s;
   }
 }
 
-__global__ void __launch_bounds__(256, 2) mlp_bwd_kernel(Args a) {
+__global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bid = blockIdx.x;
   const Net& N = a.net[(a.nnets > 1 && bid >= a.net[1].tile0) ? 1 : 0];
   const int tile = bid - N.tile0, m0 = tile * TM;
   const int rows_valid = N.n - m0;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane >> 5, c = lane & 31;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
   const int nout = N.n_out;
   float* D4 = lds + B_D4; float* D3 = lds + B_D3; float* D2 = lds + B_D2;
-  Phase<1, 4> p3;     // dh3 = dout W4: columns w * 32 .. + 31, K = n_out
-  Phase<2, 2> p2;     // dh2 = dz3 W3: columns w * 64 .. + 63, K = 128
-  Phase<4, 1> p1;     // dh1 = dz2 W2: columns w * 128 .. + 127, K = 256
-  p3.prefetch(N.wb[3], H3, w * 32 + c, r, 0, pad8(nout) >> 3);
+  Phase<2, 2> p3;     // dh3 = dout W4: columns w * 32 .. + 31, K = n_out
+  Phase<4, 1> p2;     // dh2 = dz3 W3: columns w * 64 .. + 63, K = 128
+  Phase<8, 1> p1;     // dh1 = dz2 W2: columns w * 128 .. + 127, K = 256
+  p3.prefetch(N.wb[3], H3, w * 32 + c, q, 0, pad16(nout) >> 4);
   // ---- the tile of dLoss/dout, zero beyond the tile's rows / the layer's columns
   for (int e = threadIdx.x; e < TM * NOUT_MAX; e += 256) {
     const int rr = e >> 5, k = e & 31;
     D4[rr * P4 + k] = (rr < rows_valid && k < nout) ? N.dout[(size_t)(m0 + rr) * nout + k] : 0.0f;
   }
   __syncthreads();
-  const size_t q0 = (size_t)(m0 >> 2);   // the tile's first row quad
+  const size_t q0 = (size_t)(m0 >> 2), ql = q0 + q;   // the tile's first row quad, this lane's row quad
   if (threadIdx.x < nout) {   // output layer's bias gradient: tile sums of dout
     float s = 0.0f;
     for (int rr = 0; rr < TM; rr++) s += D4[rr * P4 + threadIdx.x];
     N.bias_partial[3][(size_t)tile * nout + threadIdx.x] = s;
   }
   for (int e = threadIdx.x; e < (TM / 4) * nout; e += 256) {   // quad-row copy of dout (the weight-gradient launch's operand)
-    const int q = e / nout, k = e - q * nout;
+    const int qq = e / nout, k = e - qq * nout;
     f32x4 v;
 #pragma unroll
-    for (int t = 0; t < 4; t++) v[t] = D4[(4 * q + t) * P4 + k];
-    *reinterpret_cast<f32x4*>(N.doutp + ((q0 + q) * nout + k) * 4) = v;
+    for (int t = 0; t < 4; t++) v[t] = D4[(4 * qq + t) * P4 + k];
+    *reinterpret_cast<f32x4*>(N.doutp + ((q0 + qq) * nout + k) * 4) = v;
   }
   {
-    f32x16 acc[1];
-    zero(acc[0]);
+    f32x4 acc[2];
+    zero(acc);
     const int col = w * 32 + c;
-    p3.run(acc, D4 + c * P4 + 4 * r);
-    p2.prefetch(N.wb[2], H2, w * 64 + c, r, 0, H3 / 8);
-    bwd_epilogue<1>(acc, N.g[2] + (q0 * H3 + col) * 4, N.dz[2] + (q0 * H3 + col) * 4, H3, D3 + col, P3, N.bias_partial[2] + (size_t)tile * H3 + col, r);
+    p3.run(acc, D4 + c * P4 + 4 * q);
+    p2.prefetch(N.wb[2], H2, w * 64 + c, q, 0, H3 / 16);
+    bwd_epilogue<2>(acc, N.g[2] + (ql * H3 + col) * 4, N.dz[2] + (ql * H3 + col) * 4, D3 + col, P3, N.bias_partial[2] + (size_t)tile * H3 + col, q);
   }
   __syncthreads();
   {
-    f32x16 acc[2];
-    zero(acc[0]); zero(acc[1]);
+    f32x4 acc[4];
+    zero(acc);
     const int col = w * 64 + c;
-    p2.run(acc, D3 + c * P3 + 4 * r);
-    p1.prefetch(N.wb[1], H1, w * 128 + c, r, 0, H2 / 8);
-    bwd_epilogue<2>(acc, N.g[1] + (q0 * H2 + col) * 4, N.dz[1] + (q0 * H2 + col) * 4, H2, D2 + col, P2, N.bias_partial[1] + (size_t)tile * H2 + col, r);
+    p2.run(acc, D3 + c * P3 + 4 * q);
+    p1.prefetch(N.wb[1], H1, w * 128 + c, q, 0, H2 / 16);
+    bwd_epilogue<4>(acc, N.g[1] + (ql * H2 + col) * 4, N.dz[1] + (ql * H2 + col) * 4, D2 + col, P2, N.bias_partial[1] + (size_t)tile * H2 + col, q);
   }
   __syncthreads();
   {
-    f32x16 acc[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) zero(acc[k]);
+    f32x4 acc[8];
+    zero(acc);
     const int col = w * 128 + c;
-    p1.run(acc, D2 + c * P2 + 4 * r);
-    bwd_epilogue<4>(acc, N.g[0] + (q0 * H1 + col) * 4, N.dz[0] + (q0 * H1 + col) * 4, H1, nullptr, 0, N.bias_partial[0] + (size_t)tile * H1 + col, r);
+    p1.run(acc, D2 + c * P2 + 4 * q);
+    bwd_epilogue<8>(acc, N.g[0] + (ql * H1 + col) * 4, N.dz[0] + (ql * H1 + col) * 4, nullptr, 0, N.bias_partial[0] + (size_t)tile * H1 + col, q);
   }
 }
 
 // ---- parameters -> packed weight copies.  Weight k: params[off .. off + rows * cols), torch layout [rows = n_out][cols = n_in];
-// forward copy at fwd_off: [pad8(cols) / 4][rows][4] (reduction over the input index), backward copy at bwd_off (< 0: none):
-// [pad8(rows) / 4][cols][4] (reduction over the output index).  Padding elements are never written: the caller zeroes the
+// forward copy at fwd_off: [pad16(cols) / 4][rows][4] (reduction over the input index), backward copy at bwd_off (< 0: none):
+// [pad16(rows) / 4][cols][4] (reduction over the output index).  Padding elements are never written: the caller zeroes the
 // buffers once.
 struct WeightTable { long long off[8], fwd[8], bwd[8]; int rows[8], cols[8]; int n; };
 
@@ -516,8 +520,8 @@ int fill_table(WeightTable& t, const odk_weight_table* h, long long n, long long
     if (!on) continue;
     const long long rc = (long long)t.rows[k] * t.cols[k];
     if (t.off[k] < 0 || t.rows[k] <= 0 || t.cols[k] <= 0 || t.off[k] + rc > n) return 1;
-    if (t.fwd[k] < 0 || (t.fwd[k] & 3) || t.fwd[k] + (long long)pad8(t.cols[k]) * t.rows[k] > nf) return 1;
-    if (t.bwd[k] >= 0 && ((t.bwd[k] & 3) || t.bwd[k] + (long long)pad8(t.rows[k]) * t.cols[k] > nb)) return 1;
+    if (t.fwd[k] < 0 || (t.fwd[k] & 3) || t.fwd[k] + (long long)pad16(t.cols[k]) * t.rows[k] > nf) return 1;
+    if (t.bwd[k] >= 0 && ((t.bwd[k] & 3) || t.bwd[k] + (long long)pad16(t.rows[k]) * t.cols[k] > nb)) return 1;
   }
   return 0;
 }

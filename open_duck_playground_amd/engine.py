@@ -60,7 +60,7 @@ class WeightTableC(C.Structure):
 
 
 MLP_HIDDEN = (512, 256, 128)     # ODK_MLP_H1..3: the hidden widths the fused network kernels are built for
-MLP_MAX_IN, MLP_MAX_OUT, MLP_TILE = 224, 32, 32
+MLP_MAX_IN, MLP_MAX_OUT, MLP_TILE = 224, 32, 16
 
 
 class OdkError(RuntimeError):
@@ -292,7 +292,7 @@ class ColsumFinalize:
 
 
 def quad_rows(n: int) -> int:
-    """Rows of a quad-row buffer for n samples: n rounded up to whole 32-sample tiles."""
+    """Rows of a quad-row buffer for n samples: n rounded up to whole 16-sample tiles (a multiple of 8, as odk_dw_gemm wants)."""
     return (int(n) + MLP_TILE - 1) // MLP_TILE * MLP_TILE
 
 
@@ -352,8 +352,8 @@ class DwGemm:
                                         _ptr(flat_out), _stream(flat_out)))
 
 
-def _pad8(k: int) -> int:
-    return (int(k) + 7) // 8 * 8
+def _pad16(k: int) -> int:
+    return (int(k) + 15) // 16 * 16
 
 
 class WeightTable:
@@ -371,9 +371,9 @@ class WeightTable:
         self.fwd, self.bwd = [], []
         for k, (o, r, c, bw) in enumerate(self.entries):
             t.off[k], t.rows[k], t.cols[k] = o, r, c
-            t.fwd_off[k] = fo; self.fwd.append((fo, _pad8(c) * r)); fo += _pad8(c) * r
+            t.fwd_off[k] = fo; self.fwd.append((fo, _pad16(c) * r)); fo += _pad16(c) * r
             if bw:
-                t.bwd_off[k] = bo; self.bwd.append((bo, _pad8(r) * c)); bo += _pad8(r) * c
+                t.bwd_off[k] = bo; self.bwd.append((bo, _pad16(r) * c)); bo += _pad16(r) * c
             else:
                 t.bwd_off[k] = -1; self.bwd.append(None)
         self.c, self.fwd_size, self.bwd_size = t, fo, max(bo, 4)
@@ -433,7 +433,7 @@ class FusedMLP:
     """One or two swish MLPs (n_in -> 512 -> 256 -> 128 -> n_out) whose forward pass is ONE launch and whose backward-data chain is
     ONE launch (`odk_mlp_forward` / `odk_mlp_backward`, csrc/odk_mlp.hip).  Each net is a dict of tensors:
       x [n, n_in], wf[4] (forward-packed weights: `WeightTable.fwd_view`), b[4], out [n, n_out]; for training also wb[4]
-      (backward-packed, wb[0] may be None), dout [n, n_out], bias_partial[4] ([ceil(n / 32), width]) and the flat QUAD-ROW
+      (backward-packed, wb[0] may be None), dout [n, n_out], bias_partial[4] ([ceil(n / 16), width]) and the flat QUAD-ROW
       buffers (`quad_rows(n)` x width floats, layout of `quad_pack`) xp (copy of x), h[3], g[3] (activations, swish'), dz[3],
       doutp (copy of dout) -- `train_buffers` allocates them."""
 
@@ -461,7 +461,7 @@ class FusedMLP:
                 raise OdkError("FusedMLP: n_in <= 224, n_out <= 32")
             _f32c(x, out, *nt["wf"], *nt["b"])
             for l in range(4):
-                if nt["wf"][l].numel() != _pad8(widths[l]) * widths[l + 1] or nt["b"][l].numel() != widths[l + 1]:
+                if nt["wf"][l].numel() != _pad16(widths[l]) * widths[l + 1] or nt["b"][l].numel() != widths[l + 1]:
                     raise OdkError(f"FusedMLP: layer {l} is not {widths[l]} -> {widths[l + 1]} (hidden widths are fixed at {MLP_HIDDEN})")
             d.x, d.out, d.n, d.n_in, d.n_out = x.data_ptr(), out.data_ptr(), int(n), int(n_in), int(n_out)
             for l in range(4):
@@ -475,7 +475,7 @@ class FusedMLP:
                     raise OdkError("FusedMLP: xp / doutp must be quad-row buffers of quad_rows(n) rows")
                 d.xp, d.doutp = nt["xp"].data_ptr(), nt["doutp"].data_ptr()
                 for l in range(1, 4):
-                    if nt["wb"][l].numel() != _pad8(widths[l + 1]) * widths[l]:
+                    if nt["wb"][l].numel() != _pad16(widths[l + 1]) * widths[l]:
                         raise OdkError(f"FusedMLP: backward-packed weight {l} has the wrong size")
                     d.wb[l] = nt["wb"][l].data_ptr()
                 for l in range(3):

@@ -85,12 +85,12 @@ def _mlp_params(n_in, n_out, g):
 
 
 def _packed_reference(Wk):
-    """[K, N] matrix (reduction index first) -> the packed layout [pad8(K) / 4][N][4], zero padding."""
+    """[K, N] matrix (reduction index first) -> the packed layout [pad16(K) / 4][N][4], zero padding."""
     K, N = Wk.shape
-    K8 = (K + 7) // 8 * 8
-    full = torch.zeros(K8, N, device=Wk.device)
+    K16 = (K + 15) // 16 * 16
+    full = torch.zeros(K16, N, device=Wk.device)
     full[:K] = Wk
-    return full.view(K8 // 4, 4, N).permute(0, 2, 1).contiguous().reshape(-1)
+    return full.view(K16 // 4, 4, N).permute(0, 2, 1).contiguous().reshape(-1)
 
 
 @pytest.mark.parametrize("n, n_in, n_out", [(320, 101, 28), (336, 212, 1), (5120, 85, 28), (77, 153, 1)])   # whole / ragged tiles, odd and even K, Joystick and Standing sizes
@@ -108,7 +108,7 @@ def test_fused_mlp_matches_torch(n, n_in, n_out):
     assert table.bwd_view(pb, 0) is None
     x = torch.randn(n, n_in, device="cuda", generator=g)
     dout = torch.randn(n, n_out, device="cuda", generator=g)
-    tiles = (n + 31) // 32
+    tiles = (n + 15) // 16
     buf = lambda w: torch.full((n, w), float("nan"), device="cuda")
     wf, wb = [table.fwd_view(pf, l) for l in range(4)], [table.bwd_view(pb, l) for l in range(4)]
     tb = engine.FusedMLP.train_buffers(n, n_in, n_out, "cuda")
@@ -163,7 +163,7 @@ def test_fused_mlp_two_networks_one_launch_and_adam_keeps_the_packed_copies():
     nets = []
     for n, n_in, n_out in ((320, 101, 28), (336, 212, 1)):
         widths, W, b, flat, table, pf, pb = _mlp_params(n_in, n_out, g)
-        tiles = (n + 31) // 32
+        tiles = (n + 15) // 16
         x, dout = torch.randn(n, n_in, device="cuda", generator=g), torch.randn(n, n_out, device="cuda", generator=g)
         mk = lambda: dict(x=x, wf=[table.fwd_view(pf, l) for l in range(4)], wb=[table.bwd_view(pb, l) for l in range(4)], b=b,
                           out=torch.empty(n, n_out, device="cuda"), dout=dout, **engine.FusedMLP.train_buffers(n, n_in, n_out, "cuda"))
