@@ -385,17 +385,17 @@ __global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
 // forward copy at fwd_off: [pad16(cols) / 4][rows][4] (reduction over the input index), backward copy at bwd_off (< 0: none):
 // [pad16(rows) / 4][cols][4] (reduction over the output index).  Padding elements are never written: the caller zeroes the
 // buffers once.
-struct WeightTable { long long off[8], fwd[8], bwd[8]; int rows[8], cols[8]; int n; };
+struct WeightTable { int off[8], fwd[8], bwd[8], rows[8], cols[8]; int n; };   // (32-bit: the buffers are far below 2^31 floats; checked by the host)
 
-__device__ __forceinline__ void packed_store(const WeightTable& t, long long i, float v, float* __restrict__ pf, float* __restrict__ pb) {
+__device__ __forceinline__ void packed_store(const WeightTable& t, int i, float v, float* __restrict__ pf, float* __restrict__ pb) {
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     if (k < t.n) {
-      const long long e = i - t.off[k];
-      if (e >= 0 && e < (long long)t.rows[k] * t.cols[k]) {
-        const int o = (int)(e / t.cols[k]), in = (int)(e - (long long)o * t.cols[k]);
-        pf[t.fwd[k] + ((long long)(in >> 2) * t.rows[k] + o) * 4 + (in & 3)] = v;
-        if (t.bwd[k] >= 0) pb[t.bwd[k] + ((long long)(o >> 2) * t.cols[k] + in) * 4 + (o & 3)] = v;
+      const unsigned e = (unsigned)(i - t.off[k]);     // i < off wraps to a huge value
+      if (e < (unsigned)(t.rows[k] * t.cols[k])) {
+        const unsigned o = e / (unsigned)t.cols[k], in = e - o * (unsigned)t.cols[k];
+        pf[t.fwd[k] + ((in >> 2) * t.rows[k] + o) * 4 + (in & 3)] = v;
+        if (t.bwd[k] >= 0) pb[t.bwd[k] + ((o >> 2) * t.cols[k] + in) * 4 + (o & 3)] = v;
         return;
       }
     }
@@ -403,7 +403,7 @@ __device__ __forceinline__ void packed_store(const WeightTable& t, long long i, 
 }
 
 __global__ void pack_weights_kernel(const float* __restrict__ p, float* __restrict__ pf, float* __restrict__ pb, long long n, WeightTable t) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) packed_store(t, i, p[i], pf, pb);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) packed_store(t, (int)i, p[i], pf, pb);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -440,7 +440,7 @@ __global__ void adam_packed_kernel(float* __restrict__ p, float* __restrict__ pf
     m[i] = mi; v[i] = vi;
     const float pi = p[i] - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
     p[i] = pi;
-    packed_store(t, i, pi, pf, pb);
+    packed_store(t, (int)i, pi, pf, pb);
   }
 }
 __global__ void sqnorm_p_kernel(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
@@ -511,17 +511,17 @@ int fill_args(Args& a, const odk_mlp_desc* nets, int count, bool backward, int& 
 }
 
 int fill_table(WeightTable& t, const odk_weight_table* h, long long n, long long nf, long long nb) {
-  if (!h || h->count < 0 || h->count > 8) return 1;
+  if (!h || h->count < 0 || h->count > 8 || n >= (1ll << 30) || nf >= (1ll << 30) || nb >= (1ll << 30)) return 1;
   t.n = h->count;
   for (int k = 0; k < 8; k++) {
     const bool on = k < h->count;
-    t.off[k] = on ? h->off[k] : 0; t.fwd[k] = on ? h->fwd_off[k] : 0; t.bwd[k] = on ? h->bwd_off[k] : -1;
+    t.off[k] = on ? (int)h->off[k] : 0; t.fwd[k] = on ? (int)h->fwd_off[k] : 0; t.bwd[k] = on ? (int)h->bwd_off[k] : -1;
     t.rows[k] = on ? h->rows[k] : 0; t.cols[k] = on ? h->cols[k] : 1;
     if (!on) continue;
-    const long long rc = (long long)t.rows[k] * t.cols[k];
-    if (t.off[k] < 0 || t.rows[k] <= 0 || t.cols[k] <= 0 || t.off[k] + rc > n) return 1;
-    if (t.fwd[k] < 0 || (t.fwd[k] & 3) || t.fwd[k] + (long long)pad16(t.cols[k]) * t.rows[k] > nf) return 1;
-    if (t.bwd[k] >= 0 && ((t.bwd[k] & 3) || t.bwd[k] + (long long)pad16(t.rows[k]) * t.cols[k] > nb)) return 1;
+    const long long rc = (long long)h->rows[k] * h->cols[k];
+    if (h->off[k] < 0 || t.rows[k] <= 0 || t.cols[k] <= 0 || h->off[k] + rc > n) return 1;
+    if (h->fwd_off[k] < 0 || (h->fwd_off[k] & 3) || h->fwd_off[k] + (long long)pad16(t.cols[k]) * t.rows[k] > nf) return 1;
+    if (h->bwd_off[k] >= 0 && ((h->bwd_off[k] & 3) || h->bwd_off[k] + (long long)pad16(t.rows[k]) * t.cols[k] > nb)) return 1;
   }
   return 0;
 }

@@ -304,7 +304,7 @@ class FlatLearner:
                             self.stats if cfg["normalize_advantage"] else None, self.vs.view(n), baseline, self.noise, self.dlogits,
                             self.dval_all[:n].view(n), self.losses, cfg["clipping_epsilon"], cfg["entropy_cost"], 1.0 / self.world)
             self.fused.backward()
-            self.fold()
+            self.fold()       # (as a side branch beside the weight-gradient launch the fork / join cost more than the 7 us it hides)
             self.dw_all()
             return
         # policy and value networks are independent until the loss head: two branches of the captured graph

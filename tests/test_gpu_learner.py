@@ -200,15 +200,21 @@ def test_fused_mlp_two_networks_one_launch_and_adam_keeps_the_packed_copies():
     assert torch.equal(table.fwd_view(pf, 1), _packed_reference(p2[4160:4160 + 840].view(40, 21).t()))
 
 
-@pytest.mark.parametrize("normalize_advantage, N", [(True, 64), (False, 64), (True, 1024)])   # N = 1024: 256 x 20 rows, the dW kernel's path
-def test_flat_learner_gradients_match_autograd(normalize_advantage, N):
-    """loss scalars and every parameter gradient of the fused step == autograd of ppo_loss (same entropy noise)."""
+@pytest.mark.parametrize("normalize_advantage, N, fused", [(True, 64, True), (False, 64, True), (True, 1024, True), (True, 64, False),
+                                                          (True, 64, None)])
+def test_flat_learner_gradients_match_autograd(normalize_advantage, N, fused, monkeypatch):
+    """loss scalars and every parameter gradient of the captured step == autograd of ppo_loss (same entropy noise): on the
+    whole-network kernels (csrc/odk_mlp.hip; N = 1024: the reference minibatch, 256 x 20 rows), on the library path (one GEMM
+    per layer: `fused` false), and for an architecture the fused kernels are not built for (`fused` None: falls back)."""
+    from open_duck_playground_amd.ppo import learner as LM
     from open_duck_playground_amd.ppo import train as T
     from open_duck_playground_amd.ppo.learner import FlatLearner, prepare_rollout
     from open_duck_playground_amd.ppo.networks import PPONetworks
     dev = torch.device("cuda")
     torch.manual_seed(0)
-    net = PPONetworks(101, 212, 14).to(dev)
+    if fused is False:
+        monkeypatch.setattr(LM, "_FUSED_MLP", False)
+    net = (PPONetworks(101, 212, 14) if fused is not None else PPONetworks(101, 212, 14, policy_hidden=(256, 128), value_hidden=(256, 256, 64))).to(dev)
     cfg = T.ppo_config(); cfg["normalize_advantage"] = normalize_advantage
     Tn, nmb = 20, 4
     data = _fake_rollout(N, Tn, dev)
@@ -217,7 +223,7 @@ def test_flat_learner_gradients_match_autograd(normalize_advantage, N):
     lr = FlatLearner(net, cfg, N // nmb, Tn, use_graph=False)
     idx = torch.arange(3, 3 + N // nmb, device=dev)
     lr.load_minibatch(prepare_rollout(net, data, cfg), idx)
-    assert lr.fused is not None                                 # the reference architecture runs on the fused network kernels
+    assert (lr.fused is not None) == (fused is True)            # the reference architecture runs on the fused network kernels
     lr._draw_noise(); lr._loss_and_grads()
     mb = {k: v[idx] for k, v in data.items()}
     mb["noise"] = lr.noise.view(N // nmb, Tn, 14).clone()
