@@ -476,6 +476,54 @@ class FlatLearner:
         self.sync_weights()
 
 
+class FusedPolicy:
+    """Policy inference for a rollout through the whole-network kernel (csrc/odk_mlp.hip in inference mode: ONE launch for the
+    four layers, nothing but the logits written) instead of four library GEMMs + three activation launches.  Holds its own
+    forward-packed copy of the policy weights: `refresh()` rebuilds it from the current parameters (once per rollout -- the
+    parameters do not move inside one).  `ok` is false for architectures the kernel is not built for."""
+
+    def __init__(self, net: PPONetworks, rows: int):
+        lins = list(net.policy.layers)
+        dev = lins[0].weight.device
+        self.net, self.rows, self.op, self.key = net, int(rows), None, None
+        self.ok = (dev.type == "cuda" and _FUSED_MLP and len(lins) == 4 and tuple(l.out_features for l in lins[:3]) == engine.MLP_HIDDEN
+                   and lins[0].in_features <= engine.MLP_MAX_IN and lins[3].out_features <= engine.MLP_MAX_OUT)
+        if not self.ok:
+            return
+        self.tables = [engine.WeightTable([(0, l.out_features, l.in_features, False)]) for l in lins]
+        self.wf = [torch.zeros(t.fwd_size, device=dev) for t in self.tables]
+        self.nobwd = torch.zeros(4, device=dev)
+        self.x = torch.empty(self.rows, lins[0].in_features, device=dev)
+        self.out = torch.empty(self.rows, lins[3].out_features, device=dev)
+
+    @torch.no_grad()
+    def refresh(self):
+        for lin, t, wf in zip(self.net.policy.layers, self.tables, self.wf):
+            engine.pack_weights(lin.weight.data.reshape(-1), wf, self.nobwd, t)
+
+    @torch.no_grad()
+    def __call__(self, obs):
+        """Logits [rows, 2 A] of the normalised observations (a persistent buffer: consume before the next call)."""
+        nrm = self.net.norm_obs
+        torch.sub(obs, nrm.mean, out=self.x)
+        self.x.div_(nrm.std)
+        key = tuple(l.bias.data_ptr() for l in self.net.policy.layers)     # FlatLearner re-homes the parameters once
+        if key != self.key:
+            self.op = engine.FusedMLP([dict(x=self.x, wf=self.wf, b=[l.bias.data for l in self.net.policy.layers], out=self.out)])
+            self.key = key
+        self.op.forward()
+        return self.out
+
+
+def fused_policy(net: PPONetworks, rows: int):
+    """The net's cached `FusedPolicy` for `rows` observations per call, or None when the fused kernel does not apply."""
+    cache = net.__dict__.setdefault("_fused_policy", {})
+    fp = cache.get(rows)
+    if fp is None:
+        fp = cache[rows] = FusedPolicy(net, rows)
+    return fp if fp.ok else None
+
+
 @torch.no_grad()
 def prepare_rollout(net: PPONetworks, data: Dict[str, torch.Tensor], cfg: Dict) -> Dict[str, torch.Tensor]:
     """Per-training-step preprocessing shared by all 128 minibatch steps: observation normalisation (the

@@ -175,11 +175,17 @@ def rollout(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generat
     """brax acting.generate_unroll: returns ([B, T, ...] transition tensors, final state)."""
     keys = ("obs", "priv", "raw_action", "log_prob", "reward", "done", "truncation")
     buf = {k: [] for k in keys}
+    fp = None
+    if state.obs["state"].is_cuda:   # all four policy layers in one launch (csrc/odk_mlp.hip, inference mode)
+        from .learner import fused_policy
+        fp = fused_policy(net, state.obs["state"].shape[0])
+        if fp is not None:
+            fp.refresh()
     for _ in range(unroll_length):
         obs, priv = state.obs["state"].clone(), state.obs["privileged_state"].clone()
         if obs.is_cuda:   # one launch for softplus / sample / tanh / log-density (csrc policy_sample_kernel)
             from .. import engine
-            logits = net.policy(net.norm_obs(obs))
+            logits = fp(obs) if fp is not None else net.policy(net.norm_obs(obs))
             A = net.action_size
             z = torch.zeros(obs.shape[0], A, device=obs.device) if deterministic else torch.randn(obs.shape[0], A, generator=gen, device=obs.device)
             raw, action, logp = engine.policy_sample(logits, z)

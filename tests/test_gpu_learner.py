@@ -460,3 +460,23 @@ def test_gae_treats_any_nonzero_flag_as_set_in_every_kernel():
         a = engine.gae(trunc, term, rew, val, boot, 0.95, 0.97)
         b = engine.gae(trunc * 3.0, term * 0.25, rew, val, boot, 0.95, 0.97)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_fused_policy_inference_matches_the_module():
+    """Rollout-side policy inference through the whole-network kernel == the torch module (same parameters, after an update too)."""
+    from open_duck_playground_amd.ppo.learner import fused_policy
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    torch.manual_seed(2)
+    net = PPONetworks(101, 212, 14).cuda()
+    obs = torch.randn(300, 101, device="cuda")
+    net.norm_obs.update(obs * 3 + 1)
+    fp = fused_policy(net, 300)
+    assert fp is not None and fused_policy(net, 300) is fp
+    for rnd in range(2):
+        fp.refresh()
+        ref = net.policy(net.norm_obs(obs))
+        torch.testing.assert_close(fp(obs), ref, rtol=2e-5, atol=2e-6)
+        with torch.no_grad():
+            for p_ in net.policy.parameters():
+                p_.mul_(1.01)
+    assert fused_policy(PPONetworks(101, 212, 14, policy_hidden=(64, 64)).cuda(), 8) is None
