@@ -201,8 +201,23 @@ int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_de
  * multiple of 8); ws_dev is a workspace of kslices * ws_stride floats laid out like out_dev (ws_stride >= every out_off +
  * n_out * n_in, a multiple of 4; every out_off and n_out * n_in a multiple of 4; ws_dev and out_dev 16-byte aligned); the slices
  * are folded in a fixed order, so the result is bit-reproducible.  dz_dev / h_dev / n_out / n_in / out_off / nrows are HOST arrays. */
+/* Optional extra work of odk_dw_gemm's slice-fold launch (the launch that finishes the gradient): the bias gradients
+ * bias_grad[f][c] = sum over the nblk[f] tile rows of bias_partial[f][tile, c] (what odk_colsum_fold does), and -- when
+ * sq_partials_dev is not NULL -- per-block partial sums of the squared norm of everything the launch wrote (all weight and bias
+ * gradients), for odk_adam_clip_packed(norm_blocks = nblocks): sq_partials_dev[0 .. nblocks), nblocks <= ODK_ADAM_MAX_PARTIALS is
+ * returned in the struct; step_counter_dev (may be NULL) is incremented by 1.  Host struct; the pointers inside are device pointers. */
+typedef struct odk_grad_finish {
+  const float* bias_partial[8];
+  float* bias_grad[8];
+  int width[8], nblk[8];
+  int nbias;
+  float* sq_partials_dev;
+  float* step_counter_dev;
+  int nblocks;               /* out */
+} odk_grad_finish;
 int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int* n_out, const int* n_in, const long long* out_off, int nlayers,
-                const int* nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, void* stream);
+                const int* nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, odk_grad_finish* finish /* may be NULL */,
+                void* stream);
 
 /* ---- fused policy / value networks (csrc/odk_mlp.hip): a swish MLP  n_in -> 512 -> 256 -> 128 -> n_out  (brax ppo.networks as
  * configured by the reference, common/runner.py:86-118) forward in ONE launch and its backward-data chain in ONE launch, on the
@@ -250,10 +265,12 @@ typedef struct odk_weight_table {
 /* (re)builds the packed copies from the parameters */
 int odk_pack_weights(const float* params_dev, long long n, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
                      const odk_weight_table* table, void* stream);
-/* odk_adam_clip that also keeps the packed copies current (every updated weight is written to all of its places) */
+/* odk_adam_clip that also keeps the packed copies current (every updated weight is written to all of its places).
+ * norm_blocks > 0: acc[2 .. 2 + norm_blocks) already hold the partial sums of the squared gradient norm and acc[1] the advanced step
+ * count (odk_dw_gemm with an odk_grad_finish whose sq_partials_dev = acc + 2, step_counter_dev = acc + 1): no norm launch of its own. */
 int odk_adam_clip_packed(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
                          float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
-                         const odk_weight_table* table, void* stream);
+                         const odk_weight_table* table, int norm_blocks, void* stream);
 /* colsum[f][c] = sum over the nblk[f] tile rows of partial[f][tile, c] for up to 8 layers in one launch (fixed order);
  * partial_dev / colsum_dev / widths / nblk are HOST arrays */
 int odk_colsum_fold(const float* const* partial_dev, float* const* colsum_dev, const int* widths, const int* nblk, int count, void* stream);

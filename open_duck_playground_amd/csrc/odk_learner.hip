@@ -12,6 +12,7 @@
 // captured into a HIP graph together with the GEMMs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -459,21 +460,57 @@ __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
   }
 }
 // out[off + e] = sum over the row slices, in slice order, for the weight ranges of the layers (e < count); four consecutive
-// elements per thread (offsets, counts and the slice stride are multiples of 4: checked by the host)
+// elements per thread (offsets, counts and the slice stride are multiples of 4: checked by the host).  The same launch can
+// finish the bias gradients (blocks past the first nb_reduce: 16 columns x 16 row phases each fold the per-tile column sums
+// of one layer, fixed order) and leave per-block partial sums of the squared gradient norm for the clip + Adam launch
+// (sq != null; block 0 then also advances the step counter) -- two launches less per SGD step.
 struct DwRanges { long long off[DW_MAX], count[DW_MAX]; int n; };
-__global__ void dw_reduce_kernel(const float* __restrict__ ws, long long ws_stride, int kslices, DwRanges rg, float* __restrict__ out) {
-  long long total = 0;
-  for (int k = 0; k < rg.n; k++) total += rg.count[k];
-  for (long long i = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x); i < total; i += 4 * (long long)gridDim.x * blockDim.x) {
-    long long e = i, off = rg.off[0];
+struct FinishArgs { const float* partial[8]; float* out[8]; int w[8], nblk[8], blk0[8]; int nbias, nb_reduce; float* sq; float* counter; };
+__global__ void __launch_bounds__(256) grad_finish_kernel(const float* __restrict__ ws, long long ws_stride, int kslices, DwRanges rg, float* __restrict__ out,
+                                                         FinishArgs fa) {
+  __shared__ float sh[16][17];
+  __shared__ float red[16];
+  float sq = 0.0f;
+  if ((int)blockIdx.x < fa.nb_reduce) {
+    long long total = 0;
+    for (int k = 0; k < rg.n; k++) total += rg.count[k];
+    for (long long i = 4 * ((long long)blockIdx.x * blockDim.x + threadIdx.x); i < total; i += 4 * (long long)fa.nb_reduce * blockDim.x) {
+      long long e = i, off = rg.off[0];
 #pragma unroll
-    for (int k = 0; k < DW_MAX - 1; k++) if (k + 1 < rg.n && e >= rg.count[k]) { e -= rg.count[k]; off = rg.off[k + 1]; } else break;
-    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int sl = 0; sl < kslices; sl++) {
-      const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)sl * ws_stride + off + e);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      for (int k = 0; k < DW_MAX - 1; k++) if (k + 1 < rg.n && e >= rg.count[k]) { e -= rg.count[k]; off = rg.off[k + 1]; } else break;
+      float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int sl = 0; sl < kslices; sl++) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)sl * ws_stride + off + e);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(out + off + e) = s;
+      sq += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
     }
-    *reinterpret_cast<float4*>(out + off + e) = s;
+  } else {
+    const int fb = (int)blockIdx.x - fa.nb_reduce;
+    int f = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) if (k < fa.nbias && fb >= fa.blk0[k]) f = k;
+    const int w = fa.w[f], nblk = fa.nblk[f];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = (fb - fa.blk0[f]) * 16 + tx;
+    const float* partial = fa.partial[f];
+    float s = 0.0f;
+    if (c < w)
+      for (int bk = ty; bk < nblk; bk += 16) s += partial[(size_t)bk * w + c];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < w) {
+      float t = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; k++) t += sh[k][tx];
+      fa.out[f][c] = t;
+      sq = t * t;
+    }
+  }
+  if (fa.sq) {   // (uniform)
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) { fa.sq[blockIdx.x] = sq; if (blockIdx.x == 0 && fa.counter) *fa.counter += 1.0f; }
   }
 }
 
@@ -591,7 +628,8 @@ extern "C" int odk_gather_rows(const float* const* src_dev, float* const* dst_de
 }
 
 extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int* n_out, const int* n_in, const long long* out_off,
-                           int nlayers, const int* nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, void* stream) {
+                           int nlayers, const int* nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, odk_grad_finish* finish,
+                           void* stream) {
   if (!dz_dev || !h_dev || !n_out || !n_in || !out_off || !ws_dev || !out_dev || nlayers <= 0 || nlayers > DW_MAX || !nrows || kslices <= 0 ||
       (kslices & 7) != 0 || (ws_stride & 3) != 0 || ((uintptr_t)ws_dev & 15) != 0 || ((uintptr_t)out_dev & 15) != 0)
     return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad arguments (1..8 layers, kslices a multiple of 8, ws_stride a multiple of 4, 16-byte aligned buffers)");
@@ -618,7 +656,27 @@ extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev
   long long total = 0;
   for (int l = 0; l < nlayers; l++) total += rg.count[l];
   int blocks = (int)((total / 4 + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws_dev, ws_stride, kslices, rg, out_dev);
+  FinishArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  int nfold = 0;
+  if (finish) {
+    if (finish->nbias < 0 || finish->nbias > 8) return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: finish: at most 8 bias gradients");
+    fa.nbias = finish->nbias;
+    for (int f = 0; f < 8; f++) {
+      const bool on = f < finish->nbias;
+      if (on && (!finish->bias_partial[f] || !finish->bias_grad[f] || finish->width[f] <= 0 || finish->nblk[f] <= 0))
+        return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: finish: bad bias-gradient entry");
+      fa.partial[f] = on ? finish->bias_partial[f] : nullptr; fa.out[f] = on ? finish->bias_grad[f] : nullptr;
+      fa.w[f] = on ? finish->width[f] : 0; fa.nblk[f] = on ? finish->nblk[f] : 0; fa.blk0[f] = on ? nfold : (1 << 30);
+      if (on) nfold += (finish->width[f] + 15) / 16;
+    }
+    fa.sq = finish->sq_partials_dev; fa.counter = finish->step_counter_dev;
+  }
+  const int cap = ODK_ADAM_MAX_PARTIALS - nfold;     // the partial sums of the norm must fit the Adam scratch
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: finish: too many bias columns");
+  fa.nb_reduce = blocks;
+  if (finish) finish->nblocks = blocks + nfold;
+  hipLaunchKernelGGL(grad_finish_kernel, dim3(blocks + nfold), dim3(256), 0, st, ws_dev, ws_stride, kslices, rg, out_dev, fa);
   return check_launch("odk_dw_gemm: launch failed");
 }

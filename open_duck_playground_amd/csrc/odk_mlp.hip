@@ -564,7 +564,7 @@ extern "C" int odk_pack_weights(const float* params_dev, long long n, float* fwd
 
 extern "C" int odk_adam_clip_packed(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
                                     float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
-                                    const odk_weight_table* table, void* stream) {
+                                    const odk_weight_table* table, int norm_blocks, void* stream) {
   WeightTable t;
   if (!params_dev || !fwd_packed_dev || !bwd_packed_dev || !grads_dev || !m_dev || !v_dev || !acc_dev || n <= 0 || fill_table(t, table, n, n_fwd, n_bwd))
     return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip_packed: bad arguments");
@@ -572,9 +572,10 @@ extern "C" int odk_adam_clip_packed(float* params_dev, const float* grads_dev, f
   const int threads = 256;
   int blocks = (int)((n + threads * 4 - 1) / (threads * 4));
   if (blocks > ODK_ADAM_MAX_PARTIALS) blocks = ODK_ADAM_MAX_PARTIALS;
-  hipLaunchKernelGGL(sqnorm_p_kernel, dim3(blocks), dim3(threads), 0, st, grads_dev, acc_dev, (int64_t)n);
-  hipLaunchKernelGGL(adam_packed_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, fwd_packed_dev, bwd_packed_dev, grads_dev, m_dev, v_dev, acc_dev, blocks,
-                     (int64_t)n, lr, b1, b2, eps, max_grad_norm, t);
+  if (norm_blocks < 0 || norm_blocks > ODK_ADAM_MAX_PARTIALS) return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip_packed: norm_blocks out of range");
+  if (norm_blocks == 0) hipLaunchKernelGGL(sqnorm_p_kernel, dim3(blocks), dim3(threads), 0, st, grads_dev, acc_dev, (int64_t)n);
+  hipLaunchKernelGGL(adam_packed_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, fwd_packed_dev, bwd_packed_dev, grads_dev, m_dev, v_dev, acc_dev,
+                     norm_blocks > 0 ? norm_blocks : blocks, (int64_t)n, lr, b1, b2, eps, max_grad_norm, t);
   return check_launch("odk_adam_clip_packed: launch failed");
 }
 

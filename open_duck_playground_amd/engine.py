@@ -53,6 +53,12 @@ class MlpDesc(C.Structure):
                 ("bias_partial", C.c_void_p * 4), ("n", C.c_int), ("n_in", C.c_int), ("n_out", C.c_int)]
 
 
+class GradFinish(C.Structure):
+    """odk_grad_finish (include/odk.h)."""
+    _fields_ = [("bias_partial", C.c_void_p * 8), ("bias_grad", C.c_void_p * 8), ("width", C.c_int * 8), ("nblk", C.c_int * 8), ("nbias", C.c_int),
+                ("sq_partials_dev", C.c_void_p), ("step_counter_dev", C.c_void_p), ("nblocks", C.c_int)]
+
+
 class WeightTableC(C.Structure):
     """odk_weight_table (include/odk.h)."""
     _fields_ = [("count", C.c_int), ("off", C.c_longlong * 8), ("rows", C.c_int * 8), ("cols", C.c_int * 8), ("fwd_off", C.c_longlong * 8),
@@ -123,14 +129,15 @@ def load_library() -> C.CDLL:
     L.odk_silu_bwd_colsum.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
     L.odk_colsum_partial.argtypes = [P, P, C.c_int, C.c_int, P]
     L.odk_colsum_finalize.argtypes = [PP, PP, C.POINTER(C.c_int), C.c_int, C.c_int, P]
-    L.odk_dw_gemm.argtypes = [PP, PP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int), C.c_int, P, C.c_longlong, P, P]
+    L.odk_dw_gemm.argtypes = [PP, PP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_int), C.c_int, P, C.c_longlong, P,
+                              C.POINTER(GradFinish), P]
     IP, LP = C.POINTER(C.c_int), C.POINTER(C.c_longlong)
     L.odk_mlp_forward.argtypes = [C.POINTER(MlpDesc), C.c_int, P]
     L.odk_mlp_backward.argtypes = [C.POINTER(MlpDesc), C.c_int, P]
     L.odk_mlp_set_profile.argtypes = [P]
     L.odk_mlp_set_profile.restype = None
     L.odk_pack_weights.argtypes = [P, C.c_longlong, P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), P]
-    L.odk_adam_clip_packed.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), P]
+    L.odk_adam_clip_packed.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), C.c_int, P]
     L.odk_colsum_fold.argtypes = [PP, PP, IP, IP, C.c_int, P]
     L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, P, C.c_int, C.c_longlong, P]
     _lib = L
@@ -315,9 +322,12 @@ class DwGemm:
     """Weight gradients out[off_l : off_l + n_out n_in] = dz_l^T h_l of up to 8 layers in one launch (`odk_dw_gemm`, f32
     matrix cores, split over `kslices` row slices folded in a fixed order).  `layers`: [(dz, h, n_out, n_in, offset in
     `flat_out`)] with dz / h flat QUAD-ROW buffers ([np / 4][width][4], `quad_pack`; np a multiple of 8, >= 8 * kslices);
-    `workspace`: kslices * workspace_stride(flat_out.numel()) floats."""
+    `workspace`: kslices * workspace_stride(flat_out.numel()) floats.
+    `bias`: [(tile sums [nblk, width], bias gradient [width], nblk)] folded by the same finishing launch (what `ColsumFold` does);
+    `acc`: the Adam scratch -- the finishing launch then also leaves the partial sums of the squared gradient norm in acc[2:] and
+    advances the step count acc[1]; `norm_blocks` is what `adam_clip_packed` wants to hear about it."""
 
-    def __init__(self, layers, flat_out, workspace, kslices: int = 16):
+    def __init__(self, layers, flat_out, workspace, kslices: int = 16, bias=(), acc=None):
         k = len(layers)
         _f32c(flat_out, workspace, *[t for dz, h, _, _, _ in layers for t in (dz, h)])
         if k > 8 or kslices % 8 != 0:
@@ -341,6 +351,23 @@ class DwGemm:
         self.n_out = (C.c_int * k)(*[int(l[2]) for l in layers])
         self.n_in = (C.c_int * k)(*[int(l[3]) for l in layers])
         self.off = (C.c_longlong * k)(*[int(l[4]) for l in layers])
+        self.finish, self.norm_blocks = None, 0
+        if bias or acc is not None:
+            if len(bias) > 8:
+                raise OdkError("DwGemm: at most 8 bias gradients")
+            f = GradFinish()
+            f.nbias = len(bias)
+            for i, (part, grad, nblk) in enumerate(bias):
+                _f32c(part, grad)
+                if part.numel() < int(nblk) * grad.numel():
+                    raise OdkError("DwGemm: bias tile sums too small")
+                f.bias_partial[i], f.bias_grad[i], f.width[i], f.nblk[i] = part.data_ptr(), grad.data_ptr(), int(grad.numel()), int(nblk)
+            if acc is not None:
+                _f32c(acc)
+                if acc.numel() < ADAM_ACC_FLOATS:
+                    raise OdkError("DwGemm: acc needs ADAM_ACC_FLOATS floats")
+                f.sq_partials_dev, f.step_counter_dev = acc.data_ptr() + 8, acc.data_ptr() + 4
+            self.finish, self.keep_finish = f, (bias, acc)
 
     @staticmethod
     def workspace_stride(numel: int) -> int:
@@ -349,7 +376,9 @@ class DwGemm:
     def __call__(self):
         _, flat_out, ws = self.keep
         _chk(load_library().odk_dw_gemm(self.dz, self.h, self.n_out, self.n_in, self.off, self.k, self.n, self.kslices, _ptr(ws), self.stride,
-                                        _ptr(flat_out), _stream(flat_out)))
+                                        _ptr(flat_out), C.byref(self.finish) if self.finish is not None else None, _stream(flat_out)))
+        if self.finish is not None and self.finish.sq_partials_dev:
+            self.norm_blocks = int(self.finish.nblocks)
 
 
 def _pad16(k: int) -> int:
@@ -399,14 +428,16 @@ def pack_weights(params, fwd_packed, bwd_packed, table: WeightTable):
 
 
 def adam_clip_packed(params, grads, m, v, acc, fwd_packed, bwd_packed, table: WeightTable, lr: float, max_grad_norm: float = 0.0, b1: float = 0.9,
-                     b2: float = 0.999, eps: float = 1e-8):
-    """`adam_clip` that also writes every updated weight to its places in the packed copies (`odk_adam_clip_packed`)."""
+                     b2: float = 0.999, eps: float = 1e-8, norm_blocks: int = 0):
+    """`adam_clip` that also writes every updated weight to its places in the packed copies (`odk_adam_clip_packed`).
+    `norm_blocks` > 0: the gradient's finishing launch (`DwGemm(..., acc=acc)`) already left that many partial sums of the
+    squared norm in acc[2:] and advanced the step count: no norm launch here."""
     _f32c(params, grads, m, v, acc, fwd_packed, bwd_packed)
     if acc.numel() < ADAM_ACC_FLOATS or fwd_packed.numel() < table.fwd_size or bwd_packed.numel() < table.bwd_size:
         raise OdkError("adam_clip_packed: acc needs ADAM_ACC_FLOATS floats, the packed buffers table.fwd_size / bwd_size")
     _chk(load_library().odk_adam_clip_packed(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
                                              max_grad_norm or 0.0, _ptr(fwd_packed), fwd_packed.numel(), _ptr(bwd_packed), bwd_packed.numel(),
-                                             C.byref(table.c), _stream(params)))
+                                             C.byref(table.c), int(norm_blocks), _stream(params)))
 
 
 class ColsumFold:

@@ -237,9 +237,11 @@ class FlatLearner:
     KEYS = ("obs", "priv", "raw_action", "log_prob", "reward", "termination", "truncation")
 
     def __init__(self, net: PPONetworks, cfg: Dict, B: int, T: int, world: int = 1, group=None, use_graph: bool = True,
-                 split_update=None):
+                 split_update=None, fused_norm: bool = True):
         """`split_update` (default: world > 1) runs the step as graph A (loss + gradients) -> all-reduce of the flat gradient
-        -> graph B (clip + Adam); tests force it at world size 1 to drive the RCCL stream hand-over on one GPU."""
+        -> graph B (clip + Adam); tests force it at world size 1 to drive the RCCL stream hand-over on one GPU.
+        `fused_norm` false: the gradient norm from its own launch even without an all-reduce (the summation order of the split
+        path: tests compare the two bit for bit)."""
         dev = next(net.parameters()).device
         if dev.type != "cuda":
             raise engine.OdkError("FlatLearner runs on the GPU only (the autograd path in train.py is the CPU reference)")
@@ -276,8 +278,12 @@ class FlatLearner:
             self.wtable = engine.WeightTable([(o, w.shape[0], w.shape[1], l > 0) for f in nets for l, (o, w) in enumerate(zip(f.goff, f.W))])
             self.packed_f, self.packed_b = z(self.wtable.fwd_size), z(self.wtable.bwd_size)
             self.fused = engine.FusedMLP([f.fused_desc(self.wtable, 4 * k, self.packed_f, self.packed_b) for k, f in enumerate(nets)])
-            self.fold = engine.ColsumFold([(t, f.gb[i]) for f in nets for i, t in enumerate(f.tile_sums)], [f.tiles for f in nets for _ in f.W])
-            self.dw_all = engine.DwGemm([l for f in nets for l in f.dw_layers], self.flat_g, self.dw_ws, kslices)
+            # the launch that folds the weight gradients' row slices also folds the bias gradients' tile sums and -- unless the
+            # gradient still has to be all-reduced -- leaves the partial sums of its squared norm for the clip + Adam launch
+            self.split_update = world > 1 if split_update is None else bool(split_update)
+            self.dw_all = engine.DwGemm([l for f in nets for l in f.dw_layers], self.flat_g, self.dw_ws, kslices,
+                                        bias=[(t, f.gb[i], f.tiles) for f in nets for i, t in enumerate(f.tile_sums)],
+                                        acc=None if (self.split_update or not fused_norm) else self.acc)
             self.sync_weights()
         self.losses = z(4)                          # running SUMS of (total, policy, value, entropy) over the steps since metrics()
         self.nsteps = 0
@@ -304,8 +310,7 @@ class FlatLearner:
                             self.stats if cfg["normalize_advantage"] else None, self.vs.view(n), baseline, self.noise, self.dlogits,
                             self.dval_all[:n].view(n), self.losses, cfg["clipping_epsilon"], cfg["entropy_cost"], 1.0 / self.world)
             self.fused.backward()
-            self.fold()       # (as a side branch beside the weight-gradient launch the fork / join cost more than the 7 us it hides)
-            self.dw_all()
+            self.dw_all()     # weight gradients; its finishing launch: slice fold + bias gradients (+ the norm's partial sums)
             return
         # policy and value networks are independent until the loss head: two branches of the captured graph
         cur = torch.cuda.current_stream()
@@ -362,7 +367,7 @@ class FlatLearner:
     def _update(self):
         if self.fused is not None:
             engine.adam_clip_packed(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.packed_f, self.packed_b, self.wtable,
-                                    self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0)
+                                    self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0, norm_blocks=self.dw_all.norm_blocks)
         else:
             engine.adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0)
 

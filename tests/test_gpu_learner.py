@@ -65,6 +65,22 @@ def test_dw_gemm_matches_torch_mm_and_is_reproducible():
     with pytest.raises(engine.OdkError):
         engine.DwGemm([(torch.zeros(32 * 8, device="cuda"), torch.zeros(32 * 8, device="cuda"), 8, 8, 0)], torch.zeros(64, device="cuda"),
                       torch.zeros(8 * 64, device="cuda"), 8)                              # fewer row groups than slices
+    # the finishing launch's extra duties: bias gradients from tile sums, partial sums of the squared norm, step count
+    n, (o, i) = 640, (40, 52)
+    dz, h = torch.randn(n, o, device="cuda", generator=g), torch.randn(n, i, device="cuda", generator=g)
+    tiles = [(torch.randn(37, 28, device="cuda", generator=g), 37), (torch.randn(5, 1, device="cuda", generator=g), 5), (torch.randn(40, 512, device="cuda", generator=g), 40)]
+    flat = torch.zeros(o * i, device="cuda")
+    bias = [torch.full((t.shape[1],), 3.0, device="cuda") for t, _ in tiles]
+    acc = torch.zeros(engine.ADAM_ACC_FLOATS, device="cuda"); acc[1] = 4.0
+    ws = torch.empty(8 * engine.DwGemm.workspace_stride(o * i), device="cuda")
+    op = engine.DwGemm([(engine.quad_pack(dz), engine.quad_pack(h), o, i, 0)], flat, ws, 8, bias=[(t.reshape(-1), b_, nb) for (t, nb), b_ in zip(tiles, bias)], acc=acc)
+    op()
+    assert float(acc[1]) == 5.0 and 0 < op.norm_blocks <= 1024
+    for (t, _), b_ in zip(tiles, bias):
+        torch.testing.assert_close(b_, t.sum(0), rtol=1e-5, atol=1e-5)
+    want = float(flat.double().square().sum() + sum(b_.double().square().sum() for b_ in bias))
+    got = float(acc[2:2 + op.norm_blocks].double().sum())
+    assert abs(got - want) < 1e-5 * want and float((flat.view(o, i).double() - dz.double().t() @ h.double()).abs().max()) < 1e-3
 
 
 def _mlp_params(n_in, n_out, g):
@@ -402,7 +418,7 @@ def test_split_update_over_rccl_matches_the_single_graph_step():
             n = PPONetworks(101, 212, 14).to(dev)
             n.norm_obs.update(data["obs"], dist.group.WORLD); n.norm_priv.update(data["priv"], dist.group.WORLD)
             nets.append(n)
-        one = FlatLearner(nets[0], cfg, 16, 20)
+        one = FlatLearner(nets[0], cfg, 16, 20, fused_norm=False)     # (the norm summed as the split path sums it: bit-comparable)
         two = FlatLearner(nets[1], cfg, 16, 20, world=1, group=dist.group.WORLD, split_update=True)
         assert one.graph_b is None and two.graph_b is not None
         prep = prepare_rollout(nets[0], data, cfg)
