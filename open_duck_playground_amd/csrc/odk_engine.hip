@@ -402,6 +402,9 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   const bool live = env < a.nenv;
   const int e = live ? env : a.nenv - 1;
   float* L = lds + slot * E::TOTAL;
+#ifdef ODK_PROFILE
+  const long long t_k0 = clock64();   // kernel-level stamps (profile build): prologue / substeps / epilogue pieces -> S_PROF slots 18, 19 + dbg tail
+#endif
   const int* RT = load_shared<S>(lds, 64 / G, a.m);   // ordered before its first use by the ODK_SYNCs below
 #ifdef ODK_POISON_LDS   // debug build: every read of LDS that was not written by this launch surfaces as NaN
   for (int k = lane; k < E::TOTAL; k += G) L[k] = __int_as_float(0x7fc00000);
@@ -482,6 +485,10 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     CTRL[u] = mt;
   }
   ODK_SYNC();
+#ifdef ODK_PROFILE
+  const long long t_k1 = clock64();
+  if (lane == 0) L[S::O_SCR + S::S_PROF + 18] = (float)(t_k1 - t_k0);
+#endif
   // ---- mjx_env.step: n_substeps x (forward + Euler)   (:420)
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
@@ -501,6 +508,9 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     if (last && a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
     euler_env<S, G>(L, ms, st, lane_s);
   }
+#ifdef ODK_PROFILE
+  const long long t_k2 = clock64();
+#endif
   // same trick for the epilogue: its table addresses would otherwise be shared (CSE) with the prologue's and carried
   // across the substep loop in scratch
   size_t opaque1 = 0;
@@ -647,6 +657,9 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     for (int k = lane; k < rec::NINFO; k += G) rco[R::INFO + k] = INFO[k];
     write_outputs<S, G>(a, L, env, reward, done_f, trunc, metrics, lane);
   }
+#ifdef ODK_PROFILE
+  if (a.dbg_lds && live && lane == 0) a.dbg_lds[(size_t)env * S::TOTAL + S::O_SCR + S::S_PROF + 19] = (float)(clock64() - t_k2);
+#endif
 }
 
 // mjx_env.step alone: ctrl = action buffer, no env logic (parity tests)

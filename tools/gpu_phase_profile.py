@@ -38,3 +38,5 @@ labels = ["P0 sincos", "P1 top-down sweep (pose,cdof,cvel,cacc,cinert)", "P2 bot
 print(f"{task} G={lanes} nenv={nenv}: cycles per env step (lane-0 clock, 10 forwards), total {tot:,.0f}")
 for i in range(18):
     print(f"  {labels[i]:48s} {mean[i]:12,.0f}  {100 * mean[i] / tot:5.1f}%")
+print(f"  {'env-step prologue (kernel start -> first substep)':48s} {mean[18]:12,.0f}  {100 * mean[18] / tot:5.1f}% of the substeps' total")
+print(f"  {'env-step epilogue (last Euler -> kernel end)':48s} {mean[19]:12,.0f}  {100 * mean[19] / tot:5.1f}% of the substeps' total")
