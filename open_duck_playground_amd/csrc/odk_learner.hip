@@ -375,7 +375,8 @@ __global__ void gather_rows_kernel(GatherArgs a, const long long* __restrict__ i
 // row group G takes rows 8 G + 4 r + {0..3} of column i0 + c (dz) / j0 + c (h), and the group's MFMAs j = 0..3 use component j
 // of both (v_mfma_f32_32x32x2_f32: A[m = c][k = r], B[k = r][n = c]).  No LDS, no transposes, 4 loads per 16 MFMAs (with one
 // 4-byte load per lane and MFMA -- the first version -- the CU's address unit was the limit: ~30 % of the matrix pipe).
-// One wave = one 64 x 64 output tile (2 x 2 MFMA blocks, 64 accumulator registers) over one slice of the rows (split-K);
+// One wave = one 128 x 64 output tile (4 x 2 MFMA blocks, 128 accumulator registers: 6 operand loads per 32 MFMAs) over one slice
+// of the rows (split-K);
 // partial tiles go to a workspace laid out like the flat gradient buffer, and dw_reduce_kernel folds the slices in a fixed
 // order (data-parallel replicas must stay bit-identical: no float atomics).  Block b runs on XCD b % 8: the blocks of an XCD
 // share the same row slices, so each XCD's L2 reads its part of dz / h once and serves all tiles from it.
@@ -388,7 +389,12 @@ constexpr int DW_MAX = 8;
 struct DwLayer { const float* dz; const float* h; int n_out, n_in, tj, tile0, ngroups; long long out_off; };   // ngroups = rows / 8
 struct DwArgs { DwLayer L[DW_MAX]; int nlayers, ntiles, kslices; float* ws; long long ws_stride; };
 
+#ifndef DW_MI
+#define DW_MI 4      // output tile of a wave: DW_MI x DW_MJ blocks of 32 x 32 (rows = n_out side, columns = n_in side)
+#define DW_MJ 2
+#endif
 __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
+  constexpr int MI = DW_MI, MJ = DW_MJ;
   const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
   const int per_xcd = a.kslices >> 3;                 // kslices is a multiple of 8
   const int slice = xcd * per_xcd + q / a.ntiles, tile = q % a.ntiles;
@@ -397,27 +403,37 @@ __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
   for (int k = 1; k < DW_MAX; k++) if (k < a.nlayers && tile >= a.L[k].tile0) l = k;
   const DwLayer& Ly = a.L[l];
   const int n_out = Ly.n_out, n_in = Ly.n_in;
-  const int t = tile - Ly.tile0, i0 = (t / Ly.tj) * 64, j0 = (t % Ly.tj) * 64;
+  const int t = tile - Ly.tile0, i0 = (t / Ly.tj) * (32 * MI), j0 = (t % Ly.tj) * (32 * MJ);
   const int lane = threadIdx.x, r = lane >> 5, c = lane & 31;
   const int g_lo = (int)((long long)slice * Ly.ngroups / a.kslices), g_hi = (int)((long long)(slice + 1) * Ly.ngroups / a.kslices);
-  const bool ma0 = i0 + c < n_out, ma1 = i0 + 32 + c < n_out, mb0 = j0 + c < n_in, mb1 = j0 + 32 + c < n_in;
   // Out-of-range columns read column 0 of the tile (always valid) and are NOT zeroed: entry (i, j) depends on column i of dz and
   // column j of h only, so whatever the clamped loads bring into the padding never reaches a stored element.
-  const f32x4* pa0 = reinterpret_cast<const f32x4*>(Ly.dz) + (size_t)r * n_out + (ma0 ? i0 + c : i0);
-  const f32x4* pa1 = reinterpret_cast<const f32x4*>(Ly.dz) + (size_t)r * n_out + (ma1 ? i0 + 32 + c : i0);
-  const f32x4* pb0 = reinterpret_cast<const f32x4*>(Ly.h) + (size_t)r * n_in + (mb0 ? j0 + c : j0);
-  const f32x4* pb1 = reinterpret_cast<const f32x4*>(Ly.h) + (size_t)r * n_in + (mb1 ? j0 + 32 + c : j0);
+  const f32x4* pa[MI]; const f32x4* pb[MJ];
+  bool ma[MI], mb[MJ];
+#pragma unroll
+  for (int k = 0; k < MI; k++) { ma[k] = i0 + 32 * k + c < n_out; pa[k] = reinterpret_cast<const f32x4*>(Ly.dz) + (size_t)r * n_out + (ma[k] ? i0 + 32 * k + c : i0); }
+#pragma unroll
+  for (int k = 0; k < MJ; k++) { mb[k] = j0 + 32 * k + c < n_in; pb[k] = reinterpret_cast<const f32x4*>(Ly.h) + (size_t)r * n_in + (mb[k] ? j0 + 32 * k + c : j0); }
   const size_t sa = (size_t)2 * n_out, sb = (size_t)2 * n_in;   // one row group = two row quads
-  f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
-  const bool two_i = i0 + 32 < n_out, two_j = j0 + 32 < n_in;   // wave-uniform: skip the empty halves of edge tiles
-  struct Ops { f32x4 a0, a1, b0, b1; };
+  f32x16 acc[MI][MJ];
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < MJ; j++)
+#pragma unroll
+      for (int v = 0; v < 16; v++) acc[i][j][v] = 0.0f;
+  const int ni = (n_out - i0 + 31) / 32, nj = (n_in - j0 + 31) / 32;   // wave-uniform: blocks of an edge tile that exist
+  struct Ops { f32x4 a[MI], b[MJ]; };
   auto fetch = [&](int g, Ops& x) {
     const size_t o = (size_t)(g < g_hi ? g : g_lo);   // past the slice: re-read its first group (in bounds, unused)
-    x.a0 = pa0[o * sa]; x.a1 = pa1[o * sa]; x.b0 = pb0[o * sb]; x.b1 = pb1[o * sb];
+#pragma unroll
+    for (int k = 0; k < MI; k++) x.a[k] = pa[k][o * sa];
+#pragma unroll
+    for (int k = 0; k < MJ; k++) x.b[k] = pb[k][o * sb];
   };
-  // the loads of the next DW_AHEAD groups are in flight under a group's 16 MFMAs (a ring of register sets, the trip unrolled so
+  // the loads of the next DW_AHEAD groups are in flight under a group's MFMAs (a ring of register sets, the trip unrolled so
   // that the sets swap roles without copies); sched_barrier keeps the scheduler from sinking the loads down to their MFMAs.
-  // The loop exists twice: whole tiles (no branch between the MFMAs) and edge tiles (the empty halves skipped).
+  // The loop exists twice: whole tiles (no branch between the MFMAs) and edge tiles (the missing blocks skipped).
   constexpr int AH = DW_AHEAD;
   Ops ring[AH + 1];
 #pragma unroll
@@ -432,32 +448,31 @@ __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
         if (g + k < g_hi) {
           const Ops& x = ring[k];
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a0[j], x.b0[j], c00, 0, 0, 0);
-            if (FULL || two_j) c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a0[j], x.b1[j], c01, 0, 0, 0);
-            if (FULL || two_i) c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a1[j], x.b0[j], c10, 0, 0, 0);
-            if (FULL || (two_i && two_j)) c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a1[j], x.b1[j], c11, 0, 0, 0);
-          }
+          for (int j4 = 0; j4 < 4; j4++)
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+              for (int j = 0; j < MJ; j++)
+                if (FULL || (i < ni && j < nj)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a[i][j4], x.b[j][j4], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
-  if (two_i && two_j) sweep(std::true_type{}); else sweep(std::false_type{});
+  if (ni >= MI && nj >= MJ) sweep(std::true_type{}); else sweep(std::false_type{});
   // C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float* w = a.ws + (size_t)slice * a.ws_stride + Ly.out_off;
 #pragma unroll
-  for (int v = 0; v < 16; v++) {
-    const int row = (v & 3) + 8 * (v >> 2) + 4 * r;
-    if (i0 + row < n_out) {
-      if (mb0) w[(size_t)(i0 + row) * n_in + j0 + c] = c00[v];
-      if (mb1) w[(size_t)(i0 + row) * n_in + j0 + 32 + c] = c01[v];
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int row = i0 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * r;
+      if (row < n_out) {
+#pragma unroll
+        for (int j = 0; j < MJ; j++)
+          if (mb[j]) w[(size_t)row * n_in + j0 + 32 * j + c] = acc[i][j][v];
+      }
     }
-    if (i0 + 32 + row < n_out) {
-      if (mb0) w[(size_t)(i0 + 32 + row) * n_in + j0 + c] = c10[v];
-      if (mb1) w[(size_t)(i0 + 32 + row) * n_in + j0 + 32 + c] = c11[v];
-    }
-  }
 }
 // out[off + e] = sum over the row slices, in slice order, for the weight ranges of the layers (e < count); four consecutive
 // elements per thread (offsets, counts and the slice stride are multiples of 4: checked by the host).  The same launch can
@@ -644,8 +659,8 @@ extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev
         return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad layer (rows a multiple of 8 and >= 8 * kslices, offset and element count multiples of 4, "
                                           "16-byte aligned operands)");
       L.dz = dz_dev[l]; L.h = h_dev[l]; L.n_out = n_out[l]; L.n_in = n_in[l]; L.out_off = out_off[l]; L.ngroups = nrows[l] / 8;
-      L.tj = (n_in[l] + 63) / 64; L.tile0 = a.ntiles;
-      a.ntiles += ((n_out[l] + 63) / 64) * L.tj;
+      L.tj = (n_in[l] + 32 * DW_MJ - 1) / (32 * DW_MJ); L.tile0 = a.ntiles;
+      a.ntiles += ((n_out[l] + 32 * DW_MI - 1) / (32 * DW_MI)) * L.tj;
       rg.off[l] = out_off[l]; rg.count[l] = (long long)n_out[l] * n_in[l];
     } else {
       L.dz = L.h = nullptr; L.n_out = L.n_in = L.tj = L.ngroups = 0; L.tile0 = 1 << 30; L.out_off = 0; rg.off[l] = 0; rg.count[l] = 0;
