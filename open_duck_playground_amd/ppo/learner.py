@@ -2,13 +2,16 @@
 
 brax runs `num_updates_per_batch * num_minibatches` (= 128) clipped-Adam steps per training step
 (reference common/runner.py:104-118 -> brax ppo.train); each is ~10 small GEMMs surrounded by ~300
-element-wise ops, so under an autograd engine it is launch-bound.  Here one step is a single HIP graph of
+element-wise ops, so under an autograd engine it is launch-bound.  Here one step is a single HIP graph of 8 launches
+(the reference architecture, in -> 512 -> 256 -> 128 -> out; csrc/odk_mlp.hip, csrc/odk_learner.hip):
 
-    7 + 7 forward GEMM/activation launches (hipBLASLt on MFMA, bias fused; policy and value networks are two
-    parallel branches of the graph, forward and backward),
-    1 GAE launch, 1 loss-head launch (forward + gradients, csrc/odk_learner.hip),
-    14 + 14 backward launches writing straight into one flat gradient buffer,
-    [one RCCL all-reduce of that buffer when data-parallel], 2 launches for clip + Adam on the flat buffers.
+    minibatch gather, forward of both networks (all layers, f32 matrix cores), GAE, loss head (forward + gradients),
+    backward-data of both networks, weight gradients of all 8 layers, their finishing launch (slice fold, bias gradients,
+    partial sums of the gradient norm), clip + Adam (which also refreshes the packed weight copies the kernels read);
+    data-parallel: an RCCL all-reduce of the flat gradient (and the norm in its own launch) before the clip + Adam.
+
+Other architectures (and ODK_LEARNER_FUSED=0) run the library path: one hipBLASLt GEMM per layer with the activation /
+bias-gradient kernels between them, policy and value networks as two parallel branches of the graph.
 
 Parameters live in ONE flat fp32 buffer (the modules' `.data` are views of it, so the rollout policy sees
 every update), gradients in another: the data-parallel exchange is exactly one all-reduce of 1.97 MB.
@@ -265,11 +268,12 @@ class FlatLearner:
         self.vs, self.adv, self.stats = z(B, T), z(B, T), z(2)
         self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
         fused = self.policy.fused_ok() and self.value.fused_ok()
+        self.split_update = world > 1 if split_update is None else bool(split_update)
         self.policy.bind(self.static["obs"].view(n, -1), self.dlogits, fused)
         self.value.bind(self.priv_all, self.dval_all, fused)
         # whole-network launches (csrc/odk_mlp.hip): forward of both networks = 1 launch, backward-data of both = 1 launch, the
-        # bias gradients' fold = 1, the weight gradients of all 8 layers = 1 (+ its slice fold); the kernels read the weights
-        # from packed copies (16-byte pieces along the reduction index) that the Adam launch keeps current
+        # weight gradients of all 8 layers = 1 + its finishing launch; the kernels read the weights from packed copies (16-byte
+        # pieces along the reduction index) that the Adam launch keeps current
         self.fused = None
         if fused:
             kslices = 16
@@ -280,17 +284,15 @@ class FlatLearner:
             self.fused = engine.FusedMLP([f.fused_desc(self.wtable, 4 * k, self.packed_f, self.packed_b) for k, f in enumerate(nets)])
             # the launch that folds the weight gradients' row slices also folds the bias gradients' tile sums and -- unless the
             # gradient still has to be all-reduced -- leaves the partial sums of its squared norm for the clip + Adam launch
-            self.split_update = world > 1 if split_update is None else bool(split_update)
             self.dw_all = engine.DwGemm([l for f in nets for l in f.dw_layers], self.flat_g, self.dw_ws, kslices,
                                         bias=[(t, f.gb[i], f.tiles) for f in nets for i, t in enumerate(f.tile_sums)],
                                         acc=None if (self.split_update or not fused_norm) else self.acc)
             self.sync_weights()
         self.losses = z(4)                          # running SUMS of (total, policy, value, entropy) over the steps since metrics()
         self.nsteps = 0
-        self.split_update = world > 1 if split_update is None else bool(split_update)
         self.graph_a = self.graph_b = None
         self._gather = None; self._gather_src = ()
-        self.side = torch.cuda.Stream() if os.environ.get("ODK_LEARNER_BRANCHES", "1") == "1" else None   # policy || value
+        self.side = torch.cuda.Stream() if (not fused and os.environ.get("ODK_LEARNER_BRANCHES", "1") == "1") else None   # library path: policy || value
         self.sample_noise = True                    # plain-launch path only: tests inject self.noise instead
         self._pool, self._pool_k = None, 0
         if use_graph:
