@@ -26,10 +26,14 @@ class Evaluator:
         self._acc = None              # persistent accumulators (the captured graph updates them in place)
         self._graph = None
         self._graph_key = None
+        self._fp = None
 
     def _one_step(self, net):
         st = self._state
-        loc = net.policy(net.norm_obs(st.obs["state"]))[..., : net.action_size]   # the mode needs no scale (softplus skipped)
+        # all four policy layers in one launch when the architecture allows (csrc/odk_mlp.hip, inference mode); the mode needs
+        # no scale (softplus skipped)
+        logits = self._fp(st.obs["state"]) if self._fp is not None else net.policy(net.norm_obs(st.obs["state"]))
+        loc = logits[..., : net.action_size]
         st = self.env.step(st, torch.tanh(loc).contiguous())
         a = self._acc
         if a["matrix"] is not None:
@@ -69,6 +73,11 @@ class Evaluator:
             for v in a["sums"].values():
                 v.zero_()
         nsteps = self.episode_length // self.action_repeat
+        if dev.type == "cuda":
+            from .learner import fused_policy
+            self._fp = fused_policy(net, n)
+            if self._fp is not None:
+                self._fp.refresh()                               # its packed weight copy <- the current parameters
         if dev.type == "cuda" and self.use_graph:
             # the env's outputs are persistent buffers and the accumulators are updated in place, so one step replays as
             # a graph; re-captured when the parameters move (FlatLearner re-homes them in its flat buffer)

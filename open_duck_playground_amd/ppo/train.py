@@ -181,13 +181,16 @@ def rollout(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generat
         fp = fused_policy(net, state.obs["state"].shape[0])
         if fp is not None:
             fp.refresh()
-    for _ in range(unroll_length):
+    noise = None
+    if state.obs["state"].is_cuda and not deterministic:   # the unroll's sampling noise in one launch instead of one per step
+        noise = torch.randn(unroll_length, state.obs["state"].shape[0], net.action_size, generator=gen, device=state.obs["state"].device)
+    for t in range(unroll_length):
         obs, priv = state.obs["state"].clone(), state.obs["privileged_state"].clone()
         if obs.is_cuda:   # one launch for softplus / sample / tanh / log-density (csrc policy_sample_kernel)
             from .. import engine
             logits = fp(obs) if fp is not None else net.policy(net.norm_obs(obs))
             A = net.action_size
-            z = torch.zeros(obs.shape[0], A, device=obs.device) if deterministic else torch.randn(obs.shape[0], A, generator=gen, device=obs.device)
+            z = torch.zeros(obs.shape[0], A, device=obs.device) if deterministic else noise[t]
             raw, action, logp = engine.policy_sample(logits, z)
         else:
             loc, scale = net.dist_params(obs)
