@@ -235,6 +235,8 @@ int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int
 #define ODK_MLP_TILE 16        /* samples per workgroup */
 typedef struct odk_mlp_desc {
   const float* x;            /* [n, n_in] network input */
+  const float* in_mean;      /* forward, optional (both or none): the input is normalised on load, x <- (x - in_mean) / in_std, per column */
+  const float* in_std;
   const float* wf[4];        /* forward-packed weights of the four layers (16-byte aligned) */
   const float* wb[4];        /* backward-packed weights (wb[0] is not read: the input's gradient is never formed) */
   const float* b[4];         /* biases */

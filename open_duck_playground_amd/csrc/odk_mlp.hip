@@ -60,7 +60,7 @@ constexpr int B_D4 = 0, B_D3 = B_D4 + TM * P4, B_D2 = B_D3 + TM * P3, B_TOTAL = 
 __host__ __device__ constexpr int pad16(int k) { return (k + 15) & ~15; }
 
 struct Net {
-  const float* x; const float* wf[4]; const float* wb[4]; const float* b[4];
+  const float* x; const float* in_mean; const float* in_std; const float* wf[4]; const float* wb[4]; const float* b[4];
   float* h[3]; float* g[3]; float* out; float* xp;
   const float* dout; float* dz[3]; float* doutp; float* bias_partial[4];
   int n, n_in, n_out, tile0;
@@ -201,6 +201,15 @@ __global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
       const float* src = N.x + (size_t)row * kin;
 #pragma unroll
       for (int t = 0; t < T; t++) { const int k = lane + 64 * t; xv[i][t] = src[k < kin ? k : 0]; }
+    }
+    if (N.in_mean) {   // observation normaliser folded into the load: (x - mean) / std, IEEE division (bit-identical to the torch ops it replaces)
+      float mu[T], sd[T];
+#pragma unroll
+      for (int t = 0; t < T; t++) { const int k = lane + 64 * t; mu[t] = N.in_mean[k < kin ? k : 0]; sd[t] = N.in_std[k < kin ? k : 0]; }
+#pragma unroll
+      for (int i = 0; i < TM / 4; i++)
+#pragma unroll
+        for (int t = 0; t < T; t++) xv[i][t] = (xv[i][t] - mu[t]) / sd[t];
     }
     ODK_PIN();
 #pragma unroll
@@ -496,12 +505,13 @@ int fill_args(Args& a, const odk_mlp_desc* nets, int count, bool backward, int& 
     const bool has_act = d.h[0] && d.h[1] && d.h[2] && d.g[0] && d.g[1] && d.g[2] && d.xp;
     if (!backward) {
       if (!d.x || !d.out) { err = "missing x / out"; return 1; }
+      if ((d.in_mean != nullptr) != (d.in_std != nullptr)) { err = "in_mean / in_std: both or none"; return 1; }
       if (!has_act && (d.h[0] || d.h[1] || d.h[2] || d.g[0] || d.g[1] || d.g[2] || d.xp)) { err = "xp / h / g buffers: all seven or none"; return 1; }
     } else {
       if (!d.dout || !d.doutp || !d.g[0] || !d.g[1] || !d.g[2] || !d.dz[0] || !d.dz[1] || !d.dz[2] || !d.bias_partial[0] || !d.bias_partial[1] ||
           !d.bias_partial[2] || !d.bias_partial[3]) { err = "backward needs dout, doutp, g, dz and bias_partial"; return 1; }
     }
-    N.x = d.x; N.out = d.out; N.dout = d.dout; N.xp = d.xp; N.doutp = d.doutp; N.n = d.n; N.n_in = d.n_in; N.n_out = d.n_out; N.tile0 = tiles;
+    N.x = d.x; N.in_mean = d.in_mean; N.in_std = d.in_std; N.out = d.out; N.dout = d.dout; N.xp = d.xp; N.doutp = d.doutp; N.n = d.n; N.n_in = d.n_in; N.n_out = d.n_out; N.tile0 = tiles;
     for (int l = 0; l < 4; l++) { N.wf[l] = d.wf[l]; N.wb[l] = d.wb[l]; N.b[l] = d.b[l]; N.bias_partial[l] = d.bias_partial[l]; }
     for (int l = 0; l < 3; l++) { N.h[l] = has_act ? d.h[l] : nullptr; N.g[l] = d.g[l]; N.dz[l] = d.dz[l]; }
     if (!backward && !has_act) for (int l = 0; l < 3; l++) N.g[l] = nullptr;

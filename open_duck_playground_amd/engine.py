@@ -48,7 +48,7 @@ class Outputs(C.Structure):
 
 class MlpDesc(C.Structure):
     """odk_mlp_desc (include/odk.h)."""
-    _fields_ = [("x", C.c_void_p), ("wf", C.c_void_p * 4), ("wb", C.c_void_p * 4), ("b", C.c_void_p * 4), ("xp", C.c_void_p), ("h", C.c_void_p * 3),
+    _fields_ = [("x", C.c_void_p), ("in_mean", C.c_void_p), ("in_std", C.c_void_p), ("wf", C.c_void_p * 4), ("wb", C.c_void_p * 4), ("b", C.c_void_p * 4), ("xp", C.c_void_p), ("h", C.c_void_p * 3),
                 ("g", C.c_void_p * 3), ("out", C.c_void_p), ("dout", C.c_void_p), ("doutp", C.c_void_p), ("dz", C.c_void_p * 3),
                 ("bias_partial", C.c_void_p * 4), ("n", C.c_int), ("n_in", C.c_int), ("n_out", C.c_int)]
 
@@ -463,7 +463,8 @@ class ColsumFold:
 class FusedMLP:
     """One or two swish MLPs (n_in -> 512 -> 256 -> 128 -> n_out) whose forward pass is ONE launch and whose backward-data chain is
     ONE launch (`odk_mlp_forward` / `odk_mlp_backward`, csrc/odk_mlp.hip).  Each net is a dict of tensors:
-      x [n, n_in], wf[4] (forward-packed weights: `WeightTable.fwd_view`), b[4], out [n, n_out]; for training also wb[4]
+      x [n, n_in], wf[4] (forward-packed weights: `WeightTable.fwd_view`), b[4], out [n, n_out], optionally in_mean / in_std [n_in]
+      (the input is normalised on load); for training also wb[4]
       (backward-packed, wb[0] may be None), dout [n, n_out], bias_partial[4] ([ceil(n / 16), width]) and the flat QUAD-ROW
       buffers (`quad_rows(n)` x width floats, layout of `quad_pack`) xp (copy of x), h[3], g[3] (activations, swish'), dz[3],
       doutp (copy of dout) -- `train_buffers` allocates them."""
@@ -495,6 +496,11 @@ class FusedMLP:
                 if nt["wf"][l].numel() != _pad16(widths[l]) * widths[l + 1] or nt["b"][l].numel() != widths[l + 1]:
                     raise OdkError(f"FusedMLP: layer {l} is not {widths[l]} -> {widths[l + 1]} (hidden widths are fixed at {MLP_HIDDEN})")
             d.x, d.out, d.n, d.n_in, d.n_out = x.data_ptr(), out.data_ptr(), int(n), int(n_in), int(n_out)
+            if nt.get("in_mean") is not None:      # normalise the input on load: (x - in_mean) / in_std
+                _f32c(nt["in_mean"], nt["in_std"])
+                if nt["in_mean"].numel() != n_in or nt["in_std"].numel() != n_in:
+                    raise OdkError("FusedMLP: in_mean / in_std must have n_in entries")
+                d.in_mean, d.in_std = nt["in_mean"].data_ptr(), nt["in_std"].data_ptr()
             for l in range(4):
                 d.wf[l], d.b[l] = nt["wf"][l].data_ptr(), nt["b"][l].data_ptr()
             train = "h" in nt

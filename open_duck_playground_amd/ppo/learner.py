@@ -500,7 +500,6 @@ class FusedPolicy:
         self.tables = [engine.WeightTable([(0, l.out_features, l.in_features, False)]) for l in lins]
         self.wf = [torch.zeros(t.fwd_size, device=dev) for t in self.tables]
         self.nobwd = torch.zeros(4, device=dev)
-        self.x = torch.empty(self.rows, lins[0].in_features, device=dev)
         self.out = torch.empty(self.rows, lins[3].out_features, device=dev)
 
     @torch.no_grad()
@@ -510,13 +509,15 @@ class FusedPolicy:
 
     @torch.no_grad()
     def __call__(self, obs):
-        """Logits [rows, 2 A] of the normalised observations (a persistent buffer: consume before the next call)."""
+        """Logits [rows, 2 A] of the RAW observations `obs` (contiguous [rows, in]); the normaliser (x - mean) / std runs inside
+        the kernel's load.  The result is a persistent buffer: consume it before the next call."""
         nrm = self.net.norm_obs
-        torch.sub(obs, nrm.mean, out=self.x)
-        self.x.div_(nrm.std)
-        key = tuple(l.bias.data_ptr() for l in self.net.policy.layers)     # FlatLearner re-homes the parameters once
+        key = (obs.data_ptr(),) + tuple(l.bias.data_ptr() for l in self.net.policy.layers)     # FlatLearner re-homes the parameters once
         if key != self.key:
-            self.op = engine.FusedMLP([dict(x=self.x, wf=self.wf, b=[l.bias.data for l in self.net.policy.layers], out=self.out)])
+            if not (obs.is_contiguous() and tuple(obs.shape) == (self.rows, self.net.policy.layers[0].in_features)):
+                raise engine.OdkError("FusedPolicy: contiguous [rows, in] observations expected")
+            self.op = engine.FusedMLP([dict(x=obs, in_mean=nrm.mean, in_std=nrm.std, wf=self.wf, b=[l.bias.data for l in self.net.policy.layers],
+                                            out=self.out)])
             self.key = key
         self.op.forward()
         return self.out

@@ -188,7 +188,7 @@ def rollout(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generat
         obs, priv = state.obs["state"].clone(), state.obs["privileged_state"].clone()
         if obs.is_cuda:   # one launch for softplus / sample / tanh / log-density (csrc policy_sample_kernel)
             from .. import engine
-            logits = fp(obs) if fp is not None else net.policy(net.norm_obs(obs))
+            logits = fp(state.obs["state"]) if fp is not None else net.policy(net.norm_obs(obs))   # (the env's own buffer: a fixed address)
             A = net.action_size
             z = torch.zeros(obs.shape[0], A, device=obs.device) if deterministic else noise[t]
             raw, action, logp = engine.policy_sample(logits, z)
