@@ -251,12 +251,19 @@ def adam_clip(params, grads, m, v, acc, lr: float, max_grad_norm: float = 0.0, b
                                       max_grad_norm or 0.0, _stream(params)))
 
 
-def policy_sample(logits, noise):
-    """(raw_action, action, log_prob) of the tanh-normal policy for logits [n, 2A] and standard-normal noise [n, A]."""
+def policy_sample(logits, noise, out=None):
+    """(raw_action, action, log_prob) of the tanh-normal policy for logits [n, 2A] and standard-normal noise [n, A];
+    `out`: the three result tensors to write into (contiguous [n, A], [n, A], [n]) instead of fresh ones."""
     import torch
     n, A = noise.shape
     _f32c(logits, noise)
-    raw, act, logp = torch.empty_like(noise), torch.empty_like(noise), torch.empty(n, device=noise.device)
+    if out is not None:
+        raw, act, logp = out
+        _f32c(raw, act, logp)
+        if raw.numel() != n * A or act.numel() != n * A or logp.numel() != n:
+            raise OdkError("policy_sample: out tensors of the wrong size")
+    else:
+        raw, act, logp = torch.empty_like(noise), torch.empty_like(noise), torch.empty(n, device=noise.device)
     _chk(load_library().odk_policy_sample(_ptr(logits), _ptr(noise), _ptr(raw), _ptr(act), _ptr(logp), n, A, _stream(noise)))
     return raw, act, logp
 
@@ -535,6 +542,30 @@ class FusedMLP:
         if not all(self.train):
             raise OdkError("FusedMLP.backward: built without training buffers")
         _chk(load_library().odk_mlp_backward(self.desc, self.k, _stream(self.keep[0]["x"])))
+
+
+class MultiCopy:
+    """dst[f] <- src[f] for up to 10 (src, dst) pairs of equally sized contiguous float32 CUDA tensors in ONE launch (the block
+    copy mode of `odk_gather_rows`): e.g. the five per-step snapshots of a rollout."""
+
+    def __init__(self, pairs):
+        import torch
+        n = len(pairs)
+        if not 1 <= n <= 10:
+            raise OdkError("MultiCopy: 1..10 pairs")
+        for s_, d_ in pairs:
+            _f32c(s_, d_)
+            if s_.numel() != d_.numel():
+                raise OdkError("MultiCopy: sizes differ")
+        self.n, self.keep = n, pairs
+        self.src = (C.c_void_p * n)(*[s_.data_ptr() for s_, _ in pairs])
+        self.dst = (C.c_void_p * n)(*[d_.data_ptr() for _, d_ in pairs])
+        self.rows = (C.c_int * n)(*[int(s_.numel()) for s_, _ in pairs])
+        self.base = (C.c_longlong * n)(*([0] * n))
+        self.idx = torch.zeros(1, dtype=torch.int64, device=pairs[0][0].device)   # (unused: every field is a block copy)
+
+    def __call__(self):
+        _chk(load_library().odk_gather_rows(self.src, self.dst, self.rows, self.base, self.n, _ptr(self.idx), 1, 1, _stream(self.keep[0][0])))
 
 
 class RowGather:

@@ -170,33 +170,75 @@ def make_learner(net, data, cfg, world: int = 1, group=None):
                        use_graph=os.environ.get("ODK_LEARNER_GRAPH", "1") != "0")
 
 
+class _RolloutBuffers:
+    """Time-major history of one unroll of an engine-backed env ([T, N, ...] per field) and the per-step snapshot launches: the
+    env's output tensors are persistent, so step t's five snapshots (reward / done / truncation of step t, the observations
+    step t + 1 starts from) are ONE launch with fixed addresses instead of five `clone`s."""
+
+    def __init__(self, state, T: int, A: int):
+        from .. import engine
+        obs, priv = state.obs["state"], state.obs["privileged_state"]
+        N, dev = obs.shape[0], obs.device
+        E = lambda *s: torch.empty(*s, device=dev)
+        self.T, self.src = T, (obs.data_ptr(), priv.data_ptr(), state.reward.data_ptr(), state.done.data_ptr(), state.info["truncation"].data_ptr())
+        self.buf = dict(obs=E(T, N, obs.shape[1]), priv=E(T, N, priv.shape[1]), raw_action=E(T, N, A), log_prob=E(T, N), reward=E(T, N), done=E(T, N),
+                        truncation=E(T, N))
+        self.action = E(N, A)
+        b = self.buf
+        self.first = engine.MultiCopy([(obs, b["obs"][0]), (priv, b["priv"][0])])
+        self.after = []
+        for t in range(T):
+            pairs = [(state.reward, b["reward"][t]), (state.done, b["done"][t]), (state.info["truncation"], b["truncation"][t])]
+            if t + 1 < T:
+                pairs += [(obs, b["obs"][t + 1]), (priv, b["priv"][t + 1])]
+            self.after.append(engine.MultiCopy(pairs))
+
+    def matches(self, state, T: int) -> bool:
+        return T == self.T and self.src == (state.obs["state"].data_ptr(), state.obs["privileged_state"].data_ptr(), state.reward.data_ptr(),
+                                            state.done.data_ptr(), state.info["truncation"].data_ptr())
+
+
 @torch.no_grad()
-def rollout(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generator, deterministic: bool = False):
-    """brax acting.generate_unroll: returns ([B, T, ...] transition tensors, final state)."""
+def _rollout_engine(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generator, deterministic: bool):
+    """`rollout` for an engine-backed env on the GPU: per step the policy's whole-network launch (when the architecture allows),
+    the sampling launch writing straight into the history, the fused env-step launch and one snapshot launch."""
+    from .. import engine
+    from .learner import fused_policy
+    T, A = unroll_length, net.action_size
+    rb = net.__dict__.get("_rollout_buffers")
+    if rb is None or not rb.matches(state, T):
+        rb = net.__dict__["_rollout_buffers"] = _RolloutBuffers(state, T, A)
+    N = state.obs["state"].shape[0]
+    fp = fused_policy(net, N)
+    if fp is not None:
+        fp.refresh()
+    noise = torch.zeros(T, N, A, device=state.reward.device) if deterministic else torch.randn(T, N, A, generator=gen, device=state.reward.device)
+    b = rb.buf
+    rb.first()
+    for t in range(T):
+        logits = fp(state.obs["state"]) if fp is not None else net.policy(net.norm_obs(state.obs["state"]))
+        engine.policy_sample(logits, noise[t], out=(b["raw_action"][t], rb.action, b["log_prob"][t]))
+        state = env.step(state, rb.action)
+        rb.after[t]()
+    data = {k: v.transpose(0, 1).contiguous() for k, v in b.items()}
+    data["last_priv"] = state.obs["privileged_state"].clone()
+    return data, state
+
+
+@torch.no_grad()
+def rollout(env, net: PPONetworks, state, unroll_length: int, gen: torch.Generator, deterministic: bool = False, engine_path: bool = True):
+    """brax acting.generate_unroll: returns ([B, T, ...] transition tensors, final state).  `engine_path` false forces the
+    generic loop below for an engine-backed env too (tests compare the two)."""
+    if engine_path and state.obs["state"].is_cuda and hasattr(env, "batch") and "truncation" in state.info:
+        return _rollout_engine(env, net, state, unroll_length, gen, deterministic)
     keys = ("obs", "priv", "raw_action", "log_prob", "reward", "done", "truncation")
     buf = {k: [] for k in keys}
-    fp = None
-    if state.obs["state"].is_cuda:   # all four policy layers in one launch (csrc/odk_mlp.hip, inference mode)
-        from .learner import fused_policy
-        fp = fused_policy(net, state.obs["state"].shape[0])
-        if fp is not None:
-            fp.refresh()
-    noise = None
-    if state.obs["state"].is_cuda and not deterministic:   # the unroll's sampling noise in one launch instead of one per step
-        noise = torch.randn(unroll_length, state.obs["state"].shape[0], net.action_size, generator=gen, device=state.obs["state"].device)
-    for t in range(unroll_length):
+    for _ in range(unroll_length):
         obs, priv = state.obs["state"].clone(), state.obs["privileged_state"].clone()
-        if obs.is_cuda:   # one launch for softplus / sample / tanh / log-density (csrc policy_sample_kernel)
-            from .. import engine
-            logits = fp(state.obs["state"]) if fp is not None else net.policy(net.norm_obs(obs))   # (the env's own buffer: a fixed address)
-            A = net.action_size
-            z = torch.zeros(obs.shape[0], A, device=obs.device) if deterministic else noise[t]
-            raw, action, logp = engine.policy_sample(logits, z)
-        else:
-            loc, scale = net.dist_params(obs)
-            raw = loc if deterministic else loc + scale * torch.randn(loc.shape, generator=gen, device=loc.device)
-            logp = tanh_normal_log_prob(loc, scale, raw)
-            action = torch.tanh(raw).contiguous()
+        loc, scale = net.dist_params(obs)
+        raw = loc if deterministic else loc + scale * torch.randn(loc.shape, generator=gen, device=loc.device)
+        logp = tanh_normal_log_prob(loc, scale, raw)
+        action = torch.tanh(raw).contiguous()
         state = env.step(state, action)
         buf["obs"].append(obs); buf["priv"].append(priv); buf["raw_action"].append(raw); buf["log_prob"].append(logp)
         buf["reward"].append(state.reward.clone()); buf["done"].append(state.done.clone()); buf["truncation"].append(state.info["truncation"].clone())
