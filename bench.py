@@ -29,6 +29,25 @@ HBM_PEAK_GBS = 8000.0                                                       # MI
 VALU_PEAK_TFLOPS = 157.3
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a box may show 256 logical
+    CPUs and grant 16 cores' worth of time: threads beyond that only add throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())         # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(task: str, target_seconds: float = 12.0):
     """Times the oracle's env step (the CPU restatement, kind='port') on all host cores of this box,
     on a bounded sample of the same workload: same model, same protocol, fewer envs and steps."""
@@ -39,17 +58,19 @@ def cpu_baseline(task: str, target_seconds: float = 12.0):
     model = load_task_model(task)
     z = np.load(asset_path("prm_table.npz"))
     prm_arrays = {k: z[k] for k in z.files}
-    om = O.OracleModel(model.blob())
-    prm = O.OraclePRM(prm_arrays)
-    L = O.lib()
-    cores = os.cpu_count() or 1
+    # the float32 build of the oracle (-O3; the arithmetic type of the GPU path): ~3x the float64 checker build
+    om = O.OracleModel(model.blob(), f32=True)
+    prm = O.OraclePRM(prm_arrays, f32=True)
+    L = O.lib(True)
+    cores = usable_cores()
     nenv = 16 * cores
     rate = L.lib.odko_rollout_mt(om.h, prm.h, nenv, 20, 5, cores, 0)          # calibration (~1 s)
     nsteps = max(20, int(rate * target_seconds / nenv))
     rate = L.lib.odko_rollout_mt(om.h, prm.h, nenv, nsteps, 10, cores, 0)
     return {"value": round(rate, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/odk_oracle*.c (float64 C restatement of the same env step), {nenv} envs x {nsteps} steps, "
-                      f"{cores} pthreads, same random-action protocol"}
+            "sample": f"oracle/odk_oracle*.c (C restatement of the same env step, float32 -O3 build), {nenv} envs x {nsteps} steps, "
+                      f"{cores} pthreads (= the cores the box grants this process: affinity mask and cgroup CPU quota; "
+                      f"{os.cpu_count()} logical CPUs visible), same random-action protocol"}
 
 
 def main():
@@ -153,7 +174,7 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(args.task)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": usable_cores(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1:
