@@ -267,7 +267,7 @@ class FlatLearner:
         self.noise = z(n, A)
         self.vs, self.adv, self.stats = z(B, T), z(B, T), z(2)
         self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
-        fused = self.policy.fused_ok() and self.value.fused_ok()
+        fused = self.policy.fused_ok() and self.value.fused_ok() and n >= 128   # (the weight-gradient launch wants >= 8 rows per slice)
         self.split_update = world > 1 if split_update is None else bool(split_update)
         self.policy.bind(self.static["obs"].view(n, -1), self.dlogits, fused)
         self.value.bind(self.priv_all, self.dval_all, fused)

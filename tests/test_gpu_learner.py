@@ -496,3 +496,20 @@ def test_fused_policy_inference_matches_the_module():
             for p_ in net.policy.parameters():
                 p_.mul_(1.01)
     assert fused_policy(PPONetworks(101, 212, 14, policy_hidden=(64, 64)).cuda(), 8) is None
+
+
+def test_tiny_minibatch_falls_back_to_the_library_path():
+    """A minibatch of fewer than 128 samples (8 rows per slice of the weight-gradient launch) runs the library path."""
+    from open_duck_playground_amd.ppo import train as T
+    from open_duck_playground_amd.ppo.learner import FlatLearner, prepare_rollout
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    net = PPONetworks(101, 212, 14).to(dev)
+    cfg = T.ppo_config(); cfg["tune_gemms"] = False
+    data = _fake_rollout(8, 5, dev)
+    lr = FlatLearner(net, cfg, 4, 5, use_graph=False)
+    assert lr.fused is None
+    lr.load_minibatch(prepare_rollout(net, data, cfg), torch.arange(4, device=dev))
+    lr.step()
+    assert torch.isfinite(lr.flat_p).all() and float(lr.acc[1]) == 1.0
