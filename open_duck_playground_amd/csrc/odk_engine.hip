@@ -721,7 +721,7 @@ struct odk_batch {
   float* d_recs = nullptr; float* d_first = nullptr; float* d_dr = nullptr; float* d_dbg = nullptr; float* d_hfield = nullptr;
   std::vector<float> h_dr; bool dr_enabled = false;
   int rec_size, frec_size, lds_total, dr_size, env_lds;
-  bool timing = false; std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t ev_used = 0;
+  int timing = 0; size_t timing_count = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t ev_used = 0;   // timing: 0 off, n: every n-th launch
 };
 
 extern "C" const char* odk_last_error(void) { return g_err.c_str(); }
@@ -1367,7 +1367,7 @@ extern "C" int odk_step(odk_batch* b, const float* action_dev, const odk_outputs
   a.action = action_dev;
   a.dbg_lds = g_debug_dump ? b->d_dbg : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (b->timing) {
+  if (b->timing > 0 && (b->timing_count++ % (size_t)b->timing) == 0) {
     if (b->ev_used == b->events.size()) {
       hipEvent_t e0, e1;
       HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1406,8 +1406,8 @@ extern "C" int odk_batch_timing(odk_batch* b, int enable, float* avg_ms, int* la
   }
   if (avg_ms) *avg_ms = b->ev_used ? (float)(tot / b->ev_used) : 0.0f;
   if (launches) *launches = (int)b->ev_used;
-  b->ev_used = 0;
-  b->timing = enable != 0;
+  b->ev_used = 0; b->timing_count = 0;
+  b->timing = enable > 0 ? enable : 0;
   return ODK_OK;
 }
 

@@ -705,7 +705,9 @@ class Batch:
         _chk(self.L.odk_batch_get_records(self._b, _fp(r)))
         return r
 
-    def timing(self, enable: bool):
+    def timing(self, enable):
+        """Average kernel milliseconds of the timed launches since the last call; `enable`: False / 0 = off, True / 1 = time every
+        launch from now on, n = every n-th launch (`odk_batch_timing`)."""
         ms, n = C.c_float(0), C.c_int(0)
         _chk(self.L.odk_batch_timing(self._b, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
