@@ -180,24 +180,40 @@ def test_env_kernels_have_no_scratch_and_fit_two_waves_per_simd(tmp_path):
     if not all(os.path.exists(t) for t in tools):
         pytest.skip("ROCm LLVM tools not present")
     lib = os.path.join(ROOT, "open_duck_playground_amd", "csrc", "libodk.so")
-    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    fat = str(tmp_path / "fat.bin")
     subprocess.check_call([tools[0], "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
-    subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
-    notes = subprocess.check_output([tools[2], "--notes", co], text=True)
+    # one offload bundle per translation unit (engine, learner kernels, network kernels), concatenated in the section
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
     kernels = {}
-    name = None
-    for line in notes.splitlines():
-        m = re.match(r"\s+\.name:\s+(\S+)", line)
-        if m:
-            name = m.group(1); kernels[name] = {}
-        m = re.match(r"\s+\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|vgpr_count|group_segment_fixed_size):\s+(\d+)", line)
-        if m and name:
-            kernels[name][m.group(1)] = int(m.group(2))
+    for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(blob)])):
+        piece, co = str(tmp_path / f"bundle{n}.bin"), str(tmp_path / f"dev{n}.co")
+        open(piece, "wb").write(blob[a:b])
+        subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={piece}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+        notes = subprocess.check_output([tools[2], "--notes", co], text=True)
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s+\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1); kernels[name] = {}
+            m = re.match(r"\s+\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|vgpr_count|group_segment_fixed_size):\s+(\d+)", line)
+            if m and name:
+                kernels[name][m.group(1)] = int(m.group(2))
     env = {k: v for k, v in kernels.items() if "step_kernel" in k or "reset_kernel" in k}
     assert len(env) >= 8, sorted(kernels)          # A / B / B+hfield at 32 lanes, A at 64 lanes: step + reset each
     for k, v in env.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
         assert v["vgpr_count"] <= 256, (k, v)      # 2 waves per SIMD (launch bounds 64, 2)
+    # the learner's whole-network kernels run four workgroups of four waves per CU (<= 128 registers), the
+    # weight-gradient kernel keeps its 128 accumulators beside <= 128 other registers; none of them spills
+    mlp = {k: v for k, v in kernels.items() if "mlp_fwd_kernel" in k or "mlp_bwd_kernel" in k}
+    dw = {k: v for k, v in kernels.items() if "dw_gemm_kernel" in k}
+    assert len(mlp) == 2 and len(dw) == 1, sorted(kernels)
+    for k, v in {**mlp, **dw}.items():
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0, (k, v)
+    for k, v in mlp.items():
+        assert v["vgpr_count"] <= 128, (k, v)
 
 
 @pytest.mark.parametrize("extra, what", [
