@@ -1454,14 +1454,19 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   // the dof lanes through YB (LDS, NR floats); vi = v of this lane's dof.
   auto mul_M = [&](const float* VB, float* YB, float vi) -> float {
     float acc = 0.0f;
+    const int lane_r = lane < NR ? lane : 0;   // (lanes past the reduced dofs: masks are empty, any in-range row)
+    // dofs are numbered parents first: j < lane can only be an ancestor of this lane's dof (entry in this lane's row, column
+    // depth_j), j > lane only a descendant (entry in j's row, column depth_i), j == lane the diagonal -- one mask test and one
+    // address select per j
+    const int rel = st.r_ancmask | st.r_descmask | (st.r_on ? (1 << lane_r) : 0);
+    const int own = st.r_Madr, dep = st.r_depth;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
       const int aj = ubcast(st.r_Madr, j), dj = ubcast(st.r_depth, j);
-      const bool isanc = (st.r_ancmask >> j) & 1, isdesc = (st.r_descmask >> j) & 1;
-      const int adr = isanc ? st.r_Madr + dj : (isdesc ? aj + st.r_depth : st.r_Madr + st.r_depth);
+      const int adr = j < lane_r ? own + dj : aj + dep;     // (j == lane: aj + dep = own + depth = the diagonal)
       const float mij = M[adr];
       const float vj = VB[j];
-      acc += (isanc || isdesc || j == lane) ? mij * vj : 0.0f;
+      acc += ((rel >> j) & 1) ? mij * vj : 0.0f;
     }
     if constexpr (S::PAIRED) {
       if (st.r_on) YB[lane] = acc;
