@@ -2030,34 +2030,39 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   const float gtol = m->tolerance * m->ls_tolerance * sqrtf(sn) * m->meaninertia * (float)(NV > 1 ? NV : 1);
   // evaluate up to three step sizes at once: cost, first and second derivative along the search
   auto ls_eval3 = [&](const float* al, float* cost, float* d0, float* d1) {
+    // branch-free: a lane without a row of some kind holds D = 0 or jar = jv = 0 there, so its terms are exact zeros (the
+    // divergent `if`s around them cost more exec-mask traffic than the few idle multiplies)
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (lane < nfl) {
-      const float D = fs.D, jar = jar_fl, jv = jv_fl;
+    {
+      const float D = fs.D, jar = jar_fl, jv = jv_fl;   // lanes >= nfl: jar = jv = 0
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
+      const float lo0 = fl_f * (-0.5f * fl_rf - jar), lo1 = -fl_f * jv, hi0 = fl_f * (-0.5f * fl_rf + jar), hi1 = fl_f * jv;
+      const bool row = lane < nfl;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const float xx = jar + al[a] * jv;
-        if (xx <= -fl_rf) { acc[3 * a] += fl_f * (-0.5f * fl_rf - jar); acc[3 * a + 1] += -fl_f * jv; }
-        else if (xx >= fl_rf) { acc[3 * a] += fl_f * (-0.5f * fl_rf + jar); acc[3 * a + 1] += fl_f * jv; }
-        else { acc[3 * a] += q0; acc[3 * a + 1] += q1; acc[3 * a + 2] += q2; }
+        const bool lo = xx <= -fl_rf, hi = xx >= fl_rf;
+        const float c0 = lo ? lo0 : (hi ? hi0 : q0), c1 = lo ? lo1 : (hi ? hi1 : q1), c2 = (lo || hi) ? 0.0f : q2;
+        acc[3 * a] += row ? c0 : 0.0f; acc[3 * a + 1] += row ? c1 : 0.0f; acc[3 * a + 2] += row ? c2 : 0.0f;
       }
     }
-    if (lim_D > 0) {
-      const float D = lim_D, jar = jar_lim, jv = jv_lim;
+    {
+      const float D = lim_D, jar = jar_lim, jv = jv_lim;   // lanes without a limit row: D = 0
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
 #pragma unroll
-      for (int a = 0; a < 3; a++)
-        if (jar + al[a] * jv < 0) { acc[3 * a] += q0; acc[3 * a + 1] += q1; acc[3 * a + 2] += q2; }
+      for (int a = 0; a < 3; a++) {
+        const bool on = jar + al[a] * jv < 0;
+        acc[3 * a] += on ? q0 : 0.0f; acc[3 * a + 1] += on ? q1 : 0.0f; acc[3 * a + 2] += on ? q2 : 0.0f;
+      }
     }
 #pragma unroll
     for (int t = 0; t < NCL; t++) {
-      const float D = cD[t];
-      if (D > 0) {
-        const float jar = cjar[t], jv = cjv[t];
-        const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
+      const float D = cD[t], jar = cjar[t], jv = cjv[t];   // inactive rows: D = 0
+      const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
 #pragma unroll
-        for (int a = 0; a < 3; a++)
-          if (jar + al[a] * jv < 0) { acc[3 * a] += q0; acc[3 * a + 1] += q1; acc[3 * a + 2] += q2; }
+      for (int a = 0; a < 3; a++) {
+        const bool on = jar + al[a] * jv < 0;
+        acc[3 * a] += on ? q0 : 0.0f; acc[3 * a + 1] += on ? q1 : 0.0f; acc[3 * a + 2] += on ? q2 : 0.0f;
       }
     }
     gsum_n<G, 9>(acc);
