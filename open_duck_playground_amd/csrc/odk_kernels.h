@@ -327,6 +327,7 @@ struct Statics {
   int c_len, c_idx, c_n;                 // c_len > 0 on the lane of a reduced chain's first dof (length, chain index); c_n chains
   int ch_first, ch_len;                  // the serial chain this lane's reduced dof belongs to (ch_len 0: base dof / no chain)
   int r_on, r_depth, r_Madr, r_ancmask, r_descmask, r_foot;   // reduced tree layout (virtual-tree statics: fetched in the rare path)
+  int r_pk;                              // r_Madr | r_depth << 16: one v_readlane hands both to the M v product
   // dof role (lane = dof)
   int d_on, d_body;
   int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
@@ -361,6 +362,7 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
     st.r_depth = m->red_depth[r]; st.r_Madr = m->red_Madr[r]; st.r_ancmask = m->red_ancmask[r]; st.r_descmask = m->red_descmask[r];
     st.r_foot = st.r_on ? m->red_foot[r] : 0;
     if (!st.r_on) { st.r_ancmask = 0; st.r_descmask = 0; st.r_depth = 0; }
+    st.r_pk = st.r_Madr | (st.r_depth << 16);
   }
   const int i = lane < S::NV ? lane : 0;
   st.d_on = lane < S::NV;
@@ -1462,7 +1464,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     const int own = st.r_Madr, dep = st.r_depth;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
-      const int aj = ubcast(st.r_Madr, j), dj = ubcast(st.r_depth, j);
+      const int pk = ubcast(st.r_pk, j), aj = pk & 0xFFFF, dj = pk >> 16;   // one readlane; the unpacking runs on the scalar unit
       const int adr = j < lane_r ? own + dj : aj + dep;     // (j == lane: aj + dep = own + depth = the diagonal)
       const float mij = M[adr];
       const float vj = VB[j];
