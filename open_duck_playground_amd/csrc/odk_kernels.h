@@ -2032,20 +2032,19 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   const float gtol = m->tolerance * m->ls_tolerance * sqrtf(sn) * m->meaninertia * (float)(NV > 1 ? NV : 1);
   // evaluate up to three step sizes at once: cost, first and second derivative along the search
   auto ls_eval3 = [&](const float* al, float* cost, float* d0, float* d1) {
-    // branch-free: a lane without a row of some kind holds D = 0 or jar = jv = 0 there, so its terms are exact zeros (the
-    // divergent `if`s around them cost more exec-mask traffic than the few idle multiplies)
+    // branch-free: a lane without a row of some kind holds D = 0 or f = jar = jv = 0 there, so its terms are exact zeros (the
+    // divergent `if`s around them cost more exec-mask traffic than the few idle multiplies); an active quadratic row enters
+    // as weight 1 (one select + three FMAs instead of three selects + three adds)
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     {
-      const float D = fs.D, jar = jar_fl, jv = jv_fl;   // lanes >= nfl: jar = jv = 0
+      const float D = fs.D, jar = jar_fl, jv = jv_fl;   // lanes >= nfl: f = rf = jar = jv = 0 -> every piece below is 0
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
       const float lo0 = fl_f * (-0.5f * fl_rf - jar), lo1 = -fl_f * jv, hi0 = fl_f * (-0.5f * fl_rf + jar), hi1 = fl_f * jv;
-      const bool row = lane < nfl;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const float xx = jar + al[a] * jv;
         const bool lo = xx <= -fl_rf, hi = xx >= fl_rf;
-        const float c0 = lo ? lo0 : (hi ? hi0 : q0), c1 = lo ? lo1 : (hi ? hi1 : q1), c2 = (lo || hi) ? 0.0f : q2;
-        acc[3 * a] += row ? c0 : 0.0f; acc[3 * a + 1] += row ? c1 : 0.0f; acc[3 * a + 2] += row ? c2 : 0.0f;
+        acc[3 * a] += lo ? lo0 : (hi ? hi0 : q0); acc[3 * a + 1] += lo ? lo1 : (hi ? hi1 : q1); acc[3 * a + 2] += (lo || hi) ? 0.0f : q2;
       }
     }
     {
@@ -2053,8 +2052,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const bool on = jar + al[a] * jv < 0;
-        acc[3 * a] += on ? q0 : 0.0f; acc[3 * a + 1] += on ? q1 : 0.0f; acc[3 * a + 2] += on ? q2 : 0.0f;
+        const float w = jar + al[a] * jv < 0 ? 1.0f : 0.0f;
+        acc[3 * a] = fmaf(w, q0, acc[3 * a]); acc[3 * a + 1] = fmaf(w, q1, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, q2, acc[3 * a + 2]);
       }
     }
 #pragma unroll
@@ -2063,8 +2062,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const bool on = jar + al[a] * jv < 0;
-        acc[3 * a] += on ? q0 : 0.0f; acc[3 * a + 1] += on ? q1 : 0.0f; acc[3 * a + 2] += on ? q2 : 0.0f;
+        const float w = jar + al[a] * jv < 0 ? 1.0f : 0.0f;
+        acc[3 * a] = fmaf(w, q0, acc[3 * a]); acc[3 * a + 1] = fmaf(w, q1, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, q2, acc[3 * a + 2]);
       }
     }
     gsum_n<G, 9>(acc);
