@@ -1797,12 +1797,14 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   if (lane < nfl) { MV[fs.dof] = f_fl; MA[fs.dof] = quad_fl ? fs.D : 0.0f; }
   const bool c_act[3] = {fminf(fminf(CDIST[0], CDIST[1]), fminf(CDIST[2], CDIST[3])) < 0, fminf(fminf(CDIST[4], CDIST[5]), fminf(CDIST[6], CDIST[7])) < 0,
                          fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0};
+  // wave-uniform: some env of the wave has a penetrating foot-foot contact.  Without one, contact rows 32-47 have D = 0 in
+  // both envs and their lane slot (G = 32: the second one) is skipped in the force sums and in the line search.
+  const bool any_ff = __builtin_amdgcn_ballot_w64(c_act[2]) != 0;
   // Foot wrench sums FF_f = sum_r w_r f_r and 6x6 blocks K_f = sum_r D_r [active] w_r w_r^T.  Contact row rc sits in
   // lane rc: rows 0-15 (left foot), 16-31 (right foot) and 32-47 (foot-foot) are exactly the 16-lane DPP rows, so
   // each sum is four DPP adds; lane 0 of a row stores its block.  (G = 32: the foot-foot rows are a second slot.)
   {
     constexpr int NSLOT = (S::NCROW + G - 1) / G;
-    const bool any_ff = __builtin_amdgcn_ballot_w64(c_act[2]) != 0;   // wave-uniform
 #pragma unroll
     for (int t = 0; t < NSLOT; t++) {
       if (t * G >= 32 && !any_ff) continue;   // foot-foot slot with nothing active anywhere in the wave
@@ -2023,6 +2025,11 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   for (int t = 0; t < NCL; t++) {
     const int rc = lane + t * G;
     const bool on = rc < S::NCROW;
+    if (t * G >= 32 && !any_ff) {   // foot-foot slot, nothing active in the wave
+      cD[t] = 0.0f; cjar[t] = 0.0f; cjv[t] = 0.0f;
+      if (on) JV[r0c + rc] = 0.0f;  // debug image only
+      continue;
+    }
     cD[t] = on ? ED[r0c + rc] : 0.0f;
     cjar[t] = on ? JAR[r0c + rc] : 0.0f;
     cjv[t] = (on && cD[t] > 0) ? contact_jx(rc, SCR + S::S_VF) : 0.0f;
@@ -2058,6 +2065,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     }
 #pragma unroll
     for (int t = 0; t < NCL; t++) {
+      if (t * G >= 32 && !any_ff) continue;
       const float D = cD[t], jar = cjar[t], jv = cjv[t];   // inactive rows: D = 0
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
 #pragma unroll
