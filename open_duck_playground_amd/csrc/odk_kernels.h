@@ -2037,11 +2037,14 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   }
   ODK_PROF(15);
   const float gtol = m->tolerance * m->ls_tolerance * sqrtf(sn) * m->meaninertia * (float)(NV > 1 ? NV : 1);
-  // evaluate up to three step sizes at once: cost, first and second derivative along the search
-  auto ls_eval3 = [&](const float* al, float* cost, float* d0, float* d1) {
+  // Three step sizes at once.  The bracketing iterations only steer on the first and second derivative along the search, so
+  // they evaluate those alone (COST = false: two sums per step size); the costs that pick the final step -- at lo, hi and 0 --
+  // are one evaluation at the end (COST = true: one sum per step size, the quadratic combined per lane before the reduction).
+  auto ls_eval = [&](auto cost_tag, const float* al, float* cost, float* d0, float* d1) {
+    constexpr bool COST = decltype(cost_tag)::value;
     // branch-free: a lane without a row of some kind holds D = 0 or f = jar = jv = 0 there, so its terms are exact zeros (the
     // divergent `if`s around them cost more exec-mask traffic than the few idle multiplies); an active quadratic row enters
-    // as weight 1 (one select + three FMAs instead of three selects + three adds)
+    // as weight 1 (one select + FMAs instead of a select + add per term)
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     {
       const float D = fs.D, jar = jar_fl, jv = jv_fl;   // lanes >= nfl: f = rf = jar = jv = 0 -> every piece below is 0
@@ -2051,7 +2054,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       for (int a = 0; a < 3; a++) {
         const float xx = jar + al[a] * jv;
         const bool lo = xx <= -fl_rf, hi = xx >= fl_rf;
-        acc[3 * a] += lo ? lo0 : (hi ? hi0 : q0); acc[3 * a + 1] += lo ? lo1 : (hi ? hi1 : q1); acc[3 * a + 2] += (lo || hi) ? 0.0f : q2;
+        if constexpr (COST) acc[3 * a] = lo ? lo0 : (hi ? hi0 : q0);
+        acc[3 * a + 1] = lo ? lo1 : (hi ? hi1 : q1); acc[3 * a + 2] = (lo || hi) ? 0.0f : q2;
       }
     }
     {
@@ -2060,7 +2064,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const float w = jar + al[a] * jv < 0 ? 1.0f : 0.0f;
-        acc[3 * a] = fmaf(w, q0, acc[3 * a]); acc[3 * a + 1] = fmaf(w, q1, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, q2, acc[3 * a + 2]);
+        if constexpr (COST) acc[3 * a] = fmaf(w, q0, acc[3 * a]);
+        acc[3 * a + 1] = fmaf(w, q1, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, q2, acc[3 * a + 2]);
       }
     }
 #pragma unroll
@@ -2071,48 +2076,62 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         const float w = jar + al[a] * jv < 0 ? 1.0f : 0.0f;
-        acc[3 * a] = fmaf(w, q0, acc[3 * a]); acc[3 * a + 1] = fmaf(w, q1, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, q2, acc[3 * a + 2]);
+        if constexpr (COST) acc[3 * a] = fmaf(w, q0, acc[3 * a]);
+        acc[3 * a + 1] = fmaf(w, q1, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, q2, acc[3 * a + 2]);
       }
     }
-    gsum_n<G, 9>(acc);
+    if constexpr (COST) {
+      float c[3];
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const float t0 = acc[3 * a] + gauss, t1 = acc[3 * a + 1] + qg1, t2 = acc[3 * a + 2] + qg2;
-      cost[a] = al[a] * al[a] * t2 + al[a] * t1 + t0;
-      d0[a] = 2.0f * al[a] * t2 + t1;
-      d1[a] = 2.0f * t2 + (t2 == 0.0f ? MINVAL_F : 0.0f);
+      for (int a = 0; a < 3; a++) c[a] = fmaf(al[a], fmaf(al[a], acc[3 * a + 2], acc[3 * a + 1]), acc[3 * a]);
+      gsum_n<G, 3>(c);
+#pragma unroll
+      for (int a = 0; a < 3; a++) cost[a] = c[a] + fmaf(al[a], fmaf(al[a], qg2, qg1), gauss);
+    } else {
+      float r[6] = {acc[1], acc[2], acc[4], acc[5], acc[7], acc[8]};
+      gsum_n<G, 6>(r);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float t1 = r[2 * a] + qg1, t2 = r[2 * a + 1] + qg2;
+        d0[a] = 2.0f * al[a] * t2 + t1;
+        d1[a] = 2.0f * t2 + (t2 == 0.0f ? MINVAL_F : 0.0f);
+      }
     }
   };
+  using Deriv = std::integral_constant<bool, false>; using Cost = std::integral_constant<bool, true>;
   auto sdiv = [](float a, float b) { return b == 0.0f ? 0.0f : a * __builtin_amdgcn_rcpf(b); };   // Newton step of the 1-D search: 1 ulp is plenty
   float al[3] = {0, 0, 0}, cs[3], e0[3], e1[3];
-  ls_eval3(al, cs, e0, e1);
-  const float p0_cost = cs[0], p0_d0 = e0[0], p0_d1 = e1[0];
+  ls_eval(Deriv(), al, cs, e0, e1);   // three equal step sizes: the compiler folds them into one evaluation
+  const float p0_d0 = e0[0], p0_d1 = e1[0];
   al[0] = -sdiv(p0_d0, p0_d1); al[1] = al[0]; al[2] = al[0];
-  ls_eval3(al, cs, e0, e1);
-  float lo_a, lo_c, lo_d0, lo_d1, hi_a, hi_c, hi_d0, hi_d1;
-  if (e0[0] < p0_d0) { lo_a = al[0]; lo_c = cs[0]; lo_d0 = e0[0]; lo_d1 = e1[0]; hi_a = 0; hi_c = p0_cost; hi_d0 = p0_d0; hi_d1 = p0_d1; }
-  else { hi_a = al[0]; hi_c = cs[0]; hi_d0 = e0[0]; hi_d1 = e1[0]; lo_a = 0; lo_c = p0_cost; lo_d0 = p0_d0; lo_d1 = p0_d1; }
+  ls_eval(Deriv(), al, cs, e0, e1);
+  float lo_a, lo_d0, lo_d1, hi_a, hi_d0, hi_d1;
+  if (e0[0] < p0_d0) { lo_a = al[0]; lo_d0 = e0[0]; lo_d1 = e1[0]; hi_a = 0; hi_d0 = p0_d0; hi_d1 = p0_d1; }
+  else { hi_a = al[0]; hi_d0 = e0[0]; hi_d1 = e1[0]; lo_a = 0; lo_d0 = p0_d0; lo_d1 = p0_d1; }
   bool swap = true;
   for (int it = 0; it < m->ls_iterations; it++) {
     bool done = !swap || (lo_d0 < 0 && lo_d0 > -gtol) || (hi_d0 > 0 && hi_d0 < gtol);
     if (done) break;
     al[0] = lo_a - sdiv(lo_d0, lo_d1); al[1] = hi_a - sdiv(hi_d0, hi_d1); al[2] = 0.5f * (lo_a + hi_a);
-    ls_eval3(al, cs, e0, e1);
+    ls_eval(Deriv(), al, cs, e0, e1);
     // lo_next = 0, hi_next = 1, mid = 2
     const bool s1 = (lo_d0 > 0) || (lo_d0 < e0[0]);
-    if (s1) { lo_a = al[0]; lo_c = cs[0]; lo_d0 = e0[0]; lo_d1 = e1[0]; }
+    if (s1) { lo_a = al[0]; lo_d0 = e0[0]; lo_d1 = e1[0]; }
     const bool s2 = (e0[2] < 0) && (lo_d0 < e0[2]);
-    if (s2) { lo_a = al[2]; lo_c = cs[2]; lo_d0 = e0[2]; lo_d1 = e1[2]; }
+    if (s2) { lo_a = al[2]; lo_d0 = e0[2]; lo_d1 = e1[2]; }
     const bool s3 = (e0[1] < 0) && (lo_d0 < e0[1]);
-    if (s3) { lo_a = al[1]; lo_c = cs[1]; lo_d0 = e0[1]; lo_d1 = e1[1]; }
+    if (s3) { lo_a = al[1]; lo_d0 = e0[1]; lo_d1 = e1[1]; }
     const bool s4 = (hi_d0 < 0) || (hi_d0 > e0[1]);
-    if (s4) { hi_a = al[1]; hi_c = cs[1]; hi_d0 = e0[1]; hi_d1 = e1[1]; }
+    if (s4) { hi_a = al[1]; hi_d0 = e0[1]; hi_d1 = e1[1]; }
     const bool s5 = (e0[2] > 0) && (hi_d0 > e0[2]);
-    if (s5) { hi_a = al[2]; hi_c = cs[2]; hi_d0 = e0[2]; hi_d1 = e1[2]; }
+    if (s5) { hi_a = al[2]; hi_d0 = e0[2]; hi_d1 = e1[2]; }
     const bool s6 = (e0[0] > 0) && (hi_d0 > e0[0]);
-    if (s6) { hi_a = al[0]; hi_c = cs[0]; hi_d0 = e0[0]; hi_d1 = e1[0]; }
+    if (s6) { hi_a = al[0]; hi_d0 = e0[0]; hi_d1 = e1[0]; }
     swap = s1 || s2 || s3 || s4 || s5 || s6;
   }
+  al[0] = lo_a; al[1] = hi_a; al[2] = 0.0f;
+  ls_eval(Cost(), al, cs, e0, e1);
+  const float lo_c = cs[0], hi_c = cs[1], p0_cost = cs[2];
   const bool improved = (lo_c < p0_cost) || (hi_c < p0_cost);
   const float alpha = improved ? (lo_c < hi_c ? lo_a : hi_a) : 0.0f;
   if (st.d_on) {
