@@ -324,7 +324,7 @@ struct Statics {
   static constexpr int NHE = (S::NHR + G - 1) / G;  // reduced virtual-tree Hessian entries per lane
   int j_qadr, j_dadr;                    // joint role (sin/cos phase, Euler)
   // reduced-dof role (lane = reduced dof, DevModel::paired; a model without twins: reduced dof = dof)
-  int c_len, c_idx, c_n;                 // c_len > 0 on the lane of a reduced chain's first dof (length, chain index); c_n chains
+  int cs_pk;                             // chain_solve roles: lane 8 c + b -> chain c's length | head depth << 3 | first dof << 8 | row address << 14; lane q -> base entry (tb << 24 | tb2 << 27)
   int ch_first, ch_len;                  // the serial chain this lane's reduced dof belongs to (ch_len 0: base dof / no chain)
   int r_on, r_depth, r_Madr, r_ancmask, r_descmask, r_foot;   // reduced tree layout (virtual-tree statics: fetched in the rare path)
   int r_pk;                              // r_Madr | r_depth << 16: one v_readlane hands both to the M v product
@@ -351,8 +351,18 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
     st.j_qadr = on ? m->jnt_qposadr[on ? lane : 0] : -1;
     st.j_dadr = m->jnt_dofadr[on ? lane : 0];
   }
-  st.c_len = 0; st.c_idx = 0; st.c_n = m->nrchain;
-  for (int c = 0; c < 3; c++) if (c < m->nrchain && lane == m->rchain_first[c]) { st.c_len = m->rchain_len[c]; st.c_idx = c; }
+  {
+    st.cs_pk = 0;
+    const int c = lane >> 3;
+    if (c < 3 && c < m->nrchain) {
+      const int f = m->rchain_first[c];
+      st.cs_pk = m->rchain_len[c] | (m->red_depth[f] << 3) | (f << 8) | (m->red_Madr[f] << 14);
+    }
+    int tb = 0, tb2 = 0;
+    if (lane < 21) { while ((tb + 1) * (tb + 2) / 2 <= lane) tb++; tb2 = lane - tb * (tb + 1) / 2; }
+    else if (lane < 27) { tb = lane - 21; tb2 = 6; }
+    st.cs_pk |= (tb << 24) | (tb2 << 27);
+  }
   st.ch_first = 0; st.ch_len = 0;
   for (int c = 0; c < 3; c++)
     if (c < m->nrchain && lane >= m->rchain_first[c] && lane < m->rchain_first[c] + m->rchain_len[c]) { st.ch_first = m->rchain_first[c]; st.ch_len = m->rchain_len[c]; }
@@ -579,96 +589,80 @@ __device__ __forceinline__ float solve_rows(const float* A, float xi, int lane, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// In-register solve of (L^T D L) x = b for a "tree of chains" (floating base + up to three serial chains), the
-// shape of this robot.  The matrices are tiny (6 + 5 + 4 + 5), so lane-parallel elimination is bound by ~19
-// dependent hand-offs; instead ONE lane eliminates a whole chain block in its registers (dense, fully unrolled),
-// the three chains run in three lanes at once, lane 0 finishes the 6x6 base block with the chains' Schur
-// complements, and the chains back-substitute.  Two LDS hand-offs in total.  A is the tree layout (read only);
-// VEC holds b on entry and x on exit (LDS); XCH is >= 87 floats of LDS scratch.
-struct ChainSt { int c_len, c_idx, c_n, d_depth, d_Madr; };   // c_len > 0 on the lane of a chain's first dof; its depth / row address
+// Solve of (L^T D L) x = b for a "tree of chains" (floating base + up to three serial chains), the shape of this
+// robot.  The matrices are tiny (6 + 5 + 4 + 5): eliminating lane-parallel by dof is bound by ~19 dependent hand-offs, and
+// one lane per chain doing its whole block in registers (the previous version) issues ~600 VALU instructions per solve for
+// three busy lanes -- and the kernel is bound by VALU issue.  Now the block of chain c, [T | C | y] with T the chain's own
+// 5 x 5 part, C its 5 x 6 coupling to the base dofs and y its right-hand side, is eliminated by COLUMN: lane 8 c + b holds
+// column b of [C | y] (b = 6: y) and a private copy of T, so the seven columns of the three chains go through the same ~50
+// instructions at once.  Then 27 lanes form the base block's Schur complement and right-hand side (one entry each, 15
+// FMAs), every lane factors and solves the 6 x 6 base system (redundantly: no hand-off), and the y-lanes back-substitute.
+// Three LDS hand-offs.  A is the tree layout (read only); VEC holds b on entry and x on exit (LDS); XCH: 132 floats and
+// XSV: 105 floats of LDS scratch.  cs = Statics::cs_pk.
 template <class S, int G>
-__device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* XCH, const ChainSt& st, int lane) {
+__device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* XCH, float* XSV, int cs, int lane) {
   constexpr int CL = S::CL > 0 ? S::CL : 1;
-  constexpr int NB6 = 6;
-  const bool head = st.c_len > 0;
-  const int d0 = st.d_depth;   // on a chain-head lane: depth of the chain's first dof (= 6)
-  float T[CL][CL], Cb[CL][NB6], y[CL], dinv[CL], Sx[21], rb[NB6];
-  // ---- load the chain block (rows beyond the chain's length are identity padding)
+  constexpr int NB6 = 6, P = 7, BASE = 3 * CL * P;   // P: pitch of one (chain, row) record; BASE: base block behind the records
+  const int len = cs & 7, d0 = (cs >> 3) & 31, first = (cs >> 8) & 63, madr = (cs >> 14) & 1023;
+  const int c = (lane >> 3) < 3 ? (lane >> 3) : 0, bcol = lane & 7;
+  const bool col = lane < 24 && bcol < P;   // lanes that hold a column (all zeros when the chain does not exist: len = 0)
+  float T[CL][CL], v[CL], dinv[CL];
+  // ---- load T and this lane's column (rows beyond the chain's length are identity padding)
 #pragma unroll
   for (int p = 0; p < CL; p++) {
-    const bool valid = head && p < st.c_len;
-    const int radr = valid ? st.d_Madr + p * (d0 + 1) + (p * (p - 1)) / 2 : 0;
+    const bool valid = p < len;
+    const int radr = valid ? madr + p * (d0 + 1) + (p * (p - 1)) / 2 : 0;
 #pragma unroll
-    for (int b = 0; b < NB6; b++) { const float v = A[radr + b]; Cb[p][b] = valid ? v : 0.0f; }
-#pragma unroll
-    for (int q = 0; q <= p; q++) { const float v = A[radr + d0 + q]; T[p][q] = valid ? v : (q == p ? 1.0f : 0.0f); }
-    const float bv = VEC[valid ? lane + p : 0];
-    y[p] = valid ? bv : 0.0f;
+    for (int q = 0; q <= p; q++) { const float t = A[radr + d0 + q]; T[p][q] = valid ? t : (q == p ? 1.0f : 0.0f); }
+    const float* src = bcol < NB6 ? A + radr + bcol : VEC + (valid ? first + p : 0);
+    const float cv = *src;
+    v[p] = valid ? cv : 0.0f;
   }
-#pragma unroll
-  for (int q = 0; q < 21; q++) Sx[q] = 0.0f;
-#pragma unroll
-  for (int b = 0; b < NB6; b++) rb[b] = 0.0f;
-  // ---- eliminate the chain from its leaf: L entries replace T / Cb, y <- L^-T b, base gets Schur terms
+  // ---- eliminate the chain from its leaf: L entries replace T, the column becomes L^-T (column)
 #pragma unroll
   for (int k = CL - 1; k >= 0; k--) {
     const float inv = __builtin_amdgcn_rcpf(T[k][k]);
     dinv[k] = inv;
-    const float yk = y[k];
 #pragma unroll
     for (int i = k - 1; i >= 0; i--) {   // towards the root: row k's entries j <= i are still unscaled
       const float l = T[k][i] * inv;
 #pragma unroll
       for (int j = 0; j <= i; j++) T[i][j] = fmaf(-l, T[k][j], T[i][j]);
-#pragma unroll
-      for (int b = 0; b < NB6; b++) Cb[i][b] = fmaf(-l, Cb[k][b], Cb[i][b]);
-      y[i] = fmaf(-l, yk, y[i]);
+      v[i] = fmaf(-l, v[k], v[i]);
       T[k][i] = l;
     }
-    float lb[NB6];
-#pragma unroll
-    for (int b = 0; b < NB6; b++) lb[b] = Cb[k][b] * inv;
-    {
-      int q = 0;
-#pragma unroll
-      for (int b = 0; b < NB6; b++)
-#pragma unroll
-        for (int b2 = 0; b2 <= b; b2++) { Sx[q] = fmaf(-lb[b], Cb[k][b2], Sx[q]); q++; }
-    }
-#pragma unroll
-    for (int b = 0; b < NB6; b++) { rb[b] = fmaf(-lb[b], yk, rb[b]); Cb[k][b] = lb[b]; }
   }
-  // ---- hand the Schur complement and rhs contributions to the base lane
-  {
-    const int cidx = st.c_idx;
-    if (head) {
+  float sv[CL];
 #pragma unroll
-      for (int q = 0; q < 21; q++) XCH[27 * cidx + q] = Sx[q];
+  for (int k = 0; k < CL; k++) sv[k] = v[k] * dinv[k];
+  if (col) {
 #pragma unroll
-      for (int b = 0; b < NB6; b++) XCH[27 * cidx + 21 + b] = rb[b];
-    }
+    for (int k = 0; k < CL; k++) { XCH[(c * CL + k) * P + bcol] = v[k]; XSV[(c * CL + k) * P + bcol] = sv[k]; }
   }
   ODK_SYNC();
-  // ---- base 6x6 (meaningful on lane 0): B += sum of Schur terms, factor, solve
+  // ---- base block: entry (tb, tb2) of B - sum_chains C^T T^-1 C (lanes 0-20, lower triangle) and component tb of
+  // b_base - sum_chains C^T T^-1 y (lanes 21-26: tb2 = 6, the y column)
   {
-    float Bm[NB6][NB6], bb[NB6], xb[NB6], binv[NB6];
-    const int nch = st.c_n;   // chains per env (uniform)
+    const int tb = (cs >> 24) & 7, tb2 = (cs >> 27) & 7;
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3 * CL; r++) sum = fmaf(XSV[r * P + tb], XCH[r * P + tb2], sum);
+    const float* src = lane < 21 ? A + lane : VEC + (lane < 27 ? lane - 21 : 0);
+    const float a0 = *src;
+    if (lane < 27) XCH[BASE + lane] = a0 - sum;
+  }
+  ODK_SYNC();
+  // ---- base 6x6, in every lane: factor, solve
+  float xb[NB6];
+  {
+    float Bm[NB6][NB6], bb[NB6], binv[NB6];
     {
       int q = 0;
 #pragma unroll
       for (int b = 0; b < NB6; b++) {
 #pragma unroll
-        for (int b2 = 0; b2 <= b; b2++) {
-          float v = A[q];
-#pragma unroll
-          for (int c = 0; c < 3; c++) { const float sx = XCH[27 * c + q]; v += (c < nch) ? sx : 0.0f; }
-          Bm[b][b2] = v;
-          q++;
-        }
-        float r = VEC[b];
-#pragma unroll
-        for (int c = 0; c < 3; c++) { const float rx = XCH[27 * c + 21 + b]; r += (c < nch) ? rx : 0.0f; }
-        bb[b] = r;
+        for (int b2 = 0; b2 <= b; b2++) Bm[b][b2] = XCH[BASE + q++];
+        bb[b] = XCH[BASE + 21 + b];
       }
     }
 #pragma unroll
@@ -691,27 +685,24 @@ __device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* X
       for (int i = 0; i < k; i++) x = fmaf(-Bm[k][i], xb[i], x);
       xb[k] = x;
     }
-    ODK_SYNC();   // every lane has read b[0..5] and the exchange area before lane 0 overwrites VEC[0..5]
-    if (lane == 0) {
+    if (lane == 0) {   // (b[0..5] was read before the hand-off above)
 #pragma unroll
       for (int b = 0; b < NB6; b++) VEC[b] = xb[b];
     }
   }
-  ODK_SYNC();
-  // ---- chains back-substitute with the base solution
+  // ---- the y-lanes back-substitute their chain with the base solution
   {
-    float xb[NB6], x[CL];
-#pragma unroll
-    for (int b = 0; b < NB6; b++) xb[b] = VEC[b];
+    float x[CL];
+    const bool ycol = lane < 24 && bcol == NB6;
 #pragma unroll
     for (int k = 0; k < CL; k++) {
-      float v = y[k] * dinv[k];
+      float val = sv[k];
 #pragma unroll
-      for (int b = 0; b < NB6; b++) v = fmaf(-Cb[k][b], xb[b], v);
+      for (int b = 0; b < NB6; b++) val = fmaf(-XSV[(c * CL + k) * P + b], xb[b], val);
 #pragma unroll
-      for (int i = 0; i < k; i++) v = fmaf(-T[k][i], x[i], v);
-      x[k] = v;
-      if (head && k < st.c_len) VEC[lane + k] = v;
+      for (int i = 0; i < k; i++) val = fmaf(-T[k][i], x[i], val);
+      x[k] = val;
+      if (ycol && k < len) VEC[first + k] = val;
     }
   }
   ODK_SYNC();
@@ -1412,7 +1403,6 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   ODK_PROF(4);
   // ---------------- P5: qacc_smooth = M^-1 qfrc_smooth; dense symmetric row of M into registers
   float qas;
-  const ChainSt cst{st.c_len, st.c_idx, st.c_n, st.r_depth, st.r_Madr};
   if constexpr (S::PAIRED) {
     // M = P Mr P^T + diag(armature): reduced system with the pairs' series armature on the diagonal (HL), one chain solve
 #pragma unroll
@@ -1428,13 +1418,13 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     if (st.r_on) GRAD[lane] = pair_rhs<S>(QFS, ARM, nullptr, m, lane);
     ODK_SYNC();
     ODK_PROF(5);
-    chain_solve<S, G>(HL, GRAD, SCR + S::S_K, cst, lane);
+    chain_solve<S, G>(HL, GRAD, SCR + S::S_K, BUF6, st.cs_pk, lane);
     qas = pair_expand<S, G>(GRAD, QFS, qfs, ARM, nullptr, st, lane);
     if (st.d_on) QAS[lane] = qas;
   } else if constexpr (S::CL > 0) {
     if (st.d_on) QAS[lane] = qfs;
     ODK_SYNC();
-    chain_solve<S, G>(M, QAS, SCR + S::S_K, cst, lane);
+    chain_solve<S, G>(M, QAS, SCR + S::S_K, BUF6, st.cs_pk, lane);
     ODK_PROF(5);
     qas = st.d_on ? QAS[lane] : 0.0f;
   } else {
@@ -1938,11 +1928,11 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     ODK_SYNC();
     ODK_PROF(12);
     if constexpr (S::PAIRED) {
-      chain_solve<S, G>(HL, MV, SCR + S::S_K, cst, lane);
+      chain_solve<S, G>(HL, MV, SCR + S::S_K, BUF6, st.cs_pk, lane);
       ODK_PROF(13);
       search = -pair_expand<S, G>(MV, GRAD, grad, ARM, JV, st, lane);
     } else if constexpr (S::CL > 0) {
-      chain_solve<S, G>(HL, GRAD, SCR + S::S_K, cst, lane);
+      chain_solve<S, G>(HL, GRAD, SCR + S::S_K, BUF6, st.cs_pk, lane);
       ODK_PROF(13);
       search = st.d_on ? -GRAD[lane] : 0.0f;
     } else {   // generic tree: the inertia's own (shallower) row layout instead of the virtual tree's
