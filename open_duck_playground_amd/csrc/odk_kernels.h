@@ -1439,13 +1439,14 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     qas = solve_rows<G, NV>(HL, qfs, lane, st.r_on, st.r_depth, st.r_Madr, st.r_ancmask, st.r_descmask, st.r_depth, st.r_Madr);
     if (st.d_on) QAS[lane] = qas;
   }
-  // y = M v with the dense symmetric row of the reduced M gathered on the fly (unconditional LDS loads + selects);
-  // recomputed at both uses instead of holding NR registers across the whole solver.  VB = P^T v (LDS, one entry per reduced
-  // dof; v itself without twins) is read with uniform addresses (broadcast reads on the LDS pipe) instead of 2 x v_readlane
-  // + select per element on the VALU.  Twin dofs: y_i = (Mr P^T v)_r(i) + ARM[i] v_i, handed from the reduced-dof lanes to
-  // the dof lanes through YB (LDS, NR floats); vi = v of this lane's dof.
-  auto mul_M = [&](const float* VB, float* YB, float vi) -> float {
-    float acc = 0.0f;
+  // y = M v with the dense symmetric row of the reduced M in registers: gathered once per substep (unconditional LDS loads +
+  // selects, at the start of the solver) and used by both products -- NR registers held through the solver, which the
+  // column-wise chain solve left room for (gathering at each use cost ~120 VALU instructions per product).  VB = P^T v (LDS,
+  // one entry per reduced dof; v itself without twins) is read with uniform addresses (broadcast reads on the LDS pipe) instead
+  // of 2 x v_readlane + select per element on the VALU.  Twin dofs: y_i = (Mr P^T v)_r(i) + ARM[i] v_i, handed from the
+  // reduced-dof lanes to the dof lanes through YB (LDS, NR floats); vi = v of this lane's dof.
+  float mrow[NR];
+  auto gather_M = [&]() {
     const int lane_r = lane < NR ? lane : 0;   // (lanes past the reduced dofs: masks are empty, any in-range row)
     // dofs are numbered parents first: j < lane can only be an ancestor of this lane's dof (entry in this lane's row, column
     // depth_j), j > lane only a descendant (entry in j's row, column depth_i), j == lane the diagonal -- one mask test and one
@@ -1457,9 +1458,15 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       const int pk = ubcast(st.r_pk, j), aj = pk & 0xFFFF, dj = pk >> 16;   // one readlane; the unpacking runs on the scalar unit
       const int adr = j < lane_r ? own + dj : aj + dep;     // (j == lane: aj + dep = own + depth = the diagonal)
       const float mij = M[adr];
-      const float vj = VB[j];
-      acc += ((rel >> j) & 1) ? mij * vj : 0.0f;
+      mrow[j] = ((rel >> j) & 1) ? mij : 0.0f;
     }
+  };
+  auto mul_M = [&](const float* VB, float* YB, float vi) -> float {
+    float acc0 = 0.0f, acc1 = 0.0f;   // two chains: a single accumulator is NR dependent FMAs
+#pragma unroll
+    for (int j = 0; j + 1 < NR; j += 2) { acc0 = fmaf(mrow[j], VB[j], acc0); acc1 = fmaf(mrow[j + 1], VB[j + 1], acc1); }
+    if constexpr (NR & 1) acc0 = fmaf(mrow[NR - 1], VB[NR - 1], acc0);
+    float acc = acc0 + acc1;
     if constexpr (S::PAIRED) {
       if (st.r_on) YB[lane] = acc;
       ODK_SYNC();
@@ -1672,6 +1679,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   ODK_PROF(9);
 
   // ---------------- P9: Newton solver, one iteration (mjx solver.solve)
+  gather_M();
   const float warm = st.d_on ? WARM[lane] : 0.0f;
   // foot twists of both candidates: VF = sum_{d above foot} cdof[d] qacc_smooth[d], VF2 likewise for the warmstart.
   // NOTE: v_readlane (ubcast / bcast) must stay in uniform control flow -- inside a divergent branch the source
