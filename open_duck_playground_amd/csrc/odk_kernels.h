@@ -8,8 +8,9 @@
 // playground/open_duck_mini_v2/joystick.py:420.
 //
 // What makes it fast (all exact in real arithmetic; DESIGN.md 4.1 has the measurements):
-//  * occupancy by construction: 256 VGPRs => 2 waves/SIMD = 8 workgroups/CU, and the LDS image is sized so that 8
-//    workgroups fit (shape A: 2 412 floats/env) => 8192 envs are exactly two rounds;
+//  * occupancy by construction: <= 256 VGPRs => 2 waves/SIMD = 8 workgroups/CU, and the LDS image is sized so that 8
+//    workgroups fit (shape A: 2 412 floats/env; LDS, not registers, is what rules out a third wave) => 8192 envs are
+//    exactly two rounds.  The kernel is bound by VALU issue: what pays is fewer instructions, not fewer loads;
 //  * per-lane statics (a lane's dof depth, row address, ancestor / descendant masks...) are read once per launch into
 //    registers (struct Statics); phase-local constants are re-fetched from the L2-resident model where they are used;
 //    the model pointer is made opaque once per substep so that table addresses are not hoisted into scratch;
@@ -20,8 +21,13 @@
 //    6-vector w_r = [r x dir; dir], so J x, J^T f and J^T D J collapse to 6-vector / 6x6 algebra;
 //  * both feet's plane-convex manifolds run in one pass, one 16-lane DPP row per foot;
 //  * inertia and Newton Hessian share a tree-sparse row layout (row i = its ancestors by depth) and a fill-free
-//    L^T D L: shape A eliminates each serial dof chain in ONE lane's registers (chain_solve), shape B eliminates the
-//    three chains' pivots together (factor_chains);
+//    L^T D L: floating base + serial chains are solved by chain_solve -- the seven columns [C | y] of each chain's block
+//    in seven lanes, the base block's Schur complement one entry per lane; generic trees eliminate the chains' pivots
+//    together (factor_chains);
+//  * the dense symmetric row of M sits in registers through the solver (gathered once per substep): both M v products
+//    are 20 FMAs on LDS broadcast reads;
+//  * the line search's bracketing iterations evaluate derivatives only (two sums per step size), the three costs that
+//    pick the step are one evaluation at the end;
 //  * group reductions are fused v_add_f32_dpp / v_max_u32_dpp butterflies + gfx950 v_permlane16/32_swap; whole-vector
 //    broadcasts are LDS broadcast reads (the VALU is the busy unit, the LDS pipe is not).
 #pragma once
