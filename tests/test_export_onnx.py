@@ -48,3 +48,20 @@ def test_wire_format_is_valid_protobuf():
     out = X.run_onnx(m, np.array([[1, 2, 3, 4, 5]], np.float32))
     x = np.array([1, 2, 3, 4]) ; h = x / (1 + np.exp(-x)) * 1.0
     np.testing.assert_allclose(out, np.tanh(np.full((1, 3), h.sum())), rtol=1e-6)
+
+
+def test_self_check_survives_constant_observation_entries(tmp_path):
+    """Standing's unused command slots never vary: their std clamps to 1e-6, an all-ones observation normalises to 1e6 there
+    and float32 evaluations of the same network differ by rounding alone.  The export's self-check (which once ended a
+    training run at its last checkpoint) compares at mean +- std and only asks the all-ones input for finite actions."""
+    torch.manual_seed(1)
+    net = PPONetworks(85, 153, 14)
+    obs = torch.randn(4096, 85) * 2.0
+    obs[:, 10:17] = 0.0                      # entries that never vary
+    net.norm_obs.update(obs)
+    assert float(net.norm_obs.std[10]) == 1e-6
+    with torch.no_grad():                    # large first-layer weights on those entries: rounding is amplified
+        net.policy.layers[0].weight[:, 10:17] *= 50.0
+    path = X.export_onnx(net, str(tmp_path / "policy.onnx"), check=True)
+    m = X.load_onnx(open(path, "rb").read())
+    assert np.all(np.isfinite(X.run_onnx(m, np.ones((1, 85), np.float32))))
