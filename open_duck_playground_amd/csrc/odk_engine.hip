@@ -224,14 +224,18 @@ __device__ __forceinline__ void draw_block(uint32_t k0, uint32_t k1, uint32_t ct
 }
 
 // _get_obs (joystick.py:487-620): builds privileged_state[212] (whose first 101 entries are `state`) in LDS; NZ: draw_block
-template <class S, int G>
-__device__ __forceinline__ void build_obs(float* L, const DevModel* m, const EnvCfg& c, const float* contact, const float* NZ,
+// KIND (0 Joystick, 1 Standing) and the element loop are compile-time: element ks of pass `it` is lane + G it, so every
+// pass keeps only the few layout segments its 32 / 64 elements can fall into (as one runtime loop over c.npriv, each of the
+// seven passes walked all 23 segments' divergent branches).
+template <class S, int G, int KIND>
+__device__ __forceinline__ void build_obs_kind(float* L, const DevModel* m, const EnvCfg& c, const float* contact, const float* NZ,
                           int imitation_i, const float* phase, int lane) {
   using E = EnvL<S>;
   float* P = L + E::O_PRIV; float* INFO = L + E::O_INFO; const float* SENS = L + S::O_SENS; const float* SCR = L + S::O_SCR;
   const float* QPOS = L + S::O_QPOS; const float* QVEL = L + S::O_QVEL;
   const float lvl = c.noise_level;
   constexpr int NU = S::NU;
+  const float con0 = contact[0], con1 = contact[1], ph0 = phase[0], ph1 = phase[1];
   // imu history ring (noisy gravity, never emitted: joystick.py:522-530)
   float ng = 0;
   if (lane < 3) ng = SCR[S::S_MISC + 10 + lane] + (2.0f * NZ[10 - 4 + lane] - 1.0f) * lvl * c.noise_gravity;
@@ -240,8 +244,13 @@ __device__ __forceinline__ void build_obs(float* L, const DevModel* m, const Env
   ODK_SYNC();
   if (lane < 3) { INFO[rec::IMU + lane] = ng; INFO[rec::IMU + 3 + lane] = h0; INFO[rec::IMU + 6 + lane] = h1; }
   // Standing (standing.py:524-565) = the Joystick layout minus motor_targets, imitation phase, reference motion, imitation_i
-  const bool standing = c.kind != 0;
-  for (int ks = lane; ks < c.npriv; ks += G) {
+  constexpr bool standing = KIND != 0;
+  constexpr int NP = standing ? ODK_NPRIV_STANDING : ODK_NPRIV;
+#pragma unroll
+  for (int it = 0; it < (NP + G - 1) / G; it++) {
+    const int ks = lane + it * G;
+    __builtin_assume(ks >= it * G && ks < it * G + G);
+    if (ks >= NP) continue;
     const int k = !standing ? ks : (ks < 13 + 5 * NU ? ks : (ks < 15 + 5 * NU ? ks + NU : ks + ODK_NOBS - (15 + 5 * NU)));
     float v = 0;
     if (k < 3) v = SENS[m->adr_gyro + k] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_gyro;
@@ -258,8 +267,8 @@ __device__ __forceinline__ void build_obs(float* L, const DevModel* m, const Env
     else if (k < 13 + 4 * NU) v = INFO[rec::LAST2 + k - 13 - 3 * NU];
     else if (k < 13 + 5 * NU) v = INFO[rec::LAST3 + k - 13 - 4 * NU];
     else if (k < 13 + 6 * NU) v = INFO[rec::MT + k - 13 - 5 * NU];
-    else if (k < 15 + 6 * NU) v = contact[k - 13 - 6 * NU];
-    else if (k < 17 + 6 * NU) v = phase[k - 15 - 6 * NU];
+    else if (k < 15 + 6 * NU) v = (k - 13 - 6 * NU) ? con1 : con0;   // (scalars + selects: a runtime index parks the two-element arrays in scratch)
+    else if (k < 17 + 6 * NU) v = (k - 15 - 6 * NU) ? ph1 : ph0;
     else {
       int q = k - ODK_NOBS;  // privileged tail (joystick.py:596-615)
       if (q < 3) v = SENS[m->adr_gyro + q];
@@ -271,16 +280,22 @@ __device__ __forceinline__ void build_obs(float* L, const DevModel* m, const Env
       else if (q < 15 + 2 * NU) v = QVEL[m->act_dofadr[q - 15 - NU]];
       else if (q == 15 + 2 * NU) v = QPOS[2];
       else if (q < 16 + 3 * NU) v = L[S::O_ACTF + q - 16 - 2 * NU];
-      else if (q < 18 + 3 * NU) v = contact[q - 16 - 3 * NU];
+      else if (q < 18 + 3 * NU) v = (q - 16 - 3 * NU) ? con1 : con0;
       else if (q < 24 + 3 * NU) { const int t = q - 18 - 3 * NU; v = SENS[m->adr_foot_linvel[t / 3] + t % 3]; }
       else if (q < 26 + 3 * NU) v = INFO[rec::AIR + q - 24 - 3 * NU];
       else if (q < 66 + 3 * NU) v = L[E::O_REF + q - 26 - 3 * NU];
       else if (q == 66 + 3 * NU) v = (float)imitation_i;
-      else v = phase[q - 67 - 3 * NU];
+      else v = (q - 67 - 3 * NU) ? ph1 : ph0;
     }
     P[ks] = v;
   }
   ODK_SYNC();
+}
+template <class S, int G>
+__device__ __forceinline__ void build_obs(float* L, const DevModel* m, const EnvCfg& c, const float* contact, const float* NZ,
+                          int imitation_i, const float* phase, int lane) {
+  if (c.kind == 0) build_obs_kind<S, G, 0>(L, m, c, contact, NZ, imitation_i, phase, lane);
+  else build_obs_kind<S, G, 1>(L, m, c, contact, NZ, imitation_i, phase, lane);
 }
 
 __device__ __forceinline__ void foot_contact_flags(const float* CDIST, float* contact) {
