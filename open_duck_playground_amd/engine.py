@@ -93,6 +93,11 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise OdkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback for the env engine)")
+    # torch first: its wheel carries its own HIP runtime (torch/lib/libamdhip64.so), and the process must end up with ONE
+    # runtime -- libodk.so takes torch's device pointers and streams.  Loaded the other way round (dlopen here before any
+    # `import torch`, e.g. build() then smoke() in one process), libodk.so pulls /opt/rocm's copy in first and its
+    # hipSetDevice then reports "no ROCm-capable device" on a box whose GPU torch drives happily.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     P, PP = C.c_void_p, C.POINTER(C.c_void_p)
     FP, DP = C.POINTER(C.c_float), C.POINTER(C.c_double)

@@ -259,3 +259,15 @@ def test_engine_rollout_path_matches_the_generic_loop():
             if u == 0:
                 torch.testing.assert_close(a[:, 0], b[:, 0], rtol=1e-4, atol=1e-4)
             assert torch.equal(a, out[2][u][k])
+
+
+def test_smoke_after_library_load_in_a_fresh_process():
+    """The driver's entry points in ONE process, library first: `engine.load_library()` (what build() ends with) before anything
+    imported torch, then smoke().  libodk.so must end up on torch's HIP runtime, not on a second copy from /opt/rocm (whose
+    hipSetDevice found no device on the GPU box)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; assert 'torch' not in sys.modules; from open_duck_playground_amd import engine; engine.load_library(); "
+            "import __graft_entry__ as g; g.smoke()")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
