@@ -165,8 +165,10 @@ class Joystick:
 
     def make_eval_env(self, num_envs: int = 128):
         """Sibling env for the Evaluator (brax wraps `eval_env or environment` a second time with num_eval_envs)."""
+        # a few hundred envs leave most SIMDs empty, so an evaluation of 1000 sequential steps is bound by ONE wave's latency:
+        # 64 lanes per env (one env per wave) finish a step 7 % sooner than two envs sharing a wave (0.194 vs 0.209 ms at 128 envs)
         return type(self)(task=self._task, config=self._config, num_envs=num_envs, device=self._batch.device, autoreset=True,
-                          env_id_offset=1 << 24)
+                          lanes_per_env=64 if num_envs <= 1024 else 0, env_id_offset=1 << 24)
 
     def randomize(self, rng: np.random.Generator):
         """randomization_fn hook of brax ppo.train (reference runner.py:26, common/runner.py:108)."""
