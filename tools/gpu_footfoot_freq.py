@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0, '/root/repo')
+"""How often the foot-foot pair needs more than the bounding-sphere test in a random-action rollout (fractions of envs / of
+waves whose boxes overlap or whose feet penetrate):  python tools/gpu_footfoot_freq.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from open_duck_playground_amd import engine
 from open_duck_playground_amd.model import load_task_model

@@ -1,3 +1,4 @@
+"""Median duration per (kernel, grid) of a rocprofv3 kernel trace found under DIR:  python tools/kernel_trace_medians.py DIR [min_count]"""
 import csv, glob, collections, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
