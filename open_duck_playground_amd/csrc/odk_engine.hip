@@ -510,7 +510,8 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     // The model pointer is made opaque once per substep: the per-lane 64-bit table addresses (and loop-invariant table
     // loads) would otherwise be hoisted out of the loop and, with 256 VGPRs taken, parked in scratch -- ~150 dwords per
     // lane, private per wave, evicted to HBM (hundreds of MB per launch) -- while recomputing an address is one VALU op
-    // and the tables themselves are 60 KB shared by every wave (L1 / L2 resident).
+    // and the tables themselves are 60 KB shared by every wave (L1 / L2 resident).  (Still a win with ~60 VGPRs free: -6 % without
+    // the opaque pointer, -1 % without the opaque lane id -- the hoisted values lengthen live ranges, the loads they save are covered.)
     size_t opaque0 = 0;
     asm volatile("" : "+s"(opaque0));   // an offset, not the pointer itself: the address space (global) stays known
     const DevModel* ms = reinterpret_cast<const DevModel*>(reinterpret_cast<const char*>(m) + opaque0);
@@ -867,7 +868,7 @@ static void pack_imp(const float* solref, const float* solimp, float dt, float* 
 
 // Twin-dof detection and the reduced (twins merged) tree layouts -- see DevModel::paired.  Called after the dof / joint /
 // foot tables are in place.  Returns false when the reduced tree is not "floating base + up to three serial chains of <= 5
-// dofs" (the form the in-register chain solver is built for).
+// dofs" (the form chain_solve is built for).
 namespace {
 struct SparseLayout { int depth[MAXV], adr[MAXV], ancmask[MAXV], descmask[MAXV], anc_at[MAXV][MAXV], nnz; };
 // rows in dof order; row i = entries for i's ancestors by depth (c = depth[i]: the diagonal) -- tables.py _sparse_layout
