@@ -1878,8 +1878,9 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         for (int k = 0; k < 6; k++) qc += cd[k] * SCR[S::S_FF + 6 * f + k];
       }
     grad = ma - qfs - qc;
-    // T_f[column] = K_f cdof[column] (a twin shares its main dof's column)
-    if (st.d_tkind != 2) {
+    // T_f[column] = K_f cdof[column] (a twin shares its main dof's column).  Floating base + chains: done below, one (foot,
+    // column) pair per lane
+    if (S::CL == 0 && st.d_tkind != 2) {
 #pragma unroll
       for (int f = 0; f < 2; f++) {
         float* T = f ? BUF6B : BUF6;
@@ -1896,6 +1897,28 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       }
     }
     JV[i] = hdiag_extra;  // JV[0..NV) lies below the contact rows: free scratch for the per-dof diagonal addend
+  }
+  if constexpr (S::CL > 0) {
+    // The columns the Hessian entries read are those of the dofs above a foot: the six base dofs and the foot's own chain,
+    // 11 per foot at most.  Lane 11 f + idx computes column idx of foot f (36 FMAs) instead of every dof lane doing both
+    // feet (72); the other columns of BUF6 / BUF6B are never read (hess_entry tests the foot masks).
+    const int f = lane >= 6 + S::CL ? 1 : 0, idx = lane - (6 + S::CL) * f;
+    const int c0 = f ? m->foot_rchain_first[1] : m->foot_rchain_first[0], cl = f ? m->foot_rchain_len[1] : m->foot_rchain_len[0];
+    const bool lane_on = lane < 2 * (6 + S::CL) && idx - 6 < cl;
+    const int col = lane_on ? (idx < 6 ? idx : c0 + idx - 6) : 0;
+    const bool on = lane_on && ((f ? c_act[1] : c_act[0]) || c_act[2]);
+    float cdc[6];
+#pragma unroll
+    for (int b2 = 0; b2 < 6; b2++) cdc[b2] = CDOF[b2 * NR + col];
+    const float* Kf = SCR + S::S_K + 36 * f;
+    float* T = f ? BUF6B : BUF6;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+      float s0 = 0.0f;
+#pragma unroll
+      for (int b2 = 0; b2 < 6; b2++) s0 = fmaf(Kf[6 * a + b2], cdc[b2], s0);
+      if (lane_on) T[a * NR + col] = on ? s0 : 0.0f;
+    }
   }
   ODK_SYNC();
   ODK_PROF(11);
