@@ -333,7 +333,7 @@ struct Statics {
   int cs_pk;                             // chain_solve roles: lane 8 c + b -> chain c's length | head depth << 3 | first dof << 8 | row address << 14; lane q -> base entry (tb << 24 | tb2 << 27)
   int ch_first, ch_len;                  // the serial chain this lane's reduced dof belongs to (ch_len 0: base dof / no chain)
   int r_on, r_depth, r_Madr, r_ancmask, r_descmask, r_foot;   // reduced tree layout (virtual-tree statics: fetched in the rare path)
-  int r_pk;                              // r_Madr | r_depth << 16: one v_readlane hands both to the M v product
+  int m_adr[(S::NVR + 1) / 2];           // M v product: byte offset (from the env's LDS image) of M's entry (lane, j), two per register; unrelated dofs -> a structural zero
   // dof role (lane = dof)
   int d_on, d_body;
   int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
@@ -378,7 +378,20 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
     st.r_depth = m->red_depth[r]; st.r_Madr = m->red_Madr[r]; st.r_ancmask = m->red_ancmask[r]; st.r_descmask = m->red_descmask[r];
     st.r_foot = st.r_on ? m->red_foot[r] : 0;
     if (!st.r_on) { st.r_ancmask = 0; st.r_descmask = 0; st.r_depth = 0; }
-    st.r_pk = st.r_Madr | (st.r_depth << 16);
+    // dofs are numbered parents first: j < lane can only be an ancestor of this lane's dof (entry in this lane's row, column
+    // depth_j), j > lane only a descendant (entry in j's row, column depth_lane), j == lane the diagonal.  Unrelated pairs
+    // (and lanes past the reduced dofs) point at CDOF[0][0], the angular x component of the base's x translation: always 0.
+    const int rel = st.r_ancmask | st.r_descmask | (st.r_on ? (1 << r) : 0);
+    for (int jp = 0; jp < (S::NVR + 1) / 2; jp++) {
+      int pk = 0;
+      for (int h = 0; h < 2; h++) {
+        const int j = 2 * jp + h;
+        int off = S::O_CDOF * 4;
+        if (j < S::NVR && ((rel >> j) & 1)) off = (S::O_M + (j < r ? st.r_Madr + m->red_depth[j] : m->red_Madr[j] + st.r_depth)) * 4;
+        pk |= off << (16 * h);
+      }
+      st.m_adr[jp] = pk;
+    }
   }
   const int i = lane < S::NV ? lane : 0;
   st.d_on = lane < S::NV;
@@ -1452,19 +1465,13 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   // of 2 x v_readlane + select per element on the VALU.  Twin dofs: y_i = (Mr P^T v)_r(i) + ARM[i] v_i, handed from the
   // reduced-dof lanes to the dof lanes through YB (LDS, NR floats); vi = v of this lane's dof.
   float mrow[NR];
-  auto gather_M = [&]() {
-    const int lane_r = lane < NR ? lane : 0;   // (lanes past the reduced dofs: masks are empty, any in-range row)
-    // dofs are numbered parents first: j < lane can only be an ancestor of this lane's dof (entry in this lane's row, column
-    // depth_j), j > lane only a descendant (entry in j's row, column depth_i), j == lane the diagonal -- one mask test and one
-    // address select per j
-    const int rel = st.r_ancmask | st.r_descmask | (st.r_on ? (1 << lane_r) : 0);
-    const int own = st.r_Madr, dep = st.r_depth;
+  auto gather_M = [&]() {   // (addresses: Statics::m_adr, one unpack per entry)
+    static_assert(S::CL > 0, "the zero entry of unrelated dofs is the floating base's CDOF[0][0]");
+    static_assert(S::TOTAL * 4 < 65536, "16-bit byte offsets");
 #pragma unroll
     for (int j = 0; j < NR; j++) {
-      const int pk = ubcast(st.r_pk, j), aj = pk & 0xFFFF, dj = pk >> 16;   // one readlane; the unpacking runs on the scalar unit
-      const int adr = j < lane_r ? own + dj : aj + dep;     // (j == lane: aj + dep = own + depth = the diagonal)
-      const float mij = M[adr];
-      mrow[j] = ((rel >> j) & 1) ? mij : 0.0f;
+      const unsigned off = ((unsigned)st.m_adr[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+      mrow[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(L) + off);
     }
   };
   auto mul_M = [&](const float* VB, float* YB, float vi) -> float {
