@@ -1405,18 +1405,24 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   ODK_PROF(3);
   // ---------------- P4: sparse reduced inertia entries (lane = entry): cdof_j . (crb cdof_i), armature on the unpaired
   // diagonals only (a pair's armatures enter the solves as the series term pair_einv, and M v as ARM[i] v_i)
+  // Branch-free and batched: all table reads, then all operand reads, then the sums -- as a loop of guarded passes every pass
+  // was two dependent LDS round trips behind the previous one's (lanes past the last entry redo entry 0 and store nothing).
+  {
+    int ee[ST::NME];
 #pragma unroll
-  for (int t = 0; t < ST::NME; t++) {
-    const int pq = lane + t * G;
-    const int e = pq < S::NMR ? RT[pq] : -1;
-    if (e >= 0) {
-      const int i = e & 31, j = (e >> 5) & 31;
+    for (int t = 0; t < ST::NME; t++) { const int pq = lane + t * G; ee[t] = RT[pq < S::NMR ? pq : 0]; }
+    float vv[ST::NME];
+#pragma unroll
+    for (int t = 0; t < ST::NME; t++) {
+      const int e = ee[t], i = e & 31, j = (e >> 5) & 31;
+      const float arm = ARM[(e >> 16) & 31];
       float v = 0;
 #pragma unroll
       for (int k = 0; k < 6; k++) v += CDOF[k * NR + j] * BUF6[k * NR + i];
-      if (((e >> 14) & 3) == 1) v += ARM[(e >> 16) & 31];   // diagonal of an unpaired dof
-      M[lane + t * G] = v;
+      vv[t] = v + ((((e >> 14) & 3) == 1) ? arm : 0.0f);   // diagonal of an unpaired dof
     }
+#pragma unroll
+    for (int t = 0; t < ST::NME; t++) { const int pq = lane + t * G; if (pq < S::NMR) M[pq] = vv[t]; }
   }
   ODK_SYNC();
   ODK_PROF(4);
