@@ -1969,10 +1969,38 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   float search;
   if (!any_ffa) {
     // ---- common case: no foot-foot coupling -> the Hessian has the reduced inertia's own tree pattern
+    // hess_entry, branch-free and batched like the inertia entries (P4): table + M reads, then the operands, then the sums.
+    // A one-foot entry takes its K cdof column from a per-lane buffer select; entries between two base dofs (both feet) are
+    // the first 21 of the layout -- rows 0 .. 5 -- so the second foot's term exists in the first pass only.  Unused terms are
+    // dropped by selects, never multiplied by zero (their operands may be unwritten).
+    {
+      static_assert(G >= 21, "base x base entries must sit in the first pass");
+      int ee[ST::NME]; float mm[ST::NME], hv[ST::NME];
 #pragma unroll
-    for (int t = 0; t < ST::NME; t++) {
-      const int p = lane + t * G;
-      if (p < S::NMR) HL[p] = hess_entry(RT[p], M[p]);
+      for (int t = 0; t < ST::NME; t++) { const int p = lane + t * G, pc = p < S::NMR ? p : 0; ee[t] = RT[pc]; mm[t] = M[pc]; }
+#pragma unroll
+      for (int t = 0; t < ST::NME; t++) {
+        const int e = ee[t], i = e & 31, j = (e >> 5) & 31, both = (e >> 10) & (e >> 12) & 3, u = (e >> 16) & 31;
+        float dterm = JV[u];
+        if constexpr (S::PAIRED) { const float pe = pair_einv(ARM, JV, u); dterm = ((e >> 15) & 1) ? pe : dterm; }
+        float cj[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cj[k] = CDOF[k * NR + j];
+        const float* T1 = (both & 1) ? BUF6 : BUF6B;
+        float s1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s1 = fmaf(cj[k], T1[k * NR + i], s1);
+        float v = mm[t] + (((e >> 14) & 1) ? dterm : 0.0f) + (both ? s1 : 0.0f);
+        if (t == 0) {
+          float s2 = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 6; k++) s2 = fmaf(cj[k], BUF6B[k * NR + i], s2);
+          v += both == 3 ? s2 : 0.0f;
+        }
+        hv[t] = v;
+      }
+#pragma unroll
+      for (int t = 0; t < ST::NME; t++) { const int p = lane + t * G; if (p < S::NMR) HL[p] = hv[t]; }
     }
     if constexpr (S::PAIRED) { if (st.r_on) MV[lane] = rhs; }
     ODK_SYNC();
