@@ -1783,16 +1783,28 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     jar_lim_s = lim_sgn * qas - ar; jar_lim_w = lim_sgn * warm - ar;
     cost_s += quad_cost(lim_D, jar_lim_s, fo); cost_w += quad_cost(lim_D, jar_lim_w, fo);
   }
-  for (int rc = lane; rc < S::NCROW; rc += G) {
-    const int r = r0c + rc;
-    const float D = ED[r];
-    float js = 0, jw = 0;
+  const bool c_act[3] = {fminf(fminf(CDIST[0], CDIST[1]), fminf(CDIST[2], CDIST[3])) < 0, fminf(fminf(CDIST[4], CDIST[5]), fminf(CDIST[6], CDIST[7])) < 0,
+                         fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0};
+  // wave-uniform: some env of the wave has a penetrating foot-foot contact.  Without one, contact rows 32-47 have D = 0 in
+  // both envs and their lane slot (G = 32: the second one) is skipped in the force sums and in the line search.
+  const bool any_ff = __builtin_amdgcn_ballot_w64(c_act[2]) != 0;
+  // contact rows of this lane (rc = lane + t G): D and Jaref stay in registers from here to the end of the line search
+  constexpr int NCL = (S::NCROW + G - 1) / G;
+  float cD[NCL], cjar[NCL], cjv[NCL];   // cjv: the warmstart candidate's Jaref until the choice below, J search in the line search
+#pragma unroll
+  for (int t = 0; t < NCL; t++) {
+    const int rc = lane + t * G;
+    cD[t] = 0.0f; cjar[t] = 0.0f; cjv[t] = 0.0f;
+    if (t * G >= 32 && !any_ff) continue;   // foot-foot slot, nothing active in the wave
+    const bool on = rc < S::NCROW;
+    const int rcl = on ? rc : 0, r = r0c + rcl;
+    const float D = on ? ED[r] : 0.0f;
+    cD[t] = D;
     if (D > 0) {
       const float ar = AREF[r];
-      js = contact_jx(rc, SCR + S::S_VF) - ar; jw = contact_jx(rc, SCR + S::S_VF2) - ar;
-      cost_s += quad_cost(D, js, fo); cost_w += quad_cost(D, jw, fo);
+      cjar[t] = contact_jx(rcl, SCR + S::S_VF) - ar; cjv[t] = contact_jx(rcl, SCR + S::S_VF2) - ar;
+      cost_s += quad_cost(D, cjar[t], fo); cost_w += quad_cost(D, cjv[t], fo);
     }
-    JAR[r] = js; JV[r] = jw;
   }
   float gauss_w;
   { float r3[3] = {cost_s, gw, cost_w}; gsum_n<G, 3>(r3); cost_s = r3[0]; gauss_w = 0.5f * r3[1]; cost_w = r3[2] + gauss_w; }
@@ -1801,9 +1813,12 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   const float x = use_warm ? warm : qas;
   const float ma = use_warm ? ma_w : qfs;
   const float jar_fl = use_warm ? jar_fl_w : jar_fl_s, jar_lim = use_warm ? jar_lim_w : jar_lim_s;
-  ODK_SYNC();
-  if (use_warm) for (int rc = lane; rc < S::NCROW; rc += G) JAR[r0c + rc] = JV[r0c + rc];
-  ODK_SYNC();
+#pragma unroll
+  for (int t = 0; t < NCL; t++) {
+    cjar[t] = use_warm ? cjv[t] : cjar[t];
+    const int rc = lane + t * G;
+    if (rc < S::NCROW) JAR[r0c + rc] = cjar[t];   // debug image only
+  }
   ODK_PROF(10);
   // forces of the chosen point: friction / limit rows stay in registers, contact forces -> JV
   float f_fl = 0, f_lim = 0;
@@ -1812,11 +1827,6 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   if (st.d_lim_on) quad_cost(lim_D, jar_lim, f_lim);
   // friction-row quantities are owned by lane = row; the dof that needs them is another lane: hand over through LDS
   if (lane < nfl) { MV[fs.dof] = f_fl; MA[fs.dof] = quad_fl ? fs.D : 0.0f; }
-  const bool c_act[3] = {fminf(fminf(CDIST[0], CDIST[1]), fminf(CDIST[2], CDIST[3])) < 0, fminf(fminf(CDIST[4], CDIST[5]), fminf(CDIST[6], CDIST[7])) < 0,
-                         fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0};
-  // wave-uniform: some env of the wave has a penetrating foot-foot contact.  Without one, contact rows 32-47 have D = 0 in
-  // both envs and their lane slot (G = 32: the second one) is skipped in the force sums and in the line search.
-  const bool any_ff = __builtin_amdgcn_ballot_w64(c_act[2]) != 0;
   // Foot wrench sums FF_f = sum_r w_r f_r and 6x6 blocks K_f = sum_r D_r [active] w_r w_r^T.  Contact row rc sits in
   // lane rc: rows 0-15 (left foot), 16-31 (right foot) and 32-47 (foot-foot) are exactly the 16-lane DPP rows, so
   // each sum is four DPP adds; lane 0 of a row stores its block.  (G = 32: the foot-foot rows are a second slot.)
@@ -1831,7 +1841,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       float w[6];
 #pragma unroll
       for (int k = 0; k < 6; k++) w[k] = W[6 * rcl + k];
-      const float D = ED[r], jar = JAR[r];
+      const float D = cD[t], jar = cjar[t];
       const float act = (on && D > 0 && jar < 0) ? D : 0.0f;
       const float fr = -act * jar;
       float v[27];
@@ -2086,21 +2096,13 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   float jv_fl = 0, jv_lim = 0;
   if (lane < nfl) jv_fl = GRAD[fs.dof];
   if (st.d_lim_on) jv_lim = lim_sgn * search;
-  // contact rows of this lane in registers for the line search
-  constexpr int NCL = (S::NCROW + G - 1) / G;
-  float cD[NCL], cjar[NCL], cjv[NCL];
+  // J search of this lane's contact rows
 #pragma unroll
   for (int t = 0; t < NCL; t++) {
     const int rc = lane + t * G;
     const bool on = rc < S::NCROW;
-    if (t * G >= 32 && !any_ff) {   // foot-foot slot, nothing active in the wave
-      cD[t] = 0.0f; cjar[t] = 0.0f; cjv[t] = 0.0f;
-      if (on) JV[r0c + rc] = 0.0f;  // debug image only
-      continue;
-    }
-    cD[t] = on ? ED[r0c + rc] : 0.0f;
-    cjar[t] = on ? JAR[r0c + rc] : 0.0f;
-    cjv[t] = (on && cD[t] > 0) ? contact_jx(rc, SCR + S::S_VF) : 0.0f;
+    cjv[t] = 0.0f;
+    if (!(t * G >= 32 && !any_ff)) cjv[t] = (on && cD[t] > 0) ? contact_jx(rc, SCR + S::S_VF) : 0.0f;
     if (on) JV[r0c + rc] = cjv[t];  // debug image only
   }
   ODK_PROF(15);
