@@ -1430,15 +1430,17 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   float qas;
   if constexpr (S::PAIRED) {
     // M = P Mr P^T + diag(armature): reduced system with the pairs' series armature on the diagonal (HL), one chain solve
+    {   // (branch-free and batched, as P4)
+      int ee[ST::NME]; float mm[ST::NME];
 #pragma unroll
-    for (int t = 0; t < ST::NME; t++) {
-      const int p = lane + t * G;
-      if (p < S::NMR) {
-        const int e = RT[p];
-        float v = M[p];
-        if ((e >> 15) & 1) v += pair_einv(ARM, nullptr, (e >> 16) & 31);
-        HL[p] = v;
+      for (int t = 0; t < ST::NME; t++) { const int p = lane + t * G, pc = p < S::NMR ? p : 0; ee[t] = RT[pc]; mm[t] = M[pc]; }
+#pragma unroll
+      for (int t = 0; t < ST::NME; t++) {
+        const float pe = pair_einv(ARM, nullptr, (ee[t] >> 16) & 31);
+        mm[t] += ((ee[t] >> 15) & 1) ? pe : 0.0f;
       }
+#pragma unroll
+      for (int t = 0; t < ST::NME; t++) { const int p = lane + t * G; if (p < S::NMR) HL[p] = mm[t]; }
     }
     if (st.r_on) GRAD[lane] = pair_rhs<S>(QFS, ARM, nullptr, m, lane);
     ODK_SYNC();
