@@ -888,6 +888,35 @@ void sparse_layout(const int* parent, int n, SparseLayout& L) {
   }
 }
 }  // namespace
+// DevModel::body_st: what forward_env's sweeps need of each body, flattened (index MAXB: the record of a lane without a body)
+static void fill_body_st(DevModel& m) {
+  auto fill = [&](BodySt& b, int bi, bool in) {
+    memset(&b, 0, sizeof(b));
+    b.level = in ? m.body_level[bi] : -2;
+    b.parent = m.body_parent[bi];
+    b.nchild = in ? m.body_nchild[bi] : 0;
+    b.pathmask = in ? m.body_pathmask[bi] : 0;
+    b.is_path = in ? m.body_is_path[bi] : 0;
+    b.upmask = in ? m.body_upmask[bi] : 0;
+    b.path_head = in ? m.body_path_head[bi] : 0;
+    for (int k = 0; k < 3; k++) b.child[k] = m.body_children[bi][k];
+    b.njnt = (in && b.level > 0) ? m.body_jntnum[bi] : 0;
+    for (int k = 0; k < 2; k++) {
+      const bool on = k < b.njnt;
+      const int j = on ? m.body_jntadr[bi] + k : 0;
+      b.jj[k] = j;
+      b.jd[k] = m.jnt_dofadr[j];
+      b.jr[k] = (m.paired && m.dof_tkind[b.jd[k]] == 2) ? -1 : m.dof_red[b.jd[k]];
+      for (int c = 0; c < 3; c++) b.ax[k][c] = on ? m.jnt_axis[j][c] : 0.0f;
+    }
+    for (int c = 0; c < 3; c++) { b.pos[c] = m.body_pos[bi][c]; b.ipos[c] = m.body_ipos[bi][c]; }
+    for (int c = 0; c < 4; c++) b.quat[c] = m.body_quat[bi][c];
+    for (int c = 0; c < 6; c++) b.inertia[c] = m.body_inertia[bi][c];
+  };
+  for (int bi = 0; bi < m.nb; bi++) fill(m.body_st[bi], bi, true);
+  fill(m.body_st[MAXB], 0, false);
+}
+
 static bool build_reduced_tables(DevModel& m) {
   m.paired = 0; m.nrchain = 0;
   int ntwin = 0;
@@ -1188,6 +1217,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     }
   }
   if (!build_reduced_tables(m)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "dof tree is not a floating base with up to three serial chains of <= 5 (twin-merged) dofs"); }
+  fill_body_st(m);
   int dt_max = 0, dv_max = 0;
   for (int d = 0; d < m.nv; d++) { dt_max = m.dof_depth[d] > dt_max ? m.dof_depth[d] : dt_max; dv_max = m.vdof_depth[d] > dv_max ? m.vdof_depth[d] : dv_max; }
   auto fits = [&](int nq, int nv, int nb, int nu, int nj, int nM, int nH, int nrow, int DT, int DV) {

@@ -343,10 +343,7 @@ struct Statics {
 };
 // Phase-local statics: fetched from the model (L1/L2-resident, one batch of loads per phase and substep)
 // right where they are used, so they do not occupy registers for the rest of the substep.
-struct BodySt {
-  int level, parent, nchild, child[3], njnt, jd[2], jj[2], jr[2], pathmask, is_path, upmask, path_head;   // jr: CDOF column of the joint's dof (-1: twin, its main dof's column is the same vector)
-  float pos[3], quat[4], ipos[3], inertia[6], ax[2][3];
-};
+// (BodySt: odk_model.h -- the per-body records are part of the device model)
 struct ActSt { float bias2, clo, chi, flo, fhi; int climited, flimited; };
 struct FlSt { float D, R, b; int dof; };
 
@@ -409,27 +406,7 @@ __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* 
 }
 template <class S>
 __device__ __forceinline__ void load_body(BodySt& b, const DevModel* __restrict__ m, int lane) {
-  const int bi = lane < S::NB ? lane : 0;
-  b.level = lane < S::NB ? m->body_level[bi] : -2;
-  b.parent = m->body_parent[bi];
-  b.nchild = lane < S::NB ? m->body_nchild[bi] : 0;
-  b.pathmask = lane < S::NB ? m->body_pathmask[bi] : 0;
-  b.is_path = lane < S::NB ? m->body_is_path[bi] : 0;
-  b.upmask = lane < S::NB ? m->body_upmask[bi] : 0;
-  b.path_head = lane < S::NB ? m->body_path_head[bi] : 0;
-  for (int k = 0; k < 3; k++) b.child[k] = m->body_children[bi][k];
-  b.njnt = (lane < S::NB && b.level > 0) ? m->body_jntnum[bi] : 0;
-  for (int k = 0; k < 2; k++) {
-    const bool on = k < b.njnt;
-    const int j = on ? m->body_jntadr[bi] + k : 0;
-    b.jj[k] = j;
-    b.jd[k] = m->jnt_dofadr[j];
-    b.jr[k] = (S::PAIRED && m->dof_tkind[b.jd[k]] == 2) ? -1 : m->dof_red[b.jd[k]];
-    for (int c = 0; c < 3; c++) b.ax[k][c] = on ? m->jnt_axis[j][c] : 0.0f;
-  }
-  for (int c = 0; c < 3; c++) { b.pos[c] = m->body_pos[bi][c]; b.ipos[c] = m->body_ipos[bi][c]; }
-  for (int c = 0; c < 4; c++) b.quat[c] = m->body_quat[bi][c];
-  for (int c = 0; c < 6; c++) b.inertia[c] = m->body_inertia[bi][c];
+  b = m->body_st[lane < S::NB ? lane : MAXB];   // one record per body, host-built (DevModel::body_st)
 }
 __device__ __forceinline__ void load_act(ActSt& a, const DevModel* __restrict__ m, int act) {
   const int u = act >= 0 ? act : 0;

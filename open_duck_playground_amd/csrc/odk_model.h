@@ -19,7 +19,17 @@ constexpr int MAXSENS = 16;
 constexpr int NCON = 12;     // 3 geom pairs x 4 contacts
 constexpr int NSENSD = 46;
 
+// Per-body constants of the kinematics / inertia sweeps, one record per body (+ one "no body" record at index MAXB for the lanes
+// past the last body), filled on the host (odk_engine.hip fill_body_st): the kernel fetches a lane's record with ONE address
+// computation and no dependent loads (as separate tables the joint-derived fields were three dependent loads deep).
+struct BodySt {
+  int level, parent, nchild, child[3], njnt, jd[2], jj[2], jr[2], pathmask, is_path, upmask, path_head;   // jr: CDOF column of the joint's dof (-1: twin, its main dof's column is the same vector)
+  float pos[3], quat[4], ipos[3], inertia[6], ax[2][3];
+  int pad;   // 40 dwords
+};
+
 struct DevModel {
+  BodySt body_st[MAXB + 1];
   int nq, nv, nu, nb, nj, nM, nH, nfl, nlim, nrow, nsite, nsensor;
   float dt, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int ls_iterations, iterations;
