@@ -1232,6 +1232,10 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     return fail(ODK_ERR_UNSUPPORTED, "the 30-dof kernels expect backlash twins (same body, anchor and axis as their joint) over the 20-dof tree");
   }
   if (mo->shape == 0 && m.paired) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "twin dofs in a model of the 20-dof shape"); }
+  for (int lane = 0; lane < 64; lane++) {   // per-lane statics of the kernels (LaneSt)
+    memset(&m.lane_st[lane], 0, sizeof(LaneSt));
+    if (mo->shape == 0) compute_statics<ShapeA>(m.lane_st[lane], &m, lane); else compute_statics<ShapeB>(m.lane_st[lane], &m, lane);
+  }
   *out = mo;
   return ODK_OK;
 }

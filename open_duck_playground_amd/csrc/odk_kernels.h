@@ -325,21 +325,10 @@ __device__ __forceinline__ int randint3(float u) { int i = (int)(u * 3.0f); retu
 // Persistent part: what the factor / solve / solver phases need all the time (kept small: register pressure
 // decides whether two wavefronts fit on a SIMD).
 template <class S, int G>
-struct Statics {
+struct Statics : LaneSt {   // (data members: odk_model.h LaneSt)
   static constexpr int NME = (S::NMR + G - 1) / G;  // reduced inertia entries per lane
   static constexpr int NHE = (S::NHR + G - 1) / G;  // reduced virtual-tree Hessian entries per lane
-  int j_qadr, j_dadr;                    // joint role (sin/cos phase, Euler)
-  // reduced-dof role (lane = reduced dof, DevModel::paired; a model without twins: reduced dof = dof)
-  int cs_pk;                             // chain_solve roles: lane 8 c + b -> chain c's length | head depth << 3 | first dof << 8 | row address << 14; lane q -> base entry (tb << 24 | tb2 << 27)
-  int ch_first, ch_len;                  // the serial chain this lane's reduced dof belongs to (ch_len 0: base dof / no chain)
-  int r_on, r_depth, r_Madr, r_ancmask, r_descmask, r_foot;   // reduced tree layout (virtual-tree statics: fetched in the rare path)
-  int m_adr[(S::NVR + 1) / 2];           // M v product: byte offset (from the env's LDS image) of M's entry (lane, j), two per register; unrelated dofs -> a structural zero
-  // dof role (lane = dof)
-  int d_on, d_body;
-  int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
-  int d_qadr, d_lim_on;                  // hinge qpos address (-1: free joint); has a limit row
-  int d_tkind, d_red;                    // twin dofs (DevModel::paired): 0 unpaired / 1 main (twin = dof + 1) / 2 twin; reduced dof
-  float d_damping, d_lo, d_hi;           // joint range of the dof's hinge
+  static_assert((S::NVR + 1) / 2 <= 16, "LaneSt::m_adr");
 };
 // Phase-local statics: fetched from the model (L1/L2-resident, one batch of loads per phase and substep)
 // right where they are used, so they do not occupy registers for the rest of the substep.
@@ -347,8 +336,13 @@ struct Statics {
 struct ActSt { float bias2, clo, chi, flo, fhi; int climited, flimited; };
 struct FlSt { float D, R, b; int dof; };
 
+// Device side: the lane's host-built record (DevModel::lane_st, filled by compute_statics below at model load)
 template <class S, int G>
 __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* __restrict__ m, int lane) {
+  static_cast<LaneSt&>(st) = m->lane_st[lane];
+}
+template <class S>
+__host__ __device__ inline void compute_statics(LaneSt& st, const DevModel* m, int lane) {
   {
     const bool on = lane >= 1 && lane < S::NJ;
     st.j_qadr = on ? m->jnt_qposadr[on ? lane : 0] : -1;

@@ -28,8 +28,26 @@ struct BodySt {
   int pad;   // 40 dwords
 };
 
+// Per-lane statics of the step kernels (odk_kernels.h Statics = this + compile-time counts), host-built per lane like the body
+// records: compute_statics runs on the host once per model, the kernels copy their lane's record.
+struct LaneSt {
+  int j_qadr, j_dadr;                    // joint role (sin/cos phase, Euler)
+  // reduced-dof role (lane = reduced dof, DevModel::paired; a model without twins: reduced dof = dof)
+  int cs_pk;                             // chain_solve roles: lane 8 c + b -> chain c's length | head depth << 3 | first dof << 8 | row address << 14; lane q -> base entry (tb << 24 | tb2 << 27)
+  int ch_first, ch_len;                  // the serial chain this lane's reduced dof belongs to (ch_len 0: base dof / no chain)
+  int r_on, r_depth, r_Madr, r_ancmask, r_descmask, r_foot;   // reduced tree layout (virtual-tree statics: fetched in the rare path)
+  int m_adr[16];                         // M v product: byte offset (from the env's LDS image) of M's entry (lane, j), two per register; unrelated dofs -> a structural zero
+  // dof role (lane = dof)
+  int d_on, d_body;
+  int d_act, d_flrow, d_limrow, d_foot;  // d_foot: bit0 moves left foot, bit1 right foot
+  int d_qadr, d_lim_on;                  // hinge qpos address (-1: free joint); has a limit row
+  int d_tkind, d_red;                    // twin dofs (DevModel::paired): 0 unpaired / 1 main (twin = dof + 1) / 2 twin; reduced dof
+  float d_damping, d_lo, d_hi;           // joint range of the dof's hinge
+};
+
 struct DevModel {
   BodySt body_st[MAXB + 1];
+  LaneSt lane_st[64];
   int nq, nv, nu, nb, nj, nM, nH, nfl, nlim, nrow, nsite, nsensor;
   float dt, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int ls_iterations, iterations;
