@@ -10,7 +10,9 @@
 // What makes it fast (all exact in real arithmetic; DESIGN.md 4.1 has the measurements):
 //  * occupancy by construction: <= 256 VGPRs => 2 waves/SIMD = 8 workgroups/CU, and the LDS image is sized so that 8
 //    workgroups fit (shape A: 2 412 floats/env; LDS, not registers, is what rules out a third wave) => 8192 envs are
-//    exactly two rounds.  The kernel is bound by VALU issue: what pays is fewer instructions, not fewer loads;
+//    exactly two rounds.  Two waves keep the VALU ~70 % busy; each wave is paced by its own chain of dependent
+//    instructions and LDS round trips (a second wave stretches every phase by 1.0-1.2x only): what pays is fewer
+//    instructions and fewer serialised round trips -- not fewer loads from the model, those are covered;
 //  * per-lane statics (a lane's dof depth, row address, ancestor / descendant masks...) are read once per launch into
 //    registers (struct Statics); phase-local constants are re-fetched from the L2-resident model where they are used;
 //    the model pointer is made opaque once per substep so that table addresses are not hoisted into scratch;
