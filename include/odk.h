@@ -143,6 +143,9 @@ int odk_lds_offset(const odk_batch* b, const char* name);
 /* raw per-env info record (floats, layout in csrc/odk_engine.hip) for tests */
 int odk_batch_record_size(const odk_batch* b);
 int odk_batch_get_records(odk_batch* b, float* host_records);
+/* writes the records back (synchronous): restores a saved batch, or presets carried `info` fields -- e.g. info["step"] = 500 so
+ * that the next step resamples the command (joystick.py:456-466) */
+int odk_batch_set_records(odk_batch* b, const float* host_records);
 
 /* ---- learner-side kernels (csrc/odk_learner.hip): the element-wise halves of one PPO minibatch step.  The
  * reference reaches them through brax ppo.train (common/runner.py:104-118): ppo.losses.compute_gae /

@@ -1470,6 +1470,13 @@ extern "C" int odk_batch_get_records(odk_batch* b, float* host) {
   HIPCHK(hipMemcpy(host, b->d_recs, (size_t)b->nenv * b->rec_size * sizeof(float), hipMemcpyDeviceToHost));
   return ODK_OK;
 }
+extern "C" int odk_batch_set_records(odk_batch* b, const float* host) {   // checkpoint restore / test presets of the carried info
+  if (!b || !host) return fail(ODK_ERR_INVALID, "null");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(b->d_recs, host, (size_t)b->nenv * b->rec_size * sizeof(float), hipMemcpyHostToDevice));
+  return ODK_OK;
+}
 extern "C" int odk_batch_get_lds(odk_batch* b, float* host) {  // debug image of the last forward pass (reset / physics_step / step with dump on)
   if (!b || !host) return fail(ODK_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(b->device));

@@ -126,6 +126,7 @@ def load_library() -> C.CDLL:
     L.odk_lds_offset.argtypes = [P, C.c_char_p]
     L.odk_batch_record_size.argtypes = [P]
     L.odk_batch_get_records.argtypes = [P, FP]
+    L.odk_batch_set_records.argtypes = [P, FP]
     L.odk_batch_timing.argtypes = [P, C.c_int, FP, C.POINTER(C.c_int)]
     L.odk_gae.argtypes = [P, P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_float, P]
     L.odk_ppo_head.argtypes = [P] * 11 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P]
@@ -154,7 +155,7 @@ EXPORTED_SYMBOLS = (
     "odk_model_env_lds_floats", "odk_batch_create",
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
-    "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
+    "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_set_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
     "odk_policy_sample", "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows", "odk_dw_gemm",
     "odk_mlp_forward", "odk_mlp_backward", "odk_mlp_set_profile", "odk_pack_weights", "odk_adam_clip_packed", "odk_colsum_fold")
 
@@ -709,6 +710,11 @@ class Batch:
         r = np.zeros((self.nenv, n), np.float32)
         _chk(self.L.odk_batch_get_records(self._b, _fp(r)))
         return r
+
+    def set_records(self, records: np.ndarray):
+        r = np.ascontiguousarray(records, np.float32)
+        assert r.shape == (self.nenv, self.L.odk_batch_record_size(self._b))
+        _chk(self.L.odk_batch_set_records(self._b, _fp(r)))
 
     def timing(self, enable):
         """Average kernel milliseconds of the timed launches since the last call; `enable`: False / 0 = off, True / 1 = time every

@@ -239,6 +239,11 @@ odko_env* odko_env_new(const odko_model* m, const odko_prm* prm, const odko_env_
   return e;
 }
 void odko_env_free(odko_env* e) { free(e); }
+odko_env* odko_env_clone(const odko_env* e) { /* flat struct (model / table pointers are shared): tests step copies from one state */
+  odko_env* c = (odko_env*)malloc(sizeof(odko_env));
+  memcpy(c, e, sizeof(odko_env));
+  return c;
+}
 odko_data* odko_env_data(odko_env* e) { return &e->d; }
 
 #define CF(nm, cnt) if (!strcmp(name, #nm)) { *count = (cnt); return (real*)&e->cfg.nm; }

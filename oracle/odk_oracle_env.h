@@ -76,6 +76,7 @@ void odko_prm_eval64(const odko_prm* p, double dx, double dy, double dth, int i,
 
 odko_env* odko_env_new(const odko_model* m, const odko_prm* prm, const odko_env_cfg* cfg);
 void odko_env_free(odko_env* e);
+odko_env* odko_env_clone(const odko_env* e);
 real* odko_env_config(odko_env* e, const char* name, int* count);
 real* odko_env_field(odko_env* e, const char* name, int* count);
 int* odko_env_int(odko_env* e, const char* name, int* count);

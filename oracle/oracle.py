@@ -56,6 +56,7 @@ class _Lib:
         L.odko_prm_index.argtypes = [P, self.real, self.real, self.real, C.POINTER(C.c_int)]
         L.odko_env_new.restype = P; L.odko_env_new.argtypes = [P, P, P]
         L.odko_env_free.argtypes = [P]
+        L.odko_env_clone.restype = P; L.odko_env_clone.argtypes = [P]
         L.odko_env_config.restype = RP; L.odko_env_config.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
         L.odko_env_field.restype = RP; L.odko_env_field.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
         L.odko_env_int.restype = C.POINTER(C.c_int); L.odko_env_int.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
@@ -218,15 +219,19 @@ class OraclePRM:
 class OracleEnv:
     """One Joystick environment (reference joystick.py) incl. Episode/AutoReset wrappers."""
 
-    def __init__(self, model: OracleModel, prm: OraclePRM, standing: bool = False):
+    def __init__(self, model: OracleModel, prm: OraclePRM, standing: bool = False, _handle=None):
         self.L = model.L
         self.m, self.prm = model, prm
-        self.h = self.L.lib.odko_env_new(model.h, prm.h, None)
-        if standing:   # reference standing.py defaults on top of the Joystick ones
+        self.h = _handle if _handle is not None else self.L.lib.odko_env_new(model.h, prm.h, None)
+        if standing and _handle is None:   # reference standing.py defaults on top of the Joystick ones
             self.L.lib.odko_env_set_standing(self.h)
         self.f = _Fields(self.L, self.h, self.L.lib.odko_env_field)
         self.cfg = _Fields(self.L, self.h, self.L.lib.odko_env_config)
         self.data = OracleData(model, _handle=self.L.lib.odko_env_data(self.h), owner=False)
+
+    def clone(self) -> "OracleEnv":
+        """an independent copy of the whole env (state, info, wrappers, config) sharing the model and the motion table"""
+        return OracleEnv(self.m, self.prm, _handle=self.L.lib.odko_env_clone(self.h))
 
     def __getitem__(self, name):
         return self.f.view(name)

@@ -194,20 +194,24 @@ def test_lanes64_geometry_matches_default():
     assert np.abs(a[4] - c[4]).max() < 2e-4
 
 
-def test_full_size_rollout_properties():
-    """BASELINE size (8192 envs, flat_terrain, noise and pushes on): size-independent properties of a 60-step
-    random-action rollout -- everything finite, rewards inside the clip range, alive reward constant, terminations
-    happen but stay a minority, truncation only ever together with done, and a second batch with the same seed
-    reproduces the run bit for bit."""
+@pytest.mark.parametrize("task,dr", [("flat_terrain", False), ("flat_terrain_backlash", True), ("rough_terrain_backlash", True)])
+def test_full_size_rollout_properties(task, dr):
+    """BASELINE size (8192 envs; configs 2, 3 and 4: flat_terrain, flat_terrain_backlash + randomize.py, rough_terrain_backlash +
+    randomize.py; noise and pushes on): size-independent properties of a 60-step random-action rollout -- everything finite,
+    rewards inside the clip range, alive reward constant, terminations happen but stay a minority, truncation only ever together
+    with done, and a second batch with the same seed reproduces the run bit for bit."""
     import torch
-    from open_duck_playground_amd import engine
+    from open_duck_playground_amd import engine, randomize
     from open_duck_playground_amd.model import load_task_model
-    model = load_task_model("flat_terrain")
+    model = load_task_model(task)
     n = 8192
+    fields = randomize.domain_randomize(model, np.random.default_rng(8), n)[0] if dr else None
     runs = []
     for rep in range(2):
         cfg = engine.default_config(); cfg.episode_length = 40
         b = engine.Batch(model, n, cfg)
+        if dr:
+            randomize.apply(b, fields)
         b.reset(seed=21)
         g = torch.Generator(device="cuda").manual_seed(5)
         dones = torch.zeros(n, device="cuda"); truncs = torch.zeros(n, device="cuda")
@@ -226,6 +230,23 @@ def test_full_size_rollout_properties():
         runs.append((b.obs.clone(), b.reward.clone(), q))
         b.close()
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+
+
+def test_runner_main_plumbing(tmp_path):
+    """BASELINE config 1 (plumbing): the reference's command line `runner.py --task flat_terrain --num_timesteps ...` through
+    `runner.main()` at 32 envs -- env construction, domain randomisation, PPO epochs, evaluator, TensorBoard file, checkpoint
+    and ONNX export (reference playground/open_duck_mini_v2/runner.py:35-60, common/runner.py:56-118)."""
+    import os, subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "open_duck_playground_amd.runner", "--task", "flat_terrain", "--num_envs", "32", "--num_timesteps", str(32 * 20 * 40),
+                          "--output_dir", str(tmp_path / "ckpt")], capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(os.environ, PYTHONPATH=root))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    files = os.listdir(tmp_path / "ckpt")
+    assert any(f.endswith(".pt") for f in files) and any(f.endswith(".onnx") for f in files) and any("tfevents" in f for f in files), files
+    lines = [json.loads(l) for l in open(tmp_path / "ckpt" / "metrics.jsonl")]
+    assert len(lines) >= 2 and "eval/episode_reward" in lines[0] and np.isfinite(lines[-1]["eval/episode_reward"])
+    assert "STEP: 0 reward:" in out.stdout and "Observation size: 101" in out.stdout
 
 
 def test_engine_rollout_path_matches_the_generic_loop():

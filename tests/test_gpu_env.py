@@ -1,56 +1,221 @@
 """GPU parity of the full env step (wrappers + Joystick.step + obs/reward) vs the CPU oracle env,
-with observation noise, action delay and pushes ON (both sides draw from the same counter RNG)."""
+with observation noise, action delay and pushes ON (both sides draw from the same counter RNG).
+
+Error measure: |gpu - oracle| / max(|oracle|, 1) per element ("relative with floor 1").  The accelerometer slots are judged
+separately: they are linear in qacc, which one Newton iteration in fp32 resolves to ~1e-3 relative (test_gpu_parity.py).
+Bounds = ~3x the worst case measured on MI355X; the measured values of the last run are written next to the bounds into
+gpurun_out/parity_worst.json (committed copy: profiles/r3/parity_worst.json).
+
+The physics state is re-synchronised from the oracle before every step, but ten substeps of a one-iteration Newton solver with a
+five-iteration line search are not a smooth map: 2-5 % of random-action env steps sit on a branch point (a contact row switching
+on, a manifold tie, a line-search bracket) where the fp64 oracle ITSELF changes its answer by 1e-2 ... 1 when its input moves by
+1e-6.  Those env steps are detected on the oracle side alone (ten perturbed oracle runs per env step) and set aside -- counted,
+bounded in number, not judged."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
+# obs / priv without the accelerometer, accelerometer slots, reward, metrics (BASELINE north_star: 1e-4 on the state after one
+# mjx.step; an env step is 10 of them plus sensors).  Measured on MI355X over the well-conditioned env steps (round 3):
+# obs <= 7e-5, accelerometer <= 3.2e-4, reward <= 1.5e-5, metrics <= 3.2e-4.
+ENV_BOUNDS = dict(obs=2.5e-4, acc=1e-3, reward=5e-5, metrics=1e-3)
+# An env step is set aside as ill-conditioned when the ORACLE's own outputs move by more than this under rounding-level input
+# noise (`_perturbed_oracle_steps`); measured: 2-5 % of the env steps of a random-action rollout.
+SENSITIVITY = dict(obs=2.5e-4, acc=2.5e-3, reward=2.5e-4, metrics=5e-4)
+# Judged env steps beyond a bound ("outliers": a line-search / manifold branch flipped between fp32 and fp64 without any of the
+# perturbed oracle runs flipping it) may be at most this fraction; measured 1 in 1841 (flat), 3 in 1847 (rough terrain).
+SET_ASIDE = dict(ill_fraction=0.08, outlier_fraction=0.002)
+RESET_BOUNDS = dict(obs=1e-5, acc=1e-3, qpos=1e-6, qvel=1e-6)   # measured: 3.5e-6, 3.2e-4, 1.8e-7, 2e-9
 
-def _mk(oracle_mod, task, n, cfg_edit=None, standing=False):
+
+def _mk(oracle_mod, task, n, cfg_edit=None, standing=False, dr_fields=None):
     import torch
-    from open_duck_playground_amd import engine
+    from open_duck_playground_amd import engine, randomize
     from open_duck_playground_amd.model import load_task_model
     model = load_task_model(task)
     cfg = engine.default_config(standing)
     if cfg_edit:
         cfg_edit(cfg)
     b = engine.Batch(model, n, cfg)
-    om = oracle_mod.OracleModel(model.blob())
+    base = oracle_mod.OracleModel(model.blob())
     prm = oracle_mod.OraclePRM(engine.load_prm())
-    envs = [oracle_mod.OracleEnv(om, prm, standing=standing) for _ in range(n)]
+    oms = [base] * n
+    if dr_fields is not None:     # per-env model fields of randomize.py:119-144 on both sides
+        randomize.apply(b, dr_fields)
+        oms = [_dr_model(model, base, dr_fields, e) for e in range(n)]
+    envs = [oracle_mod.OracleEnv(oms[i], prm, standing=standing) for i in range(n)]
     for e in envs:
         e.cfg["episode_length"][0] = cfg.episode_length
         e.cfg["noise_level"][0] = cfg.noise_level
         e.cfg["push_enable"][0] = cfg.push_enable
-    return torch, model, b, envs, (om, prm)
+    return torch, model, b, envs, (base, prm, oms)
 
 
-def _close(a, b, rtol, atol):
-    return np.abs(a - b) <= atol + rtol * np.abs(b)
+def _dr_model(model, base, fields, e):
+    act_jnt = np.asarray(model.a["actuator_trnid"]); dofs = np.asarray(model.a["jnt_dofadr"])[act_jnt]; qadr = np.asarray(model.a["jnt_qposadr"])[act_jnt]
+    om = base.copy()
+    om.f["body_mass"][:] = fields["body_mass"][e]
+    om.f["body_ipos"][3:6] = fields["body_ipos"][e]
+    om.f["dof_frictionloss"][dofs] = fields["dof_frictionloss"][e]
+    om.f["dof_armature"][dofs] = fields["dof_armature"][e]
+    om.f["qpos0"][qadr] = fields["qpos0"][e]
+    om.f["actuator_gainprm0"][:] = fields["actuator_gainprm"][e]
+    om.f["actuator_biasprm"][1::3] = fields["actuator_biasprm"][e]
+    return om
+
+
+def _rel1(a, b):
+    return np.abs(a - b) / np.maximum(np.abs(b), 1.0)
+
+
+def _obs_err(obs, priv, env, nobs, npriv):
+    """(worst error over obs / priv outside the accelerometer slots, worst error over the accelerometer slots)"""
+    eo = _rel1(obs, env["obs"][:nobs]); ep = _rel1(priv, env["priv"][:npriv])
+    acc = max(eo[3:6].max(), ep[nobs + 3: nobs + 6].max())
+    eo[3:6] = 0; ep[3:6] = 0; ep[nobs + 3: nobs + 6] = 0
+    return max(eo.max(), ep.max()), acc
+
+
+def _resync(b, envs, model):
+    qp = np.stack([np.array(e.data["qpos"][: model.nq]) for e in envs])
+    qv = np.stack([np.array(e.data["qvel"][: model.nv]) for e in envs])
+    wm = np.stack([np.array(e.data["qacc_warmstart"][: model.nv]) for e in envs])
+    b.set_state(qp, qv, wm)
+
+
+PERTURB_CLONES = 10
+
+
+def _perturbed_oracle_steps(e, act, model, rng):
+    """How far the ORACLE's own outputs of this env step move when its input state is perturbed at the level of fp32 rounding
+    through a substep (qpos 1e-6, qvel 5e-6 relative: what test_gpu_parity measures after one mjx.step).  An env step that sits on
+    a discontinuity of the model -- a contact or limit row switching on (|dist| ~ 0), a manifold tie, the warm-start pick -- moves
+    by orders of magnitude more than a smooth one; no fp32 implementation can agree with an fp64 one there."""
+    clones = []
+    for _ in range(PERTURB_CLONES):
+        c = e.clone()
+        q = c.data["qpos"][: model.nq]; v = c.data["qvel"][: model.nv]
+        q += 1e-6 * rng.standard_normal(model.nq) * np.maximum(np.abs(q), 0.1)
+        v += 5e-6 * rng.standard_normal(model.nv) * np.maximum(np.abs(v), 1.0)
+        c.step(act)
+        clones.append(c)
+    return clones
+
+
+# per-env info record behind qpos | qvel | warmstart (csrc/odk_engine.hip namespace rec)
+_REC = dict(CMD=0, LAST=7, LAST2=21, LAST3=35, MT=49, AIR=63, PEAK=65, PUSH=67, AHIST=69, IMU=111, EPSTEPS=120, TRUNC=121, DONE=122, EPSUM=123,
+            EPLEN=124, EPMET=125, KEY0=133, KEY1=134, CTR=135, STEP=136, PSTEP=137, PINT=138, IMI=139, LCON=140)
+
+
+def _push_info(b, envs, model, which):
+    """Overwrites the carried info of the envs in `which` with the oracle's (after an ill-conditioned step the two sides may
+    legitimately disagree on a contact flag, and air time / swing peak / last_contact carry that forward).  All other envs keep
+    the info the GPU produced itself."""
+    if not which:
+        return
+    rec = b.records()
+    I = model.nq + 2 * model.nv
+    R = _REC
+    for i in which:
+        e = envs[i]
+        r = rec[i, I:]
+        ri = r.view(np.int32)
+        r[R["CMD"]: R["CMD"] + 7] = e["command"][:7]
+        for k, nm in (("LAST", "last_act"), ("LAST2", "last_last_act"), ("LAST3", "last_last_last_act"), ("MT", "motor_targets")):
+            r[R[k]: R[k] + 14] = e[nm][:14]
+        r[R["AIR"]: R["AIR"] + 2] = e["feet_air_time"][:2]; r[R["PEAK"]: R["PEAK"] + 2] = e["swing_peak"][:2]; r[R["PUSH"]: R["PUSH"] + 2] = e["push"][:2]
+        r[R["AHIST"]: R["AHIST"] + 42] = e["action_history"][:42]; r[R["IMU"]: R["IMU"] + 9] = e["imu_history"][:9]
+        r[R["EPSTEPS"]] = e["ep_steps"][0]; r[R["TRUNC"]] = e["truncation"][0]; r[R["DONE"]] = e["episode_done"][0]
+        r[R["EPSUM"]] = e["ep_sum_reward"][0]; r[R["EPLEN"]] = e["ep_length"][0]; r[R["EPMET"]: R["EPMET"] + 8] = e["ep_metrics"][:8]
+        ri[R["CTR"]] = e.ints("rng_ctr")[0]; ri[R["STEP"]] = e.ints("step")[0]; ri[R["PSTEP"]] = e.ints("push_step")[0]
+        ri[R["PINT"]] = e.ints("push_interval_steps")[0]; ri[R["IMI"]] = e.ints("imitation_i")[0]
+        lc = e.ints("last_contact")
+        ri[R["LCON"]] = int(lc[0] != 0) | (int(lc[1] != 0) << 1)
+    b.set_records(rec)
+
+
+def _step_and_compare(torch, b, envs, act, nobs, npriv, t, W, model=None):
+    """One env step on both sides.  Well-conditioned env steps: done / truncation must agree exactly and the errors are folded into
+    W (dict of maxima).  Ill-conditioned ones (`_perturbed_oracle_steps`: the oracle's own outputs move by more than half a bound under
+    rounding-level input noise) are counted in W["n_ill"] and not judged; their carried info is re-synchronised before the next step."""
+    model = model if model is not None else b.model
+    _push_info(b, envs, model, W.pop("resync_info", []))
+    rng = np.random.default_rng(1000 + t)
+    clones = [_perturbed_oracle_steps(e, act[i], model, rng) for i, e in enumerate(envs)]
+    b.step(torch.tensor(act, device="cuda"))
+    obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy(); rew = b.reward.cpu().numpy(); done = b.done.cpu().numpy()
+    trunc = b.truncation.cpu().numpy(); met = b.metrics.cpu().numpy()
+    ill_envs = []
+    for i, e in enumerate(envs):
+        e.step(act[i])
+        sens = dict(obs=0.0, acc=0.0, reward=0.0, metrics=0.0, done=0.0)
+        for c in clones[i]:
+            so, sa = _obs_err(np.array(c["obs"][:nobs]), np.array(c["priv"][:npriv]), e, nobs, npriv)
+            sr = float(_rel1(c["reward"][0], e["reward"][0])); sm = float(_rel1(np.array(c["metrics"][:8]), e["metrics"][:8]).max())
+            for k, v in (("obs", so), ("acc", sa), ("reward", sr), ("metrics", sm), ("done", float(c["done"][0] != e["done"][0]))):
+                sens[k] = max(sens[k], v)
+        ill = sens["done"] > 0 or any(sens[k] > SENSITIVITY[k] for k in ("obs", "acc", "reward", "metrics"))
+        W["n"] += 1
+        W["n_done"] += int(done[i]); W["n_trunc"] += int(trunc[i])
+        if ill:
+            W["n_ill"] += 1
+            ill_envs.append(i)
+            continue
+        assert done[i] == e["done"][0], (t, i)
+        assert trunc[i] == e["truncation"][0], (t, i)
+        o, a = _obs_err(obs[i], priv[i], e, nobs, npriv)
+        r = float(_rel1(rew[i], e["reward"][0])); m = float(_rel1(met[i], e["metrics"][:8]).max())
+        err = dict(obs=o, acc=a, reward=r, metrics=m)
+        if any(err[k] > ENV_BOUNDS[k] for k in err):
+            print(f"[outlier] t={t} env={i} err={ {k: float(f'{v:.2e}') for k, v in err.items()} } oracle sensitivity={ {k: float(f'{v:.2e}') for k, v in sens.items()} }")
+            W["n_outlier"] += 1
+            for k, v in err.items():
+                W["outlier_" + k] = max(W.get("outlier_" + k, 0.0), v)
+            continue
+        for k, v in err.items():
+            W[k] = max(W[k], v)
+    W["resync_info"] = ill_envs
+    return W
+
+
+def _new_W():
+    return dict(obs=0.0, acc=0.0, reward=0.0, metrics=0.0, n_done=0, n_trunc=0, n=0, n_ill=0, n_outlier=0)
+
+
+def _errs(W):
+    """the judged quantities: worst errors over the well-conditioned env steps inside the bounds, the fraction of env steps set
+    aside as ill-conditioned, the fraction of judged ones beyond a bound (and how far they were)"""
+    out = dict({k: W[k] for k in ("obs", "acc", "reward", "metrics")}, ill_fraction=W["n_ill"] / max(W["n"], 1),
+               outlier_fraction=W["n_outlier"] / max(W["n"] - W["n_ill"], 1), env_steps=W["n"])
+    out.update({k: v for k, v in W.items() if k.startswith("outlier_")})
+    return out
 
 
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
-def test_reset_matches_oracle(oracle_mod, task):
+def test_reset_matches_oracle(oracle_mod, parity_log, task):
     torch, model, b, envs, keep = _mk(oracle_mod, task, 32)
     b.reset(seed=5, env_id_offset=100)
     obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy()
     qpos, qvel, warm = b.get_state()
     rec = b.records()
+    W = dict(obs=0.0, acc=0.0, qpos=0.0, qvel=0.0)
     for i, e in enumerate(envs):
         e.reset(5, 100 + i)
-        np.testing.assert_allclose(qpos[i], e.data["qpos"][: model.nq], rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(qvel[i], e.data["qvel"][: model.nv], rtol=1e-5, atol=1e-6)
-        # accelerometer spikes to O(100) m/s^2 at reset (feet start 1.5 cm inside the floor): compare relatively
-        assert _close(obs[i], e["obs"][:101], 2e-3, 2e-3).all(), (i, np.abs(obs[i] - e["obs"][:101]).max())
-        assert _close(priv[i], e["priv"][:212], 2e-3, 2e-3).all()
+        W["qpos"] = max(W["qpos"], np.abs(qpos[i] - e.data["qpos"][: model.nq]).max())
+        W["qvel"] = max(W["qvel"], np.abs(qvel[i] - e.data["qvel"][: model.nv]).max())
+        # the accelerometer spikes to O(100) m/s^2 at reset (feet start 1.5 cm inside the floor): judged relatively, own bound
+        o, a = _obs_err(obs[i], priv[i], e, 101, 212)
+        W["obs"] = max(W["obs"], o); W["acc"] = max(W["acc"], a)
         info = rec[i, model.nq + 2 * model.nv:]
         np.testing.assert_allclose(info[0:7], e["command"], rtol=1e-6, atol=1e-7)
         assert int(info[138:139].view(np.int32)[0]) == int(e.ints("push_interval_steps")[0])
     b.close()
+    parity_log.check(f"reset/{task}", RESET_BOUNDS, **W)
 
 
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
-def test_step_sequence_with_resync(oracle_mod, task):
+def test_step_sequence_with_resync(oracle_mod, parity_log, task):
     """60 env steps with random actions.  The physics state is re-synchronised from the oracle before every
     step (fp32-vs-fp64 chaos through contact would otherwise dominate), everything else -- info ring
     buffers, RNG counters, episode counters, auto-reset -- runs free on the GPU."""
@@ -62,27 +227,12 @@ def test_step_sequence_with_resync(oracle_mod, task):
     for i, e in enumerate(envs):
         e.reset(9, i)
     rng = np.random.default_rng(0)
-    n_done = n_trunc = 0
+    W = _new_W()
     for t in range(60):
-        qp = np.stack([np.array(e.data["qpos"][: model.nq]) for e in envs])
-        qv = np.stack([np.array(e.data["qvel"][: model.nv]) for e in envs])
-        wm = np.stack([np.array(e.data["qacc_warmstart"][: model.nv]) for e in envs])
-        b.set_state(qp, qv, wm)
+        _resync(b, envs, model)
         act = rng.uniform(-1, 1, (n, 14)).astype(np.float32)
-        b.step(torch.tensor(act, device="cuda"))
-        obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy(); rew = b.reward.cpu().numpy(); done = b.done.cpu().numpy()
-        trunc = b.truncation.cpu().numpy(); met = b.metrics.cpu().numpy()
-        bad = 0
-        for i, e in enumerate(envs):
-            e.step(act[i])
-            assert done[i] == e["done"][0], (t, i)
-            assert trunc[i] == e["truncation"][0], (t, i)
-            ok = _close(obs[i], e["obs"][:101], 5e-3, 5e-3).all() and _close(priv[i], e["priv"][:212], 5e-3, 5e-3).all()
-            ok = ok and _close(rew[i], e["reward"][0], 5e-3, 1e-3) and _close(met[i], e["metrics"][:8], 1e-2, 2e-3).all()
-            bad += 0 if ok else 1
-            n_done += int(done[i]); n_trunc += int(trunc[i])
-        assert bad <= 1, (t, bad)   # a contact-manifold tie may flip between fp32 and fp64 once in a while
-    assert n_done > 0 and n_trunc > 0, "sequence must cross terminations and truncations"
+        _step_and_compare(torch, b, envs, act, 101, 212, t, W)
+    assert W["n_done"] > 0 and W["n_trunc"] > 0, "sequence must cross terminations and truncations"
     rec = b.records()
     for i, e in enumerate(envs):
         info = rec[i, model.nq + 2 * model.nv:]
@@ -91,9 +241,112 @@ def test_step_sequence_with_resync(oracle_mod, task):
         assert int(info[135:136].view(np.int32)[0]) == int(e.ints("rng_ctr")[0])
         assert int(info[139:140].view(np.int32)[0]) == int(e.ints("imitation_i")[0])
     b.close()
+    parity_log.check(f"env_step/{task}", {**ENV_BOUNDS, **SET_ASIDE}, **_errs(W))
 
 
-def test_free_running_rollout_stays_close(oracle_mod):
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+def test_in_step_command_resample(oracle_mod, parity_log, task):
+    """sample_command inside step (joystick.py:456-466): info["step"] is preset to 499 / 500 / 123 on both sides through the raw
+    record; the step that takes it past 500 must draw the same new command (same counter-RNG draws, incl. the all-zero
+    branch) and reset the counter to 0, the others keep theirs, and the next step's obs carry the new command."""
+    torch, model, b, envs, keep = _mk(oracle_mod, task, 64)
+    n = len(envs)
+    b.reset(seed=13)
+    for i, e in enumerate(envs):
+        e.reset(13, i)
+    rec = b.records()
+    INFO = model.nq + 2 * model.nv
+    STEP = INFO + 136
+    preset = np.where(np.arange(n) % 4 == 0, 123, np.where(np.arange(n) % 4 == 1, 499, 500)).astype(np.int32)
+    rec[:, STEP] = preset.view(np.float32)
+    b.set_records(rec)
+    for i, e in enumerate(envs):
+        e.ints("step")[0] = int(preset[i])
+    old_cmd = np.stack([np.array(e["command"][:7]) for e in envs])
+    rng = np.random.default_rng(4)
+    W = _new_W()
+    n_resampled = n_zero = 0
+    for t in range(3):
+        _resync(b, envs, model)
+        act = rng.uniform(-1, 1, (n, 14)).astype(np.float32)
+        _step_and_compare(torch, b, envs, act, 101, 212, t, W)
+        rec = b.records()
+        for i, e in enumerate(envs):
+            info = rec[i, INFO:]
+            cmd_g = info[0:7]; cmd_o = np.array(e["command"][:7])
+            np.testing.assert_allclose(cmd_g, cmd_o, rtol=1e-6, atol=1e-7)
+            assert int(info[136:137].view(np.int32)[0]) == int(e.ints("step")[0]), (t, i)
+            if t == 0:
+                if preset[i] == 500:     # 501 > 500: resampled, counter back to 0
+                    assert int(e.ints("step")[0]) == 0
+                    n_resampled += int(not np.array_equal(cmd_o, old_cmd[i])); n_zero += int(np.all(cmd_o == 0))
+                else:                    # 124 / 500: not yet
+                    assert np.array_equal(cmd_o, old_cmd[i]) and (int(e.ints("step")[0]) == preset[i] + 1 or e["done"][0] != 0)
+            if t == 1 and preset[i] == 499 and envs[i]["done"][0] == 0:
+                assert int(e.ints("step")[0]) == 0
+    assert n_resampled >= n // 2 - 1 and W["n_done"] < n // 2
+    b.close()
+    parity_log.rec(f"command_resample/{task}", None, resampled=n_resampled, all_zero_draws=n_zero)
+    parity_log.check(f"command_resample/{task}", {**ENV_BOUNDS, **SET_ASIDE}, **_errs(W))
+
+
+@pytest.mark.parametrize("task,standing", [("flat_terrain_backlash", False), ("flat_terrain", False), ("rough_terrain_backlash", False), ("flat_terrain_backlash", True)])
+def test_env_step_with_domain_randomisation(oracle_mod, parity_log, task, standing):
+    """randomize.py's per-env model fields through odk_reset / odk_step (not only the physics call): reset obs, then 30
+    resynchronised env steps, obs / reward / metrics against oracle envs that each own a randomised copy of the model."""
+    from open_duck_playground_amd import randomize
+    from open_duck_playground_amd.model import load_task_model
+    n = 32
+    fields, _ = randomize.domain_randomize(load_task_model(task), np.random.default_rng(17), n)
+
+    def edit(cfg):
+        cfg.episode_length = 20
+    torch, model, b, envs, keep = _mk(oracle_mod, task, n, edit, standing=standing, dr_fields=fields)
+    nobs, npriv = (85, 153) if standing else (101, 212)
+    b.reset(seed=21)
+    obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy()
+    WR = dict(obs=0.0, acc=0.0)
+    for i, e in enumerate(envs):
+        e.reset(21, i)
+        o, a = _obs_err(obs[i], priv[i], e, nobs, npriv)
+        WR["obs"] = max(WR["obs"], o); WR["acc"] = max(WR["acc"], a)
+    # the randomised qpos0 must be visible: the same pose gives different body frames => different obs than the nominal model
+    rng = np.random.default_rng(6)
+    W = _new_W()
+    for t in range(30):
+        _resync(b, envs, model)
+        act = rng.uniform(-1, 1, (n, 14)).astype(np.float32)
+        _step_and_compare(torch, b, envs, act, nobs, npriv, t, W)
+    b.close()
+    tag = f"env_step_dr/{task}/{'standing' if standing else 'joystick'}"
+    parity_log.check(tag + "/reset", dict(obs=RESET_BOUNDS["obs"], acc=RESET_BOUNDS["acc"]), **WR)
+    parity_log.check(tag, {**ENV_BOUNDS, **SET_ASIDE}, **_errs(W))
+
+
+def test_domain_randomisation_changes_the_env_step(oracle_mod):
+    """guard for the test above: with the SAME seed and actions, randomised parameters must move the GPU outputs (a kernel that
+    ignored the per-env block would still match a nominal oracle)."""
+    import torch
+    from open_duck_playground_amd import engine, randomize
+    from open_duck_playground_amd.model import load_task_model
+    model = load_task_model("flat_terrain_backlash")
+    n = 32
+    fields, _ = randomize.domain_randomize(model, np.random.default_rng(17), n)
+    outs = []
+    for dr in (False, True):
+        b = engine.Batch(model, n)
+        if dr:
+            randomize.apply(b, fields)
+        b.reset(seed=21)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for _ in range(3):
+            b.step(torch.empty(n, 14, device="cuda").uniform_(-1, 1, generator=g))
+        outs.append((b.priv.clone(), b.reward.clone()))
+        b.close()
+    assert float((outs[0][0] - outs[1][0]).abs().max()) > 1e-2 and float((outs[0][1] - outs[1][1]).abs().max()) > 1e-4
+
+
+def test_free_running_rollout_stays_close(oracle_mod, parity_log):
     """5 free-running env steps (50 substeps): median state error small, no NaNs."""
     def edit(cfg):
         cfg.noise_level = 0.0
@@ -113,12 +366,13 @@ def test_free_running_rollout_stays_close(oracle_mod):
     ref = np.stack([np.array(e.data["qpos"][: model.nq]) for e in envs])
     err = np.abs(qpos - ref).max(axis=1)
     assert np.isfinite(qpos).all()
-    assert np.median(err) < 2e-4 and (err < 5e-3).mean() > 0.9, (np.median(err), err.max())
     b.close()
+    parity_log.check("free_running_5_steps/flat_terrain", dict(median_qpos_abs=5e-5, frac_above_5e3=0.1),
+                     median_qpos_abs=float(np.median(err)), frac_above_5e3=float((err >= 5e-3).mean()), max_qpos_abs=float(err.max()))
 
 
-@pytest.mark.parametrize("task", ["flat_terrain", "rough_terrain_backlash"])
-def test_standing_env_matches_oracle(oracle_mod, task):
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
+def test_standing_env_matches_oracle(oracle_mod, parity_log, task):
     """Standing (reference standing.py): reset + 40 resynchronised steps; obs rows are 85 / 153 floats wide."""
     def edit(cfg):
         cfg.episode_length = 25
@@ -130,33 +384,22 @@ def test_standing_env_matches_oracle(oracle_mod, task):
         e.reset(11, i)
     obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy()
     qpos, qvel, _ = b.get_state()
+    WR = dict(obs=0.0, acc=0.0, qvel=0.0)
     for i, e in enumerate(envs):
-        np.testing.assert_allclose(qvel[i], e.data["qvel"][: model.nv], rtol=1e-5, atol=1e-6)
-        assert _close(obs[i], e["obs"][:85], 2e-3, 2e-3).all(), (i, np.abs(obs[i] - e["obs"][:85]).max())
-        assert _close(priv[i], e["priv"][:153], 2e-3, 2e-3).all()
+        WR["qvel"] = max(WR["qvel"], np.abs(qvel[i] - e.data["qvel"][: model.nv]).max())
+        o, a = _obs_err(obs[i], priv[i], e, 85, 153)
+        WR["obs"] = max(WR["obs"], o); WR["acc"] = max(WR["acc"], a)
     assert np.abs(qvel[:, :6]).max() > 0.05      # the Standing reset range
     rng = np.random.default_rng(2)
-    n_done = 0
+    W = _new_W()
     for t in range(40):
-        qp = np.stack([np.array(e.data["qpos"][: model.nq]) for e in envs])
-        qv = np.stack([np.array(e.data["qvel"][: model.nv]) for e in envs])
-        wm = np.stack([np.array(e.data["qacc_warmstart"][: model.nv]) for e in envs])
-        b.set_state(qp, qv, wm)
+        _resync(b, envs, model)
         act = rng.uniform(-1, 1, (n, 14)).astype(np.float32)
-        b.step(torch.tensor(act, device="cuda"))
-        obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy(); rew = b.reward.cpu().numpy(); done = b.done.cpu().numpy()
-        met = b.metrics.cpu().numpy()
-        bad = 0
-        for i, e in enumerate(envs):
-            e.step(act[i])
-            assert done[i] == e["done"][0], (t, i)
-            ok = _close(obs[i], e["obs"][:85], 5e-3, 5e-3).all() and _close(priv[i], e["priv"][:153], 5e-3, 5e-3).all()
-            ok = ok and _close(rew[i], e["reward"][0], 5e-3, 1e-3) and _close(met[i], e["metrics"][:8], 1e-2, 2e-3).all()
-            bad += 0 if ok else 1
-            n_done += int(done[i])
-        assert bad <= 1, (t, bad)
-    assert n_done > 0
+        _step_and_compare(torch, b, envs, act, 85, 153, t, W)
+    assert W["n_done"] > 0
     b.close()
+    parity_log.check(f"standing/{task}/reset", dict(obs=RESET_BOUNDS["obs"], acc=RESET_BOUNDS["acc"], qvel=RESET_BOUNDS["qvel"]), **WR)
+    parity_log.check(f"standing/{task}", {**ENV_BOUNDS, **SET_ASIDE}, **_errs(W))
 
 
 def test_standing_python_env_surface():
