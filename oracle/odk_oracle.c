@@ -133,6 +133,7 @@ static int load_i(const unsigned char* blob, uint64_t len, const char* name, int
 #define LF(name, dst, max) if (load_f(b, len, name, (real*)(dst), max) < 0) { fprintf(stderr, "odko: missing %s\n", name); ok = 0; }
 #define LI(name, dst, max) if (load_i(b, len, name, (int*)(dst), max) < 0) { fprintf(stderr, "odko: missing %s\n", name); ok = 0; }
 
+static void build_mesh_convex(odko_model* m);
 odko_model* odko_model_load(const void* blob, uint64_t len) {
   const unsigned char* b = (const unsigned char*)blob;
   if (len < 16 || memcmp(b, "ODKM", 4) != 0) return NULL;
@@ -206,6 +207,7 @@ odko_model* odko_model_load(const void* blob, uint64_t len) {
           m->pair_g1[m->npair] = first; m->pair_g2[m->npair] = second; m->npair++;
         }
       }
+  build_mesh_convex(m);
   return m;
 }
 void odko_model_free(odko_model* m) { free(m); }
@@ -238,6 +240,7 @@ int odko_model_int(const odko_model* m, const char* name) {
 int odko_model_set_int(odko_model* m, const char* name, int value) {
   if (!strcmp(name, "iterations")) { m->iterations = value; return 0; }
   if (!strcmp(name, "ls_iterations")) { m->ls_iterations = value; return 0; }
+  if (!strcmp(name, "hfield_mode")) { m->hfield_mode = value; return 0; }
   return -1;
 }
 
@@ -552,9 +555,11 @@ static void plane_convex(const odko_model* m, odko_data* d, int gp, int gc, int 
   plane_convex_at(m, d, d->geom_xpos[gp], pn_w, gc, c0);
 }
 
+#include "odk_oracle_convex.inc"
+
 static void hull_aabb(const odko_model* m, int g, real* c, real* h);
-/* Height field vs convex foot (config "rough_terrain_backlash").  BUILD-DEFINED APPROXIMATION, PARITY UNPINNED: MJX
- * collides the mesh with the prisms of a sub-grid of cells; here the terrain under the foot is replaced by the plane
+/* Round-2 approximation of the height-field floor, kept behind m->hfield_mode = 1 so that its difference to the prism algorithm
+ * below can be measured (tests/test_oracle_physics.py): the terrain under the foot is replaced by the plane
  * of the height-field triangle below the hull's centre (cell (c, r) is split along the (c+1, r)-(c, r+1) diagonal)
  * and plane_convex runs against that plane.  Exact on flat patches; the terrain's slopes are <= 1 cm per 7.8 cm cell. */
 static void hfield_plane(const odko_model* m, const odko_data* d, int gh, const real* point_w, real* pos_w, real* n_w) {
@@ -584,7 +589,7 @@ static void hfield_plane(const odko_model* m, const odko_data* d, int gh, const 
   mat_mulvec(pos_w, R, a);
   v3_addscl(pos_w, pos_w, d->geom_xpos[gh], 1);
 }
-static void hfield_convex(const odko_model* m, odko_data* d, int gh, int gc, int c0) {
+static void hfield_convex_one_triangle(const odko_model* m, odko_data* d, int gh, int gc, int c0) {
   real c[3], h[3], cw[3], pos_w[3], n_w[3];
   hull_aabb(m, gc, c, h);
   mat_mulvec(cw, d->geom_xmat[gc], c);
@@ -593,35 +598,61 @@ static void hfield_convex(const odko_model* m, odko_data* d, int gh, int gc, int
   plane_convex_at(m, d, pos_w, n_w, gc, c0);
 }
 
-/* Conservative separating test for two convex hulls: projects both vertex sets on the candidate
- * axes (face normals of both hulls + world-frame OBB-like axes).  If any axis separates the hulls
- * by a positive gap, MJX's convex-convex routine would report dist > 0 for all 4 contacts, which
- * contributes exactly nothing to the dynamics (inactive rows have J = 0, SURVEY "Hard parts").
- * Returns the largest separation found (>0: separated). */
-static real hull_separation(const odko_model* m, const odko_data* d, int g1, int g2, real* axis_out) {
-  real best = -1e30;
-  int gs[2] = {g1, g2};
-  real w1[ODKO_MAXHV][3], w2[ODKO_MAXHV][3];
-  int n1 = m->cgeom_vertnum[g1], n2 = m->cgeom_vertnum[g2];
-  for (int i = 0; i < n1; i++) { mat_mulvec(w1[i], d->geom_xmat[g1], m->hull_vert[m->cgeom_vertadr[g1] + i]); v3_addscl(w1[i], w1[i], d->geom_xpos[g1], 1); }
-  for (int i = 0; i < n2; i++) { mat_mulvec(w2[i], d->geom_xmat[g2], m->hull_vert[m->cgeom_vertadr[g2] + i]); v3_addscl(w2[i], w2[i], d->geom_xpos[g2], 1); }
-  for (int s = 0; s < 2; s++) {
-    int g = gs[s];
-    for (int f = 0; f < m->cgeom_facenum[g]; f++) {
-      const int* tri = m->hull_face[m->cgeom_faceadr[g] + f];
-      const real (*wv)[3] = s == 0 ? w1 : w2;
-      real e1[3], e2[3], nrm[3];
-      v3_sub(e1, wv[tri[1]], wv[tri[0]]); v3_sub(e2, wv[tri[2]], wv[tri[0]]);
-      v3_cross(nrm, e1, e2);
-      if (v3_normalize(nrm) == 0) continue;
-      real max1 = -1e30, min1 = 1e30, max2 = -1e30, min2 = 1e30;
-      for (int i = 0; i < n1; i++) { real p = v3_dot(w1[i], nrm); if (p > max1) max1 = p; if (p < min1) min1 = p; }
-      for (int i = 0; i < n2; i++) { real p = v3_dot(w2[i], nrm); if (p > max2) max2 = p; if (p < min2) min2 = p; }
-      real sep = (min2 - max1 > min1 - max2) ? (min2 - max1) : (min1 - max2);
-      if (sep > best) { best = sep; if (axis_out) { v3_copy(axis_out, nrm); if (min1 - max2 > min2 - max1) { axis_out[0] = -nrm[0]; axis_out[1] = -nrm[1]; axis_out[2] = -nrm[2]; } } }
+/* mjx collision_convex.hfield_convex -> _hfield_collision (see odk_oracle_convex.inc): the foot against the prisms of every cell
+ * under its bounding sphere, the four deepest contacts of all prisms kept (ties: lower candidate index, as lax.top_k), each with
+ * the normal of its own prism test.  Candidate order: rows, then columns, then the two triangles of the cell, then the prism's
+ * four manifold slots. */
+#define HF_MAXCAND 256
+static void hfield_convex(const odko_model* m, odko_data* d, int gh, int gc, int c0) {
+  if (m->hfield_mode == 1) { hfield_convex_one_triangle(m, d, gh, gc, c0); return; }
+  const real* Rh = d->geom_xmat[gh]; const real* ph = d->geom_xpos[gh];
+  odko_convex Fw, F;
+  mesh_convex_world(m, d, gc, &Fw);
+  F = Fw; /* foot in the height field's frame */
+  for (int i = 0; i < Fw.nv; i++) { real t[3]; v3_sub(t, Fw.v[i], ph); mat_tmulvec(F.v[i], Rh, t); }
+  for (int f = 0; f < Fw.nf; f++) mat_tmulvec(F.fnorm[f], Rh, Fw.fnorm[f]);
+  { real t[3]; v3_sub(t, Fw.c, ph); mat_tmulvec(F.c, Rh, t); }
+  real bc[3], bh[3], cw[3], cl[3];
+  hull_aabb(m, gc, bc, bh);
+  mat_mulvec(cw, d->geom_xmat[gc], bc); v3_addscl(cw, cw, d->geom_xpos[gc], 1);
+  { real t[3]; v3_sub(t, cw, ph); mat_tmulvec(cl, Rh, t); }
+  real rad = sqrt(v3_dot(bh, bh));
+  int nc = m->hfield_ncol, nr = m->hfield_nrow;
+  real sx = m->hfield_size[0], sy = m->hfield_size[1];
+  real dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
+  int cmin = (int)floor((cl[0] - rad + sx) / dx), cmax = (int)floor((cl[0] + rad + sx) / dx);
+  int rmin = (int)floor((cl[1] - rad + sy) / dy), rmax = (int)floor((cl[1] + rad + sy) / dy);
+  if (cmin < 0) cmin = 0;
+  if (rmin < 0) rmin = 0;
+  if (cmax > nc - 2) cmax = nc - 2;
+  if (rmax > nr - 2) rmax = nr - 2;
+  real cd[HF_MAXCAND], cp[HF_MAXCAND][3], cn[HF_MAXCAND][3];
+  int ncand = 0;
+  for (int r = rmin; r <= rmax; r++)
+    for (int c = cmin; c <= cmax; c++)
+      for (int tri = 0; tri < 2; tri++) {
+        if (ncand + 4 > HF_MAXCAND) continue;
+        odko_convex P;
+        hfield_prism(m, c, r, tri, &P);
+        real dist4[4], pos4[4][3], nrm[3];
+        convex_convex_sat(&P, &F, dist4, pos4, nrm, NULL);
+        for (int k = 0; k < 4; k++) { cd[ncand] = dist4[k]; v3_copy(cp[ncand], pos4[k]); v3_copy(cn[ncand], nrm); ncand++; }
+      }
+  int used[HF_MAXCAND] = {0};
+  for (int k = 0; k < 4; k++) {
+    int bi = -1;
+    for (int i = 0; i < ncand; i++) if (!used[i] && (bi < 0 || cd[i] < cd[bi])) bi = i;
+    real nw[3] = {Rh[2], Rh[5], Rh[8]}, pw[3] = {0, 0, 0};
+    real dist = 1.0;
+    if (bi >= 0) {
+      used[bi] = 1; dist = cd[bi];
+      mat_mulvec(nw, Rh, cn[bi]);
+      mat_mulvec(pw, Rh, cp[bi]); v3_addscl(pw, pw, ph, 1);
     }
+    d->contact_dist[c0 + k] = dist;
+    v3_copy(d->contact_pos[c0 + k], pw);
+    make_frame(d->contact_frame[c0 + k], nw);
   }
-  return best;
 }
 
 /* Oriented-bounding-box cull (15-axis SAT on the hull AABBs expressed in each geom frame).  A positive
@@ -669,17 +700,14 @@ static real obb_separation(const odko_model* m, const odko_data* d, int g1, int 
   return best;
 }
 
-/* convex-convex (foot vs foot).  When a face-normal axis separates the hulls the pair is culled
- * (dist = separation > 0 on all four slots: inactive).  Penetrating configurations use the
- * minimum-penetration face axis and a 4-point manifold from the deepest vertices of hull 2 --
- * an approximation of MJX's SAT + polygon clipping (edge-edge axes omitted).  PARITY UNPINNED. */
+/* convex-convex (foot vs foot): mjx collision_convex.convex_convex (odk_oracle_convex.inc).  Bounding spheres / boxes with a
+ * positive gap are culled first: MJX would report dist > 0 on all four slots, which adds nothing to the dynamics (inactive rows
+ * have J = 0); slot 0 then carries the gap. */
 static void convex_convex(const odko_model* m, odko_data* d, int g1, int g2, int c0) {
-  real axis[3] = {0, 0, 1};
   real sep = obb_separation(m, d, g1, g2);
-  if (sep <= 0) sep = hull_separation(m, d, g1, g2, axis);
-  real frame[9];
-  make_frame(frame, axis);
   if (sep > 0) {
+    real axis[3] = {0, 0, 1}, frame[9];
+    make_frame(frame, axis);
     for (int k = 0; k < 4; k++) {
       d->contact_dist[c0 + k] = (k == 0) ? sep : 1.0;
       for (int q = 0; q < 3; q++) d->contact_pos[c0 + k][q] = 0.5 * (d->geom_xpos[g1][q] + d->geom_xpos[g2][q]);
@@ -687,31 +715,36 @@ static void convex_convex(const odko_model* m, odko_data* d, int g1, int g2, int
     }
     return;
   }
-  /* penetrating: treat hull 1's separating face as a plane through its support point along axis */
-  int n1 = m->cgeom_vertnum[g1], n2 = m->cgeom_vertnum[g2];
-  real max1 = -1e30;
-  for (int i = 0; i < n1; i++) {
-    real w[3]; mat_mulvec(w, d->geom_xmat[g1], m->hull_vert[m->cgeom_vertadr[g1] + i]); v3_addscl(w, w, d->geom_xpos[g1], 1);
-    real p = v3_dot(w, axis); if (p > max1) max1 = p;
-  }
-  real w2[ODKO_MAXHV][3], support[ODKO_MAXHV], smax = -1e30;
-  int mask[ODKO_MAXHV], idx[4];
-  for (int i = 0; i < n2; i++) {
-    mat_mulvec(w2[i], d->geom_xmat[g2], m->hull_vert[m->cgeom_vertadr[g2] + i]); v3_addscl(w2[i], w2[i], d->geom_xpos[g2], 1);
-    support[i] = max1 - v3_dot(w2[i], axis);
-    if (support[i] > smax) smax = support[i];
-  }
-  real thr = smax - 1e-3; if (thr < 0) thr = 0;
-  for (int i = 0; i < n2; i++) mask[i] = support[i] > thr;
-  manifold_points((const real (*)[3])w2, mask, n2, axis, idx);
+  odko_convex A, B;
+  mesh_convex_world(m, d, g1, &A); mesh_convex_world(m, d, g2, &B);
+  real dist4[4], pos4[4][3], nrm[3], frame[9];
+  convex_convex_sat(&A, &B, dist4, pos4, nrm, NULL);
+  make_frame(frame, nrm);
   for (int k = 0; k < 4; k++) {
-    int unique = 1;
-    for (int q = 0; q < k; q++) if (idx[q] == idx[k]) unique = 0;
-    real dist = unique ? -support[idx[k]] : 1.0;
-    d->contact_dist[c0 + k] = dist;
-    v3_addscl(d->contact_pos[c0 + k], w2[idx[k]], axis, -0.5 * dist);
+    d->contact_dist[c0 + k] = dist4[k];
+    v3_copy(d->contact_pos[c0 + k], pos4[k]);
     memcpy(d->contact_frame[c0 + k], frame, sizeof(frame));
   }
+}
+
+/* test entry: two polytopes given as vertices + outward triangles and poses (pos[3], row-major mat[9]); out = dist[4], pos[12],
+ * normal[3], sat[3] = (best face separation of A, of B, best Minkowski-edge separation), kind (0 reference A, 1 reference B, 2 edge) */
+int odko_convex_pair(const real* va, int nva, const int* ta, int nta, const real* pa, const real* ma, const real* vb, int nvb, const int* tb,
+                     int ntb, const real* pb, const real* mb, real* dist4, real* pos12, real* normal3, real* sat3) {
+  if (nva > CV_MAXV || nvb > CV_MAXV || nta > CV_MAXF || ntb > CV_MAXF) return -1;
+  odko_convex LA, LB, A, B;
+  convex_from_tris(&LA, (const real (*)[3])va, nva, (const int (*)[3])ta, nta); convex_from_tris(&LB, (const real (*)[3])vb, nvb, (const int (*)[3])tb, ntb);
+  convex_transform(&A, &LA, pa, ma); convex_transform(&B, &LB, pb, mb);
+  odko_sat S;
+  convex_convex_sat(&A, &B, dist4, (real (*)[3])pos12, normal3, &S);
+  sat3[0] = S.sep_a; sat3[1] = S.sep_b; sat3[2] = S.sep_e;
+  return S.kind;
+}
+/* test entry: face / edge counts of mesh geom g after the coplanar merge, and of a height-field prism */
+int odko_model_convex_counts(const odko_model* m, int g, int* nv, int* nf, int* ne) {
+  if (g < 0 || g >= m->ncgeom) return -1;
+  *nv = m->cgeom_convex[g].nv; *nf = m->cgeom_convex[g].nf; *ne = m->cgeom_convex[g].ne;
+  return 0;
 }
 
 static void collision(const odko_model* m, odko_data* d) {

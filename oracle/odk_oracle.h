@@ -48,6 +48,23 @@ enum { ODKO_GEOM_PLANE = 0, ODKO_GEOM_HFIELD = 1, ODKO_GEOM_MESH = 7 };
 enum { ODKO_S_GYRO = 0, ODKO_S_VELOCIMETER, ODKO_S_ACCELEROMETER, ODKO_S_FRAMEZAXIS, ODKO_S_FRAMEXAXIS,
        ODKO_S_FRAMELINVEL, ODKO_S_FRAMEANGVEL, ODKO_S_FRAMEPOS, ODKO_S_FRAMEQUAT };
 
+/* a convex polytope: vertices, face polygons, unique edges with their two faces (odk_oracle_convex.inc) */
+#define CV_MAXV 32
+#define CV_MAXF 64
+#define CV_MAXP 10  /* vertices of one face polygon */
+#define CV_MAXE 96
+#define CV_MAXCLIP (4 * CV_MAXP)
+
+typedef struct {
+  int nv, nf, ne;
+  real v[CV_MAXV][3];
+  int fcnt[CV_MAXF], fidx[CV_MAXF][CV_MAXP]; /* face polygons, counter-clockwise seen from outside */
+  real fnorm[CV_MAXF][3];                    /* outward unit normals */
+  int e[CV_MAXE][2], ef[CV_MAXE][2];         /* unique edges a -> b; ef[0] = face that runs a -> b, ef[1] = face that runs b -> a */
+  real c[3];                                 /* mean of the vertices (interior point) */
+} odko_convex;
+
+
 typedef struct {
   int nq, nv, nu, nbody, njnt, nsite, nsensor, nsensordata, ncgeom, nhullvert, nhullface;
   real timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
@@ -85,8 +102,10 @@ typedef struct {
   int hfield_nrow, hfield_ncol;
   real hfield_size[4];                 /* x half-extent, y half-extent, elevation scale, base thickness */
   real hfield_data[ODKO_MAXHFIELD];
-  /* derived: contact pair list */
+  /* derived: contact pair list, face polygons / edges of the mesh geoms (geom frame) */
   int npair, pair_g1[3], pair_g2[3];
+  odko_convex cgeom_convex[ODKO_MAXG];
+  int hfield_mode;   /* 0: prisms of the cells under the geom (MJX hfield_convex); 1: round-2's one-triangle plane (kept to measure the difference) */
 } odko_model;
 
 typedef struct {
@@ -129,7 +148,10 @@ odko_model* odko_model_copy(const odko_model* m);
 /* named access for tests / domain randomisation: returns pointer + element count, NULL if unknown */
 real* odko_model_field(odko_model* m, const char* name, int* count);
 int odko_model_int(const odko_model* m, const char* name);
-int odko_model_set_int(odko_model* m, const char* name, int value); /* "iterations" / "ls_iterations" */
+int odko_model_set_int(odko_model* m, const char* name, int value); /* "iterations" / "ls_iterations" / "hfield_mode" */
+int odko_convex_pair(const real* va, int nva, const int* ta, int nta, const real* pa, const real* ma, const real* vb, int nvb, const int* tb,
+                     int ntb, const real* pb, const real* mb, real* dist4, real* pos12, real* normal3, real* sat3);
+int odko_model_convex_counts(const odko_model* m, int g, int* nv, int* nf, int* ne);
 
 /* physics */
 odko_data* odko_data_new(void);

@@ -38,6 +38,10 @@ class _Lib:
         L.odko_model_field.restype = RP; L.odko_model_field.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
         L.odko_model_int.restype = C.c_int; L.odko_model_int.argtypes = [P, C.c_char_p]
         L.odko_model_set_int.restype = C.c_int; L.odko_model_set_int.argtypes = [P, C.c_char_p, C.c_int]
+        IP = C.POINTER(C.c_int)
+        L.odko_convex_pair.restype = C.c_int
+        L.odko_convex_pair.argtypes = [RP, C.c_int, IP, C.c_int, RP, RP, RP, C.c_int, IP, C.c_int, RP, RP, RP, RP, RP, RP]
+        L.odko_model_convex_counts.argtypes = [P, C.c_int, IP, IP, IP]
         L.odko_data_new.restype = P
         L.odko_data_free.argtypes = [P]
         for fn in ("odko_make_data", "odko_forward", "odko_step"):
@@ -96,6 +100,23 @@ def lib(f32: bool = False) -> _Lib:
     return _libs[f32]
 
 
+def convex_pair(va, ta, pa, Ra, vb, tb, pb, Rb, f32: bool = False):
+    """convex_convex (odk_oracle_convex.inc) on two polytopes given as vertices + outward triangles and poses.
+    Returns dict(dist[4], pos[4,3], normal[3], sep_a, sep_b, sep_e, kind) -- kind 0 / 1: face contact with A / B as reference, 2: edge."""
+    L = lib(f32)
+    A = lambda x: L.arr(np.asarray(x, dtype=np.float64).reshape(-1))
+    I = lambda x: np.ascontiguousarray(np.asarray(x, dtype=np.int32).reshape(-1))
+    va_, vb_, pa_, pb_, Ra_, Rb_ = A(va), A(vb), A(pa), A(pb), A(Ra), A(Rb)
+    ta_, tb_ = I(ta), I(tb)
+    dist, pos, nrm, sat = L.arr(np.zeros(4)), L.arr(np.zeros(12)), L.arr(np.zeros(3)), L.arr(np.zeros(3))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    kind = L.lib.odko_convex_pair(L.ptr(va_), len(va_) // 3, ip(ta_), len(ta_) // 3, L.ptr(pa_), L.ptr(Ra_), L.ptr(vb_), len(vb_) // 3, ip(tb_),
+                                  len(tb_) // 3, L.ptr(pb_), L.ptr(Rb_), L.ptr(dist), L.ptr(pos), L.ptr(nrm), L.ptr(sat))
+    if kind < 0:
+        raise ValueError("polytope too large for the oracle's fixed arrays")
+    return dict(dist=dist.copy(), pos=pos.reshape(4, 3).copy(), normal=nrm.copy(), sep_a=float(sat[0]), sep_b=float(sat[1]), sep_e=float(sat[2]), kind=kind)
+
+
 class _Fields:
     """numpy views into a native struct via the *_field(name) accessors."""
 
@@ -127,6 +148,13 @@ class OracleModel:
         if self.L.lib.odko_model_set_int(self.h, name.encode(), int(value)) != 0:
             raise KeyError(name)
         setattr(self, name, int(value))
+
+    def convex_counts(self, g: int):
+        """(vertices, faces after the coplanar merge, unique edges) of mesh geom g"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        if self.L.lib.odko_model_convex_counts(self.h, g, C.byref(a), C.byref(b), C.byref(c)) != 0:
+            raise IndexError(g)
+        return a.value, b.value, c.value
 
     def copy(self) -> "OracleModel":
         return OracleModel(b"", self.L.f32, _handle=self.L.lib.odko_model_copy(self.h))

@@ -177,8 +177,9 @@ def test_against_mjx_golden_if_present(oracle_mod, model_a, model_b, task):
         np.testing.assert_allclose(d["qvel"][: om.nv], g["qvel1"][i], rtol=1e-3, atol=1e-4)
 
 
-def test_height_field_contacts_follow_the_terrain(oracle_mod):
-    """rough_terrain_backlash: the contact normal under each foot is the normal of the height-field triangle below
+def test_height_field_one_triangle_mode(oracle_mod):
+    """rough_terrain_backlash, hfield_mode = 1 (round 2's approximation, kept to measure its difference to the prism algorithm of
+    tests/test_oracle_convex.py): the contact normal under each foot is the normal of the height-field triangle below
     it (independent numpy evaluation of the same rule), the robot settles on the bumps, and flat patches reduce
     to the plane case."""
     from open_duck_playground_amd.model import load_task_model
@@ -207,6 +208,7 @@ def test_height_field_contacts_follow_the_terrain(oracle_mod):
         q = np.array(a["key_qpos"], dtype=np.float64)
         q[0:2] = rng.uniform(-4, 4, 2); q[2] = 0.16
         _om, d = _data(oracle_mod, model, qpos=q)
+        _om.set_int("hfield_mode", 1)
         d.forward()
         frames = np.array(d["contact_frame"][: 8 * 9]).reshape(8, 9)
         dist = np.array(d["contact_dist"][:8]); pos = np.array(d["contact_pos"][: 8 * 3]).reshape(8, 3)
@@ -233,6 +235,7 @@ def test_height_field_contacts_follow_the_terrain(oracle_mod):
     assert 0.05 < max(tilts) < 10.0 and min(tilts) >= 0.0                                # gentle bumps: <= 1 cm per 7.8 cm cell
     # settles on the terrain
     _om, d = _data(oracle_mod, model, qpos=np.array(a["key_qpos"], dtype=np.float64))
+    _om.set_int("hfield_mode", 1)
     ctrl = np.asarray(a["key_ctrl"], dtype=np.float64)
     for _ in range(40):
         d.env_physics_step(ctrl, 10)
