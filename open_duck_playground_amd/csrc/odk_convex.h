@@ -1,0 +1,501 @@
+// odk_convex.h -- convex-convex narrow phase on 16-lane rows (gfx950): separating-axis test over face normals and the edge pairs
+// that form a face of the Minkowski difference (Gauss-map test), clipped 4-point face manifolds, edge-edge contacts, and the
+// height-field floor as prisms.  What the reference runs here is mujoco-mjx collision_convex.py (`convex_convex`,
+// `_create_contact_manifold`, `hfield_convex`; third party, reached through mjx.step at playground/open_duck_mini_v2/joystick.py:420)
+// for the foot-foot mesh pair (open_duck_mini_v2.xml:203-205,408-410) and the terrain of scene_rough_terrain_backlash.xml:22.
+//
+// Mapping: one polytope pair is worked on by ONE 16-lane DPP row (lane j of the row): face queries put a face per lane, the edge
+// query keeps the second polytope's edges in registers (3 per lane) and walks the first one's, the clipped manifold puts one
+// candidate point per lane, so every arg-max / arg-min is a row-local DPP reduction (no LDS, no readlane).  The two feet of an env
+// are two rows, i.e. they share every instruction.  Geometry sits in LDS that is dead between the inertia and the constraint
+// phases; topology tables (face polygons, unique edges with their two faces) are built at model load (odk_engine.hip).
+#pragma once
+
+namespace odk {
+
+// one polytope of a pair: geometry in LDS (work frame), topology in global memory
+struct Cvx {
+  const float* V;     // [nv][3]
+  const float* N;     // [nf][3] outward unit normals
+  const int* poly;    // [nf][5]: vertex count (3 or 4), then the vertices counter-clockwise seen from outside
+  const int* edge;    // [ne][4]: va, vb, face that runs va -> vb, face that runs vb -> va
+  int nv, nf, ne;
+  float c[3];         // an interior point
+};
+
+#define ODK_ROWBASE ((int)(threadIdx.x & 48u))
+__device__ __forceinline__ float row_get(float v, int src) { return __shfl(v, ODK_ROWBASE | src, 64); }
+// lowest index among the row's maxima of (v, i); vmax = the maximum
+__device__ __forceinline__ int row_argmax(float v, int i, float& vmax) {
+  const unsigned k = fkey(v), mx = rreduce_u<true>(k);
+  vmax = fkey_inv(mx);
+  return (int)rreduce_u<false>(k == mx ? (unsigned)i : 0x7FFFFFFFu);
+}
+__device__ __forceinline__ void sub3(float* r, const float* a, const float* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+__device__ __forceinline__ void ld3(float* r, const float* p) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; }
+
+// largest over the faces of P of the smallest signed distance of Q's vertices to the face plane (first maximum in face order)
+__device__ __forceinline__ void face_query_row(const Cvx& P, const Cvx& Q, int j, float& sep, int& face) {
+  float best = -3.0e38f;
+  int bi = 0x7FFFFFFF;
+  for (int f = j; f < P.nf; f += 16) {
+    float n[3], v0[3];
+    ld3(n, P.N + 3 * f); ld3(v0, P.V + 3 * P.poly[5 * f + 1]);
+    float smin = 3.0e38f;
+    for (int q = 0; q < Q.nv; q++) {
+      float t[3];
+      sub3(t, Q.V + 3 * q, v0);
+      smin = fminf(smin, dot3(t, n));
+    }
+    if (smin > best) { best = smin; bi = f; }
+  }
+  face = row_argmax(best, bi, sep);
+}
+
+// per edge of A: b x a of its two face normals and its direction: 6 floats, written by the row
+__device__ __forceinline__ void edge_prepare_row(const Cvx& A, float* AE, int j, bool act) {
+  for (int i = j; i < A.ne; i += 16) {
+    const int* e = A.edge + 4 * i;
+    float a[3], b[3], bxa[3], d[3];
+    ld3(a, A.N + 3 * e[2]); ld3(b, A.N + 3 * e[3]);
+    cross3(bxa, b, a);
+    sub3(d, A.V + 3 * e[1], A.V + 3 * e[0]);
+    if (act) {
+      float* o = AE + 6 * i;
+      o[0] = bxa[0]; o[1] = bxa[1]; o[2] = bxa[2]; o[3] = d[0]; o[4] = d[1]; o[5] = d[2];
+    }
+  }
+}
+
+// the edges of B this lane owns (edge j + 16 s), negated face normals and their cross product ready for the Gauss-map test
+template <int NSLOT> struct EdgeRegs {
+  float c[NSLOT][3], d[NSLOT][3], dxc[NSLOT][3];   // (direction and a point of the edge are fetched only for the few pairs that pass the test)
+  int vv[NSLOT];                                   // va | vb << 8
+  bool on[NSLOT];
+};
+template <int NSLOT> __device__ __forceinline__ void edge_regs_load(EdgeRegs<NSLOT>& R, const Cvx& B, int j) {
+#pragma unroll
+  for (int s = 0; s < NSLOT; s++) {
+    const int jb = j + 16 * s;
+    R.on[s] = jb < B.ne;
+    const int* e = B.edge + 4 * (R.on[s] ? jb : 0);
+    for (int k = 0; k < 3; k++) { R.c[s][k] = -B.N[3 * e[2] + k]; R.d[s][k] = -B.N[3 * e[3] + k]; }
+    R.vv[s] = e[0] | (e[1] << 8);
+    cross3(R.dxc[s], R.d[s], R.c[s]);
+  }
+}
+
+// Largest separation over the edge pairs (edge i of A, edge jb of B) whose Gauss-map arcs cross (they span a face of the Minkowski
+// difference); ties to the lowest (i, jb).  pair = i << 8 | jb (0x7FFFFFFF: none), axis oriented away from A's interior.
+// Edges closer to parallel than 1e-4 (sine) give no axis.
+template <int NSLOT>
+__device__ __forceinline__ void edge_query_row(const Cvx& A, const Cvx& B, const float* AE, const EdgeRegs<NSLOT>& R, int j, float& sep, int& pair, float* axis) {
+  float best = -3.0e38f, bax[3] = {0.0f, 0.0f, 1.0f};
+  int bi = 0x7FFFFFFF;
+  for (int i = 0; i < A.ne; i++) {
+    const float* ae = AE + 6 * i;
+    const float bxa[3] = {ae[0], ae[1], ae[2]}, ea[3] = {ae[3], ae[4], ae[5]};
+    const int* et = A.edge + 4 * i;   // uniform address (i and the table are the same in every lane): scalar loads
+    float a[3], b[3], pa[3], ta[3];
+    ld3(a, A.N + 3 * et[2]); ld3(b, A.N + 3 * et[3]); ld3(pa, A.V + 3 * et[0]);
+    sub3(ta, pa, A.c);
+    const float ea2 = dot3(ea, ea);
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+      const float cba = dot3(R.c[s], bxa), dba = dot3(R.d[s], bxa), adc = dot3(a, R.dxc[s]), bdc = dot3(b, R.dxc[s]);
+      if (R.on[s] && cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f) {
+        float ax[3], t[3], pb[3], eb[3];
+        const int* be = B.edge + 4 * (j + 16 * s);
+        ld3(pb, B.V + 3 * be[0]);
+        sub3(eb, B.V + 3 * be[1], pb);
+        cross3(ax, ea, eb);
+        const float len = sqrtf(dot3(ax, ax));
+        if (len >= 1e-4f * sqrtf(ea2 * dot3(eb, eb)) + 1e-30f) {
+          const float inv = 1.0f / len;
+          ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
+          if (dot3(ax, ta) < 0.0f) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; }
+          sub3(t, pb, pa);
+          const float sp = dot3(ax, t);
+          if (sp > best) { best = sp; bi = (i << 8) | (j + 16 * s); bax[0] = ax[0]; bax[1] = ax[1]; bax[2] = ax[2]; }
+        }
+      }
+    }
+  }
+  pair = row_argmax(best, bi, sep);
+  const int src = pair & 15;   // jb = j + 16 s: the owner's row lane
+  for (int k = 0; k < 3; k++) axis[k] = row_get(bax[k], src);
+}
+
+// mjx _manifold_points over the row's candidates (lane j = candidate j, `cand`: the lane holds one): four points of roughly
+// maximal area among the masked ones; every arg-max takes the lowest index among ties, like jp.argmax
+__device__ __forceinline__ void manifold4_row(const float* p, bool cand, bool mask, const float* n, int np, int j, int* idx) {
+  const float dm = cand ? (mask ? 0.0f : -1e6f) : -3.0e38f;
+  float vm;
+  idx[0] = row_argmax(dm, j, vm);
+  float a[3], b[3], c[3];
+  for (int k = 0; k < 3; k++) a[k] = row_get(p[k], idx[0]);
+  float ap[3];
+  sub3(ap, a, p);
+  idx[1] = row_argmax(cand ? dot3(ap, ap) + dm : -3.0e38f, j, vm);
+  for (int k = 0; k < 3; k++) b[k] = row_get(p[k], idx[1]);
+  float amb[3], ab[3];
+  sub3(amb, a, b);
+  cross3(ab, n, amb);
+  idx[2] = row_argmax(cand ? fabsf(dot3(ap, ab)) + dm : -3.0e38f, j, vm);
+  for (int k = 0; k < 3; k++) c[k] = row_get(p[k], idx[2]);
+  float amc[3], bmc[3], ac[3], bc[3], bp[3];
+  sub3(amc, a, c); sub3(bmc, b, c);
+  cross3(ac, n, amc); cross3(bc, n, bmc);
+  sub3(bp, b, p);
+  const float v1 = fabsf(dot3(bp, bc)) + dm, v2 = fabsf(dot3(ap, ac)) + dm;
+  float vv = v1; int vi = j;
+  if (v2 > v1) { vv = v2; vi = np + j; }
+  if (!cand) { vv = -3.0e38f; vi = 2 * np + j; }
+  idx[3] = row_argmax(vv, vi, vm);
+  idx[3] = idx[3] >= np ? idx[3] - np : idx[3];
+}
+
+// mjx _clip_edge_to_planes: the edge (p0, p1) against the side planes of polygon Q (nq vertices at QP, normal qn); the `which`-th
+// of the two clipped points, returns the mask
+__device__ __forceinline__ bool clip_edge_row(const float* p0, const float* p1, const float* QP, int nq, const float* qn, int which, float* out) {
+  float d01[3], best0 = -3.0e38f, best1 = -3.0e38f, n0[3], n1[3];
+  sub3(d01, p1, p0);
+  ld3(n0, p0); ld3(n1, p1);
+  bool both = false;
+  for (int k = 0; k < nq; k++) {
+    const float* pa = QP + 3 * (k == 0 ? nq - 1 : k - 1); const float* pb = QP + 3 * k;
+    float e[3], pn[3], t0[3], t1[3];
+    sub3(e, pb, pa);
+    cross3(pn, e, qn);
+    sub3(t0, p0, pa); sub3(t1, p1, pa);
+    const bool f0 = dot3(t0, pn) > 1e-6f, f1 = dot3(t1, pn) > 1e-6f;
+    both = both || (f0 && f1);
+    // _closest_segment_point_plane
+    const float denom = dot3(pn, d01);
+    float t = (dot3(pa, pn) - dot3(pn, p0)) / (denom + (denom == 0.0f ? 1e-6f : 0.0f));
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float cand[3] = {p0[0] + t * d01[0], p0[1] + t * d01[1], p0[2] + t * d01[2]};
+    {   // most along p0 -> p1 among {clipped point where p0 is in front, else p0}
+      const float q[3] = {f0 ? cand[0] : p0[0], f0 ? cand[1] : p0[1], f0 ? cand[2] : p0[2]};
+      float tq[3];
+      sub3(tq, q, p0);
+      const float s = dot3(tq, d01);
+      if (s > best0) { best0 = s; ld3(n0, q); }
+    }
+    {   // most along p1 -> p0
+      const float q[3] = {f1 ? cand[0] : p1[0], f1 ? cand[1] : p1[1], f1 ? cand[2] : p1[2]};
+      float tq[3];
+      sub3(tq, q, p1);
+      const float s = -dot3(tq, d01);
+      if (s > best1) { best1 = s; ld3(n1, q); }
+    }
+  }
+  bool mask = !both;
+  const float* o0 = mask ? n0 : p0; const float* o1 = mask ? n1 : p1;
+  float dd[3];
+  sub3(dd, o0, o1);
+  if (-dot3(d01, dd) < 0.0f) mask = false;   // (p0 - p1) . (o0 - o1) < 0: the clipped points crossed
+  ld3(out, which ? o1 : o0);
+  return mask;
+}
+
+// Scratch of one row (floats): RP | IP = reference / incident polygon of the current face contact ([4][3] each), NEW = this pair's
+// four contacts.  A contact = dist, pos[3], normal[3].
+struct RowScratch { float* RP; float* IP; float* NEW; };
+
+// mjx _create_contact_manifold on the polygons in S.RP (rcnt vertices, normal n_ref) / S.IP (icnt, n_inc): lane j = candidate j of
+// _clip -- (incident edge e clipped by the reference side planes) x 2, then (reference edge, projected on the incident plane along
+// the reference normal, clipped by the incident side planes) x 2 -- projected on the reference plane, four of them by
+// _manifold_points, written to S.NEW with the normal sg * n_ref (skip: an edge contact replaces them).
+__device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int icnt, const float* n_ref, const float* n_inc, float sg, bool skip, int j, bool act) {
+  const int e = j >> 1, which = j & 1, np = 2 * (icnt + rcnt);
+  const bool cand = j < np;
+  float pt[3] = {0.0f, 0.0f, 0.0f};
+  bool mask = false;
+  if (cand) {
+    if (e < icnt) {
+      mask = clip_edge_row(S.IP + 3 * (e == 0 ? icnt - 1 : e - 1), S.IP + 3 * e, S.RP, rcnt, n_ref, which, pt);
+    } else {
+      const int er = e - icnt;
+      float a[3], b[3];
+      const float d = dot3(S.IP, n_inc), den = dot3(n_ref, n_inc), dsafe = den + (den == 0.0f ? 1e-6f : 0.0f);
+      const float* ra = S.RP + 3 * (er == 0 ? rcnt - 1 : er - 1); const float* rb = S.RP + 3 * er;
+      const float ta = (d - dot3(ra, n_inc)) / dsafe, tb = (d - dot3(rb, n_inc)) / dsafe;
+      for (int k = 0; k < 3; k++) { a[k] = ra[k] + ta * n_ref[k]; b[k] = rb[k] + tb * n_ref[k]; }
+      mask = clip_edge_row(a, b, S.IP, icnt, n_inc, which, pt);
+    }
+  }
+  float t0[3], pref[3];
+  sub3(t0, pt, S.RP);
+  const float off = dot3(t0, n_ref);
+  for (int k = 0; k < 3; k++) pref[k] = pt[k] - off * n_ref[k];
+  mask = mask && (-off > 1e-6f);   // behind the reference plane
+  int idx[4];
+  manifold4_row(pref, cand, mask, n_ref, np, j, idx);
+  ODK_SYNC();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (act && !skip && j == idx[k]) {
+      const float pen = -off;
+      float* o = S.NEW + 7 * k;
+      o[0] = mask ? -pen : 1.0f;
+      for (int t = 0; t < 3; t++) { o[1 + t] = pref[t] - 0.5f * pen * n_ref[t]; o[4 + t] = sg * n_ref[t]; }
+    }
+  }
+}
+
+// ONE contact at the closest points of the edges (p1, q1) / (p2, q2) (Ericson 5.1.9), depth sep, normal ax; slots 1..3 inactive
+__device__ __forceinline__ void edge_contact_row(const float* p1, const float* q1, const float* p2, const float* q2, float sep, const float* ax, const RowScratch& S, int j, bool act) {
+  float d1[3], d2[3], r[3];
+  sub3(d1, q1, p1); sub3(d2, q2, p2); sub3(r, p1, p2);
+  const float a = dot3(d1, d1), ee = dot3(d2, d2), f = dot3(d2, r), c = dot3(d1, r), b = dot3(d1, d2), den = a * ee - b * b;
+  float s = den > 1e-30f ? (b * f - c * ee) / den : 0.0f;
+  s = fminf(fmaxf(s, 0.0f), 1.0f);
+  float t = (b * s + f) / (ee > 1e-30f ? ee : 1.0f);
+  if (t < 0.0f) { t = 0.0f; s = fminf(fmaxf(-c / (a > 1e-30f ? a : 1.0f), 0.0f), 1.0f); }
+  else if (t > 1.0f) { t = 1.0f; s = fminf(fmaxf((b - c) / (a > 1e-30f ? a : 1.0f), 0.0f), 1.0f); }
+  if (act && j < 4) {
+    float* o = S.NEW + 7 * j;
+    o[0] = j == 0 ? sep : 1.0f;
+    for (int k = 0; k < 3; k++) { o[1 + k] = 0.5f * ((p1[k] + s * d1[k]) + (p2[k] + t * d2[k])); o[4 + k] = ax[k]; }
+  }
+}
+
+// One polytope pair on one row, both given by tables: SAT decision + contacts into S.NEW[4][7] (normal pointing from A to B).
+// All lanes of the row call this together; `act` gates the LDS writes (rows that have nothing to do run along).
+template <int NSLOT>
+__device__ __forceinline__ void sat_pair_row(const Cvx& A, const Cvx& B, const float* AE, const EdgeRegs<NSLOT>& RB, const RowScratch& S, int j, bool act) {
+  float sep_a, sep_b, sep_e, eax[3];
+  int face_a, face_b, pair;
+  face_query_row(A, B, j, sep_a, face_a);
+  face_query_row(B, A, j, sep_b, face_b);
+  edge_query_row<NSLOT>(A, B, AE, RB, j, sep_e, pair, eax);
+  const bool ref_a = sep_a >= sep_b;
+  const float face_sep = ref_a ? sep_a : sep_b;
+  const bool is_edge = pair != 0x7FFFFFFF && sep_e > face_sep + 1e-5f;
+  // ---- face contact (computed by every row; an edge contact replaces it below)
+  const Cvx& R = ref_a ? A : B; const Cvx& I = ref_a ? B : A;
+  int rf = ref_a ? face_a : face_b;
+  rf = (unsigned)rf < (unsigned)R.nf ? rf : 0;   // (rows that only run along may hold garbage: keep every table index in range)
+  float n_ref[3];
+  ld3(n_ref, R.N + 3 * rf);
+  int inc;
+  {
+    float best = -3.0e38f, vm; int bi = 0x7FFFFFFF;
+    for (int f = j; f < I.nf; f += 16) { const float s = -dot3(I.N + 3 * f, n_ref); if (s > best) { best = s; bi = f; } }
+    inc = row_argmax(best, bi, vm);
+    inc = (unsigned)inc < (unsigned)I.nf ? inc : 0;
+  }
+  float n_inc[3];
+  ld3(n_inc, I.N + 3 * inc);
+  const int rcnt = R.poly[5 * rf], icnt = I.poly[5 * inc];
+  ODK_SYNC();
+  if (act && j < 8) {
+    const bool isr = j < 4; const int k = j & 3;
+    const int cnt = isr ? rcnt : icnt;
+    if (k < cnt) {
+      const int v = isr ? R.poly[5 * rf + 1 + k] : I.poly[5 * inc + 1 + k];
+      const float* src = (isr ? R.V : I.V) + 3 * v;
+      float* dst = (isr ? S.RP : S.IP) + 3 * k;
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    }
+  }
+  ODK_SYNC();
+  manifold_row(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act);
+  if (is_edge) {   // row-uniform
+    const int ia = pair >> 8, ib = pair & 255;
+    const int* ea = A.edge + 4 * (ia < A.ne ? ia : 0); const int* eb = B.edge + 4 * (ib < B.ne ? ib : 0);
+    edge_contact_row(A.V + 3 * ea[0], A.V + 3 * ea[1], B.V + 3 * eb[0], B.V + 3 * eb[1], sep_e, eax, S, j, act);
+  }
+  ODK_SYNC();
+}
+
+// ---- height-field prisms: the first polytope's topology is known at compile time and its geometry fits registers
+// vertices 0..2 = top triangle (counter-clockwise seen from above), 3..5 below them at z = -base; faces: top, bottom, the sides over
+// the edges 0-1, 1-2, 2-0 (what build_convex_tables makes of the prism's eight triangles: odk_engine.hip)
+struct Prism {
+  float x[3], y[3], z[3], base;
+  float nt[3];      // top normal
+  float ns[3][2];   // side normals (x, y)
+};
+__device__ __forceinline__ void prism_vert(const Prism& P, int k, float* o) { const int t = k % 3; o[0] = P.x[t]; o[1] = P.y[t]; o[2] = k < 3 ? P.z[t] : -P.base; }
+__device__ __forceinline__ void prism_norm(const Prism& P, int f, float* o) {
+  if (f == 0) { o[0] = P.nt[0]; o[1] = P.nt[1]; o[2] = P.nt[2]; }
+  else if (f == 1) { o[0] = 0.0f; o[1] = 0.0f; o[2] = -1.0f; }
+  else { o[0] = P.ns[f - 2][0]; o[1] = P.ns[f - 2][1]; o[2] = 0.0f; }
+}
+// unique edges (va, vb, face running va -> vb, face running vb -> va) and face polygons (count, vertices) of the prism
+__device__ constexpr int PRISM_EDGE[9][4] = {{0, 1, 0, 2}, {1, 2, 0, 3}, {3, 5, 1, 4}, {0, 3, 2, 4}, {3, 4, 2, 1}, {1, 4, 3, 2}, {4, 5, 3, 1}, {2, 5, 4, 3}, {0, 2, 4, 0}};
+__device__ constexpr int PRISM_POLY[5][5] = {{3, 0, 1, 2, 0}, {3, 3, 5, 4, 3}, {4, 0, 3, 4, 1}, {4, 1, 4, 5, 2}, {4, 2, 5, 3, 0}};
+
+// the faces of the second polytope this lane owns (face j + 16 s): normal, plane offset n . v0, polygon packed 3 | 5 x 4 bits
+template <int NFS> struct FaceRegs { float n[NFS][3], d[NFS]; int poly[NFS]; bool on[NFS]; };
+template <int NFS> __device__ __forceinline__ void face_regs_load(FaceRegs<NFS>& R, const Cvx& B, int j) {
+#pragma unroll
+  for (int s = 0; s < NFS; s++) {
+    const int f = j + 16 * s;
+    R.on[s] = f < B.nf;
+    const int* pl = B.poly + 5 * (R.on[s] ? f : 0);
+    ld3(R.n[s], B.N + 3 * (R.on[s] ? f : 0));
+    R.d[s] = dot3(B.V + 3 * pl[1], R.n[s]);
+    R.poly[s] = pl[0] | (pl[1] << 3) | (pl[2] << 8) | (pl[3] << 13) | (pl[4] << 18);
+  }
+}
+
+// prism P (first polytope, in registers; its own face query already done: sep_a, face_a) against the hull B (geometry in LDS,
+// faces / edges of this lane in FB / RB); PV: the prism's vertices in LDS for the polygon fetch
+template <int NFS, int NSLOT>
+__device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, const float* PV, const Cvx& B, const FaceRegs<NFS>& FB, const EdgeRegs<NSLOT>& RB,
+                                              float sep_a, int face_a, const RowScratch& S, int j, bool act) {
+  // ---- face query of the hull against the prism's six vertices
+  float sep_b; int face_b;
+  {
+    float best = -3.0e38f; int bi = 0x7FFFFFFF;
+#pragma unroll
+    for (int s = 0; s < NFS; s++) {
+      float smin = 3.0e38f;
+#pragma unroll
+      for (int q = 0; q < 6; q++) { float v[3]; prism_vert(P, q, v); smin = fminf(smin, dot3(v, FB.n[s]) - FB.d[s]); }
+      if (FB.on[s] && smin > best) { best = smin; bi = j + 16 * s; }
+    }
+    face_b = row_argmax(best, bi, sep_b);
+  }
+  // ---- edge query: the prism's nine edges (compile-time topology) against the hull edges of this lane.  The Gauss-map test of all
+  // 27 pairs of a lane first (a pass bit each), then the few passing pairs in a short loop: taken inline, some lane of the wave
+  // passes nearly every test, so every lane would walk through all 27 axis computations.
+  float sep_e, eax[3]; int pair;
+  {
+    static_assert(NSLOT == 3, "pass bit = 3 i + slot");
+    unsigned pass = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      float a[3], b[3], bxa[3];
+      prism_norm(P, PRISM_EDGE[i][2], a); prism_norm(P, PRISM_EDGE[i][3], b);
+      cross3(bxa, b, a);
+#pragma unroll
+      for (int s = 0; s < NSLOT; s++) {
+        const float cba = dot3(RB.c[s], bxa), dba = dot3(RB.d[s], bxa), adc = dot3(a, RB.dxc[s]), bdc = dot3(b, RB.dxc[s]);
+        const bool ok = RB.on[s] && cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f;
+        pass |= ok ? (1u << (3 * i + s)) : 0u;
+      }
+    }
+    float best = -3.0e38f, bax[3] = {0.0f, 0.0f, 1.0f};
+    int bi = 0x7FFFFFFF;
+    while (__builtin_amdgcn_ballot_w64(pass != 0u) != 0) {
+      const bool has = pass != 0u;
+      const int kk = has ? __ffs((int)pass) - 1 : 0;
+      pass &= pass - 1u;
+      const int i = (kk * 11) >> 5, sl = kk - 3 * i;   // kk / 3 for kk < 27
+      // prism edge i: vertices from the packed table (va | vb << 3, 6 bits per edge), geometry from the LDS copy
+      const unsigned long long PKE = 0ull | (0ull | 1ull << 3) | ((1ull | 2ull << 3) << 6) | ((3ull | 5ull << 3) << 12) | ((0ull | 3ull << 3) << 18) |
+                                     ((3ull | 4ull << 3) << 24) | ((1ull | 4ull << 3) << 30) | ((4ull | 5ull << 3) << 36) | ((2ull | 5ull << 3) << 42) | ((0ull | 2ull << 3) << 48);
+      const int ve = (int)((PKE >> (6 * i)) & 63ull);
+      const int vv = sl == 0 ? RB.vv[0] : (sl == 1 ? RB.vv[1] : RB.vv[2]);
+      float pa[3], qa[3], pb[3], qb[3], ea[3], eb[3], ta[3], ax[3], t[3];
+      ld3(pa, PV + 3 * (ve & 7)); ld3(qa, PV + 3 * (ve >> 3)); ld3(pb, B.V + 3 * (vv & 255)); ld3(qb, B.V + 3 * (vv >> 8));
+      sub3(ea, qa, pa); sub3(eb, qb, pb); sub3(ta, pa, pc);
+      cross3(ax, ea, eb);
+      const float l2 = dot3(ax, ax);
+      if (has && l2 >= 1e-8f * dot3(ea, ea) * dot3(eb, eb) && l2 > 1e-30f) {   // edges closer to parallel than 1e-4 (sine) give no axis
+        const float inv = rsqrtf(l2);
+        ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
+        if (dot3(ax, ta) < 0.0f) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; }
+        sub3(t, pb, pa);
+        const float sp = dot3(ax, t);
+        const int id = (i << 8) | (j + 16 * sl);
+        if (sp > best || (sp == best && id < bi)) { best = sp; bi = id; bax[0] = ax[0]; bax[1] = ax[1]; bax[2] = ax[2]; }
+      }
+    }
+    pair = row_argmax(best, bi, sep_e);
+    const int src = pair & 15;
+    for (int k = 0; k < 3; k++) eax[k] = row_get(bax[k], src);
+  }
+  const bool ref_a = sep_a >= sep_b;
+  const float face_sep = ref_a ? sep_a : sep_b;
+  const bool is_edge = pair != 0x7FFFFFFF && sep_e > face_sep + 1e-5f;
+  // ---- reference / incident faces
+  face_b = (unsigned)face_b < (unsigned)B.nf ? face_b : 0;
+  face_a = (unsigned)face_a < 5u ? face_a : 0;
+  float n_ref[3], n_inc[3];
+  int pf_pk;    // the hull face involved (reference or incident), packed polygon
+  int pa_f;     // the prism face involved
+  if (ref_a) {  // row-uniform
+    pa_f = face_a;
+    n_ref[0] = face_a == 0 ? P.nt[0] : (face_a == 1 ? 0.0f : (face_a == 2 ? P.ns[0][0] : (face_a == 3 ? P.ns[1][0] : P.ns[2][0])));
+    n_ref[1] = face_a == 0 ? P.nt[1] : (face_a == 1 ? 0.0f : (face_a == 2 ? P.ns[0][1] : (face_a == 3 ? P.ns[1][1] : P.ns[2][1])));
+    n_ref[2] = face_a == 0 ? P.nt[2] : (face_a == 1 ? -1.0f : 0.0f);
+    float best = -3.0e38f, vm; int bi = 0x7FFFFFFF;
+#pragma unroll
+    for (int s = 0; s < NFS; s++) { const float sc = -dot3(FB.n[s], n_ref); if (FB.on[s] && sc > best) { best = sc; bi = j + 16 * s; } }
+    int inc = row_argmax(best, bi, vm);
+    inc = (unsigned)inc < (unsigned)B.nf ? inc : 0;
+    const int sl = inc >> 4;
+    for (int k = 0; k < 3; k++) n_inc[k] = row_get(sl == 0 ? FB.n[0][k] : FB.n[NFS - 1][k], inc & 15);
+    pf_pk = __float_as_int(row_get(__int_as_float(sl == 0 ? FB.poly[0] : FB.poly[NFS - 1]), inc & 15));
+  } else {
+    const int sl = face_b >> 4;
+    for (int k = 0; k < 3; k++) n_ref[k] = row_get(sl == 0 ? FB.n[0][k] : FB.n[NFS - 1][k], face_b & 15);
+    pf_pk = __float_as_int(row_get(__int_as_float(sl == 0 ? FB.poly[0] : FB.poly[NFS - 1]), face_b & 15));
+    float best = 3.0e38f; pa_f = 0;   // most anti-parallel prism face, first minimum
+#pragma unroll
+    for (int f = 0; f < 5; f++) { float nf[3]; prism_norm(P, f, nf); const float sc = dot3(nf, n_ref); if (sc < best) { best = sc; pa_f = f; } }
+    n_inc[0] = pa_f == 0 ? P.nt[0] : (pa_f == 1 ? 0.0f : (pa_f == 2 ? P.ns[0][0] : (pa_f == 3 ? P.ns[1][0] : P.ns[2][0])));
+    n_inc[1] = pa_f == 0 ? P.nt[1] : (pa_f == 1 ? 0.0f : (pa_f == 2 ? P.ns[0][1] : (pa_f == 3 ? P.ns[1][1] : P.ns[2][1])));
+    n_inc[2] = pa_f == 0 ? P.nt[2] : (pa_f == 1 ? -1.0f : 0.0f);
+  }
+  static_assert(NFS == 2, "face slots: face = lane + 16 slot, two slots");
+  // packed prism polygons (count | v0 << 3 | v1 << 6 | v2 << 9 | v3 << 12), selected without a table load
+  const int pp_pk = pa_f == 0 ? (3 | 0 << 3 | 1 << 6 | 2 << 9 | 0 << 12) : (pa_f == 1 ? (3 | 3 << 3 | 5 << 6 | 4 << 9 | 3 << 12)
+                  : (pa_f == 2 ? (4 | 0 << 3 | 3 << 6 | 4 << 9 | 1 << 12) : (pa_f == 3 ? (4 | 1 << 3 | 4 << 6 | 5 << 9 | 2 << 12) : (4 | 2 << 3 | 5 << 6 | 3 << 9 | 0 << 12))));
+  const int pcnt = pp_pk & 7, fcnt = pf_pk & 7;
+  const int rcnt = ref_a ? pcnt : fcnt, icnt = ref_a ? fcnt : pcnt;
+  ODK_SYNC();
+  if (act && j < 8) {
+    const bool isr = j < 4; const int k = j & 3;
+    const bool from_prism = isr == ref_a;
+    const int cnt = from_prism ? pcnt : fcnt;
+    if (k < cnt) {
+      const int v = from_prism ? (pp_pk >> (3 + 3 * k)) & 7 : (pf_pk >> (3 + 5 * k)) & 31;
+      const float* src = (from_prism ? PV : B.V) + 3 * v;
+      float* dst = (isr ? S.RP : S.IP) + 3 * k;
+      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    }
+  }
+  ODK_SYNC();
+  manifold_row(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act);
+  if (is_edge) {   // row-uniform
+    int ia = pair >> 8, ib = pair & 255;
+    ia = ia < 9 ? ia : 0; ib = ib < B.ne ? ib : 0;
+    const int va = ia == 2 || ia == 4 ? 3 : (ia == 6 ? 4 : (ia == 1 || ia == 5 ? 1 : (ia == 7 ? 2 : 0)));   // PRISM_EDGE[ia][0]
+    const int vb = ia == 0 ? 1 : (ia == 1 || ia == 8 ? 2 : (ia == 3 ? 3 : (ia == 4 || ia == 5 ? 4 : 5)));       // PRISM_EDGE[ia][1]
+    const int* eb = B.edge + 4 * ib;
+    edge_contact_row(PV + 3 * va, PV + 3 * vb, B.V + 3 * eb[0], B.V + 3 * eb[1], sep_e, eax, S, j, act);
+  }
+  ODK_SYNC();
+}
+
+// keeps the four smallest dist of TOP[4] ++ NEW[4] in TOP (stable: earlier entries win ties, like a stable sort of the whole list)
+__device__ __forceinline__ void merge_top4_row(float* TOP, const float* NEW, int j, bool act) {
+  float mine[7], dist[8];
+  const float* src = j < 4 ? TOP + 7 * j : NEW + 7 * ((j - 4) & 3);
+  for (int k = 0; k < 7; k++) mine[k] = src[k];
+  for (int k = 0; k < 8; k++) dist[k] = k < 4 ? TOP[7 * k] : NEW[7 * (k - 4)];
+  int rank = 0;
+  for (int k = 0; k < 8; k++) rank += (dist[k] < mine[0] || (dist[k] == mine[0] && k < j)) ? 1 : 0;
+  ODK_SYNC();
+  if (act && j < 8 && rank < 4) { float* o = TOP + 7 * rank; for (int k = 0; k < 7; k++) o[k] = mine[k]; }
+  ODK_SYNC();
+}
+
+__device__ __forceinline__ void make_frame_dev(const float* n, float* fr) {   // mju_makeFrame / mjx math.make_frame
+  float b[3] = {0.0f, 0.0f, 0.0f}, cc[3];
+  if (fabsf(n[1]) < 0.5f) b[1] = 1.0f; else b[2] = 1.0f;
+  const float dtb = dot3(n, b);
+  b[0] -= dtb * n[0]; b[1] -= dtb * n[1]; b[2] -= dtb * n[2];
+  const float inv = 1.0f / sqrtf(dot3(b, b));
+  b[0] *= inv; b[1] *= inv; b[2] *= inv;
+  cross3(cc, n, b);
+  for (int t = 0; t < 3; t++) { fr[t] = n[t]; fr[3 + t] = b[t]; fr[6 + t] = cc[t]; }
+}
+
+}  // namespace odk

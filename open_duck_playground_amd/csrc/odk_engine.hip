@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -1009,6 +1010,90 @@ static bool build_reduced_tables(DevModel& m) {
   return ok;
 }
 
+// Face polygons and unique edges of a convex hull given as outward triangles (what mjx mesh.py prepares for collision_convex:
+// coplanar facets merged, edges with their two faces).  Triangles that share an edge and a plane (normals within 1e-6) become one
+// polygon (at most a quad here: larger merges are refused).  Order matters downstream (first-index tie-breaks): faces in order of
+// their first triangle, polygons start at the first boundary edge, edges in face order with va < vb.
+static bool build_convex_tables(const double (*v)[3], int nv, const int (*tri)[3], int nt, int* npoly, int (*poly)[5], float (*fnorm)[3], int* nedge,
+                                int (*edge)[4], float* centroid, int maxf, int maxe) {
+  std::vector<std::array<double, 3>> tn(nt);
+  std::vector<int> grp(nt);
+  double c[3] = {0, 0, 0};
+  for (int i = 0; i < nv; i++) for (int k = 0; k < 3; k++) c[k] += v[i][k] / nv;
+  for (int k = 0; k < 3; k++) centroid[k] = (float)c[k];
+  for (int t = 0; t < nt; t++) {
+    double e1[3], e2[3], n[3];
+    for (int k = 0; k < 3; k++) { e1[k] = v[tri[t][1]][k] - v[tri[t][0]][k]; e2[k] = v[tri[t][2]][k] - v[tri[t][0]][k]; }
+    n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+    const double l = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (l == 0) return false;
+    tn[t] = {n[0] / l, n[1] / l, n[2] / l};
+    grp[t] = t;
+  }
+  for (int it = 0; it < nt; it++)
+    for (int a = 0; a < nt; a++)
+      for (int b = a + 1; b < nt; b++) {
+        if (grp[a] == grp[b]) continue;
+        int shared = 0;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) if (tri[a][i] == tri[b][j]) shared++;
+        if (shared == 2 && fabs(tn[a][0] - tn[b][0]) < 1e-6 && fabs(tn[a][1] - tn[b][1]) < 1e-6 && fabs(tn[a][2] - tn[b][2]) < 1e-6) {
+          const int ga = grp[a], gb = grp[b], lo = ga < gb ? ga : gb;
+          for (int t = 0; t < nt; t++) if (grp[t] == ga || grp[t] == gb) grp[t] = lo;
+        }
+      }
+  int nf = 0;
+  for (int g = 0; g < nt; g++) {
+    std::vector<int> ea, eb;
+    bool any = false;
+    for (int t = 0; t < nt; t++) {
+      if (grp[t] != g) continue;
+      any = true;
+      for (int i = 0; i < 3; i++) {
+        const int a = tri[t][i], b = tri[t][(i + 1) % 3];
+        bool inner = false;
+        for (int u = 0; u < nt && !inner; u++) {
+          if (grp[u] != g || u == t) continue;
+          for (int j = 0; j < 3; j++) if (tri[u][j] == b && tri[u][(j + 1) % 3] == a) inner = true;
+        }
+        if (!inner) { ea.push_back(a); eb.push_back(b); }
+      }
+    }
+    if (!any) continue;
+    if (nf >= maxf || ea.size() > 4) return false;
+    int cur = ea[0], cnt = 0;
+    for (size_t step = 0; step < ea.size(); step++) {
+      poly[nf][1 + cnt++] = cur;
+      int nxt = -1;
+      for (size_t k = 0; k < ea.size(); k++) if (ea[k] == cur) { nxt = eb[k]; break; }
+      cur = nxt;
+      if (cur == ea[0] || cur < 0) break;
+    }
+    poly[nf][0] = cnt;
+    for (int k = cnt; k < 4; k++) poly[nf][1 + k] = poly[nf][1];
+    for (int k = 0; k < 3; k++) fnorm[nf][k] = (float)tn[g][k];
+    nf++;
+  }
+  int ne = 0;
+  for (int f = 0; f < nf; f++)
+    for (int i = 0; i < poly[f][0]; i++) {
+      const int a = poly[f][1 + i], b = poly[f][1 + (i + 1) % poly[f][0]];
+      if (a > b) continue;
+      if (ne >= maxe) return false;
+      edge[ne][0] = a; edge[ne][1] = b; edge[ne][2] = f; edge[ne][3] = -1; ne++;
+    }
+  for (int f = 0; f < nf; f++)
+    for (int i = 0; i < poly[f][0]; i++) {
+      const int a = poly[f][1 + i], b = poly[f][1 + (i + 1) % poly[f][0]];
+      if (a < b) continue;
+      bool found = false;
+      for (int k = 0; k < ne; k++) if (edge[k][0] == b && edge[k][1] == a) { edge[k][3] = f; found = true; }
+      if (!found) return false;   // open surface
+    }
+  for (int k = 0; k < ne; k++) if (edge[k][2] < 0 || edge[k][3] < 0) return false;
+  *npoly = nf; *nedge = ne;
+  return true;
+}
+
 extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   if (!blob || !out || len < 16 || memcmp(blob, "ODKM", 4) != 0) return fail(ODK_ERR_INVALID, "odk_model_load: not an ODKM blob");
   Blob B{(const unsigned char*)blob, len};
@@ -1141,6 +1226,25 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     for (int k = 0; k < 3; k++) { cl[k] = 0.5 * (lo[k] + hi[k]); m.foot_obb_half[f][k] = (float)(0.5 * (hi[k] - lo[k])); }
     for (int k = 0; k < 3; k++) m.foot_obb_center[f][k] = (float)(cg_pos[3 * g + k] + gm[3 * k] * cl[0] + gm[3 * k + 1] * cl[1] + gm[3 * k + 2] * cl[2]);
     for (int k = 0; k < 9; k++) m.foot_obb_axes[f][k] = (float)gm[k];
+    {   // polygons / edges / normals of the hull in the body frame (double precision, then rounded)
+      double bv[MAXHV][3];
+      int tr[MAXHF][3];
+      for (int v = 0; v < cg_vnum[g]; v++) {
+        const double* p = hv + 3 * (cg_vadr[g] + v);
+        for (int k = 0; k < 3; k++) bv[v][k] = cg_pos[3 * g + k] + gm[3 * k] * p[0] + gm[3 * k + 1] * p[1] + gm[3 * k + 2] * p[2];
+      }
+      for (int t = 0; t < cg_fnum[g]; t++) for (int k = 0; k < 3; k++) tr[t][k] = hf[3 * (cg_fadr[g] + t) + k];
+      if (!build_convex_tables(bv, cg_vnum[g], tr, cg_fnum[g], &m.foot_npoly[f], m.foot_poly[f], m.foot_fnorm[f], &m.foot_nedge[f], m.foot_edge[f],
+                               m.foot_centroid[f], MAXHF, 48)) {
+        delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull: not a closed polytope with <= 4-vertex faces and <= 48 edges");
+      }
+    }
+  }
+  {   // a height-field prism's topology (odk_convex.h): vertices 0..2 top, 3..5 bottom
+    const double pv[6][3] = {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {0, 0, 0}, {1, 0, 0}, {0, 1, 0}};
+    const int ptri[8][3] = {{0, 1, 2}, {3, 5, 4}, {0, 3, 4}, {0, 4, 1}, {1, 4, 5}, {1, 5, 2}, {2, 5, 3}, {2, 3, 0}};
+    int np = 0, ne = 0; float fn[5][3], cc[3];
+    if (!build_convex_tables(pv, 6, ptri, 8, &np, m.prism_poly, fn, &ne, m.prism_edge, cc, 5, 9) || np != 5 || ne != 9) { delete mo; return fail(ODK_ERR_INVALID, "prism tables"); }
   }
   {
     int g = floor_cg[0];
@@ -1377,6 +1481,9 @@ static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st
   return hipErrorNotSupported;
 #elif defined(ODK_DEV_A32)
   if (b->model.shape == 0 && b->G == 32) return launch_sg<ShapeA, 32, false>(which, a, st);
+  return hipErrorNotSupported;
+#elif defined(ODK_DEV_HF)
+  if (!b->model.h.floor_is_plane) return launch_sg<ShapeB, 32, true>(which, a, st);
   return hipErrorNotSupported;
 #endif
   // height-field floors exist only with the backlash model (scene_rough_terrain_backlash.xml) and run 32 lanes per env

@@ -777,34 +777,6 @@ __device__ __forceinline__ void row_params(const float* P, float pos, float invw
 //   flags bit0: compute sensordata / debug outputs (last substep only)
 // mjx collision_convex._manifold_points: 4 support points of approximately maximal area among the vertices within
 // 1e-3 of the deepest one (lane = vertex; `n` = contact normal)
-// Plane of the height-field triangle below world point pw (cell (c, r) split along the (c+1, r)-(c, r+1) diagonal):
-// world position of one of its vertices and its upward unit normal.  Mirrors oracle hfield_plane.
-__device__ __forceinline__ void hfield_plane(const DevModel* __restrict__ m, const float* __restrict__ hf, const float* pw, float* pos_w, float* n_w) {
-  const float* R = m->floor_mat;
-  const float rel[3] = {pw[0] - m->plane_pos[0], pw[1] - m->plane_pos[1], pw[2] - m->plane_pos[2]};
-  const float px = R[0] * rel[0] + R[3] * rel[1] + R[6] * rel[2], py = R[1] * rel[0] + R[4] * rel[1] + R[7] * rel[2];
-  const int nc = m->hfield_ncol, nr = m->hfield_nrow;
-  const float sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
-  const float dx = 2.0f * sx / (float)(nc - 1), dy = 2.0f * sy / (float)(nr - 1);
-  const float fx = (px + sx) / dx, fy = (py + sy) / dy;
-  int c = (int)floorf(fx), r = (int)floorf(fy);
-  c = c < 0 ? 0 : (c > nc - 2 ? nc - 2 : c);
-  r = r < 0 ? 0 : (r > nr - 2 ? nr - 2 : r);
-  const float tx = fx - (float)c, ty = fy - (float)r;
-  const float x0 = -sx + (float)c * dx, y0 = -sy + (float)r * dy;
-  const float z00 = hf[r * nc + c] * sz, z10 = hf[r * nc + c + 1] * sz, z01 = hf[(r + 1) * nc + c] * sz, z11 = hf[(r + 1) * nc + c + 1] * sz;
-  float a[3], e1[3], e2[3], nl[3];
-  if (tx + ty <= 1.0f) { a[0] = x0; a[1] = y0; a[2] = z00; e1[0] = dx; e1[1] = 0; e1[2] = z10 - z00; e2[0] = 0; e2[1] = dy; e2[2] = z01 - z00; }
-  else { a[0] = x0 + dx; a[1] = y0 + dy; a[2] = z11; e1[0] = -dx; e1[1] = 0; e1[2] = z01 - z11; e2[0] = 0; e2[1] = -dy; e2[2] = z10 - z11; }
-  cross3(nl, e1, e2);
-  const float inv = 1.0f / sqrtf(dot3(nl, nl));
-  nl[0] *= inv; nl[1] *= inv; nl[2] *= inv;
-  for (int k = 0; k < 3; k++) {
-    n_w[k] = R[3 * k] * nl[0] + R[3 * k + 1] * nl[1] + R[3 * k + 2] * nl[2];
-    pos_w[k] = m->plane_pos[k] + R[3 * k] * a[0] + R[3 * k + 1] * a[1] + R[3 * k + 2] * a[2];
-  }
-}
-
 template <int G>
 __device__ __forceinline__ void select4(const float* w, bool has, float sup, int nvt, const float* n, int* idx, int lane) {
   const float smax = gmax<G>(sup);
@@ -895,105 +867,224 @@ __device__ __forceinline__ void select4_rows(const float* w, bool has, float sup
   idx[3] = idx[3] >= nvt ? idx[3] - nvt : idx[3];
 }
 
-// Foot-foot (mesh-mesh) contact manifold: face-normal SAT over both hulls + 4-point manifold, the same restatement as
-// oracle convex_convex.  Called by every lane of the wave; envs whose boxes are separated are masked by `overlap`.
+}  // namespace odk
+#include "odk_convex.h"
+namespace odk {
+
+// Foot-foot (mesh-mesh) contacts: mjx convex_convex on the two hulls in the world frame (odk_convex.h), worked on by the first
+// 16-lane row of every env whose boxes overlap; the other rows (and envs whose boxes are separated: `overlap` false) run along
+// with their writes gated off.  Called by every lane of the wave (wave-uniform branch at the caller).  Rare path, out of line:
+// it must not take part in the hot path's register allocation.
+// LDS (all dead between the inertia phase and the constraint rows): world vertices / face normals of both feet in the row
+// region D | aref | jar | jv, the first hull's edge data in cfrc | crb, polygons + this pair's contacts in BUF6.
 template <class S, int G>
 __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict__ m, int lane, bool overlap) {
   constexpr int NB = S::NB;
-  float* W = L + S::O_W; float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR;
+  static_assert(4 * S::NROW >= 282 && 16 * S::NB >= 6 * 48 && 6 * S::NVR >= 52, "foot-foot scratch does not fit");
+  float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR;
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
-  float fR[2][9], fP[2][3];
+  float* FVb = L + S::O_D;       // [2][17][3] vertices | [2][30][3] normals
+  float* AE = L + S::O_CFRC;     // [<= 48][6]
+  float* RS = L + S::O_BUF6;     // RP 12 | IP 12 | NEW 28
+  const int row = lane >> 4, j = lane & 15;
+  const bool act = overlap && row == 0;
+  float cw[2][3];
+#pragma unroll
   for (int f = 0; f < 2; f++) {
     const int fb = m->foot_body[f];
-    float q[4];
+    float q[4], R[9], P[3];
     for (int k = 0; k < 4; k++) q[k] = XQUAT[k * NB + fb];
-    for (int k = 0; k < 3; k++) fP[f][k] = XPOS[k * NB + fb];
-    q2mat(fR[f], q);
+    for (int k = 0; k < 3; k++) P[k] = XPOS[k * NB + fb];
+    q2mat(R, q);
+    for (int v = lane; v < m->foot_nvert[f]; v += G) {
+      const float vb[3] = {m->foot_vert[f][v][0], m->foot_vert[f][v][1], m->foot_vert[f][v][2]};
+      for (int k = 0; k < 3; k++) FVb[f * 51 + 3 * v + k] = P[k] + R[3 * k] * vb[0] + R[3 * k + 1] * vb[1] + R[3 * k + 2] * vb[2];
+    }
+    for (int t = lane; t < m->foot_npoly[f]; t += G) {
+      const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
+      for (int k = 0; k < 3; k++) FVb[102 + f * 90 + 3 * t + k] = R[3 * k] * nb[0] + R[3 * k + 1] * nb[1] + R[3 * k + 2] * nb[2];
+    }
+    for (int k = 0; k < 3; k++) cw[f][k] = P[k] + R[3 * k] * m->foot_centroid[f][0] + R[3 * k + 1] * m->foot_centroid[f][1] + R[3 * k + 2] * m->foot_centroid[f][2];
   }
-    // Overlapping boxes (feet about to touch, rare): face-normal SAT over both hulls + 4-point manifold, the same
-    // restatement as oracle convex_convex.  Wave-uniform branch; envs whose boxes are separated are masked out.
-    {
-      float* VW = W;   // [2][MAXHV][3] world vertices; the wrench area is free until P8
-      const int n1 = m->foot_nvert[0], n2 = m->foot_nvert[1];
-      float w2[3] = {0, 0, 0};
-#pragma unroll
-      for (int f = 0; f < 2; f++) {
-        if (lane < m->foot_nvert[f]) {
-          const float vb[3] = {m->foot_vert[f][lane][0], m->foot_vert[f][lane][1], m->foot_vert[f][lane][2]};
-          for (int k = 0; k < 3; k++) {
-            const float x = fP[f][k] + fR[f][3 * k] * vb[0] + fR[f][3 * k + 1] * vb[1] + fR[f][3 * k + 2] * vb[2];
-            VW[(f * MAXHV + lane) * 3 + k] = x;
-            if (f == 1) w2[k] = x;
-          }
-        }
-      }
-      ODK_SYNC();
-      float mybest = -3.0e38f, myax[3] = {0, 0, 1};
-      int myidx = 1 << 20;
-      for (int f = 0; f < 2; f++) {
-        for (int fi = lane; fi < m->foot_nface[f]; fi += G) {
-          const float* v0 = VW + (f * MAXHV + m->foot_face[f][fi][0]) * 3;
-          const float* v1 = VW + (f * MAXHV + m->foot_face[f][fi][1]) * 3;
-          const float* v2 = VW + (f * MAXHV + m->foot_face[f][fi][2]) * 3;
-          const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]}, e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
-          float nr[3];
-          cross3(nr, e1, e2);
-          const float nn = sqrtf(dot3(nr, nr));
-          if (nn == 0.0f) continue;
-          nr[0] /= nn; nr[1] /= nn; nr[2] /= nn;
-          float max1 = -3.0e38f, min1 = 3.0e38f, max2 = -3.0e38f, min2 = 3.0e38f;
-          for (int i = 0; i < n1; i++) { const float pr = dot3(VW + i * 3, nr); max1 = fmaxf(max1, pr); min1 = fminf(min1, pr); }
-          for (int i = 0; i < n2; i++) { const float pr = dot3(VW + (MAXHV + i) * 3, nr); max2 = fmaxf(max2, pr); min2 = fminf(min2, pr); }
-          const float sa = min2 - max1, sb = min1 - max2;
-          const float sp = sa > sb ? sa : sb;
-          if (sp > mybest) {
-            mybest = sp; myidx = f * MAXHF + fi;
-            const float sg = sb > sa ? -1.0f : 1.0f;
-            myax[0] = sg * nr[0]; myax[1] = sg * nr[1]; myax[2] = sg * nr[2];
-          }
-        }
-      }
-      const float hsep = gmax<G>(mybest);
-      const int widx = (int)gmin<G>(mybest == hsep ? (float)myidx : 1.0e9f);   // first face in (hull, face) order wins ties
-      ODK_SYNC();
-      if (overlap && myidx == widx) { SCR[S::S_VF] = myax[0]; SCR[S::S_VF + 1] = myax[1]; SCR[S::S_VF + 2] = myax[2]; }
-      ODK_SYNC();
-      const float ax[3] = {SCR[S::S_VF], SCR[S::S_VF + 1], SCR[S::S_VF + 2]};
-      // penetrating: hull 1's support plane along the axis vs the deepest vertices of hull 2
-      const float p1 = (lane < n1) ? dot3(VW + lane * 3, ax) : -3.0e38f;
-      const float max1 = gmax<G>(p1);
-      const bool has2 = lane < n2;
-      const float sup2 = has2 ? max1 - dot3(w2, ax) : -3.0e38f;
-      int idx[4];
-      select4<G>(w2, has2, sup2, n2, ax, idx, lane);
-      const bool pen = overlap && !(hsep > 0.0f);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        bool uniq = true;
-        for (int q = 0; q < k; q++) uniq = uniq && (idx[q] != idx[k]);
-        const int c = 8 + k;
-        if (pen && lane == idx[k]) {
-          const float dist = uniq ? -sup2 : 1.0f;
-          CDIST[c] = dist;
-          for (int t = 0; t < 3; t++) CR[3 * c + t] = w2[t] - 0.5f * dist * ax[t] - ref[t];
-        }
-        if (overlap && !pen && lane == 0) CDIST[c] = k == 0 ? hsep : 1.0f;
-      }
-      if (overlap && lane == 0) {
-        SCR[S::S_MISC] = hsep;
-        // contact frame (make_frame): normal, then a tangent from the less aligned of y / z
-        float b[3] = {0, 0, 0}, cc[3];
-        if (fabsf(ax[1]) < 0.5f) b[1] = 1.0f; else b[2] = 1.0f;
-        const float dtb = dot3(ax, b);
-        b[0] -= dtb * ax[0]; b[1] -= dtb * ax[1]; b[2] -= dtb * ax[2];
-        const float nb = sqrtf(dot3(b, b));
-        b[0] /= nb; b[1] /= nb; b[2] /= nb;
-        cross3(cc, ax, b);
-        for (int t = 0; t < 3; t++) { SCR[S::S_VF + 3 + t] = b[t]; SCR[S::S_VF + 6 + t] = cc[t]; }
-      }
+  ODK_SYNC();
+  Cvx A = {FVb, FVb + 102, &m->foot_poly[0][0][0], &m->foot_edge[0][0][0], m->foot_nvert[0], m->foot_npoly[0], m->foot_nedge[0], {cw[0][0], cw[0][1], cw[0][2]}};
+  Cvx B = {FVb + 51, FVb + 192, &m->foot_poly[1][0][0], &m->foot_edge[1][0][0], m->foot_nvert[1], m->foot_npoly[1], m->foot_nedge[1], {cw[1][0], cw[1][1], cw[1][2]}};
+  EdgeRegs<3> RB;
+  edge_regs_load<3>(RB, B, j);
+  edge_prepare_row(A, AE, j, row == 0);
+  ODK_SYNC();
+  RowScratch RSS = {RS, RS + 12, RS + 24};
+  sat_pair_row<3>(A, B, AE, RB, RSS, j, row == 0);
+  if (act && j < 4) {
+    const float* o = RS + 24 + 7 * j;
+    const int c = 8 + j;
+    CDIST[c] = o[0];
+    for (int t = 0; t < 3; t++) CR[3 * c + t] = o[1 + t] - ref[t];
+    if (j == 0) make_frame_dev(o + 4, SCR + S::S_VF);   // the pair's contact frame (one normal for all four), consumed by P8
+  }
+}
+
+// Height-field floor (scene_rough_terrain_backlash.xml:22): mjx hfield_convex -- the prisms of the cells under the foot's bounding
+// sphere, convex_convex per prism, the four deepest contacts kept, each with the normal of its own prism test (odk_convex.h).
+// Foot f = 16-lane row f of the env.  A prism whose own faces already separate it from the foot (face query of the prism
+// against the hull's vertices > 0) cannot contribute an active contact (MJX reports dist > 0 for it) and is dropped before the
+// pair loop; the loop runs over each row's surviving prisms, as many iterations as the longest list in the wave.
+// The prism of an iteration lives in registers (compile-time topology: sat_prism_row); the hull's faces and edges of a lane stay in
+// registers over the whole loop.  LDS: hull vertices / face normals in the height field's frame in cfrc | crb; per row the prism's
+// vertices + the two polygons of the face contact in BUF6 / BUF6B; per row prism list, running best four, current four in
+// D | aref | jar | jv; at the end the eight contact frames go to jv ([8][9], read by the constraint-row phase).
+template <class S, int G>
+__device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __restrict__ m, const float* __restrict__ hf, int lane) {
+  constexpr int NB = S::NB;
+  static_assert(G == 32, "height-field floors run 32 lanes per env (two 16-lane rows = two feet)");
+  static_assert(4 * S::NROW >= 344 && 16 * S::NB >= 282 && 6 * S::NVR >= 42 && S::NROW >= 72, "height-field scratch does not fit");
+  float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR;
+  const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
+  const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
+  const int f = (lane >> 4) & 1, j = lane & 15;
+  float* FV = L + S::O_CFRC + f * 51; float* FN = L + S::O_CFRC + 102 + f * 90;
+  float* RS = L + (f ? S::O_BUF6B : S::O_BUF6);
+  float* PV = RS;                                                      // prism vertices [6][3]
+  float* RL = L + S::O_D + f * 172;
+  float* LIST = RL; float* TOP = RL + 108; float* NEW = RL + 136;      // [18][6] | [4][7] | [4][7]
+  const RowScratch RSS = {RS + 18, RS + 30, NEW};                      // RP [4][3], IP [4][3]
+  const float* Rh = m->floor_mat; const float ph[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
+  // ---- the hull in the height field's frame: v_h = Rh^T (P + R v - ph)
+  float Rw[9], Pw[3], cl[3];
+  {
+    const int fb = m->foot_body[f];
+    float q[4], R[9], P[3];
+    for (int k = 0; k < 4; k++) q[k] = XQUAT[k * NB + fb];
+    for (int k = 0; k < 3; k++) P[k] = XPOS[k * NB + fb] - ph[k];
+    q2mat(R, q);
+    for (int a = 0; a < 3; a++) {
+      for (int b = 0; b < 3; b++) Rw[3 * a + b] = Rh[a] * R[b] + Rh[3 + a] * R[3 + b] + Rh[6 + a] * R[6 + b];
+      Pw[a] = Rh[a] * P[0] + Rh[3 + a] * P[1] + Rh[6 + a] * P[2];
     }
   }
+  const int nvt = m->foot_nvert[f], nfc = m->foot_npoly[f];
+  for (int v = j; v < nvt; v += 16) {
+    const float vb[3] = {m->foot_vert[f][v][0], m->foot_vert[f][v][1], m->foot_vert[f][v][2]};
+    for (int k = 0; k < 3; k++) FV[3 * v + k] = Pw[k] + Rw[3 * k] * vb[0] + Rw[3 * k + 1] * vb[1] + Rw[3 * k + 2] * vb[2];
+  }
+  for (int t = j; t < nfc; t += 16) {
+    const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
+    for (int k = 0; k < 3; k++) FN[3 * t + k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2];
+  }
+  float fc[3];
+  for (int k = 0; k < 3; k++) {
+    cl[k] = Pw[k] + Rw[3 * k] * m->foot_obb_center[f][0] + Rw[3 * k + 1] * m->foot_obb_center[f][1] + Rw[3 * k + 2] * m->foot_obb_center[f][2];
+    fc[k] = Pw[k] + Rw[3 * k] * m->foot_centroid[f][0] + Rw[3 * k + 1] * m->foot_centroid[f][1] + Rw[3 * k + 2] * m->foot_centroid[f][2];
+  }
+  if (j < 4) { float* o = TOP + 7 * j; o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f; }
+  ODK_SYNC();
+  // ---- cells under the bounding sphere
+  const int nc = m->hfield_ncol, nr = m->hfield_nrow;
+  const float sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2], base = m->hfield_size[3];
+  const float dx = 2.0f * sx / (float)(nc - 1), dy = 2.0f * sy / (float)(nr - 1);
+  const float rad = sqrtf(dot3(m->foot_obb_half[f], m->foot_obb_half[f]));
+  int cmin = (int)floorf((cl[0] - rad + sx) / dx), cmax = (int)floorf((cl[0] + rad + sx) / dx);
+  int rmin = (int)floorf((cl[1] - rad + sy) / dy), rmax = (int)floorf((cl[1] + rad + sy) / dy);
+  cmin = cmin < 0 ? 0 : cmin; rmin = rmin < 0 ? 0 : rmin; cmax = cmax > nc - 2 ? nc - 2 : cmax; rmax = rmax > nr - 2 ? nr - 2 : rmax;
+  int ncw = cmax - cmin + 1, nrw = rmax - rmin + 1;
+  ncw = ncw > 3 ? 3 : ncw; nrw = nrw > 3 ? 3 : nrw;   // the sphere (radius < a cell) spans at most 3 cells per axis
+  const float idiag = 1.0f / sqrtf(dx * dx + dy * dy);
+  // prism p = 2 (ri ncw + ci) + tri of this row's window: grid corners of its top triangle (counter-clockwise seen from above)
+  auto corners = [&](int p, int* cc, int* rr) {
+    const int q = p >> 1, tri = p & 1;
+    const int ri = ncw == 1 ? q : (ncw == 2 ? (q >> 1) : (q >= 6 ? 2 : (q >= 3 ? 1 : 0)));
+    const int c = cmin + q - ri * ncw, r = rmin + ri;
+    cc[0] = tri ? c + 1 : c; rr[0] = tri ? r + 1 : r; cc[1] = tri ? c : c + 1; rr[1] = tri ? r + 1 : r; cc[2] = tri ? c + 1 : c; rr[2] = tri ? r : r + 1;
+  };
+  auto prism = [&](int p, const float* z, Prism& P) {
+    int cc[3], rr[3];
+    corners(p, cc, rr);
+    for (int k = 0; k < 3; k++) { P.x[k] = -sx + (float)cc[k] * dx; P.y[k] = -sy + (float)rr[k] * dy; P.z[k] = z[k]; }
+    P.base = base;
+    const float e1[3] = {P.x[1] - P.x[0], P.y[1] - P.y[0], P.z[1] - P.z[0]}, e2[3] = {P.x[2] - P.x[0], P.y[2] - P.y[0], P.z[2] - P.z[0]};
+    cross3(P.nt, e1, e2);
+    const float inv = 1.0f / sqrtf(dot3(P.nt, P.nt));
+    P.nt[0] *= inv; P.nt[1] *= inv; P.nt[2] *= inv;
+    // side over the edge a -> b of the top triangle: (e.y, -e.x, 0) / |e|; the edges run along x, the diagonal, along y
+    const float sg = (p & 1) ? -1.0f : 1.0f;
+    P.ns[0][0] = 0.0f; P.ns[0][1] = -sg;
+    P.ns[1][0] = sg * dy * idiag; P.ns[1][1] = sg * dx * idiag;
+    P.ns[2][0] = -sg; P.ns[2][1] = 0.0f;
+  };
+  // ---- pass over the window, lane = prism: the prism's own face query against the hull vertices; survivors into the list
+  int cnt = 0;
+  const int nprism = (ncw > 0 && nrw > 0) ? 2 * ncw * nrw : 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const int p = 16 * pass + j;
+    const bool valid = p < nprism;
+    if (__builtin_amdgcn_ballot_w64(valid) == 0) break;
+    float z[3] = {0.0f, 0.0f, 0.0f};
+    if (valid) { int cc[3], rr[3]; corners(p, cc, rr); for (int k = 0; k < 3; k++) z[k] = hf[rr[k] * nc + cc[k]] * sz; }
+    Prism P;
+    prism(valid ? p : 0, z, P);
+    // plane offsets n . v0 of the five faces (v0: vertex 0 / 3 / 0 / 1 / 2), then min over the hull's vertices of n . v - offset
+    float d5[5], s5[5] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+    d5[0] = P.nt[0] * P.x[0] + P.nt[1] * P.y[0] + P.nt[2] * P.z[0]; d5[1] = base;
+    d5[2] = P.ns[0][0] * P.x[0] + P.ns[0][1] * P.y[0]; d5[3] = P.ns[1][0] * P.x[1] + P.ns[1][1] * P.y[1]; d5[4] = P.ns[2][0] * P.x[2] + P.ns[2][1] * P.y[2];
+    for (int q = 0; q < nvt; q++) {
+      const float v[3] = {FV[3 * q], FV[3 * q + 1], FV[3 * q + 2]};
+      s5[0] = fminf(s5[0], dot3(P.nt, v)); s5[1] = fminf(s5[1], -v[2]);
+      s5[2] = fminf(s5[2], P.ns[0][0] * v[0] + P.ns[0][1] * v[1]); s5[3] = fminf(s5[3], P.ns[1][0] * v[0] + P.ns[1][1] * v[1]);
+      s5[4] = fminf(s5[4], P.ns[2][0] * v[0] + P.ns[2][1] * v[1]);
+    }
+    float sep = -3.0e38f; int face = 0;
+#pragma unroll
+    for (int fa = 0; fa < 5; fa++) { const float sv = s5[fa] - d5[fa]; if (sv > sep) { sep = sv; face = fa; } }
+    const bool keep = valid && !(sep > 0.0f);
+    const unsigned rowmask = (unsigned)((__builtin_amdgcn_ballot_w64(keep) >> (threadIdx.x & 48u)) & 0xFFFFull);
+    const int pos = cnt + __popc(rowmask & ((1u << j) - 1u));
+    if (keep) { float* o = LIST + 6 * pos; o[0] = __int_as_float(p); o[1] = z[0]; o[2] = z[1]; o[3] = z[2]; o[4] = sep; o[5] = __int_as_float(face); }
+    cnt += __popc(rowmask);
+  }
+  ODK_SYNC();
+  const Cvx B = {FV, FN, &m->foot_poly[f][0][0], &m->foot_edge[f][0][0], nvt, nfc, m->foot_nedge[f], {fc[0], fc[1], fc[2]}};
+  EdgeRegs<3> RB;
+  edge_regs_load<3>(RB, B, j);
+  FaceRegs<2> FB;
+  face_regs_load<2>(FB, B, j);
+  // ---- pair loop
+#pragma unroll 1
+  for (int k = 0; __builtin_amdgcn_ballot_w64(k < cnt) != 0; k++) {
+    const bool act = k < cnt;
+    const float* en = LIST + 6 * (act ? k : 0);
+    const int p = act ? __float_as_int(en[0]) : 0;
+    const float z[3] = {en[1], en[2], en[3]};
+    const float sep_a = en[4]; const int face_a = act ? __float_as_int(en[5]) : 0;
+    Prism P;
+    prism(p, z, P);
+    {   // lane j < 6 writes vertex j for the polygon fetch (selects, no per-lane indexing of register arrays: that is scratch)
+      const int t = j < 3 ? j : j - 3;
+      const float vx = t == 0 ? P.x[0] : (t == 1 ? P.x[1] : P.x[2]), vy = t == 0 ? P.y[0] : (t == 1 ? P.y[1] : P.y[2]);
+      const float vz = j >= 3 ? -base : (j == 0 ? z[0] : (j == 1 ? z[1] : z[2]));
+      if (act && j < 6) { PV[3 * j] = vx; PV[3 * j + 1] = vy; PV[3 * j + 2] = vz; }
+    }
+    const float pc[3] = {(P.x[0] + P.x[1] + P.x[2]) * (1.0f / 3.0f), (P.y[0] + P.y[1] + P.y[2]) * (1.0f / 3.0f), (z[0] + z[1] + z[2] - 3.0f * base) * (1.0f / 6.0f)};
+    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act);
+    merge_top4_row(TOP, NEW, j, act);
+  }
+  // ---- the best four: contact distance, position (relative to the base origin), frame; back in the world frame
+  float out[7];
+  for (int k = 0; k < 7; k++) out[k] = TOP[7 * (j & 3) + k];
+  ODK_SYNC();
+  if (j < 4) {
+    const int c = 4 * f + j;
+    float pw[3], nw[3];
+    for (int a = 0; a < 3; a++) {
+      pw[a] = ph[a] + Rh[3 * a] * out[1] + Rh[3 * a + 1] * out[2] + Rh[3 * a + 2] * out[3];
+      nw[a] = Rh[3 * a] * out[4] + Rh[3 * a + 1] * out[5] + Rh[3 * a + 2] * out[6];
+    }
+    CDIST[c] = out[0];
+    for (int t = 0; t < 3; t++) CR[3 * c + t] = pw[t] - ref[t];
+    make_frame_dev(nw, L + S::O_JV + 9 * c);
+  }
+}
 
 template <class S, int G, bool HF>
 __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags) {
@@ -1481,8 +1572,11 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     for (int k = 0; k < 3; k++) fP[f][k] = XPOS[k * NB + fb];
     q2mat(fR[f], q);
   }
+  if constexpr (HF) {
+    // height-field floor (rough terrain; its own kernel instantiation): prisms of the cells under each foot, out of line
+    hfield_contacts<S, G>(L, m, hfield, lane);
+  } else {
   const float pn0[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
-  constexpr bool flat = !HF;   // plane floor, or height field (rough terrain; its own kernel instantiation)
   {
     // both feet at once: foot f = 16-lane row f of the env's lanes (vertices 0..15), the 17th vertex rides along in every lane
     const int f = (lane >> 4) & 1, j = lane & 15;
@@ -1495,21 +1589,6 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     for (int k = 0; k < 9; k++) Rf[k] = f ? fR[1][k] : fR[0][k];
 #pragma unroll
     for (int k = 0; k < 3; k++) Pf[k] = f ? fP[1][k] : fP[0][k];
-    if (!flat) {   // terrain under this foot := plane of the height-field triangle below the hull's box centre (oracle hfield_convex)
-      float cw[3];
-      for (int k = 0; k < 3; k++) cw[k] = Pf[k] + Rf[3 * k] * m->foot_obb_center[f][0] + Rf[3 * k + 1] * m->foot_obb_center[f][1] + Rf[3 * k + 2] * m->foot_obb_center[f][2];
-      hfield_plane(m, hfield, cw, pp, pn);
-      if (inrow && j == 0) {   // contact frame of this pair (make_frame), consumed by P8
-        float b[3] = {0, 0, 0}, cc[3];
-        if (fabsf(pn[1]) < 0.5f) b[1] = 1.0f; else b[2] = 1.0f;
-        const float dtb = dot3(pn, b);
-        b[0] -= dtb * pn[0]; b[1] -= dtb * pn[1]; b[2] -= dtb * pn[2];
-        const float nb = sqrtf(dot3(b, b));
-        b[0] /= nb; b[1] /= nb; b[2] /= nb;
-        cross3(cc, pn, b);
-        for (int t = 0; t < 3; t++) { SCR[S::S_K + 9 * f + t] = pn[t]; SCR[S::S_K + 9 * f + 3 + t] = b[t]; SCR[S::S_K + 9 * f + 6 + t] = cc[t]; }
-      }
-    }
     float w[3] = {0, 0, 0}, we[3] = {0, 0, 0}, sup = -3.0e38f, supe = -3.0e38f;
     {
       const int jv = has ? j : 0;
@@ -1539,6 +1618,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         for (int t = 0; t < 3; t++) CR[3 * c + t] = (ext ? we[t] : w[t]) - 0.5f * dist * pn[t] - ref[t];
       }
     }
+  }
   }
   ODK_PROF(7);
   // foot-foot: bounding spheres first (a positive gap already means "inactive pair"); only when the spheres of some env
@@ -1644,8 +1724,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     const float dist = CDIST[c];
     const float mu = CT[pair];
     const float fs = (s & 1) ? -mu : mu;
-    // foot-foot frame: left in S_VF by the SAT routine; height-field floor: per-foot frames left in S_K by P7
-    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && HF) ? SCR + S::S_K + 9 * pair : CT + 33);
+    // foot-foot frame: left in S_VF by the SAT routine; height-field floor: one frame per contact left in the jv rows by P7
+    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && HF) ? L + S::O_JV + 9 * c : CT + 33);
     const int td = 3 * (1 + (s >> 1));
     const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
     const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};

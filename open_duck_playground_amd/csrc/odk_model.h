@@ -13,6 +13,7 @@ constexpr int MAXU = 16;     // actuators
 constexpr int MAXNZ = 512;   // sparse matrix entries
 constexpr int MAXHV = 20;    // hull vertices per foot
 constexpr int MAXHF = 40;    // hull faces per foot
+constexpr int MAXHE = 64;    // unique hull edges per foot
 constexpr int MAXCHAIN = 8;
 constexpr int MAXSITE = 8;
 constexpr int MAXSENS = 16;
@@ -117,6 +118,16 @@ struct DevModel {
   float foot_vert[2][MAXHV][3];  // hull vertices in the BODY frame (geom pos/quat folded in)
   int foot_face[2][MAXHF][3];
   float foot_obb_center[2][3], foot_obb_half[2][3], foot_obb_axes[2][9];  // body-frame OBB (columns = axes)
+  // convex-convex narrow phase (odk_convex.h): face polygons after the coplanar merge (count, then <= 4 vertices counter-clockwise
+  // seen from outside), their outward normals in the BODY frame, unique edges (va, vb, face running va -> vb, face running
+  // vb -> va), an interior point; built at load (odk_engine.hip build_foot_convex).  prism_*: the same tables for a height-field
+  // prism (vertices 0..2 top, 3..5 bottom; faces: top, bottom, sides 0-1, 1-2, 2-0).
+  int foot_npoly[2], foot_nedge[2];
+  int foot_poly[2][MAXHF][5];
+  float foot_fnorm[2][MAXHF][3];
+  int foot_edge[2][MAXHE][4];
+  float foot_centroid[2][3];
+  int prism_poly[5][5], prism_edge[9][4];
   float plane_pos[3], plane_n[3], plane_frame[9];
   int floor_is_plane;
   // height-field floor (rough terrain): geom frame = (plane_pos, floor_mat); samples live in HBM (KArgs.hfield)
