@@ -141,13 +141,13 @@ __device__ __forceinline__ void manifold4_row(const float* p, bool cand, bool ma
   float amb[3], ab[3];
   sub3(amb, a, b);
   cross3(ab, n, amb);
-  idx[2] = row_argmax(cand ? fabsf(dot3(ap, ab)) + dm : -3.0e38f, j, vm);
+  idx[2] = row_argmax(cand ? area0(fabsf(dot3(ap, ab))) + dm : -3.0e38f, j, vm);
   for (int k = 0; k < 3; k++) c[k] = row_get(p[k], idx[2]);
   float amc[3], bmc[3], ac[3], bc[3], bp[3];
   sub3(amc, a, c); sub3(bmc, b, c);
   cross3(ac, n, amc); cross3(bc, n, bmc);
   sub3(bp, b, p);
-  const float v1 = fabsf(dot3(bp, bc)) + dm, v2 = fabsf(dot3(ap, ac)) + dm;
+  const float v1 = area0(fabsf(dot3(bp, bc))) + dm, v2 = area0(fabsf(dot3(ap, ac))) + dm;
   float vv = v1; int vi = j;
   if (v2 > v1) { vv = v2; vi = np + j; }
   if (!cand) { vv = -3.0e38f; vi = 2 * np + j; }
@@ -329,15 +329,14 @@ __device__ constexpr int PRISM_EDGE[9][4] = {{0, 1, 0, 2}, {1, 2, 0, 3}, {3, 5, 
 __device__ constexpr int PRISM_POLY[5][5] = {{3, 0, 1, 2, 0}, {3, 3, 5, 4, 3}, {4, 0, 3, 4, 1}, {4, 1, 4, 5, 2}, {4, 2, 5, 3, 0}};
 
 // the faces of the second polytope this lane owns (face j + 16 s): normal, plane offset n . v0, polygon packed 3 | 5 x 4 bits
-template <int NFS> struct FaceRegs { float n[NFS][3], d[NFS]; int poly[NFS]; bool on[NFS]; };
+template <int NFS> struct FaceRegs { float d[NFS]; int poly[NFS]; bool on[NFS]; };   // (the normals are re-read from LDS per pair: registers are the scarce resource)
 template <int NFS> __device__ __forceinline__ void face_regs_load(FaceRegs<NFS>& R, const Cvx& B, int j) {
 #pragma unroll
   for (int s = 0; s < NFS; s++) {
     const int f = j + 16 * s;
     R.on[s] = f < B.nf;
     const int* pl = B.poly + 5 * (R.on[s] ? f : 0);
-    ld3(R.n[s], B.N + 3 * (R.on[s] ? f : 0));
-    R.d[s] = dot3(B.V + 3 * pl[1], R.n[s]);
+    R.d[s] = dot3(B.V + 3 * pl[1], B.N + 3 * (R.on[s] ? f : 0));
     R.poly[s] = pl[0] | (pl[1] << 3) | (pl[2] << 8) | (pl[3] << 13) | (pl[4] << 18);
   }
 }
@@ -349,13 +348,16 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
                                               float sep_a, int face_a, const RowScratch& S, int j, bool act) {
   // ---- face query of the hull against the prism's six vertices
   float sep_b; int face_b;
+  float fn[NFS][3];   // this lane's hull face normals (slot s = face j + 16 s; lanes without a second face read face 0's)
+#pragma unroll
+  for (int s = 0; s < NFS; s++) ld3(fn[s], B.N + 3 * (FB.on[s] ? j + 16 * s : 0));
   {
     float best = -3.0e38f; int bi = 0x7FFFFFFF;
 #pragma unroll
     for (int s = 0; s < NFS; s++) {
       float smin = 3.0e38f;
 #pragma unroll
-      for (int q = 0; q < 6; q++) { float v[3]; prism_vert(P, q, v); smin = fminf(smin, dot3(v, FB.n[s]) - FB.d[s]); }
+      for (int q = 0; q < 6; q++) { float v[3]; prism_vert(P, q, v); smin = fminf(smin, dot3(v, fn[s]) - FB.d[s]); }
       if (FB.on[s] && smin > best) { best = smin; bi = j + 16 * s; }
     }
     face_b = row_argmax(best, bi, sep_b);
@@ -426,15 +428,15 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
     n_ref[2] = face_a == 0 ? P.nt[2] : (face_a == 1 ? -1.0f : 0.0f);
     float best = -3.0e38f, vm; int bi = 0x7FFFFFFF;
 #pragma unroll
-    for (int s = 0; s < NFS; s++) { const float sc = -dot3(FB.n[s], n_ref); if (FB.on[s] && sc > best) { best = sc; bi = j + 16 * s; } }
+    for (int s = 0; s < NFS; s++) { const float sc = -dot3(fn[s], n_ref); if (FB.on[s] && sc > best) { best = sc; bi = j + 16 * s; } }
     int inc = row_argmax(best, bi, vm);
     inc = (unsigned)inc < (unsigned)B.nf ? inc : 0;
     const int sl = inc >> 4;
-    for (int k = 0; k < 3; k++) n_inc[k] = row_get(sl == 0 ? FB.n[0][k] : FB.n[NFS - 1][k], inc & 15);
+    ld3(n_inc, B.N + 3 * inc);
     pf_pk = __float_as_int(row_get(__int_as_float(sl == 0 ? FB.poly[0] : FB.poly[NFS - 1]), inc & 15));
   } else {
     const int sl = face_b >> 4;
-    for (int k = 0; k < 3; k++) n_ref[k] = row_get(sl == 0 ? FB.n[0][k] : FB.n[NFS - 1][k], face_b & 15);
+    ld3(n_ref, B.N + 3 * face_b);
     pf_pk = __float_as_int(row_get(__int_as_float(sl == 0 ? FB.poly[0] : FB.poly[NFS - 1]), face_b & 15));
     float best = 3.0e38f; pa_f = 0;   // most anti-parallel prism face, first minimum
 #pragma unroll

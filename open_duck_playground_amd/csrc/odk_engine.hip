@@ -669,7 +669,11 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   if (live) {
     // record store addresses recomputed here (opaque offset) instead of being shared with the prologue's loads and
     // carried across the substep loop: 69 64-bit per-lane pointers = 138 scratch dwords otherwise
-    float* rco = reinterpret_cast<float*>(reinterpret_cast<char*>(rc) + opaque1);
+    // (the env index is made opaque as well: the 64-bit record offset is then one multiply-add here instead of a value the
+    // register allocator carries from the prologue -- in scratch, in the height-field kernel)
+    int e_out = e;
+    asm volatile("" : "+v"(e_out));
+    float* rco = reinterpret_cast<float*>(reinterpret_cast<char*>(a.recs + (size_t)e_out * R::SIZE) + opaque1);
     for (int i = lane; i < S::NQ + 2 * S::NV; i += G) rco[i] = L[S::O_QPOS + i];
     for (int k = lane; k < rec::NINFO; k += G) rco[R::INFO + k] = INFO[k];
     write_outputs<S, G>(a, L, env, reward, done_f, trunc, metrics, lane);

@@ -777,6 +777,9 @@ __device__ __forceinline__ void row_params(const float* P, float pos, float invw
 //   flags bit0: compute sensordata / debug outputs (last substep only)
 // mjx collision_convex._manifold_points: 4 support points of approximately maximal area among the vertices within
 // 1e-3 of the deepest one (lane = vertex; `n` = contact normal)
+// area measures below 1e-7 m^2 count as zero (oracle manifold_points AREA0: collinear / coincident candidates tie like in exact
+// arithmetic instead of by rounding residue)
+__device__ __forceinline__ float area0(float v) { return v < 1e-7f ? 0.0f : v; }
 template <int G>
 __device__ __forceinline__ void select4(const float* w, bool has, float sup, int nvt, const float* n, int* idx, int lane) {
   const float smax = gmax<G>(sup);
@@ -789,13 +792,13 @@ __device__ __forceinline__ void select4(const float* w, bool has, float sup, int
   float bq[3] = {__shfl(w[0], idx[1], G), __shfl(w[1], idx[1], G), __shfl(w[2], idx[1], G)};
   float amb[3] = {a[0] - bq[0], a[1] - bq[1], a[2] - bq[2]}, ab[3];
   cross3(ab, n, amb);
-  idx[2] = gargmax<G>(has ? fabsf(dot3(ap, ab)) + dm : -3.0e38f, lane);
+  idx[2] = gargmax<G>(has ? area0(fabsf(dot3(ap, ab))) + dm : -3.0e38f, lane);
   float cq[3] = {__shfl(w[0], idx[2], G), __shfl(w[1], idx[2], G), __shfl(w[2], idx[2], G)};
   float amc[3] = {a[0] - cq[0], a[1] - cq[1], a[2] - cq[2]}, bmc[3] = {bq[0] - cq[0], bq[1] - cq[1], bq[2] - cq[2]}, ac[3], bc[3];
   cross3(ac, n, amc);
   cross3(bc, n, bmc);
   float bp[3] = {bq[0] - w[0], bq[1] - w[1], bq[2] - w[2]};
-  float v1 = fabsf(dot3(bp, bc)) + dm, v2 = fabsf(dot3(ap, ac)) + dm;
+  float v1 = area0(fabsf(dot3(bp, bc))) + dm, v2 = area0(fabsf(dot3(ap, ac))) + dm;
   float vv = v1; int vi = lane;
   if (v2 > v1) { vv = v2; vi = nvt + lane; }
   if (!has) { vv = -3.0e38f; vi = 2 * nvt + lane; }
@@ -846,7 +849,7 @@ __device__ __forceinline__ void select4_rows(const float* w, bool has, float sup
   const float amb[3] = {a[0] - bq[0], a[1] - bq[1], a[2] - bq[2]};
   float ab[3];
   cross3(ab, n, amb);
-  idx[2] = amax(has ? fabsf(dot3(ap, ab)) + dm : -3.0e38f, j, has_e ? fabsf(dot3(ape, ab)) + dme : -3.0e38f, 16);
+  idx[2] = amax(has ? area0(fabsf(dot3(ap, ab))) + dm : -3.0e38f, j, has_e ? area0(fabsf(dot3(ape, ab))) + dme : -3.0e38f, 16);
   float cq[3];
   fetch(idx[2], cq);
   const float amc[3] = {a[0] - cq[0], a[1] - cq[1], a[2] - cq[2]}, bmc[3] = {bq[0] - cq[0], bq[1] - cq[1], bq[2] - cq[2]};
@@ -855,7 +858,7 @@ __device__ __forceinline__ void select4_rows(const float* w, bool has, float sup
   cross3(bc, n, bmc);
   auto last = [&](const float* x, const float* apx, float dmx, bool hx, int ix, float& vv, int& vi) {
     const float bp[3] = {bq[0] - x[0], bq[1] - x[1], bq[2] - x[2]};
-    const float v1 = fabsf(dot3(bp, bc)) + dmx, v2 = fabsf(dot3(apx, ac)) + dmx;
+    const float v1 = area0(fabsf(dot3(bp, bc))) + dmx, v2 = area0(fabsf(dot3(apx, ac))) + dmx;
     vv = v1; vi = ix;
     if (v2 > v1) { vv = v2; vi = nvt + ix; }
     if (!hx) { vv = -3.0e38f; vi = 2 * nvt + ix; }
@@ -964,21 +967,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     }
   }
   const int nvt = m->foot_nvert[f], nfc = m->foot_npoly[f];
-  for (int v = j; v < nvt; v += 16) {
-    const float vb[3] = {m->foot_vert[f][v][0], m->foot_vert[f][v][1], m->foot_vert[f][v][2]};
-    for (int k = 0; k < 3; k++) FV[3 * v + k] = Pw[k] + Rw[3 * k] * vb[0] + Rw[3 * k + 1] * vb[1] + Rw[3 * k + 2] * vb[2];
-  }
-  for (int t = j; t < nfc; t += 16) {
-    const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
-    for (int k = 0; k < 3; k++) FN[3 * t + k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2];
-  }
-  float fc[3];
-  for (int k = 0; k < 3; k++) {
-    cl[k] = Pw[k] + Rw[3 * k] * m->foot_obb_center[f][0] + Rw[3 * k + 1] * m->foot_obb_center[f][1] + Rw[3 * k + 2] * m->foot_obb_center[f][2];
-    fc[k] = Pw[k] + Rw[3 * k] * m->foot_centroid[f][0] + Rw[3 * k + 1] * m->foot_centroid[f][1] + Rw[3 * k + 2] * m->foot_centroid[f][2];
-  }
-  if (j < 4) { float* o = TOP + 7 * j; o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f; }
-  ODK_SYNC();
+  for (int k = 0; k < 3; k++) cl[k] = Pw[k] + Rw[3 * k] * m->foot_obb_center[f][0] + Rw[3 * k + 1] * m->foot_obb_center[f][1] + Rw[3 * k + 2] * m->foot_obb_center[f][2];
   // ---- cells under the bounding sphere
   const int nc = m->hfield_ncol, nr = m->hfield_nrow;
   const float sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2], base = m->hfield_size[3];
@@ -989,18 +978,34 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   cmin = cmin < 0 ? 0 : cmin; rmin = rmin < 0 ? 0 : rmin; cmax = cmax > nc - 2 ? nc - 2 : cmax; rmax = rmax > nr - 2 ? nr - 2 : rmax;
   int ncw = cmax - cmin + 1, nrw = rmax - rmin + 1;
   ncw = ncw > 3 ? 3 : ncw; nrw = nrw > 3 ? 3 : nrw;   // the sphere (radius < a cell) spans at most 3 cells per axis
+  // Everything below works relative to the window's first grid corner: the terrain spans +-10 m, a contact depth is a fraction of
+  // a millimetre, and float32 coordinates in the height field's own frame would carry ~1e-6 m of rounding each.
+  const float org[2] = {-sx + (float)cmin * dx, -sy + (float)rmin * dy};
+  Pw[0] -= org[0]; Pw[1] -= org[1];
+  for (int v = j; v < nvt; v += 16) {
+    const float vb[3] = {m->foot_vert[f][v][0], m->foot_vert[f][v][1], m->foot_vert[f][v][2]};
+    for (int k = 0; k < 3; k++) FV[3 * v + k] = Pw[k] + Rw[3 * k] * vb[0] + Rw[3 * k + 1] * vb[1] + Rw[3 * k + 2] * vb[2];
+  }
+  for (int t = j; t < nfc; t += 16) {
+    const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
+    for (int k = 0; k < 3; k++) FN[3 * t + k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2];
+  }
+  float fc[3];
+  for (int k = 0; k < 3; k++) fc[k] = Pw[k] + Rw[3 * k] * m->foot_centroid[f][0] + Rw[3 * k + 1] * m->foot_centroid[f][1] + Rw[3 * k + 2] * m->foot_centroid[f][2];
+  if (j < 4) { float* o = TOP + 7 * j; o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f; }
+  ODK_SYNC();
   const float idiag = 1.0f / sqrtf(dx * dx + dy * dy);
   // prism p = 2 (ri ncw + ci) + tri of this row's window: grid corners of its top triangle (counter-clockwise seen from above)
   auto corners = [&](int p, int* cc, int* rr) {
     const int q = p >> 1, tri = p & 1;
     const int ri = ncw == 1 ? q : (ncw == 2 ? (q >> 1) : (q >= 6 ? 2 : (q >= 3 ? 1 : 0)));
-    const int c = cmin + q - ri * ncw, r = rmin + ri;
+    const int c = q - ri * ncw, r = ri;   // relative to (cmin, rmin)
     cc[0] = tri ? c + 1 : c; rr[0] = tri ? r + 1 : r; cc[1] = tri ? c : c + 1; rr[1] = tri ? r + 1 : r; cc[2] = tri ? c + 1 : c; rr[2] = tri ? r : r + 1;
   };
   auto prism = [&](int p, const float* z, Prism& P) {
     int cc[3], rr[3];
     corners(p, cc, rr);
-    for (int k = 0; k < 3; k++) { P.x[k] = -sx + (float)cc[k] * dx; P.y[k] = -sy + (float)rr[k] * dy; P.z[k] = z[k]; }
+    for (int k = 0; k < 3; k++) { P.x[k] = (float)cc[k] * dx; P.y[k] = (float)rr[k] * dy; P.z[k] = z[k]; }
     P.base = base;
     const float e1[3] = {P.x[1] - P.x[0], P.y[1] - P.y[0], P.z[1] - P.z[0]}, e2[3] = {P.x[2] - P.x[0], P.y[2] - P.y[0], P.z[2] - P.z[0]};
     cross3(P.nt, e1, e2);
@@ -1021,7 +1026,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     const bool valid = p < nprism;
     if (__builtin_amdgcn_ballot_w64(valid) == 0) break;
     float z[3] = {0.0f, 0.0f, 0.0f};
-    if (valid) { int cc[3], rr[3]; corners(p, cc, rr); for (int k = 0; k < 3; k++) z[k] = hf[rr[k] * nc + cc[k]] * sz; }
+    if (valid) { int cc[3], rr[3]; corners(p, cc, rr); for (int k = 0; k < 3; k++) z[k] = hf[(rmin + rr[k]) * nc + cmin + cc[k]] * sz; }
     Prism P;
     prism(valid ? p : 0, z, P);
     // plane offsets n . v0 of the five faces (v0: vertex 0 / 3 / 0 / 1 / 2), then min over the hull's vertices of n . v - offset
@@ -1077,7 +1082,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     const int c = 4 * f + j;
     float pw[3], nw[3];
     for (int a = 0; a < 3; a++) {
-      pw[a] = ph[a] + Rh[3 * a] * out[1] + Rh[3 * a + 1] * out[2] + Rh[3 * a + 2] * out[3];
+      pw[a] = ph[a] + Rh[3 * a] * (out[1] + org[0]) + Rh[3 * a + 1] * (out[2] + org[1]) + Rh[3 * a + 2] * out[3];
       nw[a] = Rh[3 * a] * out[4] + Rh[3 * a + 1] * out[5] + Rh[3 * a + 2] * out[6];
     }
     CDIST[c] = out[0];

@@ -473,7 +473,13 @@ static void make_frame(real* frame, const real* n) {
   v3_copy(frame, a); v3_copy(frame + 3, b); v3_copy(frame + 6, c);
 }
 
-/* mjx collision_convex._manifold_points: 4 points of approximately maximal area among masked */
+/* mjx collision_convex._manifold_points: 4 points of approximately maximal area among masked.
+ * [BUILD-DEFINED] AREA0: an area measure below 1e-7 m^2 counts as zero.  When the masked candidates are collinear or coincide
+ * (a clipped sliver, one surviving point: common between a foot and a height-field prism) every measure is zero in exact
+ * arithmetic and jp.argmax takes the first index; in floating point the zeros come out as +-1e-10 residues and the pick -- and
+ * with it how many of the four slots repeat which point, i.e. the weight of each contact -- would be rounding noise, different
+ * in float32 and float64.  With the threshold both resolve the tie like exact arithmetic does. */
+#define AREA0(v) ((v) < 1e-7 ? 0.0 : (v))
 static void manifold_points(const real (*poly)[3], const int* mask, int n, const real* norm, int* idx) {
   real dm[ODKO_MAXHV];
   int ai = 0, bi = 0, ci = 0, di = 0;
@@ -493,7 +499,7 @@ static void manifold_points(const real (*poly)[3], const int* mask, int n, const
   best = -1e30;
   for (int i = 0; i < n; i++) {
     real ap[3]; v3_sub(ap, a, poly[i]);
-    real v = fabs(v3_dot(ap, ab)) + dm[i];
+    real v = AREA0(fabs(v3_dot(ap, ab))) + dm[i];
     if (v > best) { best = v; ci = i; }
   }
   const real* c = poly[ci];
@@ -504,12 +510,12 @@ static void manifold_points(const real (*poly)[3], const int* mask, int n, const
   /* argmax over concat([dist_bp, dist_ap]) % n : first half (bp) wins ties */
   for (int i = 0; i < n; i++) {
     real bp[3]; v3_sub(bp, b, poly[i]);
-    real v = fabs(v3_dot(bp, bc)) + dm[i];
+    real v = AREA0(fabs(v3_dot(bp, bc))) + dm[i];
     if (v > best) { best = v; di = i; }
   }
   for (int i = 0; i < n; i++) {
     real ap[3]; v3_sub(ap, a, poly[i]);
-    real v = fabs(v3_dot(ap, ac)) + dm[i];
+    real v = AREA0(fabs(v3_dot(ap, ac))) + dm[i];
     if (v > best) { best = v; di = i; }
   }
   idx[0] = ai; idx[1] = bi; idx[2] = ci; idx[3] = di;
