@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the fused MI355X env step (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task T] [--lanes G] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--envs E] [--task T] [--lanes G] [--no-cpu-baseline]
+    python bench.py --mode ppo [--task flat_terrain_backlash] [--gpus N] [--steps K] [--warmup W]      (BASELINE configs 3 / 4 / 5)
 
 One "step" = one env step of every resident env: AutoReset/Episode wrappers + Joystick.step +
 10 x mjx.step + obs/reward, all inside one HIP kernel launch (reference joystick.py:323-481).
@@ -10,6 +11,13 @@ actions a ~ U(-1,1)^14 fresh every step, observation noise off, pushes off, imit
 auto-reset on.  Inputs (state, actions) are resident in HBM before the
 timed region.  Multi-GPU: one process per GPU (torchrun), envs sharded, no data-path collective
  -> weak scaling; timing = max over ranks between barriers.
+
+Default protocol = BASELINE.md section 4: 100 warm-up env steps, then 1 000 timed env steps, five times (`--reps`); `value` is the
+mean over the repetitions, every repetition bracketed by barrier + synchronize.
+
+`--mode ppo`: one "step" = one PPO training step of the reference's hyper-parameters (rollout of 20 env steps on every env with
+the policy in the loop + 128 clipped-Adam minibatch steps; with N > 1 ranks the flat gradient is all-reduced over RCCL in every
+minibatch step), domain randomisation on; `value` = env steps per second INCLUDING the learner.
 
 Prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`.
 """
@@ -48,47 +56,104 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(task: str, target_seconds: float = 12.0):
-    """Times the oracle's env step (the CPU restatement, kind='port') on all host cores of this box,
-    on a bounded sample of the same workload: same model, same protocol, fewer envs and steps."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+def _mujoco_baseline(task: str, cores: int, target_seconds: float):
+    """MuJoCo-C on the host cores, if the box has it -- one MjData per worker thread, env step = ctrl + 10 x
+    mj_step, random actions (mj_step releases the GIL).  Needs the reference's scene XML, which does not travel to the GPU box
+    unless ODK_MJCF points at a copy: returns None when either is missing."""
+    try:
+        import mujoco  # noqa: F401
+    except Exception as e:
+        return None, f"import mujoco failed ({type(e).__name__}: {e})"
+    xml = os.environ.get("ODK_MJCF")   # the build ships compiled models (assets/*.npz), not the reference's XML / STL tree
+    if not xml or not os.path.exists(xml):
+        return None, "mujoco is importable but the scene XML is not on this box (point ODK_MJCF at scene_flat_terrain.xml)"
+    import threading
     import numpy as np
+    m = mujoco.MjModel.from_xml_path(xml)
+    m.opt.timestep = 0.002                       # reference base.py:56
+    per_thread_envs = 16
+
+    def work(tid, nsteps, out):
+        rng = np.random.default_rng(tid)
+        ds = [mujoco.MjData(m) for _ in range(per_thread_envs)]
+        for d in ds:
+            mujoco.mj_resetDataKeyframe(m, d, 0)
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            for d in ds:
+                d.ctrl[:] = m.key_ctrl[0] + 0.25 * rng.uniform(-1, 1, m.nu)
+                for _s in range(10):
+                    mujoco.mj_step(m, d)
+        out[tid] = time.perf_counter() - t0
+
+    def run(nsteps):
+        out = [0.0] * cores
+        th = [threading.Thread(target=work, args=(t, nsteps, out)) for t in range(cores)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]; [t.join() for t in th]
+        return cores * per_thread_envs * nsteps / (time.perf_counter() - t0)
+
+    rate = run(5)
+    nsteps = max(5, int(rate * target_seconds / (cores * per_thread_envs)))
+    rate = run(nsteps)
+    return ({"value": round(rate, 1), "unit": "env-steps/s", "cores": cores, "kind": "mujoco-c",
+             "sample": f"mujoco {mujoco.__version__} mj_step x 10 per env step on {xml}, {cores} threads x {per_thread_envs} MjData x {nsteps} env steps, "
+                       "random actions; physics only (no observation / reward code)"}, "ok")
+
+
+def cpu_baseline(task: str, target_seconds: float = 12.0):
+    """CPU baseline beside the GPU number, on the cores the box grants this process:
+      1. MuJoCo-C through `import mujoco` when the box has it (kind = "mujoco-c");
+      2. otherwise the oracle's env step (own C restatement of the same step, kind = "port"), float32 build, rebuilt with
+         -march=native on the box when a compiler is there (flags stated in `sample`).
+    A bounded sample of the same workload: same model, same random-action protocol, fewer envs and steps."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    cores = usable_cores()
+    mj, why = None, "not tried"
+    try:
+        mj, why = _mujoco_baseline(task, cores, target_seconds)
+    except Exception as e:
+        why = f"mujoco baseline failed ({type(e).__name__}: {e})"
+    if mj is not None:
+        return mj
+    import subprocess
+    import tempfile
+    import numpy as np
+    flags = "gcc -O3 (shipped build, no -march: compiled in the build container)"
+    native = os.path.join(tempfile.gettempdir(), f"odk_oracle_f32_native_{os.getpid()}.so")
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native", f"OUT={native}"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=120)
+        os.environ["ODK_ORACLE_F32_LIB"] = native
+        flags = "gcc -O3 -march=native, compiled on this box"
+    except Exception:
+        pass
     import oracle as O
     from open_duck_playground_amd.model import load_task_model, asset_path
     model = load_task_model(task)
     z = np.load(asset_path("prm_table.npz"))
     prm_arrays = {k: z[k] for k in z.files}
-    # the float32 build of the oracle (-O3; the arithmetic type of the GPU path): ~3x the float64 checker build
+    # the float32 build of the oracle (the arithmetic type of the GPU path): ~3x the float64 checker build
     om = O.OracleModel(model.blob(), f32=True)
     prm = O.OraclePRM(prm_arrays, f32=True)
     L = O.lib(True)
-    cores = usable_cores()
     nenv = 16 * cores
     rate = L.lib.odko_rollout_mt(om.h, prm.h, nenv, 20, 5, cores, 0)          # calibration (~1 s)
     nsteps = max(20, int(rate * target_seconds / nenv))
     rate = L.lib.odko_rollout_mt(om.h, prm.h, nenv, nsteps, 10, cores, 0)
+    try:
+        os.remove(native)
+    except OSError:
+        pass
     return {"value": round(rate, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/odk_oracle*.c (C restatement of the same env step, float32 -O3 build), {nenv} envs x {nsteps} steps, "
+            "sample": f"oracle/odk_oracle*.c (C restatement of the same env step, float32, {flags}), {nenv} envs x {nsteps} steps, "
                       f"{cores} pthreads (= the cores the box grants this process: affinity mask and cgroup CPU quota; "
-                      f"{os.cpu_count()} logical CPUs visible), same random-action protocol"}
+                      f"{os.cpu_count()} logical CPUs visible), same random-action protocol.  MuJoCo-C: {why}"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--envs", type=int, default=8192, help="envs per GPU")
-    ap.add_argument("--task", default="flat_terrain")
-    ap.add_argument("--lanes", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
+def _init_dist():
     import torch
     import torch.distributed as dist
-    from open_duck_playground_amd import engine
-    from open_duck_playground_amd.model import load_task_model
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -105,7 +170,162 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists for the env engine)")
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    return rank, world, local_rank, torch.device("cuda", local_rank)
+
+
+def _clock_ramp(dev):
+    """the GPU's clock governor needs ~0.1 s of load to leave the idle state (a short region timed right after process start-up
+    runs 1.5 % slower than the steady state): 0.3 s of unrelated matrix products first; the timed steps stay exactly W + K"""
+    import torch
+    ramp = torch.randn(4096, 4096, device=dev)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.3:
+        torch.mm(ramp, ramp)
+        torch.cuda.synchronize()
+
+
+def _counters(task: str, envs: int):
+    """Per-launch counter figures of the dominant kernel from the committed PMC passes of the SAME command (rocprofv3 --pmc in
+    separate passes, profiles/README.md): HBM bytes, and the float32 operations behind `valu_frac`.  Counters cannot be read
+    from inside this process; the newest round that holds them wins, the source file is named in the output."""
+    if task != "flat_terrain" or envs != 8192:
+        return None, None, None
+    for rnd in ("r3", "r2"):
+        tpath = os.path.join(ROOT, "profiles", rnd, "traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            return t.get("hbm_bytes_per_launch"), t.get("valu_flop_per_launch"), f"profiles/{rnd}/traffic.json"
+    return None, None, None
+
+
+def main_ppo(args):
+    """BASELINE configs 3 / 4 (1 GPU) and 5 (N GPUs, envs sharded, flat gradient all-reduced over RCCL in each of the 128
+    minibatch steps): K full PPO training steps after W warm-up ones."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank, world, local_rank, dev = _init_dist()
+    from open_duck_playground_amd import joystick
+    from open_duck_playground_amd.ppo import train as T
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    task = args.task or "flat_terrain_backlash"
+    env = joystick.Joystick(task=task, num_envs=args.envs, device=local_rank, env_id_offset=rank * args.envs)
+    env.randomize(np.random.default_rng([0, rank, 0]))          # randomize.py domain randomisation, own draws per rank
+    cfg = T.ppo_config()
+    grp = dist.group.WORLD if world > 1 else None
+    torch.manual_seed(0)                                        # identical initial parameters on every rank
+    net = PPONetworks(env.observation_size["state"][0], env.observation_size["privileged_state"][0], env.action_size).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=cfg["learning_rate"], capturable=True)
+    gen = torch.Generator(device=dev); gen.manual_seed(1000 + rank)
+    state = env.reset(rank)
+    learner = None
+    steps, warmup = args.steps if args.steps is not None else 10, args.warmup if args.warmup is not None else 3
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def training_step(rec=None):
+        nonlocal state, learner
+        if rec: rec[0].record()
+        data, state = T.rollout(env, net, state, cfg["unroll_length"], gen)
+        if rec: rec[1].record()
+        net.norm_obs.update(data["obs"], grp); net.norm_priv.update(data["priv"], grp)
+        if learner is None:
+            learner = T.make_learner(net, data, cfg, world, grp)
+        T.sgd_epoch(net, opt, data, cfg, gen, world, grp, learner=learner, meter=T.LossMeter())
+        if rec: rec[2].record()
+        return data
+
+    _clock_ramp(dev)
+    for _ in range(max(warmup, 1)):      # (the first step builds the learner and captures its graphs: never timed)
+        training_step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        data = training_step(ev[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        T.assert_replicas_identical(net, grp)
+    rollout_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+    learner_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+    allreduce_ms = None
+    if world > 1:   # the collective alone, outside the timed region: 128 all-reduces of a gradient-sized buffer
+        n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
+        g = torch.zeros(n_par, device=dev)
+        for _ in range(8): dist.all_reduce(g)
+        torch.cuda.synchronize(); ta = time.perf_counter()
+        nsgd = cfg["num_minibatches"] * cfg["num_updates_per_batch"]
+        for _ in range(nsgd): dist.all_reduce(g)
+        torch.cuda.synchronize()
+        allreduce_ms = 1e3 * (time.perf_counter() - ta)
+    env_steps = world * args.envs * cfg["unroll_length"] * steps
+    if rank == 0:
+        nsgd = cfg["num_minibatches"] * cfg["num_updates_per_batch"]
+        # learner roofline (the training step's dominant part): f32 matrix-core work of the three whole-network kernels
+        mb = args.envs * cfg["unroll_length"] // cfg["num_minibatches"]
+        flop_step = 0.0
+        for dims in ((101, 512, 256, 128, 28), (212, 512, 256, 128, 1)):
+            flop_step += 3 * sum(2.0 * mb * a * b for a, b in zip(dims[:-1], dims[1:]))      # forward + backward-data + weight gradients
+        achieved = nsgd * flop_step / (learner_ms * 1e-3) / 1e12 if learner_ms > 0 else 0.0
+        out = {
+            "metric": METRIC, "value": round(env_steps / elapsed, 1), "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": max(warmup, 1),
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"full PPO (BASELINE config {'5' if world > 1 else ('4' if 'rough' in task else '3')}): open_duck_mini_v2 {task} + randomize.py domain "
+                                   f"randomisation, {args.envs} envs/GPU, one step = rollout of {cfg['unroll_length']} env steps with the policy in the loop + {nsgd} "
+                                   f"clipped-Adam minibatch steps of {mb} samples (reference hyper-parameters, common/runner.py:86-118); value counts env steps "
+                                   "per second INCLUDING the learner; noise, pushes, imitation reward, auto-reset on",
+                       "mode": "ppo", "envs_per_gpu": args.envs, "global_envs": args.envs * world, "unroll_length": cfg["unroll_length"],
+                       "sgd_steps_per_training_step": nsgd, "parallelism": f"env-sharded x{world}" + (", flat-gradient all-reduce (RCCL) per minibatch step" if world > 1 else ", no collective"),
+                       "rollout_ms_per_training_step": round(rollout_ms, 3), "learner_ms_per_training_step": round(learner_ms, 3),
+                       "allreduce_ms_per_training_step_isolated": None if allreduce_ms is None else round(allreduce_ms, 3),
+                       "learner_path": "fused whole-network kernels" if (learner is not None and getattr(learner, "fused", None) is not None) else "library GEMMs / autograd",
+                       "reward_per_step_last_rollout": round(float(data["reward"].mean()), 4)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
+                         "traffic": None, "kernel": "mlp_fwd_kernel + mlp_bwd_kernel + dw_gemm_kernel (learner, f32 matrix cores)",
+                         "note": "algorithmic FLOPs of the 128 minibatch steps / learner time (HIP events), incl. the element-wise launches between them; "
+                                 "peak = dense f32 MFMA"},
+        }
+        print(json.dumps(out), flush=True)
+    if learner is not None:
+        learner.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="physics", choices=["physics", "ppo"])
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="physics: env steps per repetition (default 1000); ppo: training steps (default 10)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 100 (physics) / 3 (ppo)")
+    ap.add_argument("--reps", type=int, default=None, help="physics: repetitions of the K timed steps, value = mean (default 5; 1 when --steps is given)")
+    ap.add_argument("--envs", type=int, default=8192, help="envs per GPU")
+    ap.add_argument("--task", default=None)
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.mode == "ppo":
+        return main_ppo(args)
+    args.task = args.task or "flat_terrain"
+    if args.reps is None:
+        args.reps = 5 if args.steps is None else 1       # an explicit --steps K is timed once: exactly K steps
+    args.steps = 1000 if args.steps is None else args.steps
+    args.warmup = 100 if args.warmup is None else args.warmup
+
+    import torch
+    import torch.distributed as dist
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+
+    rank, world, local_rank, dev = _init_dist()
 
     model = load_task_model(args.task)
     cfg = engine.default_config()
@@ -114,11 +334,10 @@ def main():
     cfg.lanes_per_env = args.lanes
     batch = engine.Batch(model, args.envs, cfg, device=local_rank)
     batch.reset(seed=0, env_id_offset=rank * args.envs)
-    total = args.steps + args.warmup
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     # fresh action per step, generated before the timed region (HBM-resident inputs)
-    chunk = min(total, 256)
+    chunk = min(args.steps + args.warmup, 256)
     actions = torch.empty(chunk, args.envs, 14, device=dev, dtype=torch.float32).uniform_(-1.0, 1.0, generator=gen)
 
     def barrier():
@@ -126,14 +345,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the GPU's clock governor needs ~0.1 s of load to leave the idle state (a 20-step region timed right after process start-up
-    # runs 1.5 % slower than the steady state): 0.3 s of unrelated matrix products first; the env steps stay exactly W + K
-    ramp = torch.randn(4096, 4096, device=dev)
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.3:
-        torch.mm(ramp, ramp)
-        torch.cuda.synchronize()
-    del ramp
+    _clock_ramp(dev)
     for i in range(args.warmup):
         batch.step(actions[i % chunk])
     barrier()
@@ -141,28 +353,32 @@ def main():
     # for ~7 us, 1.2 % of this step when every launch carries one
     timing_stride = 4 if args.steps <= 64 else 16
     batch.timing(timing_stride)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        batch.step(actions[(args.warmup + i) % chunk])
-    barrier()
-    elapsed = time.perf_counter() - t0
+    times = []
+    k = args.warmup
+    for rep in range(args.reps):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            batch.step(actions[(k + i) % chunk])
+        barrier()
+        el = time.perf_counter() - t0
+        k += args.steps
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        times.append(el)
+    elapsed = sum(times) / len(times)
     kernel_ms, launches = batch.timing(False)
     done_frac = float(batch.done.mean().item())
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     value = world * args.envs * args.steps / elapsed
 
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r2", "traffic.json")
-        if args.task == "flat_terrain" and args.envs == 8192 and os.path.exists(tpath):
-            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, profiles/README.md)
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        bytes_per_launch = BYTES_PER_ENV_STEP.get(args.task, 2844) * args.envs
+        traffic, flop_launch, csrc = _counters(args.task, args.envs)
+        bytes_per_launch = BYTES_PER_ENV_STEP.get(args.task, 3564 if "backlash" in args.task else 2844) * args.envs
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        valu = args.envs * FLOP_PER_ENV_STEP / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        flop = flop_launch if flop_launch else args.envs * FLOP_PER_ENV_STEP
+        valu = flop / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         out = {
             "metric": METRIC, "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
@@ -170,16 +386,19 @@ def main():
             "config": {"workload": f"open_duck_mini_v2 {args.task}, {args.envs} envs/GPU, random-action rollout "
                                    "(wrappers + Joystick.step + 10 x mjx.step + obs/reward fused in one launch), "
                                    "noise off, pushes off, imitation on, auto-reset on",
-                       "envs_per_gpu": args.envs, "global_envs": args.envs * world, "n_substeps": 10,
+                       "mode": "physics", "envs_per_gpu": args.envs, "global_envs": args.envs * world, "n_substeps": 10,
                        "lanes_per_env": batch.cfg.lanes_per_env or 32, "parallelism": f"env-sharded x{world}, no collective",
-                       "done_fraction_last_step": round(done_frac, 4)},
+                       "done_fraction_last_step": round(done_frac, 4),
+                       "repetitions": args.reps, "value_per_repetition": [round(world * args.envs * args.steps / t, 1) for t in times],
+                       "protocol": "BASELINE.md 4: W warm-up env steps, then K timed env steps x repetitions, value = K / mean time"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "counter_source": csrc,
                          "kernel": "step_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": launches, "timed_every": timing_stride,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "fused env step is not HBM-bound (SURVEY.md 0.4); secondary roof = FP32 VALU",
                          "valu_achieved_tflops": round(valu, 3), "valu_peak_tflops": VALU_PEAK_TFLOPS,
-                         "valu_frac": round(valu / VALU_PEAK_TFLOPS, 5)},
+                         "valu_frac": round(valu / VALU_PEAK_TFLOPS, 5),
+                         "valu_flop_source": "SQ_INSTS_VALU_* counters (" + csrc + ")" if flop_launch else "1.2 MFLOP per env step (SURVEY.md 8d estimate)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

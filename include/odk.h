@@ -243,7 +243,8 @@ typedef struct odk_mlp_desc {
   const float* wf[4];        /* forward-packed weights of the four layers (16-byte aligned) */
   const float* wb[4];        /* backward-packed weights (wb[0] is not read: the input's gradient is never formed) */
   const float* b[4];         /* biases */
-  /* training buffers, all in the QUAD-ROW layout [np / 4][width][4] with np = n rounded up to a multiple of 32 (element (s, f) at
+  /* training buffers, all in the QUAD-ROW layout [np / 4][width][4] with np = n rounded up to a multiple of ODK_MLP_TILE = 16 (the kernels work on 16-sample tiles and write ceil(n / 16) tile rows of
+   * bias_partial; element (s, f) at
    * ((s / 4) * width + f) * 4 + s % 4; the operand layout of odk_dw_gemm); rows n .. np - 1 are written as zeros in h / g / dz / doutp */
   float* xp;                 /* forward out: quad-row copy of x, width n_in (rows past n: copies of row n - 1) */
   float* h[3];               /* forward out: swish(z_l), width H_l; all of xp / h / g NULL: inference only, nothing but `out` is written */

@@ -1,11 +1,12 @@
 // odk_mlp.hip -- the policy / value networks of the PPO learner as two launches: every layer of a swish MLP
 // (in -> 512 -> 256 -> 128 -> out, brax ppo.networks as configured by reference common/runner.py:86-118) forward in ONE
-// kernel, and the whole backward-data chain in ONE kernel, on the f32 matrix cores (v_mfma_f32_32x32x2_f32).  gfx950 only.
+// kernel, and the whole backward-data chain in ONE kernel, on the f32 matrix cores (v_mfma_f32_16x16x4_f32; the text below tells the story from the
+// first, 32-sample / 32x32x2 version on -- the shipped tile is ODK_MLP_TILE = 16 samples, see "16-sample tiles").  gfx950 only.
 //
 // Why: a minibatch is 5 120 samples and the layers are at most 512 wide, so as separate GEMMs every layer is a ~10 us
 // launch that under-fills the chip, with a 5 us element-wise launch (bias + swish, swish' + bias-gradient sums) between two
-// of them: ~25 launches per network and minibatch step, 128 steps per training step.  Here a workgroup owns a tile of 32
-// samples for ALL layers: the tile's activations stay in LDS, the weights stream from the L2 (both networks together are
+// of them: ~25 launches per network and minibatch step, 128 steps per training step.  Here a workgroup owns a tile of ODK_MLP_TILE = 16
+// samples (32 in the first version) for ALL layers: the tile's activations stay in LDS, the weights stream from the L2 (both networks together are
 // 2 MB: resident in every XCD's 4 MB L2), and the epilogues (bias, swish, swish', the bias gradients' tile sums) run on the
 // accumulator registers.
 //
@@ -24,7 +25,8 @@
 //
 // Forward, per workgroup (4 waves): layer 1 is produced in four 128-column chunks (wave w: one 32 x 32 block per chunk) and
 // each chunk is consumed at once as a K-slice of layer 2 (wave w: 64 columns, accumulators live across the chunks), so the
-// 512-wide activation never exists in LDS: X 29 KB + chunk 16.5 KB + layer-2 output 32.5 KB = 78 KB => two workgroups per
+// 512-wide activation never exists in LDS: (first version, 32-sample tiles: X 29 KB + chunk 16.5 KB + layer-2 output 32.5 KB = 78 KB => two
+// workgroups per CU; shipped, 16-sample tiles: <= 40 KB, static_assert below => FOUR workgroups per
 // CU (all 328 tiles of the two networks resident at once).  Layer 3: one block per wave; output layer (<= 32 columns): K
 // split over the four waves, partial blocks folded through LDS.
 // Backward: dz_top (from the loss head) -> dh3 = dz_top W4 -> dz3 = dh3 * swish'(z3) -> ... -> dz1, each dz written once to

@@ -20,6 +20,7 @@ The autograd path in `train.py` (`ppo_loss`) is the reference implementation the
 from __future__ import annotations
 
 import os
+import weakref
 import tempfile
 from typing import Dict
 
@@ -196,12 +197,16 @@ class _FlatMLP:
         self.fold = engine.ColsumFinalize([(p, self.gb[i]) for i, p in enumerate(self.partials)], n)
 
     def fused_ok(self) -> bool:
-        """The shapes csrc/odk_mlp.hip is built for: in -> 512 -> 256 -> 128 -> out with in <= 224, out <= 32."""
+        """The shapes csrc/odk_mlp.hip is built for: in -> 512 -> 256 -> 128 -> out with in <= 224, out <= 32 -- and every weight
+        at a flat offset / with an element count that is a multiple of 4 (the weight-gradient launch writes 16-byte pieces: an
+        odd action size, 2 A = 14, 18, ..., shifts everything behind the policy's last bias off that grid).  Otherwise the learner
+        falls back to the library-GEMM path instead of failing in `engine.DwGemm`."""
         return (_FUSED_MLP and len(self.W) == 4 and tuple(w.shape[0] for w in self.W[:3]) == engine.MLP_HIDDEN
-                and self.W[0].shape[1] <= engine.MLP_MAX_IN and self.W[3].shape[0] <= engine.MLP_MAX_OUT)
+                and self.W[0].shape[1] <= engine.MLP_MAX_IN and self.W[3].shape[0] <= engine.MLP_MAX_OUT
+                and all(o % 4 == 0 and w.numel() % 4 == 0 for o, w in zip(self.goff, self.W)))
 
     def fused_desc(self, table, k0, packed_f, packed_b):
-        """This network for `engine.FusedMLP`: the bound buffers + swish' buffers, bias-gradient tile sums (32-row tiles) and the
+        """This network for `engine.FusedMLP`: the bound buffers + swish' buffers, bias-gradient tile sums (16-row tiles, engine.MLP_TILE) and the
         views of its weights (entries k0 .. k0 + 3 of `table`) inside the packed buffers."""
         n, n_in, n_out = self.x.shape[0], self.x.shape[1], self.W[-1].shape[0]
         tb = engine.FusedMLP.train_buffers(n, n_in, n_out, self.x.device)
@@ -384,7 +389,8 @@ class FlatLearner:
         keep = [t.clone() for t in (self.flat_p, self.m, self.v, self.acc)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        tuned = _tunable(True) if self.cfg.get("tune_gemms", True) else False
+        # (no library GEMM is captured on the whole-network path: leave PyTorch's process-wide TunableOp switch alone there)
+        tuned = _tunable(True) if (self.cfg.get("tune_gemms", True) and self.fused is None) else False
         with torch.cuda.stream(side):               # warm-up outside capture (hipBLASLt workspaces, allocator, GEMM tuning)
             for _ in range(2):
                 self._draw_noise(); self._loss_and_grads(); self._update()
@@ -523,9 +529,12 @@ class FusedPolicy:
         return self.out
 
 
+_FUSED_POLICIES = weakref.WeakKeyDictionary()
+
+
 def fused_policy(net: PPONetworks, rows: int):
     """The net's cached `FusedPolicy` for `rows` observations per call, or None when the fused kernel does not apply."""
-    cache = net.__dict__.setdefault("_fused_policy", {})
+    cache = _FUSED_POLICIES.setdefault(net, {})   # weakly keyed by the module, not stored in it (deepcopy / pickling of the net stay clean)
     fp = cache.get(rows)
     if fp is None:
         fp = cache[rows] = FusedPolicy(net, rows)

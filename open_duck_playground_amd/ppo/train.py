@@ -11,6 +11,7 @@ from __future__ import annotations
 import json
 import os
 import time
+import weakref
 from typing import Callable, Dict, Optional
 
 import torch
@@ -181,6 +182,7 @@ class _RolloutBuffers:
         N, dev = obs.shape[0], obs.device
         E = lambda *s: torch.empty(*s, device=dev)
         self.T, self.src = T, (obs.data_ptr(), priv.data_ptr(), state.reward.data_ptr(), state.done.data_ptr(), state.info["truncation"].data_ptr())
+        self.shape = (N, obs.shape[1], priv.shape[1], A)
         self.buf = dict(obs=E(T, N, obs.shape[1]), priv=E(T, N, priv.shape[1]), raw_action=E(T, N, A), log_prob=E(T, N), reward=E(T, N), done=E(T, N),
                         truncation=E(T, N))
         self.action = E(N, A)
@@ -193,9 +195,15 @@ class _RolloutBuffers:
                 pairs += [(obs, b["obs"][t + 1]), (priv, b["priv"][t + 1])]
             self.after.append(engine.MultiCopy(pairs))
 
-    def matches(self, state, T: int) -> bool:
-        return T == self.T and self.src == (state.obs["state"].data_ptr(), state.obs["privileged_state"].data_ptr(), state.reward.data_ptr(),
-                                            state.done.data_ptr(), state.info["truncation"].data_ptr())
+    def matches(self, state, T: int, A: int) -> bool:
+        obs, priv = state.obs["state"], state.obs["privileged_state"]
+        return (T == self.T and self.shape == (obs.shape[0], obs.shape[1], priv.shape[1], A)
+                and self.src == (obs.data_ptr(), priv.data_ptr(), state.reward.data_ptr(), state.done.data_ptr(), state.info["truncation"].data_ptr()))
+
+
+# Rollout history buffers per network, held weakly OUTSIDE the module: ~220 MB of [T, N, ...] history and ctypes descriptor arrays
+# hidden in net.__dict__ would ride along with copy.deepcopy(net) / torch.save(net) -- and the ctypes pointers cannot be pickled.
+_ROLLOUT_BUFFERS = weakref.WeakKeyDictionary()
 
 
 @torch.no_grad()
@@ -205,9 +213,9 @@ def _rollout_engine(env, net: PPONetworks, state, unroll_length: int, gen: torch
     from .. import engine
     from .learner import fused_policy
     T, A = unroll_length, net.action_size
-    rb = net.__dict__.get("_rollout_buffers")
-    if rb is None or not rb.matches(state, T):
-        rb = net.__dict__["_rollout_buffers"] = _RolloutBuffers(state, T, A)
+    rb = _ROLLOUT_BUFFERS.get(net)
+    if rb is None or not rb.matches(state, T, A):
+        rb = _ROLLOUT_BUFFERS[net] = _RolloutBuffers(state, T, A)
     N = state.obs["state"].shape[0]
     fp = fused_policy(net, N)
     if fp is not None:

@@ -13,7 +13,7 @@ _DIR = os.path.dirname(os.path.abspath(__file__))
 
 
 def build(force: bool = False) -> None:
-    srcs = [os.path.join(_DIR, f) for f in ("odk_oracle.c", "odk_oracle_env.c", "odk_oracle.h", "odk_oracle_env.h", "Makefile")]
+    srcs = [os.path.join(_DIR, f) for f in ("odk_oracle.c", "odk_oracle_env.c", "odk_oracle_convex.inc", "odk_oracle.h", "odk_oracle_env.h", "Makefile")]
     libs = [os.path.join(_DIR, f) for f in ("libodk_oracle.so", "libodk_oracle_f32.so")]
     if not force and all(os.path.exists(l) for l in libs):
         newest = max(os.path.getmtime(s) for s in srcs if os.path.exists(s))
@@ -28,7 +28,12 @@ class _Lib:
         self.f32 = f32
         self.real = C.c_float if f32 else C.c_double
         self.npreal = np.float32 if f32 else np.float64
-        self.lib = C.CDLL(os.path.join(_DIR, "libodk_oracle_f32.so" if f32 else "libodk_oracle.so"))
+        # ODK_ORACLE_F32_LIB: bench.py's cpu_baseline points the float32 build at a copy compiled with -march=native on the box
+        path = os.path.join(_DIR, "libodk_oracle_f32.so" if f32 else "libodk_oracle.so")
+        if f32 and os.environ.get("ODK_ORACLE_F32_LIB") and os.path.exists(os.environ["ODK_ORACLE_F32_LIB"]):
+            path = os.environ["ODK_ORACLE_F32_LIB"]
+        self.path = path
+        self.lib = C.CDLL(path)
         L = self.lib
         P = C.c_void_p
         RP = C.POINTER(self.real)

@@ -147,6 +147,33 @@ def test_bench_multi_rank_launch_path():
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
 
 
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_ppo_mode(ranks):
+    """bench.py --mode ppo (BASELINE configs 3 / 5): full training steps -- rollout with the policy in the loop + 128 minibatch
+    steps, flat-gradient all-reduce when ranks > 1 (two gloo ranks on GPU 0 here: RCCL wants one rank per device) -- and one
+    JSON line with the whole-job env steps per second including the learner."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ODK_BENCH_BACKEND="gloo", ODK_BENCH_DEVICE="0")
+    tail = [os.path.join(root, "bench.py"), "--mode", "ppo", "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--envs", "256"]
+    if ranks == 1:
+        cmd = [sys.executable] + tail
+    else:
+        port = 29900 + os.getpid() % 300
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["steps"] == 2 and d["unit"] == "env-steps/s" and d["config"]["mode"] == "ppo"
+    assert d["config"]["global_envs"] == 256 * ranks and d["config"]["sgd_steps_per_training_step"] == 128
+    assert abs(d["value"] - 256 * ranks * 20 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-3
+    assert d["config"]["rollout_ms_per_training_step"] > 0 and d["config"]["learner_ms_per_training_step"] > 0
+    assert d["config"]["learner_path"].startswith("fused") and d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0
+    assert (d["config"]["allreduce_ms_per_training_step_isolated"] is not None) == (ranks > 1)
+
+
 def test_evaluator_graph_replay_matches_plain_launches():
     """The evaluation step captured as a HIP graph (policy + fused env step + first-episode accumulators) reproduces the
     plain-launch evaluation, also when re-used for a second evaluation and after the parameters move."""

@@ -2,7 +2,7 @@
 # Copies the evidence gathered on the GPU box (gpurun_out/, scratch) into profiles/<round>/ (tracked):
 #   tools/collect_round_profiles.sh r2      after tools/gpu_profile_round.sh, gpu_learner_trace.sh, gpu_rollout_trace.sh,
 #   gpu_substep_scan.py, gpu_train_runs.sh, gpu_phase_profile.py and gpu_icache_pmc.sh wrote their outputs
-set -u
+set -eu   # a missing input must fail loudly: stale evidence in profiles/ is worse than none
 R=${1:-r2}; P=profiles/$R; G=gpurun_out/prof_$R
 cp $G/kernel_stats.csv $G/bench_under_rocprof.json $G/pmc_summary.json $P/
 cp $G/bench_default.json $P/bench_default_run.json

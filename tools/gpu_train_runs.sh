@@ -4,9 +4,9 @@
 set -u
 TAG=${1:-x}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=gpurun_out/train_$TAG
-mkdir -p $OUT
 cd $ROOT
+OUT=$ROOT/gpurun_out/train_$TAG
+mkdir -p $OUT
 run() {  # name, args...
   local name=$1; shift
   local t0=$(date +%s)
