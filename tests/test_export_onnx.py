@@ -65,3 +65,21 @@ def test_self_check_survives_constant_observation_entries(tmp_path):
     path = X.export_onnx(net, str(tmp_path / "policy.onnx"), check=True)
     m = X.load_onnx(open(path, "rb").read())
     assert np.all(np.isfinite(X.run_onnx(m, np.ones((1, 85), np.float32))))
+
+
+def test_file_read_back_by_an_independent_decoder(tmp_path):
+    """The same file through the decoder of tests/test_gpu_export_eval.py -- onnx.proto3 field numbers written out there, nothing
+    shared with the exporter's own load_onnx -- and a numpy run with the operator semantics of the ONNX spec."""
+    import test_gpu_export_eval as D
+    torch.manual_seed(3)
+    net = PPONetworks(85, 153, 14)
+    net.norm_obs.update(torch.randn(4096, 1, 85) * 2.0 + 0.3)
+    m = D._decode_model(open(X.export_onnx(net, str(tmp_path / "policy.onnx")), "rb").read())
+    assert m["ir_version"] == 6 and m["opsets"] == [("", 11)]
+    assert m["inputs"] == [("obs", [1, 85])] and m["outputs"] == [("continuous_actions", [1, 14])]
+    assert m["nodes"][2]["attrs"] == {"alpha": 1.0, "beta": 1.0, "transA": 0, "transB": 1}
+    obs = torch.randn(16, 85) * 2.0
+    with torch.no_grad():
+        ref = torch.tanh(net.dist_params(obs)[0]).numpy()
+    got = np.concatenate([D._run(m, obs.numpy()[i: i + 1]) for i in range(16)])
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-6)
