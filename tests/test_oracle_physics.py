@@ -158,25 +158,6 @@ def test_float32_build_tracks_float64(oracle_mod, model_a):
     np.testing.assert_allclose(res[1][1], res[0][1], rtol=1e-3, atol=2e-4)
 
 
-@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
-def test_against_mjx_golden_if_present(oracle_mod, model_a, model_b, task):
-    """Closes the parity gap when tools/dump_mjx_golden.py has been run somewhere MJX is installable."""
-    import os
-    from conftest import GOLDEN
-    path = os.path.join(GOLDEN, f"mjx_step_{task}.npz")
-    if not os.path.exists(path):
-        pytest.skip("no MJX golden vectors (physics parity unpinned, DESIGN.md section 2)")
-    g = np.load(path)
-    model = model_a if task == "flat_terrain" else model_b
-    om = oracle_mod.OracleModel(model.blob())
-    for i in range(len(g["qpos"])):
-        d = oracle_mod.OracleData(om)
-        d["qpos"][: om.nq] = g["qpos"][i]; d["qvel"][: om.nv] = g["qvel"][i]; d["qacc_warmstart"][: om.nv] = g["warm"][i]
-        d.env_physics_step(g["ctrl"][i], 1)
-        np.testing.assert_allclose(d["qpos"][: om.nq], g["qpos1"][i], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(d["qvel"][: om.nv], g["qvel1"][i], rtol=1e-3, atol=1e-4)
-
-
 def test_height_field_one_triangle_mode(oracle_mod):
     """rough_terrain_backlash, hfield_mode = 1 (round 2's approximation, kept to measure its difference to the prism algorithm of
     tests/test_oracle_convex.py): the contact normal under each foot is the normal of the height-field triangle below
