@@ -31,6 +31,12 @@ __device__ __forceinline__ int row_argmax(float v, int i, float& vmax) {
   vmax = fkey_inv(mx);
   return (int)rreduce_u<false>(k == mx ? (unsigned)i : 0x7FFFFFFFu);
 }
+// lowest index among the row's minima of (v, i); vmin = the minimum
+__device__ __forceinline__ int row_argmin(float v, int i, float& vmin) {
+  const unsigned k = fkey(v), mn = rreduce_u<false>(k);
+  vmin = fkey_inv(mn);
+  return (int)rreduce_u<false>(k == mn ? (unsigned)i : 0x7FFFFFFFu);
+}
 __device__ __forceinline__ void sub3(float* r, const float* a, const float* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
 __device__ __forceinline__ void ld3(float* r, const float* p) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; }
 
@@ -200,7 +206,7 @@ __device__ __forceinline__ bool clip_edge_row(const float* p0, const float* p1, 
 }
 
 // Scratch of one row (floats): RP | IP = reference / incident polygon of the current face contact ([4][3] each), NEW = this pair's
-// four contacts.  A contact = dist, pos[3], normal[3].
+// four contacts.  A contact = dist, pos[3], normal[3], (candidate index: the caller's) -- 8 floats.
 struct RowScratch { float* RP; float* IP; float* NEW; };
 
 // mjx _create_contact_manifold on the polygons in S.RP (rcnt vertices, normal n_ref) / S.IP (icnt, n_inc): lane j = candidate j of
@@ -212,18 +218,21 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
   const bool cand = j < np;
   float pt[3] = {0.0f, 0.0f, 0.0f};
   bool mask = false;
-  if (cand) {
-    if (e < icnt) {
-      mask = clip_edge_row(S.IP + 3 * (e == 0 ? icnt - 1 : e - 1), S.IP + 3 * e, S.RP, rcnt, n_ref, which, pt);
-    } else {
-      const int er = e - icnt;
-      float a[3], b[3];
+  {
+    // ONE clip per lane: the two kinds of candidate differ only in their operands (as two branches every lane walked both)
+    const bool subj = e < icnt;
+    const int er = subj ? e : e - icnt, cntp = subj ? icnt : rcnt;
+    const float* src = subj ? S.IP : S.RP;
+    float a[3], b[3];
+    ld3(a, src + 3 * (er == 0 ? cntp - 1 : er - 1)); ld3(b, src + 3 * (er < cntp ? er : 0));
+    if (!subj) {   // reference edge: projected on the incident plane along the reference normal
       const float d = dot3(S.IP, n_inc), den = dot3(n_ref, n_inc), dsafe = den + (den == 0.0f ? 1e-6f : 0.0f);
-      const float* ra = S.RP + 3 * (er == 0 ? rcnt - 1 : er - 1); const float* rb = S.RP + 3 * er;
-      const float ta = (d - dot3(ra, n_inc)) / dsafe, tb = (d - dot3(rb, n_inc)) / dsafe;
-      for (int k = 0; k < 3; k++) { a[k] = ra[k] + ta * n_ref[k]; b[k] = rb[k] + tb * n_ref[k]; }
-      mask = clip_edge_row(a, b, S.IP, icnt, n_inc, which, pt);
+      const float ta = (d - dot3(a, n_inc)) / dsafe, tb = (d - dot3(b, n_inc)) / dsafe;
+      for (int k = 0; k < 3; k++) { a[k] += ta * n_ref[k]; b[k] += tb * n_ref[k]; }
     }
+    const float qn[3] = {subj ? n_ref[0] : n_inc[0], subj ? n_ref[1] : n_inc[1], subj ? n_ref[2] : n_inc[2]};
+    const bool m1 = clip_edge_row(a, b, subj ? S.RP : S.IP, subj ? rcnt : icnt, qn, which, pt);
+    mask = cand && m1;
   }
   float t0[3], pref[3];
   sub3(t0, pt, S.RP);
@@ -237,7 +246,7 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
   for (int k = 0; k < 4; k++) {
     if (act && !skip && j == idx[k]) {
       const float pen = -off;
-      float* o = S.NEW + 7 * k;
+      float* o = S.NEW + 8 * k;
       o[0] = mask ? -pen : 1.0f;
       for (int t = 0; t < 3; t++) { o[1 + t] = pref[t] - 0.5f * pen * n_ref[t]; o[4 + t] = sg * n_ref[t]; }
     }
@@ -255,7 +264,7 @@ __device__ __forceinline__ void edge_contact_row(const float* p1, const float* q
   if (t < 0.0f) { t = 0.0f; s = fminf(fmaxf(-c / (a > 1e-30f ? a : 1.0f), 0.0f), 1.0f); }
   else if (t > 1.0f) { t = 1.0f; s = fminf(fmaxf((b - c) / (a > 1e-30f ? a : 1.0f), 0.0f), 1.0f); }
   if (act && j < 4) {
-    float* o = S.NEW + 7 * j;
+    float* o = S.NEW + 8 * j;
     o[0] = j == 0 ? sep : 1.0f;
     for (int k = 0; k < 3; k++) { o[1 + k] = 0.5f * ((p1[k] + s * d1[k]) + (p2[k] + t * d2[k])); o[4 + k] = ax[k]; }
   }
@@ -476,16 +485,17 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
   ODK_SYNC();
 }
 
-// keeps the four smallest dist of TOP[4] ++ NEW[4] in TOP (stable: earlier entries win ties, like a stable sort of the whole list)
+// keeps the four smallest of TOP[4] ++ NEW[4] in TOP; entries are 8 floats (dist, pos[3], normal[3], candidate index) ordered by
+// (dist, candidate index): the order of a stable sort of the whole candidate list, whatever order the pairs were worked in
 __device__ __forceinline__ void merge_top4_row(float* TOP, const float* NEW, int j, bool act) {
-  float mine[7], dist[8];
-  const float* src = j < 4 ? TOP + 7 * j : NEW + 7 * ((j - 4) & 3);
-  for (int k = 0; k < 7; k++) mine[k] = src[k];
-  for (int k = 0; k < 8; k++) dist[k] = k < 4 ? TOP[7 * k] : NEW[7 * (k - 4)];
+  float mine[8], dist[8], cidx[8];
+  const float* src = j < 4 ? TOP + 8 * j : NEW + 8 * ((j - 4) & 3);
+  for (int k = 0; k < 8; k++) mine[k] = src[k];
+  for (int k = 0; k < 8; k++) { const float* e = k < 4 ? TOP + 8 * k : NEW + 8 * (k - 4); dist[k] = e[0]; cidx[k] = e[7]; }
   int rank = 0;
-  for (int k = 0; k < 8; k++) rank += (dist[k] < mine[0] || (dist[k] == mine[0] && k < j)) ? 1 : 0;
+  for (int k = 0; k < 8; k++) rank += (dist[k] < mine[0] || (dist[k] == mine[0] && cidx[k] < mine[7])) ? 1 : 0;
   ODK_SYNC();
-  if (act && j < 8 && rank < 4) { float* o = TOP + 7 * rank; for (int k = 0; k < 7; k++) o[k] = mine[k]; }
+  if (act && j < 8 && rank < 4) { float* o = TOP + 8 * rank; for (int k = 0; k < 8; k++) o[k] = mine[k]; }
   ODK_SYNC();
 }
 

@@ -128,7 +128,7 @@ struct Shape {
   static constexpr int O_CR = O_CDIST + NCON;        // [12][3] contact position relative to the base origin
   static constexpr int O_SCR = O_CR + 3 * NCON;      // scratch: foot twists, wrenches, 6x6 blocks, sensor inputs
 #ifdef ODK_PROFILE
-  static constexpr int N_SCR = 192;
+  static constexpr int N_SCR = 200;                  // + S_PROF (20) + S_PROF2 (8: sub-phases of the height-field contacts)
 #else
   static constexpr int N_SCR = 172;                  // no S_PROF slots outside profile builds
 #endif
@@ -145,6 +145,7 @@ struct Shape {
   static constexpr int S_FFX = 144;   // [6] wrench sum of the foot-foot rows
   static constexpr int S_MISC = 156;  // misc scalars (16)
   static constexpr int S_PROF = 172;  // [20] per-phase cycle counters (ODK_PROFILE builds)
+  static constexpr int S_PROF2 = 192; // [8] height-field contacts: hull setup, cull pass, register loads, pair loop, iterations, list length, -, -
 };
 
 // Phase timing (build with -DODK_PROFILE): lane 0 accumulates shader-clock deltas per phase into the
@@ -883,13 +884,13 @@ namespace odk {
 template <class S, int G>
 __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict__ m, int lane, bool overlap) {
   constexpr int NB = S::NB;
-  static_assert(4 * S::NROW >= 282 && 16 * S::NB >= 6 * 48 && 6 * S::NVR >= 52, "foot-foot scratch does not fit");
+  static_assert(4 * S::NROW >= 282 && 16 * S::NB >= 6 * 48 && 6 * S::NVR >= 56, "foot-foot scratch does not fit");
   float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR;
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
   float* FVb = L + S::O_D;       // [2][17][3] vertices | [2][30][3] normals
   float* AE = L + S::O_CFRC;     // [<= 48][6]
-  float* RS = L + S::O_BUF6;     // RP 12 | IP 12 | NEW 28
+  float* RS = L + S::O_BUF6;     // RP 12 | IP 12 | NEW 32
   const int row = lane >> 4, j = lane & 15;
   const bool act = overlap && row == 0;
   float cw[2][3];
@@ -920,7 +921,7 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
   RowScratch RSS = {RS, RS + 12, RS + 24};
   sat_pair_row<3>(A, B, AE, RB, RSS, j, row == 0);
   if (act && j < 4) {
-    const float* o = RS + 24 + 7 * j;
+    const float* o = RS + 24 + 8 * j;
     const int c = 8 + j;
     CDIST[c] = o[0];
     for (int t = 0; t < 3; t++) CR[3 * c + t] = o[1 + t] - ref[t];
@@ -946,11 +947,19 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
   const int f = (lane >> 4) & 1, j = lane & 15;
+#ifdef ODK_PROFILE
+  long long _hp = clock64();
+#define HF_PROF(i) do { if (lane == 0) { const long long _t = clock64(); L[S::O_SCR + S::S_PROF2 + (i)] += (float)(_t - _hp); _hp = _t; } } while (0)
+#define HF_COUNT(i, v) do { if (lane == 0) L[S::O_SCR + S::S_PROF2 + (i)] += (float)(v); } while (0)
+#else
+#define HF_PROF(i) do { } while (0)
+#define HF_COUNT(i, v) do { } while (0)
+#endif
   float* FV = L + S::O_CFRC + f * 51; float* FN = L + S::O_CFRC + 102 + f * 90;
   float* RS = L + (f ? S::O_BUF6B : S::O_BUF6);
   float* PV = RS;                                                      // prism vertices [6][3]
   float* RL = L + S::O_D + f * 172;
-  float* LIST = RL; float* TOP = RL + 108; float* NEW = RL + 136;      // [18][6] | [4][7] | [4][7]
+  float* LIST = RL; float* TOP = RL + 108; float* NEW = RL + 140;      // [18][6] | [4][8] | [4][8]
   const RowScratch RSS = {RS + 18, RS + 30, NEW};                      // RP [4][3], IP [4][3]
   const float* Rh = m->floor_mat; const float ph[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
   // ---- the hull in the height field's frame: v_h = Rh^T (P + R v - ph)
@@ -992,7 +1001,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   }
   float fc[3];
   for (int k = 0; k < 3; k++) fc[k] = Pw[k] + Rw[3 * k] * m->foot_centroid[f][0] + Rw[3 * k + 1] * m->foot_centroid[f][1] + Rw[3 * k + 2] * m->foot_centroid[f][2];
-  if (j < 4) { float* o = TOP + 7 * j; o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f; }
+  if (j < 4) { float* o = TOP + 8 * j; o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f; o[7] = 1.0e9f + (float)j; }
   ODK_SYNC();
   const float idiag = 1.0f / sqrtf(dx * dx + dy * dy);
   // prism p = 2 (ri ncw + ci) + tri of this row's window: grid corners of its top triangle (counter-clockwise seen from above)
@@ -1017,6 +1026,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     P.ns[1][0] = sg * dy * idiag; P.ns[1][1] = sg * dx * idiag;
     P.ns[2][0] = -sg; P.ns[2][1] = 0.0f;
   };
+  HF_PROF(0);
   // ---- pass over the window, lane = prism: the prism's own face query against the hull vertices; survivors into the list
   int cnt = 0;
   const int nprism = (ncw > 0 && nrw > 0) ? 2 * ncw * nrw : 0;
@@ -1049,16 +1059,34 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     cnt += __popc(rowmask);
   }
   ODK_SYNC();
+  HF_PROF(1);
+  HF_COUNT(5, cnt);
   const Cvx B = {FV, FN, &m->foot_poly[f][0][0], &m->foot_edge[f][0][0], nvt, nfc, m->foot_nedge[f], {fc[0], fc[1], fc[2]}};
   EdgeRegs<3> RB;
   edge_regs_load<3>(RB, B, j);
   FaceRegs<2> FB;
   face_regs_load<2>(FB, B, j);
-  // ---- pair loop
+  HF_PROF(2);
+  // ---- pair loop.  Every contact of a pair is at least as far out as the pair's best separating axis, which is at least the prism's
+  // own face separation `sep` (kept in the list): a prism whose sep lies beyond the fourth-deepest contact found so far cannot enter
+  // the best four.  So each row works through its prisms from the deepest sep on and stops at the first one that cannot matter;
+  // the result does not depend on the order (entries are ranked by (dist, candidate index), like a stable sort of MJX's whole
+  // candidate list).  Typically two or three of the six to eight overlapping prisms get the full test.
+  unsigned done = 0u;   // row-uniform: list entries already taken
 #pragma unroll 1
-  for (int k = 0; __builtin_amdgcn_ballot_w64(k < cnt) != 0; k++) {
-    const bool act = k < cnt;
-    const float* en = LIST + 6 * (act ? k : 0);
+  for (;;) {
+    asm volatile("; HF_LOOP_BEGIN" ::: "memory");
+    // this row's next prism: the smallest sep among the entries not taken yet (lane j looks at entries j and j + 16)
+    float s0 = 3.0e38f, s1 = 3.0e38f;
+    if (j < cnt && !((done >> j) & 1u)) s0 = LIST[6 * j + 4];
+    if (j + 16 < cnt && !((done >> (j + 16)) & 1u)) s1 = LIST[6 * (j + 16) + 4];
+    float smin;
+    const int kmin = row_argmin(s1 < s0 ? s1 : s0, s1 < s0 ? j + 16 : j, smin);
+    const bool act = smin < 3.0e38f && !(smin > TOP[8 * 3]);
+    if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+    const int kk = act ? kmin : 0;
+    done |= act ? (1u << kk) : 0u;
+    const float* en = LIST + 6 * kk;
     const int p = act ? __float_as_int(en[0]) : 0;
     const float z[3] = {en[1], en[2], en[3]};
     const float sep_a = en[4]; const int face_a = act ? __float_as_int(en[5]) : 0;
@@ -1072,11 +1100,16 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     }
     const float pc[3] = {(P.x[0] + P.x[1] + P.x[2]) * (1.0f / 3.0f), (P.y[0] + P.y[1] + P.y[2]) * (1.0f / 3.0f), (z[0] + z[1] + z[2] - 3.0f * base) * (1.0f / 6.0f)};
     sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act);
+    if (act && j < 4) NEW[8 * j + 7] = (float)(4 * p + j);   // candidate index in MJX's list: prism-major, then the pair's four slots
+    ODK_SYNC();
     merge_top4_row(TOP, NEW, j, act);
+    HF_COUNT(4, 1);
+    asm volatile("; HF_LOOP_END" ::: "memory");
   }
+  HF_PROF(3);
   // ---- the best four: contact distance, position (relative to the base origin), frame; back in the world frame
   float out[7];
-  for (int k = 0; k < 7; k++) out[k] = TOP[7 * (j & 3) + k];
+  for (int k = 0; k < 7; k++) out[k] = TOP[8 * (j & 3) + k];
   ODK_SYNC();
   if (j < 4) {
     const int c = 4 * f + j;

@@ -29,6 +29,7 @@ torch.cuda.synchronize()
 img = b.lds_image()
 o = b.lds_offset("scr") + 172
 prof = img[:, o:o + 20].astype(np.float64)
+prof2 = img[:, o + 20:o + 28].astype(np.float64).mean(axis=0)
 mean = prof.mean(axis=0)
 tot = mean[:18].sum()
 labels = ["P0 sincos", "P1 top-down sweep (pose,cdof,cvel,cacc,cinert)", "P2 bottom-up sweep (crb,cfrc)", "P3 per-dof bias/act/qfrc_smooth",
@@ -40,3 +41,6 @@ for i in range(18):
     print(f"  {labels[i]:48s} {mean[i]:12,.0f}  {100 * mean[i] / tot:5.1f}%")
 print(f"  {'env-step prologue (kernel start -> first substep)':48s} {mean[18]:12,.0f}  {100 * mean[18] / tot:5.1f}% of the substeps' total")
 print(f"  {'env-step epilogue (last Euler -> kernel end)':48s} {mean[19]:12,.0f}  {100 * mean[19] / tot:5.1f}% of the substeps' total")
+if "rough" in task:
+    print(f"  height-field contacts (per env step = 10 forwards): hull setup {prof2[0]:,.0f}  cull pass {prof2[1]:,.0f}  register loads {prof2[2]:,.0f}  "
+          f"pair loop {prof2[3]:,.0f} cycles; loop iterations {prof2[4] / 10:.2f} per forward (longest row of the wave), list length of foot 0 {prof2[5] / 10:.2f}")
