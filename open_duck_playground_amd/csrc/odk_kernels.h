@@ -9,7 +9,7 @@
 //
 // What makes it fast (all exact in real arithmetic; DESIGN.md 4.1 has the measurements):
 //  * occupancy by construction: <= 256 VGPRs => 2 waves/SIMD = 8 workgroups/CU, and the LDS image is sized so that 8
-//    workgroups fit (shape A: 2 412 floats/env; LDS, not registers, is what rules out a third wave) => 8192 envs are
+//    workgroups fit (shape A: 2 296 floats/env; LDS, not registers, is what rules out a third wave) => 8192 envs are
 //    exactly two rounds.  Two waves keep the VALU ~70 % busy; each wave is paced by its own chain of dependent
 //    instructions and LDS round trips (a second wave stretches every phase by 1.0-1.2x only): what pays is fewer
 //    instructions and fewer serialised round trips -- not fewer loads from the model, those are covered;
