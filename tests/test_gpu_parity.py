@@ -187,6 +187,45 @@ def test_one_substep_stages(torch_cuda, oracle_mod, parity_log, task, lanes):
     parity_log.check(f"one_mjx_step/{task}/lanes{lanes}", dict(STAGE_BOUNDS, tie_fraction=0.6 if "rough" in task else 0.1), tie_fraction=n_tie / n, **worst)
 
 
+def test_height_field_far_from_the_origin(torch_cuda, oracle_mod, parity_log):
+    """The terrain spans +-10 m and a contact depth is a fraction of a millimetre: the kernel works relative to the first grid
+    corner of each foot's window, so contacts 7-9 m from the origin must agree with the float64 oracle as well as those next to it."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    torch = torch_cuda
+    model = load_task_model("rough_terrain_backlash")
+    n = 32
+    rng = np.random.default_rng(21)
+    qpos, qvel = _random_states(model, n, rng, airborne_frac=0.0)
+    qpos[:, 0] += rng.choice([-1.0, 1.0], n) * rng.uniform(7.0, 9.0, n); qpos[:, 1] += rng.choice([-1.0, 1.0], n) * rng.uniform(7.0, 9.0, n)
+    om = oracle_mod.OracleModel(model.blob())
+    qpos = _settle_on_terrain(oracle_mod, om, qpos, rng, np.zeros(n, bool))
+    ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.2, 0.2, (n, 14))
+    b = engine.Batch(model, n)
+    b.set_state(qpos, qvel, np.zeros((n, model.nv)))
+    b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 1)
+    img = b.lds_image()
+    o_cd, o_qa = b.lds_offset("contact_dist"), b.lds_offset("qacc")
+    prng = np.random.default_rng(5)
+    wd = wa = 0.0
+    n_tie = 0
+    for e in range(n):
+        d = oracle_mod.OracleData(om)
+        d["qpos"][: om.nq] = qpos[e]; d["qvel"][: om.nv] = qvel[e]; d["ctrl"][:14] = ctrl[e]
+        d.forward()
+        if _contact_tie(oracle_mod, om, qpos[e], qvel[e], ctrl[e], prng, _contacts(d)):
+            n_tie += 1
+            continue
+        cd_o, cd_g = np.array(d["contact_dist"][:8]), img[e][o_cd: o_cd + 8]
+        act = (cd_o < 0) | (cd_g < 0)
+        assert act.any()
+        wd = max(wd, np.abs(cd_g[act] - cd_o[act]).max())
+        wa = max(wa, _rel(img[e][o_qa: o_qa + model.nv], d["qacc"][: model.nv], 5.0).max())
+    b.close()
+    # the base position itself is a float32 in the state record: 8 m carries 5e-7 m of rounding, which is the floor here
+    parity_log.check("hfield_far_from_origin", dict(dist=6e-7, qacc=1e-3, tie_fraction=0.5), dist=wd, qacc=wa, tie_fraction=n_tie / n)
+
+
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
 def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
     """mjx_env.step (10 substeps) from standing-ish states: state after one env step within 1e-4 relative."""
