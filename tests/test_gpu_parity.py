@@ -271,8 +271,8 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
     parity_log.check(f"ten_substeps/{task}", dict(TEN_BOUNDS, ill_fraction=0.7 if "rough" in task else 0.35), qpos=wq, qvel=wv, ill_fraction=n_ill / n)
 
 
-@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
-def test_foot_foot_contacts(torch_cuda, oracle_mod, parity_log, task):
+@pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32)])
+def test_foot_foot_contacts(torch_cuda, oracle_mod, parity_log, task, lanes):
     """Feet pressed into each other (hip rolls inwards, robot lifted off the floor): the foot-foot SAT manifold,
     its contact rows and the coupled (virtual-tree) Hessian path against the oracle, one mjx.step."""
     from open_duck_playground_amd import engine
@@ -297,7 +297,8 @@ def test_foot_foot_contacts(torch_cuda, oracle_mod, parity_log, task):
         qvel[e, 6:] = rng.normal(0, 0.5, model.nv - 6)
     warm = np.zeros((n, model.nv))
     ctrl = np.stack([qpos[e, aq] for e in range(n)])
-    b = engine.Batch(model, n)
+    cfg = engine.default_config(); cfg.lanes_per_env = lanes
+    b = engine.Batch(model, n, cfg)
     b.set_state(qpos, qvel, warm)
     b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 1)
     gq, gv, _ = b.get_state()
@@ -332,10 +333,10 @@ def test_foot_foot_contacts(torch_cuda, oracle_mod, parity_log, task):
     print(task, dict(n=n, penetrating=n_pen, flips=n_flip, ties=n_tie, **{k: float(f"{v:.3g}") for k, v in worst.items()}))
     b.close()
     assert n_pen >= 30, "the grid must contain penetrating poses"
-    parity_log.rec(f"foot_foot/{task}", dict(flips=0, ties=n // 3), flips=n_flip, penetrating=n_pen, ties=n_tie, poses=n, single_contact_poses=n_single)
+    parity_log.rec(f"foot_foot/{task}/lanes{lanes}", dict(flips=0, ties=n // 3), flips=n_flip, penetrating=n_pen, ties=n_tie, poses=n, single_contact_poses=n_single)
     assert n_single >= 5, "the grid must contain edge-edge (single-contact) poses"
     assert n_flip == 0 and n_tie <= n // 3
-    parity_log.check(f"foot_foot/{task}", FOOT_BOUNDS, **worst)
+    parity_log.check(f"foot_foot/{task}/lanes{lanes}", FOOT_BOUNDS, **worst)
 
 
 def test_yaw_equivariance_full_size(torch_cuda):
