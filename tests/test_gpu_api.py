@@ -319,3 +319,46 @@ def test_smoke_after_library_load_in_a_fresh_process():
             "import __graft_entry__ as g; g.smoke()")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0 and "smoke ok" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("task", ["flat_terrain", "rough_terrain_backlash"])
+def test_free_running_statistics_match_the_oracle(oracle_mod, parity_log, task):
+    """Chaos makes trajectories of a float32 and a float64 implementation part within a few env steps, but their STATISTICS must
+    agree: 8192 GPU envs against 192 oracle envs over the same 40 free-running random-action steps from the same reset
+    distribution -- mean reward, termination rate, foot-contact fractions, mean joint speed -- within the oracle sample's
+    standard error (a systematic bias of the kernels, e.g. in the contact forces, would show here even where the per-step
+    parity tests set ill-conditioned steps aside)."""
+    import torch
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    model = load_task_model(task)
+    n, no, T = 8192, 192, 40
+    b = engine.Batch(model, n)
+    b.reset(seed=33)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    G = dict(reward=[], done=[], contact=[], jspeed=[])
+    for t in range(T):
+        b.step(torch.empty(n, 14, device="cuda").uniform_(-1, 1, generator=g))
+        G["reward"].append(b.reward.mean().item()); G["done"].append(b.done.mean().item())
+        G["contact"].append(b.obs[:, 97:99].mean().item()); G["jspeed"].append(b.priv[:, 130:144].abs().mean().item())
+    b.close()
+    om = oracle_mod.OracleModel(model.blob()); prm = oracle_mod.OraclePRM(engine.load_prm())
+    rng = np.random.default_rng(9)
+    O = dict(reward=[], done=[], contact=[], jspeed=[])
+    envs = [oracle_mod.OracleEnv(om, prm) for _ in range(no)]
+    for i, e in enumerate(envs):
+        e.reset(33, 100000 + i)          # other env ids than the GPU batch: independent draws from the same reset distribution
+    per_env = {k: np.zeros((T, no)) for k in O}
+    for t in range(T):
+        for i, e in enumerate(envs):
+            e.step(rng.uniform(-1, 1, 14))
+            per_env["reward"][t, i] = e["reward"][0]; per_env["done"][t, i] = e["done"][0]
+            per_env["contact"][t, i] = np.mean(e["obs"][97:99]); per_env["jspeed"][t, i] = np.abs(e["priv"][130:144]).mean()
+    out = {}
+    for k in O:
+        mo = per_env[k].mean()                                   # over time and envs
+        se = per_env[k].mean(axis=0).std(ddof=1) / np.sqrt(no)   # standard error of the per-env time averages
+        mg = float(np.mean(G[k]))
+        out[k + "_z"] = abs(mg - mo) / max(se, 1e-9)
+        out[k + "_gpu"] = mg; out[k + "_oracle"] = float(mo)
+    parity_log.check(f"free_running_statistics/{task}", dict(reward_z=4.0, done_z=4.0, contact_z=4.0, jspeed_z=4.0), **out)
