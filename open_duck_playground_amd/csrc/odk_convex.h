@@ -207,7 +207,7 @@ __device__ __forceinline__ bool clip_edge_row(const float* p0, const float* p1, 
 
 // Scratch of one row (floats): RP | IP = reference / incident polygon of the current face contact ([4][3] each), NEW = this pair's
 // four contacts.  A contact = dist, pos[3], normal[3], (candidate index: the caller's) -- 8 floats.
-struct RowScratch { float* RP; float* IP; float* NEW; };
+struct RowScratch { float* RP; float* IP; float* NEW; float* PW; float* VV; };   // PW [16] / VV [48]: the row's pass words and hull-edge vertex pairs (height field only)
 
 // mjx _create_contact_manifold on the polygons in S.RP (rcnt vertices, normal n_ref) / S.IP (icnt, n_inc): lane j = candidate j of
 // _clip -- (incident edge e clipped by the reference side planes) x 2, then (reference edge, projected on the incident plane along
@@ -354,7 +354,16 @@ template <int NFS> __device__ __forceinline__ void face_regs_load(FaceRegs<NFS>&
 // faces / edges of this lane in FB / RB); PV: the prism's vertices in LDS for the polygon fetch
 template <int NFS, int NSLOT>
 __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, const float* PV, const Cvx& B, const FaceRegs<NFS>& FB, const EdgeRegs<NSLOT>& RB,
-                                              float sep_a, int face_a, const RowScratch& S, int j, bool act) {
+                                              float sep_a, int face_a, const RowScratch& S, int j, bool act
+#ifdef ODK_PROFILE
+                                              , float* prof, long long& tp
+#endif
+                                              ) {
+#ifdef ODK_PROFILE
+#define SAT_PROF(i) do { const long long _t = clock64(); if (prof) prof[i] += (float)(_t - tp); tp = _t; } while (0)
+#else
+#define SAT_PROF(i) do { } while (0)
+#endif
   // ---- face query of the hull against the prism's six vertices
   float sep_b; int face_b;
   float fn[NFS][3];   // this lane's hull face normals (slot s = face j + 16 s; lanes without a second face read face 0's)
@@ -371,6 +380,7 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
     }
     face_b = row_argmax(best, bi, sep_b);
   }
+  SAT_PROF(1);
   // ---- edge query: the prism's nine edges (compile-time topology) against the hull edges of this lane.  The Gauss-map test of all
   // 27 pairs of a lane first (a pass bit each), then the few passing pairs in a short loop: taken inline, some lane of the wave
   // passes nearly every test, so every lane would walk through all 27 axis computations.
@@ -390,19 +400,38 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
         pass |= ok ? (1u << (3 * i + s)) : 0u;
       }
     }
+    SAT_PROF(2);
+    // The passing pairs of the ROW are shared out evenly: a lane's own count varies from 0 to a dozen, and worked off lane by lane
+    // the loop ran as long as the unluckiest lane of the wave (7 k of the pair's 19 k cycles).  Every lane publishes its pass bits,
+    // reads all sixteen words, and takes the (j + 16 t)-th passing pair of the row's concatenated list: its owner lane w, the
+    // owner's slot and the prism edge come out of the bit position; the hull edge's vertices from the row's copy (S.VV).
+    S.PW[j] = __uint_as_float(pass);
+    ODK_SYNC();
+    int incl[16];
+    {
+      int run = 0;
+#pragma unroll
+      for (int w = 0; w < 16; w++) { run += __popc(__float_as_uint(S.PW[w])); incl[w] = run; }
+    }
+    const int total = incl[15];
     float best = -3.0e38f, bax[3] = {0.0f, 0.0f, 1.0f};
     int bi = 0x7FFFFFFF;
-    while (__builtin_amdgcn_ballot_w64(pass != 0u) != 0) {
-      const bool has = pass != 0u;
-      const int kk = has ? __ffs((int)pass) - 1 : 0;
-      pass &= pass - 1u;
+    for (int t = 0; __builtin_amdgcn_ballot_w64(16 * t < total) != 0; t++) {
+      const int g = j + 16 * t;
+      const bool has = g < total;
+      int w = 0, before = 0;
+#pragma unroll
+      for (int k = 0; k < 15; k++) { const bool ge = g >= incl[k]; w += ge ? 1 : 0; before = ge ? incl[k] : before; }
+      unsigned word = has ? __float_as_uint(S.PW[w]) : 1u;
+      for (int r = has ? g - before : 0; r > 0; r--) word &= word - 1u;       // drop the r lowest passing pairs of that lane
+      const int kk = __ffs((int)word) - 1;
       const int i = (kk * 11) >> 5, sl = kk - 3 * i;   // kk / 3 for kk < 27
       // prism edge i: vertices from the packed table (va | vb << 3, 6 bits per edge), geometry from the LDS copy
       const unsigned long long PKE = 0ull | (0ull | 1ull << 3) | ((1ull | 2ull << 3) << 6) | ((3ull | 5ull << 3) << 12) | ((0ull | 3ull << 3) << 18) |
                                      ((3ull | 4ull << 3) << 24) | ((1ull | 4ull << 3) << 30) | ((4ull | 5ull << 3) << 36) | ((2ull | 5ull << 3) << 42) | ((0ull | 2ull << 3) << 48);
       const int ve = (int)((PKE >> (6 * i)) & 63ull);
-      const int vv = sl == 0 ? RB.vv[0] : (sl == 1 ? RB.vv[1] : RB.vv[2]);
-      float pa[3], qa[3], pb[3], qb[3], ea[3], eb[3], ta[3], ax[3], t[3];
+      const int vv = __float_as_int(S.VV[3 * w + sl]);
+      float pa[3], qa[3], pb[3], qb[3], ea[3], eb[3], ta[3], ax[3], tt[3];
       ld3(pa, PV + 3 * (ve & 7)); ld3(qa, PV + 3 * (ve >> 3)); ld3(pb, B.V + 3 * (vv & 255)); ld3(qb, B.V + 3 * (vv >> 8));
       sub3(ea, qa, pa); sub3(eb, qb, pb); sub3(ta, pa, pc);
       cross3(ax, ea, eb);
@@ -411,16 +440,19 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
         const float inv = rsqrtf(l2);
         ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
         if (dot3(ax, ta) < 0.0f) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; }
-        sub3(t, pb, pa);
-        const float sp = dot3(ax, t);
-        const int id = (i << 8) | (j + 16 * sl);
+        sub3(tt, pb, pa);
+        const float sp = dot3(ax, tt);
+        const int id = (i << 8) | (w + 16 * sl);
         if (sp > best || (sp == best && id < bi)) { best = sp; bi = id; bax[0] = ax[0]; bax[1] = ax[1]; bax[2] = ax[2]; }
       }
     }
     pair = row_argmax(best, bi, sep_e);
-    const int src = pair & 15;
+    // the lane that worked the winning pair hands its axis to the row
+    const unsigned own = (unsigned)((__builtin_amdgcn_ballot_w64(bi == pair) >> (threadIdx.x & 48u)) & 0xFFFFull);
+    const int src = own ? __ffs((int)own) - 1 : 0;
     for (int k = 0; k < 3; k++) eax[k] = row_get(bax[k], src);
   }
+  SAT_PROF(3);
   const bool ref_a = sep_a >= sep_b;
   const float face_sep = ref_a ? sep_a : sep_b;
   const bool is_edge = pair != 0x7FFFFFFF && sep_e > face_sep + 1e-5f;
@@ -473,7 +505,9 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
     }
   }
   ODK_SYNC();
+  SAT_PROF(4);
   manifold_row(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act);
+  SAT_PROF(5);
   if (is_edge) {   // row-uniform
     int ia = pair >> 8, ib = pair & 255;
     ia = ia < 9 ? ia : 0; ib = ib < B.ne ? ib : 0;

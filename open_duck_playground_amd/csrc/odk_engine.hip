@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     g_par.store(L, drp != nullptr, lane);   // syncs
   }
 #ifdef ODK_PROFILE
-  if (lane < 28) L[S::O_SCR + S::S_PROF + lane] = 0;
+  for (int k = lane; k < 36; k += G) L[S::O_SCR + S::S_PROF + k] = 0;
 #endif
   Statics<S, G> st;
   load_statics<S, G>(st, m, lane);
@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   for (int u = lane; u < S::NU; u += G) L[S::O_CTRL + u] = a.action[(size_t)e * S::NU + u];
   load_params<S, G>(L, a.m, a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr, lane);
 #ifdef ODK_PROFILE
-  if (lane < 28) L[S::O_SCR + S::S_PROF + lane] = 0;
+  for (int k = lane; k < 36; k += G) L[S::O_SCR + S::S_PROF + k] = 0;
 #endif
   ODK_SYNC();
   Statics<S, G> st;

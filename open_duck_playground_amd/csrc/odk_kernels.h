@@ -128,7 +128,7 @@ struct Shape {
   static constexpr int O_CR = O_CDIST + NCON;        // [12][3] contact position relative to the base origin
   static constexpr int O_SCR = O_CR + 3 * NCON;      // scratch: foot twists, wrenches, 6x6 blocks, sensor inputs
 #ifdef ODK_PROFILE
-  static constexpr int N_SCR = 200;                  // + S_PROF (20) + S_PROF2 (8: sub-phases of the height-field contacts)
+  static constexpr int N_SCR = 208;                  // + S_PROF (20) + S_PROF2 (16: sub-phases of the height-field contacts)
 #else
   static constexpr int N_SCR = 172;                  // no S_PROF slots outside profile builds
 #endif
@@ -145,7 +145,8 @@ struct Shape {
   static constexpr int S_FFX = 144;   // [6] wrench sum of the foot-foot rows
   static constexpr int S_MISC = 156;  // misc scalars (16)
   static constexpr int S_PROF = 172;  // [20] per-phase cycle counters (ODK_PROFILE builds)
-  static constexpr int S_PROF2 = 192; // [8] height-field contacts: hull setup, cull pass, register loads, pair loop, iterations, list length, -, -
+  static constexpr int S_PROF2 = 192; // [16] height-field contacts: hull setup, cull pass, register loads, pair loop, iterations, list length, -, -,
+                                      //      then inside a pair: select + prism, face query, Gauss-map tests, passing pairs, faces / polygons, clip + manifold, merge
 };
 
 // Phase timing (build with -DODK_PROFILE): lane 0 accumulates shader-clock deltas per phase into the
@@ -918,7 +919,7 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
   edge_regs_load<3>(RB, B, j);
   edge_prepare_row(A, AE, j, row == 0);
   ODK_SYNC();
-  RowScratch RSS = {RS, RS + 12, RS + 24};
+  RowScratch RSS = {RS, RS + 12, RS + 24, nullptr, nullptr};
   sat_pair_row<3>(A, B, AE, RB, RSS, j, row == 0);
   if (act && j < 4) {
     const float* o = RS + 24 + 8 * j;
@@ -942,7 +943,7 @@ template <class S, int G>
 __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __restrict__ m, const float* __restrict__ hf, int lane) {
   constexpr int NB = S::NB;
   static_assert(G == 32, "height-field floors run 32 lanes per env (two 16-lane rows = two feet)");
-  static_assert(4 * S::NROW >= 344 && 16 * S::NB >= 282 && 6 * S::NVR >= 42 && S::NROW >= 72, "height-field scratch does not fit");
+  static_assert(4 * S::NROW >= 344 && 16 * S::NB >= 282 && 6 * S::NVR >= 106 && S::NROW >= 72, "height-field scratch does not fit");
   float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR;
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
@@ -960,7 +961,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   float* PV = RS;                                                      // prism vertices [6][3]
   float* RL = L + S::O_D + f * 172;
   float* LIST = RL; float* TOP = RL + 108; float* NEW = RL + 140;      // [18][6] | [4][8] | [4][8]
-  const RowScratch RSS = {RS + 18, RS + 30, NEW};                      // RP [4][3], IP [4][3]
+  const RowScratch RSS = {RS + 18, RS + 30, NEW, RS + 42, RS + 58};    // RP [4][3], IP [4][3], pass words [16], hull-edge vertex pairs [48]
   const float* Rh = m->floor_mat; const float ph[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
   // ---- the hull in the height field's frame: v_h = Rh^T (P + R v - ph)
   float Rw[9], Pw[3], cl[3];
@@ -1066,6 +1067,8 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   edge_regs_load<3>(RB, B, j);
   FaceRegs<2> FB;
   face_regs_load<2>(FB, B, j);
+  for (int sl = 0; sl < 3; sl++) RSS.VV[3 * j + sl] = __int_as_float(RB.vv[sl]);
+  ODK_SYNC();
   HF_PROF(2);
   // ---- pair loop.  Every contact of a pair is at least as far out as the pair's best separating axis, which is at least the prism's
   // own face separation `sep` (kept in the list): a prism whose sep lies beyond the fourth-deepest contact found so far cannot enter
@@ -1073,6 +1076,9 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   // the result does not depend on the order (entries are ranked by (dist, candidate index), like a stable sort of MJX's whole
   // candidate list).  Typically two or three of the six to eight overlapping prisms get the full test.
   unsigned done = 0u;   // row-uniform: list entries already taken
+#ifdef ODK_PROFILE
+  const long long _loop0 = clock64();
+#endif
 #pragma unroll 1
   for (;;) {
     asm volatile("; HF_LOOP_BEGIN" ::: "memory");
@@ -1099,14 +1105,26 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
       if (act && j < 6) { PV[3 * j] = vx; PV[3 * j + 1] = vy; PV[3 * j + 2] = vz; }
     }
     const float pc[3] = {(P.x[0] + P.x[1] + P.x[2]) * (1.0f / 3.0f), (P.y[0] + P.y[1] + P.y[2]) * (1.0f / 3.0f), (z[0] + z[1] + z[2] - 3.0f * base) * (1.0f / 6.0f)};
+#ifdef ODK_PROFILE
+    float* prof = lane == 0 ? L + S::O_SCR + S::S_PROF2 + 8 : nullptr;
+    long long tp = clock64();
+    if (prof) { prof[0] += (float)(tp - _hp); }
+    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act, prof, tp);
+#else
     sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act);
+#endif
     if (act && j < 4) NEW[8 * j + 7] = (float)(4 * p + j);   // candidate index in MJX's list: prism-major, then the pair's four slots
     ODK_SYNC();
     merge_top4_row(TOP, NEW, j, act);
+#ifdef ODK_PROFILE
+    { const long long t2 = clock64(); if (prof) prof[6] += (float)(t2 - tp); _hp = t2; }
+#endif
     HF_COUNT(4, 1);
     asm volatile("; HF_LOOP_END" ::: "memory");
   }
-  HF_PROF(3);
+#ifdef ODK_PROFILE
+  if (lane == 0) { const long long _t = clock64(); L[S::O_SCR + S::S_PROF2 + 3] += (float)(_t - _loop0); _hp = _t; }
+#endif
   // ---- the best four: contact distance, position (relative to the base origin), frame; back in the world frame
   float out[7];
   for (int k = 0; k < 7; k++) out[k] = TOP[8 * (j & 3) + k];

@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 img = b.lds_image()
 o = b.lds_offset("scr") + 172
 prof = img[:, o:o + 20].astype(np.float64)
-prof2 = img[:, o + 20:o + 28].astype(np.float64).mean(axis=0)
+prof2 = img[:, o + 20:o + 36].astype(np.float64).mean(axis=0)
 mean = prof.mean(axis=0)
 tot = mean[:18].sum()
 labels = ["P0 sincos", "P1 top-down sweep (pose,cdof,cvel,cacc,cinert)", "P2 bottom-up sweep (crb,cfrc)", "P3 per-dof bias/act/qfrc_smooth",
@@ -44,3 +44,6 @@ print(f"  {'env-step epilogue (last Euler -> kernel end)':48s} {mean[19]:12,.0f}
 if "rough" in task:
     print(f"  height-field contacts (per env step = 10 forwards): hull setup {prof2[0]:,.0f}  cull pass {prof2[1]:,.0f}  register loads {prof2[2]:,.0f}  "
           f"pair loop {prof2[3]:,.0f} cycles; loop iterations {prof2[4] / 10:.2f} per forward (longest row of the wave), list length of foot 0 {prof2[5] / 10:.2f}")
+    it = max(prof2[4], 1.0)
+    names = ["select + prism", "face query (hull faces)", "27 Gauss-map tests", "passing pairs", "faces / polygons", "clip + manifold selection", "contact writes + merge"]
+    print("  per pair-loop iteration (cycles): " + ", ".join(f"{nm} {prof2[8 + i] / it:,.0f}" for i, nm in enumerate(names)))
