@@ -333,9 +333,7 @@ __device__ __forceinline__ void prism_norm(const Prism& P, int f, float* o) {
   else if (f == 1) { o[0] = 0.0f; o[1] = 0.0f; o[2] = -1.0f; }
   else { o[0] = P.ns[f - 2][0]; o[1] = P.ns[f - 2][1]; o[2] = 0.0f; }
 }
-// unique edges (va, vb, face running va -> vb, face running vb -> va) and face polygons (count, vertices) of the prism
-__device__ constexpr int PRISM_EDGE[9][4] = {{0, 1, 0, 2}, {1, 2, 0, 3}, {3, 5, 1, 4}, {0, 3, 2, 4}, {3, 4, 2, 1}, {1, 4, 3, 2}, {4, 5, 3, 1}, {2, 5, 4, 3}, {0, 2, 4, 0}};
-__device__ constexpr int PRISM_POLY[5][5] = {{3, 0, 1, 2, 0}, {3, 3, 5, 4, 3}, {4, 0, 3, 4, 1}, {4, 1, 4, 5, 2}, {4, 2, 5, 3, 0}};
+// (PRISM_EDGE / PRISM_POLY: odk_model.h; only ever indexed with compile-time constants here)
 
 // the faces of the second polytope this lane owns (face j + 16 s): normal, plane offset n . v0, polygon packed 3 | 5 x 4 bits
 template <int NFS> struct FaceRegs { float d[NFS]; int poly[NFS]; bool on[NFS]; };   // (the normals are re-read from LDS per pair: registers are the scarce resource)

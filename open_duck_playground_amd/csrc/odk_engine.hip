@@ -1244,11 +1244,14 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       }
     }
   }
-  {   // a height-field prism's topology (odk_convex.h): vertices 0..2 top, 3..5 bottom
+  {   // a height-field prism's topology: the kernels' compile-time tables (odk_model.h) against this file's table builder
     const double pv[6][3] = {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {0, 0, 0}, {1, 0, 0}, {0, 1, 0}};
     const int ptri[8][3] = {{0, 1, 2}, {3, 5, 4}, {0, 3, 4}, {0, 4, 1}, {1, 4, 5}, {1, 5, 2}, {2, 5, 3}, {2, 3, 0}};
-    int np = 0, ne = 0; float fn[5][3], cc[3];
-    if (!build_convex_tables(pv, 6, ptri, 8, &np, m.prism_poly, fn, &ne, m.prism_edge, cc, 5, 9) || np != 5 || ne != 9) { delete mo; return fail(ODK_ERR_INVALID, "prism tables"); }
+    int np = 0, ne = 0, ppoly[5][5], pedge[9][4]; float fn[5][3], cc[3];
+    bool same = build_convex_tables(pv, 6, ptri, 8, &np, ppoly, fn, &ne, pedge, cc, 5, 9) && np == 5 && ne == 9;
+    for (int f = 0; same && f < 5; f++) for (int k = 0; k < 5; k++) same = same && ppoly[f][k] == PRISM_POLY[f][k];
+    for (int k = 0; same && k < 9; k++) for (int t = 0; t < 4; t++) same = same && pedge[k][t] == PRISM_EDGE[k][t];
+    if (!same) { delete mo; return fail(ODK_ERR_INVALID, "the kernels' compile-time prism tables disagree with build_convex_tables"); }
   }
   {
     int g = floor_cg[0];

@@ -120,14 +120,12 @@ struct DevModel {
   float foot_obb_center[2][3], foot_obb_half[2][3], foot_obb_axes[2][9];  // body-frame OBB (columns = axes)
   // convex-convex narrow phase (odk_convex.h): face polygons after the coplanar merge (count, then <= 4 vertices counter-clockwise
   // seen from outside), their outward normals in the BODY frame, unique edges (va, vb, face running va -> vb, face running
-  // vb -> va), an interior point; built at load (odk_engine.hip build_foot_convex).  prism_*: the same tables for a height-field
-  // prism (vertices 0..2 top, 3..5 bottom; faces: top, bottom, sides 0-1, 1-2, 2-0).
+  // vb -> va), an interior point; built at load (odk_engine.hip build_convex_tables).
   int foot_npoly[2], foot_nedge[2];
   int foot_poly[2][MAXHF][5];
   float foot_fnorm[2][MAXHF][3];
   int foot_edge[2][MAXHE][4];
   float foot_centroid[2][3];
-  int prism_poly[5][5], prism_edge[9][4];
   float plane_pos[3], plane_n[3], plane_frame[9];
   int floor_is_plane;
   // height-field floor (rough terrain): geom frame = (plane_pos, floor_mat); samples live in HBM (KArgs.hfield)
@@ -139,6 +137,13 @@ struct DevModel {
   int sensor_type[MAXSENS], sensor_site[MAXSENS], sensor_adr[MAXSENS];
   int adr_gyro, adr_local_linvel, adr_accelerometer, adr_upvector, adr_global_angvel, adr_foot_linvel[2];
 };
+
+// Topology of a height-field prism (vertices 0..2 = top triangle counter-clockwise seen from above, 3..5 below them; faces: top,
+// bottom, the sides over the edges 0-1, 1-2, 2-0): unique edges (va, vb, face running va -> vb, face running vb -> va) and face
+// polygons (count, vertices).  Compile-time for the kernels (odk_convex.h unrolls over them); odk_model_load checks at run time that
+// build_convex_tables -- the routine that prepares the foot hulls -- makes exactly these tables of a prism's eight triangles.
+constexpr int PRISM_EDGE[9][4] = {{0, 1, 0, 2}, {1, 2, 0, 3}, {3, 5, 1, 4}, {0, 3, 2, 4}, {3, 4, 2, 1}, {1, 4, 3, 2}, {4, 5, 3, 1}, {2, 5, 4, 3}, {0, 2, 4, 0}};
+constexpr int PRISM_POLY[5][5] = {{3, 0, 1, 2, 0}, {3, 3, 5, 4, 3}, {4, 0, 3, 4, 1}, {4, 1, 4, 5, 2}, {4, 2, 5, 3, 0}};
 
 // reference-motion table header (poly_reference_motion.py)
 struct DevPRM {
