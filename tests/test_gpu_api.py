@@ -362,3 +362,38 @@ def test_free_running_statistics_match_the_oracle(oracle_mod, parity_log, task):
         out[k + "_z"] = abs(mg - mo) / max(se, 1e-9)
         out[k + "_gpu"] = mg; out[k + "_oracle"] = float(mo)
     parity_log.check(f"free_running_statistics/{task}", dict(reward_z=4.0, done_z=4.0, contact_z=4.0, jspeed_z=4.0), **out)
+
+
+def test_config5_env_partition_at_full_size():
+    """BASELINE config 5's env side on one GPU: 65 536 envs of flat_terrain_backlash + randomize.py as ONE batch against the eight
+    8192-env shards the eight ranks would own (env_id_offset = rank x 8192, each shard with its slice of the per-env model fields):
+    observations, rewards, dones and states bit for bit equal over a few steps -- the partition is invisible, so the only thing an
+    8-GPU run adds to what is tested on one GPU is the gradient all-reduce (tests/test_gpu_learner.py, test_bench_ppo_mode)."""
+    import torch
+    from open_duck_playground_amd import engine, randomize
+    from open_duck_playground_amd.model import load_task_model
+    model = load_task_model("flat_terrain_backlash")
+    W, n = 8, 8192
+    fields, _ = randomize.domain_randomize(model, np.random.default_rng(3), W * n)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    acts = torch.empty(3, W * n, 14, device="cuda").uniform_(-1, 1, generator=g)
+    whole = engine.Batch(model, W * n)
+    randomize.apply(whole, fields)
+    whole.reset(seed=11, env_id_offset=0)
+    for t in range(3):
+        whole.step(acts[t])
+    ref = dict(obs=whole.obs.clone(), priv=whole.priv.clone(), reward=whole.reward.clone(), done=whole.done.clone())
+    qw = whole.get_state()[0]
+    whole.close()
+    assert torch.isfinite(ref["obs"]).all() and float(ref["reward"].max()) > 0
+    for r in range(W):
+        sl = slice(r * n, (r + 1) * n)
+        b = engine.Batch(model, n)
+        randomize.apply(b, {k: v[sl] for k, v in fields.items()})
+        b.reset(seed=11, env_id_offset=r * n)
+        for t in range(3):
+            b.step(acts[t, sl].contiguous())
+        for name in ("obs", "priv", "reward", "done"):
+            assert torch.equal(getattr(b, name), ref[name][sl]), (r, name)
+        assert np.array_equal(b.get_state()[0], qw[sl]), r
+        b.close()
