@@ -7,7 +7,7 @@ re-states the part of the MJCF compiler the Open Duck scenes actually use
 (SURVEY.md section 7 step 1):
 
   <include>, nested <default class>, childclass, <option>/<flag>, <compiler angle meshdir>,
-  bodies with <inertial fullinertia>, <freejoint>, hinge joints, mesh / plane / hfield geoms
+  bodies with <inertial fullinertia>, <freejoint>, hinge joints, mesh / box / plane / hfield geoms
   with contype/conaffinity/priority/friction/condim, sites, the 9 sensor types of
   xmls/open_duck_mini_v2.xml:26-42, <position> actuators with kp/kv/forcerange/inheritrange,
   <keyframe>.
@@ -248,7 +248,7 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
             friction=_floats(a.get("friction"), 3, DEFAULT_GEOM_FRICTION),
             pos=_floats(a.get("pos"), 3, [0, 0, 0]),
             quat=_normalize(_floats(a.get("quat"), 4, [1, 0, 0, 0])),
-            mesh=a.get("mesh"), hfield=a.get("hfield"),
+            mesh=a.get("mesh"), hfield=a.get("hfield"), size=_floats(a.get("size"), None, []) if a.get("size") else np.zeros(0),
             solref=_floats(a.get("solref"), 2, DEFAULT_SOLREF),
             solimp=_floats(a.get("solimp"), 5, DEFAULT_SOLIMP),
             solmix=float(a.get("solmix", 1.0)), margin=float(a.get("margin", 0.0)),
@@ -420,9 +420,16 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
     # ---- collision geoms (everything with contype|conaffinity != 0)
     col = [g for g in geoms if (g["contype"] or g["conaffinity"])]
     for g in col:
-        if g["type"] not in ("plane", "hfield", "mesh"):
-            raise NotImplementedError(f"colliding geom '{g['name']}' of type {g['type']}: only plane / hfield floors and convex meshes "
-                                      "collide in this engine (give visual primitives contype=conaffinity=0)")
+        if g["type"] == "box":
+            # a colliding box = the convex hull of its eight corners, which is how MJX collides a box with a plane, a height field
+            # or a mesh (collision_driver: plane_convex / hfield_convex / convex_convex take boxes as convex meshes)
+            if len(g["size"]) != 3:
+                raise ValueError(f"box geom '{g['name']}' needs size='hx hy hz'")
+            g["box_corners"] = np.array([[sx * g["size"][0], sy * g["size"][1], sz * g["size"][2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], np.float64)
+        elif g["type"] not in ("plane", "hfield", "mesh"):
+            raise NotImplementedError(f"colliding geom '{g['name']}' of type {g['type']}: plane / hfield floors, convex meshes and boxes "
+                                      "collide in this engine; spheres, capsules, ellipsoids and cylinders do not (give visual "
+                                      "primitives contype=conaffinity=0)")
     col_ids = [i for i, g in enumerate(geoms) if (g["contype"] or g["conaffinity"])]
     geom_name2id = {g["name"]: i for i, g in enumerate(geoms) if g["name"]}
 
@@ -504,7 +511,7 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
     # collision geoms: the scenes have exactly {plane|hfield floor, 2 convex foot meshes}
     ncol = len(col)
     out["cgeom_id"] = I32(col_ids)
-    out["cgeom_type"] = I32([{"plane": GEOM_PLANE, "hfield": GEOM_HFIELD, "mesh": GEOM_MESH}[g["type"]] for g in col])
+    out["cgeom_type"] = I32([{"plane": GEOM_PLANE, "hfield": GEOM_HFIELD, "mesh": GEOM_MESH, "box": GEOM_MESH}[g["type"]] for g in col])
     out["cgeom_bodyid"] = I32([g["body"] for g in col])
     out["cgeom_pos"] = F64([g["pos"] for g in col]); out["cgeom_quat"] = F64([g["quat"] for g in col])
     out["cgeom_friction"] = F64([g["friction"] for g in col])
@@ -516,12 +523,13 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
     vadr, vnum, fadr, fnum, allv, allf = [], [], [], [], [], []
     cache = {}
     for g in col:
-        if g["type"] == "mesh":
-            if g["mesh"] not in cache:
-                hv, hf = convex_hull(load_stl_vertices(meshes[g["mesh"]]))
-                cache[g["mesh"]] = (sum(len(v) for v in allv), len(hv), sum(len(f) for f in allf), len(hf))
+        if g["type"] in ("mesh", "box"):
+            ckey = g["mesh"] if g["type"] == "mesh" else ("box",) + tuple(g["size"])
+            if ckey not in cache:
+                hv, hf = convex_hull(load_stl_vertices(meshes[g["mesh"]]) if g["type"] == "mesh" else g["box_corners"])
+                cache[ckey] = (sum(len(v) for v in allv), len(hv), sum(len(f) for f in allf), len(hf))
                 allv.append(hv); allf.append(hf)
-            va, vn, fa, fn = cache[g["mesh"]]
+            va, vn, fa, fn = cache[ckey]
         else:
             va, vn, fa, fn = 0, 0, 0, 0
         vadr.append(va); vnum.append(vn); fadr.append(fa); fnum.append(fn)

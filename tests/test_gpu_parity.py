@@ -382,3 +382,78 @@ def test_yaw_equivariance_full_size(torch_cuda):
     assert np.quantile(err_p, 0.99) < 2e-5 and np.quantile(err_j, 0.99) < 2e-4, (np.quantile(err_p, 0.99), np.quantile(err_j, 0.99))
     assert np.quantile(err_v, 0.99) < 2e-3 and np.quantile(err_w, 0.99) < 2e-2, (np.quantile(err_v, 0.99), np.quantile(err_w, 0.99))
     assert np.median(err_j) < 2e-6 and np.median(err_p) < 1e-6
+
+
+def _box_feet_variant(task):
+    """the task's model with both foot meshes replaced by a BOX collider of the sole's size (what the compiler emits for
+    <geom type="box">: eight corners, twelve outward triangles), in the same geom frame"""
+    from open_duck_playground_amd.mjcf import convex_hull
+    from open_duck_playground_amd.model import Model, load_task_model
+    base = load_task_model(task)
+    a = dict(base.a)
+    v = np.asarray(a["hull_vert"])[: int(a["cgeom_vertnum"][0])]
+    lo, hi = v.min(0), v.max(0)
+    corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+    hv, hf = convex_hull(corners)
+    a["hull_vert"] = hv; a["hull_face"] = hf
+    for k, val in (("cgeom_vertadr", 0), ("cgeom_vertnum", len(hv)), ("cgeom_faceadr", 0), ("cgeom_facenum", len(hf))):
+        arr = np.array(a[k]); arr[:2] = val; a[k] = arr
+    return Model(a, base.xml_path)
+
+
+@pytest.mark.parametrize("task", ["flat_terrain", "rough_terrain_backlash"])
+def test_box_feet_variant(torch_cuda, oracle_mod, parity_log, task):
+    """SURVEY 8(f).3, first step: a colliding BOX (the compiler turns it into its corner hull: tests/test_mjcf_box.py) in place of
+    the foot meshes runs through the same kernels -- plane-convex on the flat floor, the prism routine on the height field, the
+    convex-convex routine between the feet -- and agrees with the oracle like the mesh feet do."""
+    from open_duck_playground_amd import engine
+    torch = torch_cuda
+    model = _box_feet_variant(task)
+    assert int(model.a["cgeom_vertnum"][0]) == 8
+    om = oracle_mod.OracleModel(model.blob())
+    assert om.convex_counts(0) == (8, 6, 12)
+    n = 48
+    rng = np.random.default_rng(31)
+    qpos, qvel = _random_states(model, n, rng)
+    if "rough" in task:
+        qpos = _settle_on_terrain(oracle_mod, om, qpos, rng, qpos[:, 2] > 0.25)
+    else:   # a third of the poses with the feet pressed against each other, off the floor
+        aq = build_tables(model)["k_act_qposadr"]
+        for e in range(0, n, 3):
+            qpos[e] = np.asarray(model.a["key_qpos"]); qpos[e, 2] = 0.3
+            qpos[e, int(aq[1])] = rng.uniform(0.4, 0.6); qpos[e, int(aq[10])] = rng.uniform(-0.6, -0.4); qpos[e, int(aq[0])] += rng.uniform(-0.3, 0.3)
+    ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.3, 0.3, (n, 14))
+    b = engine.Batch(model, n)
+    b.set_state(qpos, qvel, np.zeros((n, model.nv)))
+    b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 1)
+    gq, gv, _ = b.get_state()
+    img = b.lds_image()
+    o_cd = b.lds_offset("contact_dist")
+    prng = np.random.default_rng(32)
+    W = dict(dist=0.0, qpos=0.0, qvel=0.0)
+    n_tie = n_contact = n_ff = 0
+    for e in range(n):
+        d = oracle_mod.OracleData(om)
+        d["qpos"][: om.nq] = qpos[e]; d["qvel"][: om.nv] = qvel[e]; d["ctrl"][:14] = ctrl[e]
+        d.forward()
+        cd_o = np.array(d["contact_dist"][:12]); cd_g = img[e][o_cd: o_cd + 12]
+        n_contact += int((cd_o[:8] < 0).any()); n_ff += int((cd_o[8:] < 0).any())
+        if _contact_tie(oracle_mod, om, qpos[e], qvel[e], ctrl[e], prng, _contacts(d)):
+            n_tie += 1
+            continue
+        act = cd_o < 0
+        assert set(np.flatnonzero(act)) == set(np.flatnonzero(cd_g < 0)), e
+        if act.any():
+            W["dist"] = max(W["dist"], np.abs(cd_g[act] - cd_o[act]).max())
+        ds = _oracle_step(oracle_mod, om, qpos[e], qvel[e], np.zeros(model.nv), ctrl[e], 1)
+        W["qpos"] = max(W["qpos"], _rel(gq[e], ds["qpos"][: om.nq], 1e-2).max())
+        W["qvel"] = max(W["qvel"], _rel(gv[e], ds["qvel"][: om.nv], 1.0).max())
+    b.close()
+    assert n_contact >= n // 3 and ("rough" in task or n_ff >= 5), (n_contact, n_ff)
+    # a box sole is exactly flat: on the plane its four corners tie in depth whenever the foot lies flat (rare in these random poses)
+    parity_log.check(f"box_feet/{task}", dict(dist=1e-6, qpos=1e-5, qvel=4e-5, tie_fraction=0.6), tie_fraction=n_tie / n, **W)
+
+
+def build_tables(model):
+    from open_duck_playground_amd.tables import build_kernel_tables
+    return build_kernel_tables(model.a)
