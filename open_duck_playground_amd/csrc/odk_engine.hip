@@ -1201,6 +1201,8 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I("cgeom_vertadr", cg_vadr, 4); B.I("cgeom_vertnum", cg_vnum, 4); B.I("cgeom_faceadr", cg_fadr, 4); B.I("cgeom_facenum", cg_fnum, 4);
   B.D("cgeom_pos", cg_pos, 12); B.D("cgeom_quat", cg_quat, 16); B.D("cgeom_friction", cg_fric, 12);
   B.D("cgeom_solref", cg_solref, 8); B.D("cgeom_solimp", cg_solimp, 20); B.D("cgeom_solmix", cg_solmix, 4);
+  double cg_size[12] = {0};
+  { const bool was_ok = B.ok; const std::string miss = B.missing; B.D("cgeom_size", cg_size, 12); B.ok = was_ok; B.missing = miss; }   // optional: absent in blobs without primitive colliders
   int nhv = B.D("hull_vert", hv, 64 * 3) / 3; int nhf = B.I("hull_face", hf, 128 * 3) / 3;
   B.D("body_invweight0", biw, MAXB * 2);
   B.I("k_foot_body", m.foot_body, 2); B.I2("k_foot_dofmask", &m.foot_dofmask[0][0], 2, MAXV);
@@ -1211,11 +1213,25 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   }
   if (!B.ok || ncg != 3) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   (void)nhv; (void)nhf;
+  m.foot_prim = 0;
   for (int f = 0; f < 2; f++) {
     int g = foot_cg[f];
     if (cg_vnum[g] > MAXHV || cg_fnum[g] > MAXHF || cg_condim[g] != 3) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull too large / condim != 3"); }
     double gm[9];
     quat2mat(cg_quat + 4 * g, gm);
+    m.foot_gtype[f] = cg_type[g];
+    for (int k = 0; k < 3; k++) { m.foot_gpos[f][k] = (float)cg_pos[3 * g + k]; m.foot_gaxis[f][k] = (float)gm[3 * k + 2]; m.foot_gsize[f][k] = (float)cg_size[3 * g + k]; }
+    if (cg_type[g] == 2 || cg_type[g] == 3) {   // sphere / capsule foot: no hull; bounding box for the records only
+      if (!(cg_size[3 * g] > 0) || (cg_type[g] == 3 && !(cg_size[3 * g + 1] > 0))) { delete mo; return fail(ODK_ERR_INVALID, "primitive foot collider without a size"); }
+      m.foot_prim = 1;
+      m.foot_nvert[f] = 0; m.foot_nface[f] = 0; m.foot_npoly[f] = 0; m.foot_nedge[f] = 0;
+      const double hz = cg_type[g] == 3 ? cg_size[3 * g] + cg_size[3 * g + 1] : cg_size[3 * g];
+      m.foot_obb_half[f][0] = m.foot_obb_half[f][1] = (float)cg_size[3 * g]; m.foot_obb_half[f][2] = (float)hz;
+      for (int k = 0; k < 3; k++) { m.foot_obb_center[f][k] = (float)cg_pos[3 * g + k]; m.foot_centroid[f][k] = (float)cg_pos[3 * g + k]; }
+      for (int k = 0; k < 9; k++) m.foot_obb_axes[f][k] = (float)gm[k];
+      continue;
+    }
+    if (cg_type[g] != 7) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot collider must be a convex mesh / box hull, a sphere or a capsule"); }
     m.foot_nvert[f] = cg_vnum[g]; m.foot_nface[f] = cg_fnum[g];
     double lo[3] = {1e30, 1e30, 1e30}, hi[3] = {-1e30, -1e30, -1e30};
     for (int v = 0; v < cg_vnum[g]; v++) {
@@ -1256,6 +1272,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   {
     int g = floor_cg[0];
     m.floor_is_plane = cg_type[g] == 0;
+    if (!m.floor_is_plane && m.foot_prim) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "sphere / capsule feet on a height-field floor (MJX hfield_sphere / hfield_capsule) are not built"); }
     double pm[9];
     quat2mat(cg_quat + 4 * g, pm);
     // floor body is static at the world origin in every reference scene

@@ -1142,6 +1142,112 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   }
 }
 
+// Primitive foot colliders (sphere / capsule feet on the plane floor): mjx collision_primitive.py as the oracle restates
+// it -- plane_sphere, plane_capsule (two contacts, frame aligned with the capsule axis), sphere_sphere, sphere_capsule,
+// capsule_capsule.  A handful of scalar operations: lane 0 of the env does them; out of line so that the duck's own kernels pay one
+// uniform branch.  Writes all twelve contact slots, the eight floor-contact frames (jv rows, as the height-field path) and the
+// foot-foot frame (S_VF, as the convex-convex path).
+template <class S, int G>
+__device__ __noinline__ void prim_contacts(float* L, const DevModel* __restrict__ m, int lane) {
+  constexpr int NB = S::NB;
+  float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR; float* FR = L + S::O_JV;
+  const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
+  if (lane != 0) return;
+  const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
+  const float pn[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]}, pp[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
+  float cw[2][3], aw[2][3];
+  for (int f = 0; f < 2; f++) {
+    const int fb = m->foot_body[f];
+    float q[4], R[9];
+    for (int t = 0; t < 4; t++) q[t] = XQUAT[t * NB + fb];
+    q2mat(R, q);
+    for (int t = 0; t < 3; t++) {
+      cw[f][t] = XPOS[t * NB + fb] + R[3 * t] * m->foot_gpos[f][0] + R[3 * t + 1] * m->foot_gpos[f][1] + R[3 * t + 2] * m->foot_gpos[f][2];
+      aw[f][t] = R[3 * t] * m->foot_gaxis[f][0] + R[3 * t + 1] * m->foot_gaxis[f][1] + R[3 * t + 2] * m->foot_gaxis[f][2];
+    }
+  }
+  auto put = [&](int c, float dist, const float* pos) { CDIST[c] = dist; CR[3 * c] = pos[0] - ref[0]; CR[3 * c + 1] = pos[1] - ref[1]; CR[3 * c + 2] = pos[2] - ref[2]; };
+  const float zero3[3] = {ref[0], ref[1], ref[2]};
+  // ---- floor
+  for (int f = 0; f < 2; f++) {
+    const float r = m->foot_gsize[f][0], hl = m->foot_gsize[f][1];
+    const bool cap = m->foot_gtype[f] == 3;
+    float fr[9];
+    if (cap) {   // frame aligned with the capsule axis: b = axis - n (n . axis), y / z when the capsule stands on end
+      float b[3];
+      const float na = dot3(pn, aw[f]);
+      for (int t = 0; t < 3; t++) b[t] = aw[f][t] - pn[t] * na;
+      const float bn = sqrtf(dot3(b, b));
+      if (bn < 0.5f) { const bool yy = -0.5f < pn[1] && pn[1] < 0.5f; b[0] = 0.0f; b[1] = yy ? 1.0f : 0.0f; b[2] = yy ? 0.0f : 1.0f; }
+      else { const float inv = 1.0f / bn; b[0] *= inv; b[1] *= inv; b[2] *= inv; }
+      fr[0] = pn[0]; fr[1] = pn[1]; fr[2] = pn[2]; fr[3] = b[0]; fr[4] = b[1]; fr[5] = b[2];
+      cross3(fr + 6, pn, b);
+    } else {
+      make_frame_dev(pn, fr);
+    }
+    const int nco = cap ? 2 : 1;
+    for (int s = 0; s < 4; s++) {
+      const int c = 4 * f + s;
+      if (s < nco) {
+        const float sg = cap ? (s == 0 ? hl : -hl) : 0.0f;
+        const float e[3] = {cw[f][0] + sg * aw[f][0], cw[f][1] + sg * aw[f][1], cw[f][2] + sg * aw[f][2]};
+        const float dist = (e[0] - pp[0]) * pn[0] + (e[1] - pp[1]) * pn[1] + (e[2] - pp[2]) * pn[2] - r;
+        const float pos[3] = {e[0] - pn[0] * (r + 0.5f * dist), e[1] - pn[1] * (r + 0.5f * dist), e[2] - pn[2] * (r + 0.5f * dist)};
+        put(c, dist, pos);
+      } else {
+        put(c, 1.0f, zero3);
+      }
+      for (int t = 0; t < 9; t++) FR[9 * c + t] = fr[t];
+    }
+  }
+  // ---- foot against foot: closest points of the two axes' segments (a sphere: a segment of length zero), then sphere_sphere
+  auto seg_point = [](const float* a, const float* b, const float* pt, float* out) {   // math.closest_segment_point
+    float ab[3], t[3];
+    sub3(ab, b, a); sub3(t, pt, a);
+    float tt = dot3(t, ab) / (dot3(ab, ab) + 1e-6f);
+    tt = fminf(fmaxf(tt, 0.0f), 1.0f);
+    for (int i = 0; i < 3; i++) out[i] = a[i] + tt * ab[i];
+  };
+  float p1[3], p2[3];
+  const bool c1 = m->foot_gtype[0] == 3, c2 = m->foot_gtype[1] == 3;
+  const float h1 = m->foot_gsize[0][1], h2 = m->foot_gsize[1][1];
+  float a0[3], a1[3], b0[3], b1[3];
+  for (int t = 0; t < 3; t++) { a0[t] = cw[0][t] - h1 * aw[0][t]; a1[t] = cw[0][t] + h1 * aw[0][t]; b0[t] = cw[1][t] - h2 * aw[1][t]; b1[t] = cw[1][t] + h2 * aw[1][t]; }
+  if (c1 && c2) {   // math.closest_segment_to_segment_points
+    float da[3], db[3], am[3], bm[3], diff[3];
+    sub3(da, a1, a0); sub3(db, b1, b0);
+    const float la = sqrtf(dot3(da, da)), lb = sqrtf(dot3(db, db));
+    for (int t = 0; t < 3; t++) { da[t] /= la; db[t] /= lb; am[t] = 0.5f * (a0[t] + a1[t]); bm[t] = 0.5f * (b0[t] + b1[t]); }
+    sub3(diff, am, bm);
+    const float dota = dot3(da, diff), dotb = dot3(db, diff), dab = dot3(da, db);
+    const float ota = (-dota + dab * dotb) / (1.0f - dab * dab + 1e-6f), otb = dotb + ota * dab;
+    const float ta = fminf(fmaxf(ota, -0.5f * la), 0.5f * la), tb = fminf(fmaxf(otb, -0.5f * lb), 0.5f * lb);
+    float ca[3], cb[3], na[3], nb[3], t1[3], t2[3];
+    for (int t = 0; t < 3; t++) { ca[t] = am[t] + ta * da[t]; cb[t] = bm[t] + tb * db[t]; }
+    seg_point(a0, a1, cb, na); seg_point(b0, b1, ca, nb);
+    sub3(t1, na, cb); sub3(t2, ca, nb);
+    const bool first = dot3(t1, t1) < dot3(t2, t2);
+    for (int t = 0; t < 3; t++) { p1[t] = first ? na[t] : ca[t]; p2[t] = first ? cb[t] : nb[t]; }
+  } else if (c2) { ld3(p1, cw[0]); seg_point(b0, b1, cw[0], p2); }
+  else if (c1) { ld3(p1, cw[1]); seg_point(a0, a1, cw[1], p2); }   // geoms ordered by type (mjx): the sphere is geom 1, the normal points from it to the capsule
+  else { ld3(p1, cw[0]); ld3(p2, cw[1]); }
+  {
+    const bool swapped = c1 && !c2;
+    const float r1 = m->foot_gsize[swapped ? 1 : 0][0], r2 = m->foot_gsize[swapped ? 0 : 1][0];
+    float n[3];
+    sub3(n, p2, p1);
+    const float len = sqrtf(dot3(n, n));
+    if (len < 1e-15f) { n[0] = 1.0f; n[1] = 0.0f; n[2] = 0.0f; } else { const float inv = 1.0f / len; n[0] *= inv; n[1] *= inv; n[2] *= inv; }
+    const float dist = len - (r1 + r2);
+    const float pos[3] = {p1[0] + n[0] * (r1 + 0.5f * dist), p1[1] + n[1] * (r1 + 0.5f * dist), p1[2] + n[2] * (r1 + 0.5f * dist)};
+    put(8, dist, pos);
+    for (int s = 1; s < 4; s++) put(8 + s, 1.0f, zero3);
+    make_frame_dev(n, SCR + S::S_VF);
+    // the Jacobian rows are frame . (v(foot 1) - v(foot 0)): with the geoms swapped that is (-frame) . (v(geom 2) - v(geom 1))
+    if (swapped) for (int t = 0; t < 9; t++) SCR[S::S_VF + t] = -SCR[S::S_VF + t];
+  }
+}
+
 template <class S, int G, bool HF>
 __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags) {
   // RT: the packed reduced entries (DevModel::R_ent) in LDS, one copy per workgroup (load_shared): every substep reads them
@@ -1631,6 +1737,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   if constexpr (HF) {
     // height-field floor (rough terrain; its own kernel instantiation): prisms of the cells under each foot, out of line
     hfield_contacts<S, G>(L, m, hfield, lane);
+  } else if (m->foot_prim) {
+    prim_contacts<S, G>(L, m, lane);   // sphere / capsule feet (model-uniform branch): floor and foot-foot contacts, out of line
   } else {
   const float pn0[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
   {
@@ -1679,7 +1787,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   ODK_PROF(7);
   // foot-foot: bounding spheres first (a positive gap already means "inactive pair"); only when the spheres of some env
   // in the wave touch: oriented-box cull, 15 axes on 15 lanes (a positive box separation bounds the hulls' from below)
-  {
+  if (!m->foot_prim) {
     float sep = -3.0e38f;
     float sph;
     {
@@ -1774,6 +1882,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   // foot-foot rows (32..47) are skipped wave-wide unless some env has a penetrating foot-foot contact (D = 0 rows
   // are never read again: the solver gates on D > 0 and on the same wave-uniform flag)
   const bool ff_rows = __builtin_amdgcn_ballot_w64(fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0.0f) != 0;
+  const bool prim_feet = !HF && m->foot_prim != 0;   // sphere / capsule feet: per-contact frames in the jv rows (prim_contacts)
   for (int rc = lane; rc < S::NCROW; rc += G) {
     const int r = r0c + rc, c = rc >> 2, s = rc & 3, pair = c >> 2;
     if (rc >= 32 && !ff_rows) { ED[r] = 0.0f; AREF[r] = 0.0f; continue; }
@@ -1781,7 +1890,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     const float mu = CT[pair];
     const float fs = (s & 1) ? -mu : mu;
     // foot-foot frame: left in S_VF by the SAT routine; height-field floor: one frame per contact left in the jv rows by P7
-    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && HF) ? L + S::O_JV + 9 * c : CT + 33);
+    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && (HF || prim_feet)) ? L + S::O_JV + 9 * c : CT + 33);
     const int td = 3 * (1 + (s >> 1));
     const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
     const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};

@@ -126,6 +126,10 @@ struct DevModel {
   float foot_fnorm[2][MAXHF][3];
   int foot_edge[2][MAXHE][4];
   float foot_centroid[2][3];
+  // primitive colliders in place of the foot hulls (mjtGeom: 2 sphere, 3 capsule; 7 = convex hull, the duck's own): centre and, for a
+  // capsule, the axis (the geom frame's z) in the BODY frame; size = radius, half length.  foot_prim = some foot is a primitive.
+  int foot_prim, foot_gtype[2];
+  float foot_gpos[2][3], foot_gaxis[2][3], foot_gsize[2][3];
   float plane_pos[3], plane_n[3], plane_frame[9];
   int floor_is_plane;
   // height-field floor (rough terrain): geom frame = (plane_pos, floor_mat); samples live in HBM (KArgs.hfield)

@@ -30,7 +30,7 @@ import numpy as np
 
 # MuJoCo enum values kept so index tables read like the reference's (base.py:88-100).
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
-GEOM_PLANE, GEOM_HFIELD, GEOM_MESH = 0, 1, 7
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_MESH = 0, 1, 2, 3, 7   # mjtGeom
 
 # sensor type codes (own numbering; order = first appearance in open_duck_mini_v2.xml:26-42)
 SENS_GYRO, SENS_VELOCIMETER, SENS_ACCELEROMETER = 0, 1, 2
@@ -249,6 +249,7 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
             pos=_floats(a.get("pos"), 3, [0, 0, 0]),
             quat=_normalize(_floats(a.get("quat"), 4, [1, 0, 0, 0])),
             mesh=a.get("mesh"), hfield=a.get("hfield"), size=_floats(a.get("size"), None, []) if a.get("size") else np.zeros(0),
+            fromto=_floats(a.get("fromto"), 6) if a.get("fromto") else None,
             solref=_floats(a.get("solref"), 2, DEFAULT_SOLREF),
             solimp=_floats(a.get("solimp"), 5, DEFAULT_SOLIMP),
             solmix=float(a.get("solmix", 1.0)), margin=float(a.get("margin", 0.0)),
@@ -426,10 +427,29 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
             if len(g["size"]) != 3:
                 raise ValueError(f"box geom '{g['name']}' needs size='hx hy hz'")
             g["box_corners"] = np.array([[sx * g["size"][0], sy * g["size"][1], sz * g["size"][2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], np.float64)
+        elif g["type"] == "sphere":
+            if len(g["size"]) < 1:
+                raise ValueError(f"sphere geom '{g['name']}' needs size='r'")
+        elif g["type"] == "capsule":
+            if g["fromto"] is not None:      # MuJoCo: the geom frame's z axis runs from -> to, pos = the midpoint, size = radius (half length derived)
+                p0, p1 = g["fromto"][:3], g["fromto"][3:]
+                ax = p1 - p0; hl = 0.5 * float(np.linalg.norm(ax)); ax = ax / (2 * hl)
+                g["pos"] = 0.5 * (p0 + p1)
+                z = np.array([0.0, 0.0, 1.0]); c = float(z @ ax)
+                if c < -1 + 1e-12:
+                    g["quat"] = np.array([0.0, 1.0, 0.0, 0.0])
+                else:
+                    w = np.cross(z, ax); q = np.array([1.0 + c, w[0], w[1], w[2]]); g["quat"] = q / np.linalg.norm(q)
+                g["size"] = np.array([float(g["size"][0]), hl])
+            if len(g["size"]) < 2:
+                raise ValueError(f"capsule geom '{g['name']}' needs size='r half_length' or fromto")
         elif g["type"] not in ("plane", "hfield", "mesh"):
-            raise NotImplementedError(f"colliding geom '{g['name']}' of type {g['type']}: plane / hfield floors, convex meshes and boxes "
-                                      "collide in this engine; spheres, capsules, ellipsoids and cylinders do not (give visual "
+            raise NotImplementedError(f"colliding geom '{g['name']}' of type {g['type']}: plane / hfield floors, convex meshes, boxes, "
+                                      "spheres and capsules collide in this engine; ellipsoids and cylinders do not (give visual "
                                       "primitives contype=conaffinity=0)")
+    if any(g["type"] == "hfield" for g in col) and any(g["type"] in ("sphere", "capsule") for g in col):
+        raise NotImplementedError("spheres / capsules against a height field (MJX hfield_sphere / hfield_capsule) are not supported: "
+                                  "the height-field floor takes convex meshes and boxes")
     col_ids = [i for i, g in enumerate(geoms) if (g["contype"] or g["conaffinity"])]
     geom_name2id = {g["name"]: i for i, g in enumerate(geoms) if g["name"]}
 
@@ -511,7 +531,9 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
     # collision geoms: the scenes have exactly {plane|hfield floor, 2 convex foot meshes}
     ncol = len(col)
     out["cgeom_id"] = I32(col_ids)
-    out["cgeom_type"] = I32([{"plane": GEOM_PLANE, "hfield": GEOM_HFIELD, "mesh": GEOM_MESH, "box": GEOM_MESH}[g["type"]] for g in col])
+    out["cgeom_type"] = I32([{"plane": GEOM_PLANE, "hfield": GEOM_HFIELD, "mesh": GEOM_MESH, "box": GEOM_MESH, "sphere": GEOM_SPHERE,
+                              "capsule": GEOM_CAPSULE}[g["type"]] for g in col])
+    out["cgeom_size"] = F64([list(g["size"][:3]) + [0.0] * (3 - min(len(g["size"]), 3)) if g["type"] in ("sphere", "capsule") else [0.0, 0.0, 0.0] for g in col])
     out["cgeom_bodyid"] = I32([g["body"] for g in col])
     out["cgeom_pos"] = F64([g["pos"] for g in col]); out["cgeom_quat"] = F64([g["quat"] for g in col])
     out["cgeom_friction"] = F64([g["friction"] for g in col])

@@ -276,12 +276,13 @@ def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
         dof_limrow[a["jnt_dofadr"][j]] = r
     out["k_dof_flrow"] = dof_flrow; out["k_dof_limrow"] = dof_limrow
 
-    # ---- feet / floor (collision geoms: exactly two convex meshes and one plane/hfield)
+    # ---- feet / floor (collision geoms: exactly two foot colliders -- convex meshes / box hulls, or spheres / capsules -- and
+    # one plane / hfield)
     ctype = a["cgeom_type"]
-    feet = [g for g in range(len(ctype)) if ctype[g] == 7]
+    feet = [g for g in range(len(ctype)) if ctype[g] in (2, 3, 7)]
     floor = [g for g in range(len(ctype)) if ctype[g] in (0, 1)]
     if len(feet) != 2 or len(floor) != 1:
-        raise ValueError("kernels expect two foot meshes and one floor geom")
+        raise ValueError("kernels expect two foot colliders and one floor geom")
     out["k_foot_cgeom"] = I(feet); out["k_floor_cgeom"] = I(floor)
     foot_body = [int(a["cgeom_bodyid"][g]) for g in feet]
     out["k_foot_body"] = I(foot_body)
@@ -293,6 +294,10 @@ def build_kernel_tables(a: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     # hull AABB (geom-local) for the foot-foot cull
     obb_c, obb_h = [], []
     for g in feet:
+        if ctype[g] != 7:   # primitive: the box around the sphere / capsule (its axis is the geom frame's z)
+            r, hl = float(a["cgeom_size"][g][0]), float(a["cgeom_size"][g][1]) if ctype[g] == 3 else 0.0
+            obb_c.append(np.zeros(3)); obb_h.append(np.array([r, r, r + hl]))
+            continue
         v = a["hull_vert"][a["cgeom_vertadr"][g]: a["cgeom_vertadr"][g] + a["cgeom_vertnum"][g]]
         obb_c.append(0.5 * (v.min(0) + v.max(0))); obb_h.append(0.5 * (v.max(0) - v.min(0)))
     out["k_foot_obb_center"] = np.asarray(obb_c, np.float64); out["k_foot_obb_half"] = np.asarray(obb_h, np.float64)

@@ -176,6 +176,7 @@ odko_model* odko_model_load(const void* blob, uint64_t len) {
   LI("cgeom_vertadr", m->cgeom_vertadr, ODKO_MAXG); LI("cgeom_vertnum", m->cgeom_vertnum, ODKO_MAXG);
   LI("cgeom_faceadr", m->cgeom_faceadr, ODKO_MAXG); LI("cgeom_facenum", m->cgeom_facenum, ODKO_MAXG);
   LF("cgeom_pos", m->cgeom_pos, ODKO_MAXG * 3); LF("cgeom_quat", m->cgeom_quat, ODKO_MAXG * 4);
+  load_f(b, len, "cgeom_size", (real*)m->cgeom_size, ODKO_MAXG * 3); /* optional: blobs of models without primitive colliders predate it */
   LF("cgeom_friction", m->cgeom_friction, ODKO_MAXG * 3); LF("cgeom_solref", m->cgeom_solref, ODKO_MAXG * 2);
   LF("cgeom_solimp", m->cgeom_solimp, ODKO_MAXG * 5); LF("cgeom_solmix", m->cgeom_solmix, ODKO_MAXG);
   m->nhullvert = load_f(b, len, "hull_vert", (real*)m->hull_vert, ODKO_MAXHV * 3) / 3;
@@ -189,18 +190,20 @@ odko_model* odko_model_load(const void* blob, uint64_t len) {
           load_f(b, len, "hfield_size", m->hfield_size, 4) < 0) { free(m); return NULL; }
     }
   }
-  /* contact pairs: contype/conaffinity filter, same-body and parent-child(weld) exclusion;
-     order: plane/hfield-vs-mesh pairs first (by geom id), then mesh-mesh (MJX groups by type pair) */
+  /* contact pairs: contype/conaffinity filter, same-weld-body exclusion, parent-child exclusion (MuJoCo's filterparent: the
+     welded parents, the world excepted); order: the floor's pairs (plane / hfield against anything) first, by geom id, then the
+     pairs between body geoms (MJX groups by type pair, and the floor types are the lowest) */
   m->npair = 0;
   for (int pass = 0; pass < 2; pass++)
     for (int i = 0; i < m->ncgeom; i++)
       for (int j = i + 1; j < m->ncgeom; j++) {
         int ti = m->cgeom_type[i], tj = m->cgeom_type[j];
-        int mm = (ti == ODKO_GEOM_MESH && tj == ODKO_GEOM_MESH);
+        int mm = !(ti == ODKO_GEOM_PLANE || ti == ODKO_GEOM_HFIELD || tj == ODKO_GEOM_PLANE || tj == ODKO_GEOM_HFIELD);
         if ((pass == 0) == mm) continue;
         if (!((m->cgeom_contype[i] & m->cgeom_conaffinity[j]) || (m->cgeom_contype[j] & m->cgeom_conaffinity[i]))) continue;
         int b1 = m->body_weldid[m->cgeom_bodyid[i]], b2 = m->body_weldid[m->cgeom_bodyid[j]];
         if (b1 == b2) continue;
+        if (b1 != 0 && b2 != 0 && (m->body_weldid[m->body_parentid[b1]] == b2 || m->body_weldid[m->body_parentid[b2]] == b1)) continue;
         if (m->npair < 3) {
           int first = i, second = j; /* geom1 = lower type (plane/hfield first) */
           if (ti > tj) { first = j; second = i; }
@@ -220,7 +223,7 @@ odko_model* odko_model_copy(const odko_model* m) {
 #define MF(nm, cnt) if (!strcmp(name, #nm)) { *count = (cnt); return (real*)m->nm; }
 real* odko_model_field(odko_model* m, const char* name, int* count) {
   MF(body_mass, m->nbody) MF(body_ipos, m->nbody * 3) MF(body_pos, m->nbody * 3) MF(body_quat, m->nbody * 4)
-  MF(body_inertia_full, m->nbody * 6) MF(body_invweight0, m->nbody * 2)
+  MF(body_inertia_full, m->nbody * 6) MF(body_invweight0, m->nbody * 2) MF(cgeom_size, m->ncgeom * 3)
   MF(dof_frictionloss, m->nv) MF(dof_armature, m->nv) MF(dof_damping, m->nv) MF(dof_invweight0, m->nv)
   MF(qpos0, m->nq) MF(key_qpos, m->nq) MF(key_ctrl, m->nu)
   MF(actuator_gainprm0, m->nu) MF(actuator_biasprm, m->nu * 3) MF(actuator_ctrlrange, m->nu * 2) MF(actuator_forcerange, m->nu * 2)
@@ -753,11 +756,118 @@ int odko_model_convex_counts(const odko_model* m, int g, int* nv, int* nf, int* 
   return 0;
 }
 
+/* ---- primitive colliders (mjx collision_primitive.py, restated from memory like the rest: plane_sphere, plane_capsule,
+ * sphere_sphere, sphere_capsule, capsule_capsule).  One or two contacts; the unused slots of a pair get dist = 1. */
+static void prim_fill(odko_data* d, int c0, int k, real dist, const real* pos, const real* frame) {
+  d->contact_dist[c0 + k] = dist;
+  v3_copy(d->contact_pos[c0 + k], pos);
+  memcpy(d->contact_frame[c0 + k], frame, 9 * sizeof(real));
+}
+static void prim_pad(odko_data* d, int c0, int from, const real* frame) {
+  real z[3] = {0, 0, 0};
+  for (int k = from; k < 4; k++) prim_fill(d, c0, k, 1.0, z, frame);
+}
+static void plane_sphere_at(const real* n, const real* ppos, const real* spos, real radius, real* dist, real* pos) { /* _plane_sphere */
+  real t[3]; v3_sub(t, spos, ppos);
+  *dist = v3_dot(t, n) - radius;
+  v3_addscl(pos, spos, n, -(radius + 0.5 * *dist));
+}
+static void plane_sphere(const odko_model* m, odko_data* d, int gp, int gs, int c0) {
+  real n[3] = {d->geom_xmat[gp][2], d->geom_xmat[gp][5], d->geom_xmat[gp][8]}, dist, pos[3], frame[9];
+  plane_sphere_at(n, d->geom_xpos[gp], d->geom_xpos[gs], m->cgeom_size[gs][0], &dist, pos);
+  make_frame(frame, n);
+  prim_fill(d, c0, 0, dist, pos, frame);
+  prim_pad(d, c0, 1, frame);
+}
+static void plane_capsule(const odko_model* m, odko_data* d, int gp, int gc, int c0) {
+  real n[3] = {d->geom_xmat[gp][2], d->geom_xmat[gp][5], d->geom_xmat[gp][8]};
+  real axis[3] = {d->geom_xmat[gc][2], d->geom_xmat[gc][5], d->geom_xmat[gc][8]};
+  /* contact frame aligned with the capsule axis: b = axis - n (n . axis), falling back to y / z when the capsule stands on end */
+  real b[3], frame[9];
+  v3_addscl(b, axis, n, -v3_dot(n, axis));
+  real bn = sqrt(v3_dot(b, b));
+  if (bn < 0.5) { b[0] = 0; b[1] = (-0.5 < n[1] && n[1] < 0.5) ? 1 : 0; b[2] = (-0.5 < n[1] && n[1] < 0.5) ? 0 : 1; }
+  else { b[0] /= bn; b[1] /= bn; b[2] /= bn; }
+  v3_copy(frame, n); v3_copy(frame + 3, b); v3_cross(frame + 6, n, b);
+  for (int k = 0; k < 2; k++) {
+    real end[3], dist, pos[3];
+    v3_addscl(end, d->geom_xpos[gc], axis, (k == 0 ? 1.0 : -1.0) * m->cgeom_size[gc][1]);
+    plane_sphere_at(n, d->geom_xpos[gp], end, m->cgeom_size[gc][0], &dist, pos);
+    prim_fill(d, c0, k, dist, pos, frame);
+  }
+  prim_pad(d, c0, 2, frame);
+}
+static void sphere_sphere_at(odko_data* d, int c0, const real* p1, real r1, const real* p2, real r2) { /* _sphere_sphere */
+  real n[3], frame[9], pos[3];
+  v3_sub(n, p2, p1);
+  real len = sqrt(v3_dot(n, n));
+  if (len < MINVAL) { n[0] = 1; n[1] = 0; n[2] = 0; } else { n[0] /= len; n[1] /= len; n[2] /= len; }
+  real dist = len - (r1 + r2);
+  v3_addscl(pos, p1, n, r1 + 0.5 * dist);
+  make_frame(frame, n);
+  prim_fill(d, c0, 0, dist, pos, frame);
+  prim_pad(d, c0, 1, frame);
+}
+static void closest_segment_point(real* out, const real* a, const real* b, const real* pt) { /* math.closest_segment_point */
+  real ab[3], t[3];
+  v3_sub(ab, b, a); v3_sub(t, pt, a);
+  real tt = v3_dot(t, ab) / (v3_dot(ab, ab) + 1e-6);
+  tt = tt < 0 ? 0 : (tt > 1 ? 1 : tt);
+  v3_addscl(out, a, ab, tt);
+}
+static void closest_segment_to_segment(real* best_a, real* best_b, const real* a0, const real* a1, const real* b0, const real* b1) {
+  /* math.closest_segment_to_segment_points: closest points of the two (infinite) lines, clamped to the segments, then each
+   * re-projected on the other segment; the pair of the two candidates with the smaller distance */
+  real dir_a[3], dir_b[3], half_a[3], half_b[3], amid[3], bmid[3];
+  v3_sub(dir_a, a1, a0); real len_a = v3_normalize(dir_a) * 0.5; (void)half_a; (void)half_b;
+  v3_sub(dir_b, b1, b0); real len_b = v3_normalize(dir_b) * 0.5;
+  for (int k = 0; k < 3; k++) { amid[k] = 0.5 * (a0[k] + a1[k]); bmid[k] = 0.5 * (b0[k] + b1[k]); }
+  real diff[3]; v3_sub(diff, amid, bmid);
+  real dot_a = v3_dot(dir_a, diff), dot_b = v3_dot(dir_b, diff), dot_ab = v3_dot(dir_a, dir_b);
+  real denom = 1.0 - dot_ab * dot_ab;
+  real orig_t_a = (-dot_a + dot_ab * dot_b) / (denom + 1e-6);
+  real orig_t_b = dot_b + orig_t_a * dot_ab;
+  real t_a = orig_t_a < -len_a ? -len_a : (orig_t_a > len_a ? len_a : orig_t_a);
+  real t_b = orig_t_b < -len_b ? -len_b : (orig_t_b > len_b ? len_b : orig_t_b);
+  real ca[3], cb[3], new_a[3], new_b[3];
+  v3_addscl(ca, amid, dir_a, t_a); v3_addscl(cb, bmid, dir_b, t_b);
+  closest_segment_point(new_a, a0, a1, cb);     /* the clamping moved a point: re-project each on the other segment ... */
+  closest_segment_point(new_b, b0, b1, ca);
+  real t1[3], t2[3];
+  v3_sub(t1, new_a, cb); v3_sub(t2, ca, new_b);
+  if (v3_dot(t1, t1) < v3_dot(t2, t2)) { v3_copy(best_a, new_a); v3_copy(best_b, cb); } /* ... and keep the closer pair */
+  else { v3_copy(best_a, ca); v3_copy(best_b, new_b); }
+}
+static void capsule_ends(const odko_model* m, const odko_data* d, int g, real* e0, real* e1) {
+  real axis[3] = {d->geom_xmat[g][2], d->geom_xmat[g][5], d->geom_xmat[g][8]};
+  v3_addscl(e0, d->geom_xpos[g], axis, -m->cgeom_size[g][1]); v3_addscl(e1, d->geom_xpos[g], axis, m->cgeom_size[g][1]);
+}
+static void sphere_capsule(const odko_model* m, odko_data* d, int gs, int gc, int c0, int flip) {
+  real e0[3], e1[3], pt[3];
+  capsule_ends(m, d, gc, e0, e1);
+  closest_segment_point(pt, e0, e1, d->geom_xpos[gs]);
+  if (!flip) sphere_sphere_at(d, c0, d->geom_xpos[gs], m->cgeom_size[gs][0], pt, m->cgeom_size[gc][0]);
+  else sphere_sphere_at(d, c0, pt, m->cgeom_size[gc][0], d->geom_xpos[gs], m->cgeom_size[gs][0]);
+}
+static void capsule_capsule(const odko_model* m, odko_data* d, int g1, int g2, int c0) {
+  real a0[3], a1[3], b0[3], b1[3], pa[3], pb[3];
+  capsule_ends(m, d, g1, a0, a1); capsule_ends(m, d, g2, b0, b1);
+  closest_segment_to_segment(pa, pb, a0, a1, b0, b1);
+  sphere_sphere_at(d, c0, pa, m->cgeom_size[g1][0], pb, m->cgeom_size[g2][0]);
+}
+
 static void collision(const odko_model* m, odko_data* d) {
   d->ncon = 0;
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_g1[p], g2 = m->pair_g2[p], c0 = d->ncon;
-    if (m->cgeom_type[g1] == ODKO_GEOM_PLANE && m->cgeom_type[g2] == ODKO_GEOM_MESH) plane_convex(m, d, g1, g2, c0);
+    const int t1 = m->cgeom_type[g1], t2 = m->cgeom_type[g2];
+    if (t1 == ODKO_GEOM_PLANE && t2 == ODKO_GEOM_SPHERE) plane_sphere(m, d, g1, g2, c0);
+    else if (t1 == ODKO_GEOM_PLANE && t2 == ODKO_GEOM_CAPSULE) plane_capsule(m, d, g1, g2, c0);
+    else if (t1 == ODKO_GEOM_SPHERE && t2 == ODKO_GEOM_SPHERE) sphere_sphere_at(d, c0, d->geom_xpos[g1], m->cgeom_size[g1][0], d->geom_xpos[g2], m->cgeom_size[g2][0]);
+    else if (t1 == ODKO_GEOM_SPHERE && t2 == ODKO_GEOM_CAPSULE) sphere_capsule(m, d, g1, g2, c0, 0);
+    else if (t1 == ODKO_GEOM_CAPSULE && t2 == ODKO_GEOM_SPHERE) sphere_capsule(m, d, g2, g1, c0, 1);
+    else if (t1 == ODKO_GEOM_CAPSULE && t2 == ODKO_GEOM_CAPSULE) capsule_capsule(m, d, g1, g2, c0);
+    else if (m->cgeom_type[g1] == ODKO_GEOM_PLANE && m->cgeom_type[g2] == ODKO_GEOM_MESH) plane_convex(m, d, g1, g2, c0);
     else if (m->cgeom_type[g1] == ODKO_GEOM_MESH && m->cgeom_type[g2] == ODKO_GEOM_MESH) convex_convex(m, d, g1, g2, c0);
     else if (m->cgeom_type[g1] == ODKO_GEOM_HFIELD && m->cgeom_type[g2] == ODKO_GEOM_MESH && m->hfield_nrow > 1) hfield_convex(m, d, g1, g2, c0);
     else { /* unsupported pair type: no contact */

@@ -43,7 +43,7 @@ typedef ODKO_REAL real;
 #define ODKO_MAXEFC 96 /* constraint rows */
 
 enum { ODKO_JNT_FREE = 0, ODKO_JNT_HINGE = 3 };
-enum { ODKO_GEOM_PLANE = 0, ODKO_GEOM_HFIELD = 1, ODKO_GEOM_MESH = 7 };
+enum { ODKO_GEOM_PLANE = 0, ODKO_GEOM_HFIELD = 1, ODKO_GEOM_SPHERE = 2, ODKO_GEOM_CAPSULE = 3, ODKO_GEOM_MESH = 7 };   /* mjtGeom */
 #define ODKO_MAXHFIELD (256 * 256)
 enum { ODKO_S_GYRO = 0, ODKO_S_VELOCIMETER, ODKO_S_ACCELEROMETER, ODKO_S_FRAMEZAXIS, ODKO_S_FRAMEXAXIS,
        ODKO_S_FRAMELINVEL, ODKO_S_FRAMEANGVEL, ODKO_S_FRAMEPOS, ODKO_S_FRAMEQUAT };
@@ -94,6 +94,7 @@ typedef struct {
   int cgeom_id[ODKO_MAXG], cgeom_type[ODKO_MAXG], cgeom_bodyid[ODKO_MAXG], cgeom_priority[ODKO_MAXG],
       cgeom_condim[ODKO_MAXG], cgeom_contype[ODKO_MAXG], cgeom_conaffinity[ODKO_MAXG];
   int cgeom_vertadr[ODKO_MAXG], cgeom_vertnum[ODKO_MAXG], cgeom_faceadr[ODKO_MAXG], cgeom_facenum[ODKO_MAXG];
+  real cgeom_size[ODKO_MAXG][3];   /* sphere: radius; capsule: radius, half length (along the geom frame's z axis) */
   real cgeom_pos[ODKO_MAXG][3], cgeom_quat[ODKO_MAXG][4], cgeom_friction[ODKO_MAXG][3], cgeom_solref[ODKO_MAXG][2],
       cgeom_solimp[ODKO_MAXG][5], cgeom_solmix[ODKO_MAXG];
   real hull_vert[ODKO_MAXHV][3];

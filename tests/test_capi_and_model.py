@@ -238,9 +238,16 @@ def test_compiler_refuses_colliding_primitives(tmp_path):
     from open_duck_playground_amd import mjcf
     xml = """<mujoco><compiler angle="radian"/><worldbody>
       <geom name="floor" type="plane" size="0 0 0.01"/>
-      <body name="a"><freejoint/><inertial pos="0 0 0" mass="1" fullinertia="1 1 1 0 0 0"/><geom name="ball" type="sphere" size="0.1"/></body>
+      <body name="a"><freejoint/><inertial pos="0 0 0" mass="1" fullinertia="1 1 1 0 0 0"/><geom name="ball" type="ellipsoid" size="0.1 0.1 0.2"/></body>
       </worldbody></mujoco>"""
     path = tmp_path / "m.xml"
     path.write_text(xml)
     with pytest.raises(NotImplementedError, match="ball"):
         mjcf.compile_mjcf(str(path))
+    path.write_text(xml.replace('type="ellipsoid" size="0.1 0.1 0.2"', 'type="cylinder" size="0.1 0.1"'))
+    with pytest.raises(NotImplementedError, match="ball"):
+        mjcf.compile_mjcf(str(path))
+    # spheres and capsules collide (tests/test_mjcf_box.py), but not against a height field
+    path.write_text(xml.replace('type="ellipsoid" size="0.1 0.1 0.2"', 'type="sphere" size="0.1"'))
+    a = mjcf.compile_mjcf(str(path))
+    assert list(a["cgeom_type"]) == [0, mjcf.GEOM_SPHERE] and a["cgeom_size"][1][0] == pytest.approx(0.1)
