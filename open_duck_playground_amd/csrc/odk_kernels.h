@@ -1214,20 +1214,29 @@ __device__ __noinline__ void prim_contacts(float* L, const DevModel* __restrict_
   float a0[3], a1[3], b0[3], b1[3];
   for (int t = 0; t < 3; t++) { a0[t] = cw[0][t] - h1 * aw[0][t]; a1[t] = cw[0][t] + h1 * aw[0][t]; b0[t] = cw[1][t] - h2 * aw[1][t]; b1[t] = cw[1][t] + h2 * aw[1][t]; }
   if (c1 && c2) {   // math.closest_segment_to_segment_points
-    float da[3], db[3], am[3], bm[3], diff[3];
-    sub3(da, a1, a0); sub3(db, b1, b0);
-    const float la = sqrtf(dot3(da, da)), lb = sqrtf(dot3(db, db));
-    for (int t = 0; t < 3; t++) { da[t] /= la; db[t] /= lb; am[t] = 0.5f * (a0[t] + a1[t]); bm[t] = 0.5f * (b0[t] + b1[t]); }
+    // the same formula in a form that keeps float32 digits when the capsules are near parallel (two feet side by side):
+    // 1 - (da.db)^2 = |da x db|^2 and -da.diff + (da.db)(db.diff) = -(db x (da x db)).diff, with the unit axes taken from the
+    // rotation matrices instead of normalised end-point differences (rounding error ~1e-7 / sin(angle), not / sin^2)
+    const float* da = aw[0]; const float* db = aw[1]; const float* am = cw[0]; const float* bm = cw[1];
+    const float la = 2.0f * h1, lb = 2.0f * h2;
+    float diff[3], cx[3], u[3];
     sub3(diff, am, bm);
-    const float dota = dot3(da, diff), dotb = dot3(db, diff), dab = dot3(da, db);
-    const float ota = (-dota + dab * dotb) / (1.0f - dab * dab + 1e-6f), otb = dotb + ota * dab;
+    cross3(cx, da, db); cross3(u, db, cx);
+    const float dotb = dot3(db, diff), dab = dot3(da, db);
+    const float ota = -dot3(u, diff) / (dot3(cx, cx) + 1e-6f), otb = dotb + ota * dab;
     const float ta = fminf(fmaxf(ota, -0.5f * la), 0.5f * la), tb = fminf(fmaxf(otb, -0.5f * lb), 0.5f * lb);
-    float ca[3], cb[3], na[3], nb[3], t1[3], t2[3];
-    for (int t = 0; t < 3; t++) { ca[t] = am[t] + ta * da[t]; cb[t] = bm[t] + tb * db[t]; }
-    seg_point(a0, a1, cb, na); seg_point(b0, b1, ca, nb);
-    sub3(t1, na, cb); sub3(t2, ca, nb);
-    const bool first = dot3(t1, t1) < dot3(t2, t2);
-    for (int t = 0; t < 3; t++) { p1[t] = first ? na[t] : ca[t]; p2[t] = first ? cb[t] : nb[t]; }
+    // (ca, cb) = the clamped points; each re-projected on the other segment (closest_segment_point, its 1e-6 included) moves
+    // by da_ / db_ along its axis; the pair with the smaller distance wins.  Away from the clamps the two distances differ only
+    // through the regularisers (1e-6 ... 1e-4 relative): d1 - d2 is formed from the shifts, not from two rounded distances.
+    float w[3];
+    for (int t = 0; t < 3; t++) w[t] = diff[t] + ta * da[t] - tb * db[t];
+    const float wda = dot3(w, da), wdb = dot3(w, db);
+    const float sa = fminf(fmaxf(la * (ta + 0.5f * la - wda) / (la * la + 1e-6f), 0.0f), 1.0f) * la;
+    const float sb = fminf(fmaxf(lb * (tb + 0.5f * lb + wdb) / (lb * lb + 1e-6f), 0.0f), 1.0f) * lb;
+    const float da_ = sa - (ta + 0.5f * la), db_ = sb - (tb + 0.5f * lb);
+    const bool first = 2.0f * da_ * wda + 2.0f * db_ * wdb + da_ * da_ - db_ * db_ < 0.0f;   // |na - cb|^2 < |ca - nb|^2
+    const float fa = first ? ta + da_ : ta, fb = first ? tb : tb + db_;
+    for (int t = 0; t < 3; t++) { p1[t] = am[t] + fa * da[t]; p2[t] = bm[t] + fb * db[t]; }
   } else if (c2) { ld3(p1, cw[0]); seg_point(b0, b1, cw[0], p2); }
   else if (c1) { ld3(p1, cw[1]); seg_point(a0, a1, cw[1], p2); }   // geoms ordered by type (mjx): the sphere is geom 1, the normal points from it to the capsule
   else { ld3(p1, cw[0]); ld3(p2, cw[1]); }

@@ -454,6 +454,28 @@ def test_box_feet_variant(torch_cuda, oracle_mod, parity_log, task):
     parity_log.check(f"box_feet/{task}", dict(dist=1e-6, qpos=1e-5, qvel=4e-5, tie_fraction=0.6), tie_fraction=n_tie / n, **W)
 
 
+def _substep_sensitivity(O, om, om32, qpos, qvel, ctrl, nsub, prng, tries=6):
+    """oracle side only, along the float64 oracle's own trajectory: the largest change of one substep's qvel (a) under 1e-6 / 5e-6
+    perturbations of that substep's state and (b) when the same substep is done by the oracle's float32 build.  Where a
+    line-search branch, a contact or the pick between two candidate pairs of closest points (near-parallel capsules: a tie by
+    construction, decided at the level of the formula's 1e-6 regularisers) flips there, no float32 implementation follows the
+    float64 one -- MJX itself runs in float32."""
+    d = O.OracleData(om)
+    d["qpos"][: om.nq] = qpos; d["qvel"][: om.nv] = qvel; d["qacc_warmstart"][: om.nv] = 0.0
+    worst = 0.0
+    for _ in range(nsub):
+        q, v, w = (np.array(d[k][:n]) for k, n in (("qpos", om.nq), ("qvel", om.nv), ("qacc_warmstart", om.nv)))
+        d.env_physics_step(ctrl, 1)
+        v1 = np.array(d["qvel"][: om.nv])
+        for _t in range(tries):
+            dq = np.zeros(om.nq); dq[7:] = prng.uniform(-1e-6, 1e-6, om.nq - 7)
+            dp = _oracle_step(O, om, q + dq, v + prng.uniform(-5e-6, 5e-6, om.nv), w, ctrl, 1)
+            worst = max(worst, _rel(np.array(dp["qvel"][: om.nv]), v1, 1.0).max())
+        d32 = _oracle_step(O, om32, q, v, w, ctrl, 1)
+        worst = max(worst, _rel(np.array(d32["qvel"][: om.nv], np.float64), v1, 1.0).max())
+    return worst
+
+
 def _prim_feet_variant(task, kinds):
     """the task's model with the foot meshes replaced by primitive colliders (what the compiler emits for <geom type="sphere"> /
     <geom type="capsule">) at the centre of the sole's bounding box; a capsule lies along the sole's longest side"""
@@ -495,6 +517,7 @@ def test_primitive_feet_variant(torch_cuda, oracle_mod, parity_log, kinds):
     torch = torch_cuda
     model = _prim_feet_variant("flat_terrain", kinds)
     om = oracle_mod.OracleModel(model.blob())
+    om32 = oracle_mod.OracleModel(model.blob(), f32=True)
     assert om.npair == 3
     n = 48
     rng = np.random.default_rng(41)
@@ -520,14 +543,10 @@ def test_primitive_feet_variant(torch_cuda, oracle_mod, parity_log, kinds):
         for e in range(n):
             ds = _oracle_step(oracle_mod, om, qpos[e], qvel[e], np.zeros(model.nv), ctrl[e], nsub)
             sfx = "" if nsub == 1 else "10"
-            if nsub == 10 and _rel(gv[e], ds["qvel"][: om.nv], 1.0).max() > 3e-4:
-                # over the bound after ten substeps: accepted only if the oracle itself is that sensitive there (a solver branch
-                # or a contact flipping under a 1e-6 perturbation of the start state, in one of ten tries) -- and counted
-                worst = 0.0
-                for _ in range(10):
-                    dq = np.zeros(om.nq); dq[7:] = prng.uniform(-1e-6, 1e-6, om.nq - 7)
-                    dp = _oracle_step(oracle_mod, om, qpos[e] + dq, qvel[e] + prng.uniform(-5e-6, 5e-6, om.nv), np.zeros(model.nv), ctrl[e], nsub)
-                    worst = max(worst, _rel(dp["qvel"][: om.nv], ds["qvel"][: om.nv], 1.0).max())
+            if nsub == 10 and _rel(gv[e], ds["qvel"][: om.nv], 1.0).max() > 1.5e-4:
+                # over the bound after ten substeps: accepted only if the oracle itself is that sensitive somewhere along the way
+                # (_substep_sensitivity) -- and counted
+                worst = _substep_sensitivity(oracle_mod, om, om32, qpos[e], qvel[e], ctrl[e], nsub, prng)
                 assert worst > 1e-4, (e, worst, _rel(gv[e], ds["qvel"][: om.nv], 1.0).max())
                 n_ill += 1
                 continue
@@ -549,7 +568,7 @@ def test_primitive_feet_variant(torch_cuda, oracle_mod, parity_log, kinds):
                     W["pos"] = max(W["pos"], np.abs(img[e][o_cr + 3 * c: o_cr + 3 * c + 3] + qpos[e, :3] - np.array(d["contact_pos"][3 * c: 3 * c + 3])).max())
         b.close()
     assert n_contact >= n // 4 and n_ff >= 5, (n_contact, n_ff)
-    parity_log.check("prim_feet/" + "-".join(kinds), dict(dist=5e-7, pos=5e-7, qpos=3e-6, qvel=4e-5, qpos10=1e-4, qvel10=3e-4, ill_fraction=0.05), ill_fraction=n_ill / n, **W)
+    parity_log.check("prim_feet/" + "-".join(kinds), dict(dist=5e-7, pos=5e-7, qpos=3e-6, qvel=4e-5, qpos10=3e-5, qvel10=1.5e-4, ill_fraction=0.05), ill_fraction=n_ill / n, **W)
 
 
 def build_tables(model):
