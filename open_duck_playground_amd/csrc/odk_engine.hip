@@ -47,6 +47,7 @@ template <class S> struct EnvL {
   static_assert(48 + 40 <= 6 * S::NVR, "draws + reference motion must fit in BUF6");
   static constexpr int O_PRIV = S::O_M;            // [212] aliases M|HL (dead after the last forward)
   static constexpr int TOTAL = O_ACT + 16;
+  static_assert(TOTAL == S::ENV_STRIDE, "Shape::ENV_STRIDE is the distance between the two env images of a workgroup");
   static_assert(S::NMR + S::NHR >= ODK_NPRIV, "privileged obs must fit in the M|HL region");
   // per WORKGROUP, behind the envs' images: static tables shared by the envs of the workgroup
   static constexpr int SHARED = S::SHARED;       // DevModel::R_ent | contact-row constants (forward_env: RT, CT)

@@ -137,6 +137,7 @@ struct Shape {
   static constexpr int O_ACTF = O_SCR + N_SCR;       // actuator_force
   static constexpr int O_QACC = O_X;                 // qacc of the last forward == final iterate
   static constexpr int TOTAL = ((O_ACTF + NU + 3) / 4) * 4;
+  static constexpr int ENV_STRIDE = TOTAL + 160;   // floats between the images of the two envs of a workgroup (odk_engine.hip EnvL::TOTAL: + info + action)
   // scratch sub-offsets
   static constexpr int S_VF = 0;      // [2][6] foot twist of the current vector
   static constexpr int S_FF = 12;     // [2][6] foot wrench sums
@@ -959,6 +960,8 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   float* FV = L + S::O_CFRC + f * 51; float* FN = L + S::O_CFRC + 102 + f * 90;
   float* RS = L + (f ? S::O_BUF6B : S::O_BUF6);
   float* PV = RS;                                                      // prism vertices [6][3]
+  float* META = RS + 106;                                              // for the other rows: ncw, hull centroid [3], mask of this foot's open list entries, the entry this ROW took last (foot << 8 | entry)
+  static_assert(6 * S::NVR >= 111, "row scratch + window record");
   float* RL = L + S::O_D + f * 172;
   float* LIST = RL; float* TOP = RL + 108; float* NEW = RL + 140;      // [18][6] | [4][8] | [4][8]
   const RowScratch RSS = {RS + 18, RS + 30, NEW, RS + 42, RS + 58};    // RP [4][3], IP [4][3], pass words [16], hull-edge vertex pairs [48]
@@ -1003,18 +1006,19 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   float fc[3];
   for (int k = 0; k < 3; k++) fc[k] = Pw[k] + Rw[3 * k] * m->foot_centroid[f][0] + Rw[3 * k + 1] * m->foot_centroid[f][1] + Rw[3 * k + 2] * m->foot_centroid[f][2];
   if (j < 4) { float* o = TOP + 8 * j; o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f; o[7] = 1.0e9f + (float)j; }
+  if (j == 0) { META[0] = __int_as_float(ncw); META[1] = fc[0]; META[2] = fc[1]; META[3] = fc[2]; META[5] = __int_as_float(0xFFFF); }
   ODK_SYNC();
   const float idiag = 1.0f / sqrtf(dx * dx + dy * dy);
   // prism p = 2 (ri ncw + ci) + tri of this row's window: grid corners of its top triangle (counter-clockwise seen from above)
-  auto corners = [&](int p, int* cc, int* rr) {
+  auto corners = [&](int p, int ncw, int* cc, int* rr) {
     const int q = p >> 1, tri = p & 1;
     const int ri = ncw == 1 ? q : (ncw == 2 ? (q >> 1) : (q >= 6 ? 2 : (q >= 3 ? 1 : 0)));
     const int c = q - ri * ncw, r = ri;   // relative to (cmin, rmin)
     cc[0] = tri ? c + 1 : c; rr[0] = tri ? r + 1 : r; cc[1] = tri ? c : c + 1; rr[1] = tri ? r + 1 : r; cc[2] = tri ? c + 1 : c; rr[2] = tri ? r : r + 1;
   };
-  auto prism = [&](int p, const float* z, Prism& P) {
+  auto prism = [&](int p, int ncw, const float* z, Prism& P) {
     int cc[3], rr[3];
-    corners(p, cc, rr);
+    corners(p, ncw, cc, rr);
     for (int k = 0; k < 3; k++) { P.x[k] = (float)cc[k] * dx; P.y[k] = (float)rr[k] * dy; P.z[k] = z[k]; }
     P.base = base;
     const float e1[3] = {P.x[1] - P.x[0], P.y[1] - P.y[0], P.z[1] - P.z[0]}, e2[3] = {P.x[2] - P.x[0], P.y[2] - P.y[0], P.z[2] - P.z[0]};
@@ -1037,9 +1041,9 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     const bool valid = p < nprism;
     if (__builtin_amdgcn_ballot_w64(valid) == 0) break;
     float z[3] = {0.0f, 0.0f, 0.0f};
-    if (valid) { int cc[3], rr[3]; corners(p, cc, rr); for (int k = 0; k < 3; k++) z[k] = hf[(rmin + rr[k]) * nc + cmin + cc[k]] * sz; }
+    if (valid) { int cc[3], rr[3]; corners(p, ncw, cc, rr); for (int k = 0; k < 3; k++) z[k] = hf[(rmin + rr[k]) * nc + cmin + cc[k]] * sz; }
     Prism P;
-    prism(valid ? p : 0, z, P);
+    prism(valid ? p : 0, ncw, z, P);
     // plane offsets n . v0 of the five faces (v0: vertex 0 / 3 / 0 / 1 / 2), then min over the hull's vertices of n . v - offset
     float d5[5], s5[5] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
     d5[0] = P.nt[0] * P.x[0] + P.nt[1] * P.y[0] + P.nt[2] * P.z[0]; d5[1] = base;
@@ -1060,44 +1064,123 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     cnt += __popc(rowmask);
   }
   ODK_SYNC();
+  {   // the list in ascending (sep, prism) order: an entry's place is the number of entries before it
+    float e0[6], e1[6];
+    for (int t = 0; t < 6; t++) { e0[t] = LIST[6 * j + t]; e1[t] = j < 2 ? LIST[6 * (j + 16) + t] : 0.0f; }
+    int rk0 = 0, rk1 = 0;
+#pragma unroll 6
+    for (int q = 0; q < 18; q++) {
+      const float sq = LIST[6 * q + 4];
+      const bool in = q < cnt;
+      rk0 += (in && (sq < e0[4] || (sq == e0[4] && q < j))) ? 1 : 0;
+      rk1 += (in && (sq < e1[4] || (sq == e1[4] && q < j + 16))) ? 1 : 0;
+    }
+    ODK_SYNC();
+    if (j < cnt) for (int t = 0; t < 6; t++) LIST[6 * rk0 + t] = e0[t];
+    if (j + 16 < cnt) for (int t = 0; t < 6; t++) LIST[6 * rk1 + t] = e1[t];
+  }
+  ODK_SYNC();
   HF_PROF(1);
   HF_COUNT(5, cnt);
-  const Cvx B = {FV, FN, &m->foot_poly[f][0][0], &m->foot_edge[f][0][0], nvt, nfc, m->foot_nedge[f], {fc[0], fc[1], fc[2]}};
-  EdgeRegs<3> RB;
-  edge_regs_load<3>(RB, B, j);
-  FaceRegs<2> FB;
-  face_regs_load<2>(FB, B, j);
-  for (int sl = 0; sl < 3; sl++) RSS.VV[3 * j + sl] = __int_as_float(RB.vv[sl]);
-  ODK_SYNC();
-  HF_PROF(2);
   // ---- pair loop.  Every contact of a pair is at least as far out as the pair's best separating axis, which is at least the prism's
   // own face separation `sep` (kept in the list): a prism whose sep lies beyond the fourth-deepest contact found so far cannot enter
-  // the best four.  So each row works through its prisms from the deepest sep on and stops at the first one that cannot matter;
-  // the result does not depend on the order (entries are ranked by (dist, candidate index), like a stable sort of MJX's whole
-  // candidate list).  Typically two or three of the six to eight overlapping prisms get the full test.
-  unsigned done = 0u;   // row-uniform: list entries already taken
+  // the best four.  So a foot's prisms are worked from the deepest sep on, and those that cannot matter any more are left out; the
+  // result does not depend on the order (entries are ranked by (dist, candidate index), like a stable sort of MJX's whole candidate
+  // list).  Typically three or four of the four to eight overlapping prisms of a foot get the full test.
+  //
+  // The four rows of the wave (two envs x two feet) share the work: a row whose own list has nothing open takes a prism of the
+  // foot with the most open entries -- left to itself the loop runs as long as the longest of the four lists (6.0 iterations per
+  // forward pass for 3.6 pairs per foot).  Per iteration: every row counts the open entries of its own list and publishes the
+  // count; every lane derives the same assignment (row -> foot, rank among the rows on that foot) from the four counts; a row on a
+  // new foot reloads that hull's faces / edges into its registers; the row takes the entry of rank `rank` among the open ones (by
+  // sep, then index), marks it taken, works the pair into its own NEW block; the blocks are merged into the foot's TOP rank by rank.
+  const int r_own = (threadIdx.x >> 4) & 3;
+  float* Lw = L - ((threadIdx.x >> 5) & 1) * S::ENV_STRIDE;   // env 0 of the workgroup
+  auto tgt_L = [&](int t) -> float* { return Lw + (t >> 1) * S::ENV_STRIDE; };
+  auto tgt_meta = [&](int t) -> float* { return tgt_L(t) + ((t & 1) ? S::O_BUF6B : S::O_BUF6) + 106; };
+  int tg = -1;                // the foot whose hull this row holds in registers
+  int ncw_t = 1;
+  Cvx B = {FV, FN, &m->foot_poly[f][0][0], &m->foot_edge[f][0][0], nvt, nfc, m->foot_nedge[f], {fc[0], fc[1], fc[2]}};
+  EdgeRegs<3> RB;
+  FaceRegs<2> FB;
+  float* LISTt = LIST; float* TOPt = TOP;
+  unsigned cur_pk = 0u | (1u << 8) | (2u << 16) | (3u << 24);   // wave-uniform: the foot each row is on
+  const float s0 = j < cnt ? LIST[6 * j + 4] : 3.0e38f, s1 = j + 16 < cnt ? LIST[6 * (j + 16) + 4] : 3.0e38f;   // own list's seps (sorted)
+  unsigned taken = 0u;        // row-uniform: entries of the own list that some row has taken
+  HF_PROF(2);
 #ifdef ODK_PROFILE
   const long long _loop0 = clock64();
 #endif
 #pragma unroll 1
   for (;;) {
     asm volatile("; HF_LOOP_BEGIN" ::: "memory");
-    // this row's next prism: the smallest sep among the entries not taken yet (lane j looks at entries j and j + 16)
-    float s0 = 3.0e38f, s1 = 3.0e38f;
-    if (j < cnt && !((done >> j) & 1u)) s0 = LIST[6 * j + 4];
-    if (j + 16 < cnt && !((done >> (j + 16)) & 1u)) s1 = LIST[6 * (j + 16) + 4];
-    float smin;
-    const int kmin = row_argmin(s1 < s0 ? s1 : s0, s1 < s0 ? j + 16 : j, smin);
-    const bool act = smin < 3.0e38f && !(smin > TOP[8 * 3]);
-    if (__builtin_amdgcn_ballot_w64(act) == 0) break;
-    const int kk = act ? kmin : 0;
-    done |= act ? (1u << kk) : 0u;
-    const float* en = LIST + 6 * kk;
+    {   // open entries of this row's own list: the prefix of the sorted list within reach of the fourth-deepest contact so far,
+        // less the entries taken (by any row) in the iterations before
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const int pk = __float_as_int(tgt_meta(r)[5]); taken |= (pk >> 8) == r_own ? 1u << (pk & 31) : 0u; }
+      const float lim = TOP[8 * 3];
+      const unsigned m0 = (unsigned)((__builtin_amdgcn_ballot_w64(!(s0 > lim)) >> (threadIdx.x & 48u)) & 0xFFFFull);
+      const unsigned m1 = (unsigned)((__builtin_amdgcn_ballot_w64(!(s1 > lim)) >> (threadIdx.x & 48u)) & 0x3ull);
+      if (j == 0) META[4] = __uint_as_float((m0 | (m1 << 16)) & ~taken);
+    }
+    ODK_SYNC();
+    unsigned open_t[4], n_pk = 0u;
+#pragma unroll
+    for (int t = 0; t < 4; t++) { open_t[t] = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(tgt_meta(t)[4])); n_pk |= (unsigned)__popc(open_t[t]) << (8 * t); }
+    if (n_pk == 0u) break;
+    // assignment: rows keep their foot while it has open entries for them, the others go where most are left
+    unsigned asg_pk = 0u, tgt_pk = 0u, rnk_pk = 0u, on_pk = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const unsigned c = (cur_pk >> (8 * r)) & 3u;
+      const unsigned left = ((n_pk >> (8 * c)) & 255u) - ((asg_pk >> (8 * c)) & 255u);
+      if (left > 0u) { tgt_pk |= c << (8 * r); rnk_pk |= ((asg_pk >> (8 * c)) & 255u) << (8 * r); asg_pk += 1u << (8 * c); on_pk |= 1u << r; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (!((on_pk >> r) & 1u)) {
+        unsigned bt = 0u, bl = 0u;
+#pragma unroll
+        for (unsigned t = 0; t < 4; t++) { const unsigned left = ((n_pk >> (8 * t)) & 255u) - ((asg_pk >> (8 * t)) & 255u); if (left > bl) { bl = left; bt = t; } }
+        if (bl > 0u) { tgt_pk |= bt << (8 * r); rnk_pk |= ((asg_pk >> (8 * bt)) & 255u) << (8 * r); asg_pk += 1u << (8 * bt); on_pk |= 1u << r; }
+        else tgt_pk |= ((cur_pk >> (8 * r)) & 3u) << (8 * r);
+      }
+    }
+    cur_pk = tgt_pk;
+    const unsigned maxq = max(max(asg_pk & 255u, (asg_pk >> 8) & 255u), max((asg_pk >> 16) & 255u, (asg_pk >> 24) & 255u)) - 1u;
+    const int my_tg = (int)((tgt_pk >> (8 * r_own)) & 3u), my_q = (int)((rnk_pk >> (8 * r_own)) & 255u);
+    const bool my_on = (on_pk >> r_own) & 1u;
+    // a row on a new foot: that hull's tables, the window's width and centroid, its faces / edges into the registers
+    const bool sw = my_on && my_tg != tg;
+    if (__builtin_amdgcn_ballot_w64(sw) != 0) {
+      if (sw) {
+        tg = my_tg;
+        float* Lt = tgt_L(tg); const int ft = tg & 1;
+        const float* mt = tgt_meta(tg);
+        ncw_t = __float_as_int(mt[0]);
+        B.V = Lt + S::O_CFRC + ft * 51; B.N = Lt + S::O_CFRC + 102 + ft * 90;
+        B.poly = &m->foot_poly[ft][0][0]; B.edge = &m->foot_edge[ft][0][0];
+        B.nv = m->foot_nvert[ft]; B.nf = m->foot_npoly[ft]; B.ne = m->foot_nedge[ft];
+        B.c[0] = mt[1]; B.c[1] = mt[2]; B.c[2] = mt[3];
+        LISTt = Lt + S::O_D + ft * 172; TOPt = LISTt + 108;
+        edge_regs_load<3>(RB, B, j);
+        face_regs_load<2>(FB, B, j);
+        for (int sl = 0; sl < 3; sl++) RSS.VV[3 * j + sl] = __int_as_float(RB.vv[sl]);
+      }
+      ODK_SYNC();
+    }
+    // the open entry of rank my_q of that foot's (sorted) list
+    unsigned wsel = my_tg == 0 ? open_t[0] : (my_tg == 1 ? open_t[1] : (my_tg == 2 ? open_t[2] : open_t[3]));
+    for (int q = 0; q < 3; q++) wsel = q < my_q ? wsel & (wsel - 1u) : wsel;
+    const bool act = my_on && wsel != 0u;
+    const int kk = act ? __ffs((int)wsel) - 1 : 0;
+    if (j == 0) META[5] = __int_as_float(act ? (my_tg << 8) | kk : 0xFFFF);
+    const float* en = LISTt + 6 * kk;
     const int p = act ? __float_as_int(en[0]) : 0;
     const float z[3] = {en[1], en[2], en[3]};
     const float sep_a = en[4]; const int face_a = act ? __float_as_int(en[5]) : 0;
     Prism P;
-    prism(p, z, P);
+    prism(p, ncw_t, z, P);
     {   // lane j < 6 writes vertex j for the polygon fetch (selects, no per-lane indexing of register arrays: that is scratch)
       const int t = j < 3 ? j : j - 3;
       const float vx = t == 0 ? P.x[0] : (t == 1 ? P.x[1] : P.x[2]), vy = t == 0 ? P.y[0] : (t == 1 ? P.y[1] : P.y[2]);
@@ -1115,11 +1198,12 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
 #endif
     if (act && j < 4) NEW[8 * j + 7] = (float)(4 * p + j);   // candidate index in MJX's list: prism-major, then the pair's four slots
     ODK_SYNC();
-    merge_top4_row(TOP, NEW, j, act);
+    for (unsigned q = 0; q <= maxq; q++) merge_top4_row(TOPt, NEW, j, act && my_q == (int)q);
 #ifdef ODK_PROFILE
     { const long long t2 = clock64(); if (prof) prof[6] += (float)(t2 - tp); _hp = t2; }
 #endif
     HF_COUNT(4, 1);
+    HF_COUNT(6, act ? 1 : 0);
     asm volatile("; HF_LOOP_END" ::: "memory");
   }
 #ifdef ODK_PROFILE
