@@ -153,12 +153,13 @@ __device__ __forceinline__ void manifold4_row(const float* p, bool cand, bool ma
   sub3(amc, a, c); sub3(bmc, b, c);
   cross3(ac, n, amc); cross3(bc, n, bmc);
   sub3(bp, b, p);
+  // last point: argmax over concat([first half: area against bc, second half: against ac]), lowest index among the values within
+  // AREA_TIE of the maximum (oracle manifold_points: for a triangle of candidates the two largest entries are equal in exact arithmetic)
   const float v1 = area0(fabsf(dot3(bp, bc))) + dm, v2 = area0(fabsf(dot3(ap, ac))) + dm;
-  float vv = v1; int vi = j;
-  if (v2 > v1) { vv = v2; vi = np + j; }
-  if (!cand) { vv = -3.0e38f; vi = 2 * np + j; }
-  idx[3] = row_argmax(vv, vi, vm);
-  idx[3] = idx[3] >= np ? idx[3] - np : idx[3];
+  const float M = fkey_inv(rreduce_u<true>(fkey(cand ? fmaxf(v1, v2) : -3.0e38f))) - AREA_TIE;
+  const unsigned id = !cand ? 0x7FFFFFFFu : (v1 >= M ? (unsigned)j : (v2 >= M ? (unsigned)(np + j) : 0x7FFFFFFFu));
+  const unsigned best = rreduce_u<false>(id);
+  idx[3] = best == 0x7FFFFFFFu ? 0 : (int)(best >= (unsigned)np ? best - (unsigned)np : best);
 }
 
 // mjx _clip_edge_to_planes: the edge (p0, p1) against the side planes of polygon Q (nq vertices at QP, normal qn); the `which`-th

@@ -783,6 +783,8 @@ __device__ __forceinline__ void row_params(const float* P, float pos, float invw
 // area measures below 1e-7 m^2 count as zero (oracle manifold_points AREA0: collinear / coincident candidates tie like in exact
 // arithmetic instead of by rounding residue)
 __device__ __forceinline__ float area0(float v) { return v < 1e-7f ? 0.0f : v; }
+// last manifold point: values within AREA_TIE of the maximum count as the maximum, the lowest index wins (oracle manifold_points)
+constexpr float AREA_TIE = 1e-8f;
 template <int G>
 __device__ __forceinline__ void select4(const float* w, bool has, float sup, int nvt, const float* n, int* idx, int lane) {
   const float smax = gmax<G>(sup);
@@ -801,12 +803,11 @@ __device__ __forceinline__ void select4(const float* w, bool has, float sup, int
   cross3(ac, n, amc);
   cross3(bc, n, bmc);
   float bp[3] = {bq[0] - w[0], bq[1] - w[1], bq[2] - w[2]};
-  float v1 = area0(fabsf(dot3(bp, bc))) + dm, v2 = area0(fabsf(dot3(ap, ac))) + dm;
-  float vv = v1; int vi = lane;
-  if (v2 > v1) { vv = v2; vi = nvt + lane; }
-  if (!has) { vv = -3.0e38f; vi = 2 * nvt + lane; }
-  idx[3] = gargmax<G>(vv, vi);
-  idx[3] = idx[3] >= nvt ? idx[3] - nvt : idx[3];
+  const float v1 = area0(fabsf(dot3(bp, bc))) + dm, v2 = area0(fabsf(dot3(ap, ac))) + dm;
+  const float M = gmax<G>(has ? fmaxf(v1, v2) : -3.0e38f) - AREA_TIE;
+  const unsigned id = !has ? 0x7FFFFFFFu : (v1 >= M ? (unsigned)lane : (v2 >= M ? (unsigned)(nvt + lane) : 0x7FFFFFFFu));
+  const unsigned best = greduce_u<G, false>(id);
+  idx[3] = best == 0x7FFFFFFFu ? 0 : (int)(best >= (unsigned)nvt ? best - (unsigned)nvt : best);
 }
 
 // 16-lane row reductions on unsigned keys (the first four butterfly stages of greduce_u: every lane ends with its row's value)
@@ -859,18 +860,20 @@ __device__ __forceinline__ void select4_rows(const float* w, bool has, float sup
   float ac[3], bc[3];
   cross3(ac, n, amc);
   cross3(bc, n, bmc);
-  auto last = [&](const float* x, const float* apx, float dmx, bool hx, int ix, float& vv, int& vi) {
+  auto last = [&](const float* x, const float* apx, float dmx, float& v1, float& v2) {
     const float bp[3] = {bq[0] - x[0], bq[1] - x[1], bq[2] - x[2]};
-    const float v1 = area0(fabsf(dot3(bp, bc))) + dmx, v2 = area0(fabsf(dot3(apx, ac))) + dmx;
-    vv = v1; vi = ix;
-    if (v2 > v1) { vv = v2; vi = nvt + ix; }
-    if (!hx) { vv = -3.0e38f; vi = 2 * nvt + ix; }
+    v1 = area0(fabsf(dot3(bp, bc))) + dmx; v2 = area0(fabsf(dot3(apx, ac))) + dmx;
   };
-  float vv, vve; int vi, vie;
-  last(w, ap, dm, has, j, vv, vi);
-  last(we, ape, dme, has_e, 16, vve, vie);
-  idx[3] = amax(vv, vi, vve, vie);
-  idx[3] = idx[3] >= nvt ? idx[3] - nvt : idx[3];
+  float v1, v2, v1e, v2e;
+  last(w, ap, dm, v1, v2);
+  last(we, ape, dme, v1e, v2e);
+  const unsigned km = rreduce_u<true>(fkey(has ? fmaxf(v1, v2) : -3.0e38f)), kme = fkey(has_e ? fmaxf(v1e, v2e) : -3.0e38f);
+  const float M = fkey_inv(km > kme ? km : kme) - AREA_TIE;
+  const unsigned id = !has ? 0x7FFFFFFFu : (v1 >= M ? (unsigned)j : (v2 >= M ? (unsigned)(nvt + j) : 0x7FFFFFFFu));
+  const unsigned ide = !has_e ? 0x7FFFFFFFu : (v1e >= M ? 16u : (v2e >= M ? (unsigned)(nvt + 16) : 0x7FFFFFFFu));
+  const unsigned ri = rreduce_u<false>(id);
+  const unsigned best = ri < ide ? ri : ide;
+  idx[3] = best == 0x7FFFFFFFu ? 0 : (int)(best >= (unsigned)nvt ? best - (unsigned)nvt : best);
 }
 
 }  // namespace odk

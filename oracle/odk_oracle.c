@@ -483,6 +483,7 @@ static void make_frame(real* frame, const real* n) {
  * with it how many of the four slots repeat which point, i.e. the weight of each contact -- would be rounding noise, different
  * in float32 and float64.  With the threshold both resolve the tie like exact arithmetic does. */
 #define AREA0(v) ((v) < 1e-7 ? 0.0 : (v))
+#define AREA_TIE 1e-8
 static void manifold_points(const real (*poly)[3], const int* mask, int n, const real* norm, int* idx) {
   real dm[ODKO_MAXHV];
   int ai = 0, bi = 0, ci = 0, di = 0;
@@ -509,18 +510,23 @@ static void manifold_points(const real (*poly)[3], const int* mask, int n, const
   real ac[3], bc[3];
   v3_sub(t, a, c); v3_cross(ac, norm, t);
   v3_sub(t, b, c); v3_cross(bc, norm, t);
+  /* argmax over concat([dist_bp, dist_ap]) % n : first half (bp) wins ties.  For a triangle of candidates (a, b, c) the two largest
+   * entries -- p = a in the first half, p = b in the second -- are both twice its area: equal in exact arithmetic, apart by rounding
+   * residue in floating point (in float64 as in float32: which of the two points ends up in two of the four slots, i.e. carries twice
+   * the weight, would be a coin flip).  Values within AREA_TIE of the maximum count as the maximum; the lowest index wins. */
+  real vd[2 * ODKO_MAXHV];
   best = -1e30;
-  /* argmax over concat([dist_bp, dist_ap]) % n : first half (bp) wins ties */
   for (int i = 0; i < n; i++) {
     real bp[3]; v3_sub(bp, b, poly[i]);
-    real v = AREA0(fabs(v3_dot(bp, bc))) + dm[i];
-    if (v > best) { best = v; di = i; }
+    vd[i] = AREA0(fabs(v3_dot(bp, bc))) + dm[i];
+    if (vd[i] > best) best = vd[i];
   }
   for (int i = 0; i < n; i++) {
     real ap[3]; v3_sub(ap, a, poly[i]);
-    real v = AREA0(fabs(v3_dot(ap, ac))) + dm[i];
-    if (v > best) { best = v; di = i; }
+    vd[n + i] = AREA0(fabs(v3_dot(ap, ac))) + dm[i];
+    if (vd[n + i] > best) best = vd[n + i];
   }
+  for (int i = 0; i < 2 * n; i++) if (vd[i] >= best - AREA_TIE) { di = i % n; break; }
   idx[0] = ai; idx[1] = bi; idx[2] = ci; idx[3] = di;
 }
 

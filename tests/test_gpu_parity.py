@@ -12,7 +12,7 @@ RTOL_Q = 1e-4   # qpos / qvel after one mjx.step (north_star)
 
 # Bounds = min(north_star, ~3x the worst case measured on MI355X at the start of round 3 -- profiles/r3/parity_worst.json keeps
 # the measured values of the last run next to these bounds).  Relative errors use the floors given in the tests.
-STAGE_BOUNDS = dict(xpos=3e-7, M=4e-4, qfs=2e-4, qas=1.5e-4, dist=2e-7, D=3e-4, aref=1.2e-3, qacc=3.5e-3, sens=5e-4, qpos=1e-5, qvel=4e-5)
+STAGE_BOUNDS = dict(xpos=3e-7, M=4e-4, qfs=2e-4, qas=1.5e-4, dist=4e-7, D=3e-4, aref=1.2e-3, qacc=3.5e-3, sens=5e-4, qpos=1e-5, qvel=4e-5)
 TEN_BOUNDS = dict(qpos=RTOL_Q, qvel=RTOL_Q)
 FOOT_BOUNDS = dict(dist=3e-7, qacc=3e-4, qpos=1e-5, qvel=1e-5)
 
@@ -224,6 +224,80 @@ def test_height_field_far_from_the_origin(torch_cuda, oracle_mod, parity_log):
     b.close()
     # the base position itself is a float32 in the state record: 8 m carries 5e-7 m of rounding, which is the floor here
     parity_log.check("hfield_far_from_origin", dict(dist=6e-7, qacc=1e-3, tie_fraction=0.5), dist=wd, qacc=wa, tie_fraction=n_tie / n)
+
+
+def _leaning_states(oracle_mod, model, om, n, rng):
+    """per pair of envs (= per wave of the G = 32 kernels): one robot leaning on ONE foot pressed 2-8 mm into the terrain (or standing on
+    both), its neighbour in the air"""
+    qpos, qvel = _random_states(model, n, rng, airborne_frac=0.0)
+    kinds = []
+    for e in range(n):
+        kind = ("one", "air") if (e // 2) % 3 == 0 else (("air", "one") if (e // 2) % 3 == 1 else ("both", "air"))
+        kinds.append(kind[e % 2])
+        qpos[e, 0:2] = rng.uniform(-6.0, 6.0, 2)
+        if kinds[e] == "air":
+            qpos[e, 2] = 0.8
+            continue
+        lean = rng.uniform(0.25, 0.4) * rng.choice([-1.0, 1.0]) if kinds[e] == "one" else rng.uniform(-0.03, 0.03)
+        qpos[e, 3:7] = [np.cos(lean / 2), np.sin(lean / 2), 0.0, 0.0]       # roll about x: the robot leans on one foot
+        qpos[e, 7:] = np.asarray(model.a["key_qpos"])[7:]
+        qpos[e, 2] = 0.5
+        target = rng.uniform(2e-3, 8e-3)                                   # pressed in deep: many prisms within reach
+        for _ in range(14):                                                # (separated prisms report their positive separation)
+            d = oracle_mod.OracleData(om)
+            d["qpos"][: om.nq] = qpos[e]; d.forward()
+            cd = np.array(d["contact_dist"][:8])
+            qpos[e, 2] -= cd.min() + target if (cd < 0).any() else max(0.8 * cd.min(), 2e-3)
+    return qpos, qvel, kinds
+
+
+def test_height_field_lists_shared_across_the_wave(torch_cuda, oracle_mod, parity_log):
+    """The four 16-lane rows of a wave (two envs x two feet) share their prism lists: a row with nothing open takes prisms of the
+    foot with the most left.  Here the lists are as unequal as they get -- per wave one robot leaning on ONE foot pressed into the
+    terrain (or standing on both), its neighbour in the air -- so that up to four rows work one foot's list at once (ranks 0 ... 3,
+    merges rank by rank, hull registers reloaded across the two env images)."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    torch = torch_cuda
+    model = load_task_model("rough_terrain_backlash")
+    om = oracle_mod.OracleModel(model.blob())
+    n = 64
+    rng = np.random.default_rng(77)
+    qpos, qvel, kinds = _leaning_states(oracle_mod, model, om, n, rng)
+    ctrl = np.tile(np.asarray(model.a["key_ctrl"]), (n, 1))
+    b = engine.Batch(model, n)
+    b.set_state(qpos, qvel * 0.2, np.zeros((n, model.nv)))
+    b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 1)
+    gq, gv, _ = b.get_state()
+    img = b.lds_image()
+    o_cd, o_qa = b.lds_offset("contact_dist"), b.lds_offset("qacc")
+    prng = np.random.default_rng(5)
+    W = dict(dist=0.0, qacc=0.0, qpos=0.0, qvel=0.0)
+    n_tie = n_one = n_judged = 0
+    for e in range(n):
+        d = oracle_mod.OracleData(om)
+        d["qpos"][: om.nq] = qpos[e]; d["qvel"][: om.nv] = 0.2 * qvel[e]; d["ctrl"][:14] = ctrl[e]
+        d.forward()
+        cd_o, cd_g = np.array(d["contact_dist"][:8]), img[e][o_cd: o_cd + 8]
+        if kinds[e] == "air":
+            assert not (cd_o < 0).any() and not (cd_g < 0).any(), e
+            continue
+        feet_on = [(cd_o[4 * f: 4 * f + 4] < 0).any() for f in (0, 1)]
+        n_one += int(sum(feet_on) == 1)
+        if _contact_tie(oracle_mod, om, qpos[e], 0.2 * qvel[e], ctrl[e], prng, _contacts(d)):
+            n_tie += 1
+            continue
+        n_judged += 1
+        act = (cd_o < 0) | (cd_g < 0)
+        assert act.any(), e
+        W["dist"] = max(W["dist"], np.abs(cd_g[act] - cd_o[act]).max())
+        W["qacc"] = max(W["qacc"], _rel(img[e][o_qa: o_qa + model.nv], d["qacc"][: model.nv], 5.0).max())
+        ds = _oracle_step(oracle_mod, om, qpos[e], 0.2 * qvel[e], np.zeros(model.nv), ctrl[e], 1)
+        W["qpos"] = max(W["qpos"], _rel(gq[e], ds["qpos"][: om.nq], 1e-2).max())
+        W["qvel"] = max(W["qvel"], _rel(gv[e], ds["qvel"][: om.nv], 1.0).max())
+    b.close()
+    assert n_one >= n // 6 and n_judged >= n // 6, (n_one, n_judged, n_tie)
+    parity_log.check("hfield_shared_lists", dict(dist=6e-7, qacc=3.5e-3, qpos=1e-5, qvel=4e-5, tie_fraction=0.7), tie_fraction=n_tie / (n - kinds.count("air")), **W)
 
 
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
