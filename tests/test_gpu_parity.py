@@ -182,9 +182,9 @@ def test_one_substep_stages(torch_cuda, oracle_mod, parity_log, task, lanes):
         worst["qvel"] = max(worst["qvel"], _rel(gv[e], ds["qvel"][:nv], 1.0).max())
     print(task, lanes, {k: float(f"{v:.3g}") for k, v in worst.items()}, "contact ties:", n_tie, "of", n)
     b.close()
-    # flat floor: a tie needs two hull vertices at the same depth (rare); height field: candidates of neighbouring prisms share
-    # vertices and edges, and these poses are pressed 1-4 cm into the terrain
-    parity_log.check(f"one_mjx_step/{task}/lanes{lanes}", dict(STAGE_BOUNDS, tie_fraction=0.6 if "rough" in task else 0.1), tie_fraction=n_tie / n, **worst)
+    # ties (the oracle's own contact set not stable under rounding-level noise): rare since the last manifold point resolves the
+    # triangle tie by rule (oracle manifold_points AREA_TIE; 21 % of the rough-terrain poses before, none now)
+    parity_log.check(f"one_mjx_step/{task}/lanes{lanes}", dict(STAGE_BOUNDS, tie_fraction=0.15 if "rough" in task else 0.1), tie_fraction=n_tie / n, **worst)
 
 
 def test_height_field_far_from_the_origin(torch_cuda, oracle_mod, parity_log):
@@ -223,7 +223,7 @@ def test_height_field_far_from_the_origin(torch_cuda, oracle_mod, parity_log):
         wa = max(wa, _rel(img[e][o_qa: o_qa + model.nv], d["qacc"][: model.nv], 5.0).max())
     b.close()
     # the base position itself is a float32 in the state record: 8 m carries 5e-7 m of rounding, which is the floor here
-    parity_log.check("hfield_far_from_origin", dict(dist=6e-7, qacc=1e-3, tie_fraction=0.5), dist=wd, qacc=wa, tie_fraction=n_tie / n)
+    parity_log.check("hfield_far_from_origin", dict(dist=6e-7, qacc=1e-3, tie_fraction=0.15), dist=wd, qacc=wa, tie_fraction=n_tie / n)
 
 
 def _leaning_states(oracle_mod, model, om, n, rng):
@@ -297,7 +297,7 @@ def test_height_field_lists_shared_across_the_wave(torch_cuda, oracle_mod, parit
         W["qvel"] = max(W["qvel"], _rel(gv[e], ds["qvel"][: om.nv], 1.0).max())
     b.close()
     assert n_one >= n // 6 and n_judged >= n // 6, (n_one, n_judged, n_tie)
-    parity_log.check("hfield_shared_lists", dict(dist=6e-7, qacc=3.5e-3, qpos=1e-5, qvel=4e-5, tie_fraction=0.7), tie_fraction=n_tie / (n - kinds.count("air")), **W)
+    parity_log.check("hfield_shared_lists", dict(dist=6e-7, qacc=3.5e-3, qpos=1e-5, qvel=4e-5, tie_fraction=0.15), tie_fraction=n_tie / (n - kinds.count("air")), **W)
 
 
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
@@ -342,7 +342,7 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
         wv = max(wv, _rel(gv[e], v1, 1.0).max())
     print(task, "10 substeps: worst rel qpos", wq, "qvel", wv, "ill-conditioned:", n_ill, "of", n)
     b.close()
-    parity_log.check(f"ten_substeps/{task}", dict(TEN_BOUNDS, ill_fraction=0.7 if "rough" in task else 0.35), qpos=wq, qvel=wv, ill_fraction=n_ill / n)
+    parity_log.check(f"ten_substeps/{task}", dict(TEN_BOUNDS, ill_fraction=0.5 if "rough" in task else 0.4), qpos=wq, qvel=wv, ill_fraction=n_ill / n)
 
 
 @pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32)])
@@ -407,9 +407,9 @@ def test_foot_foot_contacts(torch_cuda, oracle_mod, parity_log, task, lanes):
     print(task, dict(n=n, penetrating=n_pen, flips=n_flip, ties=n_tie, **{k: float(f"{v:.3g}") for k, v in worst.items()}))
     b.close()
     assert n_pen >= 30, "the grid must contain penetrating poses"
-    parity_log.rec(f"foot_foot/{task}/lanes{lanes}", dict(flips=0, ties=n // 3), flips=n_flip, penetrating=n_pen, ties=n_tie, poses=n, single_contact_poses=n_single)
+    parity_log.rec(f"foot_foot/{task}/lanes{lanes}", dict(flips=0, ties=n // 20), flips=n_flip, penetrating=n_pen, ties=n_tie, poses=n, single_contact_poses=n_single)
     assert n_single >= 5, "the grid must contain edge-edge (single-contact) poses"
-    assert n_flip == 0 and n_tie <= n // 3
+    assert n_flip == 0 and n_tie <= n // 20
     parity_log.check(f"foot_foot/{task}/lanes{lanes}", FOOT_BOUNDS, **worst)
 
 
@@ -525,7 +525,7 @@ def test_box_feet_variant(torch_cuda, oracle_mod, parity_log, task):
     b.close()
     assert n_contact >= n // 3 and ("rough" in task or n_ff >= 5), (n_contact, n_ff)
     # a box sole is exactly flat: on the plane its four corners tie in depth whenever the foot lies flat (rare in these random poses)
-    parity_log.check(f"box_feet/{task}", dict(dist=1e-6, qpos=1e-5, qvel=4e-5, tie_fraction=0.6), tie_fraction=n_tie / n, **W)
+    parity_log.check(f"box_feet/{task}", dict(dist=1e-6, qpos=1e-5, qvel=4e-5, tie_fraction=0.15), tie_fraction=n_tie / n, **W)
 
 
 def _substep_sensitivity(O, om, om32, qpos, qvel, ctrl, nsub, prng, tries=6):
