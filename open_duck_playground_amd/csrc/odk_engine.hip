@@ -1259,6 +1259,10 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
                                m.foot_centroid[f], MAXHF, 48)) {
         delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull: not a closed polytope with <= 4-vertex faces and <= 48 edges");
       }
+      for (int t = 0; t < m.foot_npoly[f]; t++) {
+        const double* v0 = bv[m.foot_poly[f][t][1]];
+        m.foot_foff[f][t] = (float)(m.foot_fnorm[f][t][0] * v0[0] + m.foot_fnorm[f][t][1] * v0[1] + m.foot_fnorm[f][t][2] * v0[2]);
+      }
     }
   }
   {   // a height-field prism's topology: the kernels' compile-time tables (odk_model.h) against this file's table builder

@@ -963,6 +963,8 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   float* FV = L + S::O_CFRC + f * 51; float* FN = L + S::O_CFRC + 102 + f * 90;
   float* RS = L + (f ? S::O_BUF6B : S::O_BUF6);
   float* PV = RS;                                                      // prism vertices [6][3]
+  float* FD = L + S::O_X + f * 30;                                      // [<= 30] plane offsets of the hull's faces (x | Ma | search | mv: dead until the solver)
+  static_assert(4 * S::NV >= 60, "hull face offsets");
   float* META = RS + 106;                                              // for the other rows: ncw, hull centroid [3], mask of this foot's open list entries, the entry this ROW took last (foot << 8 | entry)
   static_assert(6 * S::NVR >= 111, "row scratch + window record");
   float* RL = L + S::O_D + f * 172;
@@ -988,9 +990,16 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   const int nc = m->hfield_ncol, nr = m->hfield_nrow;
   const float sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2], base = m->hfield_size[3];
   const float dx = 2.0f * sx / (float)(nc - 1), dy = 2.0f * sy / (float)(nr - 1);
-  const float rad = sqrtf(dot3(m->foot_obb_half[f], m->foot_obb_half[f]));
-  int cmin = (int)floorf((cl[0] - rad + sx) / dx), cmax = (int)floorf((cl[0] + rad + sx) / dx);
-  int rmin = (int)floorf((cl[1] - rad + sy) / dy), rmax = (int)floorf((cl[1] + rad + sy) / dy);
+  // MJX takes the cells under the bounding sphere; every prism outside the hull's own x / y extent is separated from it by one of its
+  // axis-aligned or diagonal side faces (dist > 0: no force), so the window is the extent of the hull's oriented box (<= the sphere's)
+  float ex = 0.0f, ey = 0.0f;
+  for (int a = 0; a < 3; a++) {
+    const float* ax = m->foot_obb_axes[f];
+    ex += fabsf(Rw[0] * ax[a] + Rw[1] * ax[3 + a] + Rw[2] * ax[6 + a]) * m->foot_obb_half[f][a];
+    ey += fabsf(Rw[3] * ax[a] + Rw[4] * ax[3 + a] + Rw[5] * ax[6 + a]) * m->foot_obb_half[f][a];
+  }
+  int cmin = (int)floorf((cl[0] - ex + sx) / dx), cmax = (int)floorf((cl[0] + ex + sx) / dx);
+  int rmin = (int)floorf((cl[1] - ey + sy) / dy), rmax = (int)floorf((cl[1] + ey + sy) / dy);
   cmin = cmin < 0 ? 0 : cmin; rmin = rmin < 0 ? 0 : rmin; cmax = cmax > nc - 2 ? nc - 2 : cmax; rmax = rmax > nr - 2 ? nr - 2 : rmax;
   int ncw = cmax - cmin + 1, nrw = rmax - rmin + 1;
   ncw = ncw > 3 ? 3 : ncw; nrw = nrw > 3 ? 3 : nrw;   // the sphere (radius < a cell) spans at most 3 cells per axis
@@ -1004,7 +1013,9 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   }
   for (int t = j; t < nfc; t += 16) {
     const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
-    for (int k = 0; k < 3; k++) FN[3 * t + k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2];
+    float nw[3];
+    for (int k = 0; k < 3; k++) { nw[k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2]; FN[3 * t + k] = nw[k]; }
+    FD[t] = m->foot_foff[f][t] + dot3(nw, Pw);   // the face's plane offset in the window frame: n . (P + R v) = n_b . v_b + n . P
   }
   float fc[3];
   for (int k = 0; k < 3; k++) fc[k] = Pw[k] + Rw[3 * k] * m->foot_centroid[f][0] + Rw[3 * k + 1] * m->foot_centroid[f][1] + Rw[3 * k + 2] * m->foot_centroid[f][2];
@@ -1051,19 +1062,41 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     float d5[5], s5[5] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
     d5[0] = P.nt[0] * P.x[0] + P.nt[1] * P.y[0] + P.nt[2] * P.z[0]; d5[1] = base;
     d5[2] = P.ns[0][0] * P.x[0] + P.ns[0][1] * P.y[0]; d5[3] = P.ns[1][0] * P.x[1] + P.ns[1][1] * P.y[1]; d5[4] = P.ns[2][0] * P.x[2] + P.ns[2][1] * P.y[2];
-    for (int q = 0; q < nvt; q++) {
+    const int nvu = max(m->foot_nvert[0], m->foot_nvert[1]);   // (wave-uniform trip count, as for the faces below)
+#pragma unroll 2
+    for (int q = 0; q < nvu; q++) {
+      const float big = q < nvt ? 0.0f : 3.0e38f;
       const float v[3] = {FV[3 * q], FV[3 * q + 1], FV[3 * q + 2]};
-      s5[0] = fminf(s5[0], dot3(P.nt, v)); s5[1] = fminf(s5[1], -v[2]);
-      s5[2] = fminf(s5[2], P.ns[0][0] * v[0] + P.ns[0][1] * v[1]); s5[3] = fminf(s5[3], P.ns[1][0] * v[0] + P.ns[1][1] * v[1]);
-      s5[4] = fminf(s5[4], P.ns[2][0] * v[0] + P.ns[2][1] * v[1]);
+      s5[0] = fminf(s5[0], dot3(P.nt, v) + big); s5[1] = fminf(s5[1], -v[2] + big);
+      s5[2] = fminf(s5[2], P.ns[0][0] * v[0] + P.ns[0][1] * v[1] + big); s5[3] = fminf(s5[3], P.ns[1][0] * v[0] + P.ns[1][1] * v[1] + big);
+      s5[4] = fminf(s5[4], P.ns[2][0] * v[0] + P.ns[2][1] * v[1] + big);
     }
     float sep = -3.0e38f; int face = 0;
 #pragma unroll
     for (int fa = 0; fa < 5; fa++) { const float sv = s5[fa] - d5[fa]; if (sv > sep) { sep = sv; face = fa; } }
-    const bool keep = valid && !(sep > 0.0f);
+    // the hull's face query against this prism's six vertices: with the prism's own it bounds the pair's best separating axis,
+    // hence every contact of the pair, from below -- a prism beside the foot (inside the window, outside the slab) is separated by
+    // one of the hull's side faces and never enters the list; the others are ranked by the larger of the two bounds.  (The six
+    // faces of the hull's oriented box instead: a third of the cost, 0.4 more pairs per foot in the loop -- no gain.)
+    float sep_b = -3.0e38f;
+    {
+      const float zb = -base;
+      // (wave-uniform trip count: with this row's own face count the loop is divergent across the rows and costs three times as much)
+      const int nfu = max(m->foot_npoly[0], m->foot_npoly[1]);
+#pragma unroll 2
+      for (int t = 0; t < nfu; t++) {
+        const float n0 = FN[3 * t], n1 = FN[3 * t + 1], n2 = FN[3 * t + 2], dd = FD[t];
+        const float h0 = n0 * P.x[0] + n1 * P.y[0], h1 = n0 * P.x[1] + n1 * P.y[1], h2 = n0 * P.x[2] + n1 * P.y[2];
+        const float top = fminf(fminf(h0 + n2 * z[0], h1 + n2 * z[1]), h2 + n2 * z[2]), bot = fminf(fminf(h0, h1), h2) + n2 * zb;
+        const float s = fminf(top, bot) - dd;
+        sep_b = (t < nfc && s > sep_b) ? s : sep_b;
+      }
+    }
+    const float bound = fmaxf(sep, sep_b);
+    const bool keep = valid && !(bound > 0.0f);
     const unsigned rowmask = (unsigned)((__builtin_amdgcn_ballot_w64(keep) >> (threadIdx.x & 48u)) & 0xFFFFull);
     const int pos = cnt + __popc(rowmask & ((1u << j) - 1u));
-    if (keep) { float* o = LIST + 6 * pos; o[0] = __int_as_float(p); o[1] = z[0]; o[2] = z[1]; o[3] = z[2]; o[4] = sep; o[5] = __int_as_float(face); }
+    if (keep) { float* o = LIST + 6 * pos; o[0] = __int_as_float(p | (face << 8)); o[1] = z[0]; o[2] = z[1]; o[3] = z[2]; o[4] = sep; o[5] = bound; }
     cnt += __popc(rowmask);
   }
   ODK_SYNC();
@@ -1073,10 +1106,10 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     int rk0 = 0, rk1 = 0;
 #pragma unroll 6
     for (int q = 0; q < 18; q++) {
-      const float sq = LIST[6 * q + 4];
+      const float sq = LIST[6 * q + 5];
       const bool in = q < cnt;
-      rk0 += (in && (sq < e0[4] || (sq == e0[4] && q < j))) ? 1 : 0;
-      rk1 += (in && (sq < e1[4] || (sq == e1[4] && q < j + 16))) ? 1 : 0;
+      rk0 += (in && (sq < e0[5] || (sq == e0[5] && q < j))) ? 1 : 0;
+      rk1 += (in && (sq < e1[5] || (sq == e1[5] && q < j + 16))) ? 1 : 0;
     }
     ODK_SYNC();
     if (j < cnt) for (int t = 0; t < 6; t++) LIST[6 * rk0 + t] = e0[t];
@@ -1108,7 +1141,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   FaceRegs<2> FB;
   float* LISTt = LIST; float* TOPt = TOP;
   unsigned cur_pk = 0u | (1u << 8) | (2u << 16) | (3u << 24);   // wave-uniform: the foot each row is on
-  const float s0 = j < cnt ? LIST[6 * j + 4] : 3.0e38f, s1 = j + 16 < cnt ? LIST[6 * (j + 16) + 4] : 3.0e38f;   // own list's seps (sorted)
+  const float s0 = j < cnt ? LIST[6 * j + 5] : 3.0e38f, s1 = j + 16 < cnt ? LIST[6 * (j + 16) + 5] : 3.0e38f;   // own list's bounds (sorted)
   unsigned taken = 0u;        // row-uniform: entries of the own list that some row has taken
   HF_PROF(2);
 #ifdef ODK_PROFILE
@@ -1179,9 +1212,10 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     const int kk = act ? __ffs((int)wsel) - 1 : 0;
     if (j == 0) META[5] = __int_as_float(act ? (my_tg << 8) | kk : 0xFFFF);
     const float* en = LISTt + 6 * kk;
-    const int p = act ? __float_as_int(en[0]) : 0;
+    const int pf = act ? __float_as_int(en[0]) : 0;
+    const int p = pf & 255, face_a = pf >> 8;
     const float z[3] = {en[1], en[2], en[3]};
-    const float sep_a = en[4]; const int face_a = act ? __float_as_int(en[5]) : 0;
+    const float sep_a = en[4];
     Prism P;
     prism(p, ncw_t, z, P);
     {   // lane j < 6 writes vertex j for the polygon fetch (selects, no per-lane indexing of register arrays: that is scratch)

@@ -124,6 +124,7 @@ struct DevModel {
   int foot_npoly[2], foot_nedge[2];
   int foot_poly[2][MAXHF][5];
   float foot_fnorm[2][MAXHF][3];
+  float foot_foff[2][MAXHF];       // plane offsets n . v of the hull's faces in the body frame (height-field cull: hull face query per prism)
   int foot_edge[2][MAXHE][4];
   float foot_centroid[2][3];
   // primitive colliders in place of the foot hulls (mjtGeom: 2 sphere, 3 capsule; 7 = convex hull, the duck's own): centre and, for a
