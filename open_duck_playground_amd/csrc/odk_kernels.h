@@ -142,6 +142,8 @@ struct Shape {
   static constexpr int S_VF = 0;      // [2][6] foot twist of the current vector
   static constexpr int S_FF = 12;     // [2][6] foot wrench sums
   static constexpr int S_K = 24;      // [3][36] K_L, K_R, K_X
+  static constexpr int S_FR = S_K;    // [8][9] frames of the floor contacts (height field / primitive feet): contact phase -> row phase only, ALIASES
+                                      // the K blocks (born in the solver).  NOT in the row arrays: the foot-foot routine's hull copies live there.
   static constexpr int S_VF2 = 132;   // [2][6] second foot twist (warmstart candidate)
   static constexpr int S_FFX = 144;   // [6] wrench sum of the foot-foot rows
   static constexpr int S_MISC = 156;  // misc scalars (16)
@@ -1259,19 +1261,19 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     }
     CDIST[c] = out[0];
     for (int t = 0; t < 3; t++) CR[3 * c + t] = pw[t] - ref[t];
-    make_frame_dev(nw, L + S::O_JV + 9 * c);
+    make_frame_dev(nw, L + S::O_SCR + S::S_FR + 9 * c);
   }
 }
 
 // Primitive foot colliders (sphere / capsule feet on the plane floor): mjx collision_primitive.py as the oracle restates
 // it -- plane_sphere, plane_capsule (two contacts, frame aligned with the capsule axis), sphere_sphere, sphere_capsule,
 // capsule_capsule.  A handful of scalar operations: lane 0 of the env does them; out of line so that the duck's own kernels pay one
-// uniform branch.  Writes all twelve contact slots, the eight floor-contact frames (jv rows, as the height-field path) and the
+// uniform branch.  Writes all twelve contact slots, the eight floor-contact frames (S_FR, as the height-field path) and the
 // foot-foot frame (S_VF, as the convex-convex path).
 template <class S, int G>
 __device__ __noinline__ void prim_contacts(float* L, const DevModel* __restrict__ m, int lane) {
   constexpr int NB = S::NB;
-  float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR; float* FR = L + S::O_JV;
+  float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR; float* FR = L + S::O_SCR + S::S_FR;
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
   if (lane != 0) return;
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
@@ -2012,15 +2014,15 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   // foot-foot rows (32..47) are skipped wave-wide unless some env has a penetrating foot-foot contact (D = 0 rows
   // are never read again: the solver gates on D > 0 and on the same wave-uniform flag)
   const bool ff_rows = __builtin_amdgcn_ballot_w64(fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0.0f) != 0;
-  const bool prim_feet = !HF && m->foot_prim != 0;   // sphere / capsule feet: per-contact frames in the jv rows (prim_contacts)
+  const bool prim_feet = !HF && m->foot_prim != 0;   // sphere / capsule feet: per-contact frames in S_FR (prim_contacts)
   for (int rc = lane; rc < S::NCROW; rc += G) {
     const int r = r0c + rc, c = rc >> 2, s = rc & 3, pair = c >> 2;
     if (rc >= 32 && !ff_rows) { ED[r] = 0.0f; AREF[r] = 0.0f; continue; }
     const float dist = CDIST[c];
     const float mu = CT[pair];
     const float fs = (s & 1) ? -mu : mu;
-    // foot-foot frame: left in S_VF by the SAT routine; height-field floor: one frame per contact left in the jv rows by P7
-    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && (HF || prim_feet)) ? L + S::O_JV + 9 * c : CT + 33);
+    // foot-foot frame: left in S_VF by the SAT routine; height-field floor: one frame per contact left in S_FR by P7
+    const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && (HF || prim_feet)) ? SCR + S::S_FR + 9 * c : CT + 33);
     const int td = 3 * (1 + (s >> 1));
     const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
     const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};

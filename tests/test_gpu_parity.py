@@ -300,6 +300,63 @@ def test_height_field_lists_shared_across_the_wave(torch_cuda, oracle_mod, parit
     parity_log.check("hfield_shared_lists", dict(dist=6e-7, qacc=3.5e-3, qpos=1e-5, qvel=4e-5, tie_fraction=0.15), tie_fraction=n_tie / (n - kinds.count("air")), **W)
 
 
+def test_height_field_neighbour_with_touching_feet(torch_cuda, oracle_mod, parity_log):
+    """The foot-foot routine runs for the whole wave as soon as one of its two envs has overlapping feet, and copies both hulls into the
+    row arrays.  Whatever the height-field contacts of the OTHER env left for the row phase must not live there (the first version kept
+    the per-contact frames in the jv rows: three of the neighbour's floor contacts got a hull vertex for a frame).  Per wave: one robot
+    standing on the terrain, its neighbour in the air with the feet pressed together."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    torch = torch_cuda
+    model = load_task_model("rough_terrain_backlash")
+    om = oracle_mod.OracleModel(model.blob())
+    n = 48
+    rng = np.random.default_rng(91)
+    qpos, qvel = _random_states(model, n, rng, airborne_frac=0.0)
+    aq = build_tables(model)["k_act_qposadr"]
+    for e in range(n):
+        if e % 2 == 1:
+            qpos[e] = np.asarray(model.a["key_qpos"]); qpos[e, 2] = 0.5
+            qpos[e, int(aq[1])] = rng.uniform(0.4, 0.6); qpos[e, int(aq[10])] = rng.uniform(-0.6, -0.4); qpos[e, int(aq[0])] += rng.uniform(-0.3, 0.3)
+        else:
+            qpos[e, 0:2] = rng.uniform(-6.0, 6.0, 2)
+            qpos[e, 7:] = np.asarray(model.a["key_qpos"])[7:] + rng.uniform(-0.03, 0.03, model.nq - 7) * (np.asarray(model.a["key_qpos"])[7:] != 0)
+            qpos[e, 2] = 0.4
+            target = rng.uniform(5e-4, 4e-3)
+            for _ in range(14):
+                d = oracle_mod.OracleData(om)
+                d["qpos"][: om.nq] = qpos[e]; d.forward()
+                cd = np.array(d["contact_dist"][:8])
+                qpos[e, 2] -= cd.min() + target if (cd < 0).any() else max(0.8 * cd.min(), 2e-3)
+    ctrl = np.tile(np.asarray(model.a["key_ctrl"]), (n, 1))
+    b = engine.Batch(model, n)
+    b.set_state(qpos, qvel, np.zeros((n, model.nv)))
+    b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 1)
+    gq, gv, _ = b.get_state()
+    img = b.lds_image(); o_cd = b.lds_offset("contact_dist")
+    b.close()
+    prng = np.random.default_rng(92)
+    W = dict(dist=0.0, qpos=0.0, qvel=0.0)
+    n_ff = n_floor = n_tie = 0
+    for e in range(n):
+        d = oracle_mod.OracleData(om)
+        d["qpos"][: om.nq] = qpos[e]; d["qvel"][: om.nv] = qvel[e]; d["ctrl"][:14] = ctrl[e]
+        d.forward()
+        cd_o, cd_g = np.array(d["contact_dist"][:12]), img[e][o_cd: o_cd + 12]
+        n_ff += int(e % 2 == 1 and (cd_o[8:] < 0).any()); n_floor += int(e % 2 == 0 and (cd_o[:8] < 0).any())
+        if _contact_tie(oracle_mod, om, qpos[e], qvel[e], ctrl[e], prng, _contacts(d)):
+            n_tie += 1
+            continue
+        act = (cd_o < 0) | (cd_g < 0)
+        if act.any():
+            W["dist"] = max(W["dist"], np.abs(cd_g[act] - cd_o[act]).max())
+        ds = _oracle_step(oracle_mod, om, qpos[e], qvel[e], np.zeros(model.nv), ctrl[e], 1)
+        W["qpos"] = max(W["qpos"], _rel(gq[e], ds["qpos"][: om.nq], 1e-2).max())
+        W["qvel"] = max(W["qvel"], _rel(gv[e], ds["qvel"][: om.nv], 1.0).max())
+    assert n_ff >= n // 3 and n_floor >= n // 3, (n_ff, n_floor)
+    parity_log.check("hfield_neighbour_touching_feet", dict(dist=6e-7, qpos=1e-5, qvel=4e-5, tie_fraction=0.15), tie_fraction=n_tie / n, **W)
+
+
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
 def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
     """mjx_env.step (10 substeps) from standing-ish states: state after one env step within 1e-4 relative."""
