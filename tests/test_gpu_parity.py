@@ -705,3 +705,22 @@ def test_primitive_feet_variant(torch_cuda, oracle_mod, parity_log, kinds):
 def build_tables(model):
     from open_duck_playground_amd.tables import build_kernel_tables
     return build_kernel_tables(model.a)
+
+
+@pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32), ("rough_terrain_backlash", 32)])
+def test_differential_sweep(torch_cuda, oracle_mod, parity_log, task, lanes):
+    """A reduced run of tools/gpu_fuzz_parity.py: 768 random contact-rich states per model (leaning on one foot, near the home pose,
+    feet pressed together in the air / on the floor -- next to a neighbour of another kind in the same wave --, airborne, far from the
+    origin on the height field), one mjx.step.  Every state either agrees with the float64 oracle or is explained on the oracle side
+    (contact tie under rounding-level noise; the oracle's float32 build on the kernel's side; solver branch): nothing unexplained."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("gpu_fuzz_parity", os.path.join(ROOT, "tools", "gpu_fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    n = 768
+    stat, worst = fz.sweep(task, n, seed=123, lanes=lanes, nsub=1, dist_tol=3e-6 if "rough" in task else 1e-6)   # (8 m from the origin float32 positions carry 5e-7 m)
+    assert stat["in_contact"] > n // 2 and stat["foot_foot"] > n // 20 and stat["both_feet"] > n // 20, stat
+    assert stat["unexplained"] == 0, stat
+    parity_log.check(f"differential_sweep/{task}/lanes{lanes}", dict(dist=3e-6 if "rough" in task else 3e-7, qvel=1e-4, explained_fraction=0.01),
+                     explained_fraction=(stat["tie"] + stat["f32_side"] + stat["solver_branch"]) / n, **worst)
