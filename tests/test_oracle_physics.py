@@ -351,3 +351,82 @@ def test_yaw_equivariance(oracle_mod, model_a):
         np.testing.assert_allclose(a2[3:], a1[3:], atol=1e-8 * scale + 1e-9)
         np.testing.assert_allclose(s2[0:9], s1[0:9], atol=1e-8 * np.abs(s1).max())     # gyro, local linvel, accelerometer are body-frame
         np.testing.assert_allclose(s2[9:12], Rz @ s1[9:12], atol=1e-9)                  # upvector = site z axis in the WORLD frame
+
+
+def _impedance(pos, solimp):
+    """MuJoCo documentation, 'Solver parameters': d(r) rises from dmin to dmax over `width` along a two-piece power curve"""
+    dmin, dmax, width, mid, power = solimp
+    x = abs(pos) / width
+    if x >= 1.0:
+        return dmax
+    y = x ** power / mid ** (power - 1) if x < mid else 1.0 - (1.0 - x) ** power / (1.0 - mid) ** (power - 1)
+    return dmin + y * (dmax - dmin)
+
+
+def test_constraint_row_parameters_follow_the_documented_formulas(oracle_mod, model_a):
+    """Every row's regulariser D = 1 / R and reference acceleration aref, recomputed here from MuJoCo's documented soft-constraint
+    model (Computation chapter 'Solver parameters'; pyramidal rows as in mjx constraint.py): R = (1 - d) / d * A with A the row's
+    approximate inverse inertia (dof_invweight0; for a pyramid edge (1 + mu^2) (w_1 + w_2) * 2 mu^2 / impratio), aref = -b v - k d r,
+    b = 2 / (dmax timeconst), k = 1 / (dmax^2 timeconst^2 dampratio^2), timeconst >= 2 timestep (refsafe).  An independent
+    restatement in numpy: a typo in the oracle's row arithmetic would pass every oracle-vs-kernel test."""
+    a = model_a.a
+    rng = np.random.default_rng(3)
+    q = np.array(a["key_qpos"], float); q[2] = 0.148            # feet a few millimetres into the floor
+    q[10] = 1.62                                                # left knee beyond its limit
+    v = rng.normal(0, 0.5, model_a.nv)
+    om, d = _data(oracle_mod, model_a, qpos=q, qvel=v)
+    d.forward()
+    nv, nf, nl, nc = om.nv, d.i("nf"), d.i("nl"), d.i("nc")
+    assert (nf, nl, nc) == (14, 14, 48)
+    J = d.J(); D = np.array(d["efc_D"][: nf + nl + nc]); aref = np.array(d["efc_aref"][: nf + nl + nc])
+    dt = 0.002
+    dof_w = np.array(om.f.view("dof_invweight0")[:nv]); body_w = np.array(om.f.view("body_invweight0")[: 2 * om.nbody]).reshape(-1, 2)
+    vel = J @ v
+
+    def row(pos, invw, solref, solimp, vrow):
+        tc = max(solref[0], 2 * dt); dr = solref[1]
+        dmax = solimp[1]
+        imp = _impedance(pos, solimp)
+        return imp / ((1 - imp) * invw), -2.0 / (dmax * tc) * vrow - imp * pos / (dmax * dmax * tc * tc * dr * dr)
+    default_ref, default_imp = (0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)      # MuJoCo defaults: the duck's XML sets none of them
+    r = 0
+    for i in range(nv):                                                       # friction loss: pos = 0, the dof's own velocity
+        if a["dof_frictionloss"][i] > 0:
+            De, ae = row(0.0, dof_w[i], default_ref, default_imp, v[i])
+            assert D[r] == pytest.approx(De, rel=1e-12) and aref[r] == pytest.approx(ae, rel=1e-12, abs=1e-12)
+            r += 1
+    assert r == nf
+    n_active_lim = 0
+    for j in range(model_a.njnt):                                             # hinge limits
+        if not a["jnt_limited"][j] or a["jnt_type"][j] == 0:
+            continue
+        qa, da = a["jnt_qposadr"][j], a["jnt_dofadr"][j]
+        lo, hi = a["jnt_range"][j]
+        pos = min(q[qa] - lo, hi - q[qa]); sgn = 1.0 if q[qa] - lo < hi - q[qa] else -1.0
+        if pos < 0:
+            n_active_lim += 1
+            De, ae = row(pos, dof_w[da], default_ref, default_imp, sgn * v[da])
+            assert J[r, da] == sgn and D[r] == pytest.approx(De, rel=1e-12) and aref[r] == pytest.approx(ae, rel=1e-12)
+        else:
+            assert not J[r].any()
+        r += 1
+    assert r == nf + nl and n_active_lim == 1
+    cd = np.array(d["contact_dist"][:12]); n_active = 0
+    floor_mu = 0.6                                                             # scene_flat_terrain.xml:35-36, priority 1
+    for c in range(12):
+        g2_body = [int(a["cgeom_bodyid"][g]) for g in range(3) if a["cgeom_type"][g] == 7]
+        b_foot = g2_body[0] if c < 4 else g2_body[1]
+        if c >= 8:
+            assert cd[c] > 0                                                   # the feet do not touch each other here
+            r += 4
+            continue
+        mu = floor_mu
+        w = body_w[b_foot][0] + 0.0                                            # translational invweight of the two bodies (the floor: world)
+        invw = (w + mu * mu * w) * 2 * mu * mu / 1.0                           # impratio = 1
+        for k in range(4):
+            if cd[c] < 0:
+                n_active += 1
+                De, ae = row(cd[c], invw, default_ref, default_imp, vel[r])
+                assert D[r] == pytest.approx(De, rel=1e-12) and aref[r] == pytest.approx(ae, rel=1e-10)
+            r += 1
+    assert n_active >= 16
