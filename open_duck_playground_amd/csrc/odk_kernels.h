@@ -1932,6 +1932,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       const float r1 = sqrtf(dot3(m->foot_obb_half[0], m->foot_obb_half[0])), r2 = sqrtf(dot3(m->foot_obb_half[1], m->foot_obb_half[1]));
       sph = sqrtf(dot3(dc, dc)) - r1 - r2;
     }
+    float boxsep = -3.0e38f;
     if (__builtin_amdgcn_ballot_w64(!(sph > 0.0f)) != 0) {
       if (lane < 15) {
         float c1[3], c2[3], A1[9], A2[9], tt[3];
@@ -1972,8 +1973,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
           sep = fabsf(dot3(tt, ax)) - r1 - r2;
         }
       }
+      boxsep = gmax<G>(sep);   // (inside the wave-uniform branch: cross-lane ops stay in uniform control flow)
     }
-    const float boxsep = gmax<G>(sep);   // unconditional: cross-lane ops stay in uniform control flow
     const float best = sph > 0.0f ? sph : boxsep;
     if (lane < 4) {
       const int c = 8 + lane;
