@@ -786,7 +786,7 @@ __device__ __forceinline__ void row_params(const float* P, float pos, float invw
 // arithmetic instead of by rounding residue)
 __device__ __forceinline__ float area0(float v) { return v < 1e-7f ? 0.0f : v; }
 // last manifold point: values within AREA_TIE of the maximum count as the maximum, the lowest index wins (oracle manifold_points)
-constexpr float AREA_TIE = 1e-8f;
+constexpr float AREA_TIE = 1e-7f;
 template <int G>
 __device__ __forceinline__ void select4(const float* w, bool has, float sup, int nvt, const float* n, int* idx, int lane) {
   const float smax = gmax<G>(sup);
@@ -906,7 +906,7 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
     const int fb = m->foot_body[f];
     float q[4], R[9], P[3];
     for (int k = 0; k < 4; k++) q[k] = XQUAT[k * NB + fb];
-    for (int k = 0; k < 3; k++) P[k] = XPOS[k * NB + fb];
+    for (int k = 0; k < 3; k++) P[k] = XPOS[k * NB + fb] - ref[k];   // relative to the base: a robot metres from the origin keeps float32 digits for the hull
     q2mat(R, q);
     for (int v = lane; v < m->foot_nvert[f]; v += G) {
       const float vb[3] = {m->foot_vert[f][v][0], m->foot_vert[f][v][1], m->foot_vert[f][v][2]};
@@ -931,7 +931,7 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
     const float* o = RS + 24 + 8 * j;
     const int c = 8 + j;
     CDIST[c] = o[0];
-    for (int t = 0; t < 3; t++) CR[3 * c + t] = o[1 + t] - ref[t];
+    for (int t = 0; t < 3; t++) CR[3 * c + t] = o[1 + t];
     if (j == 0) make_frame_dev(o + 4, SCR + S::S_VF);   // the pair's contact frame (one normal for all four), consumed by P8
   }
 }

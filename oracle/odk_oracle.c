@@ -483,7 +483,7 @@ static void make_frame(real* frame, const real* n) {
  * with it how many of the four slots repeat which point, i.e. the weight of each contact -- would be rounding noise, different
  * in float32 and float64.  With the threshold both resolve the tie like exact arithmetic does. */
 #define AREA0(v) ((v) < 1e-7 ? 0.0 : (v))
-#define AREA_TIE 1e-8
+#define AREA_TIE 1e-7
 static void manifold_points(const real (*poly)[3], const int* mask, int n, const real* norm, int* idx) {
   real dm[ODKO_MAXHV];
   int ai = 0, bi = 0, ci = 0, di = 0;

@@ -16,9 +16,17 @@ from open_duck_playground_amd import engine  # noqa: E402
 from open_duck_playground_amd.model import load_task_model  # noqa: E402
 from test_gpu_parity import _contact_tie, _contacts, _oracle_step, _random_states, _rel  # noqa: E402
 
-def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True):
-    """one model: returns (counts, worst errors of the states that agree)"""
-    model = load_task_model(task)
+def make_states(task, n=1024, seed=0, variant=None):
+    """CPU only: the model (variant: None | "box" | "sphere-capsule" ...: the foot colliders replaced as in tests/test_gpu_parity.py),
+    its oracle models and the random contact-rich states of the sweep"""
+    if variant is None:
+        model = load_task_model(task)
+    elif variant == "box":
+        from test_gpu_parity import _box_feet_variant
+        model = _box_feet_variant(task)
+    else:
+        from test_gpu_parity import _prim_feet_variant
+        model = _prim_feet_variant(task, tuple(variant.split("-")))
     om = O.OracleModel(model.blob()); om32 = O.OracleModel(model.blob(), f32=True)
     rng = np.random.default_rng(seed)
     qpos, qvel = _random_states(model, n, rng, airborne_frac=0.1)
@@ -51,6 +59,12 @@ def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True):
             qpos[e, 2] -= cd.min() + target if (cd < 0).any() else max(0.8 * min(cd.min(), 0.2), 2e-3)
     ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.4, 0.4, (n, 14))
     warm = rng.normal(0, 3.0, (n, model.nv))
+    return model, om, om32, qpos, qvel, warm, ctrl
+
+
+def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True, variant=None):
+    """one model: returns (counts, worst errors of the states that agree)"""
+    model, om, om32, qpos, qvel, warm, ctrl = make_states(task, n, seed, variant)
     cfg = engine.default_config(); cfg.lanes_per_env = lanes if "rough" not in task else 32
     b = engine.Batch(model, n, cfg)
     b.set_state(qpos, qvel, warm)
@@ -68,7 +82,11 @@ def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True):
         cd_o = np.array(d["contact_dist"][:12]); cd_g = img[e][o_cd: o_cd + 12]
         stat["in_contact"] += int((cd_o[:8] < 0).any()); stat["both_feet"] += int((cd_o[:4] < 0).any() and (cd_o[4:8] < 0).any()); stat["foot_foot"] += int((cd_o[8:] < 0).any())
         act = (cd_o < 0) | (cd_g < 0)
-        derr = np.abs(cd_g[act] - cd_o[act]).max() if act.any() else 0.0
+        # per geom pair as multisets: which slot a manifold point lands in may differ where two candidates tie in area (a rectangle's
+        # two far corners), the set of contacts -- the physics -- is the same
+        so, sg = np.concatenate([np.sort(cd_o[4 * p: 4 * p + 4]) for p in range(3)]), np.concatenate([np.sort(cd_g[4 * p: 4 * p + 4]) for p in range(3)])
+        acts = (so < 0) | (sg < 0)
+        derr = np.abs(sg[acts] - so[acts]).max() if acts.any() else 0.0
         ds = _oracle_step(O, om, qpos[e], qvel[e], warm[e], ctrl[e], nsub)
         verr = _rel(gv[e], np.array(ds["qvel"][: om.nv]), 1.0).max()
         if nsub > 1:
@@ -83,7 +101,8 @@ def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True):
         d32["qpos"][: om.nq] = qpos[e]; d32["qvel"][: om.nv] = qvel[e]; d32["qacc_warmstart"][: om.nv] = warm[e]; d32["ctrl"][:14] = ctrl[e]
         d32.forward()
         cd_32 = np.array(d32["contact_dist"][:12], np.float64)
-        if derr >= dist_tol and (not act.any() or np.abs(cd_g[act] - cd_32[act]).max() < 2e-6):
+        s32 = np.concatenate([np.sort(cd_32[4 * p: 4 * p + 4]) for p in range(3)])
+        if derr >= dist_tol and (not acts.any() or np.abs(sg[acts] - s32[acts]).max() < 2e-6):
             stat["f32_side"] += 1
             continue
         if derr < dist_tol:   # same contacts, different solve: the oracle's own step under perturbation
@@ -108,5 +127,5 @@ if __name__ == "__main__":
     seed_ = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     O.build()
     for task_ in sys.argv[3:] or ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"]:
-        st, w = sweep(task_, n_, seed_, int(os.environ.get("ODK_FUZZ_LANES", "32")), int(os.environ.get("ODK_FUZZ_SUBSTEPS", "1")))
+        st, w = sweep(task_, n_, seed_, int(os.environ.get("ODK_FUZZ_LANES", "32")), int(os.environ.get("ODK_FUZZ_SUBSTEPS", "1")), variant=os.environ.get("ODK_FUZZ_VARIANT") or None)
         print(task_, f"n={n_}", st, {k: float(f"{v:.2e}") for k, v in w.items()}, flush=True)
