@@ -62,11 +62,18 @@ def make_states(task, n=1024, seed=0, variant=None):
     return model, om, om32, qpos, qvel, warm, ctrl
 
 
-def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True, variant=None):
-    """one model: returns (counts, worst errors of the states that agree)"""
-    model, om, om32, qpos, qvel, warm, ctrl = make_states(task, n, seed, variant)
+def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True, variant=None, dr=False):
+    """one model: returns (counts, worst errors of the states that agree); dr: every env with its own randomize.py model fields"""
+    model, om_base, om32_base, qpos, qvel, warm, ctrl = make_states(task, n, seed, variant)
+    fields = None
+    if dr:
+        from open_duck_playground_amd import randomize
+        from test_gpu_env import _dr_model
+        fields, _ = randomize.domain_randomize(model, np.random.default_rng(seed + 7), n)
     cfg = engine.default_config(); cfg.lanes_per_env = lanes if "rough" not in task else 32
     b = engine.Batch(model, n, cfg)
+    if dr:
+        randomize.apply(b, fields)
     b.set_state(qpos, qvel, warm)
     b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), nsub)
     gq, gv, _ = b.get_state()
@@ -76,6 +83,8 @@ def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True, v
     stat = dict(ok=0, tie=0, f32_side=0, solver_branch=0, unexplained=0, in_contact=0, both_feet=0, foot_foot=0)
     worst = dict(dist=0.0, qvel=0.0)
     for e in range(n):
+        om = _dr_model(model, om_base, fields, e) if dr else om_base
+        om32 = _dr_model(model, om32_base, fields, e) if dr else om32_base
         d = O.OracleData(om)
         d["qpos"][: om.nq] = qpos[e]; d["qvel"][: om.nv] = qvel[e]; d["qacc_warmstart"][: om.nv] = warm[e]; d["ctrl"][:14] = ctrl[e]
         d.forward()
@@ -127,5 +136,5 @@ if __name__ == "__main__":
     seed_ = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     O.build()
     for task_ in sys.argv[3:] or ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"]:
-        st, w = sweep(task_, n_, seed_, int(os.environ.get("ODK_FUZZ_LANES", "32")), int(os.environ.get("ODK_FUZZ_SUBSTEPS", "1")), variant=os.environ.get("ODK_FUZZ_VARIANT") or None)
+        st, w = sweep(task_, n_, seed_, int(os.environ.get("ODK_FUZZ_LANES", "32")), int(os.environ.get("ODK_FUZZ_SUBSTEPS", "1")), variant=os.environ.get("ODK_FUZZ_VARIANT") or None, dr=bool(int(os.environ.get("ODK_FUZZ_DR", "0"))))
         print(task_, f"n={n_}", st, {k: float(f"{v:.2e}") for k, v in w.items()}, flush=True)
