@@ -229,3 +229,26 @@ def test_round2_one_triangle_mode_is_still_available(oracle_mod):
         # the deepest contact is a face contact with the flat top; a slot may hold an edge-edge contact against the cell's
         # diagonal (an internal edge of the per-prism algorithm), a few degrees off the vertical
         assert nz[0] == pytest.approx(1.0, abs=1e-12) and (nz > 0.99).all()
+
+
+def test_sweep_state_generator_makes_contact_rich_states(oracle_mod):
+    """tools/gpu_fuzz_parity.make_states (CPU part of the differential sweep, tests/test_gpu_parity.py::test_differential_sweep):
+    most states touch the floor, some with both feet, some with the feet against each other, some airborne -- on every model."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("gpu_fuzz_parity", os.path.join(ROOT, "tools", "gpu_fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    for task in ("flat_terrain", "rough_terrain_backlash"):
+        model, om, om32, qpos, qvel, warm, ctrl = fz.make_states(task, 96, seed=5)
+        floor = both = ff = air = 0
+        for e in range(96):
+            d = oracle_mod.OracleData(om)
+            d["qpos"][: om.nq] = qpos[e]
+            d.forward()
+            cd = np.array(d["contact_dist"][:12])
+            f0, f1 = (cd[:4] < 0).any(), (cd[4:8] < 0).any()
+            floor += int(f0 or f1); both += int(f0 and f1); ff += int((cd[8:] < 0).any()); air += int(not (cd < 0).any())
+            if f0 or f1:
+                assert cd[:8].min() > -8e-3, (task, e, cd[:8].min())          # pressed in by at most the target depth
+        assert floor >= 60 and both >= 5 and ff >= 6 and air >= 5, (task, floor, both, ff, air)
