@@ -98,3 +98,41 @@ def test_oracle_step_matches_mjx(oracle_mod, task):
         d.env_physics_step(g["ctrl"][int(i)], 10)
         assert _rel(d["qpos"][: om.nq], g["env10_qpos"][k], 1e-2).max() < 5 * RTOL_Q, i    # float32 reference, ten contact-rich substeps
         assert _rel(d["qvel"][: om.nv], g["env10_qvel"][k], 1.0).max() < 5e-3, i
+
+
+def test_loaders_accept_a_fixture_of_the_dumper_s_layout(oracle_mod, tmp_path, monkeypatch):
+    """Plumbing only, NOT parity: a file with the keys and shapes tools/dump_mjx_golden.py writes -- filled from the compiled model and
+    the oracle itself -- runs through the three loaders above.  What it proves is that real fixtures will be READ (names, shapes,
+    index conventions), so that dropping them in needs no code change."""
+    import sys
+    from open_duck_playground_amd.model import load_task_model
+    task = "rough_terrain_backlash"
+    model = load_task_model(task); a = model.a
+    om = oracle_mod.OracleModel(model.blob())
+    rng = np.random.default_rng(0)
+    n = 5
+    out = {"const_" + k: np.asarray(a[k]) for k in ("dof_invweight0", "body_invweight0", "body_mass", "body_ipos", "body_iquat", "body_inertia", "qpos0",
+                                                     "dof_armature", "dof_damping", "dof_frictionloss", "jnt_range", "actuator_gainprm0", "key_qpos", "key_ctrl",
+                                                     "cgeom_id", "cgeom_pos", "cgeom_quat", "hfield_size", "hfield_data")}
+    out["const_meaninertia"] = np.asarray(a["stat_meaninertia"])
+    out["const_foot_mesh_vert"] = np.asarray(a["hull_vert"])[: int(a["cgeom_vertnum"][0])]
+    qpos = np.tile(np.asarray(a["key_qpos"], float), (n, 1)); qpos[:, 2] = 0.4 + 0.05 * np.arange(n)
+    qvel = rng.normal(0, 0.3, (n, model.nv)); warm = rng.normal(0, 1.0, (n, model.nv)); ctrl = np.asarray(a["key_ctrl"])[None] + rng.uniform(-0.1, 0.1, (n, 14))
+    rows = {k: [] for k in ("fwd_qacc_smooth", "fwd_actuator_force", "fwd_dist", "fwd_qacc", "fwd_sensordata", "step_qpos", "step_qvel", "env10_qpos", "env10_qvel")}
+    for i in range(n):
+        d = oracle_mod.OracleData(om)
+        d["qpos"][: om.nq] = qpos[i]; d["qvel"][: om.nv] = qvel[i]; d["qacc_warmstart"][: om.nv] = warm[i]; d["ctrl"][:14] = ctrl[i]
+        d.forward()
+        rows["fwd_qacc_smooth"].append(np.array(d["qacc_smooth"][: om.nv])); rows["fwd_actuator_force"].append(np.array(d["actuator_force"][:14]))
+        rows["fwd_dist"].append(np.array(d["contact_dist"][:12])); rows["fwd_qacc"].append(np.array(d["qacc"][: om.nv])); rows["fwd_sensordata"].append(np.array(d["sensordata"][:46]))
+        for nsub, kq, kv in ((1, "step_qpos", "step_qvel"), (10, "env10_qpos", "env10_qvel")):
+            d = oracle_mod.OracleData(om)
+            d["qpos"][: om.nq] = qpos[i]; d["qvel"][: om.nv] = qvel[i]; d["qacc_warmstart"][: om.nv] = warm[i]
+            d.env_physics_step(ctrl[i], nsub)
+            rows[kq].append(np.array(d["qpos"][: om.nq])); rows[kv].append(np.array(d["qvel"][: om.nv]))
+    out.update(qpos=qpos, qvel=qvel, warm=warm, ctrl=ctrl, env10_index=np.arange(n), **{k: np.stack(v) for k, v in rows.items()})
+    np.savez(tmp_path / f"mjx_{task}.npz", **out)
+    monkeypatch.setattr(sys.modules[__name__], "GOLDEN", str(tmp_path))
+    test_compiled_model_constants_match_mujoco(task)
+    test_oracle_forward_matches_mjx(oracle_mod, task)
+    test_oracle_step_matches_mjx(oracle_mod, task)
