@@ -32,3 +32,17 @@ def test_hip_step_matches_mjx(task, parity_log):
     b.close()
     parity_log.check(f"hip_vs_mjx/{task}", dict(qpos=RTOL_Q, qvel=RTOL_Q, qacc=2e-3, sensordata=2e-3, qpos_10_substeps=5 * RTOL_Q),
                      qpos=wq, qvel=wv, qacc=wa, sensordata=ws, qpos_10_substeps=w10)
+
+
+def test_hip_loader_accepts_a_fixture_of_the_dumper_s_layout(oracle_mod, parity_log, tmp_path, monkeypatch):
+    """Plumbing only, NOT parity against MJX: the loader above on a file of the dumper's layout filled from the oracle (the numbers it
+    compares are therefore the kernel-vs-oracle ones of tests/test_gpu_parity.py)."""
+    import test_mjx_golden as T
+    T._oracle_made_fixture(oracle_mod, "flat_terrain_backlash", tmp_path / "mjx_flat_terrain_backlash.npz")
+    monkeypatch.setattr(T, "GOLDEN", str(tmp_path))
+
+    class _Quiet:   # keeps the synthetic numbers out of the parity record
+        def check(self, name, bounds, **vals):
+            bad = {k: (v, bounds[k]) for k, v in vals.items() if k in bounds and not v <= bounds[k]}
+            assert not bad, bad
+    test_hip_step_matches_mjx("flat_terrain_backlash", _Quiet())

@@ -100,20 +100,15 @@ def test_oracle_step_matches_mjx(oracle_mod, task):
         assert _rel(d["qvel"][: om.nv], g["env10_qvel"][k], 1.0).max() < 5e-3, i
 
 
-def test_loaders_accept_a_fixture_of_the_dumper_s_layout(oracle_mod, tmp_path, monkeypatch):
-    """Plumbing only, NOT parity: a file with the keys and shapes tools/dump_mjx_golden.py writes -- filled from the compiled model and
-    the oracle itself -- runs through the three loaders above.  What it proves is that real fixtures will be READ (names, shapes,
-    index conventions), so that dropping them in needs no code change."""
-    import sys
+def _oracle_made_fixture(oracle_mod, task, path, n=5):
+    """a file with the keys and shapes tools/dump_mjx_golden.py writes, filled from the compiled model and the oracle itself"""
     from open_duck_playground_amd.model import load_task_model
-    task = "rough_terrain_backlash"
     model = load_task_model(task); a = model.a
     om = oracle_mod.OracleModel(model.blob())
     rng = np.random.default_rng(0)
-    n = 5
-    out = {"const_" + k: np.asarray(a[k]) for k in ("dof_invweight0", "body_invweight0", "body_mass", "body_ipos", "body_iquat", "body_inertia", "qpos0",
-                                                     "dof_armature", "dof_damping", "dof_frictionloss", "jnt_range", "actuator_gainprm0", "key_qpos", "key_ctrl",
-                                                     "cgeom_id", "cgeom_pos", "cgeom_quat", "hfield_size", "hfield_data")}
+    keys = ["dof_invweight0", "body_invweight0", "body_mass", "body_ipos", "body_iquat", "body_inertia", "qpos0", "dof_armature", "dof_damping", "dof_frictionloss",
+            "jnt_range", "actuator_gainprm0", "key_qpos", "key_ctrl", "cgeom_id", "cgeom_pos", "cgeom_quat"] + (["hfield_size", "hfield_data"] if "rough" in task else [])
+    out = {"const_" + k: np.asarray(a[k]) for k in keys}
     out["const_meaninertia"] = np.asarray(a["stat_meaninertia"])
     out["const_foot_mesh_vert"] = np.asarray(a["hull_vert"])[: int(a["cgeom_vertnum"][0])]
     qpos = np.tile(np.asarray(a["key_qpos"], float), (n, 1)); qpos[:, 2] = 0.4 + 0.05 * np.arange(n)
@@ -131,8 +126,18 @@ def test_loaders_accept_a_fixture_of_the_dumper_s_layout(oracle_mod, tmp_path, m
             d.env_physics_step(ctrl[i], nsub)
             rows[kq].append(np.array(d["qpos"][: om.nq])); rows[kv].append(np.array(d["qvel"][: om.nv]))
     out.update(qpos=qpos, qvel=qvel, warm=warm, ctrl=ctrl, env10_index=np.arange(n), **{k: np.stack(v) for k, v in rows.items()})
-    np.savez(tmp_path / f"mjx_{task}.npz", **out)
+    np.savez(path, **out)
+
+
+def test_loaders_accept_a_fixture_of_the_dumper_s_layout(oracle_mod, tmp_path, monkeypatch):
+    """Plumbing only, NOT parity: a file with the keys and shapes tools/dump_mjx_golden.py writes -- filled from the compiled model and
+    the oracle itself -- runs through the three loaders above.  What it proves is that real fixtures will be READ (names, shapes,
+    index conventions), so that dropping them in needs no code change."""
+    import sys
+    for task in ("flat_terrain", "rough_terrain_backlash"):
+        _oracle_made_fixture(oracle_mod, task, tmp_path / f"mjx_{task}.npz")
     monkeypatch.setattr(sys.modules[__name__], "GOLDEN", str(tmp_path))
-    test_compiled_model_constants_match_mujoco(task)
-    test_oracle_forward_matches_mjx(oracle_mod, task)
-    test_oracle_step_matches_mjx(oracle_mod, task)
+    for task in ("flat_terrain", "rough_terrain_backlash"):
+        test_compiled_model_constants_match_mujoco(task)
+        test_oracle_forward_matches_mjx(oracle_mod, task)
+        test_oracle_step_matches_mjx(oracle_mod, task)
