@@ -1498,7 +1498,11 @@ enum { K_RESET = 0, K_STEP = 1, K_PHYS = 2 };
 template <class S, int G, bool HF> static hipError_t launch_sg(int which, const KArgs& a, hipStream_t st) {
   const int per_block = 64 / G;
   const int grid = (a.nenv + per_block - 1) / per_block;
-  const size_t lds = (size_t)EnvL<S>::wg_floats(per_block) * sizeof(float);
+  size_t lds = (size_t)EnvL<S>::wg_floats(per_block) * sizeof(float);
+#ifdef ODK_OCC_EXPERIMENT   // occupancy experiment (make libodk_occ.so): extra dynamic LDS per workgroup -> fewer workgroups per CU
+  static const size_t pad = getenv("ODK_LDS_PAD") ? (size_t)atol(getenv("ODK_LDS_PAD")) : 0;
+  lds += pad;
+#endif
   if (which == K_RESET) hipLaunchKernelGGL((reset_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
   else if (which == K_STEP) hipLaunchKernelGGL((step_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
   else hipLaunchKernelGGL((physics_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
