@@ -9,10 +9,11 @@
 //
 // What makes it fast (all exact in real arithmetic; DESIGN.md 4.1 has the measurements):
 //  * occupancy by construction: <= 256 VGPRs => 2 waves/SIMD = 8 workgroups/CU, and the LDS image is sized so that 8
-//    workgroups fit (shape A: 2 296 floats/env; LDS, not registers, is what rules out a third wave) => 8192 envs are
-//    exactly two rounds.  Two waves keep the VALU ~70 % busy; each wave is paced by its own chain of dependent
-//    instructions and LDS round trips (a second wave stretches every phase by 1.0-1.2x only): what pays is fewer
-//    instructions and fewer serialised round trips -- not fewer loads from the model, those are covered;
+//    workgroups fit (shape A: 2 296 floats/env) => 8192 envs are exactly two rounds.  Two waves keep the VALU ~70 % busy;
+//    each wave is paced by its own chain of dependent instructions and LDS round trips (a second wave stretches every phase
+//    by 1.0-1.2x only): with 2 ... 8 resident workgroups per CU the launch takes ceil(16 / w) rounds of ~0.2 ms
+//    (profiles/r3/occupancy_scan.txt), so a third wave per SIMD (12 resident: still two rounds) would not shorten it.  What
+//    pays is fewer instructions and fewer serialised round trips -- not fewer loads from the model, those are covered;
 //  * per-lane statics (a lane's dof depth, row address, ancestor / descendant masks...) are read once per launch into
 //    registers (struct Statics); phase-local constants are re-fetched from the L2-resident model where they are used;
 //    the model pointer is made opaque once per substep so that table addresses are not hoisted into scratch;
