@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the fused MI355X env step (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--envs E] [--task T] [--lanes G] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--envs E] [--task T] [--lanes G] [--scaling weak|strong]
+                    [--no-cpu-baseline] [--no-secondary]
     python bench.py --mode ppo [--task flat_terrain_backlash] [--gpus N] [--steps K] [--warmup W]      (BASELINE configs 3 / 4 / 5)
+
+`--gpus N` with N > 1 works both ways: under the driver's launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`: RANK / WORLD_SIZE come from the environment and WORLD_SIZE must equal N) and as a plain `python bench.py --gpus N`, which
+starts the N ranks itself as a child `torch.distributed.run` BEFORE anything touches the GPU, relays rank 0's line and returns the
+children's exit code.  `--scaling weak` (default): `--envs` per GPU; `--scaling strong`: `--envs` in total, split over the ranks.
 
 One "step" = one env step of every resident env: AutoReset/Episode wrappers + Joystick.step +
 10 x mjx.step + obs/reward, all inside one HIP kernel launch (reference joystick.py:323-481).
@@ -19,7 +25,9 @@ mean over the repetitions, every repetition bracketed by barrier + synchronize.
 the policy in the loop + 128 clipped-Adam minibatch steps; with N > 1 ranks the flat gradient is all-reduced over RCCL in every
 minibatch step), domain randomisation on; `value` = env steps per second INCLUDING the learner.
 
-Prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`.
+Prints ONE JSON line with the driver's keys plus `roofline`, `cpu_baseline` (1 GPU) and `secondary`: short full-PPO legs run AFTER
+the headline's timed region and outside it -- BASELINE configs 3 and 4 on one GPU, config 5's shape (backlash model, envs sharded,
+flat-gradient all-reduce over RCCL per minibatch step) on N > 1 -- under a watchdog, so a failing leg can never cost the headline.
 """
 import argparse
 import json
@@ -151,26 +159,57 @@ def cpu_baseline(task: str, target_seconds: float = 12.0):
                       f"{os.cpu_count()} logical CPUs visible), same random-action protocol.  MuJoCo-C: {why}"}
 
 
-def _init_dist():
+def _spawn_ranks(args, argv) -> int:
+    """Plain `python bench.py --gpus N` (no launcher around it): start the N ranks as a CHILD `torch.distributed.run` -- never an
+    exec, and before this process has imported torch or touched the GPU -- with the same arguments; the children inherit stdout,
+    so rank 0's JSON line is this command's output, and their exit code is this command's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def _init_dist(args):
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree "
+                         "(plain `python bench.py --gpus N` starts its own ranks)")
     # test hooks (tests/test_gpu_api.py): run the multi-rank path on a one-GPU box -- RCCL refuses two ranks per device,
     # gloo does not; the driver's runs use neither variable
     backend = os.environ.get("ODK_BENCH_BACKEND", "nccl")
     local_rank = int(os.environ.get("ODK_BENCH_DEVICE", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path exists for the env engine)")
+    if backend == "nccl" and world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} HIP devices are visible (RCCL wants one rank per device)")
+    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
         else:
             dist.init_process_group(backend)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU path exists for the env engine)")
-    torch.cuda.set_device(local_rank)
     return rank, world, local_rank, torch.device("cuda", local_rank)
+
+
+def _envs_per_rank(args, world: int) -> int:
+    """weak: --envs per GPU; strong: --envs in total (8192 envs split over the ranks)."""
+    if args.scaling == "weak":
+        return args.envs
+    if args.envs % world:
+        raise SystemExit(f"bench.py --scaling strong: --envs {args.envs} is not a multiple of {world} ranks")
+    return args.envs // world
 
 
 def _clock_ramp(dev):
@@ -184,32 +223,36 @@ def _clock_ramp(dev):
         torch.cuda.synchronize()
 
 
+_COUNTER_FILES = {"flat_terrain": "traffic.json", "flat_terrain_backlash": "traffic_backlash.json", "rough_terrain_backlash": "traffic_rough.json"}
+
+
 def _counters(task: str, envs: int):
     """Per-launch counter figures of the dominant kernel from the committed PMC passes of the SAME command (rocprofv3 --pmc in
-    separate passes, profiles/README.md): HBM bytes, and the float32 operations behind `valu_frac`.  Counters cannot be read
-    from inside this process; the newest round that holds them wins, the source file is named in the output."""
-    if task != "flat_terrain" or envs != 8192:
-        return None, None, None
-    for rnd in ("r3", "r2"):
-        tpath = os.path.join(ROOT, "profiles", rnd, "traffic.json")
+    separate passes, profiles/README.md; re-collected by tools/gpu_profile_round.sh whenever the kernel changes): HBM bytes, the
+    float32 operations behind `valu_frac` and the active-lane fraction of the VALU instructions.  Counters cannot be read from
+    inside this process; the newest round that holds the task's file wins and the file is named in the output.  Other sizes than
+    the 8192 envs the passes ran at: nothing (`traffic` null)."""
+    name = _COUNTER_FILES.get(task)
+    if name is None or envs != 8192:
+        return {}, None
+    for rnd in ("r4", "r3", "r2"):
+        tpath = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(tpath):
-            t = json.load(open(tpath))
-            return t.get("hbm_bytes_per_launch"), t.get("valu_flop_per_launch"), f"profiles/{rnd}/traffic.json"
-    return None, None, None
+            return json.load(open(tpath)), f"profiles/{rnd}/{name}"
+    return {}, None
 
 
-def main_ppo(args):
-    """BASELINE configs 3 / 4 (1 GPU) and 5 (N GPUs, envs sharded, flat gradient all-reduced over RCCL in each of the 128
-    minibatch steps): K full PPO training steps after W warm-up ones."""
+def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "weak"):
+    """K full PPO training steps after W warm-up ones on this rank's `envs` envs (BASELINE configs 3 / 4 on 1 GPU, 5 on N: envs
+    sharded, flat gradient all-reduced over RCCL in each of the 128 minibatch steps).  Returns the result line on rank 0."""
     import numpy as np
     import torch
     import torch.distributed as dist
-    rank, world, local_rank, dev = _init_dist()
+    rank, world, local_rank, dev = ctx
     from open_duck_playground_amd import joystick
     from open_duck_playground_amd.ppo import train as T
     from open_duck_playground_amd.ppo.networks import PPONetworks
-    task = args.task or "flat_terrain_backlash"
-    env = joystick.Joystick(task=task, num_envs=args.envs, device=local_rank, env_id_offset=rank * args.envs)
+    env = joystick.Joystick(task=task, num_envs=envs, device=local_rank, env_id_offset=rank * envs)
     env.randomize(np.random.default_rng([0, rank, 0]))          # randomize.py domain randomisation, own draws per rank
     cfg = T.ppo_config()
     grp = dist.group.WORLD if world > 1 else None
@@ -219,7 +262,6 @@ def main_ppo(args):
     gen = torch.Generator(device=dev); gen.manual_seed(1000 + rank)
     state = env.reset(rank)
     learner = None
-    steps, warmup = args.steps if args.steps is not None else 10, args.warmup if args.warmup is not None else 3
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
 
     def barrier():
@@ -256,33 +298,33 @@ def main_ppo(args):
     rollout_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
     learner_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
     allreduce_ms = None
+    nsgd = cfg["num_minibatches"] * cfg["num_updates_per_batch"]
     if world > 1:   # the collective alone, outside the timed region: 128 all-reduces of a gradient-sized buffer
         n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
         g = torch.zeros(n_par, device=dev)
         for _ in range(8): dist.all_reduce(g)
         torch.cuda.synchronize(); ta = time.perf_counter()
-        nsgd = cfg["num_minibatches"] * cfg["num_updates_per_batch"]
         for _ in range(nsgd): dist.all_reduce(g)
         torch.cuda.synchronize()
         allreduce_ms = 1e3 * (time.perf_counter() - ta)
-    env_steps = world * args.envs * cfg["unroll_length"] * steps
+    env_steps = world * envs * cfg["unroll_length"] * steps
+    out = None
     if rank == 0:
-        nsgd = cfg["num_minibatches"] * cfg["num_updates_per_batch"]
         # learner roofline (the training step's dominant part): f32 matrix-core work of the three whole-network kernels
-        mb = args.envs * cfg["unroll_length"] // cfg["num_minibatches"]
+        mb = envs * cfg["unroll_length"] // cfg["num_minibatches"]
         flop_step = 0.0
         for dims in ((101, 512, 256, 128, 28), (212, 512, 256, 128, 1)):
             flop_step += 3 * sum(2.0 * mb * a * b for a, b in zip(dims[:-1], dims[1:]))      # forward + backward-data + weight gradients
         achieved = nsgd * flop_step / (learner_ms * 1e-3) / 1e12 if learner_ms > 0 else 0.0
         out = {
             "metric": METRIC, "value": round(env_steps / elapsed, 1), "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": max(warmup, 1),
-            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"full PPO (BASELINE config {'5' if world > 1 else ('4' if 'rough' in task else '3')}): open_duck_mini_v2 {task} + randomize.py domain "
-                                   f"randomisation, {args.envs} envs/GPU, one step = rollout of {cfg['unroll_length']} env steps with the policy in the loop + {nsgd} "
+                                   f"randomisation, {envs} envs/GPU, one step = rollout of {cfg['unroll_length']} env steps with the policy in the loop + {nsgd} "
                                    f"clipped-Adam minibatch steps of {mb} samples (reference hyper-parameters, common/runner.py:86-118); value counts env steps "
                                    "per second INCLUDING the learner; noise, pushes, imitation reward, auto-reset on",
-                       "mode": "ppo", "envs_per_gpu": args.envs, "global_envs": args.envs * world, "unroll_length": cfg["unroll_length"],
+                       "mode": "ppo", "task": task, "envs_per_gpu": envs, "global_envs": envs * world, "unroll_length": cfg["unroll_length"],
                        "sgd_steps_per_training_step": nsgd, "parallelism": f"env-sharded x{world}" + (", flat-gradient all-reduce (RCCL) per minibatch step" if world > 1 else ", no collective"),
                        "rollout_ms_per_training_step": round(rollout_ms, 3), "learner_ms_per_training_step": round(learner_ms, 3),
                        "allreduce_ms_per_training_step_isolated": None if allreduce_ms is None else round(allreduce_ms, 3),
@@ -293,52 +335,32 @@ def main_ppo(args):
                          "note": "algorithmic FLOPs of the 128 minibatch steps / learner time (HIP events), incl. the element-wise launches between them; "
                                  "peak = dense f32 MFMA"},
         }
-        print(json.dumps(out), flush=True)
     if learner is not None:
         learner.close()
-    if world > 1:
-        dist.destroy_process_group()
+    env.close() if hasattr(env, "close") else None
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="physics", choices=["physics", "ppo"])
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="physics: env steps per repetition (default 1000); ppo: training steps (default 10)")
-    ap.add_argument("--warmup", type=int, default=None, help="default 100 (physics) / 3 (ppo)")
-    ap.add_argument("--reps", type=int, default=None, help="physics: repetitions of the K timed steps, value = mean (default 5; 1 when --steps is given)")
-    ap.add_argument("--envs", type=int, default=8192, help="envs per GPU")
-    ap.add_argument("--task", default=None)
-    ap.add_argument("--lanes", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    if args.mode == "ppo":
-        return main_ppo(args)
-    args.task = args.task or "flat_terrain"
-    if args.reps is None:
-        args.reps = 5 if args.steps is None else 1       # an explicit --steps K is timed once: exactly K steps
-    args.steps = 1000 if args.steps is None else args.steps
-    args.warmup = 100 if args.warmup is None else args.warmup
-
+def physics_leg(ctx, args, envs: int):
+    """The headline: W warm-up + K timed env steps (x repetitions) of the fused env-step launch on this rank's `envs` envs."""
     import torch
     import torch.distributed as dist
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.model import load_task_model
-
-    rank, world, local_rank, dev = _init_dist()
+    rank, world, local_rank, dev = ctx
 
     model = load_task_model(args.task)
     cfg = engine.default_config()
     cfg.noise_level = 0.0
     cfg.push_enable = 0.0
     cfg.lanes_per_env = args.lanes
-    batch = engine.Batch(model, args.envs, cfg, device=local_rank)
-    batch.reset(seed=0, env_id_offset=rank * args.envs)
+    batch = engine.Batch(model, envs, cfg, device=local_rank)
+    batch.reset(seed=0, env_id_offset=rank * envs)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     # fresh action per step, generated before the timed region (HBM-resident inputs)
     chunk = min(args.steps + args.warmup, 256)
-    actions = torch.empty(chunk, args.envs, 14, device=dev, dtype=torch.float32).uniform_(-1.0, 1.0, generator=gen)
+    actions = torch.empty(chunk, envs, 14, device=dev, dtype=torch.float32).uniform_(-1.0, 1.0, generator=gen)
 
     def barrier():
         if world > 1:
@@ -371,42 +393,149 @@ def main():
     elapsed = sum(times) / len(times)
     kernel_ms, launches = batch.timing(False)
     done_frac = float(batch.done.mean().item())
-    value = world * args.envs * args.steps / elapsed
+    value = world * envs * args.steps / elapsed
+    lanes = batch.cfg.lanes_per_env or 32
+    batch.close()
+    if rank != 0:
+        return None
+    cnt, csrc = _counters(args.task, envs)
+    traffic, flop_launch = cnt.get("hbm_bytes_per_launch"), cnt.get("valu_flop_per_launch")
+    bytes_per_launch = BYTES_PER_ENV_STEP.get(args.task, 3564 if "backlash" in args.task else 2844) * envs
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    flop = flop_launch if flop_launch else envs * FLOP_PER_ENV_STEP
+    valu = flop / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    roof = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "counter_source": csrc,
+            "kernel": "step_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": launches, "timed_every": timing_stride,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "note": "fused env step is not HBM-bound (SURVEY.md 0.4); secondary roof = FP32 VALU",
+            "valu_achieved_tflops": round(valu, 3), "valu_peak_tflops": VALU_PEAK_TFLOPS,
+            "valu_frac": round(valu / VALU_PEAK_TFLOPS, 5),
+            "valu_flop_source": "SQ_INSTS_VALU_* counters (" + csrc + "): every lane of an issued instruction counted" if flop_launch
+                                else "1.2 MFLOP per env step (SURVEY.md 8d estimate)"}
+    if cnt.get("valu_active_lane_fraction"):
+        # active-lane view of the same figure: SQ_ACTIVE_INST_VALU-weighted thread cycles / (64 x instruction cycles)
+        roof["valu_active_lane_fraction"] = cnt["valu_active_lane_fraction"]
+        roof["valu_frac_active_lanes"] = round(valu / VALU_PEAK_TFLOPS * cnt["valu_active_lane_fraction"], 5)
+    return {
+        "metric": METRIC, "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"open_duck_mini_v2 {args.task}, {envs} envs/GPU, random-action rollout "
+                               "(wrappers + Joystick.step + 10 x mjx.step + obs/reward fused in one launch), "
+                               "noise off, pushes off, imitation on, auto-reset on",
+                   "mode": "physics", "envs_per_gpu": envs, "global_envs": envs * world, "n_substeps": 10,
+                   "lanes_per_env": lanes, "parallelism": f"env-sharded x{world}, no collective",
+                   "done_fraction_last_step": round(done_frac, 4),
+                   "repetitions": args.reps, "value_per_repetition": [round(world * envs * args.steps / t, 1) for t in times],
+                   "protocol": "BASELINE.md 4: W warm-up env steps, then K timed env steps x repetitions, value = K / mean time"},
+        "roofline": roof,
+    }
 
-    if rank == 0:
-        traffic, flop_launch, csrc = _counters(args.task, args.envs)
-        bytes_per_launch = BYTES_PER_ENV_STEP.get(args.task, 3564 if "backlash" in args.task else 2844) * args.envs
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        flop = flop_launch if flop_launch else args.envs * FLOP_PER_ENV_STEP
-        valu = flop / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        out = {
-            "metric": METRIC, "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"open_duck_mini_v2 {args.task}, {args.envs} envs/GPU, random-action rollout "
-                                   "(wrappers + Joystick.step + 10 x mjx.step + obs/reward fused in one launch), "
-                                   "noise off, pushes off, imitation on, auto-reset on",
-                       "mode": "physics", "envs_per_gpu": args.envs, "global_envs": args.envs * world, "n_substeps": 10,
-                       "lanes_per_env": batch.cfg.lanes_per_env or 32, "parallelism": f"env-sharded x{world}, no collective",
-                       "done_fraction_last_step": round(done_frac, 4),
-                       "repetitions": args.reps, "value_per_repetition": [round(world * args.envs * args.steps / t, 1) for t in times],
-                       "protocol": "BASELINE.md 4: W warm-up env steps, then K timed env steps x repetitions, value = K / mean time"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "counter_source": csrc,
-                         "kernel": "step_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": launches, "timed_every": timing_stride,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "fused env step is not HBM-bound (SURVEY.md 0.4); secondary roof = FP32 VALU",
-                         "valu_achieved_tflops": round(valu, 3), "valu_peak_tflops": VALU_PEAK_TFLOPS,
-                         "valu_frac": round(valu / VALU_PEAK_TFLOPS, 5),
-                         "valu_flop_source": "SQ_INSTS_VALU_* counters (" + csrc + ")" if flop_launch else "1.2 MFLOP per env step (SURVEY.md 8d estimate)"},
-        }
-        if world == 1 and not args.no_cpu_baseline:
+
+class _Watchdog:
+    """The secondary legs run after the headline is measured but before it is printed (the driver wants ONE line): if a leg
+    hangs -- config 5's RCCL path has never met more than one GPU on the build box -- every rank's timer fires, rank 0 prints the
+    headline with the failure recorded in `secondary`, and the process leaves through os._exit (a stuck collective cannot be
+    joined)."""
+
+    def __init__(self, seconds: float, rank: int, line: dict):
+        import threading
+        self.line, self.rank = line, rank
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.seconds = seconds
+
+    def _fire(self):
+        if self.rank == 0:
+            self.line.setdefault("secondary", []).append({"error": f"watchdog: secondary legs still running after {self.seconds:.0f} s; abandoned"})
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def _brief(leg: dict) -> dict:
+    c = leg["config"]
+    return {"config": c["workload"].split(":")[0].replace("full PPO (", "").rstrip(")"), "task": c["task"], "mode": "ppo", "value": leg["value"],
+            "unit": leg["unit"], "n_gpus": leg["n_gpus"], "steps": leg["steps"], "warmup": leg["warmup"], "ms_per_step": leg["ms_per_step"],
+            "envs_per_gpu": c["envs_per_gpu"], "rollout_ms": c["rollout_ms_per_training_step"], "learner_ms": c["learner_ms_per_training_step"],
+            "allreduce_ms_isolated": c["allreduce_ms_per_training_step_isolated"], "learner_path": c["learner_path"],
+            "roofline": {k: leg["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="physics", choices=["physics", "ppo"])
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="physics: env steps per repetition (default 1000); ppo: training steps (default 10)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 100 (physics) / 3 (ppo)")
+    ap.add_argument("--reps", type=int, default=None, help="physics: repetitions of the K timed steps, value = mean (default 5; 1 when --steps is given)")
+    ap.add_argument("--envs", type=int, default=8192, help="envs per GPU (--scaling weak) or in total (--scaling strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--task", default=None)
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="physics mode: skip the short full-PPO legs attached as `secondary`")
+    ap.add_argument("--secondary-steps", type=int, default=6)
+    ap.add_argument("--secondary-timeout", type=float, default=240.0)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_spawn_ranks(args, sys.argv[1:]))          # nothing has touched the GPU yet in this process
+
+    import torch.distributed as dist
+    ctx = _init_dist(args)
+    rank, world = ctx[0], ctx[1]
+    envs = _envs_per_rank(args, world)
+
+    if args.mode == "ppo":
+        out = ppo_leg(ctx, args.task or "flat_terrain_backlash", envs, args.steps if args.steps is not None else 10,
+                      args.warmup if args.warmup is not None else 3, args.scaling)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    else:
+        args.task = args.task or "flat_terrain"
+        if args.reps is None:
+            args.reps = 5 if args.steps is None else 1       # an explicit --steps K is timed once: exactly K steps
+        args.steps = 1000 if args.steps is None else args.steps
+        args.warmup = 100 if args.warmup is None else args.warmup
+        out = physics_leg(ctx, args, envs)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.task)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": usable_cores(), "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
-    batch.close()
+        if not args.no_secondary:
+            # BASELINE configs 3 / 4 (1 GPU) or 5's shape (N GPUs) as short full-PPO legs, outside the headline's timed region
+            tasks = ["flat_terrain_backlash", "rough_terrain_backlash"] if world == 1 else ["flat_terrain_backlash"]
+            line = out if rank == 0 else {}
+            with _Watchdog(args.secondary_timeout, rank, line):
+                sec = []
+                for task in tasks:
+                    try:
+                        leg = ppo_leg(ctx, task, envs, args.secondary_steps, 3, args.scaling)
+                        if rank == 0:
+                            sec.append(_brief(leg))
+                    except Exception as e:
+                        err = {"task": task, "mode": "ppo", "error": f"{type(e).__name__}: {e}"}
+                        if world > 1:   # a rank that skips a leg leaves the others inside its collectives: the headline goes out
+                            if rank == 0:       # now, the other ranks leave through their own watchdogs
+                                out["secondary"] = sec + [err]
+                                print(json.dumps(out), flush=True)
+                            os._exit(0)
+                        sec.append(err)
+                if rank == 0:
+                    out["secondary"] = sec
+        if rank == 0:
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

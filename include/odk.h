@@ -150,6 +150,14 @@ int odk_batch_get_records(odk_batch* b, float* host_records);
 /* writes the records back (synchronous): restores a saved batch, or presets carried `info` fields -- e.g. info["step"] = 500 so
  * that the next step resamples the command (joystick.py:456-466) */
 int odk_batch_set_records(odk_batch* b, const float* host_records);
+/* where a field of the carried state lives inside a record: names are the keys of the reference's `info` dict (joystick.py:278-302:
+ * "rng", "step", "command", "last_act", "last_last_act", "last_last_last_act", "motor_targets", "feet_air_time", "last_contact",
+ * "swing_peak", "push", "push_step", "push_interval_steps", "action_history", "imu_history", "imitation_i"), the wrapper's additions
+ * ("steps", "truncation", "episode_done", "episode_metrics/sum_reward", "episode_metrics/length", "episode_metrics/reward_terms")
+ * and the physics state ("qpos", "qvel", "qacc_warmstart").  *offset / *count in 4-byte words from the start of the record;
+ * *kind = 0 float32, 1 int32 / uint32, 2 bit mask in one int32 (last_contact: bit f = foot f).  `current_reference_motion` and
+ * `imitation_phase` are functions of imitation_i and the command and are not carried.  Returns ODK_ERR_INVALID for an unknown name. */
+int odk_record_field(const odk_batch* b, const char* name, int* offset, int* count, int* kind);
 
 /* ---- learner-side kernels (csrc/odk_learner.hip): the element-wise halves of one PPO minibatch step.  The
  * reference reaches them through brax ppo.train (common/runner.py:104-118): ppo.losses.compute_gae /

@@ -743,6 +743,7 @@ struct odk_batch {
   float* d_recs = nullptr; float* d_first = nullptr; float* d_dr = nullptr; float* d_dbg = nullptr; float* d_hfield = nullptr;
   std::vector<float> h_dr; bool dr_enabled = false;
   int rec_size, frec_size, lds_total, dr_size, env_lds;
+  static constexpr size_t ODK_TIMING_EVENT_PAIRS = 1024;
   int timing = 0; size_t timing_count = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> events; size_t ev_used = 0;   // timing: 0 off, n: every n-th launch
 };
 
@@ -1204,6 +1205,8 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.D("cgeom_solref", cg_solref, 8); B.D("cgeom_solimp", cg_solimp, 20); B.D("cgeom_solmix", cg_solmix, 4);
   double cg_size[12] = {0};
   { const bool was_ok = B.ok; const std::string miss = B.missing; B.D("cgeom_size", cg_size, 12); B.ok = was_ok; B.missing = miss; }   // optional: absent in blobs without primitive colliders
+  double cg_margin[4] = {0};
+  { const bool was_ok = B.ok; const std::string miss = B.missing; B.D("cgeom_margin", cg_margin, 4); B.ok = was_ok; B.missing = miss; }     // optional: blobs of rounds 1-3 have none (= 0)
   int nhv = B.D("hull_vert", hv, 64 * 3) / 3; int nhf = B.I("hull_face", hf, 128 * 3) / 3;
   B.D("body_invweight0", biw, MAXB * 2);
   B.I("k_foot_body", m.foot_body, 2); B.I2("k_foot_dofmask", &m.foot_dofmask[0][0], 2, MAXV);
@@ -1214,10 +1217,15 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   }
   if (!B.ok || ncg != 3) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   (void)nhv; (void)nhf;
+  for (int g = 0; g < 3; g++)   // the culls (height-field prisms, foot-foot boxes) drop every pair with a positive gap: only valid at margin 0
+    if (cg_margin[g] != 0) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "collision geom %d has margin %g: contacts are detected at distance 0", g, cg_margin[g]); }
   m.foot_prim = 0;
   for (int f = 0; f < 2; f++) {
     int g = foot_cg[f];
-    if (cg_vnum[g] > MAXHV || cg_fnum[g] > MAXHF || cg_condim[g] != 3) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull too large / condim != 3"); }
+    if (cg_condim[g] != 3) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot collider condim %d: the contact rows are pyramidal condim-3", cg_condim[g]); }
+    if (cg_vnum[g] > HULL_MAXV || cg_fnum[g] > MAXHF) {
+      delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull with %d vertices / %d triangles: the kernels hold <= %d vertices and <= %d merged faces", cg_vnum[g], cg_fnum[g], HULL_MAXV, HULL_MAXF);
+    }
     double gm[9];
     quat2mat(cg_quat + 4 * g, gm);
     m.foot_gtype[f] = cg_type[g];
@@ -1256,8 +1264,8 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       }
       for (int t = 0; t < cg_fnum[g]; t++) for (int k = 0; k < 3; k++) tr[t][k] = hf[3 * (cg_fadr[g] + t) + k];
       if (!build_convex_tables(bv, cg_vnum[g], tr, cg_fnum[g], &m.foot_npoly[f], m.foot_poly[f], m.foot_fnorm[f], &m.foot_nedge[f], m.foot_edge[f],
-                               m.foot_centroid[f], MAXHF, 48)) {
-        delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull: not a closed polytope with <= 4-vertex faces and <= 48 edges");
+                               m.foot_centroid[f], HULL_MAXF, HULL_MAXE)) {
+        delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull: not a closed polytope with <= 4-vertex faces, <= %d merged faces and <= %d edges", HULL_MAXF, HULL_MAXE);
       }
       for (int t = 0; t < m.foot_npoly[f]; t++) {
         const double* v0 = bv[m.foot_poly[f][t][1]];
@@ -1294,6 +1302,18 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       for (int k = 0; k < 4; k++) m.hfield_size[k] = (float)hs[k];
       mo->hfield.resize((size_t)m.hfield_nrow * m.hfield_ncol);
       for (size_t i = 0; i < mo->hfield.size(); i++) { double v; memcpy(&v, hp + 8 * i, 8); mo->hfield[i] = (float)v; }
+      // hfield_contacts works on a window of <= 3 x 3 cells under the hull's oriented box (18 prisms per foot: the LIST region):
+      // whatever the foot's orientation, its box must span less than two cells per axis (MJX sizes its sub-grid from the same
+      // ratio at trace time; a finer field or a larger foot needs a larger window here, not silently dropped cells)
+      if (m.hfield_nrow < 2 || m.hfield_ncol < 2) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height field smaller than 2 x 2 samples"); }
+      const double cell = fmin(2.0 * hs[0] / (m.hfield_ncol - 1), 2.0 * hs[1] / (m.hfield_nrow - 1));
+      for (int f = 0; f < 2; f++) {
+        const float* hh2 = m.foot_obb_half[f];
+        const double diag = 2.0 * sqrt((double)hh2[0] * hh2[0] + (double)hh2[1] * hh2[1] + (double)hh2[2] * hh2[2]);
+        if (!(diag < 2.0 * cell)) {
+          delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot %d spans %.4f m, the height field's cells are %.4f m: the prism window holds feet smaller than two cells", f, diag, cell);
+        }
+      }
     }
     // contact parameter mixing (mj_contactParam): pairs 0,1 = floor vs foot, pair 2 = foot vs foot
     for (int pr = 0; pr < 3; pr++) {
@@ -1557,12 +1577,9 @@ extern "C" int odk_step(odk_batch* b, const float* action_dev, const odk_outputs
   a.action = action_dev;
   a.dbg_lds = g_debug_dump ? b->d_dbg : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (b->timing > 0 && (b->timing_count++ % (size_t)b->timing) == 0) {
-    if (b->ev_used == b->events.size()) {
-      hipEvent_t e0, e1;
-      HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-      b->events.push_back({e0, e1});
-    }
+  // (event pairs are created by odk_batch_timing, never here: a step allocates nothing; when the pool is used up the
+  // remaining launches of the window simply go untimed)
+  if (b->timing > 0 && (b->timing_count++ % (size_t)b->timing) == 0 && b->ev_used < b->events.size()) {
     HIPCHK(hipEventRecord(b->events[b->ev_used].first, st));
     HIPCHK(launch(b, K_STEP, a, st));
     HIPCHK(hipEventRecord(b->events[b->ev_used].second, st));
@@ -1598,11 +1615,40 @@ extern "C" int odk_batch_timing(odk_batch* b, int enable, float* avg_ms, int* la
   if (launches) *launches = (int)b->ev_used;
   b->ev_used = 0; b->timing_count = 0;
   b->timing = enable > 0 ? enable : 0;
+  while (b->timing > 0 && b->events.size() < odk_batch::ODK_TIMING_EVENT_PAIRS) {
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    b->events.push_back({e0, e1});
+  }
   return ODK_OK;
 }
 
 extern "C" int odk_batch_record_size(const odk_batch* b) { return b ? b->rec_size : -1; }
 extern "C" int odk_batch_lds_size(const odk_batch* b) { return b ? b->lds_total : -1; }
+extern "C" int odk_record_field(const odk_batch* b, const char* name, int* offset, int* count, int* kind) {
+  if (!b || !name) return fail(ODK_ERR_INVALID, "null argument");
+  const int nq = b->model.h.nq, nv = b->model.h.nv, I = nq + 2 * nv, nu = b->model.h.nu;
+  struct F { const char* name; int off, n, kind; };
+  const F tab[] = {
+    {"qpos", 0, nq, 0}, {"qvel", nq, nv, 0}, {"qacc_warmstart", nq + nv, nv, 0},
+    {"command", I + rec::CMD, 7, 0}, {"last_act", I + rec::LAST, nu, 0}, {"last_last_act", I + rec::LAST2, nu, 0},
+    {"last_last_last_act", I + rec::LAST3, nu, 0}, {"motor_targets", I + rec::MT, nu, 0}, {"feet_air_time", I + rec::AIR, 2, 0},
+    {"swing_peak", I + rec::PEAK, 2, 0}, {"push", I + rec::PUSH, 2, 0}, {"action_history", I + rec::AHIST, 3 * nu, 0},
+    {"imu_history", I + rec::IMU, 9, 0}, {"steps", I + rec::EPSTEPS, 1, 0}, {"truncation", I + rec::TRUNC, 1, 0},
+    {"episode_done", I + rec::DONE, 1, 0}, {"episode_metrics/sum_reward", I + rec::EPSUM, 1, 0}, {"episode_metrics/length", I + rec::EPLEN, 1, 0},
+    {"episode_metrics/reward_terms", I + rec::EPMET, 8, 0}, {"rng", I + rec::KEY0, 3, 1}, {"step", I + rec::STEP, 1, 1},
+    {"push_step", I + rec::PSTEP, 1, 1}, {"push_interval_steps", I + rec::PINT, 1, 1}, {"imitation_i", I + rec::IMI, 1, 1},
+    {"last_contact", I + rec::LCON, 1, 2},
+  };
+  for (const F& f : tab)
+    if (!strcmp(name, f.name)) {
+      if (offset) *offset = f.off;
+      if (count) *count = f.n;
+      if (kind) *kind = f.kind;
+      return ODK_OK;
+    }
+  return fail(ODK_ERR_INVALID, "unknown record field '%s'", name);
+}
 extern "C" int odk_batch_get_records(odk_batch* b, float* host) {
   if (!b || !host) return fail(ODK_ERR_INVALID, "null");
   HIPCHK(hipSetDevice(b->device));

@@ -14,6 +14,13 @@ constexpr int MAXNZ = 512;   // sparse matrix entries
 constexpr int MAXHV = 20;    // hull vertices per foot
 constexpr int MAXHF = 40;    // hull faces per foot
 constexpr int MAXHE = 64;    // unique hull edges per foot
+// What the kernels' LDS regions hold (odk_kernels.h: [2][HULL_MAXV][3] vertices | [2][HULL_MAXF][3] normals | [HULL_MAXF] plane
+// offsets, the plane pass' 16 lanes + ONE extra vertex, FaceRegs<2> = two faces per lane of a 16-lane row, 3 edges per lane):
+// odk_model_load refuses a hull beyond these (ODK_ERR_UNSUPPORTED) -- the blob arrays above are merely the wire format's bound.
+constexpr int HULL_MAXV = 17;    // vertices
+constexpr int HULL_MAXF = 30;    // faces after the coplanar merge
+constexpr int HULL_MAXE = 48;    // unique edges
+static_assert(HULL_MAXV <= MAXHV && HULL_MAXF <= MAXHF && HULL_MAXE <= MAXHE && HULL_MAXF <= 32 && HULL_MAXE <= 48 && HULL_MAXV <= 17, "kernel hull regions");
 constexpr int MAXCHAIN = 8;
 constexpr int MAXSITE = 8;
 constexpr int MAXSENS = 16;

@@ -75,7 +75,7 @@ class OdkError(RuntimeError):
 
 def build_library(force: bool = False) -> str:
     """Compiles csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("odk_engine.hip", "odk_learner.hip", "odk_mlp.hip", "odk_kernels.h", "odk_model.h", "Makefile")]
+    srcs = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".hip", ".h", ".inc")) or f == "Makefile"]
     srcs.append(os.path.join(_CSRC, "..", "..", "include", "odk.h"))
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -128,6 +128,7 @@ def load_library() -> C.CDLL:
     L.odk_batch_get_records.argtypes = [P, FP]
     L.odk_batch_set_records.argtypes = [P, FP]
     L.odk_batch_timing.argtypes = [P, C.c_int, FP, C.POINTER(C.c_int)]
+    L.odk_record_field.argtypes = [P, C.c_char_p] + [C.POINTER(C.c_int)] * 3
     L.odk_gae.argtypes = [P, P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_float, C.c_float, P]
     L.odk_ppo_head.argtypes = [P] * 11 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P]
     L.odk_policy_sample.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P]
@@ -715,6 +716,35 @@ class Batch:
         r = np.ascontiguousarray(records, np.float32)
         assert r.shape == (self.nenv, self.L.odk_batch_record_size(self._b))
         _chk(self.L.odk_batch_set_records(self._b, _fp(r)))
+
+    INFO_FIELDS = ("rng", "step", "command", "last_act", "last_last_act", "last_last_last_act", "motor_targets", "feet_air_time", "last_contact",
+                   "swing_peak", "push", "push_step", "push_interval_steps", "action_history", "imu_history", "imitation_i",
+                   "steps", "truncation", "episode_done", "episode_metrics/sum_reward", "episode_metrics/length", "episode_metrics/reward_terms")
+
+    def record_field(self, name: str):
+        """(offset, count, kind) of a named field inside a record (`odk_record_field`; kind 0 float32, 1 int32, 2 bit mask)."""
+        o, n, k = C.c_int(0), C.c_int(0), C.c_int(0)
+        _chk(self.L.odk_record_field(self._b, name.encode(), C.byref(o), C.byref(n), C.byref(k)))
+        return o.value, n.value, k.value
+
+    def info(self, records: np.ndarray = None) -> dict:
+        """The carried `info` dict of the reference's State (joystick.py:278-302 + the wrapper's additions), one [nenv, ...] array per
+        key, as VIEWS over a host copy of the records (`records()` when none is passed): write through a view, then hand the
+        same array to `set_records` to preset a field.  int32 fields come as int32 views; `last_contact` as the packed mask
+        (bit f = foot f), with `last_contact_bool(info)` for the reference's bool[2]."""
+        r = self.records() if records is None else records
+        ri = r.view(np.int32)
+        out = {"_records": r}
+        for name in self.INFO_FIELDS:
+            o, n, k = self.record_field(name)
+            v = (r if k == 0 else ri)[:, o:o + n]
+            out[name] = v[:, 0] if n == 1 else v
+        return out
+
+    @staticmethod
+    def last_contact_bool(info: dict) -> np.ndarray:
+        m = info["last_contact"]
+        return np.stack([(m & 1) != 0, (m & 2) != 0], axis=1)
 
     def timing(self, enable):
         """Average kernel milliseconds of the timed launches since the last call; `enable`: False / 0 = off, True / 1 = time every

@@ -447,6 +447,10 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
             raise NotImplementedError(f"colliding geom '{g['name']}' of type {g['type']}: plane / hfield floors, convex meshes, boxes, "
                                       "spheres and capsules collide in this engine; ellipsoids and cylinders do not (give visual "
                                       "primitives contype=conaffinity=0)")
+    for g in col:
+        if g.get("margin", 0.0) != 0.0 or g.get("gap", 0.0) != 0.0:
+            raise NotImplementedError(f"colliding geom '{g['name']}' has margin / gap: contacts are detected at distance 0 in this engine "
+                                      "(the height-field cull and the foot-foot box cull drop separated pairs)")
     if any(g["type"] == "hfield" for g in col) and any(g["type"] in ("sphere", "capsule") for g in col):
         raise NotImplementedError("spheres / capsules against a height field (MJX hfield_sphere / hfield_capsule) are not supported: "
                                   "the height-field floor takes convex meshes and boxes")
@@ -541,6 +545,7 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
     out["cgeom_contype"] = I32([g["contype"] for g in col]); out["cgeom_conaffinity"] = I32([g["conaffinity"] for g in col])
     out["cgeom_solref"] = F64([g["solref"] for g in col]); out["cgeom_solimp"] = F64([g["solimp"] for g in col])
     out["cgeom_solmix"] = F64([g["solmix"] for g in col])
+    out["cgeom_margin"] = F64([g.get("margin", 0.0) for g in col])      # always 0 (refused above); odk_model_load checks it again
     # convex hulls (all collision meshes here share one asset, but keep it general: concat + adr)
     vadr, vnum, fadr, fnum, allv, allf = [], [], [], [], [], []
     cache = {}

@@ -44,7 +44,9 @@ def oracle_mod():
 
 class _ParityLog:
     """Worst-case GPU-vs-oracle errors per test and quantity, next to the bound the test asserts.  Written at session end to
-    gpurun_out/parity_worst.json (merged with what is there); the judged copy is profiles/r3/parity_worst.json."""
+    gpurun_out/parity_worst.json (merged with what is there); the judged copy is profiles/r<N>/parity_worst.json.  Every `check` is an
+    assert: there is no measure-only switch in this tree (tools/measure_parity.py patches this class from OUTSIDE when bounds are
+    being re-derived)."""
 
     def __init__(self):
         self.d = {}
@@ -61,10 +63,6 @@ class _ParityLog:
         """record, then assert every value against its bound"""
         self.rec(test, bounds, **vals)
         bad = {k: (float(v), bounds[k]) for k, v in vals.items() if k in bounds and not float(v) <= bounds[k]}
-        if os.environ.get("ODK_PARITY_MEASURE"):      # measuring run: record everything, judge nothing
-            if bad:
-                print(f"[parity measure] {test}: over bound {bad}")
-            return
         assert not bad, f"{test}: (measured, bound) {bad}"
 
     def dump(self):

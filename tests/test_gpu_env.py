@@ -134,36 +134,28 @@ def _perturbed_oracle_steps(e, act, model, rng):
     return clones
 
 
-# per-env info record behind qpos | qvel | warmstart (csrc/odk_engine.hip namespace rec)
-_REC = dict(CMD=0, LAST=7, LAST2=21, LAST3=35, MT=49, AIR=63, PEAK=65, PUSH=67, AHIST=69, IMU=111, EPSTEPS=120, TRUNC=121, DONE=122, EPSUM=123,
-            EPLEN=124, EPMET=125, KEY0=133, KEY1=134, CTR=135, STEP=136, PSTEP=137, PINT=138, IMI=139, LCON=140)
-
-
 def _push_info(b, envs, model, which):
     """Overwrites the carried info of the envs in `which` with the oracle's (after an ill-conditioned step the two sides may
     legitimately disagree on a contact flag, and air time / swing peak / last_contact carry that forward).  All other envs keep
-    the info the GPU produced itself."""
+    the info the GPU produced itself.  Fields are addressed by name (`Batch.info()` -> `odk_record_field`)."""
     if not which:
         return
-    rec = b.records()
-    I = model.nq + 2 * model.nv
-    R = _REC
+    I = b.info()
+    same = ("last_act", "last_last_act", "last_last_last_act", "motor_targets", "feet_air_time", "swing_peak", "push", "action_history", "imu_history")
     for i in which:
         e = envs[i]
-        r = rec[i, I:]
-        ri = r.view(np.int32)
-        r[R["CMD"]: R["CMD"] + 7] = e["command"][:7]
-        for k, nm in (("LAST", "last_act"), ("LAST2", "last_last_act"), ("LAST3", "last_last_last_act"), ("MT", "motor_targets")):
-            r[R[k]: R[k] + 14] = e[nm][:14]
-        r[R["AIR"]: R["AIR"] + 2] = e["feet_air_time"][:2]; r[R["PEAK"]: R["PEAK"] + 2] = e["swing_peak"][:2]; r[R["PUSH"]: R["PUSH"] + 2] = e["push"][:2]
-        r[R["AHIST"]: R["AHIST"] + 42] = e["action_history"][:42]; r[R["IMU"]: R["IMU"] + 9] = e["imu_history"][:9]
-        r[R["EPSTEPS"]] = e["ep_steps"][0]; r[R["TRUNC"]] = e["truncation"][0]; r[R["DONE"]] = e["episode_done"][0]
-        r[R["EPSUM"]] = e["ep_sum_reward"][0]; r[R["EPLEN"]] = e["ep_length"][0]; r[R["EPMET"]: R["EPMET"] + 8] = e["ep_metrics"][:8]
-        ri[R["CTR"]] = e.ints("rng_ctr")[0]; ri[R["STEP"]] = e.ints("step")[0]; ri[R["PSTEP"]] = e.ints("push_step")[0]
-        ri[R["PINT"]] = e.ints("push_interval_steps")[0]; ri[R["IMI"]] = e.ints("imitation_i")[0]
+        I["command"][i] = e["command"][:7]
+        for nm in same:
+            I[nm][i] = e[nm][: I[nm].shape[1]]
+        I["steps"][i] = e["ep_steps"][0]; I["truncation"][i] = e["truncation"][0]; I["episode_done"][i] = e["episode_done"][0]
+        I["episode_metrics/sum_reward"][i] = e["ep_sum_reward"][0]; I["episode_metrics/length"][i] = e["ep_length"][0]
+        I["episode_metrics/reward_terms"][i] = e["ep_metrics"][:8]
+        I["rng"][i, 2] = e.ints("rng_ctr")[0]
+        for nm in ("step", "push_step", "push_interval_steps", "imitation_i"):
+            I[nm][i] = e.ints(nm)[0]
         lc = e.ints("last_contact")
-        ri[R["LCON"]] = int(lc[0] != 0) | (int(lc[1] != 0) << 1)
-    b.set_records(rec)
+        I["last_contact"][i] = int(lc[0] != 0) | (int(lc[1] != 0) << 1)
+    b.set_records(I["_records"])
 
 
 def _step_and_compare(torch, b, envs, act, nobs, npriv, t, W, model=None):
@@ -233,7 +225,7 @@ def test_reset_matches_oracle(oracle_mod, parity_log, task):
     b.reset(seed=5, env_id_offset=100)
     obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy()
     qpos, qvel, warm = b.get_state()
-    rec = b.records()
+    I = b.info()
     W = dict(obs=0.0, acc=0.0, qpos=0.0, qvel=0.0)
     for i, e in enumerate(envs):
         e.reset(5, 100 + i)
@@ -243,9 +235,8 @@ def test_reset_matches_oracle(oracle_mod, parity_log, task):
         # the accelerometer spikes to O(100) m/s^2 at reset (feet start 1.5 cm inside the floor): judged relatively, own bound
         o, a = _obs_err(obs[i], priv[i], e, 101, 212)
         W["obs"] = max(W["obs"], o); W["acc"] = max(W["acc"], a)
-        info = rec[i, model.nq + 2 * model.nv:]
-        np.testing.assert_allclose(info[0:7], e["command"], rtol=1e-6, atol=1e-7)
-        assert int(info[138:139].view(np.int32)[0]) == int(e.ints("push_interval_steps")[0])
+        np.testing.assert_allclose(I["command"][i], e["command"], rtol=1e-6, atol=1e-7)
+        assert int(I["push_interval_steps"][i]) == int(e.ints("push_interval_steps")[0])
     b.close()
     parity_log.check(f"reset/{task}", RESET_BOUNDS, **W)
 
@@ -270,13 +261,12 @@ def test_step_sequence_with_resync(oracle_mod, parity_log, task):
         act = rng.uniform(-1, 1, (n, 14)).astype(np.float32)
         _step_and_compare(torch, b, envs, act, 101, 212, t, W)
     assert W["n_done"] > 0 and W["n_trunc"] > 0, "sequence must cross terminations and truncations"
-    rec = b.records()
+    I = b.info()
     for i, e in enumerate(envs):
-        info = rec[i, model.nq + 2 * model.nv:]
-        np.testing.assert_allclose(info[7:21], e["last_act"][:14], atol=1e-6)
-        np.testing.assert_allclose(info[69:111], e["action_history"][:42], atol=1e-6)
-        assert int(info[135:136].view(np.int32)[0]) == int(e.ints("rng_ctr")[0])
-        assert int(info[139:140].view(np.int32)[0]) == int(e.ints("imitation_i")[0])
+        np.testing.assert_allclose(I["last_act"][i], e["last_act"][:14], atol=1e-6)
+        np.testing.assert_allclose(I["action_history"][i], e["action_history"][:42], atol=1e-6)
+        assert int(I["rng"][i, 2]) == int(e.ints("rng_ctr")[0])
+        assert int(I["imitation_i"][i]) == int(e.ints("imitation_i")[0])
     b.close()
     parity_log.check(f"env_step/{task}", {**ENV_BOUNDS, **_set_aside(task)}, **_errs(W))
 
@@ -291,12 +281,10 @@ def test_in_step_command_resample(oracle_mod, parity_log, task):
     b.reset(seed=13)
     for i, e in enumerate(envs):
         e.reset(13, i)
-    rec = b.records()
-    INFO = model.nq + 2 * model.nv
-    STEP = INFO + 136
+    I = b.info()
     preset = np.where(np.arange(n) % 4 == 0, 123, np.where(np.arange(n) % 4 == 1, 499, 500)).astype(np.int32)
-    rec[:, STEP] = preset.view(np.float32)
-    b.set_records(rec)
+    I["step"][:] = preset                 # info["step"], by name
+    b.set_records(I["_records"])
     for i, e in enumerate(envs):
         e.ints("step")[0] = int(preset[i])
     old_cmd = np.stack([np.array(e["command"][:7]) for e in envs])
@@ -307,12 +295,11 @@ def test_in_step_command_resample(oracle_mod, parity_log, task):
         _resync(b, envs, model)
         act = rng.uniform(-1, 1, (n, 14)).astype(np.float32)
         _step_and_compare(torch, b, envs, act, 101, 212, t, W)
-        rec = b.records()
+        I = b.info()
         for i, e in enumerate(envs):
-            info = rec[i, INFO:]
-            cmd_g = info[0:7]; cmd_o = np.array(e["command"][:7])
+            cmd_g = I["command"][i]; cmd_o = np.array(e["command"][:7])
             np.testing.assert_allclose(cmd_g, cmd_o, rtol=1e-6, atol=1e-7)
-            assert int(info[136:137].view(np.int32)[0]) == int(e.ints("step")[0]), (t, i)
+            assert int(I["step"][i]) == int(e.ints("step")[0]), (t, i)
             if t == 0:
                 if preset[i] == 500:     # 501 > 500: resampled, counter back to 0
                     assert int(e.ints("step")[0]) == 0
