@@ -270,8 +270,17 @@ typedef struct odk_mlp_desc {
 } odk_mlp_desc;
 int odk_mlp_forward(const odk_mlp_desc* nets, int count, void* stream);
 int odk_mlp_backward(const odk_mlp_desc* nets, int count, void* stream);
+/* tools: device buffer of 4 x 1024 int64 receiving, per single-wave workgroup of odk_dw_gemm's matrix launch, its start / end on the
+ * 100 MHz wall clock and the HW_ID / XCC_ID registers (where it ran); NULL: off */
+void odk_dw_set_profile(long long* dev);
 /* tools: device buffer of 32 int64 receiving the forward kernel's phase timestamps (shader clock, workgroup 0); NULL: off */
 void odk_mlp_set_profile(long long* stamps_dev);
+/* tools: device buffer of 4 x (workgroups of a network launch) int64 receiving every workgroup's start / end on the 100 MHz wall
+ * clock, HW_ID | XCC_ID << 32 and its shader-clock cycles (forward and backward launches alike); NULL: off */
+void odk_mlp_set_wg_profile(long long* dev);
+/* tools: diagnostic variants of the network launches (results are WRONG): bit 0 = every weight load re-reads its phase's first group
+ * (what the launch costs when the weights come from the L1), bit 1 = the MFMAs are skipped (what the operand traffic alone costs) */
+void odk_mlp_set_diag(int bits);
 /* Where up to 8 weight matrices sit in a flat parameter buffer (float offset `off`, torch layout [rows = n_out, cols = n_in]) and
  * in the packed buffers (float offsets, multiples of 4; bwd_off < 0: no backward copy of that weight). */
 typedef struct odk_weight_table {

@@ -11,6 +11,9 @@
 // All launches are stream-ordered on the caller's stream and contain no host synchronisation, so they can be
 // captured into a HIP graph together with the GEMMs.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <utility>
+#include <vector>
 #include <stdint.h>
 #include <string.h>
 
@@ -387,92 +390,126 @@ constexpr int DW_MAX = 8;
 #define DW_AHEAD 2
 #endif
 struct DwLayer { const float* dz; const float* h; int n_out, n_in, tj, tile0, ngroups; long long out_off; };   // ngroups = rows / 8
-struct DwArgs { DwLayer L[DW_MAX]; int nlayers, ntiles, kslices; float* ws; long long ws_stride; };
+// Schedule (round 4).  A wave alone on its SIMD runs a full tile slice in ~35 us; the first version launched ntiles x kslices = 68 x 16
+// = 1 088 single-wave workgroups on the chip's 1 024 SIMDs, so 64 SIMDs carried two and the launch lasted two wave-times (69 us,
+// matrix pipe 40 % busy).  Now the host packs the (tile, slice) items of ONE XCD -- every tile x the kslices / 8 slices that XCD owns,
+// weighted by the MFMA blocks the tile really has (edge tiles skip their missing blocks) x the slice's row groups -- into at most
+// DW_SLOTS = SIMDs per XCD wave slots (longest item first, always onto the least-loaded slot), block b = slot (b >> 3) of XCD (b & 7)
+// works its slot's items one after the other, and a dynamic-LDS reservation of a quarter CU per workgroup keeps the dispatcher
+// from stacking more than four waves on a CU.  For the reference networks: 136 items -> 128 slots, 120 of them one full tile
+// slice, 8 a half tile + a quarter tile; the longest slot is one full slice.
+constexpr int DW_SLOTS = 128, DW_SLOT_ITEMS = 4;
+struct DwArgs { DwLayer L[DW_MAX]; int nlayers, ntiles, kslices, nslots; float* ws; long long ws_stride; long long* prof; unsigned short item[DW_SLOTS][DW_SLOT_ITEMS]; };
 
 #ifndef DW_MI
 #define DW_MI 4      // output tile of a wave: DW_MI x DW_MJ blocks of 32 x 32 (rows = n_out side, columns = n_in side)
 #define DW_MJ 2
 #endif
-__global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
-  constexpr int MI = DW_MI, MJ = DW_MJ;
-  const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
-  const int per_xcd = a.kslices >> 3;                 // kslices is a multiple of 8
-  const int slice = xcd * per_xcd + q / a.ntiles, tile = q % a.ntiles;
-  int l = 0;
-#pragma unroll
-  for (int k = 1; k < DW_MAX; k++) if (k < a.nlayers && tile >= a.L[k].tile0) l = k;
-  const DwLayer& Ly = a.L[l];
+// One (tile, slice) item with NI x NJ blocks of 32 x 32 that exist (compile time: an edge tile of the matrix runs its own
+// instantiation -- loads and MFMAs for its blocks only; as one runtime-guarded loop the edge tiles ran 2.5x longer per MFMA than
+// full ones and their slots were the launch's tail).
+template <int NI, int NJ>
+__device__ __forceinline__ void dw_tile(const DwArgs& a, const DwLayer& Ly, const int i0, const int j0, const int slice) {
   const int n_out = Ly.n_out, n_in = Ly.n_in;
-  const int t = tile - Ly.tile0, i0 = (t / Ly.tj) * (32 * MI), j0 = (t % Ly.tj) * (32 * MJ);
   const int lane = threadIdx.x, r = lane >> 5, c = lane & 31;
   const int g_lo = (int)((long long)slice * Ly.ngroups / a.kslices), g_hi = (int)((long long)(slice + 1) * Ly.ngroups / a.kslices);
   // Out-of-range columns read column 0 of the tile (always valid) and are NOT zeroed: entry (i, j) depends on column i of dz and
   // column j of h only, so whatever the clamped loads bring into the padding never reaches a stored element.
-  const f32x4* pa[MI]; const f32x4* pb[MJ];
-  bool ma[MI], mb[MJ];
+  const f32x4* pa[NI]; const f32x4* pb[NJ];
+  bool ma[NI], mb[NJ];
 #pragma unroll
-  for (int k = 0; k < MI; k++) { ma[k] = i0 + 32 * k + c < n_out; pa[k] = reinterpret_cast<const f32x4*>(Ly.dz) + (size_t)r * n_out + (ma[k] ? i0 + 32 * k + c : i0); }
+  for (int k = 0; k < NI; k++) { ma[k] = i0 + 32 * k + c < n_out; pa[k] = reinterpret_cast<const f32x4*>(Ly.dz) + (size_t)r * n_out + (ma[k] ? i0 + 32 * k + c : i0); }
 #pragma unroll
-  for (int k = 0; k < MJ; k++) { mb[k] = j0 + 32 * k + c < n_in; pb[k] = reinterpret_cast<const f32x4*>(Ly.h) + (size_t)r * n_in + (mb[k] ? j0 + 32 * k + c : j0); }
+  for (int k = 0; k < NJ; k++) { mb[k] = j0 + 32 * k + c < n_in; pb[k] = reinterpret_cast<const f32x4*>(Ly.h) + (size_t)r * n_in + (mb[k] ? j0 + 32 * k + c : j0); }
   const size_t sa = (size_t)2 * n_out, sb = (size_t)2 * n_in;   // one row group = two row quads
-  f32x16 acc[MI][MJ];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < MI; i++)
+  for (int i = 0; i < NI; i++)
 #pragma unroll
-    for (int j = 0; j < MJ; j++)
+    for (int j = 0; j < NJ; j++)
 #pragma unroll
       for (int v = 0; v < 16; v++) acc[i][j][v] = 0.0f;
-  const int ni = (n_out - i0 + 31) / 32, nj = (n_in - j0 + 31) / 32;   // wave-uniform: blocks of an edge tile that exist
-  struct Ops { f32x4 a[MI], b[MJ]; };
+  struct Ops { f32x4 a[NI], b[NJ]; };
   auto fetch = [&](int g, Ops& x) {
     const size_t o = (size_t)(g < g_hi ? g : g_lo);   // past the slice: re-read its first group (in bounds, unused)
 #pragma unroll
-    for (int k = 0; k < MI; k++) x.a[k] = pa[k][o * sa];
+    for (int k = 0; k < NI; k++) x.a[k] = pa[k][o * sa];
 #pragma unroll
-    for (int k = 0; k < MJ; k++) x.b[k] = pb[k][o * sb];
+    for (int k = 0; k < NJ; k++) x.b[k] = pb[k][o * sb];
   };
-  // the loads of the next DW_AHEAD groups are in flight under a group's MFMAs (a ring of register sets, the trip unrolled so
-  // that the sets swap roles without copies); sched_barrier keeps the scheduler from sinking the loads down to their MFMAs.
-  // The loop exists twice: whole tiles (no branch between the MFMAs) and edge tiles (the missing blocks skipped).
-  constexpr int AH = DW_AHEAD;
+  // the loads of the next AH groups are in flight under a group's MFMAs (a ring of register sets, the trip unrolled so that the
+  // sets swap roles without copies); sched_barrier keeps the scheduler from sinking the loads down to their MFMAs.  Small tiles
+  // have fewer MFMAs per group to cover a load's latency with: their ring is deeper.
+  constexpr int AH = NI * NJ >= 8 ? DW_AHEAD : (NI * NJ >= 4 ? 2 * DW_AHEAD : 4 * DW_AHEAD);
   Ops ring[AH + 1];
 #pragma unroll
   for (int k = 0; k < AH; k++) fetch(g_lo + k, ring[k]);
-  auto sweep = [&](auto full) {
-    constexpr bool FULL = decltype(full)::value;
-    for (int g = g_lo; g < g_hi; g += AH + 1) {
+  for (int g = g_lo; g < g_hi; g += AH + 1) {
 #pragma unroll
-      for (int k = 0; k <= AH; k++) {
-        fetch(g + k + AH, ring[(k + AH) % (AH + 1)]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + k < g_hi) {
-          const Ops& x = ring[k];
+    for (int k = 0; k <= AH; k++) {
+      fetch(g + k + AH, ring[(k + AH) % (AH + 1)]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + k < g_hi) {
+        const Ops& x = ring[k];
 #pragma unroll
-          for (int j4 = 0; j4 < 4; j4++)
+        for (int j4 = 0; j4 < 4; j4++)
 #pragma unroll
-            for (int i = 0; i < MI; i++)
+          for (int i = 0; i < NI; i++)
 #pragma unroll
-              for (int j = 0; j < MJ; j++)
-                if (FULL || (i < ni && j < nj)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a[i][j4], x.b[j][j4], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.a[i][j4], x.b[j][j4], acc[i][j], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-  };
-  if (ni >= MI && nj >= MJ) sweep(std::true_type{}); else sweep(std::false_type{});
+  }
   // C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
   float* w = a.ws + (size_t)slice * a.ws_stride + Ly.out_off;
 #pragma unroll
-  for (int i = 0; i < MI; i++)
+  for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int v = 0; v < 16; v++) {
       const int row = i0 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * r;
       if (row < n_out) {
 #pragma unroll
-        for (int j = 0; j < MJ; j++)
+        for (int j = 0; j < NJ; j++)
           if (mb[j]) w[(size_t)row * n_in + j0 + 32 * j + c] = acc[i][j][v];
       }
     }
+}
+__device__ __forceinline__ void dw_item(const DwArgs& a, const int tile, const int slice) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < DW_MAX; k++) if (k < a.nlayers && tile >= a.L[k].tile0) l = k;
+  const DwLayer& Ly = a.L[l];
+  const int t = tile - Ly.tile0, i0 = (t / Ly.tj) * (32 * DW_MI), j0 = (t % Ly.tj) * (32 * DW_MJ);
+  const int ni = min(DW_MI, (Ly.n_out - i0 + 31) / 32), nj = min(DW_MJ, (Ly.n_in - j0 + 31) / 32);   // wave-uniform: blocks of an edge tile that exist
+  static_assert(DW_MI == 4 && DW_MJ == 2, "the dispatch below lists the shapes of a 4 x 2 tile");
+  switch (ni * 2 + nj - 3) {     // (ni, nj) -> 0 .. 7
+    case 7: dw_tile<4, 2>(a, Ly, i0, j0, slice); break;
+    case 6: dw_tile<4, 1>(a, Ly, i0, j0, slice); break;
+    case 5: dw_tile<3, 2>(a, Ly, i0, j0, slice); break;
+    case 4: dw_tile<3, 1>(a, Ly, i0, j0, slice); break;
+    case 3: dw_tile<2, 2>(a, Ly, i0, j0, slice); break;
+    case 2: dw_tile<2, 1>(a, Ly, i0, j0, slice); break;
+    case 1: dw_tile<1, 2>(a, Ly, i0, j0, slice); break;
+    default: dw_tile<1, 1>(a, Ly, i0, j0, slice); break;
+  }
+}
+__global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
+  const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+  const int per_xcd = a.kslices >> 3;                 // kslices is a multiple of 8
+  long long t0 = 0, c0 = 0;
+  if (a.prof) { t0 = wall_clock64(); c0 = clock64(); }
+#pragma unroll 1
+  for (int k = 0; k < DW_SLOT_ITEMS; k++) {
+    const int it = a.item[slot][k];
+    if (it == 0xFFFF) break;
+    dw_item(a, it / per_xcd, xcd * per_xcd + it % per_xcd);
+  }
+  if (a.prof && threadIdx.x == 0) {   // tools/gpu_dw_profile.py: when and where each wave ran (100 MHz wall clock; HW_ID, XCC_ID)
+    a.prof[4 * b] = t0; a.prof[4 * b + 1] = wall_clock64();
+    a.prof[4 * b + 2] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 32);
+    a.prof[4 * b + 3] = clock64() - c0;      // shader-clock cycles of the wave: / its wall time = the clock the SIMD really ran at
+  }
 }
 // out[off + e] = sum over the row slices, in slice order, for the weight ranges of the layers (e < count); four consecutive
 // elements per thread (offsets, counts and the slice stride are multiples of 4: checked by the host).  The same launch can
@@ -642,6 +679,10 @@ extern "C" int odk_gather_rows(const float* const* src_dev, float* const* dst_de
   return check_launch("odk_gather_rows: launch failed");
 }
 
+static long long* g_dw_prof = nullptr;
+// tools: device buffer of 4 x (blocks of the weight-gradient launch) int64 receiving each wave's start / end (100 MHz clock), HW_ID, XCC_ID
+extern "C" void odk_dw_set_profile(long long* dev) { g_dw_prof = dev; }
+
 extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev, const int* n_out, const int* n_in, const long long* out_off,
                            int nlayers, const int* nrows, int kslices, float* ws_dev, long long ws_stride, float* out_dev, odk_grad_finish* finish,
                            void* stream) {
@@ -650,6 +691,7 @@ extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev
     return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad arguments (1..8 layers, kslices a multiple of 8, ws_stride a multiple of 4, 16-byte aligned buffers)");
   DwArgs a;
   DwRanges rg;
+  a.prof = g_dw_prof;
   a.nlayers = nlayers; a.kslices = kslices; a.ws = ws_dev; a.ws_stride = ws_stride; a.ntiles = 0; rg.n = nlayers;
   for (int l = 0; l < DW_MAX; l++) {
     DwLayer& L = a.L[l];
@@ -666,8 +708,42 @@ extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev
       L.dz = L.h = nullptr; L.n_out = L.n_in = L.tj = L.ngroups = 0; L.tile0 = 1 << 30; L.out_off = 0; rg.off[l] = 0; rg.count[l] = 0;
     }
   }
+  // ---- the per-XCD schedule: items (tile, slice-of-this-XCD) by decreasing work onto the least-loaded wave slot
+  {
+    const int per_xcd = kslices >> 3, nitems = a.ntiles * per_xcd;
+    if (nitems >= 0xFFFF) return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: too many tiles");
+    std::vector<std::pair<long long, int>> items;      // (work, item id = tile * per_xcd + k)
+    for (int l = 0; l < nlayers; l++) {
+      const DwLayer& L = a.L[l];
+      const int ti = (L.n_out + 32 * DW_MI - 1) / (32 * DW_MI);
+      for (int t = 0; t < ti * L.tj; t++) {
+        const int i0 = (t / L.tj) * 32 * DW_MI, j0 = (t % L.tj) * 32 * DW_MJ;
+        const int ni = std::min(DW_MI, (L.n_out - i0 + 31) / 32), nj = std::min(DW_MJ, (L.n_in - j0 + 31) / 32);
+        for (int k = 0; k < per_xcd; k++) {
+          // (slices of XCD 0 stand for all: the groups of a slice differ by at most one between XCDs)
+          const long long g = (long long)(k + 1) * L.ngroups / kslices - (long long)k * L.ngroups / kslices;
+          items.push_back({(long long)ni * nj * g + 8, (L.tile0 + t) * per_xcd + k});      // + 8: a tile's fixed cost (prologue, stores)
+        }
+      }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const std::pair<long long, int>& x, const std::pair<long long, int>& y) { return x.first > y.first; });
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    a.nslots = std::max(1, std::min(std::min(DW_SLOTS, nitems), cus / 8 * 4));      // wave slots = SIMDs of one XCD (MI355X: 32 CUs x 4)
+    long long load[DW_SLOTS] = {0}; int cnt[DW_SLOTS] = {0};
+    for (int sidx = 0; sidx < DW_SLOTS; sidx++) for (int k = 0; k < DW_SLOT_ITEMS; k++) a.item[sidx][k] = 0xFFFF;
+    for (const auto& itw : items) {
+      int best = -1;
+      for (int sidx = 0; sidx < a.nslots; sidx++) if (cnt[sidx] < DW_SLOT_ITEMS && (best < 0 || load[sidx] < load[best])) best = sidx;
+      if (best < 0) return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: more than DW_SLOTS x DW_SLOT_ITEMS tile slices per XCD");
+      a.item[best][cnt[best]++] = (unsigned short)itw.second; load[best] += itw.first;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(dw_gemm_kernel, dim3(a.ntiles * kslices), dim3(64), 0, st, a);
+  // 40 KB of (unused) LDS per single-wave workgroup: at most four of them per CU, i.e. one per SIMD when the XCD's slots are all taken
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dw_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024); attr = true; }
+  hipLaunchKernelGGL(dw_gemm_kernel, dim3(a.nslots * 8), dim3(64), 40 * 1024, st, a);
   long long total = 0;
   for (int l = 0; l < nlayers; l++) total += rg.count[l];
   int blocks = (int)((total / 4 + 255) / 256);

@@ -34,6 +34,8 @@
 // of every dz (the bias gradients' first half, folded by odk_colsum_fold in a fixed order).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/odk.h"
 
@@ -67,7 +69,27 @@ struct Net {
   const float* dout; float* dz[3]; float* doutp; float* bias_partial[4];
   int n, n_in, n_out, tile0;
 };
-struct Args { Net net[2]; int nnets; long long* prof; };   // prof: phase timestamps of workgroup 0, wave 0 (tools only)
+// Block -> (network, tile).  All workgroups of a launch are resident at once (<= 4 per CU) and the dispatcher hands block b to CU
+// b mod R (R = CUs; measured: tools/gpu_mlp_wg_profile.py finds exactly the predicted mixes), so with T = 656 tiles on 256 CUs
+// 144 CUs run three tiles and 112 two, and a CU's time is the sum of its tiles' matrix work: the launch lasts as long as the
+// costliest three-tile mix.  The value network's tiles (wider input) cost 1.24x the policy's; in network order the mixes were
+// PPV x 64, PVV x 80, PV x 112.  `Map` deals the costly network's tiles to the two-tile CUs first and spreads the rest one per
+// three-tile CU: PPV x 112, PPP x 32, VV x 112 -- the longest CU 7 % shorter.  Only speed depends on the dispatch order.
+struct Map { int R, rounds, rem, vin2, pin2, v3, costly, on; };
+struct Args { Net net[2]; int nnets; int diag; long long* prof; long long* wgprof; Map map; };
+__device__ __forceinline__ void map_block(const Args& a, int b, int& net, int& tile) {
+  const Map& m = a.map;
+  if (!m.on) { net = (a.nnets > 1 && b >= a.net[1].tile0) ? 1 : 0; tile = b - a.net[net].tile0; return; }
+  const int k = b % m.R, r = b / m.R;
+  bool costly; int idx;
+  if (k >= m.rem) { const int s2 = (k - m.rem) * m.rounds + r; costly = s2 < m.vin2; idx = costly ? s2 : s2 - m.vin2; }
+  else { const int c = r * m.rem + k; costly = c < m.v3; idx = costly ? m.vin2 + c : m.pin2 + (c - m.v3); }
+  net = costly ? m.costly : 1 - m.costly; tile = idx;
+}   // prof: phase timestamps of workgroup 0, wave 0; wgprof: start / end / place of every workgroup (tools only)
+#define ODK_WG_BEGIN() long long wg_t0 = 0, wg_c0 = 0; if (a.wgprof) { wg_t0 = wall_clock64(); wg_c0 = clock64(); }
+#define ODK_WG_END() do { if (a.wgprof && threadIdx.x == 0) { long long* o = a.wgprof + 4 * blockIdx.x; o[0] = wg_t0; o[1] = wall_clock64(); \
+    o[2] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF) << 32) | ((long long)net_i << 40); \
+    o[3] = clock64() - wg_c0; } } while (0)
 #define ODK_STAMP(i) do { if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[i] = clock64(); } while (0)
 
 // One GEMM phase of a wave: acc[blk] += A (16 samples x K, LDS) * Bp (packed [K / 4][N][4], columns col0 + 16 blk + c), over ng
@@ -82,12 +104,12 @@ struct Args { Net net[2]; int nnets; long long* prof; };   // prof: phase timest
 template <int NBLK, int U>
 struct Phase {
   f32x4 fb[U][NBLK];
-  const f32x4* B; unsigned lane_off, blk_off; int N4, ng;
+  const f32x4* B; unsigned lane_off, blk_off; int N4, ng; int diag = 0;
   __device__ __forceinline__ void load_b(int G0, f32x4 (*xb)[NBLK]) const {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int G = G0 + u;
-      const f32x4* bp = B + (size_t)(G < ng ? G : 0) * N4;   // wave-uniform base, 32-bit lane offset
+      const f32x4* bp = B + (size_t)((G < ng && !(diag & 1)) ? G : 0) * N4;   // wave-uniform base, 32-bit lane offset (diag 1, tools: every group re-reads group 0 -> L1 hits)
 #pragma unroll
       for (int k = 0; k < NBLK; k++) xb[u][k] = bp[lane_off + blk_off * k];
     }
@@ -110,7 +132,7 @@ struct Phase {
     auto mma = [&](int G0, const f32x4* xa, const f32x4 (*xb)[NBLK]) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        if (G0 + u < ng) {
+        if (G0 + u < ng && !(diag & 2)) {     // (diag 2, tools: no MFMAs)
 #pragma unroll
           for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -167,15 +189,18 @@ __device__ __forceinline__ void fwd_epilogue(const f32x4 (&acc)[NBLK], const flo
 
 __global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int bid = blockIdx.x;
-  const Net& N = a.net[(a.nnets > 1 && bid >= a.net[1].tile0) ? 1 : 0];
-  const int m0 = (bid - N.tile0) * TM;
+  int net_i, tile;
+  map_block(a, blockIdx.x, net_i, tile);
+  const Net& N = a.net[net_i];
+  const int m0 = tile * TM;
   const int rows_valid = N.n - m0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
   const int kin = N.n_in, k16 = pad16(kin), PX = k16 + 4;
   float* X = lds + F_X; float* C1 = lds + F_C; float* H2s = lds + F_H2; float* H3s = lds + F_X;
   Phase<2, 2> p1;     // layer 1 (32 columns of the current chunk), layer 3, output layer
   Phase<4, 1> p2;     // layer 2, K-slice = the chunk, 64 columns
+  p1.diag = p2.diag = a.diag;
+  ODK_WG_BEGIN();
   ODK_STAMP(0);
   p1.prefetch(N.wf[0], H1, w * 32 + c, q, 0, k16 >> 4);
   const int nout = N.n_out;
@@ -303,6 +328,7 @@ __global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
     }
   }
   ODK_STAMP(28);
+  ODK_WG_END();
 }
 
 // dz = dh * swish'(z) on NBLK accumulator blocks (columns col0 + 16 k): -> global in the quad-row layout (the weight-gradient
@@ -335,9 +361,10 @@ __device__ __forceinline__ void bwd_epilogue(const f32x4 (&acc)[NBLK], const flo
 
 __global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int bid = blockIdx.x;
-  const Net& N = a.net[(a.nnets > 1 && bid >= a.net[1].tile0) ? 1 : 0];
-  const int tile = bid - N.tile0, m0 = tile * TM;
+  int net_i, tile;
+  map_block(a, blockIdx.x, net_i, tile);
+  const Net& N = a.net[net_i];
+  const int m0 = tile * TM;
   const int rows_valid = N.n - m0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
   const int nout = N.n_out;
@@ -345,6 +372,8 @@ __global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
   Phase<2, 2> p3;     // dh3 = dout W4: columns w * 32 .. + 31, K = n_out
   Phase<4, 1> p2;     // dh2 = dz3 W3: columns w * 64 .. + 63, K = 128
   Phase<8, 1> p1;     // dh1 = dz2 W2: columns w * 128 .. + 127, K = 256
+  p1.diag = p2.diag = p3.diag = a.diag;
+  ODK_WG_BEGIN();
   p3.prefetch(N.wb[3], H3, w * 32 + c, q, 0, pad16(nout) >> 4);
   // ---- the tile of dLoss/dout, zero beyond the tile's rows / the layer's columns
   for (int e = threadIdx.x; e < TM * NOUT_MAX; e += 256) {
@@ -390,6 +419,7 @@ __global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
     p1.run(acc, D2 + c * P2 + 4 * q);
     bwd_epilogue<8>(acc, N.g[0] + (ql * H1 + col) * 4, N.dz[0] + (ql * H1 + col) * 4, nullptr, 0, N.bias_partial[0] + (size_t)tile * H1 + col, q);
   }
+  ODK_WG_END();
 }
 
 // ---- parameters -> packed weight copies.  Weight k: params[off .. off + rows * cols), torch layout [rows = n_out][cols = n_in];
@@ -491,9 +521,11 @@ int check_launch(const char* what) {
 }
 
 long long* g_prof = nullptr;
+long long* g_wgprof = nullptr;
+int g_diag = 0;
 
 int fill_args(Args& a, const odk_mlp_desc* nets, int count, bool backward, int& tiles, const char*& err) {
-  a.nnets = count; tiles = 0; a.prof = backward ? nullptr : g_prof;
+  a.nnets = count; tiles = 0; a.prof = backward ? nullptr : g_prof; a.wgprof = g_wgprof; a.diag = g_diag;
   for (int k = 0; k < 2; k++) {
     Net& N = a.net[k];
     if (k >= count) { N = a.net[0]; N.tile0 = 1 << 30; continue; }
@@ -519,6 +551,19 @@ int fill_args(Args& a, const odk_mlp_desc* nets, int count, bool backward, int& 
     if (!backward && !has_act) for (int l = 0; l < 3; l++) N.g[l] = nullptr;
     tiles += (d.n + TM - 1) / TM;
   }
+  // the tile deal (struct Map): two networks, more tiles than CUs, fewer than 4 per CU (all resident at once)
+  Map& m = a.map;
+  memset(&m, 0, sizeof(m));
+  static int cus = 0;
+  if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+  if (count == 2 && tiles > cus && tiles <= 4 * cus && tiles % cus != 0 && !getenv("ODK_MLP_NO_DEAL")) {
+    const int nt[2] = {a.net[1].tile0, tiles - a.net[1].tile0};
+    m.R = cus; m.rounds = tiles / cus; m.rem = tiles % cus;
+    m.costly = nets[1].n_in >= nets[0].n_in ? 1 : 0;
+    const int n2slots = (cus - m.rem) * m.rounds, nv = nt[m.costly];
+    m.vin2 = nv < n2slots ? nv : n2slots; m.pin2 = n2slots - m.vin2; m.v3 = nv - m.vin2;
+    m.on = 1;
+  }
   return 0;
 }
 
@@ -542,6 +587,10 @@ int fill_table(WeightTable& t, const odk_weight_table* h, long long n, long long
 
 // tools: device buffer of 32 int64 that receives the forward kernel's phase timestamps (workgroup 0); NULL switches it off
 extern "C" void odk_mlp_set_profile(long long* stamps_dev) { g_prof = stamps_dev; }
+// tools: device buffer of 4 x (workgroups of a network launch) int64: start / end (100 MHz wall clock), HW_ID | XCC_ID << 32, shader cycles
+extern "C" void odk_mlp_set_wg_profile(long long* dev) { g_wgprof = dev; }
+// tools: diagnostic variants of the network launches (WRONG results): bit 0 = every weight load re-reads the phase's first group (L1 hits), bit 1 = no MFMAs
+extern "C" void odk_mlp_set_diag(int bits) { g_diag = bits; }
 
 extern "C" int odk_mlp_forward(const odk_mlp_desc* nets, int count, void* stream) {
   if (!nets || count < 1 || count > 2) return odk_fail_(ODK_ERR_INVALID, "odk_mlp_forward: 1 or 2 networks");
