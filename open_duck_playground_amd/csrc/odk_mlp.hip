@@ -104,7 +104,12 @@ __device__ __forceinline__ void map_block(const Args& a, int b, int& net, int& t
 template <int NBLK, int U>
 struct Phase {
   f32x4 fb[U][NBLK];
-  const f32x4* B; unsigned lane_off, blk_off; int N4, ng; int diag = 0;
+  const f32x4* B; unsigned lane_off, blk_off; int N4, ng;
+#ifdef ODK_MLP_DIAG    // diagnostic build (make libodk_mlpdiag.so; tools/gpu_mlp_wg_profile.py): bit 0 = every group re-reads group 0 (L1 hits), bit 1 = no MFMAs
+  int diag = 0;
+#else
+  static constexpr int diag = 0;
+#endif
   __device__ __forceinline__ void load_b(int G0, f32x4 (*xb)[NBLK]) const {
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -199,7 +204,9 @@ __global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
   float* X = lds + F_X; float* C1 = lds + F_C; float* H2s = lds + F_H2; float* H3s = lds + F_X;
   Phase<2, 2> p1;     // layer 1 (32 columns of the current chunk), layer 3, output layer
   Phase<4, 1> p2;     // layer 2, K-slice = the chunk, 64 columns
+#ifdef ODK_MLP_DIAG
   p1.diag = p2.diag = a.diag;
+#endif
   ODK_WG_BEGIN();
   ODK_STAMP(0);
   p1.prefetch(N.wf[0], H1, w * 32 + c, q, 0, k16 >> 4);
@@ -372,7 +379,9 @@ __global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
   Phase<2, 2> p3;     // dh3 = dout W4: columns w * 32 .. + 31, K = n_out
   Phase<4, 1> p2;     // dh2 = dz3 W3: columns w * 64 .. + 63, K = 128
   Phase<8, 1> p1;     // dh1 = dz2 W2: columns w * 128 .. + 127, K = 256
+#ifdef ODK_MLP_DIAG
   p1.diag = p2.diag = p3.diag = a.diag;
+#endif
   ODK_WG_BEGIN();
   p3.prefetch(N.wb[3], H3, w * 32 + c, q, 0, pad16(nout) >> 4);
   // ---- the tile of dLoss/dout, zero beyond the tile's rows / the layer's columns

@@ -220,6 +220,22 @@ odko_model* odko_model_copy(const odko_model* m) {
   return c;
 }
 
+static void build_mesh_convex(odko_model* m);
+/* Moves every hull vertex by a relative `rel` (uniform in +-rel x max(|coordinate|, 1 cm), counter-hashed from `seed`) and rebuilds
+ * the polygons / normals / edges: what the collision geometry looks like to an implementation that carries its constants in
+ * another precision.  The parity tests' float32 referee uses it (rel ~ 1e-7) to tell near-ties between hull features -- decided
+ * by the last bits of the face normals, and blind to any perturbation of the STATE -- from real disagreements. */
+void odko_model_jitter_hulls(odko_model* m, unsigned seed, real rel) {
+  unsigned x = seed * 2654435761u + 12345u;
+  for (int i = 0; i < ODKO_MAXHV; i++)
+    for (int k = 0; k < 3; k++) {
+      x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+      real u = ((real)(x & 0xFFFFFF) / (real)0x800000) - 1.0, v = m->hull_vert[i][k];
+      m->hull_vert[i][k] = v + u * rel * (fabs(v) > 0.01 ? fabs(v) : 0.01);
+    }
+  build_mesh_convex(m);
+}
+
 #define MF(nm, cnt) if (!strcmp(name, #nm)) { *count = (cnt); return (real*)m->nm; }
 real* odko_model_field(odko_model* m, const char* name, int* count) {
   MF(body_mass, m->nbody) MF(body_ipos, m->nbody * 3) MF(body_pos, m->nbody * 3) MF(body_quat, m->nbody * 4)
@@ -263,6 +279,7 @@ real* odko_data_field(odko_data* d, const char* name, int* count) {
   DF(cvel, ODKO_MAXB * 6) DF(cdof_dot, ODKO_MAXV * 6) DF(cacc, ODKO_MAXB * 6)
   DF(qfrc_bias, ODKO_MAXV) DF(qfrc_passive, ODKO_MAXV) DF(qfrc_actuator, ODKO_MAXV) DF(actuator_force, ODKO_MAXU)
   DF(qfrc_smooth, ODKO_MAXV) DF(qacc_smooth, ODKO_MAXV) DF(qacc, ODKO_MAXV) DF(qfrc_constraint, ODKO_MAXV) DF(sensordata, ODKO_MAXSD)
+  DF(decision_margin, 5)
   if (!strcmp(name, "time")) { *count = 1; return &d->time; }
   if (!strcmp(name, "solver_cost0")) { *count = 1; return &d->solver_cost0; }
   if (!strcmp(name, "solver_cost1")) { *count = 1; return &d->solver_cost1; }
@@ -278,6 +295,7 @@ int odko_data_int(const odko_data* d, const char* name) {
 
 void odko_make_data(const odko_model* m, odko_data* d) {
   memset(d, 0, sizeof(*d));
+  for (int k = 0; k < 5; k++) d->decision_margin[k] = 1e30;
   for (int i = 0; i < m->nq; i++) d->qpos[i] = m->qpos0[i];
 }
 
@@ -484,6 +502,50 @@ static void make_frame(real* frame, const real* n) {
  * in float32 and float64.  With the threshold both resolve the tie like exact arithmetic does. */
 #define AREA0(v) ((v) < 1e-7 ? 0.0 : (v))
 #define AREA_TIE 1e-7
+/* ---- decision margins (test infrastructure of the test infrastructure).  The collision routines take discrete decisions -- which
+ * axis separates best, face or edge contact, which face is incident, which side of a clipping plane, which candidates span the
+ * largest area, which four contacts are the deepest -- and a float32 evaluation of the SAME algorithm takes the other branch
+ * whenever the two alternatives are closer than its rounding error, however well-conditioned the state is otherwise (moving
+ * the state by 1e-6 moves both alternatives alike: the perturbation check of the parity tests cannot see such a tie).
+ * g_margin[k] keeps, per forward pass, the smallest gap between the alternative taken and the runner-up over the decisions of
+ * every colliding pair: [0] lengths in m (separations, depths), [1] cosines between unit normals, [2] signed distances to
+ * clipping planes in m, [3] relative gaps of the manifold's arg-max steps (squared lengths / areas).  Identical alternatives
+ * (the same point twice in a candidate list) do not count.  Read through odko_data_field "decision_margin". */
+static __thread real g_margin[4] = {1e30, 1e30, 1e30, 1e30};
+/* Tie bias (odko_set_tie_bias): inside a band of `eps` around a tie, the decision classes whose bit is set in `mask` take the
+ * RUNNER-UP instead -- consistently, for as long as the bias is on.  Bits: 1 which face of a polytope separates best, 2 whose face
+ * is the reference, 4 edge contact or face contact (the EDGE_TOL threshold), 8 which face is incident, 16 side of a clipping
+ * plane, 32 the manifold's arg-max steps (band in relative units: eps_rel), 64 the cut behind the fourth-deepest height-field
+ * contact, 128 (the one solver decision) the Newton solver's starting point, warm start or unconstrained acceleration, when their
+ * costs are within eps_rel of each other; 256 / 512: the line search (see ls_search).  This is how the parity tests ask "does the kernel's answer follow from the oracle's own algorithm when THIS class
+ * of near-ties falls the other way": an implementation that carries its constants in another precision resolves a tie between
+ * two hull features the same way substep after substep, which neither a single flip nor noise on the state reproduces. */
+static __thread int g_bias_mask = 0, g_bias_request = 0, g_bias_first = 0, g_bias_last = 1 << 30, g_bias_pass = 0;
+static __thread real g_bias_eps = 0, g_bias_eps_rel = 0;
+/* the bias applies to the collision passes first .. last (0-based, counted from this call: one pass per mjx.step / forward): a
+ * foot that ROTATES THROUGH a tie within one env step crosses it in one substep only, a tie between two hull features persists */
+void odko_set_tie_bias_window(int mask, real eps, real eps_rel, int first, int last) {
+  g_bias_request = mask; g_bias_mask = 0; g_bias_eps = eps; g_bias_eps_rel = eps_rel; g_bias_first = first; g_bias_last = last; g_bias_pass = 0;
+}
+void odko_set_tie_bias(int mask, real eps, real eps_rel) { odko_set_tie_bias_window(mask, eps, eps_rel, 0, 1 << 30); }
+#define BIAS(bit, gap) ((g_bias_mask & (bit)) && fabs(gap) < g_bias_eps)
+static void margin_reset(void) { for (int k = 0; k < 4; k++) g_margin[k] = 1e30; }
+static void margin_note(int k, real gap) { gap = fabs(gap); if (gap < g_margin[k]) g_margin[k] = gap; }
+/* gap between the largest and the runner-up of v[0..n) among entries whose POINT differs from the winner's */
+static int margin_argmax(int cat, const real* v, const real (*pt)[3], int n, int win, int relative) {   /* returns the index to use */
+  real second = -1e30; int si = -1;
+  for (int i = 0; i < n; i++) {
+    if (i == win || v[i] < -1e5) continue;
+    real t[3]; v3_sub(t, pt[i], pt[win]);
+    if (v3_dot(t, t) < 1e-18) continue;
+    if (v[i] > second) { second = v[i]; si = i; }
+  }
+  if (si < 0) return win;
+  real gap = relative ? (v[win] - second) / (fabs(v[win]) > 1e-12 ? fabs(v[win]) : 1e-12) : v[win] - second;
+  margin_note(cat, gap);
+  if ((g_bias_mask & 32) && fabs(gap) < g_bias_eps_rel) return si;
+  return win;
+}
 static void manifold_points(const real (*poly)[3], const int* mask, int n, const real* norm, int* idx) {
   real dm[ODKO_MAXHV];
   int ai = 0, bi = 0, ci = 0, di = 0;
@@ -491,12 +553,15 @@ static void manifold_points(const real (*poly)[3], const int* mask, int n, const
   for (int i = 0; i < n; i++) dm[i] = mask[i] ? 0.0 : -1e6;
   best = -1e30; for (int i = 0; i < n; i++) if (dm[i] > best) { best = dm[i]; ai = i; }
   const real* a = poly[ai];
+  real vv[2 * ODKO_MAXHV];
   best = -1e30;
   for (int i = 0; i < n; i++) {
     real t[3]; v3_sub(t, a, poly[i]);
     real v = v3_dot(t, t) + dm[i];
+    vv[i] = v;
     if (v > best) { best = v; bi = i; }
   }
+  bi = margin_argmax(3, vv, poly, n, bi, 1);
   const real* b = poly[bi];
   real ab[3], t[3];
   v3_sub(t, a, b); v3_cross(ab, norm, t);
@@ -504,8 +569,10 @@ static void manifold_points(const real (*poly)[3], const int* mask, int n, const
   for (int i = 0; i < n; i++) {
     real ap[3]; v3_sub(ap, a, poly[i]);
     real v = AREA0(fabs(v3_dot(ap, ab))) + dm[i];
+    vv[i] = v;
     if (v > best) { best = v; ci = i; }
   }
+  ci = margin_argmax(3, vv, poly, n, ci, 1);
   const real* c = poly[ci];
   real ac[3], bc[3];
   v3_sub(t, a, c); v3_cross(ac, norm, t);
@@ -527,6 +594,31 @@ static void manifold_points(const real (*poly)[3], const int* mask, int n, const
     if (vd[n + i] > best) best = vd[n + i];
   }
   for (int i = 0; i < 2 * n; i++) if (vd[i] >= best - AREA_TIE) { di = i % n; break; }
+  {   /* the tie rule makes values within AREA_TIE of the maximum equal: the margin is how far the nearest OTHER point's value is from that band */
+    real second = -1e30;
+    for (int i = 0; i < 2 * n; i++) {
+      if (vd[i] < -1e5 || vd[i] >= best - AREA_TIE) continue;
+      real t[3]; v3_sub(t, poly[i % n], poly[di]);
+      if (v3_dot(t, t) < 1e-18) continue;
+      if (vd[i] > second) second = vd[i];
+    }
+    int alt = -1; real altgap = 1e30;
+    if (second > -1e29) {
+      real g = ((best - AREA_TIE) - second) / (fabs(best) > 1e-12 ? fabs(best) : 1e-12);
+      margin_note(3, g);
+      if (g < altgap) { altgap = g; for (int i = 0; i < 2 * n; i++) if (vd[i] == second) { real t[3]; v3_sub(t, poly[i % n], poly[di]); if (v3_dot(t, t) >= 1e-18) { alt = i % n; break; } } }
+    }
+    for (int i = 0; i < 2 * n; i++) {   /* and a different point INSIDE the band with a lower index would have won */
+      if (vd[i] < best - AREA_TIE || i % n == di) continue;
+      real t[3]; v3_sub(t, poly[i % n], poly[di]);
+      if (v3_dot(t, t) >= 1e-18) {
+        real g = (vd[i] - (best - AREA_TIE)) / (fabs(best) > 1e-12 ? fabs(best) : 1e-12);
+        margin_note(3, g);
+        if (g < altgap) { altgap = g; alt = i % n; }
+      }
+    }
+    if ((g_bias_mask & 32) && alt >= 0 && altgap < g_bias_eps_rel) di = alt;
+  }
   idx[0] = ai; idx[1] = bi; idx[2] = ci; idx[3] = di;
 }
 
@@ -650,13 +742,30 @@ static void hfield_convex(const odko_model* m, odko_data* d, int gh, int gc, int
         odko_convex P;
         hfield_prism(m, c, r, tri, &P);
         real dist4[4], pos4[4][3], nrm[3];
+        real keep[4]; for (int k = 0; k < 4; k++) keep[k] = g_margin[k];
+        margin_reset();
         convex_convex_sat(&P, &F, dist4, pos4, nrm, NULL);
+        int live = 0;
+        for (int k = 0; k < 4; k++) live |= dist4[k] < 0;
+        for (int k = 0; k < 4; k++) g_margin[k] = (live && g_margin[k] < keep[k]) ? g_margin[k] : keep[k];     /* a separated prism decides nothing */
         for (int k = 0; k < 4; k++) { cd[ncand] = dist4[k]; v3_copy(cp[ncand], pos4[k]); v3_copy(cn[ncand], nrm); ncand++; }
       }
   int used[HF_MAXCAND] = {0};
   for (int k = 0; k < 4; k++) {
     int bi = -1;
     for (int i = 0; i < ncand; i++) if (!used[i] && (bi < 0 || cd[i] < cd[bi])) bi = i;
+    if (bi >= 0 && cd[bi] < 0 && (k == 3 || (g_bias_mask & 64))) {
+      /* the cut behind the fourth: the nearest active candidate that is a different contact and stays out.  Under the tie bias
+       * (class 64) EVERY pick prefers a different contact within the band: two one-point manifolds of equal depth from neighbouring
+       * prisms fill the last two slots with copies of one OR the other */
+      int alt = -1;
+      for (int i = 0; i < ncand; i++) {
+        if (used[i] || i == bi || cd[i] >= 0) continue;
+        real t[3], tn[3]; v3_sub(t, cp[i], cp[bi]); v3_sub(tn, cn[i], cn[bi]);   /* (the same point from two prisms is two contacts when their normals differ) */
+        if (v3_dot(t, t) > 1e-18 || fabs(cd[i] - cd[bi]) > 0 || v3_dot(tn, tn) > 1e-12) { if (k == 3) margin_note(0, cd[i] - cd[bi]); if (alt < 0 || cd[i] < cd[alt]) alt = i; }
+      }
+      if (alt >= 0 && BIAS(64, cd[alt] - cd[bi])) bi = alt;
+    }
     real nw[3] = {Rh[2], Rh[5], Rh[8]}, pw[3] = {0, 0, 0};
     real dist = 1.0;
     if (bi >= 0) {
@@ -862,7 +971,16 @@ static void capsule_capsule(const odko_model* m, odko_data* d, int g1, int g2, i
   sphere_sphere_at(d, c0, pa, m->cgeom_size[g1][0], pb, m->cgeom_size[g2][0]);
 }
 
+static void collision_pairs(const odko_model* m, odko_data* d);
 static void collision(const odko_model* m, odko_data* d) {
+  margin_reset();
+  g_bias_mask = (g_bias_pass >= g_bias_first && g_bias_pass <= g_bias_last) ? g_bias_request : 0;
+  g_bias_pass++;
+  collision_pairs(m, d);
+  g_bias_mask = 0;
+  for (int k = 0; k < 4; k++) if (g_margin[k] < d->decision_margin[k]) d->decision_margin[k] = g_margin[k];   /* min since the caller last reset it */
+}
+static void collision_pairs(const odko_model* m, odko_data* d) {
   d->ncon = 0;
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_g1[p], g2 = m->pair_g2[p], c0 = d->ncon;
@@ -1218,37 +1336,46 @@ static void linesearch(const odko_model* m, odko_data* d, solver_ctx* c) {
   for (int i = 0; i < nv; i++) { sMa += c->search[i] * c->Ma[i]; sq += c->search[i] * d->qfrc_smooth[i]; smv += c->search[i] * mv[i]; }
   L.quad_gauss[0] = c->gauss; L.quad_gauss[1] = sMa - sq; L.quad_gauss[2] = 0.5 * smv;
 
+  /* tie bias, solver classes (odko_set_tie_bias): 256 = which end of the final bracket is returned when the two costs are within
+   * eps_rel of each other (relative to the cost at 0) -- the two ends can be far apart in alpha --, 512 = every other comparison of
+   * the bracketing (relative to the larger operand): the search has a fixed budget of iterations and each comparison steers it */
+  const int ls_on = g_bias_pass - 1 >= g_bias_first && g_bias_pass - 1 <= g_bias_last;
+#define LS_LT(a, b) (((g_bias_request & 512) && ls_on && fabs((a) - (b)) < g_bias_eps_rel * (fabs(a) > fabs(b) ? fabs(a) : fabs(b))) ? !((a) < (b)) : ((a) < (b)))
   ls_point p0 = ls_eval(&L, 0.0);
   ls_point lo_in = ls_eval(&L, -safe_div(p0.deriv0, p0.deriv1));
-  int lo_less = lo_in.deriv0 < p0.deriv0;
+  int lo_less = LS_LT(lo_in.deriv0, p0.deriv0);
   ls_point lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
   int swap = 1, it = 0;
+  const real zero = 0;
   while (1) {
     int done = it >= m->ls_iterations;
     done |= !swap;
-    done |= (lo.deriv0 < 0) && (lo.deriv0 > -gtol);
-    done |= (hi.deriv0 > 0) && (hi.deriv0 < gtol);
+    done |= LS_LT(lo.deriv0, zero) && LS_LT(-gtol, lo.deriv0);
+    done |= LS_LT(zero, hi.deriv0) && LS_LT(hi.deriv0, gtol);
     if (done) break;
     ls_point lo_next = ls_eval(&L, lo.alpha - safe_div(lo.deriv0, lo.deriv1));
     ls_point hi_next = ls_eval(&L, hi.alpha - safe_div(hi.deriv0, hi.deriv1));
     ls_point mid = ls_eval(&L, 0.5 * (lo.alpha + hi.alpha));
-    int s1 = (lo.deriv0 > 0) || (lo.deriv0 < lo_next.deriv0);
+    int s1 = LS_LT(zero, lo.deriv0) || LS_LT(lo.deriv0, lo_next.deriv0);
     if (s1) lo = lo_next;
-    int s2 = (mid.deriv0 < 0) && (lo.deriv0 < mid.deriv0);
+    int s2 = LS_LT(mid.deriv0, zero) && LS_LT(lo.deriv0, mid.deriv0);
     if (s2) lo = mid;
-    int s3 = (hi_next.deriv0 < 0) && (lo.deriv0 < hi_next.deriv0);
+    int s3 = LS_LT(hi_next.deriv0, zero) && LS_LT(lo.deriv0, hi_next.deriv0);
     if (s3) lo = hi_next;
-    int s4 = (hi.deriv0 < 0) || (hi.deriv0 > hi_next.deriv0);
+    int s4 = LS_LT(hi.deriv0, zero) || LS_LT(hi_next.deriv0, hi.deriv0);
     if (s4) hi = hi_next;
-    int s5 = (mid.deriv0 > 0) && (hi.deriv0 > mid.deriv0);
+    int s5 = LS_LT(zero, mid.deriv0) && LS_LT(mid.deriv0, hi.deriv0);
     if (s5) hi = mid;
-    int s6 = (lo_next.deriv0 > 0) && (hi.deriv0 > lo_next.deriv0);
+    int s6 = LS_LT(zero, lo_next.deriv0) && LS_LT(lo_next.deriv0, hi.deriv0);
     if (s6) hi = lo_next;
     swap = s1 | s2 | s3 | s4 | s5 | s6;
     it++;
   }
+#undef LS_LT
   int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-  real alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+  int take_lo = lo.cost < hi.cost;
+  if ((g_bias_request & 256) && ls_on && fabs(lo.cost - hi.cost) < g_bias_eps_rel * (fabs(p0.cost) > 1e-9 ? fabs(p0.cost) : 1e-9)) take_lo = !take_lo;
+  real alpha = take_lo ? lo.alpha : hi.alpha;
   if (!improved) alpha = 0;
   d->ls_alpha = alpha; d->ls_iters = it;
   for (int i = 0; i < nv; i++) { c->qacc[i] += alpha * c->search[i]; c->Ma[i] += alpha * mv[i]; }
@@ -1262,6 +1389,8 @@ static void solve(const odko_model* m, odko_data* d) {
   ctx_init(m, d, &cw, d->qacc_warmstart); update_constraint(m, d, &cw);
   ctx_init(m, d, &cs, d->qacc_smooth); update_constraint(m, d, &cs);
   d->warm_used = cw.cost < cs.cost;
+  { real g = fabs(cw.cost - cs.cost) / (fabs(cs.cost) > 1e-9 ? fabs(cs.cost) : 1e-9); if (g < d->decision_margin[4]) d->decision_margin[4] = g;   /* warm-start pick */
+    if ((g_bias_request & 128) && g_bias_pass - 1 >= g_bias_first && g_bias_pass - 1 <= g_bias_last && g < g_bias_eps_rel) d->warm_used = !d->warm_used; }   /* tie bias, class 128 */
   c = d->warm_used ? &cw : &cs;
   d->solver_cost0 = c->cost;
   update_gradient(m, d, c);

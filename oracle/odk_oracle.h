@@ -136,6 +136,10 @@ typedef struct {
   /* solver diagnostics */
   real solver_cost0, solver_cost1, ls_alpha;
   int warm_used, ls_iters;
+  /* smallest gap between the branch taken and its runner-up over the discrete decisions since the caller last set these to 1e30
+   * (odk_oracle.c "decision margins"): [0] collision lengths (m), [1] normal cosines, [2] clipping-plane distances (m), [3] manifold
+   * arg-max steps (relative), [4] warm-start pick (relative cost difference) */
+  real decision_margin[5];
 } odko_data;
 
 #ifdef __cplusplus
@@ -146,6 +150,11 @@ extern "C" {
 odko_model* odko_model_load(const void* blob, uint64_t len);
 void odko_model_free(odko_model* m);
 odko_model* odko_model_copy(const odko_model* m);
+/* tests' referee: inside a band of eps (lengths in m, cosines; eps_rel for the manifold's relative gaps) around a tie, the collision
+ * decisions whose class bit is set in mask take the runner-up (odk_oracle.c "Tie bias"); mask 0 switches it off.  Per thread. */
+void odko_set_tie_bias(int mask, real eps, real eps_rel);
+void odko_set_tie_bias_window(int mask, real eps, real eps_rel, int first_pass, int last_pass); /* only the collision passes first .. last after this call */
+void odko_model_jitter_hulls(odko_model* m, unsigned seed, real rel); /* relative noise on the hull vertices + rebuild of the convex tables (tests' referee) */
 /* named access for tests / domain randomisation: returns pointer + element count, NULL if unknown */
 real* odko_model_field(odko_model* m, const char* name, int* count);
 int odko_model_int(const odko_model* m, const char* name);

@@ -40,6 +40,9 @@ class _Lib:
         L.odko_model_load.restype = P; L.odko_model_load.argtypes = [C.c_char_p, C.c_uint64]
         L.odko_model_free.argtypes = [P]
         L.odko_model_copy.restype = P; L.odko_model_copy.argtypes = [P]
+        L.odko_set_tie_bias.restype = None; L.odko_set_tie_bias.argtypes = [C.c_int, self.real, self.real]
+        L.odko_set_tie_bias_window.restype = None; L.odko_set_tie_bias_window.argtypes = [C.c_int, self.real, self.real, C.c_int, C.c_int]
+        L.odko_model_jitter_hulls.restype = None; L.odko_model_jitter_hulls.argtypes = [P, C.c_uint32, self.real]
         L.odko_model_field.restype = RP; L.odko_model_field.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
         L.odko_model_int.restype = C.c_int; L.odko_model_int.argtypes = [P, C.c_char_p]
         L.odko_model_set_int.restype = C.c_int; L.odko_model_set_int.argtypes = [P, C.c_char_p, C.c_int]
@@ -105,6 +108,15 @@ def lib(f32: bool = False) -> _Lib:
     return _libs[f32]
 
 
+def set_tie_bias(mask: int, eps: float = 0.0, eps_rel: float = 0.0, f32: bool = False, window=None):
+    """odko_set_tie_bias: collision decisions of the classes in `mask` take the runner-up inside the band (tests' referee); 0 = off.
+    `window` = (first, last): only those collision passes after this call (one per mjx.step)."""
+    if window is None:
+        lib(f32).lib.odko_set_tie_bias(int(mask), eps, eps_rel)
+    else:
+        lib(f32).lib.odko_set_tie_bias_window(int(mask), eps, eps_rel, int(window[0]), int(window[1]))
+
+
 def convex_pair(va, ta, pa, Ra, vb, tb, pb, Rb, f32: bool = False):
     """convex_convex (odk_oracle_convex.inc) on two polytopes given as vertices + outward triangles and poses.
     Returns dict(dist[4], pos[4,3], normal[3], sep_a, sep_b, sep_e, kind) -- kind 0 / 1: face contact with A / B as reference, 2: edge."""
@@ -160,6 +172,10 @@ class OracleModel:
         if self.L.lib.odko_model_convex_counts(self.h, g, C.byref(a), C.byref(b), C.byref(c)) != 0:
             raise IndexError(g)
         return a.value, b.value, c.value
+
+    def jitter_hulls(self, seed: int, rel: float):
+        """relative noise on the hull vertices (odko_model_jitter_hulls): call on a copy()"""
+        self.L.lib.odko_model_jitter_hulls(self.h, int(seed), rel)
 
     def copy(self) -> "OracleModel":
         return OracleModel(b"", self.L.f32, _handle=self.L.lib.odko_model_copy(self.h))

@@ -34,7 +34,7 @@ d = O.OracleData(om)
 d["qpos"][: om.nq] = c0.data["qpos"][: om.nq]; d["qvel"][: om.nv] = c0.data["qvel"][: om.nv]; d["qacc_warmstart"][: om.nv] = c0.data["qacc_warmstart"][: om.nv]
 b = engine.Batch(model, 1)
 nv = model.nv
-o = {k: b.lds_offset(k) for k in ("contact_dist", "efc_D", "efc_aref", "qacc", "qacc_smooth", "jar")}
+o = {k: b.lds_offset(k) for k in ("contact_dist", "efc_D", "efc_aref", "qacc", "qacc_smooth", "jar", "contact_r")}
 ctrl = torch.tensor(mt[None], dtype=torch.float32, device="cuda")
 for s in range(10):
     q0 = np.array(d["qpos"][: om.nq]); v0 = np.array(d["qvel"][:nv]); w0 = np.array(d["qacc_warmstart"][:nv])
@@ -60,6 +60,17 @@ for s in range(10):
     both = sorted(act_rows_g & act_rows_o)
     if both:
         print(f"    D err {(np.abs(D_g[both] - D_o[both]) / np.abs(D_o[both])).max():.2e}  aref err {(np.abs(ar_g[both] - ar_o[both]) / np.maximum(np.abs(ar_o[both]), 1)).max():.2e}")
+    if both and (np.abs(ar_g[both] - ar_o[both]) / np.maximum(np.abs(ar_o[both]), 1)).max() > 0.05:
+        bad = [r for r in both if abs(ar_g[r] - ar_o[r]) / max(abs(ar_o[r]), 1) > 0.05]
+        nf, nl = d.i("nf"), d.i("nl")
+        print("    rows whose aref differs:", bad, "(friction rows", nf, "limit rows", nl, "-> contact row r belongs to contact (r - nf - nl) // 4)")
+        for r in bad[:8]:
+            print(f"      row {r}: aref gpu {ar_g[r]:.5g} oracle {ar_o[r]:.5g}  D gpu {D_g[r]:.6g} oracle {D_o[r]:.6g}  efc_pos oracle {d['efc_pos'][r]:.7g}")
+        cp = np.array(d["contact_pos"][:36]).reshape(12, 3); fr = np.array(d["contact_frame"][:108]).reshape(12, 9)
+        for c in range(8):
+            print(f"      oracle contact {c}: dist {cd_o[c]:.7f} pos {np.round(cp[c], 5).tolist()} normal {np.round(fr[c][:3], 5).tolist()}")
+        if "contact_r" in o:
+            print("      gpu contact_r:", np.round(img[o["contact_r"]: o["contact_r"] + 36].reshape(12, 3)[:8], 5).tolist())
     print(f"    state after: qpos err {np.abs(gq[0] - d['qpos'][:om.nq]).max():.2e} qvel err {(np.abs(gv[0] - d['qvel'][:nv]) / np.maximum(np.abs(d['qvel'][:nv]), 1)).max():.2e}")
 
 print("---- free-running k substeps from the env step's initial state (no resync)")
