@@ -64,6 +64,10 @@ typedef struct {
   int32_t env_kind;        /* ODK_ENV_JOYSTICK (joystick.py) or ODK_ENV_STANDING (standing.py): selects the obs layout
                               (101/212 vs 85/153 floats per env -- the output row strides) and the reward table */
   float reset_base_qvel;   /* half-range of the base velocity noise at reset: joystick.py:253 0.05, standing.py:247 0.5 */
+  int32_t hfield_up_normals_only; /* BUILD-DEFINED opt-in, default 0 = the prism algorithm as recalled from MJX.  1: on a height-field
+                              floor a prism pair's contacts count only when their normal points up (n_z > 0.5 in the field's frame): drops the
+                              sideways contacts of prism side faces.  The reading under which the reference's rough-terrain task trains
+                              (profiles/r4/hfield_variants.json); parity against the oracle's hfield_mode 3 */
 } odk_env_config;
 
 /* Caller-owned device outputs of reset/step (any pointer may be NULL to skip it). */

@@ -5,6 +5,7 @@
 // playground/open_duck_mini_v2/joystick.py (line map next to each block) and the brax
 // Episode/AutoReset wrappers.  gfx950 only; no CPU fallback of any kind.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -763,11 +764,11 @@ extern "C" void odk_default_config(odk_env_config* c) {
   const float cr[7][2] = {{-0.15f, 0.15f}, {-0.2f, 0.2f}, {-1.0f, 1.0f}, {-0.34f, 1.1f}, {-0.78f, 0.78f}, {-1.5f, 1.5f}, {-0.5f, 0.5f}};
   memcpy(c->cmd_range, cr, sizeof(cr));
   c->use_imitation = 1; c->use_motor_speed_limits = 1; c->autoreset = 1; c->episode_length = 1000; c->n_substeps = 10; c->lanes_per_env = 0;
-  c->env_kind = ODK_ENV_JOYSTICK; c->reset_base_qvel = 0.05f;
+  c->env_kind = ODK_ENV_JOYSTICK; c->reset_base_qvel = 0.05f; c->hfield_up_normals_only = 0;
 }
 extern "C" void odk_default_config_standing(odk_env_config* c) {   // reference standing.py:44-100
   odk_default_config(c);
-  c->env_kind = ODK_ENV_STANDING; c->reset_base_qvel = 0.5f;
+  c->env_kind = ODK_ENV_STANDING; c->reset_base_qvel = 0.5f; c->hfield_up_normals_only = 0;
   c->max_motor_velocity = 0.0f;   // standing.py has no speed limit (and no such config key)
   c->noise_gyro = 0.05f; c->noise_accelerometer = 0.005f;
   const float rs[7] = {-0.5f, -2.0f, -1.0e-3f, -0.375f, -0.3f, 20.0f, 0.0f};   // orientation, head_pos, torques, action_rate, stand_still, alive
@@ -1450,7 +1451,8 @@ extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, i
   for (int i = 0; i < nth; i++) hp.dths[i] = (float)dths[i];
   for (int i = 0; i < 6; i++) hp.ranges[i] = (float)ranges6[i];
   size_t tbytes = (size_t)nx * ny * nth * 640 * sizeof(float);
-  HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel))); HIPCHK(hipMemcpy(b->d_model, &m->h, sizeof(DevModel), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel)));
+  { DevModel hm = m->h; hm.hfield_filter = cfg->hfield_up_normals_only ? 3 : 0; HIPCHK(hipMemcpy(b->d_model, &hm, sizeof(DevModel), hipMemcpyHostToDevice)); }   // (the batch's own copy: the filter is a batch setting)
   b->h_prm = hp;
   HIPCHK(hipMalloc(&b->d_table, tbytes)); HIPCHK(hipMemcpy(b->d_table, prm_table, tbytes, hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&b->d_recs, (size_t)nenv * b->rec_size * sizeof(float))); HIPCHK(hipMemset(b->d_recs, 0, (size_t)nenv * b->rec_size * sizeof(float)));
@@ -1474,6 +1476,12 @@ extern "C" int odk_batch_set_config(odk_batch* b, const odk_env_config* cfg) {
   if (!b || !cfg) return fail(ODK_ERR_INVALID, "null");
   if (cfg->env_kind != b->cfg.env_kind) return fail(ODK_ERR_INVALID, "odk_batch_set_config: env_kind is fixed at creation (it sets the output strides)");
   int g = b->cfg.lanes_per_env;
+  if ((cfg->hfield_up_normals_only != 0) != (b->cfg.hfield_up_normals_only != 0)) {   // lives in the batch's device model (outside any step)
+    const int v = cfg->hfield_up_normals_only ? 3 : 0;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(reinterpret_cast<char*>(b->d_model) + offsetof(DevModel, hfield_filter), &v, sizeof(int), hipMemcpyHostToDevice));
+  }
   b->cfg = *cfg;
   b->cfg.lanes_per_env = g;
   return ODK_OK;

@@ -1237,6 +1237,25 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act);
 #endif
     if (act && j < 4) NEW[8 * j + 7] = (float)(4 * p + j);   // candidate index in MJX's list: prism-major, then the pair's four slots
+    // opt-in (odk_env_config.hfield_up_normals_only; oracle hfield_mode 3; default off): a pair's contacts count only when its
+    // normal points up -- one wave-uniform flag from the batch's model, nothing on the default path but the test
+    if (m->hfield_filter == 3) {
+      ODK_SYNC();
+      if (act && j < 4 && !(NEW[8 * j + 6] > 0.5f)) NEW[8 * j] = 1.0f;
+    }
+#if defined(ODK_HF_VARIANT) && ODK_HF_VARIANT == 4
+    // hypothesis sweep (make libodk_hfv4.so; oracle hfield_mode 4): one contact per prism, its deepest (first of equals)
+    ODK_SYNC();
+    {
+      const float d0 = NEW[0], d1 = NEW[8], d2 = NEW[16], d3 = NEW[24];
+      int kb = 0; float db = d0;
+      if (d1 < db) { db = d1; kb = 1; }
+      if (d2 < db) { db = d2; kb = 2; }
+      if (d3 < db) { db = d3; kb = 3; }
+      ODK_SYNC();
+      if (act && j < 4 && j != kb) NEW[8 * j] = 1.0f;
+    }
+#endif
     ODK_SYNC();
     for (unsigned q = 0; q <= maxq; q++) merge_top4_row(TOPt, NEW, j, act && my_q == (int)q);
 #ifdef ODK_PROFILE

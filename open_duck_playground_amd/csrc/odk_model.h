@@ -143,6 +143,7 @@ struct DevModel {
   // height-field floor (rough terrain): geom frame = (plane_pos, floor_mat); samples live in HBM (KArgs.hfield)
   int hfield_nrow, hfield_ncol;
   float hfield_size[4], floor_mat[9];
+  int hfield_filter;   // per batch (odk_env_config.hfield_up_normals_only): 0 = none, 3 = a pair's contacts count only when its normal points up
   // sites / sensors
   int site_body[MAXSITE], site_imu, site_feet[2];
   float site_pos[MAXSITE][3], site_mat[MAXSITE][9], site_quat[MAXSITE][4];

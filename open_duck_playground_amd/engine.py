@@ -38,6 +38,7 @@ class EnvConfig(C.Structure):
         ("cmd_range", (C.c_float * 2) * 7),
         ("use_imitation", C.c_int32), ("use_motor_speed_limits", C.c_int32), ("autoreset", C.c_int32), ("episode_length", C.c_int32),
         ("n_substeps", C.c_int32), ("lanes_per_env", C.c_int32), ("env_kind", C.c_int32), ("reset_base_qvel", C.c_float),
+        ("hfield_up_normals_only", C.c_int32),
     ]
 
 

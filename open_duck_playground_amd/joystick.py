@@ -106,6 +106,8 @@ def to_engine_config(cfg: ConfigDict, autoreset: bool = True, lanes_per_env: int
     c.episode_length = int(cfg.episode_length)
     c.n_substeps = int(round(cfg.ctrl_dt / cfg.sim_dt))
     c.lanes_per_env = lanes_per_env
+    # additive key (not in the reference's config): on a height-field floor, prism contacts count only when their normal points up
+    c.hfield_up_normals_only = int(bool(cfg.get("hfield_up_normals_only", False)))
     return c
 
 

@@ -32,7 +32,8 @@ class OpenDuckMiniV2Runner:
         device = args.device if self.world == 1 else local_rank
         torch.cuda.set_device(device)
         n_local = args.num_envs // self.world
-        self.env = available_envs[args.env](task=args.task, num_envs=n_local, device=device, env_id_offset=self.rank * n_local)
+        overrides = {"hfield_up_normals_only": True} if getattr(args, "hfield_up_normals_only", False) else None
+        self.env = available_envs[args.env](task=args.task, num_envs=n_local, device=device, env_id_offset=self.rank * n_local, config_overrides=overrides)
         self.action_size = self.env.action_size
         self.obs_size = int(self.env.observation_size["state"][0])
         # one generator per (seed, rank, stream): stream 0 = training envs, 1 = evaluation envs (ppo/train.py)
@@ -89,6 +90,9 @@ def main():
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--device", type=int, default=0)
     parser.add_argument("--no_randomize", action="store_true")
+    parser.add_argument("--hfield_up_normals_only", action="store_true",
+                        help="height-field floors: count a prism pair's contacts only when the normal points up (BUILD-DEFINED opt-in, DESIGN 2; "
+                             "the reading under which rough_terrain_backlash trains: profiles/r4/hfield_variants.json)")
     args = parser.parse_args()
     runner = OpenDuckMiniV2Runner(args)
     try:

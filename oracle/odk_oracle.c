@@ -184,6 +184,7 @@ odko_model* odko_model_load(const void* blob, uint64_t len) {
   if (!ok || m->nsensor < 0 || m->ncgeom < 0) { free(m); return NULL; }
   { /* optional height field (scene_rough_terrain_backlash.xml:22) */
     rec_hdr hh;
+    { const char* hm = getenv("ODK_ORACLE_HFIELD_MODE"); if (hm) m->hfield_mode = atoi(hm); }   /* hypothesis sweep: the parity tests against a variant kernel build */
     if (find_rec(b, len, "hfield_data", &hh)) {
       m->hfield_nrow = (int)hh.shape[0]; m->hfield_ncol = (int)hh.shape[1];
       if (m->hfield_nrow * m->hfield_ncol > ODKO_MAXHFIELD || load_f(b, len, "hfield_data", m->hfield_data, ODKO_MAXHFIELD) < 0 ||
@@ -741,6 +742,7 @@ static void hfield_convex(const odko_model* m, odko_data* d, int gh, int gc, int
         if (ncand + 4 > HF_MAXCAND) continue;
         odko_convex P;
         hfield_prism(m, c, r, tri, &P);
+        P.top_only = m->hfield_mode == 2;
         real dist4[4], pos4[4][3], nrm[3];
         real keep[4]; for (int k = 0; k < 4; k++) keep[k] = g_margin[k];
         margin_reset();
@@ -748,6 +750,12 @@ static void hfield_convex(const odko_model* m, odko_data* d, int gh, int gc, int
         int live = 0;
         for (int k = 0; k < 4; k++) live |= dist4[k] < 0;
         for (int k = 0; k < 4; k++) g_margin[k] = (live && g_margin[k] < keep[k]) ? g_margin[k] : keep[k];     /* a separated prism decides nothing */
+        if (m->hfield_mode == 3 && !(nrm[2] > 0.5)) for (int k = 0; k < 4; k++) dist4[k] = 1.0;              /* hypothesis sweep: upward normals only */
+        if (m->hfield_mode == 4) {                                                                          /* hypothesis sweep: the prism's deepest contact alone */
+          int kb = 0;
+          for (int k = 1; k < 4; k++) if (dist4[k] < dist4[kb]) kb = k;
+          for (int k = 0; k < 4; k++) if (k != kb) dist4[k] = 1.0;
+        }
         for (int k = 0; k < 4; k++) { cd[ncand] = dist4[k]; v3_copy(cp[ncand], pos4[k]); v3_copy(cn[ncand], nrm); ncand++; }
       }
   int used[HF_MAXCAND] = {0};

@@ -62,6 +62,7 @@ typedef struct {
   real fnorm[CV_MAXF][3];                    /* outward unit normals */
   int e[CV_MAXE][2], ef[CV_MAXE][2];         /* unique edges a -> b; ef[0] = face that runs a -> b, ef[1] = face that runs b -> a */
   real c[3];                                 /* mean of the vertices (interior point) */
+  int top_only;                              /* height-field hypothesis sweep (hfield_mode 2): of THIS polytope only face 0 and the edges of face 0 give axes / incident faces */
 } odko_convex;
 
 
@@ -106,7 +107,10 @@ typedef struct {
   /* derived: contact pair list, face polygons / edges of the mesh geoms (geom frame) */
   int npair, pair_g1[3], pair_g2[3];
   odko_convex cgeom_convex[ODKO_MAXG];
-  int hfield_mode;   /* 0: prisms of the cells under the geom (MJX hfield_convex); 1: round-2's one-triangle plane (kept to measure the difference) */
+  int hfield_mode;   /* 0: prisms of the cells under the geom (MJX hfield_convex as recalled; what the kernels run); 1: round-2's one-triangle plane;
+                      * hypothesis sweep (tools/hfield_variants.py; oracle only): 2 = a prism's side / bottom faces and vertical edges give no axis and are never
+                      * incident (only its top triangle collides), 3 = mode 0 but a contact is kept only when its normal points up (n_z > 0.5 in the field's
+                      * frame), 4 = one contact per prism (its deepest), the four deepest of those kept (MuJoCo-C's mjc_ConvexHField gives one per prism) */
 } odko_model;
 
 typedef struct {

@@ -581,3 +581,58 @@ double odko_rollout_mt(const odko_model* m, const odko_prm* prm, int nenv, int n
   double sec = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
   return (double)nenv * nsteps / sec;
 }
+
+/* ------------------------------------------------------------------ a vector of envs stepped by a pool of threads (tools: the
+ * height-field hypothesis sweep trains a policy against the ORACLE -- tools/hfield_variants.py -- which needs the brax-style batched
+ * reset / step surface; float32 in and out whatever `real` is) */
+struct odko_vec { const odko_model* m; const odko_prm* prm; int n; odko_env** e; };
+typedef struct { odko_vec* v; int e0, e1, reset; uint32_t seed, offset; const float* act; float *obs, *priv, *rew, *done, *trunc, *met; } vec_arg;
+
+odko_vec* odko_vec_new(const odko_model* m, const odko_prm* prm, int n, int standing) {
+  odko_vec* v = (odko_vec*)malloc(sizeof(odko_vec));
+  v->m = m; v->prm = prm; v->n = n; v->e = (odko_env**)malloc(sizeof(odko_env*) * (n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) { v->e[i] = odko_env_new(m, prm, NULL); if (standing) odko_env_set_standing(v->e[i]); }
+  return v;
+}
+void odko_vec_free(odko_vec* v) { if (!v) return; for (int i = 0; i < v->n; i++) odko_env_free(v->e[i]); free(v->e); free(v); }
+odko_env* odko_vec_env(odko_vec* v, int i) { return (i >= 0 && i < v->n) ? v->e[i] : NULL; }
+static void* vec_worker(void* p) {
+  vec_arg* a = (vec_arg*)p;
+  const int nu = a->v->m->nu;
+  for (int i = a->e0; i < a->e1; i++) {
+    odko_env* e = a->v->e[i];
+    if (a->reset) odko_env_reset(e, a->seed, a->offset + (uint32_t)i);
+    else { real act[ODKO_MAXU]; for (int u = 0; u < nu; u++) act[u] = (real)a->act[(size_t)i * nu + u]; odko_env_step(e, act); }
+    const int no = odko_env_nobs(e), np = odko_env_npriv(e);
+    for (int k = 0; k < no; k++) a->obs[(size_t)i * no + k] = (float)e->obs[k];
+    for (int k = 0; k < np; k++) a->priv[(size_t)i * np + k] = (float)e->priv[k];
+    if (a->rew) a->rew[i] = (float)e->reward;
+    if (a->done) a->done[i] = (float)e->done;
+    if (a->trunc) a->trunc[i] = (float)e->truncation;
+    if (a->met) for (int k = 0; k < ODKO_NMETRIC; k++) a->met[(size_t)i * ODKO_NMETRIC + k] = (float)e->metrics[k];
+  }
+  return NULL;
+}
+static void vec_run(vec_arg proto, int nthreads) {
+  const int n = proto.v->n;
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > n) nthreads = n > 0 ? n : 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
+  vec_arg* args = (vec_arg*)malloc(sizeof(vec_arg) * nthreads);
+  for (int t = 0; t < nthreads; t++) {
+    args[t] = proto; args[t].e0 = (int)((long)n * t / nthreads); args[t].e1 = (int)((long)n * (t + 1) / nthreads);
+    pthread_create(&th[t], NULL, vec_worker, &args[t]);
+  }
+  for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+  free(th); free(args);
+}
+void odko_vec_reset(odko_vec* v, uint32_t seed, uint32_t env_offset, int nthreads, float* obs, float* priv) {
+  vec_arg a; memset(&a, 0, sizeof(a));
+  a.v = v; a.reset = 1; a.seed = seed; a.offset = env_offset; a.obs = obs; a.priv = priv;
+  vec_run(a, nthreads);
+}
+void odko_vec_step(odko_vec* v, const float* actions, int nthreads, float* obs, float* priv, float* reward, float* done, float* trunc, float* metrics) {
+  vec_arg a; memset(&a, 0, sizeof(a));
+  a.v = v; a.act = actions; a.obs = obs; a.priv = priv; a.rew = reward; a.done = done; a.trunc = trunc; a.met = metrics;
+  vec_run(a, nthreads);
+}

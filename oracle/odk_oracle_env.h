@@ -105,6 +105,14 @@ real odko_reward_imitation(const real* base_qpos, const real* base_qvel, const r
 
 /* multi-threaded random-action rollout for the CPU baseline: returns env-steps/sec */
 double odko_rollout_mt(const odko_model* m, const odko_prm* prm, int nenv, int nsteps, int nwarm, int nthreads, uint32_t seed);
+/* a vector of envs behind the batched reset / step surface, stepped by nthreads pthreads (tools only: tools/hfield_variants.py) */
+typedef struct odko_vec odko_vec;
+odko_vec* odko_vec_new(const odko_model* m, const odko_prm* prm, int n, int standing);
+void odko_vec_free(odko_vec* v);
+odko_env* odko_vec_env(odko_vec* v, int i);
+void odko_vec_reset(odko_vec* v, uint32_t seed, uint32_t env_offset, int nthreads, float* obs, float* priv);
+void odko_vec_step(odko_vec* v, const float* actions, int nthreads, float* obs, float* priv, float* reward, float* done, float* trunc, float* metrics);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,3 +311,61 @@ class OracleEnv:
         if getattr(self, "h", None):
             self.L.lib.odko_env_free(self.h)
             self.h = None
+
+
+class OracleVecEnv:
+    """N oracle envs behind the batched reset / step surface of the product's Joystick (tools only: the height-field hypothesis sweep
+    trains against the oracle).  Tensors are torch tensors on `device`; the physics runs on `threads` host threads."""
+
+    METRIC_NAMES = ("reward/tracking_lin_vel", "reward/tracking_ang_vel", "cost/torques", "cost/action_rate", "cost/stand_still",
+                    "reward/alive", "reward/imitation", "swing_peak")
+
+    def __init__(self, model: OracleModel, prm: OraclePRM, n: int, device="cpu", threads: int = 8, standing: bool = False, env_id_offset: int = 0):
+        import torch
+        self.L, self.m, self.prm, self.num_envs, self.device, self.threads, self.offset = model.L, model, prm, int(n), torch.device(device), int(threads), int(env_id_offset)
+        lib_ = self.L.lib
+        P, FP = C.c_void_p, C.POINTER(C.c_float)
+        lib_.odko_vec_new.restype = P; lib_.odko_vec_new.argtypes = [P, P, C.c_int, C.c_int]
+        lib_.odko_vec_free.argtypes = [P]
+        lib_.odko_vec_env.restype = P; lib_.odko_vec_env.argtypes = [P, C.c_int]
+        lib_.odko_vec_reset.argtypes = [P, C.c_uint32, C.c_uint32, C.c_int, FP, FP]
+        lib_.odko_vec_step.argtypes = [P, FP, C.c_int, FP, FP, FP, FP, FP, FP]
+        self.h = lib_.odko_vec_new(model.h, prm.h, self.num_envs, int(standing))
+        e0 = OracleEnv(model, prm, _handle=lib_.odko_vec_env(self.h, 0)); e0.h = None     # (borrowed handle: never freed here)
+        self.nobs, self.npriv = lib_.odko_env_nobs(lib_.odko_vec_env(self.h, 0)), lib_.odko_env_npriv(lib_.odko_vec_env(self.h, 0))
+        self.action_size = model.nu
+        self.observation_size = {"state": (self.nobs,), "privileged_state": (self.npriv,)}
+        z = lambda *s: np.zeros(s, np.float32)
+        self._obs, self._priv, self._rew, self._done, self._trunc, self._met = z(n, self.nobs), z(n, self.npriv), z(n), z(n), z(n), z(n, 8)
+
+    def config(self, name: str, value):
+        """sets a config field (odko_env_config name) on every env"""
+        for i in range(self.num_envs):
+            e = OracleEnv(self.m, self.prm, _handle=self.L.lib.odko_vec_env(self.h, i))
+            e.cfg[name][:] = value
+            e.h = None
+
+    def _state(self):
+        import torch
+        from types import SimpleNamespace
+        t = lambda a: torch.from_numpy(a.copy()).to(self.device)
+        met = t(self._met)
+        return SimpleNamespace(data=None, obs={"state": t(self._obs), "privileged_state": t(self._priv)}, reward=t(self._rew), done=t(self._done),
+                               metrics={nm: met[:, i] for i, nm in enumerate(self.METRIC_NAMES)}, info={"truncation": t(self._trunc)})
+
+    def reset(self, seed: int = 0):
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        self.L.lib.odko_vec_reset(self.h, int(seed), self.offset, self.threads, fp(self._obs), fp(self._priv))
+        self._rew[:] = 0; self._done[:] = 0; self._trunc[:] = 0; self._met[:] = 0
+        return self._state()
+
+    def step(self, state, action):
+        a = np.ascontiguousarray(action.detach().to("cpu").numpy(), np.float32)
+        fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        self.L.lib.odko_vec_step(self.h, fp(a), self.threads, fp(self._obs), fp(self._priv), fp(self._rew), fp(self._done), fp(self._trunc), fp(self._met))
+        return self._state()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.lib.odko_vec_free(self.h)
+            self.h = None

@@ -187,6 +187,70 @@ def test_one_substep_stages(torch_cuda, oracle_mod, parity_log, task, lanes):
     parity_log.check(f"one_mjx_step/{task}/lanes{lanes}", dict(STAGE_BOUNDS, tie_fraction=0.15 if "rough" in task else 0.1), tie_fraction=n_tie / n, **worst)
 
 
+def test_height_field_up_normals_option(torch_cuda, oracle_mod, parity_log):
+    """odk_env_config.hfield_up_normals_only (BUILD-DEFINED opt-in, default off): a prism pair's contacts count only when its
+    normal points up.  Against the oracle's hfield_mode 3 on feet pressed 0.3 ... 8 mm into the terrain at tilts up to 0.6 rad (where
+    prism side faces win the separating-axis test): contact distances, one mjx.step and ten; and the option must CHANGE the contacts of
+    some of these states (a kernel that ignored it would still match the default oracle), switch on and off through
+    odk_batch_set_config, and leave the default path bit-identical."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import load_task_model
+    torch = torch_cuda
+    model = load_task_model("rough_terrain_backlash")
+    n = 96
+    rng = np.random.default_rng(31)
+    qpos, qvel = _random_states(model, n, rng, airborne_frac=0.0)
+    for e in range(n):      # larger tilts than the standing-ish default: a tilted sole overlaps neighbouring prisms at its rim
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(-0.6, 0.6)
+        qpos[e, 3:7] = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+    om0 = oracle_mod.OracleModel(model.blob())
+    om3 = om0.copy(); om3.set_int("hfield_mode", 3)
+    qpos = _settle_on_terrain(oracle_mod, om0, qpos, rng, np.zeros(n, bool))
+    qpos[:, 2] -= rng.uniform(0.0, 0.015, n)        # ... then pressed in by up to 1.5 cm, like the reset states of the task (joystick.py:206-258 ignores the elevation)
+    qvel *= 0.3
+    warm = np.zeros((n, model.nv))
+    ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.2, 0.2, (n, 14))
+    ctrl_t = torch.tensor(ctrl, dtype=torch.float32, device="cuda")
+    cfg = engine.default_config(); cfg.hfield_up_normals_only = 1
+    b = engine.Batch(model, n, cfg)
+    b0 = engine.Batch(model, n)
+    o_cd = b.lds_offset("contact_dist")
+    res = {}
+    for name, bb in (("on", b), ("off", b0)):
+        bb.set_state(qpos, qvel, warm); bb.physics_step(ctrl_t, 1)
+        res[name] = (bb.lds_image()[:, o_cd: o_cd + 8].copy(),) + bb.get_state()[:2]
+    W = dict(dist=0.0, qpos=0.0, qvel=0.0)
+    prng = np.random.default_rng(3)
+    n_changed = n_tie = 0
+    for e in range(n):
+        d3, d0 = oracle_mod.OracleData(om3), oracle_mod.OracleData(om0)
+        for d in (d3, d0):
+            d["qpos"][: om0.nq] = qpos[e]; d["qvel"][: om0.nv] = qvel[e]; d["ctrl"][:14] = ctrl[e]
+            d.forward()
+        c3, c0 = np.array(d3["contact_dist"][:8]), np.array(d0["contact_dist"][:8])
+        n_changed += int(not np.allclose(np.sort(np.minimum(c3, 0)), np.sort(np.minimum(c0, 0)), atol=1e-6))
+        if _contact_tie(oracle_mod, om3, qpos[e], qvel[e], ctrl[e], prng, _contacts(d3)) or _contact_tie(oracle_mod, om0, qpos[e], qvel[e], ctrl[e], prng, _contacts(d0)):
+            n_tie += 1
+            continue
+        for name, c_o, om in (("on", c3, om3), ("off", c0, om0)):
+            cd_g, gq, gv = res[name][0][e], res[name][1][e], res[name][2][e]
+            act = (c_o < 0) | (cd_g < 0)
+            if act.any():
+                W["dist"] = max(W["dist"], np.abs(cd_g[act] - c_o[act]).max())
+            ds = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 1)
+            W["qpos"] = max(W["qpos"], _rel(gq, ds["qpos"][: om.nq], 1e-2).max()); W["qvel"] = max(W["qvel"], _rel(gv, ds["qvel"][: om.nv], 1.0).max())
+    assert n_changed >= n // 12, (n_changed, n)       # the option matters on these poses (12 of 96 measured)
+    # switching through odk_batch_set_config: the default batch turned on reproduces the opt-in batch bit for bit, and back
+    c_on = engine.default_config(); c_on.hfield_up_normals_only = 1
+    b0.set_config(c_on); b0.set_state(qpos, qvel, warm); b0.physics_step(ctrl_t, 1)
+    assert np.array_equal(b0.lds_image()[:, o_cd: o_cd + 8], res["on"][0]) and np.array_equal(b0.get_state()[0], res["on"][1])
+    b0.set_config(engine.default_config()); b0.set_state(qpos, qvel, warm); b0.physics_step(ctrl_t, 1)
+    assert np.array_equal(b0.lds_image()[:, o_cd: o_cd + 8], res["off"][0]) and np.array_equal(b0.get_state()[0], res["off"][1])
+    b.close(); b0.close()
+    parity_log.rec("hfield_up_normals_option", None, states=n, states_whose_contacts_change=n_changed)
+    parity_log.check("hfield_up_normals_option", dict(dist=STAGE_BOUNDS["dist"], qpos=STAGE_BOUNDS["qpos"], qvel=STAGE_BOUNDS["qvel"], tie_fraction=0.3), tie_fraction=n_tie / n, **W)
+
+
 def test_height_field_far_from_the_origin(torch_cuda, oracle_mod, parity_log):
     """The terrain spans +-10 m and a contact depth is a fraction of a millimetre: the kernel works relative to the first grid
     corner of each foot's window, so contacts 7-9 m from the origin must agree with the float64 oracle as well as those next to it."""
