@@ -283,7 +283,9 @@ void odk_mlp_set_profile(long long* stamps_dev);
  * clock, HW_ID | XCC_ID << 32 and its shader-clock cycles (forward and backward launches alike); NULL: off */
 void odk_mlp_set_wg_profile(long long* dev);
 /* tools: diagnostic variants of the network launches (results are WRONG): bit 0 = every weight load re-reads its phase's first group
- * (what the launch costs when the weights come from the L1), bit 1 = the MFMAs are skipped (what the operand traffic alone costs) */
+ * (what the launch costs when the weights come from the L1), bit 1 = the MFMAs are skipped (what the operand traffic alone costs), bit 2 = no
+ * operand loads inside the loops (what the MFMAs alone cost), bit 3 = no activation stores, bit 4 = every second weight load skipped.  Only the
+ * diagnostic build (make libodk_mlpdiag.so) honours them */
 void odk_mlp_set_diag(int bits);
 /* Where up to 8 weight matrices sit in a flat parameter buffer (float offset `off`, torch layout [rows = n_out, cols = n_in]) and
  * in the packed buffers (float offsets, multiples of 4; bwd_off < 0: no backward copy of that weight). */

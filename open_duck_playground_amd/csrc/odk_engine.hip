@@ -76,6 +76,11 @@ template <class S> __device__ __forceinline__ const int* load_shared(float* lds,
 
 using ShapeA = Shape<21, 20, 18, 14, 15, 145, 170, 76, 10, 15>;   // flat_terrain
 using ShapeB = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25>;   // *_backlash
+// A robot that is not the duck (tests/assets/tail_biped.xml: biped with a five-link tail, 21 dofs, 15 actuators, 19 bodies,
+// box feet): the PHYSICS kernels only (odk_physics_step, state / debug accessors) -- the env kernels' task logic (observation layout,
+// rewards, 14 actions) is the duck's, as the reference's own joystick.py is.  What adding it took: this line, the three dispatch
+// lines below that name it, and nothing in odk_kernels.h beyond admitting nv = 21 to the chain solver.
+using ShapeC = Shape<22, 21, 19, 15, 16, 156, 181, 78, 10, 15>;
 
 struct KArgs {
   const DevModel* m;
@@ -734,7 +739,7 @@ static int fail(int code, const char* fmt, ...) {
 int odk_fail_(int code, const char* msg) { return fail(code, "%s", msg); }   // for odk_learner.hip
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(ODK_ERR_HIP, "%s: %s", #x, hipGetErrorString(_e)); } while (0)
 
-struct odk_model { DevModel h; int shape; std::vector<float> hfield; };  // shape: 0 = A, 1 = B; hfield: [nrow][ncol] in [0, 1]
+struct odk_model { DevModel h; int shape; std::vector<float> hfield; };  // shape: 0 = A, 1 = B, 2 = C (physics only); hfield: [nrow][ncol] in [0, 1]
 
 struct odk_batch {
   odk_model model;
@@ -1218,6 +1223,16 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   }
   if (!B.ok || ncg != 3) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   (void)nhv; (void)nhf;
+  {   // the kernels' pair structure is fixed: floor x left foot, floor x right foot, left foot x right foot.  MuJoCo collides geoms g1, g2 when
+      // (contype1 & conaffinity2) || (contype2 & conaffinity1): a model whose masks leave one of the three out would get a pair it does not have
+    int ct[4] = {1, 1, 1, 1}, ca[4] = {1, 1, 1, 1};
+    { const bool was_ok = B.ok; const std::string miss = B.missing; B.I("cgeom_contype", ct, 4); B.I("cgeom_conaffinity", ca, 4); B.ok = was_ok; B.missing = miss; }
+    auto collide = [&](int g1, int g2) { return ((ct[g1] & ca[g2]) | (ct[g2] & ca[g1])) != 0; };
+    if (!collide(floor_cg[0], foot_cg[0]) || !collide(floor_cg[0], foot_cg[1]) || !collide(foot_cg[0], foot_cg[1])) {
+      delete mo;
+      return fail(ODK_ERR_UNSUPPORTED, "contype / conaffinity exclude one of the three geom pairs the kernels collide (floor x each foot, foot x foot)");
+    }
+  }
   for (int g = 0; g < 3; g++)   // the culls (height-field prisms, foot-foot boxes) drop every pair with a positive gap: only valid at margin 0
     if (cg_margin[g] != 0) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "collision geom %d has margin %g: contacts are detected at distance 0", g, cg_margin[g]); }
   m.foot_prim = 0;
@@ -1379,16 +1394,19 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   };
   if (fits(ShapeA::NQ, ShapeA::NV, ShapeA::NB, ShapeA::NU, ShapeA::NJ, ShapeA::NM, ShapeA::NH, ShapeA::NROW, ShapeA::DT, ShapeA::DV)) mo->shape = 0;
   else if (fits(ShapeB::NQ, ShapeB::NV, ShapeB::NB, ShapeB::NU, ShapeB::NJ, ShapeB::NM, ShapeB::NH, ShapeB::NROW, ShapeB::DT, ShapeB::DV)) mo->shape = 1;
+  else if (fits(ShapeC::NQ, ShapeC::NV, ShapeC::NB, ShapeC::NU, ShapeC::NJ, ShapeC::NM, ShapeC::NH, ShapeC::NROW, ShapeC::DT, ShapeC::DV)) mo->shape = 2;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
   if (mo->shape == 1 && !(m.paired && m.nvr == ShapeB::NVR && m.nMr == ShapeB::NMR && m.nHr == ShapeB::NHR)) {
     delete mo;
     return fail(ODK_ERR_UNSUPPORTED, "the 30-dof kernels expect backlash twins (same body, anchor and axis as their joint) over the 20-dof tree");
   }
-  if (mo->shape == 0 && m.paired) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "twin dofs in a model of the 20-dof shape"); }
+  if (mo->shape != 1 && m.paired) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "twin dofs in a model of the 20-dof shape"); }
   for (int lane = 0; lane < 64; lane++) {   // per-lane statics of the kernels (LaneSt)
     memset(&m.lane_st[lane], 0, sizeof(LaneSt));
-    if (mo->shape == 0) compute_statics<ShapeA>(m.lane_st[lane], &m, lane); else compute_statics<ShapeB>(m.lane_st[lane], &m, lane);
+    if (mo->shape == 0) compute_statics<ShapeA>(m.lane_st[lane], &m, lane);
+    else if (mo->shape == 1) compute_statics<ShapeB>(m.lane_st[lane], &m, lane);
+    else compute_statics<ShapeC>(m.lane_st[lane], &m, lane);
   }
   *out = mo;
   return ODK_OK;
@@ -1413,7 +1431,7 @@ extern "C" int odk_model_reduced(const odk_model* m, int* paired, int* nvr, int*
 }
 extern "C" int odk_model_env_lds_floats(const odk_model* m) {
   if (!m) return -1;
-  return m->shape == 0 ? EnvL<ShapeA>::TOTAL : EnvL<ShapeB>::TOTAL;
+  return m->shape == 0 ? EnvL<ShapeA>::TOTAL : (m->shape == 1 ? EnvL<ShapeB>::TOTAL : EnvL<ShapeC>::TOTAL);
 }
 
 template <class S> static void fill_sizes(odk_batch* b) {
@@ -1442,7 +1460,7 @@ extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, i
   b->model = *m; b->nenv = nenv; b->device = device; b->cfg = *cfg;
   b->G = cfg->lanes_per_env == 64 ? 64 : 32;
   if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 32 && cfg->lanes_per_env != 64) { delete b; return fail(ODK_ERR_INVALID, "lanes_per_env must be 0, 32 or 64"); }
-  if (m->shape == 0) fill_sizes<ShapeA>(b); else fill_sizes<ShapeB>(b);
+  if (m->shape == 0) fill_sizes<ShapeA>(b); else if (m->shape == 1) fill_sizes<ShapeB>(b); else fill_sizes<ShapeC>(b);
   DevPRM hp;
   memset(&hp, 0, sizeof(hp));
   hp.nx = nx; hp.ny = ny; hp.nth = nth; hp.nsteps = nsteps;
@@ -1536,8 +1554,19 @@ template <class S, int G, bool HF> static hipError_t launch_sg(int which, const 
   else hipLaunchKernelGGL((physics_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
   return hipGetLastError();
 }
+// physics only (ShapeC: a robot whose task logic is not the duck's)
+template <class S, int G> static hipError_t launch_phys(int which, const KArgs& a, hipStream_t st) {
+  if (which != K_PHYS) return hipErrorNotSupported;
+  const int per_block = 64 / G;
+  const int grid = (a.nenv + per_block - 1) / per_block;
+  hipLaunchKernelGGL((physics_kernel<S, G, false>), dim3(grid), dim3(64), (size_t)EnvL<S>::wg_floats(per_block) * sizeof(float), st, a);
+  return hipGetLastError();
+}
 static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st) {
-#if defined(ODK_DEV_B32)   // development builds: one instantiation only (make libodk_devB.so / libodk_devA.so: ~25 s instead of 2 min)
+#if defined(ODK_DEV_C32)   // development build: the tail_biped shape alone
+  if (b->model.shape == 2 && b->G == 32) return launch_phys<ShapeC, 32>(which, a, st);
+  return hipErrorNotSupported;
+#elif defined(ODK_DEV_B32)   // development builds: one instantiation only (make libodk_devB.so / libodk_devA.so: ~25 s instead of 2 min)
   if (b->model.shape == 1 && b->model.h.floor_is_plane && b->G == 32) return launch_sg<ShapeB, 32, false>(which, a, st);
   return hipErrorNotSupported;
 #elif defined(ODK_DEV_A32)
@@ -1549,6 +1578,7 @@ static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st
 #endif
   // height-field floors exist only with the backlash model (scene_rough_terrain_backlash.xml) and run 32 lanes per env
   if (!b->model.h.floor_is_plane) return launch_sg<ShapeB, 32, true>(which, a, st);
+  if (b->model.shape == 2) return b->G == 32 ? launch_phys<ShapeC, 32>(which, a, st) : hipErrorNotSupported;
   if (b->model.shape == 0) return b->G == 64 ? launch_sg<ShapeA, 64, false>(which, a, st) : launch_sg<ShapeA, 32, false>(which, a, st);
   return b->G == 64 ? launch_sg<ShapeB, 64, false>(which, a, st) : launch_sg<ShapeB, 32, false>(which, a, st);
 }
@@ -1681,7 +1711,7 @@ extern "C" int odk_batch_get_lds(odk_batch* b, float* host) {  // debug image of
 // named offsets into the LDS image for tests
 extern "C" int odk_lds_offset(const odk_batch* b, const char* name) {
   if (!b || !name) return -1;
-#define OFF(nm, field) if (!strcmp(name, nm)) return b->model.shape == 0 ? ShapeA::field : ShapeB::field;
+#define OFF(nm, field) if (!strcmp(name, nm)) return b->model.shape == 0 ? ShapeA::field : (b->model.shape == 1 ? ShapeB::field : ShapeC::field);
   OFF("qpos", O_QPOS) OFF("qvel", O_QVEL) OFF("warm", O_WARM) OFF("ctrl", O_CTRL) OFF("xpos", O_XPOS) OFF("xquat", O_XQUAT) OFF("crb", O_CRB)
   OFF("cdof", O_CDOF) OFF("M", O_M) OFF("HL", O_HL) OFF("qfrc_smooth", O_QFS) OFF("qacc_smooth", O_QAS) OFF("x", O_X) OFF("Ma", O_MA)
   OFF("search", O_GRAD) OFF("mv", O_MV) OFF("efc_D", O_D) OFF("efc_aref", O_AREF) OFF("jar", O_JAR) OFF("jv", O_JV) OFF("W", O_W)

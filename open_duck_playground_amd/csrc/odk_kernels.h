@@ -82,7 +82,7 @@ struct Shape {
   // contact-row constants.  (Friction-loss rows, actuator constants and the foot hull were tried there too: no gain, their
   // loads from the L2-resident model are already covered.)
   static constexpr int SH_CT = NMR, SHARED = SH_CT + 42;
-  static constexpr int CL = (NV_ == 20 || PAIRED) ? 5 : 0;   // max (reduced) chain length for chain_solve (0: generic path)
+  static constexpr int CL = (NV_ == 20 || NV_ == 21 || PAIRED) ? 5 : 0;   // max (reduced) chain length for chain_solve: every compiled shape is a floating base + <= 3 serial chains of <= 5 (reduced) dofs (0: generic path)
   // persistent over the env step
   static constexpr int O_QPOS = 0;
   static constexpr int O_QVEL = O_QPOS + NQ;

@@ -105,7 +105,8 @@ template <int NBLK, int U>
 struct Phase {
   f32x4 fb[U][NBLK];
   const f32x4* B; unsigned lane_off, blk_off; int N4, ng;
-#ifdef ODK_MLP_DIAG    // diagnostic build (make libodk_mlpdiag.so; tools/gpu_mlp_wg_profile.py): bit 0 = every group re-reads group 0 (L1 hits), bit 1 = no MFMAs
+#ifdef ODK_MLP_DIAG    // diagnostic build (make libodk_mlpdiag.so; tools/gpu_mlp_wg_profile.py): bit 0 = every group re-reads group 0 (L1 hits), bit 1 = no MFMAs,
+                       // bit 2 = no operand loads inside the loops, bit 3 = no activation stores, bit 4 = half of the weight loads
   int diag = 0;
 #else
   static constexpr int diag = 0;
@@ -116,7 +117,10 @@ struct Phase {
       const int G = G0 + u;
       const f32x4* bp = B + (size_t)((G < ng && !(diag & 1)) ? G : 0) * N4;   // wave-uniform base, 32-bit lane offset (diag 1, tools: every group re-reads group 0 -> L1 hits)
 #pragma unroll
-      for (int k = 0; k < NBLK; k++) xb[u][k] = bp[lane_off + blk_off * k];
+      for (int k = 0; k < NBLK; k++) {
+        if ((diag & 16) && (k & 1)) xb[u][k] = xb[u][k - 1];       // (diag 16, tools: half of the weight loads: what the launch would cost with twice the reuse per piece)
+        else xb[u][k] = bp[lane_off + blk_off * k];
+      }
     }
   }
   // Bp: the packed weight, ncols columns; this lane's column in block k: col + blk * k (blk = 16; the output layer, narrower
@@ -148,11 +152,17 @@ struct Phase {
     load_a(0, fa);
     ODK_PIN();
     for (int G0 = 0; G0 < ng; G0 += 2 * U) {
-      load_b(G0 + U, gb); load_a(G0 + U, ga);
+      if (!(diag & 4)) { load_b(G0 + U, gb); load_a(G0 + U, ga); }        // (diag 4, tools: no operand loads inside the loop: what the MFMAs alone cost)
+      else if (G0 == 0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) { ga[u] = fa[u];
+#pragma unroll
+          for (int k = 0; k < NBLK; k++) gb[u][k] = fb[u][k]; }
+      }
       ODK_PIN();
       mma(G0, fa, fb);
       ODK_PIN();
-      load_b(G0 + 2 * U, fb); load_a(G0 + 2 * U, fa);
+      if (!(diag & 4)) { load_b(G0 + 2 * U, fb); load_a(G0 + 2 * U, fa); }
       ODK_PIN();
       mma(G0 + U, ga, gb);
       ODK_PIN();
@@ -253,7 +263,11 @@ __global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
   }
   __syncthreads();
   ODK_STAMP(1);
+#ifdef ODK_MLP_DIAG
+  const bool store = N.h[0] != nullptr && !(a.diag & 8);      // (diag 8, tools: no stores of the activations)
+#else
   const bool store = N.h[0] != nullptr;
+#endif
   const size_t q0 = (size_t)(m0 >> 2);   // the tile's first row quad
   if (store) {   // quad-row copy of the input (the weight-gradient launch's operand)
     for (int k = threadIdx.x; k < kin; k += 256)

@@ -675,7 +675,7 @@ class Batch:
         _chk(self.L.odk_step(self._b, C.c_void_p(action.data_ptr()), C.byref(self._outs), self._stream()))
 
     def physics_step(self, ctrl, n_substeps: int = 10):
-        assert ctrl.is_cuda and ctrl.dtype == self.torch.float32 and ctrl.is_contiguous() and tuple(ctrl.shape) == (self.nenv, NU)
+        assert ctrl.is_cuda and ctrl.dtype == self.torch.float32 and ctrl.is_contiguous() and tuple(ctrl.shape) == (self.nenv, self.model.nu)
         _chk(self.L.odk_physics_step(self._b, C.c_void_p(ctrl.data_ptr()), n_substeps, self._stream()))
 
     # -- synchronous host access (tests, checkpoints)
