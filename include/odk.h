@@ -215,7 +215,7 @@ int odk_colsum_finalize(const float* const* partial_dev, float* const* colsum_de
 /* Weight gradients of up to 8 dense layers in one launch on the f32 matrix cores (v_mfma_f32_32x32x2_f32):
  *   out[out_off[l] + i * n_in[l] + j] = sum over the nrows[l] minibatch rows s of dz[l](s, i) * h[l](s, j)      (= dz^T h, torch Linear weight layout)
  * dz[l] / h[l] are in the QUAD-ROW layout the fused network kernels write: [nrows / 4][width][4], element (s, f) at
- * ((s / 4) * width + f) * 4 + s % 4 (16-byte aligned; nrows[l] a multiple of 8 and >= 8 * kslices; rows past the batch hold zeros
+ * ((s / 4) * width + f) * 4 + s % 4 (16-byte aligned; nrows[l] a multiple of 8 and >= 16 * kslices; rows past the batch hold zeros
  * in at least one of the two operands).  out_dev is the flat gradient buffer.  The rows are split into kslices slices (a
  * multiple of 8); ws_dev is a workspace of kslices * ws_stride floats laid out like out_dev (ws_stride >= every out_off +
  * n_out * n_in, a multiple of 4; every out_off and n_out * n_in a multiple of 4; ws_dev and out_dev 16-byte aligned); the slices

@@ -398,7 +398,10 @@ struct DwLayer { const float* dz; const float* h; int n_out, n_in, tj, tile0, ng
 // works its slot's items one after the other, and a dynamic-LDS reservation of a quarter CU per workgroup keeps the dispatcher
 // from stacking more than four waves on a CU.  For the reference networks: 136 items -> 128 slots, 120 of them one full tile
 // slice, 8 a half tile + a quarter tile; the longest slot is one full slice.
-constexpr int DW_SLOTS = 128, DW_SLOT_ITEMS = 4;
+// Two waves per workgroup (round 4, second step): the two halves of a workspace slice's rows go to the two waves of ONE workgroup,
+// wave 1 hands its accumulators over through LDS and wave 0 adds and stores -- half the split-K workspace (8 slices instead of 16:
+// the finishing launch reads 16 MB instead of 32) for one 32 KB LDS round trip per tile.  A slot is now a workgroup slot: 64 per XCD.
+constexpr int DW_SLOTS = 64, DW_SLOT_ITEMS = 4, DW_WAVES = 2;
 struct DwArgs { DwLayer L[DW_MAX]; int nlayers, ntiles, kslices, nslots; float* ws; long long ws_stride; long long* prof; unsigned short item[DW_SLOTS][DW_SLOT_ITEMS]; };
 
 #ifndef DW_MI
@@ -409,10 +412,12 @@ struct DwArgs { DwLayer L[DW_MAX]; int nlayers, ntiles, kslices, nslots; float* 
 // instantiation -- loads and MFMAs for its blocks only; as one runtime-guarded loop the edge tiles ran 2.5x longer per MFMA than
 // full ones and their slots were the launch's tail).
 template <int NI, int NJ>
-__device__ __forceinline__ void dw_tile(const DwArgs& a, const DwLayer& Ly, const int i0, const int j0, const int slice) {
+__device__ __forceinline__ void dw_tile(const DwArgs& a, const DwLayer& Ly, const int i0, const int j0, const int slice, float* fold) {
   const int n_out = Ly.n_out, n_in = Ly.n_in;
-  const int lane = threadIdx.x, r = lane >> 5, c = lane & 31;
-  const int g_lo = (int)((long long)slice * Ly.ngroups / a.kslices), g_hi = (int)((long long)(slice + 1) * Ly.ngroups / a.kslices);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 5, c = lane & 31;
+  const int s_lo = (int)((long long)slice * Ly.ngroups / a.kslices), s_hi = (int)((long long)(slice + 1) * Ly.ngroups / a.kslices);
+  const int s_mid = s_lo + (s_hi - s_lo + 1) / 2;
+  const int g_lo = wv ? s_mid : s_lo, g_hi = wv ? s_hi : s_mid;     // this wave's half of the slice
   // Out-of-range columns read column 0 of the tile (always valid) and are NOT zeroed: entry (i, j) depends on column i of dz and
   // column j of h only, so whatever the clamped loads bring into the padding never reaches a stored element.
   const f32x4* pa[NI]; const f32x4* pb[NJ];
@@ -461,21 +466,41 @@ __device__ __forceinline__ void dw_tile(const DwArgs& a, const DwLayer& Ly, cons
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  float* w = a.ws + (size_t)slice * a.ws_stride + Ly.out_off;
+  // the two halves of the slice: wave 1's accumulators through LDS ([register][lane]: conflict-free), wave 0 adds (wave 0 + wave 1:
+  // a fixed order) and stores
+  f32x4* fold4 = reinterpret_cast<f32x4*>(fold);      // [block][quarter][lane]: 16-byte pieces, lane-contiguous (ds_write_b128 / ds_read_b128)
+  if (wv == 1) {
 #pragma unroll
-  for (int i = 0; i < NI; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
-    for (int v = 0; v < 16; v++) {
-      const int row = i0 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * r;
-      if (row < n_out) {
+      for (int j = 0; j < NJ; j++)
 #pragma unroll
-        for (int j = 0; j < NJ; j++)
-          if (mb[j]) w[(size_t)row * n_in + j0 + 32 * j + c] = acc[i][j][v];
+        for (int q4 = 0; q4 < 4; q4++)
+          fold4[((i * NJ + j) * 4 + q4) * 64 + lane] = f32x4{acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+  }
+  __syncthreads();
+  if (wv == 0) {
+    // C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float* w = a.ws + (size_t)slice * a.ws_stride + Ly.out_off;
+#pragma unroll
+    for (int i = 0; i < NI; i++)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; q4++) {
+        f32x4 other[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) other[j] = fold4[((i * NJ + j) * 4 + q4) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int v = 4 * q4 + t, row = i0 + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * r;
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+            if (row < n_out && mb[j]) w[(size_t)row * n_in + j0 + 32 * j + c] = acc[i][j][v] + other[j][t];
+        }
       }
-    }
+  }
+  __syncthreads();     // the fold buffer is free again (the slot's next item)
 }
-__device__ __forceinline__ void dw_item(const DwArgs& a, const int tile, const int slice) {
+__device__ __forceinline__ void dw_item(const DwArgs& a, const int tile, const int slice, float* fold) {
   int l = 0;
 #pragma unroll
   for (int k = 1; k < DW_MAX; k++) if (k < a.nlayers && tile >= a.L[k].tile0) l = k;
@@ -484,17 +509,18 @@ __device__ __forceinline__ void dw_item(const DwArgs& a, const int tile, const i
   const int ni = min(DW_MI, (Ly.n_out - i0 + 31) / 32), nj = min(DW_MJ, (Ly.n_in - j0 + 31) / 32);   // wave-uniform: blocks of an edge tile that exist
   static_assert(DW_MI == 4 && DW_MJ == 2, "the dispatch below lists the shapes of a 4 x 2 tile");
   switch (ni * 2 + nj - 3) {     // (ni, nj) -> 0 .. 7
-    case 7: dw_tile<4, 2>(a, Ly, i0, j0, slice); break;
-    case 6: dw_tile<4, 1>(a, Ly, i0, j0, slice); break;
-    case 5: dw_tile<3, 2>(a, Ly, i0, j0, slice); break;
-    case 4: dw_tile<3, 1>(a, Ly, i0, j0, slice); break;
-    case 3: dw_tile<2, 2>(a, Ly, i0, j0, slice); break;
-    case 2: dw_tile<2, 1>(a, Ly, i0, j0, slice); break;
-    case 1: dw_tile<1, 2>(a, Ly, i0, j0, slice); break;
-    default: dw_tile<1, 1>(a, Ly, i0, j0, slice); break;
+    case 7: dw_tile<4, 2>(a, Ly, i0, j0, slice, fold); break;
+    case 6: dw_tile<4, 1>(a, Ly, i0, j0, slice, fold); break;
+    case 5: dw_tile<3, 2>(a, Ly, i0, j0, slice, fold); break;
+    case 4: dw_tile<3, 1>(a, Ly, i0, j0, slice, fold); break;
+    case 3: dw_tile<2, 2>(a, Ly, i0, j0, slice, fold); break;
+    case 2: dw_tile<2, 1>(a, Ly, i0, j0, slice, fold); break;
+    case 1: dw_tile<1, 2>(a, Ly, i0, j0, slice, fold); break;
+    default: dw_tile<1, 1>(a, Ly, i0, j0, slice, fold); break;
   }
 }
-__global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
+__global__ void __launch_bounds__(64 * DW_WAVES) dw_gemm_kernel(DwArgs a) {
+  extern __shared__ float dw_fold[];     // [DW_MI * DW_MJ * 16][64] floats = 32 KB (the launch reserves half a CU's LDS per workgroup)
   const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
   const int per_xcd = a.kslices >> 3;                 // kslices is a multiple of 8
   long long t0 = 0, c0 = 0;
@@ -503,7 +529,7 @@ __global__ void __launch_bounds__(64) dw_gemm_kernel(DwArgs a) {
   for (int k = 0; k < DW_SLOT_ITEMS; k++) {
     const int it = a.item[slot][k];
     if (it == 0xFFFF) break;
-    dw_item(a, it / per_xcd, xcd * per_xcd + it % per_xcd);
+    dw_item(a, it / per_xcd, xcd * per_xcd + it % per_xcd, dw_fold);
   }
   if (a.prof && threadIdx.x == 0) {   // tools/gpu_dw_profile.py: when and where each wave ran (100 MHz wall clock; HW_ID, XCC_ID)
     a.prof[4 * b] = t0; a.prof[4 * b + 1] = wall_clock64();
@@ -530,10 +556,19 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const float* __restric
       long long e = i, off = rg.off[0];
 #pragma unroll
       for (int k = 0; k < DW_MAX - 1; k++) if (k + 1 < rg.n && e >= rg.count[k]) { e -= rg.count[k]; off = rg.off[k + 1]; } else break;
-      float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      for (int sl = 0; sl < kslices; sl++) {
-        const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)sl * ws_stride + off + e);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      // all slices' pieces first, then the sum in slice order: as a loop of load -> add the launch was a chain of kslices exposed
+      // memory round trips per thread (9.6 us whether it folded 16 slices or 8)
+      constexpr int KMAX = 16;
+      float4 v[KMAX];
+      const float* src = ws + off + e;
+#pragma unroll
+      for (int sl = 0; sl < KMAX; sl++) v[sl] = sl < kslices ? *reinterpret_cast<const float4*>(src + (size_t)sl * ws_stride) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      float4 s = v[0];
+#pragma unroll
+      for (int sl = 1; sl < KMAX; sl++) if (sl < kslices) { s.x += v[sl].x; s.y += v[sl].y; s.z += v[sl].z; s.w += v[sl].w; }
+      for (int sl = KMAX; sl < kslices; sl++) {     // (more slices than the batch holds: the tail one by one)
+        const float4 t = *reinterpret_cast<const float4*>(src + (size_t)sl * ws_stride);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
       *reinterpret_cast<float4*>(out + off + e) = s;
       sq += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
@@ -548,8 +583,17 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const float* __restric
     const int c = (fb - fa.blk0[f]) * 16 + tx;
     const float* partial = fa.partial[f];
     float s = 0.0f;
-    if (c < w)
-      for (int bk = ty; bk < nblk; bk += 16) s += partial[(size_t)bk * w + c];
+    if (c < w) {     // (eight loads in flight, summed in the same ascending order as one by one)
+      int bk = ty;
+      for (; bk + 16 * 7 < nblk; bk += 16 * 8) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v8[u] = partial[(size_t)(bk + 16 * u) * w + c];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v8[u];
+      }
+      for (; bk < nblk; bk += 16) s += partial[(size_t)bk * w + c];
+    }
     sh[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < w) {
@@ -696,9 +740,9 @@ extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev
   for (int l = 0; l < DW_MAX; l++) {
     DwLayer& L = a.L[l];
     if (l < nlayers) {
-      if (!dz_dev[l] || !h_dev[l] || n_out[l] <= 0 || n_in[l] <= 0 || nrows[l] <= 0 || (nrows[l] & 7) != 0 || nrows[l] / 8 < kslices || out_off[l] < 0 || out_off[l] + (long long)n_out[l] * n_in[l] > ws_stride ||
+      if (!dz_dev[l] || !h_dev[l] || n_out[l] <= 0 || n_in[l] <= 0 || nrows[l] <= 0 || (nrows[l] & 7) != 0 || nrows[l] / 8 < 2 * kslices || out_off[l] < 0 || out_off[l] + (long long)n_out[l] * n_in[l] > ws_stride ||
           (out_off[l] & 3) != 0 || (((long long)n_out[l] * n_in[l]) & 3) != 0 || ((((uintptr_t)dz_dev[l]) | ((uintptr_t)h_dev[l])) & 15) != 0)
-        return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad layer (rows a multiple of 8 and >= 8 * kslices, offset and element count multiples of 4, "
+        return odk_fail_(ODK_ERR_INVALID, "odk_dw_gemm: bad layer (rows a multiple of 8 and >= 16 * kslices, offset and element count multiples of 4, "
                                           "16-byte aligned operands)");
       L.dz = dz_dev[l]; L.h = h_dev[l]; L.n_out = n_out[l]; L.n_in = n_in[l]; L.out_off = out_off[l]; L.ngroups = nrows[l] / 8;
       L.tj = (n_in[l] + 32 * DW_MJ - 1) / (32 * DW_MJ); L.tile0 = a.ntiles;
@@ -729,7 +773,7 @@ extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev
     std::stable_sort(items.begin(), items.end(), [](const std::pair<long long, int>& x, const std::pair<long long, int>& y) { return x.first > y.first; });
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    a.nslots = std::max(1, std::min(std::min(DW_SLOTS, nitems), cus / 8 * 4));      // wave slots = SIMDs of one XCD (MI355X: 32 CUs x 4)
+    a.nslots = std::max(1, std::min(std::min(DW_SLOTS, nitems), cus / 8 * 4 / DW_WAVES));      // workgroup slots of one XCD = its SIMDs / 2 (MI355X: 32 CUs x 4 / 2)
     long long load[DW_SLOTS] = {0}; int cnt[DW_SLOTS] = {0};
     for (int sidx = 0; sidx < DW_SLOTS; sidx++) for (int k = 0; k < DW_SLOT_ITEMS; k++) a.item[sidx][k] = 0xFFFF;
     for (const auto& itw : items) {
@@ -740,10 +784,11 @@ extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  // 40 KB of (unused) LDS per single-wave workgroup: at most four of them per CU, i.e. one per SIMD when the XCD's slots are all taken
+  // 80 KB of LDS per two-wave workgroup (32 KB used by the fold): at most two of them per CU, i.e. one wave per SIMD when the XCD's
+  // slots are all taken
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dw_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024); attr = true; }
-  hipLaunchKernelGGL(dw_gemm_kernel, dim3(a.nslots * 8), dim3(64), 40 * 1024, st, a);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)dw_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }
+  hipLaunchKernelGGL(dw_gemm_kernel, dim3(a.nslots * 8), dim3(64 * DW_WAVES), 80 * 1024, st, a);
   long long total = 0;
   for (int l = 0; l < nlayers; l++) total += rg.count[l];
   int blocks = (int)((total / 4 + 255) / 256);

@@ -489,7 +489,7 @@ __device__ float block_sum(float v, float* sh) {
 // places in the packed copies
 __global__ void adam_packed_kernel(float* __restrict__ p, float* __restrict__ pf, float* __restrict__ pb, const float* __restrict__ g, float* __restrict__ m,
                                    float* __restrict__ v, float* __restrict__ acc, int nblocks, int64_t n, float lr, float b1, float b2, float eps,
-                                   float max_norm, WeightTable t) {
+                                   float max_norm, WeightTable t_) {
   __shared__ float sh[16];
   float sq = 0.0f;
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x) sq += acc[2 + i];
@@ -498,13 +498,97 @@ __global__ void adam_packed_kernel(float* __restrict__ p, float* __restrict__ pf
   const float norm = sqrtf(sq), tt = acc[1];
   const float clip = (max_norm > 0.0f && !(norm < max_norm)) ? max_norm / norm : 1.0f;
   const float c1 = 1.0f / (1.0f - powf(b1, tt)), c2 = 1.0f / (1.0f - powf(b2, tt));
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  // four consecutive parameters per thread as 16-byte pieces (one trip for the reference networks: 493 469 parameters on
+  // 482 x 256 threads); the tail element by element
+  const int64_t n4 = n >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const float4 g4 = reinterpret_cast<const float4*>(g)[q], m4 = reinterpret_cast<const float4*>(m)[q], v4 = reinterpret_cast<const float4*>(v)[q],
+                 p4 = reinterpret_cast<const float4*>(p)[q];
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+    float mo[4], vo[4], po[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const float gi = gg[t] * clip;
+      mo[t] = b1 * mm[t] + (1.0f - b1) * gi; vo[t] = b2 * vv[t] + (1.0f - b2) * gi * gi;
+      po[t] = pp[t] - lr * (mo[t] * c1) / (sqrtf(vo[t] * c2) + eps);
+    }
+    reinterpret_cast<float4*>(m)[q] = make_float4(mo[0], mo[1], mo[2], mo[3]);
+    reinterpret_cast<float4*>(v)[q] = make_float4(vo[0], vo[1], vo[2], vo[3]);
+    reinterpret_cast<float4*>(p)[q] = make_float4(po[0], po[1], po[2], po[3]);
+#pragma unroll
+    for (int t = 0; t < 4; t++) packed_store(t_, (int)(4 * q + t), po[t], pf, pb);
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * clip;
     const float mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
     const float pi = p[i] - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
     p[i] = pi;
-    packed_store(t, (int)i, pi, pf, pb);
+    packed_store(t_, (int)i, pi, pf, pb);
+  }
+}
+// The same update with the weight matrices walked in TILES of 16 output rows x 64 input columns, so that every global access is a run
+// of >= 256 bytes: the torch-layout streams (p, g, m, v) row by row, then -- through a 16 x 64 tile of the new weights in LDS -- the
+// forward-packed copy ([in / 4][out][4]: 16 consecutive outputs of one input quad = 256 bytes) and the backward-packed copy
+// ([out / 4][in][4]: 64 consecutive inputs of one output quad = 1 KB).  Element by element (adam_packed_kernel) a wave's packed
+// stores went to 64 different cache lines, 16 bytes each: 8 such instructions per 256 parameters made the launch twice as long as
+// its 18 MB of traffic.  Blocks past the tiles take the parameters outside the weight matrices (the biases) linearly.
+struct AdamTiles { int tile0[9], tj[8], ntiles, ngap; long long gap0[9], gapn[9]; };
+__global__ void __launch_bounds__(256) adam_tiled_kernel(float* __restrict__ p, float* __restrict__ pf, float* __restrict__ pb, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, float* __restrict__ acc, int nblocks, float lr, float b1,
+                                                         float b2, float eps, float max_norm, WeightTable t_, AdamTiles at) {
+  __shared__ float sh[16];
+  __shared__ float tile[16][65];
+  float sq = 0.0f;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) sq += acc[2 + i];
+  sq = block_sum(sq, sh);
+  if (blockIdx.x == 0 && threadIdx.x == 0) acc[0] = sq;
+  const float norm = sqrtf(sq), tt = acc[1];
+  const float clip = (max_norm > 0.0f && !(norm < max_norm)) ? max_norm / norm : 1.0f;
+  const float c1 = 1.0f / (1.0f - powf(b1, tt)), c2 = 1.0f / (1.0f - powf(b2, tt));
+  auto update = [&](long long i) -> float {
+    const float gi = g[i] * clip;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float pi = p[i] - lr * (mi * c1) / (sqrtf(vi * c2) + eps);
+    p[i] = pi;
+    return pi;
+  };
+  const int b = blockIdx.x;
+  if (b >= at.ntiles) {     // outside the weight matrices
+    const int gb = b - at.ntiles, ngb = gridDim.x - at.ntiles;
+    for (int k = 0; k < at.ngap; k++)
+      for (long long e = (long long)gb * blockDim.x + threadIdx.x; e < at.gapn[k]; e += (long long)ngb * blockDim.x) (void)update(at.gap0[k] + e);
+    return;
+  }
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < 8; q++) if (q < t_.n && b >= at.tile0[q]) k = q;
+  const int tloc = b - at.tile0[k], tjn = at.tj[k];
+  const int o0 = (tloc / tjn) * 16, in0 = (tloc % tjn) * 64;
+  const int rows = t_.rows[k], cols = t_.cols[k];
+  const long long off = t_.off[k];
+  {   // torch layout: lane = input column, four output rows per pass
+    const int col = threadIdx.x & 63, rr = threadIdx.x >> 6;
+    const bool cin = in0 + col < cols;
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      const int r = rr + 4 * pass, o = o0 + r;
+      float pi = 0.0f;
+      if (cin && o < rows) pi = update(off + (long long)o * cols + in0 + col);
+      tile[r][col] = pi;      // zeros outside the matrix: the packed copies' padding is zero
+    }
+  }
+  __syncthreads();
+  {   // forward-packed copy: [in / 4][rows][4]; thread = (input quad iq, output o): 16 consecutive outputs = 256 bytes
+    const int iq = threadIdx.x >> 4, o = threadIdx.x & 15;
+    if (in0 + 4 * iq < cols && o0 + o < rows)
+      *reinterpret_cast<f32x4*>(pf + t_.fwd[k] + ((long long)((in0 >> 2) + iq) * rows + o0 + o) * 4) = f32x4{tile[o][4 * iq], tile[o][4 * iq + 1], tile[o][4 * iq + 2], tile[o][4 * iq + 3]};
+  }
+  if (t_.bwd[k] >= 0) {   // backward-packed copy: [rows / 4][cols][4]; thread = (output quad oq, input in): 64 consecutive inputs = 1 KB
+    const int oq = threadIdx.x >> 6, in = threadIdx.x & 63;
+    if (in0 + in < cols && o0 + 4 * oq < rows)
+      *reinterpret_cast<f32x4*>(pb + t_.bwd[k] + ((long long)((o0 >> 2) + oq) * cols + in0 + in) * 4) = f32x4{tile[4 * oq][in], tile[4 * oq + 1][in], tile[4 * oq + 2][in], tile[4 * oq + 3][in]};
   }
 }
 __global__ void sqnorm_p_kernel(const float* __restrict__ g, float* __restrict__ acc, int64_t n) {
@@ -658,8 +742,36 @@ extern "C" int odk_adam_clip_packed(float* params_dev, const float* grads_dev, f
   if (blocks > ODK_ADAM_MAX_PARTIALS) blocks = ODK_ADAM_MAX_PARTIALS;
   if (norm_blocks < 0 || norm_blocks > ODK_ADAM_MAX_PARTIALS) return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip_packed: norm_blocks out of range");
   if (norm_blocks == 0) hipLaunchKernelGGL(sqnorm_p_kernel, dim3(blocks), dim3(threads), 0, st, grads_dev, acc_dev, (int64_t)n);
-  hipLaunchKernelGGL(adam_packed_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, fwd_packed_dev, bwd_packed_dev, grads_dev, m_dev, v_dev, acc_dev,
-                     norm_blocks > 0 ? norm_blocks : blocks, (int64_t)n, lr, b1, b2, eps, max_grad_norm, t);
+  // tiles of the weight matrices + the gaps between them (biases)
+  AdamTiles at;
+  memset(&at, 0, sizeof(at));
+  bool tiled = t.n > 0 && !getenv("ODK_ADAM_LINEAR");
+  long long covered = 0;
+  for (int k = 0; k < t.n && tiled; k++) {
+    at.tile0[k] = at.ntiles; at.tj[k] = (t.cols[k] + 63) / 64;
+    at.ntiles += ((t.rows[k] + 15) / 16) * at.tj[k];
+    if ((t.fwd[k] & 3) || (t.bwd[k] >= 0 && (t.bwd[k] & 3)) || t.off[k] < covered) tiled = false;      // (16-byte packed pieces; weights in ascending, disjoint order)
+    if (tiled) {
+      if (t.off[k] > covered) { at.gap0[at.ngap] = covered; at.gapn[at.ngap] = t.off[k] - covered; at.ngap++; }
+      covered = (long long)t.off[k] + (long long)t.rows[k] * t.cols[k];
+    }
+  }
+  if (tiled) {
+    for (int k = t.n; k < 9; k++) at.tile0[k] = 1 << 30;
+    if (covered < n) { at.gap0[at.ngap] = covered; at.gapn[at.ngap] = n - covered; at.ngap++; }
+    long long gap_total = 0;
+    for (int k = 0; k < at.ngap; k++) gap_total += at.gapn[k];
+    int gap_blocks = (int)((gap_total + 1023) / 1024);
+    if (gap_blocks < 1) gap_blocks = 1;
+    if (gap_blocks > 64) gap_blocks = 64;
+    if ((((uintptr_t)fwd_packed_dev) | ((uintptr_t)bwd_packed_dev)) & 15) tiled = false;
+    if (tiled)
+      hipLaunchKernelGGL(adam_tiled_kernel, dim3(at.ntiles + gap_blocks), dim3(256), 0, st, params_dev, fwd_packed_dev, bwd_packed_dev, grads_dev, m_dev, v_dev,
+                         acc_dev, norm_blocks > 0 ? norm_blocks : blocks, lr, b1, b2, eps, max_grad_norm, t, at);
+  }
+  if (!tiled)
+    hipLaunchKernelGGL(adam_packed_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, fwd_packed_dev, bwd_packed_dev, grads_dev, m_dev, v_dev, acc_dev,
+                       norm_blocks > 0 ? norm_blocks : blocks, (int64_t)n, lr, b1, b2, eps, max_grad_norm, t);
   return check_launch("odk_adam_clip_packed: launch failed");
 }
 

@@ -342,7 +342,7 @@ class DwGemm:
     `acc`: the Adam scratch -- the finishing launch then also leaves the partial sums of the squared gradient norm in acc[2:] and
     advances the step count acc[1]; `norm_blocks` is what `adam_clip_packed` wants to hear about it."""
 
-    def __init__(self, layers, flat_out, workspace, kslices: int = 16, bias=(), acc=None):
+    def __init__(self, layers, flat_out, workspace, kslices: int = 8, bias=(), acc=None):
         k = len(layers)
         _f32c(flat_out, workspace, *[t for dz, h, _, _, _ in layers for t in (dz, h)])
         if k > 8 or kslices % 8 != 0:
@@ -350,8 +350,8 @@ class DwGemm:
         rows = []
         for dz, h, no, ni, o in layers:
             np_ = dz.numel() // int(no)
-            if dz.numel() != np_ * no or h.numel() != np_ * ni or np_ % 8 or np_ // 8 < kslices:
-                raise OdkError("DwGemm: dz / h must be quad-row buffers of the same row count (a multiple of 8, >= 8 * kslices)")
+            if dz.numel() != np_ * no or h.numel() != np_ * ni or np_ % 8 or np_ // 8 < 2 * kslices:
+                raise OdkError("DwGemm: dz / h must be quad-row buffers of the same row count (a multiple of 8, >= 16 * kslices)")
             if int(o) % 4 or (int(no) * int(ni)) % 4:
                 raise OdkError("DwGemm: offsets and element counts must be multiples of 4")
             rows.append(np_)

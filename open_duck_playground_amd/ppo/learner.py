@@ -281,7 +281,7 @@ class FlatLearner:
         # pieces along the reduction index) that the Adam launch keeps current
         self.fused = None
         if fused:
-            kslices = 16
+            kslices = 8       # workspace slices of the weight-gradient launch (each folded from two waves inside the kernel)
             self.dw_ws = torch.empty(kslices * engine.DwGemm.workspace_stride(n_par), device=dev)   # split-K partial weight gradients
             nets = (self.policy, self.value)
             self.wtable = engine.WeightTable([(o, w.shape[0], w.shape[1], l > 0) for f in nets for l, (o, w) in enumerate(zip(f.goff, f.W))])

@@ -22,7 +22,7 @@ for n, n_in, n_out in specs:
         dz = torch.randn(n // 4, widths[l + 1], 4, device="cuda", generator=g) * 1e-2
         h = torch.randn(n // 4, widths[l], 4, device="cuda", generator=g)
         layers.append((dz, h, widths[l + 1], widths[l], entries[k][0])); k += 1
-KS = int(os.environ.get("ODK_DW_KS", "16"))
+KS = int(os.environ.get("ODK_DW_KS", "8"))
 ws = torch.empty(KS * engine.DwGemm.workspace_stride(tot), device="cuda")
 dw = engine.DwGemm(layers, flat_g, ws, KS)
 for _ in range(20): dw()

@@ -34,7 +34,7 @@ for n, n_in, n_out in specs:
 train = engine.FusedMLP(nets)
 infer = engine.FusedMLP([dict(x=d["x"], wf=d["wf"], b=d["b"], out=d["out"]) for d in nets])
 one = [engine.FusedMLP([d]) for d in nets]
-KS = int(os.environ.get("ODK_DW_KS", "16"))   # row slices of the weight-gradient launch
+KS = int(os.environ.get("ODK_DW_KS", "8"))   # row slices of the weight-gradient launch
 ws = torch.empty(KS * engine.DwGemm.workspace_stride(tot), device="cuda")
 dw = engine.DwGemm(dw_layers, flat_g, ws, KS)
 
