@@ -120,7 +120,40 @@ class State:
     reward: Any                     # [N]
     done: Any                       # [N]
     metrics: Dict[str, Any]         # reward/* cost/* swing_peak, each [N]
-    info: Dict[str, Any] = field(default_factory=dict)   # {"truncation": [N]}; the rest of info stays device-side
+    info: Dict[str, Any] = field(default_factory=dict)   # {"truncation": [N]} + every other key of the reference's info, fetched on first use (_Info)
+
+
+class _Info(dict):
+    """`State.info` (reference joystick.py:278-302 + the wrappers' additions): "truncation" is the engine's output tensor; every
+    other key of the reference's dict -- rng, step, command, last_act, last_last_act, last_last_last_act, motor_targets,
+    feet_air_time, last_contact, swing_peak, push, push_step, push_interval_steps, action_history, imu_history, imitation_i, and
+    steps / episode_done / episode_metrics/* -- lives in the engine's per-env record on the device and is copied out ON FIRST USE
+    (one synchronous read of the records per State, `Batch.info()` -> `odk_record_field`): reading `info["command"]` works like
+    in the reference, it is just not free.  Values are tensors on the env's device, [N, ...]; `last_contact` is bool [N, 2].
+    Writing goes through `Batch.info()` / `set_records` (the reference's functional update has no counterpart on a stateful engine)."""
+
+    def __init__(self, batch, truncation):
+        super().__init__(truncation=truncation)
+        self._batch = batch
+
+    def _fetch(self):
+        import torch
+        I = self._batch.info()
+        dev = self["truncation"].device
+        for k in self._batch.INFO_FIELDS:
+            if k == "truncation":
+                continue
+            v = self._batch.last_contact_bool(I) if k == "last_contact" else I[k]
+            dict.__setitem__(self, k, torch.from_numpy(np.ascontiguousarray(v)).to(dev))
+
+    def __missing__(self, key):
+        if key in self._batch.INFO_FIELDS:
+            self._fetch()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._batch.INFO_FIELDS
 
 
 class Joystick:
@@ -183,7 +216,7 @@ class Joystick:
         b = self._batch
         metrics = {name: b.metrics[:, i] for i, name in enumerate(self.METRIC_NAMES) if name is not None}
         return State(data=b, obs={"state": b.obs, "privileged_state": b.priv}, reward=b.reward, done=b.done, metrics=metrics,
-                     info={"truncation": b.truncation})
+                     info=_Info(b, b.truncation))
 
     def reset(self, rng: int) -> State:
         """reference joystick.py:206: `rng` is an integer seed; env e draws from key(seed, env_id_offset + e)."""

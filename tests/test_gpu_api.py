@@ -494,3 +494,25 @@ def test_info_accessor_names_the_reference_keys(oracle_mod):
     with pytest.raises(engine.OdkError, match="unknown record field"):
         b.record_field("no_such_key")
     b.close()
+
+
+def test_state_info_reads_like_the_reference():
+    """`State.info` of the Python env (reference joystick.py:278-302,321): info["command"], info["last_act"], info["step"] ... by the
+    reference's names, fetched from the device record on first use; "truncation" stays the engine's output tensor."""
+    import torch
+    from open_duck_playground_amd import joystick
+    env = joystick.Joystick(task="flat_terrain", num_envs=8)
+    st = env.reset(3)
+    assert st.info["truncation"] is env.batch.truncation
+    for key in ("rng", "step", "command", "last_act", "last_last_act", "last_last_last_act", "motor_targets", "feet_air_time", "last_contact", "swing_peak",
+                "push", "push_step", "push_interval_steps", "action_history", "imu_history", "imitation_i"):
+        assert key in st.info
+    assert tuple(st.info["command"].shape) == (8, 7) and st.info["command"].is_cuda
+    assert st.info["last_contact"].dtype == torch.bool and tuple(st.info["last_contact"].shape) == (8, 2)
+    assert int(st.info["step"].max()) == 0 and 250 <= int(st.info["push_interval_steps"].min()) and int(st.info["push_interval_steps"].max()) <= 500
+    act = torch.full((8, 14), 0.25, device="cuda")
+    st2 = env.step(st, act)
+    assert torch.allclose(st2.info["last_act"][st2.done == 0], act[st2.done == 0]) and int(st2.info["step"][st2.done == 0].min()) == 1
+    np.testing.assert_array_equal(st2.info["command"].cpu().numpy(), env.batch.info()["command"])
+    with pytest.raises(KeyError):
+        st2.info["no_such_key"]
