@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-to-end training evidence (the reference's command lines through this build's runner): tools/gpu_train_runs.sh TAG
-#   -> gpurun_out/train_TAG/{flat,backlash,rough,standing}/metrics.jsonl + wall times (checkpoints / ONNX files are deleted: only the metrics travel back)
+#   -> gpurun_out/train_TAG/{flat,backlash,rough,standing,rough_up_normals}/metrics.jsonl + wall times (checkpoints / ONNX files are deleted: only the metrics travel back)
 set -u
 TAG=${1:-x}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
@@ -19,4 +19,5 @@ run flat --task flat_terrain --num_timesteps 150000000
 run backlash --task flat_terrain_backlash --num_timesteps 40000000
 run rough --task rough_terrain_backlash --num_timesteps 40000000
 run standing --env standing --task flat_terrain --num_timesteps 40000000
+run rough_up_normals --task rough_terrain_backlash --num_timesteps 150000000 --hfield_up_normals_only
 cat $OUT/wall.txt
