@@ -91,6 +91,18 @@ template <int NSLOT> __device__ __forceinline__ void edge_regs_load(EdgeRegs<NSL
   }
 }
 
+// the same from the row lane's packed record (DevModel::foot_lane_rec: one 32-byte load instead of five dependent table rows)
+template <int NSLOT> __device__ __forceinline__ void edge_regs_from_rec(EdgeRegs<NSLOT>& R, const Cvx& B, const int* rec) {
+#pragma unroll
+  for (int s = 0; s < NSLOT; s++) {
+    const unsigned e = (unsigned)rec[s];
+    R.on[s] = !(e >> 31);
+    const int fa = e & 255u, fb = (e >> 8) & 255u;
+    for (int k = 0; k < 3; k++) { R.c[s][k] = -B.N[3 * fa + k]; R.d[s][k] = -B.N[3 * fb + k]; }
+    R.vv[s] = (int)((e >> 16) & 0x7FFFu);   // va | vb << 8
+    cross3(R.dxc[s], R.d[s], R.c[s]);
+  }
+}
 // Largest separation over the edge pairs (edge i of A, edge jb of B) whose Gauss-map arcs cross (they span a face of the Minkowski
 // difference); ties to the lowest (i, jb).  pair = i << 8 | jb (0x7FFFFFFF: none), axis oriented away from A's interior.
 // Edges closer to parallel than 1e-4 (sine) give no axis.
@@ -165,50 +177,39 @@ __device__ __forceinline__ void manifold4_row(const float* p, bool cand, bool ma
 // mjx _clip_edge_to_planes: the edge (p0, p1) against the side planes of polygon Q (nq vertices at QP, normal qn); the `which`-th
 // of the two clipped points, returns the mask
 __device__ __forceinline__ bool clip_edge_row(const float* p0, const float* p1, const float* QP, int nq, const float* qn, int which, float* out) {
-  float d01[3], best0 = -3.0e38f, best1 = -3.0e38f, n0[3], n1[3];
+  // Every point the routine can return lies on the edge: p0 + t (p1 - p0).  What is kept per plane is the parameter t, not the
+  // point: "most along the edge" is t |d|^2 (from p0) and (1 - t) |d|^2 (from p1) without forming the candidate, the second end's
+  // signed distance to a plane is the first end's plus pn . d, and the two clipped points have crossed when t0 > t1.
+  float d01[3];
   sub3(d01, p1, p0);
-  ld3(n0, p0); ld3(n1, p1);
+  const float dd = dot3(d01, d01);
+  float best0 = -3.0e38f, best1 = -3.0e38f, tb0 = 0.0f, tb1 = 1.0f;
   bool both = false;
   for (int k = 0; k < nq; k++) {
     const float* pa = QP + 3 * (k == 0 ? nq - 1 : k - 1); const float* pb = QP + 3 * k;
-    float e[3], pn[3], t0[3], t1[3];
+    float e[3], pn[3], t0[3];
     sub3(e, pb, pa);
     cross3(pn, e, qn);
-    sub3(t0, p0, pa); sub3(t1, p1, pa);
-    const bool f0 = dot3(t0, pn) > 1e-6f, f1 = dot3(t1, pn) > 1e-6f;
+    sub3(t0, p0, pa);
+    const float a0 = dot3(t0, pn), denom = dot3(pn, d01), a1 = a0 + denom;
+    const bool f0 = a0 > 1e-6f, f1 = a1 > 1e-6f;
     both = both || (f0 && f1);
-    // _closest_segment_point_plane
-    const float denom = dot3(pn, d01);
-    float t = (dot3(pa, pn) - dot3(pn, p0)) / (denom + (denom == 0.0f ? 1e-6f : 0.0f));
+    // _closest_segment_point_plane (v_rcp_f32, 1 ulp: an IEEE quotient is ten instructions)
+    float t = -a0 * __builtin_amdgcn_rcpf(denom + (denom == 0.0f ? 1e-6f : 0.0f));
     t = fminf(fmaxf(t, 0.0f), 1.0f);
-    const float cand[3] = {p0[0] + t * d01[0], p0[1] + t * d01[1], p0[2] + t * d01[2]};
-    {   // most along p0 -> p1 among {clipped point where p0 is in front, else p0}
-      const float q[3] = {f0 ? cand[0] : p0[0], f0 ? cand[1] : p0[1], f0 ? cand[2] : p0[2]};
-      float tq[3];
-      sub3(tq, q, p0);
-      const float s = dot3(tq, d01);
-      if (s > best0) { best0 = s; ld3(n0, q); }
-    }
-    {   // most along p1 -> p0
-      const float q[3] = {f1 ? cand[0] : p1[0], f1 ? cand[1] : p1[1], f1 ? cand[2] : p1[2]};
-      float tq[3];
-      sub3(tq, q, p1);
-      const float s = -dot3(tq, d01);
-      if (s > best1) { best1 = s; ld3(n1, q); }
-    }
+    const float s0 = f0 ? t * dd : 0.0f, s1 = f1 ? (1.0f - t) * dd : 0.0f;   // {clipped point where the end is in front, else the end}
+    if (s0 > best0) { best0 = s0; tb0 = f0 ? t : 0.0f; }
+    if (s1 > best1) { best1 = s1; tb1 = f1 ? t : 1.0f; }
   }
-  bool mask = !both;
-  const float* o0 = mask ? n0 : p0; const float* o1 = mask ? n1 : p1;
-  float dd[3];
-  sub3(dd, o0, o1);
-  if (-dot3(d01, dd) < 0.0f) mask = false;   // (p0 - p1) . (o0 - o1) < 0: the clipped points crossed
-  ld3(out, which ? o1 : o0);
+  const bool mask = !both && !(tb0 > tb1);
+  const float tt = !both ? (which ? tb1 : tb0) : (which ? 1.0f : 0.0f);   // (crossed points are returned as they are, masked out)
+  for (int k = 0; k < 3; k++) out[k] = tt == 1.0f ? p1[k] : p0[k] + tt * d01[k];
   return mask;
 }
 
 // Scratch of one row (floats): RP | IP = reference / incident polygon of the current face contact ([4][3] each), NEW = this pair's
 // four contacts.  A contact = dist, pos[3], normal[3], (candidate index: the caller's) -- 8 floats.
-struct RowScratch { float* RP; float* IP; float* NEW; float* PW; float* VV; };   // PW [16] / VV [48]: the row's pass words and hull-edge vertex pairs (height field only)
+struct RowScratch { float* RP; float* IP; float* NEW; float* PW; float* VV; };   // PW [16] | VV [48], contiguous: the row's list of passing edge pairs (height field only)
 
 // mjx _create_contact_manifold on the polygons in S.RP (rcnt vertices, normal n_ref) / S.IP (icnt, n_inc): lane j = candidate j of
 // _clip -- (incident edge e clipped by the reference side planes) x 2, then (reference edge, projected on the incident plane along
@@ -227,8 +228,8 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
     float a[3], b[3];
     ld3(a, src + 3 * (er == 0 ? cntp - 1 : er - 1)); ld3(b, src + 3 * (er < cntp ? er : 0));
     if (!subj) {   // reference edge: projected on the incident plane along the reference normal
-      const float d = dot3(S.IP, n_inc), den = dot3(n_ref, n_inc), dsafe = den + (den == 0.0f ? 1e-6f : 0.0f);
-      const float ta = (d - dot3(a, n_inc)) / dsafe, tb = (d - dot3(b, n_inc)) / dsafe;
+      const float d = dot3(S.IP, n_inc), den = dot3(n_ref, n_inc), dinv = __builtin_amdgcn_rcpf(den + (den == 0.0f ? 1e-6f : 0.0f));
+      const float ta = (d - dot3(a, n_inc)) * dinv, tb = (d - dot3(b, n_inc)) * dinv;
       for (int k = 0; k < 3; k++) { a[k] += ta * n_ref[k]; b[k] += tb * n_ref[k]; }
     }
     const float qn[3] = {subj ? n_ref[0] : n_inc[0], subj ? n_ref[1] : n_inc[1], subj ? n_ref[2] : n_inc[2]};
@@ -259,11 +260,12 @@ __device__ __forceinline__ void edge_contact_row(const float* p1, const float* q
   float d1[3], d2[3], r[3];
   sub3(d1, q1, p1); sub3(d2, q2, p2); sub3(r, p1, p2);
   const float a = dot3(d1, d1), ee = dot3(d2, d2), f = dot3(d2, r), c = dot3(d1, r), b = dot3(d1, d2), den = a * ee - b * b;
-  float s = den > 1e-30f ? (b * f - c * ee) / den : 0.0f;
+  const float ainv = __builtin_amdgcn_rcpf(a > 1e-30f ? a : 1.0f), einv = __builtin_amdgcn_rcpf(ee > 1e-30f ? ee : 1.0f);
+  float s = den > 1e-30f ? (b * f - c * ee) * __builtin_amdgcn_rcpf(den) : 0.0f;
   s = fminf(fmaxf(s, 0.0f), 1.0f);
-  float t = (b * s + f) / (ee > 1e-30f ? ee : 1.0f);
-  if (t < 0.0f) { t = 0.0f; s = fminf(fmaxf(-c / (a > 1e-30f ? a : 1.0f), 0.0f), 1.0f); }
-  else if (t > 1.0f) { t = 1.0f; s = fminf(fmaxf((b - c) / (a > 1e-30f ? a : 1.0f), 0.0f), 1.0f); }
+  float t = (b * s + f) * einv;
+  if (t < 0.0f) { t = 0.0f; s = fminf(fmaxf(-c * ainv, 0.0f), 1.0f); }
+  else if (t > 1.0f) { t = 1.0f; s = fminf(fmaxf((b - c) * ainv, 0.0f), 1.0f); }
   if (act && j < 4) {
     float* o = S.NEW + 8 * j;
     o[0] = j == 0 ? sep : 1.0f;
@@ -338,14 +340,13 @@ __device__ __forceinline__ void prism_norm(const Prism& P, int f, float* o) {
 
 // the faces of the second polytope this lane owns (face j + 16 s): normal, plane offset n . v0, polygon packed 3 | 5 x 4 bits
 template <int NFS> struct FaceRegs { float d[NFS]; int poly[NFS]; bool on[NFS]; };   // (the normals are re-read from LDS per pair: registers are the scarce resource)
-template <int NFS> __device__ __forceinline__ void face_regs_load(FaceRegs<NFS>& R, const Cvx& B, int j) {
+template <int NFS> __device__ __forceinline__ void face_regs_from_rec(FaceRegs<NFS>& R, const Cvx& B, const int* rec, int j) {
 #pragma unroll
   for (int s = 0; s < NFS; s++) {
-    const int f = j + 16 * s;
-    R.on[s] = f < B.nf;
-    const int* pl = B.poly + 5 * (R.on[s] ? f : 0);
-    R.d[s] = dot3(B.V + 3 * pl[1], B.N + 3 * (R.on[s] ? f : 0));
-    R.poly[s] = pl[0] | (pl[1] << 3) | (pl[2] << 8) | (pl[3] << 13) | (pl[4] << 18);
+    const unsigned pk = (unsigned)rec[3 + s];
+    R.on[s] = !(pk >> 31);
+    R.d[s] = dot3(B.V + 3 * ((pk >> 3) & 31u), B.N + 3 * (R.on[s] ? j + 16 * s : 0));
+    R.poly[s] = (int)(pk & 0x7FFFFFu);
   }
 }
 
@@ -353,13 +354,15 @@ template <int NFS> __device__ __forceinline__ void face_regs_load(FaceRegs<NFS>&
 // faces / edges of this lane in FB / RB); PV: the prism's vertices in LDS for the polygon fetch
 template <int NFS, int NSLOT>
 __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, const float* PV, const Cvx& B, const FaceRegs<NFS>& FB, const EdgeRegs<NSLOT>& RB,
-                                              float sep_a, int face_a, const RowScratch& S, int j, bool act
+                                              float sep_a, int face_a, const RowScratch& S, int j, bool act, int knock   // knock: 0 outside the timing experiment (ODK_HF_KNOCK)
 #ifdef ODK_PROFILE
                                               , float* prof, long long& tp
 #endif
                                               ) {
 #ifdef ODK_PROFILE
 #define SAT_PROF(i) do { const long long _t = clock64(); if (prof) prof[i] += (float)(_t - tp); tp = _t; } while (0)
+#elif defined(ODK_MARK)
+#define SAT_PROF(i) asm volatile("; SAT_MARK " #i ::: "memory")
 #else
 #define SAT_PROF(i) do { } while (0)
 #endif
@@ -368,13 +371,16 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
   float fn[NFS][3];   // this lane's hull face normals (slot s = face j + 16 s; lanes without a second face read face 0's)
 #pragma unroll
   for (int s = 0; s < NFS; s++) ld3(fn[s], B.N + 3 * (FB.on[s] ? j + 16 * s : 0));
-  {
+  HF_REP(11) {
+    HF_TOUCH(fn[0][0]);
+    // (vertices 3..5 sit under 0..2 at z = -base: the x / y part of n . v is shared by a column, as in the cull pass)
     float best = -3.0e38f; int bi = 0x7FFFFFFF;
 #pragma unroll
     for (int s = 0; s < NFS; s++) {
-      float smin = 3.0e38f;
-#pragma unroll
-      for (int q = 0; q < 6; q++) { float v[3]; prism_vert(P, q, v); smin = fminf(smin, dot3(v, fn[s]) - FB.d[s]); }
+      const float h0 = fn[s][0] * P.x[0] + fn[s][1] * P.y[0], h1 = fn[s][0] * P.x[1] + fn[s][1] * P.y[1], h2 = fn[s][0] * P.x[2] + fn[s][1] * P.y[2];
+      const float top = fminf(fminf(h0 + fn[s][2] * P.z[0], h1 + fn[s][2] * P.z[1]), h2 + fn[s][2] * P.z[2]);
+      const float bot = fminf(fminf(h0, h1), h2) - fn[s][2] * P.base;
+      const float smin = fminf(top, bot) - FB.d[s];
       if (FB.on[s] && smin > best) { best = smin; bi = j + 16 * s; }
     }
     face_b = row_argmax(best, bi, sep_b);
@@ -383,73 +389,100 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
   // ---- edge query: the prism's nine edges (compile-time topology) against the hull edges of this lane.  The Gauss-map test of all
   // 27 pairs of a lane first (a pass bit each), then the few passing pairs in a short loop: taken inline, some lane of the wave
   // passes nearly every test, so every lane would walk through all 27 axis computations.
-  float sep_e, eax[3]; int pair;
+  float sep_e, eax[3]; int pair;   // pair: the winning list entry (prism edge << 22 | hull edge << 16 | its vertices va | vb << 8), 0x7FFFFFFF: none
   {
-    static_assert(NSLOT == 3, "pass bit = 3 i + slot");
+    static_assert(NSLOT == 3, "pass bit = 9 slot + i");
     unsigned pass = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-      float a[3], b[3], bxa[3];
-      prism_norm(P, PRISM_EDGE[i][2], a); prism_norm(P, PRISM_EDGE[i][3], b);
-      cross3(bxa, b, a);
+    if (!(knock & 8)) HF_REP(12) {
+      // The prism's face normals are T = nt, (0, 0, -1), S0 = (0, a0, 0), S1 = (ux, uy, 0), S2 = (b2, 0, 0): written out, the nine
+      // b x a and the projections lose their zero terms (the compiler may not drop x * 0), and the three vertical edges' b x a are
+      // positive multiples of z -- only signs enter the test, so their c . (b x a) is c.z itself.
+      float tx = P.nt[0]; HF_TOUCH(tx);
+      const float ty = P.nt[1], tz = P.nt[2], a0 = P.ns[0][1], ux = P.ns[1][0], uy = P.ns[1][1], b2 = P.ns[2][0];
+      const float e0x = a0 * tz, e0z = -a0 * tx;                                   // S0 x T
+      const float e1x = uy * tz, e1y = -ux * tz, e1z = ux * ty - uy * tx;          // S1 x T
+      const float e8y = tz * b2, e8z = -ty * b2;                                   // T x S2
+      constexpr int FA[9] = {0, 0, 1, 2, 2, 3, 3, 4, 4}, FBK[9] = {2, 3, 4, 4, 1, 2, 1, 3, 0};   // PRISM_EDGE[i][2], [3]
+      static_assert(PRISM_EDGE[0][2] == 0 && PRISM_EDGE[0][3] == 2 && PRISM_EDGE[4][3] == 1 && PRISM_EDGE[8][2] == 4 && PRISM_EDGE[8][3] == 0, "edge faces");
 #pragma unroll
       for (int s = 0; s < NSLOT; s++) {
-        const float cba = dot3(RB.c[s], bxa), dba = dot3(RB.d[s], bxa), adc = dot3(a, RB.dxc[s]), bdc = dot3(b, RB.dxc[s]);
-        const bool ok = RB.on[s] && cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f;
-        pass |= ok ? (1u << (3 * i + s)) : 0u;
+        const float* c = RB.c[s]; const float* d = RB.d[s]; const float* x = RB.dxc[s];
+        const float pr[5] = {tx * x[0] + ty * x[1] + tz * x[2], -x[2], a0 * x[1], ux * x[0] + uy * x[1], b2 * x[0]};   // face normal . (d x c)
+        const float cb[9] = {c[0] * e0x + c[2] * e0z, c[0] * e1x + c[1] * e1y + c[2] * e1z, c[1] * b2, c[2], c[0] * a0, c[2], c[0] * uy - c[1] * ux, c[2], c[1] * e8y + c[2] * e8z};
+        const float db[9] = {d[0] * e0x + d[2] * e0z, d[0] * e1x + d[1] * e1y + d[2] * e1z, d[1] * b2, d[2], d[0] * a0, d[2], d[0] * uy - d[1] * ux, d[2], d[1] * e8y + d[2] * e8z};
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          const float adc = pr[FA[i]], bdc = pr[FBK[i]];
+          const bool ok = RB.on[s] & (cb[i] * db[i] < 0.0f) & (adc * bdc < 0.0f) & (cb[i] * bdc > 0.0f);   // (no short circuit: selects, not branches)
+          pass |= ok ? (1u << (9 * s + i)) : 0u;
+        }
       }
     }
     SAT_PROF(2);
+    HF_REP(13) {
+    HF_TOUCH(pass);
+    HF_REP_SYNC();
     // The passing pairs of the ROW are shared out evenly: a lane's own count varies from 0 to a dozen, and worked off lane by lane
-    // the loop ran as long as the unluckiest lane of the wave (7 k of the pair's 19 k cycles).  Every lane publishes its pass bits,
-    // reads all sixteen words, and takes the (j + 16 t)-th passing pair of the row's concatenated list: its owner lane w, the
-    // owner's slot and the prism edge come out of the bit position; the hull edge's vertices from the row's copy (S.VV).
-    S.PW[j] = __uint_as_float(pass);
-    ODK_SYNC();
-    int incl[16];
-    {
-      int run = 0;
-#pragma unroll
-      for (int w = 0; w < 16; w++) { run += __popc(__float_as_uint(S.PW[w])); incl[w] = run; }
-    }
-    const int total = incl[15];
+    // the loop ran as long as the unluckiest lane of the wave.  Every lane PUSHES its passing pairs into the row's list at its
+    // place in the row's running count (prefix sum over the row by DPP): one word per pair -- prism edge << 22 | hull edge << 16 |
+    // the hull edge's two vertices -- so that lane j then works entries j, j + 16, ... with one LDS read each and no search.  The
+    // list holds 64 pairs (S.PW | S.VV); a longer one (rare) is worked off in windows of 64.
+    int incl = __popc(pass);
+    const int cnt = incl;
+    incl += (int)ODK_DPPU(incl, 0x111); incl += (int)ODK_DPPU(incl, 0x112); incl += (int)ODK_DPPU(incl, 0x114); incl += (int)ODK_DPPU(incl, 0x118);   // row_shr 1, 2, 4, 8
+    const int total = (knock & 16) ? 0 : __shfl(incl, ODK_ROWBASE | 15, 64);
+    float* PL = S.PW;
+#ifdef ODK_PROFILE
+    if (prof) prof[-6] += (float)total;   // (S_PROF2 + 2: passing edge pairs of the row, summed over the iterations)
+#endif
     float best = -3.0e38f, bax[3] = {0.0f, 0.0f, 1.0f};
     int bi = 0x7FFFFFFF;
-    for (int t = 0; __builtin_amdgcn_ballot_w64(16 * t < total) != 0; t++) {
-      const int g = j + 16 * t;
-      const bool has = g < total;
-      int w = 0, before = 0;
+    for (int wb = 0; __builtin_amdgcn_ballot_w64(wb < total) != 0; wb += 64) {
+      int pos = incl - cnt - wb;   // this lane's first place, relative to the window
 #pragma unroll
-      for (int k = 0; k < 15; k++) { const bool ge = g >= incl[k]; w += ge ? 1 : 0; before = ge ? incl[k] : before; }
-      unsigned word = has ? __float_as_uint(S.PW[w]) : 1u;
-      for (int r = has ? g - before : 0; r > 0; r--) word &= word - 1u;       // drop the r lowest passing pairs of that lane
-      const int kk = __ffs((int)word) - 1;
-      const int i = (kk * 11) >> 5, sl = kk - 3 * i;   // kk / 3 for kk < 27
-      // prism edge i: vertices from the packed table (va | vb << 3, 6 bits per edge), geometry from the LDS copy
-      const unsigned long long PKE = 0ull | (0ull | 1ull << 3) | ((1ull | 2ull << 3) << 6) | ((3ull | 5ull << 3) << 12) | ((0ull | 3ull << 3) << 18) |
-                                     ((3ull | 4ull << 3) << 24) | ((1ull | 4ull << 3) << 30) | ((4ull | 5ull << 3) << 36) | ((2ull | 5ull << 3) << 42) | ((0ull | 2ull << 3) << 48);
-      const int ve = (int)((PKE >> (6 * i)) & 63ull);
-      const int vv = __float_as_int(S.VV[3 * w + sl]);
-      float pa[3], qa[3], pb[3], qb[3], ea[3], eb[3], ta[3], ax[3], tt[3];
-      ld3(pa, PV + 3 * (ve & 7)); ld3(qa, PV + 3 * (ve >> 3)); ld3(pb, B.V + 3 * (vv & 255)); ld3(qb, B.V + 3 * (vv >> 8));
-      sub3(ea, qa, pa); sub3(eb, qb, pb); sub3(ta, pa, pc);
-      cross3(ax, ea, eb);
-      const float l2 = dot3(ax, ax);
-      if (has && l2 >= 1e-8f * dot3(ea, ea) * dot3(eb, eb) && l2 > 1e-30f) {   // edges closer to parallel than 1e-4 (sine) give no axis
-        const float inv = rsqrtf(l2);
-        ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
-        if (dot3(ax, ta) < 0.0f) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; }
-        sub3(tt, pb, pa);
-        const float sp = dot3(ax, tt);
-        const int id = (i << 8) | (w + 16 * sl);
-        if (sp > best || (sp == best && id < bi)) { best = sp; bi = id; bax[0] = ax[0]; bax[1] = ax[1]; bax[2] = ax[2]; }
+      for (int s = 0; s < NSLOT; s++) {
+        const unsigned base = (unsigned)RB.vv[s] | ((unsigned)(j + 16 * s) << 16);
+#pragma unroll 1
+        for (unsigned bits = (pass >> (9 * s)) & 0x1FFu; __builtin_amdgcn_ballot_w64(bits != 0u) != 0; ) {
+          const bool on = bits != 0u;   // (one predicated write per trip, everything else unconditional: 0 & (0 - 1) stays 0)
+          const int i = __ffs((int)bits) - 1;
+          if (on & ((unsigned)pos < 64u)) PL[pos] = __uint_as_float(base | ((unsigned)i << 22));
+          pos += on ? 1 : 0;
+          bits &= bits - 1u;
+        }
       }
+      ODK_SYNC();
+#pragma unroll 1
+      for (int t = 0; t < 4 && __builtin_amdgcn_ballot_w64(wb + 16 * t < total) != 0; t++) {
+        const bool has = wb + 16 * t + j < total;
+        const unsigned en = has ? __float_as_uint(PL[16 * t + j]) : 0u;
+        const int i = en >> 22;
+        // prism edge i: vertices from the packed table (va | vb << 3, 6 bits per edge), geometry from the LDS copy
+        const unsigned long long PKE = 0ull | (0ull | 1ull << 3) | ((1ull | 2ull << 3) << 6) | ((3ull | 5ull << 3) << 12) | ((0ull | 3ull << 3) << 18) |
+                                       ((3ull | 4ull << 3) << 24) | ((1ull | 4ull << 3) << 30) | ((4ull | 5ull << 3) << 36) | ((2ull | 5ull << 3) << 42) | ((0ull | 2ull << 3) << 48);
+        const int ve = (int)((PKE >> (6 * i)) & 63ull);
+        float pa[3], qa[3], pb[3], qb[3], ea[3], eb[3], ta[3], ax[3], tt[3];
+        ld3(pa, PV + 3 * (ve & 7)); ld3(qa, PV + 3 * (ve >> 3)); ld3(pb, B.V + 3 * (en & 255u)); ld3(qb, B.V + 3 * ((en >> 8) & 255u));
+        sub3(ea, qa, pa); sub3(eb, qb, pb); sub3(ta, pa, pc);
+        cross3(ax, ea, eb);
+        const float l2 = dot3(ax, ax);
+        if (has && l2 >= 1e-8f * dot3(ea, ea) * dot3(eb, eb) && l2 > 1e-30f) {   // edges closer to parallel than 1e-4 (sine) give no axis
+          const float inv = rsqrtf(l2);
+          ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
+          if (dot3(ax, ta) < 0.0f) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; }
+          sub3(tt, pb, pa);
+          const float sp = dot3(ax, tt);
+          if (sp > best || (sp == best && (int)en < bi)) { best = sp; bi = (int)en; bax[0] = ax[0]; bax[1] = ax[1]; bax[2] = ax[2]; }   // (entries order like (i, hull edge))
+        }
+      }
+      ODK_SYNC();
     }
     pair = row_argmax(best, bi, sep_e);
     // the lane that worked the winning pair hands its axis to the row
     const unsigned own = (unsigned)((__builtin_amdgcn_ballot_w64(bi == pair) >> (threadIdx.x & 48u)) & 0xFFFFull);
     const int src = own ? __ffs((int)own) - 1 : 0;
     for (int k = 0; k < 3; k++) eax[k] = row_get(bax[k], src);
+    }
   }
   SAT_PROF(3);
   const bool ref_a = sep_a >= sep_b;
@@ -505,15 +538,15 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
   }
   ODK_SYNC();
   SAT_PROF(4);
-  manifold_row(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act);
+  if (!(knock & 32)) HF_REP(14) { HF_TOUCH(n_ref[0]); manifold_row(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act); }
   SAT_PROF(5);
   if (is_edge) {   // row-uniform
-    int ia = pair >> 8, ib = pair & 255;
-    ia = ia < 9 ? ia : 0; ib = ib < B.ne ? ib : 0;
+    int ia = pair >> 22;
+    ia = ia < 9 ? ia : 0;
+    const int evv = pair & 0xFFFF;
     const int va = ia == 2 || ia == 4 ? 3 : (ia == 6 ? 4 : (ia == 1 || ia == 5 ? 1 : (ia == 7 ? 2 : 0)));   // PRISM_EDGE[ia][0]
     const int vb = ia == 0 ? 1 : (ia == 1 || ia == 8 ? 2 : (ia == 3 ? 3 : (ia == 4 || ia == 5 ? 4 : 5)));       // PRISM_EDGE[ia][1]
-    const int* eb = B.edge + 4 * ib;
-    edge_contact_row(PV + 3 * va, PV + 3 * vb, B.V + 3 * eb[0], B.V + 3 * eb[1], sep_e, eax, S, j, act);
+    edge_contact_row(PV + 3 * va, PV + 3 * vb, B.V + 3 * (evv & 255), B.V + 3 * ((evv >> 8) & 255), sep_e, eax, S, j, act);
   }
   ODK_SYNC();
 }

@@ -1283,6 +1283,17 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
                                m.foot_centroid[f], HULL_MAXF, HULL_MAXE)) {
         delete mo; return fail(ODK_ERR_UNSUPPORTED, "foot hull: not a closed polytope with <= 4-vertex faces, <= %d merged faces and <= %d edges", HULL_MAXF, HULL_MAXE);
       }
+      for (int j = 0; j < 16; j++) {   // what a row lane keeps in registers over the height-field pair loop, as ONE 32-byte record
+        for (int sl = 0; sl < 3; sl++) {
+          const int jb = j + 16 * sl; const bool on = jb < m.foot_nedge[f]; const int* e = m.foot_edge[f][on ? jb : 0];
+          m.foot_lane_rec[f][j][sl] = (int)((unsigned)e[2] | (unsigned)e[3] << 8 | (unsigned)e[0] << 16 | (unsigned)e[1] << 24 | (on ? 0u : 0x80000000u));
+        }
+        for (int sl = 0; sl < 2; sl++) {
+          const int t = j + 16 * sl; const bool on = t < m.foot_npoly[f]; const int* pl = m.foot_poly[f][on ? t : 0];
+          m.foot_lane_rec[f][j][3 + sl] = (int)((unsigned)pl[0] | (unsigned)pl[1] << 3 | (unsigned)pl[2] << 8 | (unsigned)pl[3] << 13 | (unsigned)pl[4] << 18 | (on ? 0u : 0x80000000u));
+        }
+        for (int sl = 5; sl < 8; sl++) m.foot_lane_rec[f][j][sl] = 0;
+      }
       for (int t = 0; t < m.foot_npoly[f]; t++) {
         const double* v0 = bv[m.foot_poly[f][t][1]];
         m.foot_foff[f][t] = (float)(m.foot_fnorm[f][t][0] * v0[0] + m.foot_fnorm[f][t][1] * v0[1] + m.foot_fnorm[f][t][2] * v0[2]);
@@ -1470,7 +1481,11 @@ extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, i
   for (int i = 0; i < 6; i++) hp.ranges[i] = (float)ranges6[i];
   size_t tbytes = (size_t)nx * ny * nth * 640 * sizeof(float);
   HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel)));
-  { DevModel hm = m->h; hm.hfield_filter = cfg->hfield_up_normals_only ? 3 : 0; HIPCHK(hipMemcpy(b->d_model, &hm, sizeof(DevModel), hipMemcpyHostToDevice)); }   // (the batch's own copy: the filter is a batch setting)
+  { DevModel hm = m->h; hm.hfield_filter = cfg->hfield_up_normals_only ? 3 : 0;
+#ifdef ODK_HF_KNOCK   // timing experiment (make libodk_knock.so; WRONG results): parts of the height-field routine switched off by bit
+    if (const char* e = getenv("ODK_HF_KNOCK")) hm.hfield_filter |= atoi(e) << 8;
+#endif
+    HIPCHK(hipMemcpy(b->d_model, &hm, sizeof(DevModel), hipMemcpyHostToDevice)); }   // (the batch's own copy: the filter is a batch setting)
   b->h_prm = hp;
   HIPCHK(hipMalloc(&b->d_table, tbytes)); HIPCHK(hipMemcpy(b->d_table, prm_table, tbytes, hipMemcpyHostToDevice));
   HIPCHK(hipMalloc(&b->d_recs, (size_t)nenv * b->rec_size * sizeof(float))); HIPCHK(hipMemset(b->d_recs, 0, (size_t)nenv * b->rec_size * sizeof(float)));

@@ -880,6 +880,21 @@ __device__ __forceinline__ void select4_rows(const float* w, bool has, float sup
 }
 
 }  // namespace odk
+// Timing experiment (make libodk_knock.so, tools/gpu_hf_knock.sh): bits 8.. of the batch's filter word switch parts of the routine
+// off (bits 0-6: the results are WRONG) or run them twice (bits 8-16: same results, the launch grows by that part's cost).
+#ifdef ODK_HF_KNOCK
+#define HF_KNOCK(bit) ((m->hfield_filter >> (8 + (bit))) & 1)
+#define HF_FILTER(m) ((m)->hfield_filter & 255)
+#define HF_REP(bit) for (int _rep = 0; _rep < 1 + ((knock >> (bit)) & 1); _rep++)
+#define HF_TOUCH(x) asm volatile("" : "+v"(x))
+#define HF_REP_SYNC() ODK_SYNC()
+#else
+#define HF_KNOCK(bit) 0
+#define HF_FILTER(m) ((m)->hfield_filter)
+#define HF_REP(bit)
+#define HF_TOUCH(x) do { } while (0)
+#define HF_REP_SYNC() do { } while (0)
+#endif
 #include "odk_convex.h"
 namespace odk {
 
@@ -955,6 +970,11 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
   const int f = (lane >> 4) & 1, j = lane & 15;
+#ifdef ODK_HF_KNOCK
+  const int knock = m->hfield_filter >> 8;
+#else
+  constexpr int knock = 0;
+#endif
 #ifdef ODK_PROFILE
   long long _hp = clock64();
 #define HF_PROF(i) do { if (lane == 0) { const long long _t = clock64(); L[S::O_SCR + S::S_PROF2 + (i)] += (float)(_t - _hp); _hp = _t; } } while (0)
@@ -972,7 +992,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   static_assert(6 * S::NVR >= 111, "row scratch + window record");
   float* RL = L + S::O_D + f * 172;
   float* LIST = RL; float* TOP = RL + 108; float* NEW = RL + 140;      // [18][6] | [4][8] | [4][8]
-  const RowScratch RSS = {RS + 18, RS + 30, NEW, RS + 42, RS + 58};    // RP [4][3], IP [4][3], pass words [16], hull-edge vertex pairs [48]
+  const RowScratch RSS = {RS + 18, RS + 30, NEW, RS + 42, RS + 58};    // RP [4][3], IP [4][3], the row's list of passing edge pairs [64] (PW | VV)
   const float* Rh = m->floor_mat; const float ph[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
   // ---- the hull in the height field's frame: v_h = Rh^T (P + R v - ph)
   float Rw[9], Pw[3], cl[3];
@@ -1010,6 +1030,8 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   // a millimetre, and float32 coordinates in the height field's own frame would carry ~1e-6 m of rounding each.
   const float org[2] = {-sx + (float)cmin * dx, -sy + (float)rmin * dy};
   Pw[0] -= org[0]; Pw[1] -= org[1];
+  HF_REP(8) {
+  HF_TOUCH(Pw[0]);
   for (int v = j; v < nvt; v += 16) {
     const float vb[3] = {m->foot_vert[f][v][0], m->foot_vert[f][v][1], m->foot_vert[f][v][2]};
     for (int k = 0; k < 3; k++) FV[3 * v + k] = Pw[k] + Rw[3 * k] * vb[0] + Rw[3 * k + 1] * vb[1] + Rw[3 * k + 2] * vb[2];
@@ -1019,6 +1041,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     float nw[3];
     for (int k = 0; k < 3; k++) { nw[k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2]; FN[3 * t + k] = nw[k]; }
     FD[t] = m->foot_foff[f][t] + dot3(nw, Pw);   // the face's plane offset in the window frame: n . (P + R v) = n_b . v_b + n . P
+  }
   }
   float fc[3];
   for (int k = 0; k < 3; k++) fc[k] = Pw[k] + Rw[3 * k] * m->foot_centroid[f][0] + Rw[3 * k + 1] * m->foot_centroid[f][1] + Rw[3 * k + 2] * m->foot_centroid[f][2];
@@ -1040,7 +1063,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     P.base = base;
     const float e1[3] = {P.x[1] - P.x[0], P.y[1] - P.y[0], P.z[1] - P.z[0]}, e2[3] = {P.x[2] - P.x[0], P.y[2] - P.y[0], P.z[2] - P.z[0]};
     cross3(P.nt, e1, e2);
-    const float inv = 1.0f / sqrtf(dot3(P.nt, P.nt));
+    const float inv = __builtin_amdgcn_rsqf(dot3(P.nt, P.nt));
     P.nt[0] *= inv; P.nt[1] *= inv; P.nt[2] *= inv;
     // side over the edge a -> b of the top triangle: (e.y, -e.x, 0) / |e|; the edges run along x, the diagonal, along y
     const float sg = (p & 1) ? -1.0f : 1.0f;
@@ -1056,7 +1079,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   for (int pass = 0; pass < 2; pass++) {
     const int p = 16 * pass + j;
     const bool valid = p < nprism;
-    if (__builtin_amdgcn_ballot_w64(valid) == 0) break;
+    if (__builtin_amdgcn_ballot_w64(valid) == 0 || (pass == 1 && HF_KNOCK(0))) break;
     float z[3] = {0.0f, 0.0f, 0.0f};
     if (valid) { int cc[3], rr[3]; corners(p, ncw, cc, rr); for (int k = 0; k < 3; k++) z[k] = hf[(rmin + rr[k]) * nc + cmin + cc[k]] * sz; }
     Prism P;
@@ -1066,6 +1089,8 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     d5[0] = P.nt[0] * P.x[0] + P.nt[1] * P.y[0] + P.nt[2] * P.z[0]; d5[1] = base;
     d5[2] = P.ns[0][0] * P.x[0] + P.ns[0][1] * P.y[0]; d5[3] = P.ns[1][0] * P.x[1] + P.ns[1][1] * P.y[1]; d5[4] = P.ns[2][0] * P.x[2] + P.ns[2][1] * P.y[2];
     const int nvu = max(m->foot_nvert[0], m->foot_nvert[1]);   // (wave-uniform trip count, as for the faces below)
+    HF_REP(9) {
+    HF_TOUCH(P.nt[0]);
 #pragma unroll 2
     for (int q = 0; q < nvu; q++) {
       const float big = q < nvt ? 0.0f : 3.0e38f;
@@ -1073,6 +1098,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
       s5[0] = fminf(s5[0], dot3(P.nt, v) + big); s5[1] = fminf(s5[1], -v[2] + big);
       s5[2] = fminf(s5[2], P.ns[0][0] * v[0] + P.ns[0][1] * v[1] + big); s5[3] = fminf(s5[3], P.ns[1][0] * v[0] + P.ns[1][1] * v[1] + big);
       s5[4] = fminf(s5[4], P.ns[2][0] * v[0] + P.ns[2][1] * v[1] + big);
+    }
     }
     float sep = -3.0e38f; int face = 0;
 #pragma unroll
@@ -1082,10 +1108,12 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     // one of the hull's side faces and never enters the list; the others are ranked by the larger of the two bounds.  (The six
     // faces of the hull's oriented box instead: a third of the cost, 0.4 more pairs per foot in the loop -- no gain.)
     float sep_b = -3.0e38f;
-    {
+    if (!HF_KNOCK(1)) {
       const float zb = -base;
       // (wave-uniform trip count: with this row's own face count the loop is divergent across the rows and costs three times as much)
       const int nfu = max(m->foot_npoly[0], m->foot_npoly[1]);
+      HF_REP(10) {
+      HF_TOUCH(z[0]);
 #pragma unroll 2
       for (int t = 0; t < nfu; t++) {
         const float n0 = FN[3 * t], n1 = FN[3 * t + 1], n2 = FN[3 * t + 2], dd = FD[t];
@@ -1093,6 +1121,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
         const float top = fminf(fminf(h0 + n2 * z[0], h1 + n2 * z[1]), h2 + n2 * z[2]), bot = fminf(fminf(h0, h1), h2) + n2 * zb;
         const float s = fminf(top, bot) - dd;
         sep_b = (t < nfc && s > sep_b) ? s : sep_b;
+      }
       }
     }
     const float bound = fmaxf(sep, sep_b);
@@ -1146,7 +1175,10 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   unsigned cur_pk = 0u | (1u << 8) | (2u << 16) | (3u << 24);   // wave-uniform: the foot each row is on
   const float s0 = j < cnt ? LIST[6 * j + 5] : 3.0e38f, s1 = j + 16 < cnt ? LIST[6 * (j + 16) + 5] : 3.0e38f;   // own list's bounds (sorted)
   unsigned taken = 0u;        // row-uniform: entries of the own list that some row has taken
-  HF_PROF(2);
+  const bool up_only = HF_FILTER(m) == 3;   // (read once: every compiler barrier in the loop would fetch it again)
+#ifdef ODK_PROFILE
+  _hp = clock64();   // (slot 2 counts the passing edge pairs of lane 0's row: odk_convex.h)
+#endif
 #ifdef ODK_PROFILE
   const long long _loop0 = clock64();
 #endif
@@ -1166,7 +1198,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     unsigned open_t[4], n_pk = 0u;
 #pragma unroll
     for (int t = 0; t < 4; t++) { open_t[t] = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(tgt_meta(t)[4])); n_pk |= (unsigned)__popc(open_t[t]) << (8 * t); }
-    if (n_pk == 0u) break;
+    if (n_pk == 0u || HF_KNOCK(2)) break;
     // assignment: rows keep their foot while it has open entries for them, the others go where most are left
     unsigned asg_pk = 0u, tgt_pk = 0u, rnk_pk = 0u, on_pk = 0u;
 #pragma unroll
@@ -1202,12 +1234,16 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
         B.nv = m->foot_nvert[ft]; B.nf = m->foot_npoly[ft]; B.ne = m->foot_nedge[ft];
         B.c[0] = mt[1]; B.c[1] = mt[2]; B.c[2] = mt[3];
         LISTt = Lt + S::O_D + ft * 172; TOPt = LISTt + 108;
-        edge_regs_load<3>(RB, B, j);
-        face_regs_load<2>(FB, B, j);
-        for (int sl = 0; sl < 3; sl++) RSS.VV[3 * j + sl] = __int_as_float(RB.vv[sl]);
+        int rec[5];
+        { const int* rp = &m->foot_lane_rec[ft][j][0]; for (int k = 0; k < 5; k++) rec[k] = rp[k]; }
+        edge_regs_from_rec<3>(RB, B, rec);
+        face_regs_from_rec<2>(FB, B, rec, j);
       }
       ODK_SYNC();
     }
+#ifdef ODK_PROFILE
+    if (lane == 0) L[S::O_SCR + S::S_PROF2 + 7] += (float)(clock64() - _hp);   // (of `select + prism`: up to the end of the row switch)
+#endif
     // the open entry of rank my_q of that foot's (sorted) list
     unsigned wsel = my_tg == 0 ? open_t[0] : (my_tg == 1 ? open_t[1] : (my_tg == 2 ? open_t[2] : open_t[3]));
     for (int q = 0; q < 3; q++) wsel = q < my_q ? wsel & (wsel - 1u) : wsel;
@@ -1232,14 +1268,14 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     float* prof = lane == 0 ? L + S::O_SCR + S::S_PROF2 + 8 : nullptr;
     long long tp = clock64();
     if (prof) { prof[0] += (float)(tp - _hp); }
-    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act, prof, tp);
+    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act, 0, prof, tp);
 #else
-    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act);
+    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act, knock);
 #endif
     if (act && j < 4) NEW[8 * j + 7] = (float)(4 * p + j);   // candidate index in MJX's list: prism-major, then the pair's four slots
     // opt-in (odk_env_config.hfield_up_normals_only; oracle hfield_mode 3; default off): a pair's contacts count only when its
     // normal points up -- one wave-uniform flag from the batch's model, nothing on the default path but the test
-    if (m->hfield_filter == 3) {
+    if (up_only) {
       ODK_SYNC();
       if (act && j < 4 && !(NEW[8 * j + 6] > 0.5f)) NEW[8 * j] = 1.0f;
     }
@@ -1257,7 +1293,10 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     }
 #endif
     ODK_SYNC();
-    for (unsigned q = 0; q <= maxq; q++) merge_top4_row(TOPt, NEW, j, act && my_q == (int)q);
+#ifdef ODK_PROFILE
+    if (prof) prof[7] += (float)(clock64() - tp);   // (of `writes + merge`: the edge contact and the writes, before the merges)
+#endif
+    if (!HF_KNOCK(6)) for (unsigned q = 0; q <= maxq; q++) merge_top4_row(TOPt, NEW, j, act && my_q == (int)q);
 #ifdef ODK_PROFILE
     { const long long t2 = clock64(); if (prof) prof[6] += (float)(t2 - tp); _hp = t2; }
 #endif

@@ -133,6 +133,8 @@ struct DevModel {
   float foot_fnorm[2][MAXHF][3];
   float foot_foff[2][MAXHF];       // plane offsets n . v of the hull's faces in the body frame (height-field cull: hull face query per prism)
   int foot_edge[2][MAXHE][4];
+  int foot_lane_rec[2][16][8];   // per 16-lane row lane j: the hull edges j, j + 16, j + 32 (face a | face b << 8 | va << 16 | vb << 24) and faces j, j + 16
+                                 // (count | v0 << 3 | v1 << 8 | v2 << 13 | v3 << 18); bit 31: the hull has no such edge / face (the record is edge / face 0's)
   float foot_centroid[2][3];
   // primitive colliders in place of the foot hulls (mjtGeom: 2 sphere, 3 capsule; 7 = convex hull, the duck's own): centre and, for a
   // capsule, the axis (the geom frame's z) in the BODY frame; size = radius, half length.  foot_prim = some foot is a primitive.

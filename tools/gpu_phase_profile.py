@@ -42,8 +42,10 @@ for i in range(18):
 print(f"  {'env-step prologue (kernel start -> first substep)':48s} {mean[18]:12,.0f}  {100 * mean[18] / tot:5.1f}% of the substeps' total")
 print(f"  {'env-step epilogue (last Euler -> kernel end)':48s} {mean[19]:12,.0f}  {100 * mean[19] / tot:5.1f}% of the substeps' total")
 if "rough" in task:
-    print(f"  height-field contacts (per env step = 10 forwards): hull setup {prof2[0]:,.0f}  cull pass {prof2[1]:,.0f}  register loads {prof2[2]:,.0f}  "
+    print(f"  height-field contacts (per env step = 10 forwards): hull setup {prof2[0]:,.0f}  cull pass {prof2[1]:,.0f}  "
           f"pair loop {prof2[3]:,.0f} cycles; loop iterations {prof2[4] / 10:.2f} per forward (longest row of the wave), list length of foot 0 {prof2[5] / 10:.2f}, pairs of foot 0 given the full test {prof2[6] / 10:.2f}")
     it = max(prof2[4], 1.0)
     names = ["select + prism", "face query (hull faces)", "27 Gauss-map tests", "passing pairs", "faces / polygons", "clip + manifold selection", "contact writes + merge"]
     print("  per pair-loop iteration (cycles): " + ", ".join(f"{nm} {prof2[8 + i] / it:,.0f}" for i, nm in enumerate(names)))
+    print(f"  passing edge pairs per iteration (lane 0's row): {prof2[2] / it:.1f}")
+    print(f"  of which: select + prism up to the end of the row switch {prof2[7] / it:,.0f}; writes + merge before the merges {prof2[15] / it:,.0f}")
