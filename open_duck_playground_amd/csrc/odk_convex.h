@@ -185,8 +185,14 @@ __device__ __forceinline__ bool clip_edge_row(const float* p0, const float* p1, 
   const float dd = dot3(d01, d01);
   float best0 = -3.0e38f, best1 = -3.0e38f, tb0 = 0.0f, tb1 = 1.0f;
   bool both = false;
-  for (int k = 0; k < nq; k++) {
-    const float* pa = QP + 3 * (k == 0 ? nq - 1 : k - 1); const float* pb = QP + 3 * k;
+  // (the polygon is read once, up front: in a rolled loop every plane waited for its own LDS round trip)
+  float Q[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; k++) ld3(Q[k], QP + 3 * (k < nq ? k : 0));
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (k >= nq) break;   // (nq is 3 or 4)
+    const float* pa = k == 0 ? (nq == 4 ? Q[3] : Q[2]) : Q[k - 1]; const float* pb = Q[k];
     float e[3], pn[3], t0[3];
     sub3(e, pb, pa);
     cross3(pn, e, qn);

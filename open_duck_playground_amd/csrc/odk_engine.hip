@@ -331,7 +331,7 @@ __device__ __forceinline__ void write_outputs(const KArgs& a, const float* L, in
 
 // ================================================================================================
 // Joystick.reset (joystick.py:206-321) + Episode/AutoReset wrapper resets
-template <class S, int G, bool HF>
+template <class S, int G, int HF>
 __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
 
 // ================================================================================================
 // AutoReset.step -> Episode.step -> Joystick.step (joystick.py:323-481), all substeps fused
-template <class S, int G, bool HF>
+template <class S, int G, int HF>
 __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
 }
 
 // mjx_env.step alone: ctrl = action buffer, no env logic (parity tests)
-template <class S, int G, bool HF>
+template <class S, int G, int HF>
 __global__ void __launch_bounds__(64) physics_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
@@ -1312,7 +1312,6 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   {
     int g = floor_cg[0];
     m.floor_is_plane = cg_type[g] == 0;
-    if (!m.floor_is_plane && m.foot_prim) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "sphere / capsule feet on a height-field floor (MJX hfield_sphere / hfield_capsule) are not built"); }
     double pm[9];
     quat2mat(cg_quat + 4 * g, pm);
     // floor body is static at the world origin in every reference scene
@@ -1333,6 +1332,9 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       // whatever the foot's orientation, its box must span less than two cells per axis (MJX sizes its sub-grid from the same
       // ratio at trace time; a finer field or a larger foot needs a larger window here, not silently dropped cells)
       if (m.hfield_nrow < 2 || m.hfield_ncol < 2) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height field smaller than 2 x 2 samples"); }
+      if (m.foot_prim && !((m.foot_gtype[0] == 2 || m.foot_gtype[0] == 3) && (m.foot_gtype[1] == 2 || m.foot_gtype[1] == 3))) {
+        delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floor: both feet are hulls (hfield_convex) or both are spheres / capsules (hfield_sphere / hfield_capsule)");
+      }
       const double cell = fmin(2.0 * hs[0] / (m.hfield_ncol - 1), 2.0 * hs[1] / (m.hfield_nrow - 1));
       for (int f = 0; f < 2; f++) {
         const float* hh2 = m.foot_obb_half[f];
@@ -1556,7 +1558,7 @@ extern "C" int odk_batch_set_param(odk_batch* b, int param, const float* v, int 
 
 enum { K_RESET = 0, K_STEP = 1, K_PHYS = 2 };
 
-template <class S, int G, bool HF> static hipError_t launch_sg(int which, const KArgs& a, hipStream_t st) {
+template <class S, int G, int HF> static hipError_t launch_sg(int which, const KArgs& a, hipStream_t st) {
   const int per_block = 64 / G;
   const int grid = (a.nenv + per_block - 1) / per_block;
   size_t lds = (size_t)EnvL<S>::wg_floats(per_block) * sizeof(float);
@@ -1574,7 +1576,7 @@ template <class S, int G> static hipError_t launch_phys(int which, const KArgs& 
   if (which != K_PHYS) return hipErrorNotSupported;
   const int per_block = 64 / G;
   const int grid = (a.nenv + per_block - 1) / per_block;
-  hipLaunchKernelGGL((physics_kernel<S, G, false>), dim3(grid), dim3(64), (size_t)EnvL<S>::wg_floats(per_block) * sizeof(float), st, a);
+  hipLaunchKernelGGL((physics_kernel<S, G, 0>), dim3(grid), dim3(64), (size_t)EnvL<S>::wg_floats(per_block) * sizeof(float), st, a);
   return hipGetLastError();
 }
 static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st) {
@@ -1582,20 +1584,21 @@ static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st
   if (b->model.shape == 2 && b->G == 32) return launch_phys<ShapeC, 32>(which, a, st);
   return hipErrorNotSupported;
 #elif defined(ODK_DEV_B32)   // development builds: one instantiation only (make libodk_devB.so / libodk_devA.so: ~25 s instead of 2 min)
-  if (b->model.shape == 1 && b->model.h.floor_is_plane && b->G == 32) return launch_sg<ShapeB, 32, false>(which, a, st);
+  if (b->model.shape == 1 && b->model.h.floor_is_plane && b->G == 32) return launch_sg<ShapeB, 32, 0>(which, a, st);
   return hipErrorNotSupported;
 #elif defined(ODK_DEV_A32)
-  if (b->model.shape == 0 && b->G == 32) return launch_sg<ShapeA, 32, false>(which, a, st);
+  if (b->model.shape == 0 && b->G == 32) return launch_sg<ShapeA, 32, 0>(which, a, st);
   return hipErrorNotSupported;
 #elif defined(ODK_DEV_HF)
-  if (!b->model.h.floor_is_plane) return launch_sg<ShapeB, 32, true>(which, a, st);
+  if (!b->model.h.floor_is_plane) return launch_sg<ShapeB, 32, 1>(which, a, st);
   return hipErrorNotSupported;
 #endif
-  // height-field floors exist only with the backlash model (scene_rough_terrain_backlash.xml) and run 32 lanes per env
-  if (!b->model.h.floor_is_plane) return launch_sg<ShapeB, 32, true>(which, a, st);
+  // height-field floors exist only with the backlash model (scene_rough_terrain_backlash.xml) and run 32 lanes per env; sphere / capsule
+  // feet on one are their own instantiation (HF = 2): its out-of-line calls must not enter the duck kernel's register allocation
+  if (!b->model.h.floor_is_plane) return b->model.h.foot_prim ? launch_sg<ShapeB, 32, 2>(which, a, st) : launch_sg<ShapeB, 32, 1>(which, a, st);
   if (b->model.shape == 2) return b->G == 32 ? launch_phys<ShapeC, 32>(which, a, st) : hipErrorNotSupported;
-  if (b->model.shape == 0) return b->G == 64 ? launch_sg<ShapeA, 64, false>(which, a, st) : launch_sg<ShapeA, 32, false>(which, a, st);
-  return b->G == 64 ? launch_sg<ShapeB, 64, false>(which, a, st) : launch_sg<ShapeB, 32, false>(which, a, st);
+  if (b->model.shape == 0) return b->G == 64 ? launch_sg<ShapeA, 64, 0>(which, a, st) : launch_sg<ShapeA, 32, 0>(which, a, st);
+  return b->G == 64 ? launch_sg<ShapeB, 64, 0>(which, a, st) : launch_sg<ShapeB, 32, 0>(which, a, st);
 }
 
 static void base_args(odk_batch* b, KArgs& a, const odk_outputs* o) {

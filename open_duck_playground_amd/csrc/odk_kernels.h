@@ -1330,7 +1330,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
 // uniform branch.  Writes all twelve contact slots, the eight floor-contact frames (S_FR, as the height-field path) and the
 // foot-foot frame (S_VF, as the convex-convex path).
 template <class S, int G>
-__device__ __noinline__ void prim_contacts(float* L, const DevModel* __restrict__ m, int lane) {
+__device__ __noinline__ void prim_contacts(float* L, const DevModel* __restrict__ m, int lane, bool floor) {
   constexpr int NB = S::NB;
   float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR; float* FR = L + S::O_SCR + S::S_FR;
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
@@ -1350,8 +1350,8 @@ __device__ __noinline__ void prim_contacts(float* L, const DevModel* __restrict_
   }
   auto put = [&](int c, float dist, const float* pos) { CDIST[c] = dist; CR[3 * c] = pos[0] - ref[0]; CR[3 * c + 1] = pos[1] - ref[1]; CR[3 * c + 2] = pos[2] - ref[2]; };
   const float zero3[3] = {ref[0], ref[1], ref[2]};
-  // ---- floor
-  for (int f = 0; f < 2; f++) {
+  // ---- floor (a plane; the height-field floor's contacts are hfield_prim_floor's)
+  for (int f = 0; f < 2 && floor; f++) {
     const float r = m->foot_gsize[f][0], hl = m->foot_gsize[f][1];
     const bool cap = m->foot_gtype[f] == 3;
     float fr[9];
@@ -1439,7 +1439,258 @@ __device__ __noinline__ void prim_contacts(float* L, const DevModel* __restrict_
   }
 }
 
-template <class S, int G, bool HF>
+// Sphere / capsule feet on a height-field floor: mjx hfield_sphere / hfield_capsule as the oracle restates them
+// (oracle/odk_oracle.c: sphere_convex_at, capsule_convex_at, hfield_prim) -- the primitive against the prism of every cell under its
+// bounding sphere, the deepest contact (sphere) / the two deepest (capsule) kept, ties to the lower candidate index.  Foot f = 16-lane
+// row f of the env, lane = prism (two passes cover the 3 x 3 window).  Every face / edge of a prism is worked branch-free in unrolled
+// loops with the result of the winning one kept by selects (a runtime face index would put the prism in scratch).  Rare path, out of line.
+template <class S, int G>
+__device__ __noinline__ void hfield_prim_floor(float* L, const DevModel* __restrict__ m, const float* __restrict__ hf, int lane) {
+  constexpr int NB = S::NB;
+  static_assert(G == 32, "height-field floors run 32 lanes per env");
+  float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* FR = L + S::O_SCR + S::S_FR;
+  const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
+  const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
+  const int f = (lane >> 4) & 1, j = lane & 15;
+  const float* Rh = m->floor_mat; const float ph[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
+  const bool cap = m->foot_gtype[f] == 3;
+  const float r = m->foot_gsize[f][0], hl = cap ? m->foot_gsize[f][1] : 0.0f;
+  float cl[3], al[3];
+  {
+    const int fb = m->foot_body[f];
+    float q[4], R[9], cw[3], aw[3];
+    for (int t = 0; t < 4; t++) q[t] = XQUAT[t * NB + fb];
+    q2mat(R, q);
+    for (int t = 0; t < 3; t++) {
+      cw[t] = XPOS[t * NB + fb] - ph[t] + R[3 * t] * m->foot_gpos[f][0] + R[3 * t + 1] * m->foot_gpos[f][1] + R[3 * t + 2] * m->foot_gpos[f][2];
+      aw[t] = R[3 * t] * m->foot_gaxis[f][0] + R[3 * t + 1] * m->foot_gaxis[f][1] + R[3 * t + 2] * m->foot_gaxis[f][2];
+    }
+    for (int a = 0; a < 3; a++) { cl[a] = Rh[a] * cw[0] + Rh[3 + a] * cw[1] + Rh[6 + a] * cw[2]; al[a] = Rh[a] * aw[0] + Rh[3 + a] * aw[1] + Rh[6 + a] * aw[2]; }
+  }
+  const int nc = m->hfield_ncol, nr = m->hfield_nrow;
+  const float sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2], base = m->hfield_size[3];
+  const float dx = 2.0f * sx / (float)(nc - 1), dy = 2.0f * sy / (float)(nr - 1);
+  const float rad = r + hl;
+  int cmin = (int)floorf((cl[0] - rad + sx) / dx), cmax = (int)floorf((cl[0] + rad + sx) / dx);
+  int rmin = (int)floorf((cl[1] - rad + sy) / dy), rmax = (int)floorf((cl[1] + rad + sy) / dy);
+  cmin = cmin < 0 ? 0 : cmin; rmin = rmin < 0 ? 0 : rmin; cmax = cmax > nc - 2 ? nc - 2 : cmax; rmax = rmax > nr - 2 ? nr - 2 : rmax;
+  int ncw = cmax - cmin + 1, nrw = rmax - rmin + 1;
+  ncw = ncw > 3 ? 3 : ncw; nrw = nrw > 3 ? 3 : nrw;   // (the loader checks that the bounding sphere spans less than two cells)
+  const float org[2] = {-sx + (float)cmin * dx, -sy + (float)rmin * dy};   // everything relative to the window's first grid corner (float32 digits)
+  cl[0] -= org[0]; cl[1] -= org[1];
+  const float ea[3] = {cl[0] - hl * al[0], cl[1] - hl * al[1], cl[2] - hl * al[2]}, eb[3] = {cl[0] + hl * al[0], cl[1] + hl * al[1], cl[2] + hl * al[2]};
+  const float idiag = 1.0f / sqrtf(dx * dx + dy * dy);
+  const int nprism = (ncw > 0 && nrw > 0) ? 2 * ncw * nrw : 0;
+  // the lane's two best candidates so far, ordered by (dist, candidate index)
+  float bd[2] = {3.0e38f, 3.0e38f}, bp[2][3] = {{0, 0, 0}, {0, 0, 0}}, bn[2][3] = {{0, 0, 1}, {0, 0, 1}};
+  int bidx[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+  auto offer = [&](float d, const float* p, const float* n, int idx) {
+    const bool lt0 = d < bd[0] || (d == bd[0] && idx < bidx[0]), lt1 = d < bd[1] || (d == bd[1] && idx < bidx[1]);
+    for (int k = 0; k < 3; k++) { bp[1][k] = lt0 ? bp[0][k] : (lt1 ? p[k] : bp[1][k]); bn[1][k] = lt0 ? bn[0][k] : (lt1 ? n[k] : bn[1][k]); bp[0][k] = lt0 ? p[k] : bp[0][k]; bn[0][k] = lt0 ? n[k] : bn[0][k]; }
+    bd[1] = lt0 ? bd[0] : (lt1 ? d : bd[1]); bidx[1] = lt0 ? bidx[0] : (lt1 ? idx : bidx[1]);
+    bd[0] = lt0 ? d : bd[0]; bidx[0] = lt0 ? idx : bidx[0];
+  };
+  auto seg_point = [](const float* a, const float* b, const float* pt, float* out) {   // math.closest_segment_point
+    float ab[3], t[3];
+    sub3(ab, b, a); sub3(t, pt, a);
+    float tt = dot3(t, ab) / (dot3(ab, ab) + 1e-6f);
+    tt = fminf(fmaxf(tt, 0.0f), 1.0f);
+    for (int i = 0; i < 3; i++) out[i] = a[i] + tt * ab[i];
+  };
+#pragma unroll 1
+  for (int pass = 0; pass < 2; pass++) {
+    const int p = 16 * pass + j;
+    const bool valid = p < nprism;
+    if (__builtin_amdgcn_ballot_w64(valid) == 0) break;
+    Prism P;
+    {
+      const int pp = valid ? p : 0, q = pp >> 1, tri = pp & 1;
+      const int ri = ncw == 1 ? q : (ncw == 2 ? (q >> 1) : (q >= 6 ? 2 : (q >= 3 ? 1 : 0)));
+      const int c = q - ri * ncw;
+      const int cc[3] = {tri ? c + 1 : c, tri ? c : c + 1, tri ? c + 1 : c}, rr[3] = {tri ? ri + 1 : ri, tri ? ri + 1 : ri, tri ? ri : ri + 1};
+      for (int k = 0; k < 3; k++) { P.x[k] = (float)cc[k] * dx; P.y[k] = (float)rr[k] * dy; P.z[k] = valid ? hf[(rmin + rr[k]) * nc + cmin + cc[k]] * sz : 0.0f; }
+      P.base = base;
+      const float e1[3] = {P.x[1] - P.x[0], P.y[1] - P.y[0], P.z[1] - P.z[0]}, e2[3] = {P.x[2] - P.x[0], P.y[2] - P.y[0], P.z[2] - P.z[0]};
+      cross3(P.nt, e1, e2);
+      const float inv = 1.0f / sqrtf(dot3(P.nt, P.nt));
+      P.nt[0] *= inv; P.nt[1] *= inv; P.nt[2] *= inv;
+      const float sg = tri ? -1.0f : 1.0f;
+      P.ns[0][0] = 0.0f; P.ns[0][1] = -sg; P.ns[1][0] = sg * dy * idiag; P.ns[1][1] = sg * dx * idiag; P.ns[2][0] = -sg; P.ns[2][1] = 0.0f;
+    }
+    float V[6][3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) prism_vert(P, k, V[k]);
+    // ---- the face of least penetration among those the primitive is behind; its contact(s) computed for every face, the winner's kept
+    float best = -3.0e38f;
+    bool has_support = true;
+    float fd[2] = {1.0f, 1.0f}, fp[2][3] = {{0, 0, 0}, {0, 0, 0}}, fn_[3] = {0, 0, 1};
+#pragma unroll
+    for (int fa = 0; fa < 5; fa++) {
+      float N[3];
+      prism_norm(P, fa, N);
+      constexpr int CNT[5] = {3, 3, 4, 4, 4};
+      const int cnt = CNT[fa];
+      const float* v0 = V[PRISM_POLY[fa][1]];
+      float ta[3], tb[3];
+      sub3(ta, ea, v0); sub3(tb, eb, v0);
+      const float sa = dot3(ta, N) - r, sb = dot3(tb, N) - r;
+      float sup = fminf(sa, sb);
+      has_support = has_support && sup < 0.0f;
+      sup = sup >= 0.0f ? -1e12f : sup;
+      float cd[2], cp[2][3];
+      if (!cap) {   // (model-uniform per row: sphere)
+        float pt[3];
+        for (int k = 0; k < 3; k++) pt[k] = cl[k] - (sa + r) * N[k];   // the centre projected on the face plane
+        bool inside = true; float dmin = 3.0e38f; float q0[3] = {0, 0, 0}, q1[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k >= cnt) break;
+          const float* p0 = V[PRISM_POLY[fa][1 + (k + cnt - 1) % cnt]]; const float* p1 = V[PRISM_POLY[fa][1 + k]];
+          float e[3], en[3], tp[3];
+          sub3(e, p1, p0); cross3(en, e, N); sub3(tp, pt, p0);
+          const float ed = dot3(tp, en);
+          inside = inside && ed <= 0.0f;
+          const bool degenerate = en[0] == 0.0f && en[1] == 0.0f && en[2] == 0.0f;
+          const float val = (degenerate || ed < 0.0f) ? 1e12f : ed;
+          if (val < dmin) { dmin = val; ld3(q0, p0); ld3(q1, p1); }
+        }
+        float qe[3];
+        seg_point(q0, q1, pt, qe);
+        for (int k = 0; k < 3; k++) pt[k] = inside ? pt[k] : qe[k];
+        float nn[3];
+        sub3(nn, pt, cl);
+        const float d = sqrtf(dot3(nn, nn)), inv = 1.0f / (d + (d == 0.0f ? 1e-6f : 0.0f));
+        cd[0] = d - r; cd[1] = 1.0f;
+        for (int k = 0; k < 3; k++) { nn[k] *= inv; cp[0][k] = 0.5f * (pt[k] + cl[k] + nn[k] * r); cp[1][k] = 0.0f; }
+        if (sup > best) { best = sup; fd[0] = cd[0]; fd[1] = 1.0f; for (int k = 0; k < 3; k++) { fp[0][k] = cp[0][k]; fn_[k] = -nn[k]; } }
+      } else {
+        // the capsule's axis clipped against the face's side planes (_clip_edge_to_planes in the parametric form of clip_edge_row)
+        float d01[3];
+        sub3(d01, eb, ea);
+        const float dd = dot3(d01, d01);
+        float b0 = -3.0e38f, b1 = -3.0e38f, t0b = 0.0f, t1b = 1.0f;
+        bool both = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k >= cnt) break;
+          const float* p0 = V[PRISM_POLY[fa][1 + (k + cnt - 1) % cnt]]; const float* p1 = V[PRISM_POLY[fa][1 + k]];
+          float e[3], pn[3], t0[3];
+          sub3(e, p1, p0); cross3(pn, e, N); sub3(t0, ea, p0);
+          const float a0 = dot3(t0, pn), denom = dot3(pn, d01), a1 = a0 + denom;
+          const bool f0 = a0 > 1e-6f, f1 = a1 > 1e-6f;
+          both = both || (f0 && f1);
+          float t = -a0 / (denom + (denom == 0.0f ? 1e-6f : 0.0f));
+          t = fminf(fmaxf(t, 0.0f), 1.0f);
+          const float s0 = f0 ? t * dd : 0.0f, s1 = f1 ? (1.0f - t) * dd : 0.0f;
+          if (s0 > b0) { b0 = s0; t0b = f0 ? t : 0.0f; }
+          if (s1 > b1) { b1 = s1; t1b = f1 ? t : 1.0f; }
+        }
+        const bool mask = !both && !(t0b > t1b);
+#pragma unroll
+        for (int e2 = 0; e2 < 2; e2++) {
+          const float tt = !both ? (e2 ? t1b : t0b) : (e2 ? 1.0f : 0.0f);
+          float cpt[3], tq[3];
+          for (int k = 0; k < 3; k++) cpt[k] = (tt == 1.0f ? eb[k] : ea[k] + tt * d01[k]) - N[k] * r;   // the capsule's surface point under the clipped axis point
+          sub3(tq, cpt, v0);
+          const float off = dot3(tq, N);                                                           // its height over the face plane
+          for (int k = 0; k < 3; k++) cp[e2][k] = cpt[k] - 0.5f * off * N[k];
+          cd[e2] = mask ? off : 1.0f;   // dist = -penetration = -(face point - surface point) . N   (has_support enters below)
+        }
+        if (sup > best) { best = sup; for (int e2 = 0; e2 < 2; e2++) { fd[e2] = cd[e2]; for (int k = 0; k < 3; k++) fp[e2][k] = cp[e2][k]; } for (int k = 0; k < 3; k++) fn_[k] = N[k]; }
+      }
+    }
+    float n0[3] = {fn_[0], fn_[1], fn_[2]};
+    if (cap) {
+      if (!has_support) { fd[0] = 1.0f; fd[1] = 1.0f; }
+      // ---- a shallow edge contact: the prism edge closest to the capsule's axis
+      float e_dist = 3.0e38f, e_ax[3] = {0, 0, 1}, e_pt[3] = {0, 0, 0}, c_pt[3] = {0, 0, 0};
+      bool e_deg = true, e_front = false;
+      float da[3];
+      sub3(da, eb, ea);
+      const float la2 = dot3(da, da), la = sqrtf(la2), ila = 1.0f / (la + (la == 0.0f ? 1e-6f : 0.0f));
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        const float* a0 = V[PRISM_EDGE[k][0]]; const float* a1 = V[PRISM_EDGE[k][1]];
+        // math.closest_segment_to_segment_points(edge, capsule axis), as the oracle states it
+        float dir_a[3], dir_b[3], amid[3], bmid[3], diff[3];
+        sub3(dir_a, a1, a0);
+        const float lea = sqrtf(dot3(dir_a, dir_a)), ilea = 1.0f / (lea + (lea == 0.0f ? 1e-6f : 0.0f));
+        for (int t = 0; t < 3; t++) { dir_a[t] *= ilea; dir_b[t] = da[t] * ila; amid[t] = 0.5f * (a0[t] + a1[t]); bmid[t] = 0.5f * (ea[t] + eb[t]); diff[t] = amid[t] - bmid[t]; }
+        const float len_a = 0.5f * lea, len_b = 0.5f * la;
+        const float dot_a = dot3(dir_a, diff), dot_b = dot3(dir_b, diff), dot_ab = dot3(dir_a, dir_b);
+        const float denom = 1.0f - dot_ab * dot_ab;
+        const float ota = (-dot_a + dot_ab * dot_b) / (denom + 1e-6f), otb = dot_b + ota * dot_ab;
+        const float t_a = fminf(fmaxf(ota, -len_a), len_a), t_b = fminf(fmaxf(otb, -len_b), len_b);
+        float ca[3], cb[3], na[3], nb[3], t1[3], t2[3];
+        for (int t = 0; t < 3; t++) { ca[t] = amid[t] + t_a * dir_a[t]; cb[t] = bmid[t] + t_b * dir_b[t]; }
+        seg_point(a0, a1, cb, na); seg_point(ea, eb, ca, nb);
+        sub3(t1, na, cb); sub3(t2, ca, nb);
+        const bool first = dot3(t1, t1) < dot3(t2, t2);
+        float pe[3], pc[3], dir[3];
+        for (int t = 0; t < 3; t++) { pe[t] = first ? na[t] : ca[t]; pc[t] = first ? cb[t] : nb[t]; dir[t] = pe[t] - pc[t]; }
+        const float d2 = dot3(dir, dir), dd = sqrtf(d2);
+        if (dd < e_dist) {
+          e_dist = dd; e_deg = d2 < 1e-6f;
+          const float inv = 1.0f / (dd + (dd == 0.0f ? 1e-6f : 0.0f));
+          for (int t = 0; t < 3; t++) { e_ax[t] = dir[t] * inv; e_pt[t] = pe[t]; c_pt[t] = pc[t]; }
+          float na_[3], nb_[3];
+          prism_norm(P, PRISM_EDGE[k][2], na_); prism_norm(P, PRISM_EDGE[k][3], nb_);
+          e_front = dot3(na_, e_ax) < 0.0f && dot3(nb_, e_ax) < 0.0f;
+        }
+      }
+      const bool shallow = !e_deg && e_front;
+      const float edge_pen = shallow ? r - e_dist : -1.0f;
+      const bool parallel = fabsf(dot3(e_ax, fn_)) > 0.99f && has_support;
+      const float min_face = fminf(-fd[0], -fd[1]);
+      const bool has_edge = edge_pen > 0.0f && (min_face > 0.0f ? edge_pen < min_face : true) && !parallel;
+      if (has_edge) {
+        fd[0] = -edge_pen; fd[1] = 1.0f;
+        for (int t = 0; t < 3; t++) { fp[0][t] = 0.5f * (e_pt[t] + c_pt[t] + e_ax[t] * r); n0[t] = -e_ax[t]; }
+      }
+    }
+    const int ci = cap ? 2 * p : p;
+    if (valid) { offer(fd[0], fp[0], n0, ci); if (cap) offer(fd[1], fp[1], fn_, ci + 1); }
+  }
+  // ---- the row's best one / two, then back to the world frame
+  const int ncon = cap ? 2 : 1;
+#pragma unroll 1
+  for (int k = 0; k < 2; k++) {
+    float vm;
+    const unsigned kd = fkey(bd[0]), mn = rreduce_u<false>(kd);
+    const unsigned wi = rreduce_u<false>(kd == mn ? (unsigned)bidx[0] : 0x7FFFFFFFu);   // lowest candidate index among the minima
+    vm = fkey_inv(mn);
+    const bool mine = kd == mn && (unsigned)bidx[0] == wi;
+    const unsigned own = (unsigned)((__builtin_amdgcn_ballot_w64(mine) >> (threadIdx.x & 48u)) & 0xFFFFull);
+    const int src = own ? __ffs((int)own) - 1 : 0;
+    float wp[3], wn[3];
+    for (int t = 0; t < 3; t++) { wp[t] = row_get(bp[0][t], src); wn[t] = row_get(bn[0][t], src); }
+    const bool any = wi != 0x7FFFFFFFu && k < ncon;
+    if (j == 0) {
+      const int c = 4 * f + k;
+      float pw[3], nw[3];
+      for (int a = 0; a < 3; a++) {
+        pw[a] = ph[a] + Rh[3 * a] * (wp[0] + org[0]) + Rh[3 * a + 1] * (wp[1] + org[1]) + Rh[3 * a + 2] * wp[2];
+        nw[a] = any ? Rh[3 * a] * wn[0] + Rh[3 * a + 1] * wn[1] + Rh[3 * a + 2] * wn[2] : Rh[3 * a + 2];
+      }
+      CDIST[c] = any ? vm : 1.0f;
+      for (int t = 0; t < 3; t++) CR[3 * c + t] = any ? pw[t] - ref[t] : 0.0f;
+      make_frame_dev(nw, FR + 9 * c);
+    }
+    if (mine) {   // the winner's lane moves its second candidate up
+      bd[0] = bd[1]; bidx[0] = bidx[1]; bd[1] = 3.0e38f; bidx[1] = 0x7FFFFFFF;
+      for (int t = 0; t < 3; t++) { bp[0][t] = bp[1][t]; bn[0][t] = bn[1][t]; }
+    }
+  }
+  if (j < 2) {   // slots 2, 3 of the pair stay empty
+    const int c = 4 * f + 2 + j;
+    const float up[3] = {Rh[2], Rh[5], Rh[8]};
+    CDIST[c] = 1.0f; CR[3 * c] = 0.0f; CR[3 * c + 1] = 0.0f; CR[3 * c + 2] = 0.0f;
+    make_frame_dev(up, FR + 9 * c);
+  }
+}
+
+// HF: 0 = plane floor, 1 = height-field floor under the duck's mesh feet, 2 = height-field floor under sphere / capsule feet
+template <class S, int G, int HF>
 __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags) {
   // RT: the packed reduced entries (DevModel::R_ent) in LDS, one copy per workgroup (load_shared): every substep reads them
   // twice (inertia, Hessian), and a table load from the L2-resident model right behind a phase hand-off is ~300 exposed cycles.
@@ -1927,9 +2178,10 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   }
   if constexpr (HF) {
     // height-field floor (rough terrain; its own kernel instantiation): prisms of the cells under each foot, out of line
-    hfield_contacts<S, G>(L, m, hfield, lane);
+    if constexpr (HF == 2) { hfield_prim_floor<S, G>(L, m, hfield, lane); ODK_SYNC(); prim_contacts<S, G>(L, m, lane, false); }   // floor, then foot against foot
+    else hfield_contacts<S, G>(L, m, hfield, lane);
   } else if (m->foot_prim) {
-    prim_contacts<S, G>(L, m, lane);   // sphere / capsule feet (model-uniform branch): floor and foot-foot contacts, out of line
+    prim_contacts<S, G>(L, m, lane, true);   // sphere / capsule feet (model-uniform branch): floor and foot-foot contacts, out of line
   } else {
   const float pn0[3] = {m->plane_n[0], m->plane_n[1], m->plane_n[2]};
   {

@@ -451,9 +451,11 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
         if g.get("margin", 0.0) != 0.0 or g.get("gap", 0.0) != 0.0:
             raise NotImplementedError(f"colliding geom '{g['name']}' has margin / gap: contacts are detected at distance 0 in this engine "
                                       "(the height-field cull and the foot-foot box cull drop separated pairs)")
-    if any(g["type"] == "hfield" for g in col) and any(g["type"] in ("sphere", "capsule") for g in col):
-        raise NotImplementedError("spheres / capsules against a height field (MJX hfield_sphere / hfield_capsule) are not supported: "
-                                  "the height-field floor takes convex meshes and boxes")
+    if any(g["type"] == "hfield" for g in col):
+        kinds = {("prim" if g["type"] in ("sphere", "capsule") else "hull") for g in col if g["type"] != "hfield"}
+        if len(kinds) > 1:   # (odk_model_load repeats the check on the blob)
+            raise NotImplementedError("on a height-field floor both feet are hulls (meshes / boxes: hfield_convex) or both are spheres / "
+                                      "capsules (hfield_sphere / hfield_capsule)")
     col_ids = [i for i, g in enumerate(geoms) if (g["contype"] or g["conaffinity"])]
     geom_name2id = {g["name"]: i for i, g in enumerate(geoms) if g["name"]}
 

@@ -979,6 +979,152 @@ static void capsule_capsule(const odko_model* m, odko_data* d, int g1, int g2, i
   sphere_sphere_at(d, c0, pa, m->cgeom_size[g1][0], pb, m->cgeom_size[g2][0]);
 }
 
+/* ---- sphere / capsule against a convex polytope (mjx collision_convex._sphere_convex, _capsule_convex: restated from memory,
+ * PARITY UNPINNED like the rest of the file), both in the polytope's frame.  The normals returned here point from the polytope to
+ * the primitive: the order of the pair (height field, primitive). */
+static void sphere_convex_at(const odko_convex* C, const real* s, real r, real* dist, real* pos, real* n) {
+  real best = -1e300; int bf = 0;
+  for (int f = 0; f < C->nf; f++) { /* the face of least penetration among those the sphere is behind ("has support") */
+    real t[3]; v3_sub(t, s, C->v[C->fidx[f][0]]);
+    real sup = v3_dot(t, C->fnorm[f]) - r;
+    if (sup >= 0) sup = -1e12;
+    if (sup > best) { best = sup; bf = f; }
+  }
+  const real* N = C->fnorm[bf]; int cnt = C->fcnt[bf];
+  real pt[3], t[3];
+  v3_sub(t, s, C->v[C->fidx[bf][0]]);
+  v3_addscl(pt, s, N, -v3_dot(t, N)); /* the centre projected on the face plane */
+  int inside = 1, idx = 0; real dmin = 1e300;
+  for (int k = 0; k < cnt; k++) { /* edge k runs from vertex k - 1 to vertex k (jp.roll(face, 1)) */
+    const real* p0 = C->v[C->fidx[bf][(k + cnt - 1) % cnt]]; const real* p1 = C->v[C->fidx[bf][k]];
+    real e[3], en[3], tp[3];
+    v3_sub(e, p1, p0); v3_cross(en, e, N); v3_sub(tp, pt, p0);
+    real ed = v3_dot(tp, en);
+    if (!(ed <= 0)) inside = 0;
+    int degenerate = en[0] == 0 && en[1] == 0 && en[2] == 0;
+    real val = (degenerate || ed < 0) ? 1e12 : ed;
+    if (val < dmin) { dmin = val; idx = k; }
+  }
+  if (!inside) { /* outside the polygon: the closest point of the nearest edge the projection is in front of */
+    real q[3];
+    closest_segment_point(q, C->v[C->fidx[bf][(idx + cnt - 1) % cnt]], C->v[C->fidx[bf][idx]], pt);
+    v3_copy(pt, q);
+  }
+  real nn[3]; v3_sub(nn, pt, s);
+  real d = sqrt(v3_dot(nn, nn)), inv = 1.0 / (d + (d == 0 ? 1e-6 : 0.0)); /* math.normalize_with_norm */
+  for (int k = 0; k < 3; k++) nn[k] *= inv;
+  *dist = d - r;
+  for (int k = 0; k < 3; k++) { pos[k] = 0.5 * (pt[k] + s[k] + nn[k] * r); n[k] = -nn[k]; }
+}
+/* capsule = segment (a, b) with radius r; two contacts */
+static void capsule_convex_at(const odko_convex* C, const real* a, const real* b, real r, real* dist2, real (*pos2)[3], real (*n2)[3]) {
+  real best = -1e300; int bf = 0, has_support = 1;
+  for (int f = 0; f < C->nf; f++) {
+    real ta[3], tb[3]; v3_sub(ta, a, C->v[C->fidx[f][0]]); v3_sub(tb, b, C->v[C->fidx[f][0]]);
+    real sa = v3_dot(ta, C->fnorm[f]) - r, sb = v3_dot(tb, C->fnorm[f]) - r, sup = sa < sb ? sa : sb;
+    if (!(sup < 0)) has_support = 0;
+    if (sup >= 0) sup = -1e12;
+    if (sup > best) { best = sup; bf = f; }
+  }
+  const real* N = C->fnorm[bf]; int cnt = C->fcnt[bf];
+  real ppt[CV_MAXP][3], pn[CV_MAXP][3], clipped[2][3];
+  for (int k = 0; k < cnt; k++) {
+    const real* p0 = C->v[C->fidx[bf][(k + cnt - 1) % cnt]]; const real* p1 = C->v[C->fidx[bf][k]];
+    real e[3]; v3_sub(e, p1, p0); v3_cross(pn[k], e, N); v3_copy(ppt[k], p0);
+  }
+  int mask = clip_edge_to_planes(a, b, (const real (*)[3])ppt, (const real (*)[3])pn, cnt, clipped);
+  real face_pen[2];
+  for (int k = 0; k < 2; k++) {
+    real cp[3], fp[3], t[3];
+    v3_addscl(cp, clipped[k], N, -r);                       /* the capsule's surface point under the clipped axis point */
+    v3_sub(t, cp, C->v[C->fidx[bf][0]]);
+    v3_addscl(fp, cp, N, -v3_dot(t, N));                    /* projected on the face plane */
+    for (int q = 0; q < 3; q++) { pos2[k][q] = 0.5 * (cp[q] + fp[q]); n2[k][q] = N[q]; }
+    v3_sub(t, fp, cp);
+    face_pen[k] = (mask && has_support) ? v3_dot(t, N) : -1.0;
+  }
+  /* a shallow edge contact: the polytope edge closest to the capsule's axis */
+  real e_dist = 1e300, e_axis[3] = {0, 0, 1}, e_pt[3] = {0, 0, 0}, c_pt[3] = {0, 0, 0}; int e_deg = 1, e_idx = 0;
+  for (int k = 0; k < C->ne; k++) {
+    real pe[3], pc[3], dir[3];
+    closest_segment_to_segment(pe, pc, C->v[C->e[k][0]], C->v[C->e[k][1]], a, b);
+    v3_sub(dir, pe, pc);
+    real d2 = v3_dot(dir, dir), dd = sqrt(d2);
+    if (dd < e_dist) {
+      e_dist = dd; e_idx = k; e_deg = d2 < 1e-6;
+      real inv = 1.0 / (dd + (dd == 0 ? 1e-6 : 0.0));
+      for (int q = 0; q < 3; q++) e_axis[q] = dir[q] * inv;
+      v3_copy(e_pt, pe); v3_copy(c_pt, pc);
+    }
+  }
+  int voronoi_front = v3_dot(C->fnorm[C->ef[e_idx][0]], e_axis) < 0 && v3_dot(C->fnorm[C->ef[e_idx][1]], e_axis) < 0;
+  int shallow = !e_deg && voronoi_front;
+  real edge_pen = shallow ? r - e_dist : -1.0;
+  int parallel = fabs(v3_dot(e_axis, N)) > 0.99 && has_support;
+  real min_face = face_pen[0] < face_pen[1] ? face_pen[0] : face_pen[1];
+  int has_edge = edge_pen > 0 && (min_face > 0 ? edge_pen < min_face : 1) && !parallel;
+  if (has_edge) {
+    for (int q = 0; q < 3; q++) { pos2[0][q] = 0.5 * (e_pt[q] + c_pt[q] + e_axis[q] * r); n2[0][q] = -e_axis[q]; }
+    face_pen[0] = edge_pen; face_pen[1] = -1.0;
+  }
+  dist2[0] = -face_pen[0]; dist2[1] = -face_pen[1];
+}
+
+/* mjx collision_convex.hfield_sphere / hfield_capsule -> _hfield_collision: the primitive against the prisms of every cell under its
+ * bounding sphere; the deepest contact (sphere) / the two deepest (capsule) of all prisms kept, ties to the lower candidate index.
+ * Candidate order as in hfield_convex: rows, columns, the cell's two triangles, the prism's slots. */
+static void hfield_prim(const odko_model* m, odko_data* d, int gh, int g, int c0) {
+  const real* Rh = d->geom_xmat[gh]; const real* ph = d->geom_xpos[gh];
+  const int capsule = m->cgeom_type[g] == ODKO_GEOM_CAPSULE, ncon = capsule ? 2 : 1;
+  const real r = m->cgeom_size[g][0], hl = capsule ? m->cgeom_size[g][1] : 0.0;
+  real cl[3], al[3] = {0, 0, 1}, t[3];
+  v3_sub(t, d->geom_xpos[g], ph); mat_tmulvec(cl, Rh, t);
+  if (capsule) { real aw[3] = {d->geom_xmat[g][2], d->geom_xmat[g][5], d->geom_xmat[g][8]}; mat_tmulvec(al, Rh, aw); }
+  real ea[3], eb[3];
+  v3_addscl(ea, cl, al, -hl); v3_addscl(eb, cl, al, hl);
+  const real rad = r + hl;
+  int nc = m->hfield_ncol, nr = m->hfield_nrow;
+  real sx = m->hfield_size[0], sy = m->hfield_size[1];
+  real dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
+  int cmin = (int)floor((cl[0] - rad + sx) / dx), cmax = (int)floor((cl[0] + rad + sx) / dx);
+  int rmin = (int)floor((cl[1] - rad + sy) / dy), rmax = (int)floor((cl[1] + rad + sy) / dy);
+  if (cmin < 0) cmin = 0;
+  if (rmin < 0) rmin = 0;
+  if (cmax > nc - 2) cmax = nc - 2;
+  if (rmax > nr - 2) rmax = nr - 2;
+  real cd[HF_MAXCAND], cp[HF_MAXCAND][3], cn[HF_MAXCAND][3];
+  int ncand = 0;
+  for (int rr = rmin; rr <= rmax; rr++)
+    for (int cc = cmin; cc <= cmax; cc++)
+      for (int tri = 0; tri < 2; tri++) {
+        if (ncand + 2 > HF_MAXCAND) continue;
+        odko_convex P;
+        hfield_prism(m, cc, rr, tri, &P);
+        if (capsule) {
+          real d2[2], p2[2][3], n2[2][3];
+          capsule_convex_at(&P, ea, eb, r, d2, p2, n2);
+          for (int k = 0; k < 2; k++) { cd[ncand] = d2[k]; v3_copy(cp[ncand], p2[k]); v3_copy(cn[ncand], n2[k]); ncand++; }
+        } else {
+          sphere_convex_at(&P, cl, r, &cd[ncand], cp[ncand], cn[ncand]);
+          ncand++;
+        }
+      }
+  int used[HF_MAXCAND] = {0};
+  for (int k = 0; k < 4; k++) {
+    int bi = -1;
+    if (k < ncon) for (int i = 0; i < ncand; i++) if (!used[i] && (bi < 0 || cd[i] < cd[bi])) bi = i;
+    real nw[3] = {Rh[2], Rh[5], Rh[8]}, pw[3] = {0, 0, 0}, dist = 1.0;
+    if (bi >= 0) {
+      used[bi] = 1; dist = cd[bi];
+      mat_mulvec(nw, Rh, cn[bi]);
+      mat_mulvec(pw, Rh, cp[bi]); v3_addscl(pw, pw, ph, 1);
+    }
+    d->contact_dist[c0 + k] = dist;
+    v3_copy(d->contact_pos[c0 + k], pw);
+    make_frame(d->contact_frame[c0 + k], nw);
+  }
+}
+
 static void collision_pairs(const odko_model* m, odko_data* d);
 static void collision(const odko_model* m, odko_data* d) {
   margin_reset();
@@ -1002,6 +1148,7 @@ static void collision_pairs(const odko_model* m, odko_data* d) {
     else if (m->cgeom_type[g1] == ODKO_GEOM_PLANE && m->cgeom_type[g2] == ODKO_GEOM_MESH) plane_convex(m, d, g1, g2, c0);
     else if (m->cgeom_type[g1] == ODKO_GEOM_MESH && m->cgeom_type[g2] == ODKO_GEOM_MESH) convex_convex(m, d, g1, g2, c0);
     else if (m->cgeom_type[g1] == ODKO_GEOM_HFIELD && m->cgeom_type[g2] == ODKO_GEOM_MESH && m->hfield_nrow > 1) hfield_convex(m, d, g1, g2, c0);
+    else if (t1 == ODKO_GEOM_HFIELD && (t2 == ODKO_GEOM_SPHERE || t2 == ODKO_GEOM_CAPSULE) && m->hfield_nrow > 1) hfield_prim(m, d, g1, g2, c0);
     else { /* unsupported pair type: no contact */
       for (int k = 0; k < 4; k++) { d->contact_dist[c0 + k] = 1.0; v3_zero(d->contact_pos[c0 + k]); real z[3] = {0, 0, 1}; make_frame(d->contact_frame[c0 + k], z); }
     }

@@ -252,3 +252,71 @@ def test_sweep_state_generator_makes_contact_rich_states(oracle_mod):
             if f0 or f1:
                 assert cd[:8].min() > -8e-3, (task, e, cd[:8].min())          # pressed in by at most the target depth
         assert floor >= 60 and both >= 5 and ff >= 6 and air >= 5, (task, floor, both, ff, air)
+
+
+def _hfield_prim_model(O, kinds, heights):
+    """rough-terrain model with primitive feet (the variant the GPU test uses) and the given height samples"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _prim_feet_variant
+    from open_duck_playground_amd.model import Model
+    m = _prim_feet_variant("rough_terrain_backlash", kinds)
+    a = {k: np.array(v) for k, v in m.a.items()}
+    a["hfield_data"] = np.asarray(heights, np.float64)
+    return Model(a, m.xml_path)
+
+
+@pytest.mark.parametrize("kind", ["sphere", "capsule"])
+def test_primitive_on_a_planar_height_field_is_the_plane_collider(oracle_mod, kind):
+    """hfield_sphere / hfield_capsule (oracle/odk_oracle.c: hfield_prim) on a height field whose samples lie on ONE plane: away from
+    prism edges the answer is plane_sphere / plane_capsule against that plane -- depth = distance of the sphere centre / capsule end to
+    the plane minus the radius, normal = the plane's, position half a depth under the surface point.  (What the routine does near
+    a prism's edges, and which contacts it keeps among the prisms, is the recollection of MJX this build cannot pin.)"""
+    O = oracle_mod
+    nr = nc = 256
+    sx = 10.0; dxy = 2 * sx / (nc - 1)
+    sz = 0.01
+    gx, gy = 0.02, -0.035                                   # slopes (dimensionless) of the plane z = gx x + gy y + z0
+    xs = -sx + dxy * np.arange(nc); ys = -sx + dxy * np.arange(nr)
+    z = gx * xs[None, :] + gy * ys[:, None]
+    z0 = -z.min() + 0.001
+    model = _hfield_prim_model(O, (kind, kind), (z + z0) / sz)
+    om = O.OracleModel(model.blob())
+    nrm = np.array([-gx, -gy, 1.0]); nrm /= np.linalg.norm(nrm)
+    rng = np.random.default_rng(3)
+    checked = 0
+    for trial in range(60):
+        d = O.OracleData(om)
+        q = np.asarray(model.a["key_qpos"], np.float64).copy()
+        q[:2] = rng.uniform(-5, 5, 2); q[2] = gx * q[0] + gy * q[1] + z0 + 0.3
+        ang = rng.uniform(-0.3, 0.3); ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        q[3:7] = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+        for _ in range(4):                                  # lower the robot until a foot is ~1 mm in the plane
+            d["qpos"][: om.nq] = q; d.forward()
+            q[2] -= min(np.array(d["contact_dist"][:8]).min(), 0.05) + 1e-3
+        d["qpos"][: om.nq] = q; d.forward()
+        cd = np.array(d["contact_dist"][:8]); cp = np.array(d["contact_pos"][:24]).reshape(8, 3); fr = np.array(d["contact_frame"][:72]).reshape(8, 9)
+        gpos = np.array(d["geom_xpos"]).reshape(-1, 3); gmat = np.array(d["geom_xmat"]).reshape(-1, 9)
+        for f in range(2):
+            g = f                                            # collision geoms: left foot, right foot, floor
+            r, hl = float(model.a["cgeom_size"][f][0]), float(model.a["cgeom_size"][f][1])
+            ends = [gpos[g]] if kind == "sphere" else [gpos[g] + s * hl * gmat[g].reshape(3, 3)[:, 2] for s in (-1, 1)]
+            plane = lambda x: float(nrm @ x - z0 * nrm[2])          # signed distance to the plane through (0, 0, z0)
+            # only configurations where every kept contact is a face contact of a prism's TOP: normals equal the plane's
+            tops = [k for k in range(4 * f, 4 * f + len(ends)) if cd[k] < 0.5 and np.abs(fr[k][:3] - nrm).max() < 1e-9]
+            if len(tops) != len(ends):
+                continue
+            # the deepest contact is the deeper end's (the sphere's centre's): plane_sphere against the plane
+            np.testing.assert_allclose(min(cd[k] for k in tops), min(plane(e) - r for e in ends), atol=2e-9)
+            for k in tops:
+                # every kept contact sits under a point of the axis (a capsule's second contact is where a prism's side planes cut
+                # the axis, not the far end): that point is on the segment, its depth is the plane's, the position half a depth
+                # below the surface point
+                ax_pt = cp[k] + nrm * (r + 0.5 * cd[k])
+                a0, a1 = ends[0], ends[-1]
+                t = 0.0 if len(ends) == 1 else float(np.clip((ax_pt - a0) @ (a1 - a0) / ((a1 - a0) @ (a1 - a0)), 0, 1))
+                np.testing.assert_allclose(ax_pt, a0 + t * (a1 - a0), atol=2e-9)
+                np.testing.assert_allclose(cd[k], plane(ax_pt) - r, atol=2e-9)
+            assert (cd[4 * f + len(ends): 4 * f + 4] == 1.0).all()
+            checked += 1
+    assert checked >= 40, checked

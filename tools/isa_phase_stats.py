@@ -10,7 +10,7 @@ out = os.path.join(tempfile.gettempdir(), "odk_mark.s")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-load-store-vectorizer=0", "-DODK_MARK", *sys.argv[2:], "-S", "--cuda-device-only", "-o", out,
                        os.path.join(ROOT, "open_duck_playground_amd/csrc/odk_engine.hip")], stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z11step_kernel") and key in l and "Li32ELb0E" in l)
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z11step_kernel") and key in l and "Li32ELi0E" in l)
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 phase = "pre"
 stats = collections.OrderedDict()
