@@ -100,9 +100,10 @@ void odk_obs_sizes(int env_kind, int* nobs, int* npriv);
 
 /* mjx.put_model: parse a ModelBlob (open_duck_playground_amd/model.py; written by the MJCF compiler mjcf.py).
  * Colliders the kernels take: two feet -- convex meshes or boxes (cgeom_type 7: hull vertices + outward triangles), or spheres /
- * capsules on a plane floor (cgeom_type 2 / 3 with the optional record cgeom_size[ncgeom][3]: radius, half length) -- and one floor,
- * a plane (0) or a height field (1: hfield_data + hfield_size).  ODK_ERR_UNSUPPORTED for anything else (other foot types, primitive
- * feet on a height field, hulls with more than 17 vertices / 30 faces / 48 edges or faces of more than four vertices). */
+ * capsules (cgeom_type 2 / 3 with the optional record cgeom_size[ncgeom][3]: radius, half length) -- and one floor, a plane (0) or a
+ * height field (1: hfield_data + hfield_size).  ODK_ERR_UNSUPPORTED for anything else (other foot types, a hull foot beside a
+ * primitive one on a height field, feet wider than two height-field cells, hulls with more than 17 vertices / 30 faces / 48 edges
+ * or faces of more than four vertices). */
 int odk_model_load(const void* blob, uint64_t len, odk_model** out);
 void odk_model_free(odk_model* m);
 int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int* nbody);
