@@ -305,3 +305,26 @@ def test_loader_refuses_feet_wider_than_the_prism_window():
     a["hfield_size"] = np.array(a["hfield_size"], np.float64) * np.array([0.5, 0.5, 1, 1])     # same samples on half the area: cells 0.039 m
     with pytest.raises(engine.OdkError, match="smaller than two cells"):
         engine.model_reduction(Model(a))
+
+
+def test_loader_takes_primitive_feet_on_a_height_field_but_not_beside_a_hull():
+    """two sphere / capsule feet on the height-field floor load (their own kernel instantiation); a hull foot beside a
+    primitive one does not (hfield_contacts and hfield_prim_floor each work both feet)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _prim_feet_variant
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.mjcf import GEOM_MESH
+    from open_duck_playground_amd.model import Model, load_task_model
+    engine.model_reduction(_prim_feet_variant("rough_terrain_backlash", ("capsule", "sphere")))
+    base = load_task_model("rough_terrain_backlash")
+    prim = _prim_feet_variant("rough_terrain_backlash", ("sphere", "sphere"))
+    a = {k: np.array(v) for k, v in prim.a.items()}
+    for k in ("cgeom_type", "cgeom_pos", "cgeom_quat", "cgeom_vertnum", "cgeom_facenum", "cgeom_size"):   # foot 1 back to its hull
+        if k in base.a:
+            a[k][1] = np.asarray(base.a[k])[1]
+        else:
+            a[k][1] = 0
+    assert a["cgeom_type"][1] == GEOM_MESH
+    with pytest.raises(engine.OdkError, match="both feet are hulls"):
+        engine.model_reduction(Model(a, prim.xml_path))
