@@ -483,7 +483,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="physics mode: skip the short full-PPO legs attached as `secondary`")
-    ap.add_argument("--secondary-steps", type=int, default=6)
+    ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--secondary-timeout", type=float, default=240.0)
     args = ap.parse_args()
     if args.gpus < 1:
@@ -521,7 +521,7 @@ def main():
                 sec = []
                 for task in tasks:
                     try:
-                        leg = ppo_leg(ctx, task, envs, args.secondary_steps, 3, args.scaling)
+                        leg = ppo_leg(ctx, task, envs, args.secondary_steps, 4, args.scaling)
                         if rank == 0:
                             sec.append(_brief(leg))
                     except Exception as e:
