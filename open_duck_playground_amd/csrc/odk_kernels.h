@@ -774,7 +774,7 @@ __device__ __forceinline__ void row_params(const float* P, float pos, float invw
   }
   float imp = fminf(fmaxf(dmin + y * (dmax - dmin), dmin), dmax);
   if (x > 1.0f) imp = dmax;
-  D = imp / fmaxf(invweight * (1.0f - imp), MINVAL_F * imp);   // = 1 / max(invweight (1 - imp) / imp, MINVAL)
+  D = imp * __builtin_amdgcn_rcpf(fmaxf(invweight * (1.0f - imp), MINVAL_F * imp));   // = 1 / max(invweight (1 - imp) / imp, MINVAL); v_rcp_f32 (1 ulp), not the ten-instruction IEEE quotient
   aref = -b * vel - k * imp * pos;
 }
 
