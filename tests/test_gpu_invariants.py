@@ -76,3 +76,69 @@ def test_yaw_and_translation_invariance_on_the_plane(torch_cuda, parity_log, tas
                      beyond_1e_3=float((err_v[judged] > 1e-3).mean()), contact_set_differs=float(1.0 - judged.mean()),
                      qvel_median=float(np.median(err_v[judged])), qvel_worst=float(err_v[judged].max()))
     assert in_contact.mean() > 0.3, in_contact.mean()
+
+
+def test_shift_and_half_turn_invariance_on_a_periodic_height_field(torch_cuda, parity_log):
+    """The height-field kernel without the oracle: a terrain whose samples repeat every 8 cells and are even about the grid nodes
+    (z = a cos(2 pi i / 8) + b cos(2 pi j / 8)) is the same terrain after a shift by whole periods and after a half turn about a node
+    (the cells' diagonal split keeps its direction under a half turn, not under a quarter turn).  4096 states, half of them with
+    feet in the terrain, and their moved / turned copies, up to 6 m apart: after five substeps they agree in the robot's frame.  What
+    this exercises is the window arithmetic (cell indices, the window-relative coordinates that keep float32 digits), the prism
+    construction and the contact frames at different places of the field."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _random_states
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model, load_task_model
+    torch = torch_cuda
+    base = load_task_model("rough_terrain_backlash")
+    a = {k: np.array(v) for k, v in base.a.items()}
+    nr, nc = a["hfield_data"].shape
+    sx, sy, sz, _ = [float(v) for v in a["hfield_size"]]
+    dx, dy = 2 * sx / (nc - 1), 2 * sy / (nr - 1)
+    P = 8
+    gi = 0.5 + 0.3 * np.cos(2 * np.pi * np.arange(nc) / P); gj = 0.2 * np.cos(2 * np.pi * np.arange(nr) / P)
+    a["hfield_data"] = (gi[None, :] + gj[:, None] + 0.3).astype(np.float64)          # in [0, 1.3]: heights up to 1.3 cm
+    model = Model(a, base.xml_path)
+    n = 4096
+    rng = np.random.default_rng(23)
+    qpos, qvel = _random_states(model, n, rng)
+    qpos[:, 0] = rng.uniform(-2.5, 2.5, n); qpos[:, 1] = rng.uniform(-2.5, 2.5, n)
+    qpos[:, 2] += 0.008                                                              # about the terrain's mean height
+    qvel[:] = rng.normal(0, 0.3, qvel.shape)
+    turn = rng.integers(0, 2, n).astype(bool)                                         # half of the copies are turned by 180 degrees
+    kx, ky = rng.integers(-4, 5, n) * P, rng.integers(-4, 5, n) * P                   # whole periods (cells)
+    # x = -sx + i dx.  Shift: i' = i + kx.  Half turn about a node: i' = -i + t with t a multiple of the period -> x' = -x + (t - (nc - 1)) dx
+    tx, ty = (nc - 1) // P * P + kx, (nr - 1) // P * P + ky
+    c = np.where(turn, -1.0, 1.0)
+    Tx = np.where(turn, (tx - (nc - 1)) * dx, kx * dx); Ty = np.where(turn, (ty - (nr - 1)) * dy, ky * dy)
+    q2, v2 = qpos.copy(), qvel.copy()
+    q2[:, 0] = c * qpos[:, 0] + Tx; q2[:, 1] = c * qpos[:, 1] + Ty
+    qz = np.where(turn[:, None], np.array([[0.0, 0, 0, 1]]), np.array([[1.0, 0, 0, 0]]))
+    q2[:, 3:7] = _qmul(qz, qpos[:, 3:7])
+    v2[:, 0] = c * qvel[:, 0]; v2[:, 1] = c * qvel[:, 1]
+    assert np.abs(q2[:, :2]).max() < 9.5
+    ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.3, 0.3, (n, 14))
+    out = []
+    for q, v in ((qpos, qvel), (q2, v2)):
+        b = engine.Batch(model, n)
+        b.set_state(q, v, np.zeros((n, model.nv)))
+        b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 5)
+        gq, gv, _ = b.get_state()
+        img = b.lds_image(); o = b.lds_offset("contact_dist")
+        out.append((gq.astype(np.float64), gv.astype(np.float64), img[:, o: o + 12].copy()))
+        b.close()
+    (qa, va, ca), (qb, vb, cb) = out
+    xb = c * (qb[:, 0] - Tx); yb = c * (qb[:, 1] - Ty)
+    quat_b = _qmul(qz * np.array([1, -1, -1, -1.0]), qb[:, 3:7])
+    sign = np.sign((quat_b * qa[:, 3:7]).sum(1))[:, None]
+    err_q = np.maximum.reduce([np.abs(xb - qa[:, 0]), np.abs(yb - qa[:, 1]), np.abs(qb[:, 2] - qa[:, 2]), np.abs(sign * quat_b - qa[:, 3:7]).max(1), np.abs(qb[:, 7:] - qa[:, 7:]).max(1)])
+    err_v = np.maximum.reduce([np.abs(c * vb[:, 0] - va[:, 0]), np.abs(c * vb[:, 1] - va[:, 1]), np.abs(vb[:, 2:] - va[:, 2:]).max(1)]) / np.maximum(np.abs(va).max(1), 1.0)
+    in_contact = (ca[:, :8] < 0).any(1)
+    judged = ((ca < 0) == (cb < 0)).all(1)
+    parity_log.check("invariance/periodic_height_field", dict(qvel_q99=2.5e-4, qpos_q99=4e-6, beyond_1e_2=0.005, contact_set_differs=0.01),   # measured: 7.4e-5 (shifted 2.1e-5, turned 9.2e-5), 1.0e-6, 0, 0; median 3.4e-6, worst 2.1e-3
+                     qvel_q99=float(np.quantile(err_v[judged], 0.99)), qpos_q99=float(np.quantile(err_q[judged], 0.99)),
+                     beyond_1e_2=float((err_v[judged] > 1e-2).mean()), contact_set_differs=float(1.0 - judged.mean()),
+                     qvel_median=float(np.median(err_v[judged])), qvel_worst=float(err_v[judged].max()),
+                     qvel_q99_turned=float(np.quantile(err_v[judged & turn], 0.99)), qvel_q99_shifted=float(np.quantile(err_v[judged & ~turn], 0.99)))
+    assert in_contact.mean() > 0.3, in_contact.mean()
