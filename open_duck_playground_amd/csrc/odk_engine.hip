@@ -513,6 +513,8 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
   if (lane == 0) L[S::O_SCR + S::S_PROF + 18] = (float)(t_k1 - t_k0);
 #endif
   // ---- mjx_env.step: n_substeps x (forward + Euler)   (:420)
+  HotSt hot;
+  if constexpr (HF == 0) load_hot<S, G>(hot, m, st, lane);
   for (int s = 0; s < a.n_substeps; s++) {
     const bool last = s == a.n_substeps - 1;
     // The model pointer is made opaque once per substep: the per-lane 64-bit table addresses (and loop-invariant table
@@ -528,7 +530,8 @@ __global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
     int lane_s = lane;
     asm volatile("" : "+v"(lane_s));
     __builtin_assume(lane_s >= 0 && lane_s < 64);
-    forward_env<S, G, HF>(L, RT, ms, a.hfield, st, lane_s, last ? 1 : 0);
+    if constexpr (HF == 0) forward_env<S, G, HF, true>(L, RT, ms, a.hfield, st, lane_s, last ? 1 : 0, hot);
+    else forward_env<S, G, HF>(L, RT, ms, a.hfield, st, lane_s, last ? 1 : 0);
     if (last && a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
     euler_env<S, G>(L, ms, st, lane_s);
   }

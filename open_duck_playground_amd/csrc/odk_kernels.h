@@ -344,6 +344,10 @@ struct Statics : LaneSt {   // (data members: odk_model.h LaneSt)
 struct ActSt { float bias2, clo, chi, flo, fhi; int climited, flimited; };
 struct FlSt { float D, R, b; int dof; };
 
+// The same three records held over the whole launch instead (plane-floor kernels: ~40 registers are free there since round 3, and
+// each of these loads sat exposed right behind a phase hand-off in every substep)
+struct HotSt { ActSt as; FlSt fs; float vb[3]; };   // (the non-chain bodies' source lists the same way: +1 %, the limit rows' records: over the register budget)
+
 // Device side: the lane's host-built record (DevModel::lane_st, filled by compute_statics below at model load)
 template <class S, int G>
 __device__ __forceinline__ void load_statics(Statics<S, G>& st, const DevModel* __restrict__ m, int lane) {
@@ -419,6 +423,14 @@ __device__ __forceinline__ void load_act(ActSt& a, const DevModel* __restrict__ 
 __device__ __forceinline__ void load_fl(FlSt& f, const DevModel* __restrict__ m, int lane) {
   const int r = lane < m->nfl ? lane : 0;
   f.D = m->fl_D[r]; f.R = m->fl_R[r]; f.b = m->fl_b[r]; f.dof = m->fl_dof[r];
+}
+template <class S, int G>
+__device__ __forceinline__ void load_hot(HotSt& h, const DevModel* __restrict__ m, const Statics<S, G>& st, int lane) {
+  load_act(h.as, m, st.d_act);
+  load_fl(h.fs, m, lane);
+  const int f = (lane >> 4) & 1, j = lane & 15;   // plane-convex: foot f = 16-lane row f, lane j = hull vertex j
+  const int jv = (lane < 32 && j < m->foot_nvert[f]) ? j : 0;
+  for (int k = 0; k < 3; k++) h.vb[k] = m->foot_vert[f][jv][k];
 }
 // packed entries of the reduced layouts (DevModel::R_ent / RH_ent), -1 beyond the layout
 __device__ __forceinline__ int load_rent(const DevModel* __restrict__ m, int p, int n) { const int e = m->R_ent[p < n ? p : 0]; return p < n ? e : -1; }
@@ -1690,8 +1702,8 @@ __device__ __noinline__ void hfield_prim_floor(float* L, const DevModel* __restr
 }
 
 // HF: 0 = plane floor, 1 = height-field floor under the duck's mesh feet, 2 = height-field floor under sphere / capsule feet
-template <class S, int G, int HF>
-__device__ __forceinline__ void forward_env(float* L, const int* RT, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags) {
+template <class S, int G, int HF, bool PRE = false>
+__device__ __forceinline__ void forward_env(float* L, const int* RT, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags, const HotSt& hot = HotSt()) {
   // RT: the packed reduced entries (DevModel::R_ent) in LDS, one copy per workgroup (load_shared): every substep reads them
   // twice (inertia, Hessian), and a table load from the L2-resident model right behind a phase hand-off is ~300 exposed cycles.
   // Behind them (SH_CT): the contact-row constants -- pair_mu[3] | pair_invweight[3] | pair_imp[3][9] | plane_frame[9].
@@ -2057,7 +2069,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     const int u = st.d_act;
     if (u >= 0) {
       ActSt as;
-      load_act(as, m, u);
+      if constexpr (PRE) as = hot.as; else load_act(as, m, u);
       float ctrl = CTRL[u];
       if (as.climited) ctrl = fminf(fmaxf(ctrl, as.clo), as.chi);
       const float kp = KP[u];
@@ -2199,7 +2211,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     float w[3] = {0, 0, 0}, we[3] = {0, 0, 0}, sup = -3.0e38f, supe = -3.0e38f;
     {
       const int jv = has ? j : 0;
-      const float vb[3] = {m->foot_vert[f][jv][0], m->foot_vert[f][jv][1], m->foot_vert[f][jv][2]};
+      float vb[3];
+      if constexpr (PRE) { vb[0] = hot.vb[0]; vb[1] = hot.vb[1]; vb[2] = hot.vb[2]; } else { vb[0] = m->foot_vert[f][jv][0]; vb[1] = m->foot_vert[f][jv][1]; vb[2] = m->foot_vert[f][jv][2]; }
       const float ve[3] = {m->foot_vert[f][16][0], m->foot_vert[f][16][1], m->foot_vert[f][16][2]};
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -2305,7 +2318,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   // ---------------- P8: constraint rows: D, aref, contact wrenches
   // friction-loss rows: lane = row; limit rows: lane = dof that owns the limit; contact rows: rc = lane + t G
   FlSt fs;
-  load_fl(fs, m, lane);
+  if constexpr (PRE) fs = hot.fs; else load_fl(fs, m, lane);
   float fl_f = 0.0f, fl_rf = 0.0f;
   if (lane < nfl) {
     fl_f = FRL[fs.dof]; fl_rf = fs.R * fl_f;
