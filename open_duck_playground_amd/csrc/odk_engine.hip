@@ -1303,6 +1303,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       }
     }
   }
+  for (int f = 0; f < 2; f++) m.foot_sphere_r[f] = sqrtf(m.foot_obb_half[f][0] * m.foot_obb_half[f][0] + m.foot_obb_half[f][1] * m.foot_obb_half[f][1] + m.foot_obb_half[f][2] * m.foot_obb_half[f][2]);
   {   // a height-field prism's topology: the kernels' compile-time tables (odk_model.h) against this file's table builder
     const double pv[6][3] = {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {0, 0, 0}, {1, 0, 0}, {0, 1, 0}};
     const int ptri[8][3] = {{0, 1, 2}, {3, 5, 4}, {0, 3, 4}, {0, 4, 1}, {1, 4, 5}, {1, 5, 2}, {2, 5, 3}, {2, 3, 0}};

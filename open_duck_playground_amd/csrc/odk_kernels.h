@@ -2253,8 +2253,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         const float a2 = fP[1][k] + fR[1][3 * k] * m->foot_obb_center[1][0] + fR[1][3 * k + 1] * m->foot_obb_center[1][1] + fR[1][3 * k + 2] * m->foot_obb_center[1][2];
         dc[k] = a2 - a1;
       }
-      const float r1 = sqrtf(dot3(m->foot_obb_half[0], m->foot_obb_half[0])), r2 = sqrtf(dot3(m->foot_obb_half[1], m->foot_obb_half[1]));
-      sph = sqrtf(dot3(dc, dc)) - r1 - r2;
+      sph = sqrtf(dot3(dc, dc)) - m->foot_sphere_r[0] - m->foot_sphere_r[1];
     }
     float boxsep = -3.0e38f;
     if (__builtin_amdgcn_ballot_w64(!(sph > 0.0f)) != 0) {

@@ -125,6 +125,7 @@ struct DevModel {
   float foot_vert[2][MAXHV][3];  // hull vertices in the BODY frame (geom pos/quat folded in)
   int foot_face[2][MAXHF][3];
   float foot_obb_center[2][3], foot_obb_half[2][3], foot_obb_axes[2][9];  // body-frame OBB (columns = axes)
+  float foot_sphere_r[2];        // |foot_obb_half|: the bounding sphere of the foot-foot cull
   // convex-convex narrow phase (odk_convex.h): face polygons after the coplanar merge (count, then <= 4 vertices counter-clockwise
   // seen from outside), their outward normals in the BODY frame, unique edges (va, vb, face running va -> vb, face running
   // vb -> va), an interior point; built at load (odk_engine.hip build_convex_tables).
