@@ -14,6 +14,7 @@ opt gpurun_out/ltrace_${R}end/timeline.txt $P/learner_step_timeline.txt
 opt gpurun_out/ltrace_${R}end/stats.txt $P/learner_kernel_stats_top.txt
 opt gpurun_out/parity_worst.json $P/parity_worst.json
 opt $G/phase_profile_rough_terrain.txt $P/phase_profile_rough_terrain.txt   # ODK_LIB=.../libodk_prof.so python3 tools/gpu_phase_profile.py rough_terrain_backlash
+opt $G/phase_profile_flat_terrain.txt $P/phase_profile_flat_terrain.txt
 opt $G/hf_run_twice.txt $P/hf_run_twice.txt                                   # tools/gpu_hf_knock.sh 0 256 512 1024 2048 4096 8192 16384 0
 for t in flat backlash rough standing rough_up_normals; do opt gpurun_out/train_${R}end/$t/metrics.jsonl $P/train_${t}_metrics.jsonl; done
 opt gpurun_out/train_${R}end/wall.txt $P/train_wall_times.txt
