@@ -3,7 +3,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--reps R] [--envs E] [--task T] [--lanes G] [--scaling weak|strong]
                     [--no-cpu-baseline] [--no-secondary]
-    python bench.py --mode ppo [--task flat_terrain_backlash] [--gpus N] [--steps K] [--warmup W]      (BASELINE configs 3 / 4 / 5)
+    python bench.py --mode ppo [--task flat_terrain_backlash] [--gpus N] [--steps K] [--warmup W] [--force-split]      (BASELINE configs 3 / 4 / 5)
 
 `--gpus N` with N > 1 works both ways: under the driver's launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N`: RANK / WORLD_SIZE come from the environment and WORLD_SIZE must equal N) and as a plain `python bench.py --gpus N`, which
@@ -27,7 +27,9 @@ minibatch step), domain randomisation on; `value` = env steps per second INCLUDI
 
 Prints ONE JSON line with the driver's keys plus `roofline`, `cpu_baseline` (1 GPU) and `secondary`: short full-PPO legs run AFTER
 the headline's timed region and outside it -- BASELINE configs 3 and 4 on one GPU, config 5's shape (backlash model, envs sharded,
-flat-gradient all-reduce over RCCL per minibatch step) on N > 1 -- under a watchdog, so a failing leg can never cost the headline.
+flat-gradient all-reduce over RCCL per minibatch step) on N > 1 -- each leg in a fresh CHILD process (`bench.py --mode ppo`, one per
+rank) with a time limit, after the headline is measured: a leg that throws, hangs or takes the GPU runtime down costs its own entry
+in `secondary`, never the headline; the line is printed and THEN the exit code is 3 if a leg failed.
 """
 import argparse
 import json
@@ -223,7 +225,13 @@ def _clock_ramp(dev):
         torch.cuda.synchronize()
 
 
-_COUNTER_FILES = {"flat_terrain": "traffic.json", "flat_terrain_backlash": "traffic_backlash.json", "rough_terrain_backlash": "traffic_rough.json"}
+COUNTER_ROUNDS = ("r5", "r4", "r3", "r2")     # newest first: the newest round that holds a task's file wins
+
+
+def counter_file_name(task: str) -> str:
+    """The name tools/gpu_profile_round.sh gives a task's counter summary: `traffic.json` for the headline task, `traffic_<task>.json`
+    for every other one (tests/test_bench_launch.py checks that every benched task resolves to a committed file)."""
+    return "traffic.json" if task == "flat_terrain" else f"traffic_{task}.json"
 
 
 def _counters(task: str, envs: int):
@@ -232,17 +240,89 @@ def _counters(task: str, envs: int):
     float32 operations behind `valu_frac` and the active-lane fraction of the VALU instructions.  Counters cannot be read from
     inside this process; the newest round that holds the task's file wins and the file is named in the output.  Other sizes than
     the 8192 envs the passes ran at: nothing (`traffic` null)."""
-    name = _COUNTER_FILES.get(task)
-    if name is None or envs != 8192:
+    if envs != 8192:
         return {}, None
-    for rnd in ("r4", "r3", "r2"):
+    name = counter_file_name(task)
+    for rnd in COUNTER_ROUNDS:
         tpath = os.path.join(ROOT, "profiles", rnd, name)
         if os.path.exists(tpath):
             return json.load(open(tpath)), f"profiles/{rnd}/{name}"
     return {}, None
 
 
-def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "weak"):
+def _learner_counters():
+    """HBM bytes of ONE minibatch step of the learner (all its launches) from the committed counter passes over the full-PPO loop
+    (tools/gpu_learner_traffic.sh -> profiles/rN/learner_traffic.json), or ({}, None)."""
+    for rnd in COUNTER_ROUNDS:
+        tpath = os.path.join(ROOT, "profiles", rnd, "learner_traffic.json")
+        if os.path.exists(tpath):
+            return json.load(open(tpath)), f"profiles/{rnd}/learner_traffic.json"
+    return {}, None
+
+
+POLICY_DIMS, VALUE_DIMS = (101, 512, 256, 128, 28), (212, 512, 256, 128, 1)
+
+
+def learner_flops(mb: int, nets=(POLICY_DIMS, VALUE_DIMS)) -> dict:
+    """Matrix work of ONE minibatch step on `mb` samples, as the kernels do it: forward of every layer, backward-data of every layer
+    BUT THE FIRST (nobody needs the gradient w.r.t. the observations: include/odk.h, odk_mlp_backward), weight gradients of every
+    layer.  Reference sizes, mb = 5120: 5.03 + 3.39 + 5.03 = 13.46 GFLOP.  (Not counted: the value network's 256 bootstrap rows.)"""
+    fwd = sum(2.0 * mb * a * b for d in nets for a, b in zip(d[:-1], d[1:]))
+    bwd = sum(2.0 * mb * a * b for d in nets for a, b in zip(d[1:-1], d[2:]))
+    return {"fwd": fwd, "bwd": bwd, "dw": fwd, "total": fwd + bwd + fwd}
+
+
+def _matrix_launch_us(learner, reps: int = 50):
+    """Each of the learner's three matrix launches alone on its own buffers (HIP events on torch's current stream, which is the stream
+    the launches go to), microseconds per launch; `dw` includes its finishing launch.  None without the fused path."""
+    import torch
+    if learner is None or getattr(learner, "fused", None) is None:
+        return None
+    out = {}
+    for name, fn in (("fwd", learner.fused.forward), ("bwd", learner.fused.backward), ("dw", learner.dw_all)):
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); e1.synchronize()
+        out[name] = 1e3 * e0.elapsed_time(e1) / reps
+    return out
+
+
+def _split_learner_ms(net, opt, data, cfg, gen, steps: int):
+    """What the data-parallel form of a minibatch step costs WITHOUT a second GPU (`--force-split`): a one-rank RCCL group and
+    (a) the single-GPU step (one graph, for reference: timed the same way), (b) graph A -> host-issued all-reduce -> graph B with the
+    gradient norm in its own launch (what N > 1 ranks run), (c) the same step with the all-reduce CAPTURED inside one graph (one
+    replay per step again).  Learner milliseconds per training step of each (128 minibatch steps + their preparation)."""
+    import torch
+    import torch.distributed as dist
+    from open_duck_playground_amd.ppo import train as T
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29653")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    res = {}
+    for key, kw in (("learner_ms_one_graph", dict(split_update=False)), ("learner_ms_split", dict(split_update=True)),
+                    ("learner_ms_allreduce_captured", dict(split_update=True, capture_allreduce=True))):
+        try:
+            lr = T.make_learner(net, data, cfg, 1, dist.group.WORLD, **kw)
+            for _ in range(2):
+                T.sgd_epoch(net, opt, data, cfg, gen, 1, dist.group.WORLD, learner=lr, meter=T.LossMeter())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                T.sgd_epoch(net, opt, data, cfg, gen, 1, dist.group.WORLD, learner=lr, meter=T.LossMeter())
+            e1.record(); e1.synchronize()
+            res[key] = round(e0.elapsed_time(e1) / steps, 3)
+            lr.close()
+        except Exception as e:
+            res[key] = f"failed: {type(e).__name__}: {e}"
+    dist.destroy_process_group()
+    return res
+
+
+def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "weak", force_split: bool = False):
     """K full PPO training steps after W warm-up ones on this rank's `envs` envs (BASELINE configs 3 / 4 on 1 GPU, 5 on N: envs
     sharded, flat gradient all-reduced over RCCL in each of the 128 minibatch steps).  Returns the result line on rank 0."""
     import numpy as np
@@ -308,14 +388,20 @@ def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "
         torch.cuda.synchronize()
         allreduce_ms = 1e3 * (time.perf_counter() - ta)
     env_steps = world * envs * cfg["unroll_length"] * steps
+    launch_us = _matrix_launch_us(learner) if rank == 0 else None
+    split = _split_learner_ms(net, opt, data, cfg, gen, steps) if (force_split and world == 1) else None
     out = None
     if rank == 0:
-        # learner roofline (the training step's dominant part): f32 matrix-core work of the three whole-network kernels
+        # learner roofline (the training step's dominant part): f32 matrix-core work of the three whole-network kernels, counted as
+        # the kernels do it (no input gradient of the first layer)
         mb = envs * cfg["unroll_length"] // cfg["num_minibatches"]
-        flop_step = 0.0
-        for dims in ((101, 512, 256, 128, 28), (212, 512, 256, 128, 1)):
-            flop_step += 3 * sum(2.0 * mb * a * b for a, b in zip(dims[:-1], dims[1:]))      # forward + backward-data + weight gradients
-        achieved = nsgd * flop_step / (learner_ms * 1e-3) / 1e12 if learner_ms > 0 else 0.0
+        fl = learner_flops(mb, ((env.observation_size["state"][0], 512, 256, 128, 2 * env.action_size), (env.observation_size["privileged_state"][0], 512, 256, 128, 1)))
+        achieved = nsgd * fl["total"] / (learner_ms * 1e-3) / 1e12 if learner_ms > 0 else 0.0
+        cnt, csrc = _learner_counters() if (envs == 8192 and world == 1) else ({}, None)
+        per_launch = None
+        if launch_us:
+            per_launch = {k: {"us": round(launch_us[k], 2), "gflop": round(fl[k] / 1e9, 3), "tflops": round(fl[k] / (launch_us[k] * 1e-6) / 1e12, 1),
+                              "frac": round(fl[k] / (launch_us[k] * 1e-6) / 1e12 / VALU_PEAK_TFLOPS, 3)} for k in ("fwd", "bwd", "dw")}
         out = {
             "metric": METRIC, "value": round(env_steps / elapsed, 1), "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": max(warmup, 1),
             "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
@@ -331,10 +417,16 @@ def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "
                        "learner_path": "fused whole-network kernels" if (learner is not None and getattr(learner, "fused", None) is not None) else "library GEMMs / autograd",
                        "reward_per_step_last_rollout": round(float(data["reward"].mean()), 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
-                         "traffic": None, "kernel": "mlp_fwd_kernel + mlp_bwd_kernel + dw_gemm_kernel (learner, f32 matrix cores)",
-                         "note": "algorithmic FLOPs of the 128 minibatch steps / learner time (HIP events), incl. the element-wise launches between them; "
-                                 "peak = dense f32 MFMA"},
+                         "traffic": cnt.get("hbm_bytes_per_sgd_step"), "counter_source": csrc,
+                         "kernel": "mlp_fwd_kernel + mlp_bwd_kernel + dw_gemm_kernel (learner, f32 matrix cores)",
+                         "gflop_per_sgd_step": round(fl["total"] / 1e9, 3), "matrix_launches": per_launch,
+                         "note": "achieved = matrix FLOPs of the 128 minibatch steps as the kernels do them (forward + backward-data without the first layer + weight "
+                                 "gradients) / learner time (HIP events), i.e. INCLUDING the element-wise launches between them; matrix_launches = each of the three "
+                                 "matrix launches alone (HIP events around 50 launches on the learner's own buffers, after the timed region); traffic = HBM bytes of one "
+                                 "minibatch step from the committed counter passes; peak = dense f32 MFMA"},
         }
+        if split is not None:
+            out["config"].update(split)
     if learner is not None:
         learner.close()
     env.close() if hasattr(env, "close") else None
@@ -433,32 +525,42 @@ def physics_leg(ctx, args, envs: int):
     }
 
 
-class _Watchdog:
-    """The secondary legs run after the headline is measured but before it is printed (the driver wants ONE line): if a leg
-    hangs -- config 5's RCCL path has never met more than one GPU on the build box -- every rank's timer fires, rank 0 prints the
-    headline with the failure recorded in `secondary`, and the process leaves through os._exit (a stuck collective cannot be
-    joined)."""
-
-    def __init__(self, seconds: float, rank: int, line: dict):
-        import threading
-        self.line, self.rank = line, rank
-        self.t = threading.Timer(seconds, self._fire)
-        self.t.daemon = True
-        self.seconds = seconds
-
-    def _fire(self):
-        if self.rank == 0:
-            self.line.setdefault("secondary", []).append({"error": f"watchdog: secondary legs still running after {self.seconds:.0f} s; abandoned"})
-            print(json.dumps(self.line), flush=True)
-        os._exit(0)
-
-    def __enter__(self):
-        self.t.start()
-        return self
-
-    def __exit__(self, *exc):
-        self.t.cancel()
-        return False
+def _secondary_child(ctx, task: str, envs_arg: int, scaling: str, steps: int, timeout: float, leg_index: int):
+    """One full-PPO leg in a FRESH CHILD PROCESS per rank (`bench.py --mode ppo ...`, started with subprocess -- never an exec -- after
+    this process has measured the headline): a hard fault in a leg (a GPU memory fault aborting the HSA runtime, a SIGSEGV in the
+    library, a stuck collective) ends the child, not the process that holds the headline.  Under N > 1 ranks every rank starts its
+    own child with the launcher's RANK / LOCAL_RANK / WORLD_SIZE and a rendezvous port of its own.  Returns (result line or None,
+    error text or None); a child past `timeout` is killed by its exact PID."""
+    import subprocess
+    rank, world = ctx[0], ctx[1]
+    env = dict(os.environ)
+    if world > 1:
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 101 + leg_index)
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the child ranks rendezvous among themselves: rank 0's child hosts the store on the new port
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "ppo", "--task", task, "--gpus", str(world), "--envs", str(envs_arg), "--scaling", scaling,
+           "--steps", str(steps), "--warmup", "4"]
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except OSError as e:
+        return None, f"could not start the leg: {e}"
+    try:
+        so, se = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        so, se = p.communicate()
+        return None, f"leg still running after {timeout:.0f} s: killed"
+    if p.returncode != 0:
+        tail = " | ".join([l for l in se.strip().splitlines() if l.strip()][-3:])
+        return None, f"leg exited with code {p.returncode}: {tail[-400:]}"
+    if rank != 0:
+        return None, None
+    lines = [l for l in so.splitlines() if l.startswith("{")]
+    if not lines:
+        return None, "leg printed no result line"
+    try:
+        return json.loads(lines[-1]), None
+    except ValueError as e:
+        return None, f"leg's result line does not parse: {e}"
 
 
 def _brief(leg: dict) -> dict:
@@ -467,7 +569,7 @@ def _brief(leg: dict) -> dict:
             "unit": leg["unit"], "n_gpus": leg["n_gpus"], "steps": leg["steps"], "warmup": leg["warmup"], "ms_per_step": leg["ms_per_step"],
             "envs_per_gpu": c["envs_per_gpu"], "rollout_ms": c["rollout_ms_per_training_step"], "learner_ms": c["learner_ms_per_training_step"],
             "allreduce_ms_isolated": c["allreduce_ms_per_training_step_isolated"], "learner_path": c["learner_path"],
-            "roofline": {k: leg["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}}
+            "roofline": {k: leg["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "counter_source", "gflop_per_sgd_step", "matrix_launches")}}
 
 
 def main():
@@ -484,7 +586,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="physics mode: skip the short full-PPO legs attached as `secondary`")
     ap.add_argument("--secondary-steps", type=int, default=10)
-    ap.add_argument("--secondary-timeout", type=float, default=240.0)
+    ap.add_argument("--secondary-timeout", type=float, default=300.0, help="seconds for ALL secondary legs together (each child gets an equal share)")
+    ap.add_argument("--force-split", action="store_true", help="ppo mode, 1 GPU: also time the data-parallel form of the minibatch step on a one-rank RCCL group "
+                    "(graph A -> all-reduce -> graph B, and the all-reduce captured in one graph)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -498,7 +602,7 @@ def main():
 
     if args.mode == "ppo":
         out = ppo_leg(ctx, args.task or "flat_terrain_backlash", envs, args.steps if args.steps is not None else 10,
-                      args.warmup if args.warmup is not None else 3, args.scaling)
+                      args.warmup if args.warmup is not None else 3, args.scaling, args.force_split)
         if rank == 0:
             print(json.dumps(out), flush=True)
     else:
@@ -513,29 +617,29 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.task)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": usable_cores(), "kind": "port", "sample": f"failed: {e}"}
+        failed = 0
         if not args.no_secondary:
-            # BASELINE configs 3 / 4 (1 GPU) or 5's shape (N GPUs) as short full-PPO legs, outside the headline's timed region
+            # BASELINE configs 3 / 4 (1 GPU) or 5's shape (N GPUs) as short full-PPO legs, outside the headline's timed region, each in
+            # a child process of its own; the headline is already measured and is printed whatever the legs do
             tasks = ["flat_terrain_backlash", "rough_terrain_backlash"] if world == 1 else ["flat_terrain_backlash"]
-            line = out if rank == 0 else {}
-            with _Watchdog(args.secondary_timeout, rank, line):
-                sec = []
-                for task in tasks:
-                    try:
-                        leg = ppo_leg(ctx, task, envs, args.secondary_steps, 4, args.scaling)
-                        if rank == 0:
-                            sec.append(_brief(leg))
-                    except Exception as e:
-                        err = {"task": task, "mode": "ppo", "error": f"{type(e).__name__}: {e}"}
-                        if world > 1:   # a rank that skips a leg leaves the others inside its collectives: the headline goes out
-                            if rank == 0:       # now, the other ranks leave through their own watchdogs
-                                out["secondary"] = sec + [err]
-                                print(json.dumps(out), flush=True)
-                            os._exit(0)
-                        sec.append(err)
-                if rank == 0:
-                    out["secondary"] = sec
+            if world > 1:
+                dist.barrier()          # every rank has finished the headline before any rank's child claims its GPU
+            sec = []
+            for k, task in enumerate(tasks):
+                leg, err = _secondary_child(ctx, task, args.envs, args.scaling, args.secondary_steps, args.secondary_timeout / len(tasks), k)
+                if err is not None:
+                    failed += 1
+                    sec.append({"task": task, "mode": "ppo", "error": err})
+                elif leg is not None:
+                    sec.append(_brief(leg))
+            if rank == 0:
+                out["secondary"] = sec
         if rank == 0:
             print(json.dumps(out), flush=True)
+        if failed:
+            # the headline went out; a failed / abandoned leg still shows in the exit code (and in `secondary`)
+            sys.stdout.flush()
+            os._exit(3)        # (a rank whose peers' children are stuck cannot join them through destroy_process_group)
     if world > 1:
         dist.destroy_process_group()
 

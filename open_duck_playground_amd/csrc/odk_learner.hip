@@ -22,6 +22,7 @@
 #include "../../include/odk.h"
 
 int odk_fail_(int code, const char* msg);   // odk_engine.hip
+int odk_func_lds_attr_(const void* fn, int slot, int bytes);   // odk_mlp.hip
 
 namespace {
 
@@ -786,8 +787,7 @@ extern "C" int odk_dw_gemm(const float* const* dz_dev, const float* const* h_dev
   hipStream_t st = (hipStream_t)stream;
   // 80 KB of LDS per two-wave workgroup (32 KB used by the fold): at most two of them per CU, i.e. one wave per SIMD when the XCD's
   // slots are all taken
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)dw_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; }
+  if (odk_func_lds_attr_((const void*)dw_gemm_kernel, 0, 80 * 1024)) return odk_fail_(ODK_ERR_HIP, "odk_dw_gemm: the device refuses 80 KB of dynamic LDS per workgroup");
   hipLaunchKernelGGL(dw_gemm_kernel, dim3(a.nslots * 8), dim3(64 * DW_WAVES), 80 * 1024, st, a);
   long long total = 0;
   for (int l = 0; l < nlayers; l++) total += rg.count[l];

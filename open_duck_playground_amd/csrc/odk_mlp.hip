@@ -661,8 +661,8 @@ int fill_args(Args& a, const odk_mlp_desc* nets, int count, bool backward, int& 
   // the tile deal (struct Map): two networks, more tiles than CUs, fewer than 4 per CU (all resident at once)
   Map& m = a.map;
   memset(&m, 0, sizeof(m));
-  static int cus = 0;
-  if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
+  int cus = 0, dev = 0;     // (per call: the current device's, not the first one's)
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   if (count == 2 && tiles > cus && tiles <= 4 * cus && tiles % cus != 0 && !getenv("ODK_MLP_NO_DEAL")) {
     const int nt[2] = {a.net[1].tile0, tiles - a.net[1].tile0};
     m.R = cus; m.rounds = tiles / cus; m.rem = tiles % cus;
@@ -692,6 +692,22 @@ int fill_table(WeightTable& t, const odk_weight_table* h, long long n, long long
 
 }  // namespace
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: set once per (kernel slot, device ordinal) -- a process that drives a
+// second device must set it there too -- under a lock, return code checked.  (Once, not per call: the first call of a kernel is a warm-up
+// launch outside any stream capture.)  Returns non-zero on failure.
+#include <mutex>
+int odk_func_lds_attr_(const void* fn, int slot, int bytes) {
+  static std::mutex mu;
+  static bool done[4][64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || slot < 0 || slot >= 4) return 1;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done[slot][dev]) return 0;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return 1;
+  done[slot][dev] = true;
+  return 0;
+}
+
 // tools: device buffer of 32 int64 that receives the forward kernel's phase timestamps (workgroup 0); NULL switches it off
 extern "C" void odk_mlp_set_profile(long long* stamps_dev) { g_prof = stamps_dev; }
 // tools: device buffer of 4 x (workgroups of a network launch) int64: start / end (100 MHz wall clock), HW_ID | XCC_ID << 32, shader cycles
@@ -703,8 +719,7 @@ extern "C" int odk_mlp_forward(const odk_mlp_desc* nets, int count, void* stream
   if (!nets || count < 1 || count > 2) return odk_fail_(ODK_ERR_INVALID, "odk_mlp_forward: 1 or 2 networks");
   Args a; int tiles; const char* err = nullptr;
   if (fill_args(a, nets, count, false, tiles, err)) return odk_fail_(ODK_ERR_INVALID, err);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F_TOTAL * 4); attr = true; }
+  if (odk_func_lds_attr_((const void*)mlp_fwd_kernel, 1, F_TOTAL * 4)) return odk_fail_(ODK_ERR_HIP, "odk_mlp_forward: the device refuses the kernel's dynamic LDS size");
   hipLaunchKernelGGL(mlp_fwd_kernel, dim3(tiles), dim3(256), F_TOTAL * 4, (hipStream_t)stream, a);
   return check_launch("odk_mlp_forward: launch failed");
 }
@@ -713,8 +728,7 @@ extern "C" int odk_mlp_backward(const odk_mlp_desc* nets, int count, void* strea
   if (!nets || count < 1 || count > 2) return odk_fail_(ODK_ERR_INVALID, "odk_mlp_backward: 1 or 2 networks");
   Args a; int tiles; const char* err = nullptr;
   if (fill_args(a, nets, count, true, tiles, err)) return odk_fail_(ODK_ERR_INVALID, err);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B_TOTAL * 4); attr = true; }
+  if (odk_func_lds_attr_((const void*)mlp_bwd_kernel, 2, B_TOTAL * 4)) return odk_fail_(ODK_ERR_HIP, "odk_mlp_backward: the device refuses the kernel's dynamic LDS size");
   hipLaunchKernelGGL(mlp_bwd_kernel, dim3(tiles), dim3(256), B_TOTAL * 4, (hipStream_t)stream, a);
   return check_launch("odk_mlp_backward: launch failed");
 }

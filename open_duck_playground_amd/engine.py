@@ -654,6 +654,7 @@ class Batch:
         self.metrics = torch.zeros(self.nenv, NMETRIC, **f32)
         self._outs = Outputs(self.obs.data_ptr(), self.priv.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
                              self.truncation.data_ptr(), self.metrics.data_ptr())
+        self.generation = 0          # advanced by every call that rewrites the per-env records (reset / step / set_records): `State.info` checks it
 
     # -- streams: calls are ordered on torch's current stream
     def _stream(self):
@@ -668,10 +669,12 @@ class Batch:
         _chk(self.L.odk_batch_set_param(self._b, param, _fp(v), v.shape[1]))
 
     def reset(self, seed: int, env_id_offset: int = 0):
+        self.generation += 1
         _chk(self.L.odk_reset(self._b, seed & 0xFFFFFFFF, env_id_offset, C.byref(self._outs), self._stream()))
 
     def step(self, action):
         assert action.is_cuda and action.dtype == self.torch.float32 and action.is_contiguous() and tuple(action.shape) == (self.nenv, NU)
+        self.generation += 1
         _chk(self.L.odk_step(self._b, C.c_void_p(action.data_ptr()), C.byref(self._outs), self._stream()))
 
     def physics_step(self, ctrl, n_substeps: int = 10):
@@ -716,6 +719,7 @@ class Batch:
     def set_records(self, records: np.ndarray):
         r = np.ascontiguousarray(records, np.float32)
         assert r.shape == (self.nenv, self.L.odk_batch_record_size(self._b))
+        self.generation += 1
         _chk(self.L.odk_batch_set_records(self._b, _fp(r)))
 
     INFO_FIELDS = ("rng", "step", "command", "last_act", "last_last_act", "last_last_last_act", "motor_targets", "feet_air_time", "last_contact",

@@ -129,22 +129,35 @@ class _Info(dict):
     feet_air_time, last_contact, swing_peak, push, push_step, push_interval_steps, action_history, imu_history, imitation_i, and
     steps / episode_done / episode_metrics/* -- lives in the engine's per-env record on the device and is copied out ON FIRST USE
     (one synchronous read of the records per State, `Batch.info()` -> `odk_record_field`): reading `info["command"]` works like
-    in the reference, it is just not free.  Values are tensors on the env's device, [N, ...]; `last_contact` is bool [N, 2].
+    in the reference, it is just not free.  Every way of reading a dict triggers that fetch: `[]`, `get`, `in`, iteration, `keys` /
+    `values` / `items`, `len`, `dict(info)`, `copy`.  Values are tensors on the env's device, [N, ...]; `last_contact` is bool [N, 2].
+
+    The reference's info is an immutable snapshot; the engine is stateful and keeps ONE set of records.  A State whose info has not
+    been fetched yet when the env moves on (a later `reset` / `step` / `set_records`) can no longer produce its own step's values:
+    reading it then raises `RuntimeError` instead of silently returning the newer step's (fetch what you need before stepping on).
     Writing goes through `Batch.info()` / `set_records` (the reference's functional update has no counterpart on a stateful engine)."""
 
     def __init__(self, batch, truncation):
         super().__init__(truncation=truncation)
         self._batch = batch
+        self._generation = batch.generation
+        self._fetched = False
 
     def _fetch(self):
+        if self._fetched:
+            return
+        if self._batch.generation != self._generation:
+            raise RuntimeError("State.info: the env has been stepped / reset since this State was made and its info was never read; "
+                               "the engine holds only the current records (read info before the next step)")
         import torch
         I = self._batch.info()
-        dev = self["truncation"].device
+        dev = dict.__getitem__(self, "truncation").device
         for k in self._batch.INFO_FIELDS:
             if k == "truncation":
                 continue
             v = self._batch.last_contact_bool(I) if k == "last_contact" else I[k]
             dict.__setitem__(self, k, torch.from_numpy(np.ascontiguousarray(v)).to(dev))
+        self._fetched = True
 
     def __missing__(self, key):
         if key in self._batch.INFO_FIELDS:
@@ -154,6 +167,36 @@ class _Info(dict):
 
     def __contains__(self, key):
         return dict.__contains__(self, key) or key in self._batch.INFO_FIELDS
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __iter__(self):
+        self._fetch()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fetch()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._fetch()
+        return dict.keys(self)
+
+    def values(self):
+        self._fetch()
+        return dict.values(self)
+
+    def items(self):
+        self._fetch()
+        return dict.items(self)
+
+    def copy(self):
+        self._fetch()
+        return dict(dict.items(self))
 
 
 class Joystick:

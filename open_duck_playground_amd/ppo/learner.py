@@ -245,9 +245,13 @@ class FlatLearner:
     KEYS = ("obs", "priv", "raw_action", "log_prob", "reward", "termination", "truncation")
 
     def __init__(self, net: PPONetworks, cfg: Dict, B: int, T: int, world: int = 1, group=None, use_graph: bool = True,
-                 split_update=None, fused_norm: bool = True):
+                 split_update=None, fused_norm: bool = True, capture_allreduce=None):
         """`split_update` (default: world > 1) runs the step as graph A (loss + gradients) -> all-reduce of the flat gradient
         -> graph B (clip + Adam); tests force it at world size 1 to drive the RCCL stream hand-over on one GPU.
+        `capture_allreduce` (default: $ODK_LEARNER_CAPTURE_ALLREDUCE == "1"; needs a process group on the RCCL backend): the
+        all-reduce is CAPTURED between the two halves, so a data-parallel step is ONE graph replay again (c10d records the
+        collective on its own stream inside the capture; no host-issued call between two replays).  Opt-in: measured on a one-rank
+        group only (`bench.py --mode ppo --force-split`), no multi-GPU box has run it.
         `fused_norm` false: the gradient norm from its own launch even without an all-reduce (the summation order of the split
         path: tests compare the two bit for bit)."""
         dev = next(net.parameters()).device
@@ -274,6 +278,9 @@ class FlatLearner:
         self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
         fused = self.policy.fused_ok() and self.value.fused_ok() and n >= 128   # (the weight-gradient launch wants >= 8 rows per slice)
         self.split_update = world > 1 if split_update is None else bool(split_update)
+        if capture_allreduce is None:
+            capture_allreduce = os.environ.get("ODK_LEARNER_CAPTURE_ALLREDUCE") == "1"
+        self.capture_allreduce = bool(capture_allreduce) and self.split_update and use_graph and (world > 1 or group is not None)
         self.policy.bind(self.static["obs"].view(n, -1), self.dlogits, fused)
         self.value.bind(self.priv_all, self.dval_all, fused)
         # whole-network launches (csrc/odk_mlp.hip): forward of both networks = 1 launch, backward-data of both = 1 launch, the
@@ -393,7 +400,11 @@ class FlatLearner:
         tuned = _tunable(True) if (self.cfg.get("tune_gemms", True) and self.fused is None) else False
         with torch.cuda.stream(side):               # warm-up outside capture (hipBLASLt workspaces, allocator, GEMM tuning)
             for _ in range(2):
-                self._draw_noise(); self._loss_and_grads(); self._update()
+                self._draw_noise(); self._loss_and_grads()
+                if self.capture_allreduce:      # (the communicator must exist before a capture can record a collective on it)
+                    import torch.distributed as dist
+                    dist.all_reduce(self.flat_g, group=self.group)
+                self._update()
         torch.cuda.current_stream().wait_stream(side)
         if tuned:
             _tunable(False)                         # keep the selected kernels, never tune inside a capture
@@ -406,7 +417,11 @@ class FlatLearner:
             self._loss_and_grads()                  # the noise buffer is filled before each replay (load_minibatch)
             if not self.split_update:
                 self._update()
-        if self.split_update:
+            elif self.capture_allreduce:
+                import torch.distributed as dist
+                dist.all_reduce(self.flat_g, group=self.group)
+                self._update()
+        if self.split_update and not self.capture_allreduce:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b):
                 self._update()
@@ -435,7 +450,7 @@ class FlatLearner:
             self._loss_and_grads()
             if not self.split_update:
                 self._update()
-        if self.split_update:
+        if self.split_update and not (self.capture_allreduce and self.graph_a is not None):
             if self.world > 1 or self.group is not None:
                 import torch.distributed as dist
                 # RCCL: the collective runs on the process group's own stream; c10d makes that stream wait for the current

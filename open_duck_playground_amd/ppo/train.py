@@ -161,14 +161,15 @@ def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Gen
     return meter.mean(world, group) if own else None
 
 
-def make_learner(net, data, cfg, world: int = 1, group=None):
-    """FlatLearner for CUDA rollouts whose trajectory count divides into the minibatches; None (autograd path) otherwise."""
+def make_learner(net, data, cfg, world: int = 1, group=None, **learner_kw):
+    """FlatLearner for CUDA rollouts whose trajectory count divides into the minibatches; None (autograd path) otherwise.
+    `learner_kw`: FlatLearner options (`split_update`, `capture_allreduce`, `fused_norm`)."""
     B = data["reward"].shape[0]
     if not data["reward"].is_cuda or B % cfg["num_minibatches"] != 0 or not cfg.get("use_graphs", True):
         return None
     from .learner import FlatLearner
     return FlatLearner(net, cfg, B // cfg["num_minibatches"], data["reward"].shape[1], world, group,
-                       use_graph=os.environ.get("ODK_LEARNER_GRAPH", "1") != "0")
+                       use_graph=os.environ.get("ODK_LEARNER_GRAPH", "1") != "0", **learner_kw)
 
 
 class _RolloutBuffers:

@@ -34,3 +34,36 @@ def test_plain_command_starts_n_ranks():
 def test_no_gpu_no_number():
     out = _run(["--steps", "1", "--warmup", "0"])
     assert out.returncode != 0 and "needs a HIP device" in out.stderr
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("odk_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_every_benched_task_finds_its_counter_file():
+    """bench.py names a task's counter summary the way tools/gpu_profile_round.sh writes it, and a committed file exists for each of
+    the three tasks (a lookup that silently misses reports `traffic: null` and falls back to the FLOP estimate)."""
+    b = _bench_module()
+    for task in ("flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"):
+        cnt, src = b._counters(task, 8192)
+        assert src is not None and os.path.exists(os.path.join(ROOT, src)), task
+        assert src.endswith(b.counter_file_name(task))
+        assert cnt.get("hbm_bytes_per_launch", 0) > 1e7 and cnt.get("valu_flop_per_launch", 0) > 1e9, task
+    assert b._counters("flat_terrain", 4096) == ({}, None)
+    script = open(os.path.join(ROOT, "tools", "gpu_profile_round.sh")).read()
+    assert '[ $TASK != flat_terrain ] && SFX="_$TASK"' in script and "$OUT/traffic$SFX.json" in script       # the naming rule the lookup mirrors
+
+
+def test_learner_flop_count_is_the_work_the_kernels_do():
+    """13.46 GFLOP per minibatch step at the reference sizes: forward 5.03 + backward-data WITHOUT the first layer 3.39 + weight
+    gradients 5.03 (include/odk.h: odk_mlp_backward never forms the gradient w.r.t. the network input)."""
+    b = _bench_module()
+    fl = b.learner_flops(5120)
+    pol, val = 101 * 512 + 512 * 256 + 256 * 128 + 128 * 28, 212 * 512 + 512 * 256 + 256 * 128 + 128 * 1
+    assert fl["fwd"] == fl["dw"] == 2.0 * 5120 * (pol + val)
+    assert fl["bwd"] == 2.0 * 5120 * (pol - 101 * 512 + val - 212 * 512)
+    assert abs(fl["total"] / 1e9 - 13.46) < 0.01

@@ -206,6 +206,30 @@ def test_bench_secondary_legs_on_one_gpu():
         assert abs(s["value"] - 512 * 20 * 2 / (s["ms_per_step"] * 2 / 1e3)) / s["value"] < 1e-3
 
 
+def test_bench_failed_leg_keeps_the_headline_and_shows_in_the_exit_code():
+    """A secondary leg that does not finish (here: a time limit no leg can meet) is killed; the headline line still goes out, the leg's
+    entry in `secondary` says what happened, and the exit code is 3 -- not 0."""
+    out, lines = _bench(["--steps", "20", "--warmup", "5", "--envs", "512", "--secondary-steps", "2", "--no-cpu-baseline", "--secondary-timeout", "1"])
+    assert out.returncode == 3, (out.returncode, out.stderr[-2000:])
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = lines[0]
+    assert d["value"] > 0 and d["config"]["mode"] == "physics"
+    assert len(d["secondary"]) == 2 and all("killed" in s["error"] for s in d["secondary"]), d["secondary"]
+
+
+def test_bench_force_split_reports_the_data_parallel_cost_on_one_gpu():
+    """--mode ppo --force-split: the minibatch step's data-parallel form on a ONE-rank RCCL group -- graph A -> all-reduce -> graph B, and
+    the all-reduce captured inside one graph -- timed beside the single-GPU step."""
+    out, lines = _bench(["--mode", "ppo", "--force-split", "--steps", "1", "--warmup", "1", "--envs", "256"], extra_env={"ODK_BENCH_BACKEND": "nccl"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    c = lines[0]["config"]
+    for k in ("learner_ms_one_graph", "learner_ms_split", "learner_ms_allreduce_captured"):
+        assert isinstance(c[k], float) and c[k] > 0, (k, c[k])
+    assert c["learner_ms_allreduce_captured"] < 1.5 * c["learner_ms_one_graph"]
+    ml = lines[0]["roofline"]["matrix_launches"]
+    assert set(ml) == {"fwd", "bwd", "dw"} and all(v["us"] > 0 for v in ml.values())
+
+
 @pytest.mark.parametrize("ranks", [1, 2])
 def test_bench_ppo_mode(ranks):
     """bench.py --mode ppo (BASELINE configs 3 / 5): full training steps -- rollout with the policy in the loop + 128 minibatch
@@ -487,7 +511,7 @@ def test_info_accessor_names_the_reference_keys(oracle_mod):
         if e["done"][0] == 0:
             np.testing.assert_allclose(J["last_act"][i], act[i], atol=1e-7)
             assert int(J["step"][i]) == int(e.ints("step")[0]) == 1 and int(J["imitation_i"][i]) == int(e.ints("imitation_i")[0])
-            assert list(engine.Batch.last_contact_bool(J)[i]) == [bool(x) for x in e.ints("last_contact")[:2]] or True
+            assert list(engine.Batch.last_contact_bool(J)[i]) == [bool(x) for x in e.ints("last_contact")[:2]]
     qpos, qvel, _ = b.get_state()
     o, c, _k = b.record_field("qvel")
     np.testing.assert_array_equal(J["_records"][:, o:o + c], qvel)
@@ -516,3 +540,17 @@ def test_state_info_reads_like_the_reference():
     np.testing.assert_array_equal(st2.info["command"].cpu().numpy(), env.batch.info()["command"])
     with pytest.raises(KeyError):
         st2.info["no_such_key"]
+    # every way of reading a dict triggers the fetch (not only `[]`)
+    st3 = env.step(st2, act)
+    assert st3.info.get("command") is not None and st3.info.get("no_such_key", 7) == 7
+    st4 = env.step(st3, act)
+    assert set(env.batch.INFO_FIELDS) <= set(dict(st4.info)) and len(st4.info) >= len(env.batch.INFO_FIELDS)
+    st5 = env.step(st4, act)
+    assert "command" in [k for k, _ in st5.info.items()] and "step" in list(st5.info)
+    # a State kept across a later step: its info was fetched at its own step (st4) or is refused (never silently the newer step's)
+    assert int(st4.info["step"][st4.done == 0].min()) == 3
+    st6 = env.step(st5, act)
+    st7 = env.step(st6, act)
+    with pytest.raises(RuntimeError, match="stepped / reset since"):
+        st6.info["command"]
+    assert st6.info["truncation"] is env.batch.truncation

@@ -12,13 +12,21 @@ RTOL_Q = 1e-4   # qpos / qvel after one mjx.step (north_star)
 
 # Bounds = min(north_star, ~3x the worst case measured on MI355X at the start of round 3 -- profiles/r3/parity_worst.json keeps
 # the measured values of the last run next to these bounds).  Relative errors use the floors given in the tests.
-STAGE_BOUNDS = dict(xpos=3e-7, M=4e-4, qfs=2e-4, qas=1.5e-4, dist=4e-7, D=3e-4, aref=1.2e-3, qacc=3.5e-3, sens=5e-4, qpos=1e-5, qvel=4e-5)
-TEN_BOUNDS = dict(qpos=RTOL_Q, qvel=RTOL_Q)
+STAGE_BOUNDS = dict(xpos=3e-7, M=4e-4, qfs=2e-4, qas=1.5e-4, dist=4e-7, D=3e-4, aref=1.2e-3, qacc=3.5e-3, sens=5e-4, qpos=1e-5, qvel=4e-5,
+                    qpos_normwise=RTOL_Q, qvel_normwise=RTOL_Q)      # north star on the floor-free measure too (_nw)
+TEN_BOUNDS = dict(qpos=RTOL_Q, qvel=RTOL_Q, qpos_normwise=RTOL_Q, qvel_normwise=RTOL_Q)
 FOOT_BOUNDS = dict(dist=3e-7, qacc=3e-4, qpos=1e-5, qvel=1e-5)
 
 
 def _rel(a, b, floor=1e-3):
     return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+def _nw(a, b):
+    """Norm-wise relative error of one env's vector, NO floor: max |a - b| / max |b| (the component-wise `_rel` above divides a
+    velocity component below 1 rad/s by 1: for those it is an absolute bound; this is the measure without that allowance)."""
+    b = np.asarray(b, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 
 
 @pytest.fixture(scope="module")
@@ -135,7 +143,7 @@ def test_one_substep_stages(torch_cuda, oracle_mod, parity_log, task, lanes):
     gq, gv, gw = b.get_state()
     img = b.lds_image()
     nv, nb = model.nv, model.nbody
-    worst = dict(xpos=0, M=0, qfs=0, qas=0, dist=0, D=0, aref=0, qacc=0, qpos=0, qvel=0, sens=0)
+    worst = dict(xpos=0, M=0, qfs=0, qas=0, dist=0, D=0, aref=0, qacc=0, qpos=0, qvel=0, sens=0, qpos_normwise=0, qvel_normwise=0)
     o = {k: b.lds_offset(k) for k in ("xpos", "M", "qfrc_smooth", "qacc_smooth", "contact_dist", "efc_D", "efc_aref", "qacc", "sensordata", "actuator_force")}
     from open_duck_playground_amd.tables import build_kernel_tables, reduced_layout
     tabs = build_kernel_tables(model.a)
@@ -180,6 +188,8 @@ def test_one_substep_stages(torch_cuda, oracle_mod, parity_log, task, lanes):
         ds = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 1)
         worst["qpos"] = max(worst["qpos"], _rel(gq[e], ds["qpos"][: om.nq], 1e-2).max())
         worst["qvel"] = max(worst["qvel"], _rel(gv[e], ds["qvel"][:nv], 1.0).max())
+        worst["qpos_normwise"] = max(worst["qpos_normwise"], _nw(gq[e], ds["qpos"][: om.nq]))
+        worst["qvel_normwise"] = max(worst["qvel_normwise"], _nw(gv[e], ds["qvel"][:nv]))
     print(task, lanes, {k: float(f"{v:.3g}") for k, v in worst.items()}, "contact ties:", n_tie, "of", n)
     b.close()
     # ties (the oracle's own contact set not stable under rounding-level noise): rare since the last manifold point resolves the
@@ -443,7 +453,7 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
     b.set_state(qpos, qvel, warm)
     b.physics_step(torch.tensor(ctrl, dtype=torch.float32, device="cuda"), 10)
     gq, gv, _ = b.get_state()
-    wq = wv = 0.0
+    wq = wv = wqn = wvn = 0.0
     prng = np.random.default_rng(98)
     n_ill = 0
     for e in range(n):
@@ -463,11 +473,12 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
             continue
         wq = max(wq, _rel(gq[e], q1, 1e-2).max())
         wv = max(wv, _rel(gv[e], v1, 1.0).max())
+        wqn, wvn = max(wqn, _nw(gq[e], q1)), max(wvn, _nw(gv[e], v1))
     print(task, "10 substeps: worst rel qpos", wq, "qvel", wv, "ill-conditioned:", n_ill, "of", n)
     b.close()
     assert n - n_ill >= 150, (n, n_ill)
     parity_log.rec(f"ten_substeps/{task}", None, states=n, judged=n - n_ill)
-    parity_log.check(f"ten_substeps/{task}", dict(TEN_BOUNDS, ill_fraction=0.55 if "rough" in task else 0.45), qpos=wq, qvel=wv, ill_fraction=n_ill / n)
+    parity_log.check(f"ten_substeps/{task}", dict(TEN_BOUNDS, ill_fraction=0.55 if "rough" in task else 0.45), qpos=wq, qvel=wv, qpos_normwise=wqn, qvel_normwise=wvn, ill_fraction=n_ill / n)
 
 
 @pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32)])
