@@ -132,7 +132,8 @@ def _bench(argv, launcher_ranks=0, timeout=900, extra_env=None):
     share GPU 0 over gloo through the test hooks (RCCL wants one rank per device)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ODK_BENCH_BACKEND="gloo", ODK_BENCH_DEVICE="0", **(extra_env or {}))
+    env = dict(os.environ, ODK_BENCH_BACKEND="gloo", ODK_BENCH_DEVICE="0")
+    env.update(extra_env or {})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable]
