@@ -272,6 +272,17 @@ typedef struct odk_mlp_desc {
   float* dz[3];              /* backward out: dLoss/dz_l, width H_l */
   float* bias_partial[4];    /* backward out: per-tile column sums of dz_l (l = 3: of dout), [ceil(n / 16), width_l]; odk_colsum_fold finishes them */
   int n, n_in, n_out;        /* n_in <= ODK_MLP_MAX_IN, n_out <= 32 */
+  /* Optional row sources of the forward pass (row_idx NULL: row r of the input is x[r], as above) -- the minibatch gather of brax's
+   * sgd_step (jnp.take of the shuffled trajectories; reference common/runner.py:104-118 -> brax ppo.train) folded into the load, so that
+   * no gathered copy of the observations is ever written:
+   *   rows r <  n_main:  x[row_idx[k B + r / traj_len] * traj_len + r % traj_len]     x = the WHOLE rollout, [n_traj * traj_len, n_in]
+   *   rows r >= n_main:  x_tail[row_idx[k B + r - n_main]]                              x_tail = [n_traj, n_in] (the bootstrap observations)
+   * with B = n_main / traj_len trajectories per minibatch and k = *cursor (device int: which minibatch of the schedule row_idx holds;
+   * NULL: 0).  An index outside [0, n_traj) is never dereferenced: that row reads as NaN and the step's losses say so. */
+  const long long* row_idx;
+  const int* cursor;
+  const float* x_tail;
+  int traj_len, n_main, n_traj;
 } odk_mlp_desc;
 int odk_mlp_forward(const odk_mlp_desc* nets, int count, void* stream);
 int odk_mlp_backward(const odk_mlp_desc* nets, int count, void* stream);
@@ -305,6 +316,46 @@ int odk_pack_weights(const float* params_dev, long long n, float* fwd_packed_dev
 int odk_adam_clip_packed(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
                          float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
                          const odk_weight_table* table, int norm_blocks, void* stream);
+/* The same launch with the END-OF-STEP duties of an indexed minibatch step folded in (all optional, NULL / 0 = off), so that a step is
+ * six launches and nothing else:
+ *   cursor_dev:        *cursor_dev += 1 -- the next step's launches read the next minibatch of the schedule (odk_mlp_desc.cursor,
+ *                      odk_ppo_gae_head) without any host-side call between two graph replays;
+ *   loss_partials_dev: [n_loss_partials][4] per-workgroup sums of (total, policy, value, entropy) left by odk_ppo_gae_head, folded in
+ *                      workgroup order into losses_dev[0..3] += ... (a fixed order; as float atomics the 4 x 320 additions on four
+ *                      addresses cost the head launch ~4 us of serialisation). */
+typedef struct odk_step_tail {
+  int* cursor_dev;
+  const float* loss_partials_dev;
+  int n_loss_partials;
+  float* losses_dev;
+} odk_step_tail;
+int odk_adam_clip_packed_tail(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
+                              float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
+                              const odk_weight_table* table, int norm_blocks, const odk_step_tail* tail /* may be NULL */, void* stream);
+
+/* GAE + advantage statistics + the PPO loss head in ONE launch, reading the rollout through the minibatch's trajectory indices (what
+ * odk_gather_rows + odk_gae + odk_ppo_head do as three launches on gathered copies; same arithmetic, same summation orders; brax
+ * ppo.losses.compute_gae / compute_ppo_loss).  Every workgroup recomputes the B x T recursion in LDS (B * T <= 5120, B <= 1024) -- the
+ * advantage statistics are a global quantity and a launch boundary costs more than 80 redundant copies of a 100 KFLOP scan -- then
+ * works its own 64 samples.  Host struct; every pointer inside is a device pointer.
+ *   sample s = b T + t of minibatch k = *cursor (NULL: 0) is step t of trajectory j = row_idx[k B + b] of the rollout;
+ *   logits [n, 2A], values [n + B] (baselines, then the B bootstrap values), n = B T: the network outputs of THIS minibatch;
+ *   raw_action [n_traj, T, A], old_log_prob / reward / termination / truncation [n_traj, T]: the whole rollout;
+ *   noise: the entropy sample of minibatch k is noise[k n A ..];  dlogits [n, 2A], dvalues [n] out;
+ *   losses: loss_partials != NULL: workgroup w writes its sums of (total, policy, value, entropy) to loss_partials[4 w ..] (ODK_GAE_HEAD_SAMPLES
+ *   samples per workgroup: ceil(n / ODK_GAE_HEAD_SAMPLES) entries; odk_adam_clip_packed_tail folds them); otherwise losses[4] += ... by atomics;
+ *   adv_out / vs_out [n], stats_out[2] (mean, 1 / (std + 1e-8)): optional outputs (written by workgroup 0), may be NULL. */
+#define ODK_GAE_HEAD_SAMPLES 32
+typedef struct odk_gae_head_args {
+  const float *logits, *values, *raw_action, *old_log_prob, *reward, *termination, *truncation, *noise;
+  const long long* row_idx;
+  const int* cursor;
+  float *dlogits, *dvalues, *losses, *loss_partials, *adv_out, *vs_out, *stats_out;
+  int B, T, action_size, n_traj, normalize_advantage;
+  float gae_lambda, discount, clipping_epsilon, entropy_cost, grad_scale;
+} odk_gae_head_args;
+int odk_ppo_gae_head(const odk_gae_head_args* args, void* stream);
+
 /* colsum[f][c] = sum over the nblk[f] tile rows of partial[f][tile, c] for up to 8 layers in one launch (fixed order);
  * partial_dev / colsum_dev / widths / nblk are HOST arrays */
 int odk_colsum_fold(const float* const* partial_dev, float* const* colsum_dev, const int* widths, const int* nblk, int count, void* stream);

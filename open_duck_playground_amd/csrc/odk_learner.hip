@@ -49,6 +49,21 @@ __device__ float block_sum(float v, float* sh) {   // blockDim.x multiple of 64,
 __device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
 __device__ __forceinline__ float sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// One step (time t, walking backwards) of brax compute_gae for one trajectory, with the roundings PINNED (explicit fused / unfused
+// operations): four kernels restate this recursion (generic, register-staged, LDS-staged, fused with the loss head) and the compiler's
+// choice of which multiply-add to contract depends on the surrounding loop -- as plain expressions two of them differed in the last bit.
+// mask = 1 - truncation, nt = 1 - termination.  Returns the advantage; updates acc, v_next, vs_next; vs_t out.
+__device__ __forceinline__ float gae_step(float r, float v, float mask, float nt, float discount, float lambda_, float& acc, float& v_next, float& vs_next,
+                                          float& vs_t) {
+  const float dn = __fmul_rn(discount, nt);
+  const float delta = __fmul_rn(__fsub_rn(__fmaf_rn(dn, v_next, r), v), mask);
+  acc = __fmaf_rn(__fmul_rn(__fmul_rn(dn, mask), lambda_), acc, delta);
+  vs_t = __fadd_rn(acc, v);
+  const float a = __fmul_rn(__fsub_rn(__fmaf_rn(dn, vs_next, r), v), mask);
+  v_next = v; vs_next = vs_t;
+  return a;
+}
+
 // GAE over row-major [B, T]; one thread per trajectory, serial in time (brax compute_gae); truncation / termination are
 // FLAGS (any non-zero value counts as 1, in all three kernels); then the
 // population mean / std of the advantages (brax: (adv - mean) / (std + 1e-8), jnp.std => ddof 0).
@@ -63,13 +78,11 @@ __global__ void gae_kernel(const float* __restrict__ trunc, const float* __restr
     float acc = 0.0f, v_next = boot[b], vs_next = boot[b];
     for (int t = T - 1; t >= 0; t--) {
       const float mask = trunc[o + t] != 0.0f ? 0.0f : 1.0f, nt = term[o + t] != 0.0f ? 0.0f : 1.0f, v = val[o + t], r = rew[o + t];
-      const float delta = (r + discount * nt * v_next - v) * mask;
-      acc = delta + discount * nt * mask * lambda_ * acc;
-      const float vs_t = acc + v, a = (r + discount * nt * vs_next - v) * mask;
+      float vs_t;
+      const float a = gae_step(r, v, mask, nt, discount, lambda_, acc, v_next, vs_next, vs_t);
       adv[o + t] = a;
       vs[o + t] = vs_t;
-      s += a;
-      v_next = v; vs_next = vs_t;
+      s = __fadd_rn(s, a);
     }
   }
   if (!stats) return;
@@ -77,7 +90,7 @@ __global__ void gae_kernel(const float* __restrict__ trunc, const float* __restr
   const float mean = block_sum(s, sh) / n;
   float q = 0.0f;
   for (int b = threadIdx.x; b < B; b += blockDim.x)
-    for (int t = 0; t < T; t++) { const float d = adv[(size_t)b * T + t] - mean; q += d * d; }   // own writes: visible
+    for (int t = 0; t < T; t++) { const float d = adv[(size_t)b * T + t] - mean; q = __fmaf_rn(d, d, q); }   // own writes: visible
   const float var = block_sum(q, sh) / n;
   if (threadIdx.x == 0) { stats[0] = mean; stats[1] = 1.0f / (sqrtf(var) + 1e-8f); }
 }
@@ -105,13 +118,11 @@ __global__ void gae_kernel_reg(const float* __restrict__ trunc, const float* __r
 #pragma unroll
   for (int t = TT - 1; t >= 0; t--) {
     if (live && t < T) {
-      const float delta = (r[t] + discount * nt[t] * v_next - v[t]) * mk[t];
-      acc = delta + discount * nt[t] * mk[t] * lambda_ * acc;
-      const float vs_t = acc + v[t], a = (r[t] + discount * nt[t] * vs_next - v[t]) * mk[t];
+      float vs_t;
+      const float a = gae_step(r[t], v[t], mk[t], nt[t], discount, lambda_, acc, v_next, vs_next, vs_t);
       adv[o + t] = a;
       vs[o + t] = vs_t;
-      s += a;
-      v_next = v[t]; vs_next = vs_t;
+      s = __fadd_rn(s, a);
       r[t] = a;   // kept for the variance pass
     }
   }
@@ -121,7 +132,7 @@ __global__ void gae_kernel_reg(const float* __restrict__ trunc, const float* __r
   float q = 0.0f;
 #pragma unroll
   for (int t = 0; t < TT; t++)
-    if (live && t < T) { const float d = r[t] - mean; q += d * d; }
+    if (live && t < T) { const float d = r[t] - mean; q = __fmaf_rn(d, d, q); }
   const float var = block_sum(q, sh) / n;
   if (threadIdx.x == 0) { stats[0] = mean; stats[1] = 1.0f / (sqrtf(var) + 1e-8f); }
 }
@@ -147,13 +158,11 @@ __global__ void __launch_bounds__(1024) gae_kernel_lds(const float* __restrict__
     for (int t = T - 1; t >= 0; t--) {
       const float f = s_f[o + t], te = f >= 2.0f ? 1.0f : 0.0f, tr = f - 2.0f * te;
       const float mask = 1.0f - tr, nt = 1.0f - te, v = s_v[o + t], r = s_r[o + t];
-      const float delta = (r + discount * nt * v_next - v) * mask;
-      acc = delta + discount * nt * mask * lambda_ * acc;
-      const float vs_t = acc + v, a = (r + discount * nt * vs_next - v) * mask;
+      float vs_t;
+      const float a = gae_step(r, v, mask, nt, discount, lambda_, acc, v_next, vs_next, vs_t);
       s_r[o + t] = a;
       s_v[o + t] = vs_t;
-      s += a;
-      v_next = v; vs_next = vs_t;
+      s = __fadd_rn(s, a);
     }
   }
   __syncthreads();
@@ -163,9 +172,41 @@ __global__ void __launch_bounds__(1024) gae_kernel_lds(const float* __restrict__
   const float mean = block_sum(s, sh) / n;
   float q = 0.0f;
   for (int b = threadIdx.x; b < B; b += blockDim.x)
-    for (int t = 0; t < T; t++) { const float d = s_r[b * T + t] - mean; q += d * d; }
+    for (int t = 0; t < T; t++) { const float d = s_r[b * T + t] - mean; q = __fmaf_rn(d, d, q); }
   const float var = block_sum(q, sh) / n;
   if (threadIdx.x == 0) { stats[0] = mean; stats[1] = 1.0f / (sqrtf(var) + 1e-8f); }
+}
+
+// The loss head of ONE sample on its 16-lane row (lane j < A = action dimension j): tanh-normal log-prob, clipped surrogate, value
+// loss, sampled entropy and their gradients w.r.t. the network outputs (brax ppo.losses.compute_ppo_loss).  Shared by the stand-alone
+// head launch and the fused GAE + head launch: one arithmetic, two callers.  `advn`: the (normalised) advantage.
+struct HeadOut { float dloc, dscale_raw, dbaseline, lp, lv, le; };
+__device__ __forceinline__ HeadOut head_sample(bool on, float loc, float raw, float a, float z, float advn, float old_lp, float vs_s, float base_s, float inv_n,
+                                               float eps, float entropy_cost, float grad_scale) {
+  const float HALF_LOG_2PI = 0.91893853320467274f, LOG2 = 0.69314718055994531f;
+  const float scale = softplus(raw) + 0.001f, inv_scale = 1.0f / scale, lscale = __logf(scale);
+  const float u = (a - loc) * inv_scale;
+  const float ldj_a = 2.0f * (LOG2 - a - softplus(-2.0f * a));
+  const float lp_j = on ? (-0.5f * u * u - lscale - HALF_LOG_2PI - ldj_a) : 0.0f;
+  const float x = loc + scale * z;
+  const float ldj_x = 2.0f * (LOG2 - x - softplus(-2.0f * x));
+  const float ent_j = on ? (0.5f + HALF_LOG_2PI + lscale + ldj_x) : 0.0f;
+  const float logp = row16_sum(lp_j), ent = row16_sum(ent_j);
+  const float rho = __expf(logp - old_lp);
+  const float rc = fminf(fmaxf(rho, 1.0f - eps), 1.0f + eps);
+  const float s1 = rho * advn, s2 = rc * advn;
+  const bool inside = rho >= 1.0f - eps && rho <= 1.0f + eps;
+  const float dmin_drho = (inside || s1 < s2) ? advn : 0.0f;   // d min(s1, s2) / d rho (ties split evenly, both branches -> rho)
+  const float dL_dlogp = -dmin_drho * rho * inv_n;
+  const float verr = vs_s - base_s;
+  const float th = tanhf(x);
+  const float ce = -entropy_cost * inv_n;
+  HeadOut o;
+  o.dloc = grad_scale * (dL_dlogp * u * inv_scale + ce * (-2.0f * th));
+  o.dscale_raw = grad_scale * (dL_dlogp * (u * u - 1.0f) * inv_scale + ce * (inv_scale - 2.0f * th * z)) * sigmoid(raw);
+  o.dbaseline = grad_scale * (-0.5f * verr * inv_n);
+  o.lp = -fminf(s1, s2) * inv_n; o.lv = 0.25f * verr * verr * inv_n; o.le = -entropy_cost * ent * inv_n;
+  return o;
 }
 
 // One 16-lane row per sample, lane j < A = action dimension j.  logits [n, 2A] = (loc | raw_scale).
@@ -179,46 +220,136 @@ __global__ void ppo_head_kernel(const float* __restrict__ logits, const float* _
   const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const bool live = s < n, on = live && lane < A;
   const int sc = live ? s : n - 1;
-  const float inv_n = 1.0f / (float)n;
-  const float HALF_LOG_2PI = 0.91893853320467274f, LOG2 = 0.69314718055994531f;
   float loc = 0.f, raw = 0.f, a = 0.f, z = 0.f;
   if (on) { loc = logits[(size_t)sc * 2 * A + lane]; raw = logits[(size_t)sc * 2 * A + A + lane]; a = raw_action[(size_t)sc * A + lane]; z = noise[(size_t)sc * A + lane]; }
-  const float scale = softplus(raw) + 0.001f, inv_scale = 1.0f / scale, lscale = __logf(scale);
-  const float u = (a - loc) * inv_scale;
-  const float ldj_a = 2.0f * (LOG2 - a - softplus(-2.0f * a));
-  const float lp_j = on ? (-0.5f * u * u - lscale - HALF_LOG_2PI - ldj_a) : 0.0f;
-  const float x = loc + scale * z;
-  const float ldj_x = 2.0f * (LOG2 - x - softplus(-2.0f * x));
-  const float ent_j = on ? (0.5f + HALF_LOG_2PI + lscale + ldj_x) : 0.0f;
-  const float logp = row16_sum(lp_j), ent = row16_sum(ent_j);
   float advn = adv[sc];
   if (stats) advn = (advn - stats[0]) * stats[1];
-  const float rho = __expf(logp - old_logp[sc]);
-  const float rc = fminf(fmaxf(rho, 1.0f - eps), 1.0f + eps);
-  const float s1 = rho * advn, s2 = rc * advn;
-  const bool inside = rho >= 1.0f - eps && rho <= 1.0f + eps;
-  const float dmin_drho = (inside || s1 < s2) ? advn : 0.0f;   // d min(s1, s2) / d rho (ties split evenly, both branches -> rho)
-  const float dL_dlogp = -dmin_drho * rho * inv_n;
-  const float verr = vs[sc] - baseline[sc];
-  const float th = tanhf(x);
-  const float ce = -entropy_cost * inv_n;
+  const HeadOut h = head_sample(on, loc, raw, a, z, advn, old_logp[sc], vs[sc], baseline[sc], 1.0f / (float)n, eps, entropy_cost, grad_scale);
   if (on) {
-    const float dloc = dL_dlogp * u * inv_scale + ce * (-2.0f * th);
-    const float dscale = dL_dlogp * (u * u - 1.0f) * inv_scale + ce * (inv_scale - 2.0f * th * z);
-    dlogits[(size_t)s * 2 * A + lane] = grad_scale * dloc;
-    dlogits[(size_t)s * 2 * A + A + lane] = grad_scale * dscale * sigmoid(raw);
+    dlogits[(size_t)s * 2 * A + lane] = h.dloc;
+    dlogits[(size_t)s * 2 * A + A + lane] = h.dscale_raw;
   }
   float lp = 0.f, lv = 0.f, le = 0.f;
-  if (live && lane == 0) {
-    dbaseline[s] = grad_scale * (-0.5f * verr * inv_n);
-    lp = -fminf(s1, s2) * inv_n; lv = 0.25f * verr * verr * inv_n; le = -entropy_cost * ent * inv_n;
-  }
+  if (live && lane == 0) { dbaseline[s] = h.dbaseline; lp = h.lp; lv = h.lv; le = h.le; }
   // block totals first: one atomic per loss and workgroup (1 280 wave-level float atomics on four addresses serialised
   // into ~50 us; these sums are reporting only, the gradients above do not depend on them)
   __shared__ float sh[16];
   lp = block_sum(lp, sh); lv = block_sum(lv, sh); le = block_sum(le, sh);
   if (threadIdx.x == 0) {
     atomicAdd(&losses[0], lp + lv + le); atomicAdd(&losses[1], lp); atomicAdd(&losses[2], lv); atomicAdd(&losses[3], le);
+  }
+}
+
+// GAE + advantage statistics + the loss head in ONE launch, the rollout read through the minibatch's trajectory indices
+// (include/odk.h: odk_ppo_gae_head).  The per-step chain was gather (6.6 us) -> ... -> GAE (7.8 us, one workgroup) -> head (10.8 us):
+// three launches of dependent latency.  The advantage statistics are a global quantity, so instead of a launch boundary every
+// workgroup redoes the whole B x T recursion in its own LDS -- same arithmetic and order as gae_kernel_lds, hence the same bits in
+// every workgroup (and on every data-parallel replica) -- and then works its own 64 samples with head_sample().
+struct GaeHead {
+  const float *logits, *values, *raw_action, *old_logp, *reward, *term, *trunc, *noise;
+  const long long* idx; const int* cursor;
+  float *dlogits, *dvalues, *losses, *loss_partials, *adv_out, *vs_out, *stats_out;
+  int B, T, A, n_traj, normalize;
+  float lambda_, discount, eps, entropy_cost, grad_scale;
+};
+// Workgroup = 512 threads = 32 samples (ODK_GAE_HEAD_SAMPLES): 160 workgroups for the reference minibatch, one per CU, two waves per SIMD
+// for the head's transcendental arithmetic (the first version -- 1024 threads, 64 samples, 80 workgroups -- put 4 waves of it on every
+// SIMD of 80 CUs and left 176 idle: 19.6 us; its 4 x 80 float atomics on four addresses were another ~4 us of serialisation).
+constexpr int GH_THREADS = 16 * ODK_GAE_HEAD_SAMPLES;
+__device__ __forceinline__ void block_sum3(float& x, float& y, float& z, float (*sh3)[16]) {   // three block sums for the price of one (same order as block_sum)
+  x = wave_sum(x); y = wave_sum(y); z = wave_sum(z);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sh3[0][w] = x; sh3[1][w] = y; sh3[2][w] = z; }
+  __syncthreads();
+  float tx = 0.0f, ty = 0.0f, tz = 0.0f;
+  for (int i = 0; i < nw; i++) { tx += sh3[0][i]; ty += sh3[1][i]; tz += sh3[2][i]; }
+  x = tx; y = ty; z = tz;
+}
+__global__ void __launch_bounds__(GH_THREADS) ppo_gae_head_kernel(GaeHead a) {
+  __shared__ float s_r[GAE_LDS_N], s_v[GAE_LDS_N];   // reward -> advantage, value -> vs
+  __shared__ unsigned char s_f[GAE_LDS_N];           // trunc + 2 * term
+  __shared__ int s_j[1024];                          // the minibatch's trajectory numbers, -1 = outside the rollout
+  __shared__ float sh[16], sh3[3][16];
+  const int B = a.B, T = a.T, N = B * T, A = a.A;
+  const int k = a.cursor ? *a.cursor : 0;
+  const long long* idx = a.idx + (size_t)k * B;
+  const float nanv = __builtin_nanf("");
+  for (int b = threadIdx.x; b < B; b += GH_THREADS) { const long long j = idx[b]; s_j[b] = (j >= 0 && j < a.n_traj) ? (int)j : -1; }
+  __syncthreads();
+  // staging: element i = (trajectory b = i / T, step t); the elements are independent: unrolled so that their loads are in flight together
+  // (a trajectory outside the rollout is never read: it becomes NaN and the losses say so)
+#pragma unroll 5
+  for (int i = threadIdx.x; i < N; i += GH_THREADS) {
+    const int b = i / T, t = i - b * T;
+    const int j = s_j[b];
+    const size_t o = (size_t)(j >= 0 ? j : 0) * T + t;
+    const float r = a.reward[o], tr = a.trunc[o], te = a.term[o];
+    s_r[i] = j >= 0 ? r : nanv; s_v[i] = a.values[i];
+    s_f[i] = (unsigned char)((tr != 0.0f ? 1 : 0) + (te != 0.0f ? 2 : 0));
+  }
+  // this workgroup's own samples: everything the head needs that does not depend on the recursion, fetched BEFORE it
+  const int lane = threadIdx.x & 15;
+  const int smp = (blockIdx.x * GH_THREADS + threadIdx.x) >> 4;
+  const bool live = smp < N, on = live && lane < A;
+  const int sc = live ? smp : N - 1;
+  const int hb = sc / T, ht = sc - hb * T;
+  const int hj = s_j[hb];
+  const bool hok = hj >= 0;
+  const size_t ho = (size_t)(hok ? hj : 0) * T + ht;
+  const float* noise = a.noise + (size_t)k * N * A;
+  float loc = 0.f, raw = 0.f, act = 0.f, z = 0.f;
+  if (on) { loc = a.logits[(size_t)sc * 2 * A + lane]; raw = a.logits[(size_t)sc * 2 * A + A + lane]; act = hok ? a.raw_action[ho * A + lane] : nanv; z = noise[(size_t)sc * A + lane]; }
+  const float old_lp = hok ? a.old_logp[ho] : nanv, base_s = a.values[sc];
+  __syncthreads();
+  float s = 0.0f;
+  for (int b = threadIdx.x; b < B; b += GH_THREADS) {
+    const int o = b * T;
+    float acc = 0.0f, v_next = a.values[N + b], vs_next = v_next;
+#pragma unroll 4
+    for (int t = T - 1; t >= 0; t--) {
+      const int f = s_f[o + t];
+      const float te = (f & 2) ? 1.0f : 0.0f, tr = (f & 1) ? 1.0f : 0.0f;
+      const float mask = 1.0f - tr, nt = 1.0f - te, v = s_v[o + t], r = s_r[o + t];
+      float vs_t;
+      const float ad = gae_step(r, v, mask, nt, a.discount, a.lambda_, acc, v_next, vs_next, vs_t);
+      s_r[o + t] = ad;
+      s_v[o + t] = vs_t;
+      s = __fadd_rn(s, ad);
+    }
+  }
+  const float n = (float)B * (float)T;
+  const float mean = block_sum(s, sh) / n;          // (its barriers also publish the recursion's LDS writes)
+  float q = 0.0f;
+  for (int b = threadIdx.x; b < B; b += GH_THREADS) {
+#pragma unroll 4
+    for (int t = 0; t < T; t++) { const float d = s_r[b * T + t] - mean; q = __fmaf_rn(d, d, q); }
+  }
+  const float var = block_sum(q, sh) / n;
+  const float rstd = 1.0f / (sqrtf(var) + 1e-8f);
+  if (blockIdx.x == 0) {     // optional copies of the intermediate results (tests, debugging)
+    if (a.adv_out) for (int i = threadIdx.x; i < N; i += GH_THREADS) a.adv_out[i] = s_r[i];
+    if (a.vs_out) for (int i = threadIdx.x; i < N; i += GH_THREADS) a.vs_out[i] = s_v[i];
+    if (a.stats_out && threadIdx.x == 0) { a.stats_out[0] = mean; a.stats_out[1] = rstd; }
+  }
+  // ---- the head on this workgroup's samples
+  float advn = s_r[sc];
+  if (a.normalize) advn = (advn - mean) * rstd;
+  const HeadOut h = head_sample(on, loc, raw, act, z, advn, old_lp, s_v[sc], base_s, 1.0f / n, a.eps, a.entropy_cost, a.grad_scale);
+  if (on) {
+    a.dlogits[(size_t)smp * 2 * A + lane] = h.dloc;
+    a.dlogits[(size_t)smp * 2 * A + A + lane] = h.dscale_raw;
+  }
+  float lp = 0.f, lv = 0.f, le = 0.f;
+  if (live && lane == 0) { a.dvalues[smp] = h.dbaseline; lp = h.lp; lv = h.lv; le = h.le; }
+  block_sum3(lp, lv, le, sh3);
+  if (threadIdx.x == 0) {
+    if (a.loss_partials) {
+      float* o = a.loss_partials + 4 * blockIdx.x;
+      o[0] = lp + lv + le; o[1] = lp; o[2] = lv; o[3] = le;
+    } else {
+      atomicAdd(&a.losses[0], lp + lv + le); atomicAdd(&a.losses[1], lp); atomicAdd(&a.losses[2], lv); atomicAdd(&a.losses[3], le);
+    }
   }
 }
 
@@ -649,6 +780,23 @@ extern "C" int odk_ppo_head(const float* logits_dev, const float* raw_action_dev
                      old_log_prob_dev, adv_dev, adv_stats_dev, vs_dev, baseline_dev, noise_dev, dlogits_dev, dbaseline_dev, losses_dev, n,
                      action_size, clipping_epsilon, entropy_cost, grad_scale);
   return check_launch("odk_ppo_head: launch failed");
+}
+
+extern "C" int odk_ppo_gae_head(const odk_gae_head_args* g, void* stream) {
+  if (!g || !g->logits || !g->values || !g->raw_action || !g->old_log_prob || !g->reward || !g->termination || !g->truncation || !g->noise || !g->row_idx ||
+      !g->dlogits || !g->dvalues || (!g->losses && !g->loss_partials) || g->B <= 0 || g->T <= 0 || g->n_traj <= 0 || g->action_size <= 0 || g->action_size > 16)
+    return odk_fail_(ODK_ERR_INVALID, "odk_ppo_gae_head: bad arguments (action_size must be 1..16)");
+  if ((long long)g->B * g->T > GAE_LDS_N || g->B > 1024)
+    return odk_fail_(ODK_ERR_INVALID, "odk_ppo_gae_head: B * T <= 5120 and B <= 1024 (larger minibatches: odk_gather_rows + odk_gae + odk_ppo_head)");
+  GaeHead a;
+  a.logits = g->logits; a.values = g->values; a.raw_action = g->raw_action; a.old_logp = g->old_log_prob; a.reward = g->reward; a.term = g->termination;
+  a.trunc = g->truncation; a.noise = g->noise; a.idx = g->row_idx; a.cursor = g->cursor; a.dlogits = g->dlogits; a.dvalues = g->dvalues; a.losses = g->losses; a.loss_partials = g->loss_partials;
+  a.adv_out = g->adv_out; a.vs_out = g->vs_out; a.stats_out = g->stats_out; a.B = g->B; a.T = g->T; a.A = g->action_size; a.n_traj = g->n_traj;
+  a.normalize = g->normalize_advantage; a.lambda_ = g->gae_lambda; a.discount = g->discount; a.eps = g->clipping_epsilon; a.entropy_cost = g->entropy_cost;
+  a.grad_scale = g->grad_scale;
+  const int n = g->B * g->T;
+  hipLaunchKernelGGL(ppo_gae_head_kernel, dim3((n + ODK_GAE_HEAD_SAMPLES - 1) / ODK_GAE_HEAD_SAMPLES), dim3(GH_THREADS), 0, (hipStream_t)stream, a);
+  return check_launch("odk_ppo_gae_head: launch failed");
 }
 
 extern "C" int odk_policy_sample(const float* logits_dev, const float* noise_dev, float* raw_action_dev, float* action_dev, float* log_prob_dev,

@@ -68,6 +68,7 @@ struct Net {
   float* h[3]; float* g[3]; float* out; float* xp;
   const float* dout; float* dz[3]; float* doutp; float* bias_partial[4];
   int n, n_in, n_out, tile0;
+  const long long* row_idx; const int* cursor; const float* x_tail; int traj_len, n_main, n_traj;     // odk_mlp_desc: row sources of the forward pass
 };
 // Block -> (network, tile).  All workgroups of a launch are resident at once (<= 4 per CU) and the dispatcher hands block b to CU
 // b mod R (R = CUs; measured: tools/gpu_mlp_wg_profile.py finds exactly the predicted mixes), so with T = 656 tiles on 256 CUs
@@ -243,8 +244,19 @@ __global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
     for (int i = 0; i < TM / 4; i++) {
       const int rr = w + 4 * i, row = m0 + rr < N.n ? m0 + rr : N.n - 1;
       const float* src = N.x + (size_t)row * kin;
+      bool ok = true;
+      if (N.row_idx) {      // the minibatch gather folded into the load (odk_mlp_desc.row_idx): sample -> (trajectory of the schedule, step)
+        const int TL = N.traj_len, Bm = N.n_main / TL;
+        const long long* idx = N.row_idx + (size_t)(N.cursor ? *N.cursor : 0) * Bm;
+        const bool main_row = row < N.n_main;
+        const int b = main_row ? row / TL : row - N.n_main;
+        const long long j = idx[b];
+        ok = j >= 0 && j < N.n_traj;
+        const long long jj = ok ? j : 0;
+        src = main_row ? N.x + (size_t)(jj * TL + (row - b * TL)) * kin : N.x_tail + (size_t)jj * kin;
+      }
 #pragma unroll
-      for (int t = 0; t < T; t++) { const int k = lane + 64 * t; xv[i][t] = src[k < kin ? k : 0]; }
+      for (int t = 0; t < T; t++) { const int k = lane + 64 * t; const float v = src[k < kin ? k : 0]; xv[i][t] = ok ? v : __builtin_nanf(""); }
     }
     if (N.in_mean) {   // observation normaliser folded into the load: (x - mean) / std, IEEE division (bit-identical to the torch ops it replaces)
       float mu[T], sd[T];
@@ -485,12 +497,29 @@ __device__ float block_sum(float v, float* sh) {
   for (int i = 0; i < nw; i++) t += sh[i];
   return t;
 }
+// end-of-step duties riding on the clip + Adam launch (odk_step_tail): block 0 advances the schedule's cursor, the LAST block folds the
+// loss head's per-workgroup sums into the running losses, in workgroup order
+struct Tail { int* cursor; const float* partials; int npartials; float* losses; };
+__device__ __forceinline__ void step_tail(const Tail& t) {
+  if (t.cursor && blockIdx.x == 0 && threadIdx.x == 0) *t.cursor += 1;     // nobody in THIS launch reads it: the next step's launches do
+  if (t.partials && blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {
+    // lane = (slice q = lane / 4, component c = lane % 4): slice q sums workgroups q, q + 16, ... in ascending order, then the 16 slices fold
+    // in a fixed butterfly -- all loads of a lane are independent (as one serial loop over 160 partials the launch grew by 12 us)
+    const int c = threadIdx.x & 3, q = threadIdx.x >> 2;
+    float s = 0.0f;
+    for (int w = q; w < t.npartials; w += 16) s += t.partials[4 * w + c];
+#pragma unroll
+    for (int o = 4; o <= 32; o <<= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x < 4) t.losses[c] += s;
+  }
+}
 // adam_kernel of odk_learner.hip (same arithmetic, same fixed-order norm fold) that also writes every updated weight to its
 // places in the packed copies
 __global__ void adam_packed_kernel(float* __restrict__ p, float* __restrict__ pf, float* __restrict__ pb, const float* __restrict__ g, float* __restrict__ m,
                                    float* __restrict__ v, float* __restrict__ acc, int nblocks, int64_t n, float lr, float b1, float b2, float eps,
-                                   float max_norm, WeightTable t_) {
+                                   float max_norm, WeightTable t_, Tail tail) {
   __shared__ float sh[16];
+  step_tail(tail);
   float sq = 0.0f;
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x) sq += acc[2 + i];
   sq = block_sum(sq, sh);
@@ -536,9 +565,10 @@ __global__ void adam_packed_kernel(float* __restrict__ p, float* __restrict__ pf
 struct AdamTiles { int tile0[9], tj[8], ntiles, ngap; long long gap0[9], gapn[9]; };
 __global__ void __launch_bounds__(256) adam_tiled_kernel(float* __restrict__ p, float* __restrict__ pf, float* __restrict__ pb, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, float* __restrict__ acc, int nblocks, float lr, float b1,
-                                                         float b2, float eps, float max_norm, WeightTable t_, AdamTiles at) {
+                                                         float b2, float eps, float max_norm, WeightTable t_, AdamTiles at, Tail tail) {
   __shared__ float sh[16];
   __shared__ float tile[16][65];
+  step_tail(tail);
   float sq = 0.0f;
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x) sq += acc[2 + i];
   sq = block_sum(sq, sh);
@@ -652,6 +682,13 @@ int fill_args(Args& a, const odk_mlp_desc* nets, int count, bool backward, int& 
       if (!d.dout || !d.doutp || !d.g[0] || !d.g[1] || !d.g[2] || !d.dz[0] || !d.dz[1] || !d.dz[2] || !d.bias_partial[0] || !d.bias_partial[1] ||
           !d.bias_partial[2] || !d.bias_partial[3]) { err = "backward needs dout, doutp, g, dz and bias_partial"; return 1; }
     }
+    if (!backward && d.row_idx) {
+      const int tail = d.n - d.n_main;
+      if (d.traj_len <= 0 || d.n_main <= 0 || d.n_main % d.traj_len != 0 || tail < 0 || d.n_traj <= 0 || (tail > 0 && (!d.x_tail || tail > d.n_main / d.traj_len))) {
+        err = "row_idx: n_main a positive multiple of traj_len and <= n; n_traj > 0; rows past n_main need x_tail and number at most n_main / traj_len"; return 1;
+      }
+    }
+    N.row_idx = d.row_idx; N.cursor = d.cursor; N.x_tail = d.x_tail; N.traj_len = d.traj_len; N.n_main = d.n_main; N.n_traj = d.n_traj;
     N.x = d.x; N.in_mean = d.in_mean; N.in_std = d.in_std; N.out = d.out; N.dout = d.dout; N.xp = d.xp; N.doutp = d.doutp; N.n = d.n; N.n_in = d.n_in; N.n_out = d.n_out; N.tile0 = tiles;
     for (int l = 0; l < 4; l++) { N.wf[l] = d.wf[l]; N.wb[l] = d.wb[l]; N.b[l] = d.b[l]; N.bias_partial[l] = d.bias_partial[l]; }
     for (int l = 0; l < 3; l++) { N.h[l] = has_act ? d.h[l] : nullptr; N.g[l] = d.g[l]; N.dz[l] = d.dz[l]; }
@@ -744,9 +781,14 @@ extern "C" int odk_pack_weights(const float* params_dev, long long n, float* fwd
   return check_launch("odk_pack_weights: launch failed");
 }
 
-extern "C" int odk_adam_clip_packed(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
-                                    float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
-                                    const odk_weight_table* table, int norm_blocks, void* stream) {
+extern "C" int odk_adam_clip_packed_tail(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
+                                         float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
+                                         const odk_weight_table* table, int norm_blocks, const odk_step_tail* tail_, void* stream) {
+  Tail tail = {nullptr, nullptr, 0, nullptr};
+  if (tail_) {
+    if (tail_->loss_partials_dev && (!tail_->losses_dev || tail_->n_loss_partials <= 0)) return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip_packed_tail: loss partials need a count and losses_dev");
+    tail.cursor = tail_->cursor_dev; tail.partials = tail_->loss_partials_dev; tail.npartials = tail_->n_loss_partials; tail.losses = tail_->losses_dev;
+  }
   WeightTable t;
   if (!params_dev || !fwd_packed_dev || !bwd_packed_dev || !grads_dev || !m_dev || !v_dev || !acc_dev || n <= 0 || fill_table(t, table, n, n_fwd, n_bwd))
     return odk_fail_(ODK_ERR_INVALID, "odk_adam_clip_packed: bad arguments");
@@ -781,12 +823,19 @@ extern "C" int odk_adam_clip_packed(float* params_dev, const float* grads_dev, f
     if ((((uintptr_t)fwd_packed_dev) | ((uintptr_t)bwd_packed_dev)) & 15) tiled = false;
     if (tiled)
       hipLaunchKernelGGL(adam_tiled_kernel, dim3(at.ntiles + gap_blocks), dim3(256), 0, st, params_dev, fwd_packed_dev, bwd_packed_dev, grads_dev, m_dev, v_dev,
-                         acc_dev, norm_blocks > 0 ? norm_blocks : blocks, lr, b1, b2, eps, max_grad_norm, t, at);
+                         acc_dev, norm_blocks > 0 ? norm_blocks : blocks, lr, b1, b2, eps, max_grad_norm, t, at, tail);
   }
   if (!tiled)
     hipLaunchKernelGGL(adam_packed_kernel, dim3(blocks), dim3(threads), 0, st, params_dev, fwd_packed_dev, bwd_packed_dev, grads_dev, m_dev, v_dev, acc_dev,
-                       norm_blocks > 0 ? norm_blocks : blocks, (int64_t)n, lr, b1, b2, eps, max_grad_norm, t);
+                       norm_blocks > 0 ? norm_blocks : blocks, (int64_t)n, lr, b1, b2, eps, max_grad_norm, t, tail);
   return check_launch("odk_adam_clip_packed: launch failed");
+}
+
+extern "C" int odk_adam_clip_packed(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, float* acc_dev, long long n, float lr, float b1,
+                                    float b2, float eps, float max_grad_norm, float* fwd_packed_dev, long long n_fwd, float* bwd_packed_dev, long long n_bwd,
+                                    const odk_weight_table* table, int norm_blocks, void* stream) {
+  return odk_adam_clip_packed_tail(params_dev, grads_dev, m_dev, v_dev, acc_dev, n, lr, b1, b2, eps, max_grad_norm, fwd_packed_dev, n_fwd, bwd_packed_dev, n_bwd,
+                                   table, norm_blocks, nullptr, stream);
 }
 
 extern "C" int odk_colsum_fold(const float* const* partial_dev, float* const* colsum_dev, const int* widths, const int* nblk, int count, void* stream) {

@@ -51,7 +51,24 @@ class MlpDesc(C.Structure):
     """odk_mlp_desc (include/odk.h)."""
     _fields_ = [("x", C.c_void_p), ("in_mean", C.c_void_p), ("in_std", C.c_void_p), ("wf", C.c_void_p * 4), ("wb", C.c_void_p * 4), ("b", C.c_void_p * 4), ("xp", C.c_void_p), ("h", C.c_void_p * 3),
                 ("g", C.c_void_p * 3), ("out", C.c_void_p), ("dout", C.c_void_p), ("doutp", C.c_void_p), ("dz", C.c_void_p * 3),
-                ("bias_partial", C.c_void_p * 4), ("n", C.c_int), ("n_in", C.c_int), ("n_out", C.c_int)]
+                ("bias_partial", C.c_void_p * 4), ("n", C.c_int), ("n_in", C.c_int), ("n_out", C.c_int),
+                ("row_idx", C.c_void_p), ("cursor", C.c_void_p), ("x_tail", C.c_void_p), ("traj_len", C.c_int), ("n_main", C.c_int), ("n_traj", C.c_int)]
+
+
+class StepTail(C.Structure):
+    """odk_step_tail (include/odk.h)."""
+    _fields_ = [("cursor_dev", C.c_void_p), ("loss_partials_dev", C.c_void_p), ("n_loss_partials", C.c_int), ("losses_dev", C.c_void_p)]
+
+
+GAE_HEAD_SAMPLES = 32     # ODK_GAE_HEAD_SAMPLES: samples per workgroup of odk_ppo_gae_head (= entries of its loss partials per 32 samples)
+
+
+class GaeHeadArgs(C.Structure):
+    """odk_gae_head_args (include/odk.h)."""
+    _fields_ = [(k, C.c_void_p) for k in ("logits", "values", "raw_action", "old_log_prob", "reward", "termination", "truncation", "noise", "row_idx", "cursor",
+                                         "dlogits", "dvalues", "losses", "loss_partials", "adv_out", "vs_out", "stats_out")] + \
+               [(k, C.c_int) for k in ("B", "T", "action_size", "n_traj", "normalize_advantage")] + \
+               [(k, C.c_float) for k in ("gae_lambda", "discount", "clipping_epsilon", "entropy_cost", "grad_scale")]
 
 
 class GradFinish(C.Structure):
@@ -146,6 +163,9 @@ def load_library() -> C.CDLL:
     L.odk_mlp_set_profile.restype = None
     L.odk_pack_weights.argtypes = [P, C.c_longlong, P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), P]
     L.odk_adam_clip_packed.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), C.c_int, P]
+    L.odk_adam_clip_packed_tail.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), C.c_int,
+                                            C.POINTER(StepTail), P]
+    L.odk_ppo_gae_head.argtypes = [C.POINTER(GaeHeadArgs), P]
     L.odk_colsum_fold.argtypes = [PP, PP, IP, IP, C.c_int, P]
     L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, P, C.c_int, C.c_longlong, P]
     _lib = L
@@ -159,7 +179,8 @@ EXPORTED_SYMBOLS = (
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_set_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
     "odk_policy_sample", "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows", "odk_dw_gemm",
-    "odk_mlp_forward", "odk_mlp_backward", "odk_mlp_set_profile", "odk_pack_weights", "odk_adam_clip_packed", "odk_colsum_fold")
+    "odk_mlp_forward", "odk_mlp_backward", "odk_mlp_set_profile", "odk_pack_weights", "odk_adam_clip_packed", "odk_colsum_fold",
+    "odk_adam_clip_packed_tail", "odk_ppo_gae_head")
 
 
 def _chk(rc: int):
@@ -443,16 +464,71 @@ def pack_weights(params, fwd_packed, bwd_packed, table: WeightTable):
 
 
 def adam_clip_packed(params, grads, m, v, acc, fwd_packed, bwd_packed, table: WeightTable, lr: float, max_grad_norm: float = 0.0, b1: float = 0.9,
-                     b2: float = 0.999, eps: float = 1e-8, norm_blocks: int = 0):
+                     b2: float = 0.999, eps: float = 1e-8, norm_blocks: int = 0, cursor=None, loss_partials=None, losses=None):
     """`adam_clip` that also writes every updated weight to its places in the packed copies (`odk_adam_clip_packed`).
     `norm_blocks` > 0: the gradient's finishing launch (`DwGemm(..., acc=acc)`) already left that many partial sums of the
-    squared norm in acc[2:] and advanced the step count: no norm launch here."""
+    squared norm in acc[2:] and advanced the step count: no norm launch here.  End-of-step duties of the same launch
+    (`odk_adam_clip_packed_tail`, all optional): `cursor` (int32 CUDA tensor of one element) -- the minibatch cursor of the learner's
+    schedule, advanced by one; `loss_partials` ([w, 4], what `GaeHead` leaves) folded into `losses` ([4], +=) in workgroup order."""
     _f32c(params, grads, m, v, acc, fwd_packed, bwd_packed)
     if acc.numel() < ADAM_ACC_FLOATS or fwd_packed.numel() < table.fwd_size or bwd_packed.numel() < table.bwd_size:
         raise OdkError("adam_clip_packed: acc needs ADAM_ACC_FLOATS floats, the packed buffers table.fwd_size / bwd_size")
-    _chk(load_library().odk_adam_clip_packed(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
-                                             max_grad_norm or 0.0, _ptr(fwd_packed), fwd_packed.numel(), _ptr(bwd_packed), bwd_packed.numel(),
-                                             C.byref(table.c), int(norm_blocks), _stream(params)))
+    if cursor is not None and not (cursor.is_cuda and cursor.numel() == 1 and cursor.element_size() == 4 and not cursor.dtype.is_floating_point):
+        raise OdkError("adam_clip_packed: cursor must be a one-element int32 CUDA tensor")
+    tail = None
+    if cursor is not None or loss_partials is not None:
+        _f32c(loss_partials, losses)
+        if loss_partials is not None and (losses is None or losses.numel() < 4 or loss_partials.numel() % 4):
+            raise OdkError("adam_clip_packed: loss_partials [w, 4] need losses [4]")
+        tail = StepTail(None if cursor is None else cursor.data_ptr(), None if loss_partials is None else loss_partials.data_ptr(),
+                        0 if loss_partials is None else loss_partials.numel() // 4, None if losses is None else losses.data_ptr())
+    _chk(load_library().odk_adam_clip_packed_tail(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
+                                                  max_grad_norm or 0.0, _ptr(fwd_packed), fwd_packed.numel(), _ptr(bwd_packed), bwd_packed.numel(),
+                                                  C.byref(table.c), int(norm_blocks), C.byref(tail) if tail is not None else None, _stream(params)))
+
+
+class GaeHead:
+    """GAE + advantage statistics + PPO loss head of a minibatch in ONE launch, the rollout read through the schedule's trajectory
+    indices (`odk_ppo_gae_head`; include/odk.h names every argument).  Built once over fixed tensors:
+      logits [n, 2A], values [n + B], rollout tensors raw_action [n_traj, T, A], log_prob / reward / termination / truncation
+      [n_traj, T], noise [steps, n, A], schedule int64 [steps * B], cursor int32 [1], dlogits [n, 2A], dvalues [>= n], losses [4];
+      optional adv / vs [n] and stats [2] (copies of the intermediate results); `loss_partials` ([ceil(n / 32), 4]): the per-workgroup loss
+      sums go there instead of float atomics on `losses` (`adam_clip_packed(loss_partials=..., losses=...)` folds them)."""
+
+    def __init__(self, logits, values, rollout: dict, noise, schedule, cursor, dlogits, dvalues, losses, B: int, T: int, cfg: dict, grad_scale: float = 1.0,
+                 adv=None, vs=None, stats=None, loss_partials=None):
+        import torch
+        n, A = B * T, logits.shape[1] // 2
+        fl = [logits, values, noise, dlogits, dvalues, losses] + [rollout[k] for k in ("raw_action", "log_prob", "reward", "termination", "truncation")]
+        _f32c(*fl, adv, vs, stats, loss_partials)
+        if loss_partials is not None and loss_partials.numel() < 4 * ((n + GAE_HEAD_SAMPLES - 1) // GAE_HEAD_SAMPLES):
+            raise OdkError("GaeHead: loss_partials needs 4 floats per 32 samples")
+        n_traj = int(rollout["reward"].shape[0])
+        if tuple(logits.shape) != (n, 2 * A) or values.numel() < n + B or dlogits.numel() != n * 2 * A or dvalues.numel() < n or losses.numel() < 4:
+            raise OdkError("GaeHead: logits [B T, 2 A], values [B T + B], dlogits like logits, dvalues [>= B T], losses [4]")
+        if any(int(rollout[k].shape[0]) != n_traj or int(rollout[k][0].numel()) != T * (A if k == "raw_action" else 1)
+               for k in ("raw_action", "log_prob", "reward", "termination", "truncation")):
+            raise OdkError("GaeHead: rollout tensors must be [n_traj, T(, A)]")
+        if not (schedule.is_cuda and schedule.dtype == torch.int64 and schedule.is_contiguous() and schedule.numel() % B == 0):
+            raise OdkError("GaeHead: schedule must be a contiguous int64 CUDA tensor of steps * B entries")
+        if not (cursor.is_cuda and cursor.dtype == torch.int32 and cursor.numel() == 1):
+            raise OdkError("GaeHead: cursor must be a one-element int32 CUDA tensor")
+        if noise.numel() < (schedule.numel() // B) * n * A:
+            raise OdkError("GaeHead: the noise pool needs one [n, A] slot per schedule step")
+        if n > 5120 or B > 1024:
+            raise OdkError("GaeHead: B * T <= 5120, B <= 1024")
+        a = GaeHeadArgs()
+        a.logits, a.values, a.noise, a.dlogits, a.dvalues, a.losses = (t.data_ptr() for t in (logits, values, noise, dlogits, dvalues, losses))
+        a.raw_action, a.old_log_prob, a.reward, a.termination, a.truncation = (rollout[k].data_ptr() for k in ("raw_action", "log_prob", "reward", "termination", "truncation"))
+        a.row_idx, a.cursor = schedule.data_ptr(), cursor.data_ptr()
+        a.adv_out, a.vs_out, a.stats_out, a.loss_partials = (None if t is None else t.data_ptr() for t in (adv, vs, stats, loss_partials))
+        a.B, a.T, a.action_size, a.n_traj, a.normalize_advantage = int(B), int(T), int(A), n_traj, int(bool(cfg["normalize_advantage"]))
+        a.gae_lambda, a.discount, a.clipping_epsilon, a.entropy_cost, a.grad_scale = (float(cfg["gae_lambda"]), float(cfg["discounting"]), float(cfg["clipping_epsilon"]),
+                                                                                       float(cfg["entropy_cost"]), float(grad_scale))
+        self.a, self.keep = a, (fl, rollout, schedule, cursor, adv, vs, stats, loss_partials)
+
+    def __call__(self):
+        _chk(load_library().odk_ppo_gae_head(C.byref(self.a), _stream(self.keep[0][0])))
 
 
 class ColsumFold:
@@ -501,16 +577,26 @@ class FusedMLP:
         self.train = []
         for d, nt in zip(self.desc, nets):
             x, out = nt["x"], nt["out"]
-            n, n_in = x.shape
+            n, n_in = out.shape[0], x.shape[1]      # (with row sources x is the whole rollout: the row count is the output's)
             n_out = out.shape[1]
             widths = (n_in,) + MLP_HIDDEN + (n_out,)
-            if n_in > MLP_MAX_IN or n_out > MLP_MAX_OUT or out.shape[0] != n:
+            if n_in > MLP_MAX_IN or n_out > MLP_MAX_OUT or (nt.get("row_idx") is None and x.shape[0] != n):
                 raise OdkError("FusedMLP: n_in <= 224, n_out <= 32")
             _f32c(x, out, *nt["wf"], *nt["b"])
             for l in range(4):
                 if nt["wf"][l].numel() != _pad16(widths[l]) * widths[l + 1] or nt["b"][l].numel() != widths[l + 1]:
                     raise OdkError(f"FusedMLP: layer {l} is not {widths[l]} -> {widths[l + 1]} (hidden widths are fixed at {MLP_HIDDEN})")
             d.x, d.out, d.n, d.n_in, d.n_out = x.data_ptr(), out.data_ptr(), int(n), int(n_in), int(n_out)
+            if nt.get("row_idx") is not None:      # rows through the minibatch schedule (odk_mlp_desc.row_idx): x is the whole rollout
+                import torch
+                ri, cur = nt["row_idx"], nt["cursor"]
+                if not (ri.is_cuda and ri.dtype == torch.int64 and ri.is_contiguous() and cur.is_cuda and cur.dtype == torch.int32 and cur.numel() == 1):
+                    raise OdkError("FusedMLP: row_idx int64 / cursor int32[1] CUDA tensors")
+                d.row_idx, d.cursor = ri.data_ptr(), cur.data_ptr()
+                d.traj_len, d.n_main, d.n_traj = int(nt["traj_len"]), int(nt["n_main"]), int(nt["n_traj"])
+                if nt.get("x_tail") is not None:
+                    _f32c(nt["x_tail"])
+                    d.x_tail = nt["x_tail"].data_ptr()
             if nt.get("in_mean") is not None:      # normalise the input on load: (x - in_mean) / in_std
                 _f32c(nt["in_mean"], nt["in_std"])
                 if nt["in_mean"].numel() != n_in or nt["in_std"].numel() != n_in:

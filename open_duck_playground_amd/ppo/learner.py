@@ -179,12 +179,13 @@ class _FlatMLP:
                 off += n
         self.end = off
 
-    def bind(self, x, dz_top, fused: bool):
+    def bind(self, x, dz_top, fused: bool, n: int = None, rows: dict = None):
         """Fixes the step's tensors: x [n, in] (network input), dz_top [n, out] (gradient w.r.t. the output, written by the loss
         head).  Library path (`fused` false: one GEMM per layer): allocates z / h per layer, dz / dh per hidden layer and the
-        bias-gradient tile sums; the fused path (csrc/odk_mlp.hip) needs only the output buffer here, see `fused_desc`."""
-        n, dev = x.shape[0], x.device
-        self.x, self.dz_top = x, dz_top
+        bias-gradient tile sums; the fused path (csrc/odk_mlp.hip) needs only the output buffer here, see `fused_desc`.
+        `rows` (fused path): the row sources of `odk_mlp_desc` -- x is then the WHOLE rollout and `n` the minibatch's row count."""
+        n, dev = (x.shape[0] if n is None else int(n)), x.device
+        self.x, self.dz_top, self.n, self.rows = x, dz_top, n, rows
         self.zs = [torch.empty(n, w.shape[0], device=dev) if (not fused or i == len(self.W) - 1) else None for i, w in enumerate(self.W)]
         if fused:
             return
@@ -208,14 +209,14 @@ class _FlatMLP:
     def fused_desc(self, table, k0, packed_f, packed_b):
         """This network for `engine.FusedMLP`: the bound buffers + swish' buffers, bias-gradient tile sums (16-row tiles, engine.MLP_TILE) and the
         views of its weights (entries k0 .. k0 + 3 of `table`) inside the packed buffers."""
-        n, n_in, n_out = self.x.shape[0], self.x.shape[1], self.W[-1].shape[0]
+        n, n_in, n_out = self.n, self.x.shape[1], self.W[-1].shape[0]
         tb = engine.FusedMLP.train_buffers(n, n_in, n_out, self.x.device)
         self.tile_sums, self.tiles = tb["bias_partial"], engine.quad_rows(n) // engine.MLP_TILE
         # weight gradients dW_l = dz_l^T h_{l-1}: (dz, h, n_out, n_in, offset in the flat gradient buffer), quad-row operands
         acts, dzs = [tb["xp"]] + tb["h"], tb["dz"] + [tb["doutp"]]
         self.dw_layers = [(dzs[l], acts[l], w.shape[0], w.shape[1], self.goff[l]) for l, w in enumerate(self.W)]
         return dict(x=self.x, wf=[table.fwd_view(packed_f, k0 + l) for l in range(4)], wb=[table.bwd_view(packed_b, k0 + l) for l in range(4)],
-                    b=self.b, out=self.zs[-1], dout=self.dz_top, **tb)
+                    b=self.b, out=self.zs[-1], dout=self.dz_top, **tb, **(self.rows or {}))
 
     def forward(self):
         for i, (W, b) in enumerate(zip(self.W, self.b)):
@@ -245,13 +246,15 @@ class FlatLearner:
     KEYS = ("obs", "priv", "raw_action", "log_prob", "reward", "termination", "truncation")
 
     def __init__(self, net: PPONetworks, cfg: Dict, B: int, T: int, world: int = 1, group=None, use_graph: bool = True,
-                 split_update=None, fused_norm: bool = True, capture_allreduce=None):
+                 split_update=None, fused_norm: bool = True, capture_allreduce=None, n_traj: int = None):
         """`split_update` (default: world > 1) runs the step as graph A (loss + gradients) -> all-reduce of the flat gradient
         -> graph B (clip + Adam); tests force it at world size 1 to drive the RCCL stream hand-over on one GPU.
         `capture_allreduce` (default: $ODK_LEARNER_CAPTURE_ALLREDUCE == "1"; needs a process group on the RCCL backend): the
         all-reduce is CAPTURED between the two halves, so a data-parallel step is ONE graph replay again (c10d records the
         collective on its own stream inside the capture; no host-issued call between two replays).  Opt-in: measured on a one-rank
         group only (`bench.py --mode ppo --force-split`), no multi-GPU box has run it.
+        `n_traj`: how many trajectories of a rollout the learner's resident copy holds (default B * cfg["num_minibatches"]; grown on
+        demand).
         `fused_norm` false: the gradient norm from its own launch even without an all-reduce (the summation order of the split
         path: tests compare the two bit for bit)."""
         dev = next(net.parameters()).device
@@ -270,10 +273,6 @@ class FlatLearner:
         n = B * T
         od, pd = net.policy.layers[0].in_features, net.value.layers[0].in_features
         z = lambda *s: torch.zeros(*s, device=dev)
-        self.priv_all = z(n + B, pd)                # minibatch privileged obs, then the bootstrap rows
-        self.static = dict(obs=z(B, T, od), priv=self.priv_all[:n].view(B, T, pd), last_priv=self.priv_all[n:], raw_action=z(B, T, A),
-                           log_prob=z(B, T), reward=z(B, T), termination=z(B, T), truncation=z(B, T))
-        self.noise = z(n, A)
         self.vs, self.adv, self.stats = z(B, T), z(B, T), z(2)
         self.dlogits, self.dval_all = z(n, 2 * A), z(n + B, 1)
         fused = self.policy.fused_ok() and self.value.fused_ok() and n >= 128   # (the weight-gradient launch wants >= 8 rows per slice)
@@ -281,39 +280,93 @@ class FlatLearner:
         if capture_allreduce is None:
             capture_allreduce = os.environ.get("ODK_LEARNER_CAPTURE_ALLREDUCE") == "1"
         self.capture_allreduce = bool(capture_allreduce) and self.split_update and use_graph and (world > 1 or group is not None)
-        self.policy.bind(self.static["obs"].view(n, -1), self.dlogits, fused)
-        self.value.bind(self.priv_all, self.dval_all, fused)
+        # INDEXED form of the step (round 5): no gathered copy of the minibatch exists.  The rollout stays resident (`self.roll`), the
+        # training step's whole shuffle is a device array of trajectory indices (`self.sched`, one B-slice per minibatch step) with a
+        # device-side cursor that the clip + Adam launch advances, the entropy noise of all steps sits in a pool indexed by the same
+        # cursor: the forward launch and the fused GAE + head launch read their rows THROUGH the indices, and 128 minibatch steps are
+        # 128 graph replays with nothing between them.  (Minibatches beyond the fused GAE + head launch's LDS: the gathered form.)
+        self.indexed = fused and n <= 5120 and B <= 1024 and os.environ.get("ODK_LEARNER_INDEXED", "1") == "1"
+        self._host_cursor, self._host_steps = 0, 0
+        if self.indexed:
+            self.steps_cap = max(self.NOISE_POOL, int(cfg.get("num_minibatches", 1)) * int(cfg.get("num_updates_per_batch", 1)))
+            self.sched = torch.zeros(self.steps_cap * B, dtype=torch.int64, device=dev)
+            self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._pool = z(self.steps_cap, n, A)
+            self.loss_partials = z((n + engine.GAE_HEAD_SAMPLES - 1) // engine.GAE_HEAD_SAMPLES, 4)     # the head's per-workgroup sums, folded by the Adam launch
+            self._alloc_rollout(int(n_traj) if n_traj else B * int(cfg.get("num_minibatches", 1)), od, pd, A)
+            rows = dict(row_idx=self.sched, cursor=self.cursor, traj_len=T, n_main=n, n_traj=self.cap)
+            self.policy.bind(self.roll["obs"].view(self.cap * T, od), self.dlogits, True, n, rows)
+            self.value.bind(self.roll["priv"].view(self.cap * T, pd), self.dval_all, True, n + B, dict(rows, x_tail=self.roll["last_priv"]))
+        else:
+            self.priv_all = z(n + B, pd)                # minibatch privileged obs, then the bootstrap rows
+            self.static = dict(obs=z(B, T, od), priv=self.priv_all[:n].view(B, T, pd), last_priv=self.priv_all[n:], raw_action=z(B, T, A),
+                               log_prob=z(B, T), reward=z(B, T), termination=z(B, T), truncation=z(B, T))
+            self._noise = z(n, A)
+            self.policy.bind(self.static["obs"].view(n, -1), self.dlogits, fused)
+            self.value.bind(self.priv_all, self.dval_all, fused)
         # whole-network launches (csrc/odk_mlp.hip): forward of both networks = 1 launch, backward-data of both = 1 launch, the
         # weight gradients of all 8 layers = 1 + its finishing launch; the kernels read the weights from packed copies (16-byte
         # pieces along the reduction index) that the Adam launch keeps current
         self.fused = None
+        self._fused_norm = fused_norm
         if fused:
-            kslices = 8       # workspace slices of the weight-gradient launch (each folded from two waves inside the kernel)
-            self.dw_ws = torch.empty(kslices * engine.DwGemm.workspace_stride(n_par), device=dev)   # split-K partial weight gradients
-            nets = (self.policy, self.value)
-            self.wtable = engine.WeightTable([(o, w.shape[0], w.shape[1], l > 0) for f in nets for l, (o, w) in enumerate(zip(f.goff, f.W))])
-            self.packed_f, self.packed_b = z(self.wtable.fwd_size), z(self.wtable.bwd_size)
-            self.fused = engine.FusedMLP([f.fused_desc(self.wtable, 4 * k, self.packed_f, self.packed_b) for k, f in enumerate(nets)])
-            # the launch that folds the weight gradients' row slices also folds the bias gradients' tile sums and -- unless the
-            # gradient still has to be all-reduced -- leaves the partial sums of its squared norm for the clip + Adam launch
-            self.dw_all = engine.DwGemm([l for f in nets for l in f.dw_layers], self.flat_g, self.dw_ws, kslices,
-                                        bias=[(t, f.gb[i], f.tiles) for f in nets for i, t in enumerate(f.tile_sums)],
-                                        acc=None if (self.split_update or not fused_norm) else self.acc)
+            self._n_par = n_par
+            self._build_fused()
             self.sync_weights()
         self.losses = z(4)                          # running SUMS of (total, policy, value, entropy) over the steps since metrics()
+        self.gae_head = None
+        if self.indexed:
+            self.gae_head = engine.GaeHead(self.policy.zs[-1], self.value.zs[-1].view(-1), self.roll, self._pool, self.sched, self.cursor, self.dlogits,
+                                           self.dval_all.view(-1), self.losses, B, T, cfg, 1.0 / self.world, adv=self.adv.view(-1), vs=self.vs.view(-1),
+                                           stats=self.stats, loss_partials=self.loss_partials)
         self.nsteps = 0
-        self.graph_a = self.graph_b = None
+        self.graph_a = self.graph_b = self.graph_k = None
         self._gather = None; self._gather_src = ()
         self.side = torch.cuda.Stream() if (not fused and os.environ.get("ODK_LEARNER_BRANCHES", "1") == "1") else None   # library path: policy || value
         self.sample_noise = True                    # plain-launch path only: tests inject self.noise instead
-        self._pool, self._pool_k = None, 0
+        self._gpool, self._pool_k = None, 0
         if use_graph:
             self._capture()
+
+    def _build_fused(self):
+        dev = self.flat_p.device
+        kslices = 8       # workspace slices of the weight-gradient launch (each folded from two waves inside the kernel)
+        if getattr(self, "dw_ws", None) is None:
+            self.dw_ws = torch.empty(kslices * engine.DwGemm.workspace_stride(self._n_par), device=dev)   # split-K partial weight gradients
+        nets = (self.policy, self.value)
+        self.wtable = engine.WeightTable([(o, w.shape[0], w.shape[1], l > 0) for f in nets for l, (o, w) in enumerate(zip(f.goff, f.W))])
+        if getattr(self, "packed_f", None) is None:
+            self.packed_f, self.packed_b = torch.zeros(self.wtable.fwd_size, device=dev), torch.zeros(self.wtable.bwd_size, device=dev)
+        self.fused = engine.FusedMLP([f.fused_desc(self.wtable, 4 * k, self.packed_f, self.packed_b) for k, f in enumerate(nets)])
+        # the launch that folds the weight gradients' row slices also folds the bias gradients' tile sums and -- unless the
+        # gradient still has to be all-reduced -- leaves the partial sums of its squared norm for the clip + Adam launch
+        self.dw_all = engine.DwGemm([l for f in nets for l in f.dw_layers], self.flat_g, self.dw_ws, kslices,
+                                    bias=[(t, f.gb[i], f.tiles) for f in nets for i, t in enumerate(f.tile_sums)],
+                                    acc=None if (self.split_update or not self._fused_norm) else self.acc)
+
+    def _alloc_rollout(self, cap: int, od: int, pd: int, A: int):
+        dev, T = self.flat_p.device, self.T
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.cap = int(cap)
+        self.roll = dict(obs=z(cap, T, od), priv=z(cap, T, pd), last_priv=z(cap, pd), raw_action=z(cap, T, A), log_prob=z(cap, T), reward=z(cap, T),
+                         termination=z(cap, T), truncation=z(cap, T))
+
+    @property
+    def noise(self):
+        """The entropy sample the NEXT step reads, [n, A] (tests inject theirs here): the pool slot under the cursor."""
+        return self._pool[self._host_cursor] if self.indexed else self._noise
 
     # ---- the step, as plain stream-ordered launches (captured below) ----
     @torch.no_grad()
     def _loss_and_grads(self):
-        B, T, n, s, cfg = self.B, self.T, self.B * self.T, self.static, self.cfg
+        B, T, n, cfg = self.B, self.T, self.B * self.T, self.cfg
+        if self.indexed:
+            self.fused.forward()          # rows through the schedule: no gathered copy
+            self.gae_head()               # GAE + advantage statistics + loss head, one launch
+            self.fused.backward()
+            self.dw_all()                 # weight gradients; its finishing launch: slice fold + bias gradients (+ the norm's partial sums)
+            return
+        s = self.static
         if self.fused is not None:
             self.fused.forward()
             zp, vals = self.policy.zs[-1], self.value.zs[-1].view(-1)
@@ -358,6 +411,54 @@ class FlatLearner:
     def _draw_noise(self):
         self.noise.normal_()
 
+    @torch.no_grad()
+    def load_rollout(self, prep: Dict[str, torch.Tensor]):
+        """Indexed form: copies a PREPARED rollout (`prepare_rollout`: [N, T, ...] tensors) into the resident buffers the kernels index."""
+        N = int(prep["reward"].shape[0])
+        self._fit_rollout(N)
+        for k, buf in self.roll.items():
+            buf[:N].copy_(prep[k])
+        self.n_loaded = N
+
+    @torch.no_grad()
+    def load_rollout_from(self, net: PPONetworks, data: Dict[str, torch.Tensor], cfg: Dict):
+        """`prepare_rollout` written straight into the resident buffers (no intermediate copy of the 200 MB rollout)."""
+        N = int(data["reward"].shape[0])
+        self._fit_rollout(N)
+        prepare_rollout(net, data, cfg, out={k: v[:N] for k, v in self.roll.items()})
+        self.n_loaded = N
+
+    def _fit_rollout(self, N: int):
+        if N <= self.cap:
+            return
+        # a larger rollout than the resident copy was sized for: new buffers, new descriptors, new graphs (rare: construction-time sizing is the rule)
+        od, pd, A = self.roll["obs"].shape[2], self.roll["priv"].shape[2], self.roll["raw_action"].shape[2]
+        had_graph = self.graph_a is not None
+        self.graph_a = self.graph_b = self.graph_k = None
+        self._alloc_rollout(N, od, pd, A)
+        n, B, T = self.B * self.T, self.B, self.T
+        rows = dict(row_idx=self.sched, cursor=self.cursor, traj_len=T, n_main=n, n_traj=self.cap)
+        self.policy.bind(self.roll["obs"].view(self.cap * T, od), self.dlogits, True, n, rows)
+        self.value.bind(self.roll["priv"].view(self.cap * T, pd), self.dval_all, True, n + B, dict(rows, x_tail=self.roll["last_priv"]))
+        self._build_fused()
+        self.gae_head = engine.GaeHead(self.policy.zs[-1], self.value.zs[-1].view(-1), self.roll, self._pool, self.sched, self.cursor, self.dlogits,
+                                       self.dval_all.view(-1), self.losses, B, T, self.cfg, 1.0 / self.world, adv=self.adv.view(-1), vs=self.vs.view(-1),
+                                       stats=self.stats, loss_partials=self.loss_partials)
+        if had_graph:
+            self._capture()
+
+    @torch.no_grad()
+    def set_schedule(self, perms: torch.Tensor):
+        """Indexed form: the trajectory indices of the next `perms.numel() / B` minibatch steps (the training step's shuffles, in order);
+        resets the cursor and draws the entropy noise of all of them."""
+        steps = perms.numel() // self.B
+        if perms.numel() != steps * self.B or steps < 1 or steps > self.steps_cap:
+            raise engine.OdkError(f"set_schedule: {perms.numel()} indices are not 1..{self.steps_cap} minibatches of {self.B} trajectories")
+        self.sched[:perms.numel()].copy_(perms)
+        self.cursor.zero_()
+        self._host_cursor, self._host_steps = 0, steps
+        self._pool[:steps].normal_()
+
     NOISE_POOL = 128   # minibatch steps per refill (= steps per training step in the reference configuration)
 
     @torch.no_grad()
@@ -366,12 +467,12 @@ class FlatLearner:
         generator's seed / offset fills + the kernel); a pool refilled once per 128 steps costs none -- this step's slice is
         copied into the static noise buffer by the minibatch gather launch itself (a "direct" field of `odk_gather_rows`).
         Returns the slice's first row in the pool viewed as [NOISE_POOL * B, T * A]."""
-        if self._pool is None:
-            self._pool = torch.empty(self.NOISE_POOL, *self.noise.shape, device=self.noise.device)
+        if self._gpool is None:
+            self._gpool = torch.empty(self.NOISE_POOL, *self.noise.shape, device=self.noise.device)
             self._pool_k = self.NOISE_POOL
             self._gather = None
         if self._pool_k >= self.NOISE_POOL:
-            self._pool.normal_()
+            self._gpool.normal_()
             self._pool_k = 0
         k = self._pool_k
         self._pool_k += 1
@@ -381,7 +482,9 @@ class FlatLearner:
     def _update(self):
         if self.fused is not None:
             engine.adam_clip_packed(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.packed_f, self.packed_b, self.wtable,
-                                    self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0, norm_blocks=self.dw_all.norm_blocks)
+                                    self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0, norm_blocks=self.dw_all.norm_blocks,
+                                    cursor=self.cursor if self.indexed else None, loss_partials=self.loss_partials if self.indexed else None,
+                                    losses=self.losses if self.indexed else None)
         else:
             engine.adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.acc, self.cfg["learning_rate"], self.cfg.get("max_grad_norm") or 0.0)
 
@@ -412,6 +515,9 @@ class FlatLearner:
             t.copy_(k)                              # the warm-up steps must not train
         self.sync_weights()
         self.losses.zero_()
+        if self.indexed:
+            self.cursor.zero_()                     # (the warm-up steps advanced it)
+            self._host_cursor = 0
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self._loss_and_grads()                  # the noise buffer is filled before each replay (load_minibatch)
@@ -421,6 +527,19 @@ class FlatLearner:
                 import torch.distributed as dist
                 dist.all_reduce(self.flat_g, group=self.group)
                 self._update()
+        # K consecutive steps as ONE graph (indexed form: every step's launches are the same nodes -- the cursor moves on the device): a
+        # replay per step left ~8 us of idle GPU between two graphs (the gather launch used to sit there), K = 32 leaves none
+        self.graph_k, self.K = None, 0
+        K = int(os.environ.get("ODK_LEARNER_STEPS_PER_GRAPH", "32"))
+        if self.indexed and K > 1 and (not self.split_update or self.capture_allreduce):
+            self.graph_k, self.K = torch.cuda.CUDAGraph(), K
+            with torch.cuda.graph(self.graph_k):
+                for _ in range(K):
+                    self._loss_and_grads()
+                    if self.capture_allreduce:
+                        import torch.distributed as dist
+                        dist.all_reduce(self.flat_g, group=self.group)
+                    self._update()
         if self.split_update and not self.capture_allreduce:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b):
@@ -428,24 +547,51 @@ class FlatLearner:
 
     # ---- public ----
     def load_minibatch(self, data: Dict[str, torch.Tensor], idx: torch.Tensor):
-        """Gathers trajectories `idx` of the ([N, T, ...]) rollout tensors into the static buffers: one launch for all
-        eight fields (`odk_gather_rows`)."""
+        """ONE minibatch = trajectories `idx` of the prepared ([N, T, ...]) rollout tensors.  Indexed form: the rollout is copied into
+        the resident buffers (every call: this is the convenience path of tests and tools -- a training step goes through
+        `load_rollout_from` + `set_schedule` once and then only replays) and `idx` becomes a one-step schedule; gathered form: one
+        `odk_gather_rows` launch for all eight fields into the static minibatch buffers."""
+        if self.indexed:
+            if not (idx.is_cuda and idx.dtype == torch.int64 and idx.numel() == self.B):
+                raise engine.OdkError(f"load_minibatch: idx must be an int64 CUDA tensor of {self.B} trajectory numbers")
+            self.load_rollout(data)
+            self.sched[:self.B].copy_(idx)
+            self.cursor.zero_()
+            self._host_cursor, self._host_steps = 0, 1
+            if self.graph_a is not None:
+                self._pool[0].normal_()
+            return
         keys = self.KEYS + ("last_priv",)
         base = [self._noise_block()] if self.graph_a is not None else []     # (may replace the pool: before the gather is built)
-        srcs = tuple(data[k] for k in keys) + ((self._pool,) if base else ())
+        srcs = tuple(data[k] for k in keys) + ((self._gpool,) if base else ())
         if self._gather is None or len(srcs) != len(self._gather_src) or any(a is not b for a, b in zip(self._gather_src, srcs)):
-            direct = [(self._pool.view(self.NOISE_POOL * self.B, -1), self.noise.view(self.B, -1))] if base else []
+            direct = [(self._gpool.view(self.NOISE_POOL * self.B, -1), self.noise.view(self.B, -1))] if base else []
             self._gather = engine.RowGather([(data[k], self.static[k]) for k in keys], direct)
             self._gather_src = srcs
         self._gather(idx, base)
 
+    def run(self, steps: int):
+        """`steps` consecutive minibatch steps of the schedule: K-step graph replays while K steps are left, single steps for the rest."""
+        while steps > 0:
+            if self.graph_k is not None and steps >= self.K and self._host_cursor + self.K <= self._host_steps:
+                self.graph_k.replay()
+                self._host_cursor += self.K; self.nsteps += self.K; steps -= self.K
+            else:
+                self.step(); steps -= 1
+        return self.losses
+
     def step(self):
         """One clipped-Adam step on the loaded minibatch.  The loss head ADDS this step's (total, policy, value, entropy)
         to `self.losses` (no sync); `metrics()` turns the sums into means."""
+        if self.indexed:
+            if self._host_cursor >= self._host_steps:
+                raise engine.OdkError("FlatLearner.step: the schedule is used up (load_minibatch / set_schedule first)")
+            if self.graph_a is None and self.sample_noise:
+                self._draw_noise()                     # (before the cursor's host mirror moves: `noise` is the slot under it)
         if self.graph_a is not None:
             self.graph_a.replay()                       # (its entropy noise came with load_minibatch)
         else:
-            if self.sample_noise:
+            if self.sample_noise and not self.indexed:
                 self._draw_noise()
             self._loss_and_grads()
             if not self.split_update:
@@ -462,6 +608,8 @@ class FlatLearner:
             else:
                 self._update()
         self.nsteps += 1
+        if self.indexed:
+            self._host_cursor += 1
         if _DEBUG_NONFINITE:
             self._debug_check()
         return self.losses
@@ -472,11 +620,16 @@ class FlatLearner:
             return
         self._reported = True
         print("NONFINITE losses", self.losses.tolist(), "stats", self.stats.tolist(), "acc", self.acc.tolist(), flush=True)
-        for k, v in self.static.items():
+        for k, v in (self.roll if self.indexed else self.static).items():
             print("   static", k, bool(torch.isfinite(v).all()), float(v.abs().nan_to_num().max()), flush=True)
         for nm in ("noise", "vs", "adv", "dlogits", "dval_all", "flat_g", "flat_p", "m", "v"):
             t = getattr(self, nm)
             print("   ", nm, bool(torch.isfinite(t).all()), float(t.abs().nan_to_num().max()), flush=True)
+
+    def last_step_losses(self):
+        """(total, policy, value, entropy) of the most recent `_loss_and_grads()`: the indexed form's loss head leaves per-workgroup sums
+        that the clip + Adam launch folds into `losses`; a caller that runs the loss without the update (tests) folds them here."""
+        return self.loss_partials.sum(0) if self.indexed else self.losses
 
     def metrics(self, reset: bool = True):
         """Mean of the four losses over every minibatch step since the last reset, averaged over the data-parallel ranks
@@ -493,7 +646,7 @@ class FlatLearner:
 
     def close(self):
         """Drops the captured graphs and turns the process-wide TunableOp switch off again."""
-        self.graph_a = self.graph_b = None
+        self.graph_a = self.graph_b = self.graph_k = None
         tunable_off()
 
     def optimizer_state(self):
@@ -557,10 +710,19 @@ def fused_policy(net: PPONetworks, rows: int):
 
 
 @torch.no_grad()
-def prepare_rollout(net: PPONetworks, data: Dict[str, torch.Tensor], cfg: Dict) -> Dict[str, torch.Tensor]:
+def prepare_rollout(net: PPONetworks, data: Dict[str, torch.Tensor], cfg: Dict, out: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """Per-training-step preprocessing shared by all 128 minibatch steps: observation normalisation (the
-    normaliser is fixed during the SGD epochs, as in brax), reward scaling, termination = done & ~truncation."""
-    return dict(obs=net.norm_obs(data["obs"]), priv=net.norm_priv(data["priv"]), last_priv=net.norm_priv(data["last_priv"]),
-                raw_action=data["raw_action"],
-                log_prob=data["log_prob"], reward=data["reward"] * cfg["reward_scaling"],
-                termination=data["done"] * (1.0 - data["truncation"]), truncation=data["truncation"])
+    normaliser is fixed during the SGD epochs, as in brax), reward scaling, termination = done & ~truncation.
+    `out`: same-shaped tensors to write into (the learner's resident rollout) -- the same arithmetic, bit for bit, without the
+    intermediate allocations."""
+    if out is None:
+        return dict(obs=net.norm_obs(data["obs"]), priv=net.norm_priv(data["priv"]), last_priv=net.norm_priv(data["last_priv"]),
+                    raw_action=data["raw_action"],
+                    log_prob=data["log_prob"], reward=data["reward"] * cfg["reward_scaling"],
+                    termination=data["done"] * (1.0 - data["truncation"]), truncation=data["truncation"])
+    for key, nrm in (("obs", net.norm_obs), ("priv", net.norm_priv), ("last_priv", net.norm_priv)):
+        nrm(data[key], out=out[key])
+    out["raw_action"].copy_(data["raw_action"]); out["log_prob"].copy_(data["log_prob"]); out["truncation"].copy_(data["truncation"])
+    torch.mul(data["reward"], cfg["reward_scaling"], out=out["reward"])
+    torch.sub(1.0, data["truncation"], out=out["termination"]); out["termination"].mul_(data["done"])
+    return out

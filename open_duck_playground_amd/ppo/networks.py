@@ -66,8 +66,11 @@ class RunningStats(nn.Module):
         self.count.copy_(count); self.mean.copy_(new_mean.float()); self.summed_variance.copy_(sv.float())
         self.std.copy_(torch.sqrt(torch.clamp(sv / count, min=0)).float().clamp(self.std_min, self.std_max))
 
-    def forward(self, x):
-        return (x - self.mean) / self.std
+    def forward(self, x, out=None):
+        if out is None:
+            return (x - self.mean) / self.std
+        torch.sub(x, self.mean, out=out)        # the same two roundings, written into the caller's buffer
+        return out.div_(self.std)
 
 
 class PPONetworks(nn.Module):

@@ -134,9 +134,18 @@ def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Gen
     nmb = cfg["num_minibatches"]
     if learner is not None:
         from .learner import prepare_rollout
-        prep = prepare_rollout(net, data, cfg)
         learner.sync_weights()                        # (parameters written from outside since the last step, e.g. a restored checkpoint)
-        for _ in range(cfg["num_updates_per_batch"]):
+        nup = cfg["num_updates_per_batch"]
+        if getattr(learner, "indexed", False) and nup * nmb <= learner.steps_cap:
+            # the rollout goes into the learner's resident buffers once, the training step's shuffles become ONE device array of
+            # trajectory indices, and every minibatch step is one graph replay -- no gather, no host-side call between two steps
+            learner.load_rollout_from(net, data, cfg)
+            perms = [torch.randperm(B, generator=gen, device=data["reward"].device) for _ in range(nup)]
+            learner.set_schedule(torch.cat(perms))
+            learner.run(nup * nmb)
+            return learner.metrics() if meter is None else None
+        prep = prepare_rollout(net, data, cfg)
+        for _ in range(nup):
             perm = torch.randperm(B, generator=gen, device=data["reward"].device)
             for mbi in perm.chunk(nmb):
                 learner.load_minibatch(prep, mbi)

@@ -245,14 +245,89 @@ def test_flat_learner_gradients_match_autograd(normalize_advantage, N, fused, mo
     mb["noise"] = lr.noise.view(N // nmb, Tn, 14).clone()
     loss, met = T.ppo_loss(ref, mb, cfg)
     loss.backward()
-    torch.testing.assert_close(lr.losses[0], loss.detach(), rtol=2e-4, atol=1e-6)
-    torch.testing.assert_close(lr.losses[1], met["policy_loss"], rtol=2e-4, atol=1e-6)
-    torch.testing.assert_close(lr.losses[2], met["v_loss"], rtol=2e-4, atol=1e-6)
-    torch.testing.assert_close(lr.losses[3], met["entropy_loss"], rtol=2e-4, atol=1e-6)
+    got = lr.last_step_losses()
+    torch.testing.assert_close(got[0], loss.detach(), rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(got[1], met["policy_loss"], rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(got[2], met["v_loss"], rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(got[3], met["entropy_loss"], rtol=2e-4, atol=1e-6)
     ref_params = list(ref.policy.parameters()) + list(ref.value.parameters())
     flat_ref = torch.cat([p.grad.reshape(-1) for p in ref_params])
     err = (lr.flat_g - flat_ref).abs().max() / flat_ref.abs().max()
     assert err < 2e-4, float(err)
+
+
+def test_indexed_step_equals_the_gathered_step(monkeypatch):
+    """Round 5: the minibatch step WITHOUT a gathered copy -- forward rows through the schedule's trajectory indices
+    (odk_mlp_desc.row_idx), GAE + statistics + loss head in one launch (odk_ppo_gae_head), the cursor advanced by the clip + Adam
+    launch -- against the gathered form (odk_gather_rows + odk_gae + odk_ppo_head): same arithmetic, same orders, so gradients,
+    advantages and parameters agree BIT FOR BIT, step after step along a two-pass schedule; an index outside the rollout poisons its
+    trajectory with NaN instead of reading out of bounds."""
+    from open_duck_playground_amd.ppo import learner as LM
+    from open_duck_playground_amd.ppo import train as T
+    from open_duck_playground_amd.ppo.learner import FlatLearner, prepare_rollout
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    dev = torch.device("cuda")
+    cfg = T.ppo_config(); cfg.update(num_minibatches=4, num_updates_per_batch=2, tune_gemms=False)
+    N, Tn = 64, 20
+    data = _fake_rollout(N, Tn, dev, seed=9)
+    nets, lrs = [], []
+    for indexed in ("1", "0"):
+        monkeypatch.setenv("ODK_LEARNER_INDEXED", indexed)
+        torch.manual_seed(4)
+        n = PPONetworks(101, 212, 14).to(dev)
+        n.norm_obs.update(data["obs"]); n.norm_priv.update(data["priv"])
+        nets.append(n)
+        lrs.append(FlatLearner(n, cfg, N // 4, Tn, use_graph=True))
+    a, b = lrs
+    assert a.indexed and not b.indexed and a.gae_head is not None
+    g = torch.Generator(device=dev).manual_seed(0)
+    perms = torch.cat([torch.randperm(N, generator=g, device=dev) for _ in range(2)])
+    # indexed: one schedule, eight replays; gathered: eight load_minibatch + step, fed the SAME noise
+    a.load_rollout_from(nets[0], data, cfg)
+    a.set_schedule(perms)
+    prep = prepare_rollout(nets[1], data, cfg)
+    for k, v in prep.items():
+        assert torch.equal(a.roll[k][:N], v), k                # prepare_rollout(out=...) == prepare_rollout
+    for k in range(8):
+        b.load_minibatch(prep, perms[k * 16:(k + 1) * 16].contiguous())
+        b.noise.copy_(a.noise)                                  # a.noise = the pool slot under a's cursor
+        a.step(); b.step()
+        assert torch.equal(a.flat_g, b.flat_g), k
+        assert torch.equal(a.adv, b.adv) and torch.equal(a.vs, b.vs) and torch.equal(a.stats, b.stats), k
+        assert torch.equal(a.flat_p, b.flat_p), k
+    assert int(a.cursor) == 8 and float(a.acc[1]) == 8.0
+    torch.testing.assert_close(a.losses, b.losses, rtol=1e-5, atol=1e-6)      # (sums of float atomics: order differs)
+    with pytest.raises(LM.engine.OdkError, match="used up"):
+        a.step()
+    # the compatibility path of the indexed learner: load_minibatch == a one-step schedule
+    idx = perms[:16].contiguous()
+    a.load_minibatch(prep, idx); b.load_minibatch(prep, idx)
+    b.noise.copy_(a.noise)
+    a.step(); b.step()
+    assert torch.equal(a.flat_p, b.flat_p) and int(a.cursor) == 1
+    # an index outside the resident rollout is never dereferenced
+    bad = idx.clone(); bad[3] = a.cap + 5
+    a.load_minibatch(prep, bad)
+    a._loss_and_grads()
+    assert not torch.isfinite(a.last_step_losses()).all()
+    # K steps as one graph: `run` == the same steps one by one (two fresh learners, K = 4 through the environment)
+    monkeypatch.setenv("ODK_LEARNER_INDEXED", "1"); monkeypatch.setenv("ODK_LEARNER_STEPS_PER_GRAPH", "4")
+    pair = []
+    for _ in range(2):
+        torch.manual_seed(4)
+        n = PPONetworks(101, 212, 14).to(dev)
+        n.norm_obs.update(data["obs"]); n.norm_priv.update(data["priv"])
+        pair.append((n, FlatLearner(n, cfg, N // 4, Tn, use_graph=True)))
+    (n1, l1), (n2, l2) = pair
+    assert l1.graph_k is not None and l1.K == 4
+    for (nn, ll) in pair:
+        ll.load_rollout_from(nn, data, cfg); ll.set_schedule(perms)
+    l2._pool.copy_(l1._pool)
+    l1.run(7)                                  # one 4-step replay + three single steps
+    for _ in range(7):
+        l2.step()
+    assert torch.equal(l1.flat_p, l2.flat_p) and int(l1.cursor) == int(l2.cursor) == 7 and l1.nsteps == l2.nsteps == 7
+    torch.testing.assert_close(l1.losses, l2.losses, rtol=0, atol=0)
 
 
 def test_flat_learner_training_step_matches_eager_and_graph_replays():
