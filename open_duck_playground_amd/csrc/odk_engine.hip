@@ -1120,6 +1120,23 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I("nbody", one, 1); m.nb = one[0]; B.I("njnt", one, 1); m.nj = one[0]; B.I("nsite", one, 1); m.nsite = one[0];
   if (!B.ok) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   if (m.nq > MAXQ || m.nv > MAXV || m.nu > MAXU || m.nb > MAXB || m.nj > MAXJ || m.nsite > MAXSITE) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model too large"); }
+  {   // <equality> (mjcf.py compiles joint / connect / weld; the float64 oracle builds their rows): the kernels' row code -- friction-loss,
+      // limit and foot-wrench rows -- has no row between two dofs or two bodies yet, so a model that carries ACTIVE equalities is refused by
+      // name instead of being stepped without them
+    RecHdr eh;
+    if (find_rec((const unsigned char*)blob, len, "eq_type", &eh) && eh.nbytes > 0) {
+      int et[16], ea[16];
+      Blob E{(const unsigned char*)blob, len};
+      const int ne = E.I("eq_type", et, 16), na = E.I("eq_active", ea, 16);
+      if (ne < 0 || na != ne) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "more than 16 equality constraints / eq_active missing"); }
+      for (int k = 0; k < ne; k++)
+        if (ea[k]) {
+          static const char* nm[] = {"connect", "weld", "joint"};
+          delete mo;
+          return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d) is active: equality rows exist in the oracle only, the kernels do not model them", et[k] >= 0 && et[k] < 3 ? nm[et[k]] : "?", k);
+        }
+    }
+  }
   double dtv[1], g3[3], t1[1];
   B.D("opt_timestep", dtv, 1); m.dt = (float)dtv[0];
   B.D("opt_gravity", g3, 3); for (int k = 0; k < 3; k++) m.gravity[k] = (float)g3[k];

@@ -102,6 +102,15 @@ __device__ __forceinline__ void map_block(const Args& a, int b, int& net, int& t
 // (minimum register pressure = one exposed L2 round trip per MFMA).  Groups >= ng are fetched from group 0 (in bounds) and
 // skipped.  NBLK >= 2 everywhere: a 16x16x4 MFMA has 40 cycles of dependent latency for 32 of issue.
 #define ODK_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifndef ODK_MLP_WG_PER_CU
+#define ODK_MLP_WG_PER_CU 4       // resident workgroups per CU the register allocation is held to (4: <= 128 VGPRs, 3: <= 168)
+#endif
+#ifndef ODK_BWD_PREFETCH_G
+#define ODK_BWD_PREFETCH_G 0      // backward: a phase's swish' pieces are fetched one phase ahead instead of behind its MFMAs
+#endif
+#ifndef ODK_MLP_SETPRIO
+#define ODK_MLP_SETPRIO 0         // raise the wave's priority inside the MFMA loops
+#endif
 template <int NBLK, int U>
 struct Phase {
   f32x4 fb[U][NBLK];
@@ -135,6 +144,9 @@ struct Phase {
   // A: LDS address of act[sample c][4 q] (16-byte aligned)
   __device__ __forceinline__ void run(f32x4 (&acc)[NBLK], const float* A) {
     f32x4 fa[U], ga[U], gb[U][NBLK];
+#if ODK_MLP_SETPRIO
+    __builtin_amdgcn_s_setprio(ODK_MLP_SETPRIO);
+#endif
     auto load_a = [&](int G0, f32x4* xa) {
 #pragma unroll
       for (int u = 0; u < U; u++) xa[u] = *reinterpret_cast<const f32x4*>(A + 16 * (G0 + u));   // in bounds of the LDS image (SLACK)
@@ -168,6 +180,9 @@ struct Phase {
       mma(G0 + U, ga, gb);
       ODK_PIN();
     }
+#if ODK_MLP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
 };
 
@@ -203,7 +218,7 @@ __device__ __forceinline__ void fwd_epilogue(const f32x4 (&acc)[NBLK], const flo
   }
 }
 
-__global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
+__global__ void __launch_bounds__(256, ODK_MLP_WG_PER_CU) mlp_fwd_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int net_i, tile;
   map_block(a, blockIdx.x, net_i, tile);
@@ -369,11 +384,13 @@ __global__ void __launch_bounds__(256, 4) mlp_fwd_kernel(Args a) {
 // rows -> partial[col].  swish' is zero in the rows past the end of the batch (the forward pass wrote it so), hence so is dz.
 // gq / dzq: this lane's first column in ITS row quad.  All swish' loads are issued before the first use.
 template <int NBLK>
-__device__ __forceinline__ void bwd_epilogue(const f32x4 (&acc)[NBLK], const float* __restrict__ gq, float* dzq, float* Ls, int P, float* partial, int q) {
-  f32x4 gv[NBLK];
+__device__ __forceinline__ void load_g(f32x4 (&gv)[NBLK], const float* __restrict__ gq) {
 #pragma unroll
   for (int k = 0; k < NBLK; k++) gv[k] = *reinterpret_cast<const f32x4*>(gq + 64 * k);
   ODK_PIN();
+}
+template <int NBLK>
+__device__ __forceinline__ void bwd_epilogue(const f32x4 (&acc)[NBLK], const f32x4 (&gv)[NBLK], float* dzq, float* Ls, int P, float* partial, int q) {
 #pragma unroll
   for (int k = 0; k < NBLK; k++) {
     f32x4 dv;
@@ -392,7 +409,7 @@ __device__ __forceinline__ void bwd_epilogue(const f32x4 (&acc)[NBLK], const flo
   }
 }
 
-__global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
+__global__ void __launch_bounds__(256, ODK_MLP_WG_PER_CU) mlp_bwd_kernel(Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int net_i, tile;
   map_block(a, blockIdx.x, net_i, tile);
@@ -429,22 +446,36 @@ __global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
     for (int t = 0; t < 4; t++) v[t] = D4[(4 * qq + t) * P4 + k];
     *reinterpret_cast<f32x4*>(N.doutp + ((q0 + qq) * nout + k) * 4) = v;
   }
+  f32x4 gv3[2], gv2[4], gv1[8];
+#if ODK_BWD_PREFETCH_G
+  load_g<2>(gv3, N.g[2] + (ql * H3 + w * 32 + c) * 4);       // (the row quads' swish' pieces do not depend on anything computed here)
+  load_g<4>(gv2, N.g[1] + (ql * H2 + w * 64 + c) * 4);
+#endif
   {
     f32x4 acc[2];
     zero(acc);
     const int col = w * 32 + c;
     p3.run(acc, D4 + c * P4 + 4 * q);
     p2.prefetch(N.wb[2], H2, w * 64 + c, q, 0, H3 / 16);
-    bwd_epilogue<2>(acc, N.g[2] + (ql * H3 + col) * 4, N.dz[2] + (ql * H3 + col) * 4, D3 + col, P3, N.bias_partial[2] + (size_t)tile * H3 + col, q);
+#if !ODK_BWD_PREFETCH_G
+    load_g<2>(gv3, N.g[2] + (ql * H3 + col) * 4);
+#endif
+    bwd_epilogue<2>(acc, gv3, N.dz[2] + (ql * H3 + col) * 4, D3 + col, P3, N.bias_partial[2] + (size_t)tile * H3 + col, q);
   }
   __syncthreads();
+#if ODK_BWD_PREFETCH_G
+  load_g<8>(gv1, N.g[0] + (ql * H1 + w * 128 + c) * 4);
+#endif
   {
     f32x4 acc[4];
     zero(acc);
     const int col = w * 64 + c;
     p2.run(acc, D3 + c * P3 + 4 * q);
     p1.prefetch(N.wb[1], H1, w * 128 + c, q, 0, H2 / 16);
-    bwd_epilogue<4>(acc, N.g[1] + (ql * H2 + col) * 4, N.dz[1] + (ql * H2 + col) * 4, D2 + col, P2, N.bias_partial[1] + (size_t)tile * H2 + col, q);
+#if !ODK_BWD_PREFETCH_G
+    load_g<4>(gv2, N.g[1] + (ql * H2 + col) * 4);
+#endif
+    bwd_epilogue<4>(acc, gv2, N.dz[1] + (ql * H2 + col) * 4, D2 + col, P2, N.bias_partial[1] + (size_t)tile * H2 + col, q);
   }
   __syncthreads();
   {
@@ -452,7 +483,10 @@ __global__ void __launch_bounds__(256, 4) mlp_bwd_kernel(Args a) {
     zero(acc);
     const int col = w * 128 + c;
     p1.run(acc, D2 + c * P2 + 4 * q);
-    bwd_epilogue<8>(acc, N.g[0] + (ql * H1 + col) * 4, N.dz[0] + (ql * H1 + col) * 4, nullptr, 0, N.bias_partial[0] + (size_t)tile * H1 + col, q);
+#if !ODK_BWD_PREFETCH_G
+    load_g<8>(gv1, N.g[0] + (ql * H1 + col) * 4);
+#endif
+    bwd_epilogue<8>(acc, gv1, N.dz[0] + (ql * H1 + col) * 4, nullptr, 0, N.bias_partial[0] + (size_t)tile * H1 + col, q);
   }
   ODK_WG_END();
 }

@@ -413,10 +413,39 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
             key[k.attrib.get("name", "")] = dict(
                 qpos=_floats(k.attrib.get("qpos"), nq, qpos0), ctrl=_floats(k.attrib.get("ctrl"), nu, [0] * nu))
 
-    # ---- sections that would change the physics but have no counterpart in the kernels: refuse, never ignore
-    for tag in ("equality", "tendon", "contact"):
+    # ---- sections that would change the physics but have no counterpart anywhere in this build: refuse, never ignore
+    for tag in ("tendon", "contact"):
         if any(len(e) for e in root.findall(tag)):
             raise NotImplementedError(f"<{tag}> is not supported by this engine (Open Duck scenes have none)")
+
+    # ---- <equality>: joint / connect / weld (reference README.md:74-85 "adding a new robot"; the duck's own <equality/> is empty:
+    # open_duck_mini_v2.xml:502).  Compiled into mjModel's eq_* arrays (mjtEq: connect 0, weld 1, joint 2); the float64 oracle builds their
+    # rows, `odk_model_load` accepts what the kernels' row code expresses and refuses the rest by name.
+    body_by_name = {b["name"]: i for i, b in enumerate(bodies) if b["name"]}
+    jnt_by_name = {j["name"]: i for i, j in enumerate(joints) if j["name"]}
+    eqs = []
+    for eq_root in root.findall("equality"):
+        for e in eq_root:
+            a = dfl.get(e.attrib.get("class"), "equality")
+            a.update(e.attrib)
+            common = dict(solref=_floats(a.get("solref"), 2, DEFAULT_SOLREF), solimp=_floats(a.get("solimp"), 5, DEFAULT_SOLIMP),
+                          active=int(a.get("active", "true") == "true"), name=a.get("name", ""))
+            data = np.zeros(11)
+            if e.tag == "joint":
+                j1 = jnt_by_name[a["joint1"]]
+                j2 = jnt_by_name[a["joint2"]] if "joint2" in a else -1
+                if joints[j1]["type"] != JNT_HINGE or (j2 >= 0 and joints[j2]["type"] != JNT_HINGE):
+                    raise NotImplementedError("<equality><joint> couples scalar (hinge) joints")
+                data[:5] = _floats(a.get("polycoef"), 5, [0, 1, 0, 0, 0])
+                eqs.append(dict(type=2, obj1=j1, obj2=j2, data=data, **common))
+            elif e.tag in ("connect", "weld"):
+                if "site1" in a or "site2" in a:
+                    raise NotImplementedError(f"<equality><{e.tag}> by sites: give body1 / body2 (+ anchor)")
+                b1 = body_by_name[a["body1"]]
+                b2 = body_by_name[a["body2"]] if "body2" in a else 0
+                eqs.append(dict(type=0 if e.tag == "connect" else 1, obj1=b1, obj2=b2, data=data, attrs=a, **common))
+            else:
+                raise NotImplementedError(f"<equality><{e.tag}> (joint, connect and weld are compiled)")
 
     # ---- collision geoms (everything with contype|conaffinity != 0)
     col = [g for g in geoms if (g["contype"] or g["conaffinity"])]
@@ -580,6 +609,36 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
     out["names_site"] = np.array([s["name"] for s in sites])
     out["names_sensor"] = np.array(sensor_names)
     out["names_actuator"] = np.array([a["name"] for a in act])
+
+    # equality constraints: the second anchor / the relative pose come from the reference configuration qpos0 (MuJoCo's compiler does
+    # the same when they are not given), so that the constraint is satisfied there
+    if eqs:
+        xpos0, xquat0, _, _ = body_frames(out, qpos0)
+        for q in eqs:
+            if q["type"] == 2:
+                continue
+            a, b1, b2 = q["attrs"], q["obj1"], q["obj2"]
+            R1, R2 = quat_to_mat(xquat0[b1]), quat_to_mat(xquat0[b2])
+            anchor = _floats(a.get("anchor"), 3, [0, 0, 0])
+            if q["type"] == 0:          # connect: anchor in body1's frame; data[3:6] = the same world point in body2's frame
+                q["data"][0:3] = anchor
+                q["data"][3:6] = R2.T @ (xpos0[b1] + R1 @ anchor - xpos0[b2])
+            else:                       # weld: anchor in body2's frame (data[0:3]); data[3:6] = that point in body1's frame; data[6:10] = body2 relative to body1
+                rel = _floats(a.get("relpose"), 7, [0, 1, 0, 0, 0, 0, 0])
+                q["data"][0:3] = anchor
+                if np.any(rel[3:] != 0):
+                    rq = _normalize(rel[3:])
+                    q["data"][3:6] = rel[:3] + quat_to_mat(rq) @ anchor
+                    q["data"][6:10] = rq
+                else:
+                    q["data"][3:6] = R1.T @ (xpos0[b2] + R2 @ anchor - xpos0[b1])
+                    q["data"][6:10] = quat_mul(np.array([xquat0[b1][0], -xquat0[b1][1], -xquat0[b1][2], -xquat0[b1][3]]), xquat0[b2])
+                q["data"][10] = float(a.get("torquescale", 1.0))
+        out["eq_type"] = I32([q["type"] for q in eqs]); out["eq_obj1id"] = I32([q["obj1"] for q in eqs]); out["eq_obj2id"] = I32([q["obj2"] for q in eqs])
+        out["eq_data"] = F64([q["data"] for q in eqs]); out["eq_solref"] = F64([q["solref"] for q in eqs]); out["eq_solimp"] = F64([q["solimp"] for q in eqs])
+        out["eq_active"] = I32([q["active"] for q in eqs])
+        out["names_eq"] = np.array([q["name"] for q in eqs])
+    out["neq"] = I32([len(eqs)])
 
     _set_const(out)
     return out

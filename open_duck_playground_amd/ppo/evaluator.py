@@ -90,7 +90,11 @@ class Evaluator:
                     self._one_step(net)                          # warm-up: this IS step 1 of the evaluation
                 torch.cuda.current_stream().wait_stream(side)
                 self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
+                import torch.distributed as _dist
+                live_pg = _dist.is_available() and _dist.is_initialized()     # (the group's watchdog thread must not trip the capture: learner._capture)
+                if live_pg:
+                    torch.cuda.synchronize()
+                with torch.cuda.graph(self._graph, **(dict(capture_error_mode="thread_local") if live_pg else {})):
                     self._one_step(net)                          # captured, not executed
                 self._graph_key = key
                 done = 1

@@ -518,8 +518,17 @@ class FlatLearner:
         if self.indexed:
             self.cursor.zero_()                     # (the warm-up steps advanced it)
             self._host_cursor = 0
+        # With a live process group its watchdog thread polls events while collectives are outstanding; under the default (global) capture
+        # mode such a query from ANOTHER thread aborts the capture ("operation not permitted when stream is capturing": seen on the
+        # one-rank RCCL group once 33 steps were captured instead of one).  So: nothing outstanding when the capture starts, and the
+        # capture is thread-local.
+        import torch.distributed as _dist
+        live_pg = _dist.is_available() and _dist.is_initialized()
+        if live_pg:
+            torch.cuda.synchronize()
+        cap = dict(capture_error_mode="thread_local") if live_pg else {}
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
+        with torch.cuda.graph(self.graph_a, **cap):
             self._loss_and_grads()                  # the noise buffer is filled before each replay (load_minibatch)
             if not self.split_update:
                 self._update()
@@ -533,7 +542,7 @@ class FlatLearner:
         K = int(os.environ.get("ODK_LEARNER_STEPS_PER_GRAPH", "32"))
         if self.indexed and K > 1 and (not self.split_update or self.capture_allreduce):
             self.graph_k, self.K = torch.cuda.CUDAGraph(), K
-            with torch.cuda.graph(self.graph_k):
+            with torch.cuda.graph(self.graph_k, **cap):
                 for _ in range(K):
                     self._loss_and_grads()
                     if self.capture_allreduce:
@@ -542,7 +551,7 @@ class FlatLearner:
                     self._update()
         if self.split_update and not self.capture_allreduce:
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b):
+            with torch.cuda.graph(self.graph_b, **cap):
                 self._update()
 
     # ---- public ----

@@ -182,6 +182,17 @@ odko_model* odko_model_load(const void* blob, uint64_t len) {
   m->nhullvert = load_f(b, len, "hull_vert", (real*)m->hull_vert, ODKO_MAXHV * 3) / 3;
   m->nhullface = load_i(b, len, "hull_face", (int*)m->hull_face, ODKO_MAXHF * 3) / 3;
   if (!ok || m->nsensor < 0 || m->ncgeom < 0) { free(m); return NULL; }
+  { /* optional equality constraints (mjcf.py: <equality> joint / connect / weld) */
+    rec_hdr eh;
+    if (find_rec(b, len, "eq_type", &eh) && eh.nbytes > 0) {
+      m->neq = load_i(b, len, "eq_type", m->eq_type, ODKO_MAXEQ);
+      if (m->neq < 0 || load_i(b, len, "eq_obj1id", m->eq_obj1id, ODKO_MAXEQ) != m->neq || load_i(b, len, "eq_obj2id", m->eq_obj2id, ODKO_MAXEQ) != m->neq ||
+          load_i(b, len, "eq_active", m->eq_active, ODKO_MAXEQ) != m->neq || load_f(b, len, "eq_data", (real*)m->eq_data, ODKO_MAXEQ * 11) != 11 * m->neq ||
+          load_f(b, len, "eq_solref", (real*)m->eq_solref, ODKO_MAXEQ * 2) != 2 * m->neq || load_f(b, len, "eq_solimp", (real*)m->eq_solimp, ODKO_MAXEQ * 5) != 5 * m->neq) {
+        free(m); return NULL;
+      }
+    }
+  }
   { /* optional height field (scene_rough_terrain_backlash.xml:22) */
     rec_hdr hh;
     { const char* hm = getenv("ODK_ORACLE_HFIELD_MODE"); if (hm) m->hfield_mode = atoi(hm); }   /* hypothesis sweep: the parity tests against a variant kernel build */
@@ -245,6 +256,7 @@ real* odko_model_field(odko_model* m, const char* name, int* count) {
   MF(qpos0, m->nq) MF(key_qpos, m->nq) MF(key_ctrl, m->nu)
   MF(actuator_gainprm0, m->nu) MF(actuator_biasprm, m->nu * 3) MF(actuator_ctrlrange, m->nu * 2) MF(actuator_forcerange, m->nu * 2)
   MF(cgeom_friction, m->ncgeom * 3) MF(jnt_range, m->njnt * 2) MF(gravity, 3) MF(hull_vert, m->nhullvert * 3)
+  MF(eq_data, m->neq * 11) MF(eq_solref, m->neq * 2) MF(eq_solimp, m->neq * 5)
   if (!strcmp(name, "timestep")) { *count = 1; return &m->timestep; }
   if (!strcmp(name, "meaninertia")) { *count = 1; return &m->meaninertia; }
   *count = 0;
@@ -252,7 +264,7 @@ real* odko_model_field(odko_model* m, const char* name, int* count) {
 }
 #define MI(nm) if (!strcmp(name, #nm)) return m->nm;
 int odko_model_int(const odko_model* m, const char* name) {
-  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(nsite) MI(nsensor) MI(nsensordata) MI(ncgeom) MI(npair) MI(iterations) MI(ls_iterations)
+  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(nsite) MI(nsensor) MI(nsensordata) MI(ncgeom) MI(npair) MI(iterations) MI(ls_iterations) MI(neq)
   return -1;
 }
 
@@ -262,6 +274,13 @@ int odko_model_set_int(odko_model* m, const char* name, int value) {
   if (!strcmp(name, "ls_iterations")) { m->ls_iterations = value; return 0; }
   if (!strcmp(name, "hfield_mode")) { m->hfield_mode = value; return 0; }
   return -1;
+}
+
+/* mjData.eq_active counterpart: switches equality constraint e on / off (tests compare a run with and without it) */
+int odko_model_eq_set_active(odko_model* m, int e, int on) {
+  if (e < 0 || e >= m->neq) return -1;
+  m->eq_active[e] = on != 0;
+  return 0;
 }
 
 odko_data* odko_data_new(void) { return (odko_data*)calloc(1, sizeof(odko_data)); }
@@ -1163,8 +1182,16 @@ static void collision_pairs(const odko_model* m, odko_data* d) {
 }
 
 /* ---- constraints (mjx constraint.make_constraint) ---- */
+static void efc_row_params_imp(const odko_model* m, odko_data* d, int r, real pos, real pos_imp, real invweight, const real* solref, const real* solimp,
+                               real vel, real frictionloss);
 static void efc_row_params(const odko_model* m, odko_data* d, int r, real pos, real invweight, const real* solref, const real* solimp,
                            real vel, real frictionloss) {
+  efc_row_params_imp(m, d, r, pos, pos, invweight, solref, solimp, vel, frictionloss);
+}
+/* pos: the row's own residual (enters aref); pos_imp: the distance the impedance is evaluated at -- the same number for scalar rows, the
+ * NORM of the residual vector for the 3 rows of a connect / the 6 rows of a weld (MuJoCo getposdim; MJX constraint._row's pos_imp) */
+static void efc_row_params_imp(const odko_model* m, odko_data* d, int r, real pos, real pos_imp, real invweight, const real* solref, const real* solimp,
+                               real vel, real frictionloss) {
   real timeconst = solref[0], dampratio = solref[1];
   real dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
   if (timeconst < 2 * m->timestep) timeconst = 2 * m->timestep; /* refsafe */
@@ -1174,7 +1201,7 @@ static void efc_row_params(const odko_model* m, odko_data* d, int r, real pos, r
   real b = 2.0 / (dmax * timeconst);
   if (solref[0] <= 0) k = -solref[0] / (dmax * dmax);
   if (solref[1] <= 0) b = -solref[1] / dmax;
-  real imp_x = fabs(pos) / width;
+  real imp_x = fabs(pos_imp) / width;
   real imp_a = (1.0 / pow(mid, power - 1)) * pow(imp_x, power);
   real imp_b = 1 - (1.0 / pow(1 - mid, power - 1)) * pow(1 - imp_x, power);
   real imp_y = imp_x < mid ? imp_a : imp_b;
@@ -1218,10 +1245,92 @@ static void jac_point(const odko_model* m, const odko_data* d, int b, const real
   }
 }
 
+/* rotational Jacobian of body b (support.jac's jacr): column i = the angular part of dof i's motion axis, for the dofs above b */
+static void jac_rot(const odko_model* m, const odko_data* d, int b, real* jacr /* 3 x nv */) {
+  int nv = m->nv;
+  memset(jacr, 0, 3 * (size_t)nv * sizeof(real));
+  while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parentid[b];
+  if (b == 0) return;
+  for (int i = m->body_dofadr[b] + m->body_dofnum[b] - 1; i >= 0; i = m->dof_parentid[i])
+    for (int k = 0; k < 3; k++) jacr[k * nv + i] = d->cdof[i][k];
+}
+
+/* Equality rows (mjx constraint._efc_equality_connect / _weld / _joint, MuJoCo mj_instantiateEquality; [UPSTREAM-MEMORY] like the rest of
+ * the physics: parity unpinned; tests/test_oracle_equality.py holds the rows to their own definitions -- Jacobian = derivative of the
+ * residual, residual decays at the solref rate, a connect carries the weight).  Order as MJX builds them: connects, welds, joints.
+ * Always active, quadratic cost.  Returns the next free row. */
+static int make_equality(const odko_model* m, odko_data* d, int r) {
+  int nv = m->nv;
+  for (int pass = 0; pass < 3; pass++)
+    for (int e = 0; e < m->neq; e++) {
+      if (!m->eq_active[e] || m->eq_type[e] != pass) continue;
+      const real* data = m->eq_data[e];
+      if (pass == ODKO_EQ_JOINT) {
+        int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
+        int i1 = m->jnt_dofadr[j1], q1 = m->jnt_qposadr[j1];
+        real pos = d->qpos[q1] - m->qpos0[q1], invw = m->dof_invweight0[i1], vel = d->qvel[i1];
+        d->efc_J[r * nv + i1] = 1;
+        if (j2 >= 0) {
+          int i2 = m->jnt_dofadr[j2], q2 = m->jnt_qposadr[j2];
+          real x = d->qpos[q2] - m->qpos0[q2];
+          real poly = data[0] + x * (data[1] + x * (data[2] + x * (data[3] + x * data[4])));
+          real dpoly = data[1] + x * (2 * data[2] + x * (3 * data[3] + x * 4 * data[4]));
+          pos -= poly;
+          d->efc_J[r * nv + i2] = -dpoly;
+          invw += m->dof_invweight0[i2];
+          vel -= dpoly * d->qvel[i2];
+        } else {
+          pos -= data[0];
+        }
+        efc_row_params(m, d, r, pos, invw, m->eq_solref[e], m->eq_solimp[e], vel, 0.0);
+        r++;
+        continue;
+      }
+      int b1 = m->eq_obj1id[e], b2 = m->eq_obj2id[e];
+      const real* a1 = pass == ODKO_EQ_CONNECT ? data : data + 3;     /* anchor in body1's frame */
+      const real* a2 = pass == ODKO_EQ_CONNECT ? data + 3 : data;     /* anchor in body2's frame */
+      real p1[3], p2[3], cpos[6], t[3];
+      mat_mulvec(t, d->xmat[b1], a1); for (int k = 0; k < 3; k++) p1[k] = d->xpos[b1][k] + t[k];
+      mat_mulvec(t, d->xmat[b2], a2); for (int k = 0; k < 3; k++) p2[k] = d->xpos[b2][k] + t[k];
+      for (int k = 0; k < 3; k++) cpos[k] = p1[k] - p2[k];
+      real j1[3 * ODKO_MAXV], j2[3 * ODKO_MAXV];
+      jac_point(m, d, b1, p1, j1); jac_point(m, d, b2, p2, j2);
+      int nrow = 3;
+      for (int k = 0; k < 3; k++)
+        for (int i = 0; i < nv; i++) d->efc_J[(r + k) * nv + i] = j1[k * nv + i] - j2[k * nv + i];
+      if (pass == ODKO_EQ_WELD) {
+        real ts = data[10], quat[4], q1n[4], q2[4], r1[3 * ODKO_MAXV], r2[3 * ODKO_MAXV];
+        quat_mul(quat, d->xquat[b1], data + 6);                          /* q(body1) * relpose */
+        q1n[0] = d->xquat[b2][0]; for (int k = 1; k < 4; k++) q1n[k] = -d->xquat[b2][k];
+        quat_mul(q2, q1n, quat);                                         /* conj(q(body2)) * q(body1) * relpose: identity when welded */
+        for (int k = 0; k < 3; k++) cpos[3 + k] = q2[1 + k] * ts;
+        jac_rot(m, d, b1, r1); jac_rot(m, d, b2, r2);
+        for (int i = 0; i < nv; i++) {                                   /* d/dt of the error quaternion's axis part: 0.5 conj(q2) (0, w1 - w2) q1 relpose */
+          real ax[4] = {0, r1[i] - r2[i], r1[nv + i] - r2[nv + i], r1[2 * nv + i] - r2[2 * nv + i]}, q3[4], q4[4];
+          quat_mul(q3, q1n, ax); quat_mul(q4, q3, quat);
+          for (int k = 0; k < 3; k++) d->efc_J[(r + 3 + k) * nv + i] = 0.5 * q4[1 + k] * ts;
+        }
+        nrow = 6;
+      }
+      real nrm = 0;
+      for (int k = 0; k < nrow; k++) nrm += cpos[k] * cpos[k];
+      nrm = sqrt(nrm);
+      for (int k = 0; k < nrow; k++) {
+        real vel = 0;
+        for (int i = 0; i < nv; i++) vel += d->efc_J[(r + k) * nv + i] * d->qvel[i];
+        real invw = m->body_invweight0[b1][k < 3 ? 0 : 1] + m->body_invweight0[b2][k < 3 ? 0 : 1];
+        efc_row_params_imp(m, d, r + k, cpos[k], nrm, invw, m->eq_solref[e], m->eq_solimp[e], vel, 0.0);
+      }
+      r += nrow;
+    }
+  return r;
+}
+
 static void make_constraint(const odko_model* m, odko_data* d) {
   int nv = m->nv, r = 0;
   memset(d->efc_J, 0, sizeof(d->efc_J));
-  d->ne = 0;
+  r = make_equality(m, d, 0);
+  d->ne = r;
   /* friction loss rows: dofs with frictionloss > 0 */
   for (int i = 0; i < nv; i++) {
     if (m->dof_frictionloss[i] <= 0) continue;
@@ -1229,7 +1338,7 @@ static void make_constraint(const odko_model* m, odko_data* d) {
     efc_row_params(m, d, r, 0.0, m->dof_invweight0[i], m->dof_solref[i], m->dof_solimp[i], d->qvel[i], m->dof_frictionloss[i]);
     r++;
   }
-  d->nf = r;
+  d->nf = r - d->ne;
   /* joint limit rows (hinge) */
   for (int j = 0; j < m->njnt; j++) {
     if (!m->jnt_limited[j] || m->jnt_type[j] != ODKO_JNT_HINGE) continue;
@@ -1243,7 +1352,7 @@ static void make_constraint(const odko_model* m, odko_data* d) {
     efc_row_params(m, d, r, pos, m->dof_invweight0[i], m->jnt_solref[j], m->jnt_solimp[j], sgn * active * d->qvel[i], 0.0);
     r++;
   }
-  d->nl = r - d->nf;
+  d->nl = r - d->nf - d->ne;
   /* contact rows: pyramidal condim 3 -> 4 rows per contact */
   for (int c = 0; c < d->ncon; c++) {
     int g1 = d->contact_geom1[c], g2 = d->contact_geom2[c];
@@ -1274,7 +1383,7 @@ static void make_constraint(const odko_model* m, odko_data* d) {
         r++;
       }
   }
-  d->nc = r - d->nf - d->nl;
+  d->nc = r - d->nf - d->nl - d->ne;
   d->nefc = r;
 }
 

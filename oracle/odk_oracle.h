@@ -41,8 +41,10 @@ typedef ODKO_REAL real;
 #define ODKO_MAXHF 128 /* hull faces */
 #define ODKO_MAXCON 12 /* contacts: 3 geom pairs x 4 */
 #define ODKO_MAXEFC 96 /* constraint rows */
+#define ODKO_MAXEQ 8   /* equality constraints (<= 6 rows each) */
 
 enum { ODKO_JNT_FREE = 0, ODKO_JNT_HINGE = 3 };
+enum { ODKO_EQ_CONNECT = 0, ODKO_EQ_WELD = 1, ODKO_EQ_JOINT = 2 };   /* mjtEq */
 enum { ODKO_GEOM_PLANE = 0, ODKO_GEOM_HFIELD = 1, ODKO_GEOM_SPHERE = 2, ODKO_GEOM_CAPSULE = 3, ODKO_GEOM_MESH = 7 };   /* mjtGeom */
 #define ODKO_MAXHFIELD (256 * 256)
 enum { ODKO_S_GYRO = 0, ODKO_S_VELOCIMETER, ODKO_S_ACCELEROMETER, ODKO_S_FRAMEZAXIS, ODKO_S_FRAMEXAXIS,
@@ -104,6 +106,11 @@ typedef struct {
   int hfield_nrow, hfield_ncol;
   real hfield_size[4];                 /* x half-extent, y half-extent, elevation scale, base thickness */
   real hfield_data[ODKO_MAXHFIELD];
+  /* equality constraints (mjModel eq_*): obj = body ids (connect / weld) or joint ids (joint; obj2 = -1: none); data as MuJoCo's compiler
+   * leaves it -- connect: anchor in body1 [0:3], in body2 [3:6]; weld: anchor in body2 [0:3], in body1 [3:6], relpose quaternion [6:10],
+   * torquescale [10]; joint: polycoef [0:5] */
+  int neq, eq_type[ODKO_MAXEQ], eq_obj1id[ODKO_MAXEQ], eq_obj2id[ODKO_MAXEQ], eq_active[ODKO_MAXEQ];
+  real eq_data[ODKO_MAXEQ][11], eq_solref[ODKO_MAXEQ][2], eq_solimp[ODKO_MAXEQ][5];
   /* derived: contact pair list, face polygons / edges of the mesh geoms (geom frame) */
   int npair, pair_g1[3], pair_g2[3];
   odko_convex cgeom_convex[ODKO_MAXG];
@@ -163,6 +170,7 @@ void odko_model_jitter_hulls(odko_model* m, unsigned seed, real rel); /* relativ
 real* odko_model_field(odko_model* m, const char* name, int* count);
 int odko_model_int(const odko_model* m, const char* name);
 int odko_model_set_int(odko_model* m, const char* name, int value); /* "iterations" / "ls_iterations" / "hfield_mode" */
+int odko_model_eq_set_active(odko_model* m, int e, int on);          /* mjData.eq_active: equality constraint e on / off */
 int odko_convex_pair(const real* va, int nva, const int* ta, int nta, const real* pa, const real* ma, const real* vb, int nvb, const int* tb,
                      int ntb, const real* pb, const real* mb, real* dist4, real* pos12, real* normal3, real* sat3);
 int odko_model_convex_counts(const odko_model* m, int g, int* nv, int* nf, int* ne);

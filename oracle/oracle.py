@@ -46,6 +46,7 @@ class _Lib:
         L.odko_model_field.restype = RP; L.odko_model_field.argtypes = [P, C.c_char_p, C.POINTER(C.c_int)]
         L.odko_model_int.restype = C.c_int; L.odko_model_int.argtypes = [P, C.c_char_p]
         L.odko_model_set_int.restype = C.c_int; L.odko_model_set_int.argtypes = [P, C.c_char_p, C.c_int]
+        L.odko_model_eq_set_active.restype = C.c_int; L.odko_model_eq_set_active.argtypes = [P, C.c_int, C.c_int]
         IP = C.POINTER(C.c_int)
         L.odko_convex_pair.restype = C.c_int
         L.odko_convex_pair.argtypes = [RP, C.c_int, IP, C.c_int, RP, RP, RP, C.c_int, IP, C.c_int, RP, RP, RP, RP, RP, RP]
@@ -158,13 +159,18 @@ class OracleModel:
         if not self.h:
             raise ValueError("odko_model_load failed")
         self.f = _Fields(self.L, self.h, self.L.lib.odko_model_field)
-        for k in ("nq", "nv", "nu", "nbody", "njnt", "nsite", "nsensordata", "ncgeom", "npair"):
+        for k in ("nq", "nv", "nu", "nbody", "njnt", "nsite", "nsensordata", "ncgeom", "npair", "neq"):
             setattr(self, k, self.L.lib.odko_model_int(self.h, k.encode()))
 
     def set_int(self, name: str, value: int):
         if self.L.lib.odko_model_set_int(self.h, name.encode(), int(value)) != 0:
             raise KeyError(name)
         setattr(self, name, int(value))
+
+    def eq_set_active(self, e: int, on: bool):
+        """mjData.eq_active: equality constraint `e` on / off"""
+        if self.L.lib.odko_model_eq_set_active(self.h, int(e), int(bool(on))) != 0:
+            raise IndexError(e)
 
     def convex_counts(self, g: int):
         """(vertices, faces after the coplanar merge, unique edges) of mesh geom g"""

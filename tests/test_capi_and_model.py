@@ -219,7 +219,7 @@ def test_env_kernels_have_no_scratch_and_fit_two_waves_per_simd(tmp_path):
 
 
 @pytest.mark.parametrize("extra, what", [
-    ("<equality><weld body1='a' body2='b'/></equality>", "equality"),
+    ("<equality><tendon tendon1='t'/></equality>", "equality"),
     ("<tendon><fixed name='t'><joint joint='j' coef='1'/></fixed></tendon>", "tendon"),
     ("<contact><exclude body1='a' body2='b'/></contact>", "contact"),
 ])
@@ -234,6 +234,20 @@ def test_compiler_refuses_sections_the_kernels_do_not_model(tmp_path, extra, wha
     path.write_text(xml)
     with pytest.raises(NotImplementedError, match=what):
         mjcf.compile_mjcf(str(path))
+
+
+def test_loader_refuses_active_equalities_by_name():
+    """<equality> joint / connect / weld compile (mjcf.py) and the float64 oracle steps them (tests/test_oracle_equality.py); the kernels'
+    row code has no such rows, so `odk_model_load` refuses a model that carries an ACTIVE one -- naming it -- and loads the same model
+    with all of them switched off (eq_active = 0: MuJoCo's own off switch)."""
+    import os
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model
+    m = Model.from_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "tail_biped_equality.xml"))
+    with pytest.raises(engine.OdkError, match=r"<equality><joint> \(constraint 0\) is active"):
+        engine.model_reduction(m)
+    off = Model({**m.a, "eq_active": np.zeros_like(m.a["eq_active"])})
+    assert engine.model_reduction(off)["nvr"] == 21
 
 
 def test_compiler_refuses_colliding_primitives(tmp_path):
