@@ -415,8 +415,11 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
 
 // ================================================================================================
 // AutoReset.step -> Episode.step -> Joystick.step (joystick.py:323-481), all substeps fused
+#ifndef ODK_STEP_WAVES
+#define ODK_STEP_WAVES 2     // waves per SIMD the register allocation is held to (experiment builds: 4 = <= 128 VGPRs; profiles/r5/NOTES.md)
+#endif
 template <class S, int G, int HF>
-__global__ void __launch_bounds__(64, 2) step_kernel(KArgs a) {
+__global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
   constexpr int NU = S::NU;
