@@ -28,12 +28,12 @@ SENSITIVITY = dict(obs=2.5e-4, acc=2.5e-3, reward=2.5e-4, metrics=5e-4)
 # Every such step goes to a referee (`_F32.adjudicate`), in this order: (1) the float64 oracle re-run with ONE class of its discrete
 # decisions -- collision: separating face, reference polytope, edge-or-face contact, incident face, clipping-plane side, manifold
 # arg-max, the cut behind the fourth-deepest height-field contact; solver: warm-start pick, line-search bracket -- biased to the
-# runner-up inside a band of 3e-7 (then 2e-6) around a tie, for the whole env step or for one substep (odko_set_tie_bias): if that
+# runner-up inside a band of 1e-7, then 3e-7 (the fourth-deepest cut also 1e-6) around a tie, for the whole env step or for one substep (odko_set_tie_bias): if that
 # reproduces the kernel's outputs within ENV_BOUNDS the step is EXPLAINED, causally ("tie_<class>"); (2) the oracle's float32 build,
 # plain / with rounding-level noise on the state / on the hull vertices ("agrees_with_kernel", "departs_too").  What neither
 # explains is `outlier_fraction` (<= 0.2 % of the judged steps on every floor); a flipped contact branch moves the accelerometer by
 # O(1), so there is no magnitude cap on those few -- each one is printed and its size recorded (`outlier_over_bound`).
-SET_ASIDE = dict(ill_fraction=0.08, outlier_fraction=0.002, explained_fraction=0.01)
+SET_ASIDE = dict(ill_fraction=0.08, outlier_fraction=0.002, explained_fraction=0.004)      # explained: measured <= 0.0011 (round 5: bound 0.01 -> 0.004)
 # Height-field floor: every reset starts with the feet 1-3 cm inside the terrain (joystick.py:206-258 knows nothing of the
 # elevation) and many prisms give candidates.  Measured: 2-5 % of the env steps of the random-action sequence are ill-conditioned
 # by the oracle's own sensitivity (63-75 % until the last manifold point resolved the triangle tie by rule: oracle manifold_points
@@ -41,7 +41,7 @@ SET_ASIDE = dict(ill_fraction=0.08, outlier_fraction=0.002, explained_fraction=0
 # anti-parallel to a prism's side wall: tools/gpu_env_outlier_substeps.py).
 # Round 4: those are now adjudicated by the float32 oracle like on the flat floor, and the allowance for UNEXPLAINED ones is the
 # flat floor's.
-SET_ASIDE_ROUGH = dict(ill_fraction=0.15, outlier_fraction=0.002, explained_fraction=0.02)
+SET_ASIDE_ROUGH = dict(ill_fraction=0.15, outlier_fraction=0.002, explained_fraction=0.012)      # explained: measured <= 0.0056 (round 5: bound 0.02 -> 0.012)
 
 
 def _set_aside(task):
@@ -174,19 +174,33 @@ class _F32:
         #    is 1e-6 m, and the kernels' window-relative coordinates only remove part of that).
         #    A tie between two hull features persists through the env step (bias on in all ten collision passes); a foot that rotates
         #    THROUGH a tie crosses it in one substep (bias on in that pass only).
+        #    Round 5: the search is what the recorded cases needed and no wider.  Of the 31 explained steps on record
+        #    (20 in the suite, 11 in the sweeps) none needed a PAIR of classes, and only the cut behind the fourth-deepest height-field
+        #    contact needed a band beyond 3e-7 (a contact depth compared across prisms whose coordinates are metres from the origin):
+        #    singles only (pairs: ODK_REFEREE_PAIRS=1, tools), a ladder of bands 1e-7 -> 3e-7 for every class, 1e-6 for that class
+        #    alone (measured with the ladder in place, profiles/r5/referee_log.jsonl: 13 of 18 tie verdicts at 1e-7, the five at 1e-6 all
+        #    `fourth_deepest_cut`; the 2e-6 band of round 4 is gone); the band that sufficed and the oracle's own smallest decision margins of the step go to the referee log.
+        import os
         singles = [(bit, name) for bit, name in TIE_CLASSES]
-        pairs = [(b1 | b2, n1 + "+" + n2) for i, (b1, n1) in enumerate(TIE_CLASSES) for (b2, n2) in TIE_CLASSES[i + 1:]]
+        pairs = [(b1 | b2, n1 + "+" + n2) for i, (b1, n1) in enumerate(TIE_CLASSES) for (b2, n2) in TIE_CLASSES[i + 1:]] if os.environ.get("ODK_REFEREE_PAIRS") == "1" else []
         nsub = int(pre.cfg["n_substeps"][0])
-        for eps, tag in ((3e-7, ""), (2e-6, "@2e-6")):
+        self.last = None
+        for eps, eps_rel, tag, classes in ((1e-7, 1e-5, "@1e-7", None), (3e-7, 1e-5, "", None), (1e-6, 1e-4, "@1e-6", (64,))):
             for window in [None] + [(k, k) for k in range(nsub)]:
                 for mask, name in (singles + pairs if window is None else singles):
+                    if classes is not None and mask not in classes:
+                        continue
                     t = pre.clone()
-                    self.O.set_tie_bias(mask, eps, 1e-5 if not tag else 1e-4, window=window)
+                    self.O.set_tie_bias(mask, eps, eps_rel, window=window)
                     try:
                         t.step(act)
                     finally:
                         self.O.set_tie_bias(0)
                     if same_as_kernel(t):
+                        u = pre.clone()                          # the unbiased step's own smallest decision margins, per category
+                        u.data["decision_margin"][:] = 1e30
+                        u.step(act)
+                        self.last = dict(band=eps, margins=[float(x) for x in u.data["decision_margin"][:5]], window=None if window is None else window[0])
                         return "tie_" + name + tag + ("" if window is None else f"/substep{window[0]}")
         verdict = None
         for k in range(self.TRIES):
@@ -329,6 +343,10 @@ def _step_and_compare(torch, b, envs, act, nobs, npriv, t, W, model=None):
                 W["n_explained"] += 1
                 W["n_explained_" + why] = W.get("n_explained_" + why, 0) + 1
                 tag = "explained_"
+                last = getattr(envs.f32, "last", None)
+                if last is not None and why.startswith("tie_"):
+                    W["explained_band_max"] = max(W.get("explained_band_max", 0.0), last["band"])
+                _referee_log(dict(t=int(t), env=int(i), verdict=why, err={k: float(v) for k, v in err.items()}, **(last or {})))
             else:
                 W["n_outlier"] += 1
                 tag = "outlier_"
@@ -342,6 +360,18 @@ def _step_and_compare(torch, b, envs, act, nobs, npriv, t, W, model=None):
             W[k] = max(W[k], v)
     W["resync_info"] = ill_envs
     return W
+
+
+def _referee_log(entry):
+    """every explained env step with the band that sufficed and the oracle's smallest decision margins of that step ([0] collision
+    lengths m, [1] normal cosines, [2] clipping-plane distances m, [3] manifold arg-max steps (relative), [4] warm-start pick (relative)):
+    gpurun_out/referee_log.jsonl (committed copy: profiles/r<N>/referee_log.jsonl)"""
+    import json, os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(root, exist_ok=True)
+    entry["test"] = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    with open(os.path.join(root, "referee_log.jsonl"), "a") as f:
+        f.write(json.dumps(entry) + "\n")
 
 
 def _new_W():

@@ -18,6 +18,11 @@ TEN_BOUNDS = dict(qpos=RTOL_Q, qvel=RTOL_Q, qpos_normwise=3e-6, qvel_normwise=5e
 FOOT_BOUNDS = dict(dist=3e-7, qacc=3e-4, qpos=1e-5, qvel=1e-5)
 
 
+# the oracle's discrete decisions a test can bias (oracle/odk_oracle.c "Tie bias"; the same table as tests/test_gpu_env.py TIE_CLASSES)
+ILL_CLASSES = ((4, "edge_or_face_contact"), (8, "incident_face"), (1, "separating_face"), (2, "reference_polytope"), (16, "clipping_plane_side"),
+               (32, "manifold_argmax"), (64, "fourth_deepest_cut"), (128, "warm_start_pick"), (256, "line_search_bracket_end"), (512, "line_search_comparison"))
+
+
 def _rel(a, b, floor=1e-3):
     return np.abs(a - b) / np.maximum(np.abs(b), floor)
 
@@ -455,7 +460,8 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
     gq, gv, _ = b.get_state()
     wq = wv = wqn = wvn = 0.0
     prng = np.random.default_rng(98)
-    n_ill = 0
+    n_ill = n_classified = 0
+    why_ill = {}
     for e in range(n):
         d = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 10)
         q1, v1 = np.array(d["qpos"][: om.nq]), np.array(d["qvel"][: om.nv])
@@ -470,11 +476,27 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
                 ill = True
         if ill:
             n_ill += 1
+            if n_ill <= 64:     # WHY it is ill-conditioned: which class of the oracle's discrete decisions, biased to its runner-up
+                                # inside a 2e-6 band for the whole step, moves the oracle's own result by more than half a bound
+                hit = []
+                for bit, name in ILL_CLASSES:
+                    oracle_mod.set_tie_bias(bit, 2e-6, 1e-4)
+                    try:
+                        db = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 10)
+                    finally:
+                        oracle_mod.set_tie_bias(0)
+                    if _rel(db["qpos"][: om.nq], q1, 1e-2).max() > 0.5 * TEN_BOUNDS["qpos"] or _rel(db["qvel"][: om.nv], v1, 1.0).max() > 0.5 * TEN_BOUNDS["qvel"]:
+                        hit.append(name)
+                for name in hit or ["no_tie_class (a row switching on / off: |dist|, |limit|, J a - aref near zero)"]:
+                    why_ill[name] = why_ill.get(name, 0) + 1
+                n_classified += 1
             continue
         wq = max(wq, _rel(gq[e], q1, 1e-2).max())
         wv = max(wv, _rel(gv[e], v1, 1.0).max())
         wqn, wvn = max(wqn, _nw(gq[e], q1)), max(wvn, _nw(gv[e], v1))
     print(task, "10 substeps: worst rel qpos", wq, "qvel", wv, "ill-conditioned:", n_ill, "of", n)
+    print(task, "ill-conditioned states by the decision class that moves the oracle's own result (of", n_classified, "examined; a state may name several):", why_ill)
+    parity_log.rec(f"ten_substeps/{task}", None, ill_examined=n_classified, **{"ill_by_" + k.split(" ")[0]: v for k, v in why_ill.items()})
     b.close()
     assert n - n_ill >= 150, (n, n_ill)
     parity_log.rec(f"ten_substeps/{task}", None, states=n, judged=n - n_ill)
