@@ -1123,20 +1123,25 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I("nbody", one, 1); m.nb = one[0]; B.I("njnt", one, 1); m.nj = one[0]; B.I("nsite", one, 1); m.nsite = one[0];
   if (!B.ok) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   if (m.nq > MAXQ || m.nv > MAXV || m.nu > MAXU || m.nb > MAXB || m.nj > MAXJ || m.nsite > MAXSITE) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model too large"); }
-  {   // <equality> (mjcf.py compiles joint / connect / weld; the float64 oracle builds their rows): the kernels' row code -- friction-loss,
-      // limit and foot-wrench rows -- has no row between two dofs or two bodies yet, so a model that carries ACTIVE equalities is refused by
-      // name instead of being stepped without them
+  // <equality> (mjcf.py compiles joint / connect / weld; the float64 oracle builds all their rows).  The kernels model <equality><joint>
+  // rows between two hinges of one serial chain (odk_kernels.h "equality rows": shapes with S::EQ, at most EQ_MAX rows, a dof in at most
+  // one); every other ACTIVE equality is refused by name instead of being stepped without it.  Collected here, finished below once the
+  // reduced layout and the shape are known.
+  int eq_n = 0, eq_type[16], eq_active[16], eq_o1[16], eq_o2[16];
+  double eq_data[16 * 11], eq_solref[16 * 2], eq_solimp[16 * 5];
+  {
     RecHdr eh;
     if (find_rec((const unsigned char*)blob, len, "eq_type", &eh) && eh.nbytes > 0) {
-      int et[16], ea[16];
       Blob E{(const unsigned char*)blob, len};
-      const int ne = E.I("eq_type", et, 16), na = E.I("eq_active", ea, 16);
-      if (ne < 0 || na != ne) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "more than 16 equality constraints / eq_active missing"); }
-      for (int k = 0; k < ne; k++)
-        if (ea[k]) {
-          static const char* nm[] = {"connect", "weld", "joint"};
+      eq_n = E.I("eq_type", eq_type, 16);
+      if (eq_n < 0 || E.I("eq_active", eq_active, 16) != eq_n || E.I("eq_obj1id", eq_o1, 16) != eq_n || E.I("eq_obj2id", eq_o2, 16) != eq_n ||
+          E.D("eq_data", eq_data, 16 * 11) != 11 * eq_n || E.D("eq_solref", eq_solref, 32) != 2 * eq_n || E.D("eq_solimp", eq_solimp, 80) != 5 * eq_n) {
+        delete mo; return fail(ODK_ERR_UNSUPPORTED, "equality constraints: more than 16, or eq_* records incomplete");
+      }
+      for (int k = 0; k < eq_n; k++)
+        if (eq_active[k] && eq_type[k] != 2) {
           delete mo;
-          return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d) is active: equality rows exist in the oracle only, the kernels do not model them", et[k] >= 0 && et[k] < 3 ? nm[et[k]] : "?", k);
+          return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d) is active: the kernels model <equality><joint> rows only (the oracle has connect / weld)", eq_type[k] == 0 ? "connect" : (eq_type[k] == 1 ? "weld" : "?"), k);
         }
     }
   }
@@ -1434,6 +1439,39 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   else if (fits(ShapeC::NQ, ShapeC::NV, ShapeC::NB, ShapeC::NU, ShapeC::NJ, ShapeC::NM, ShapeC::NH, ShapeC::NROW, ShapeC::DT, ShapeC::DV)) mo->shape = 2;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
+  {   // equality rows of the kernels: joint couplings inside one serial chain of a shape compiled with them
+    m.neq = 0;
+    for (int d = 0; d < MAXV; d++) m.dof_eqrow[d] = -1;
+    for (int k = 0; k < eq_n; k++) {
+      if (!eq_active[k]) continue;
+      const bool shape_ok = mo->shape == 2 && !m.paired;      // ShapeC::EQ
+      if (!shape_ok || m.neq == EQ_MAX) {
+        delete mo;
+        return fail(ODK_ERR_UNSUPPORTED, "<equality><joint> (constraint %d) is active: %s", k,
+                    shape_ok ? "the kernels hold at most two equality rows" : "equality rows are compiled into the third model shape only (the duck's kernels carry none)");
+      }
+      const int r = m.neq, j1 = eq_o1[k], j2 = eq_o2[k];
+      if (j1 < 1 || j1 >= m.nj || j2 >= m.nj || j2 == 0 || j2 == j1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<equality><joint> (constraint %d): hinge joints expected", k); }
+      const int d1 = m.jnt_dofadr[j1], d2 = j2 > 0 ? m.jnt_dofadr[j2] : -1;
+      if (m.dof_eqrow[d1] >= 0 || (d2 >= 0 && m.dof_eqrow[d2] >= 0)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<equality><joint> (constraint %d): a joint takes part in at most one equality row", k); }
+      m.eq_dof1[r] = d1; m.eq_dof2[r] = d2; m.eq_qadr1[r] = m.jnt_qposadr[j1]; m.eq_qadr2[r] = j2 > 0 ? m.jnt_qposadr[j2] : 0;
+      m.eq_key[r] = -1;
+      if (d2 >= 0) {      // the Hessian entry (d1, d2) must exist in the reduced tree layout: same serial chain
+        for (int p = 0; p < m.nMr; p++) {
+          const int e = m.R_ent[p], i = e & 31, j = (e >> 5) & 31;
+          if ((i == d1 && j == d2) || (i == d2 && j == d1)) m.eq_key[r] = e & 0x3FF;
+        }
+        if (m.eq_key[r] < 0) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<equality><joint> (constraint %d): the two joints must lie on one serial chain (the coupling's Hessian term needs an entry of the tree layout)", k); }
+      }
+      for (int c = 0; c < 5; c++) m.eq_poly[r][c] = (float)eq_data[11 * k + c];
+      float sr[2] = {(float)eq_solref[2 * k], (float)eq_solref[2 * k + 1]}, si[5];
+      for (int c = 0; c < 5; c++) si[c] = (float)eq_solimp[5 * k + c];
+      pack_imp(sr, si, m.dt, m.eq_imp[r]);
+      m.eq_invweight[r] = (float)(dof_iw[d1] + (d2 >= 0 ? dof_iw[d2] : 0.0));
+      m.dof_eqrow[d1] = r; if (d2 >= 0) m.dof_eqrow[d2] = r;
+      m.neq++;
+    }
+  }
   if (mo->shape == 1 && !(m.paired && m.nvr == ShapeB::NVR && m.nMr == ShapeB::NMR && m.nHr == ShapeB::NHR)) {
     delete mo;
     return fail(ODK_ERR_UNSUPPORTED, "the 30-dof kernels expect backlash twins (same body, anchor and axis as their joint) over the 20-dof tree");

@@ -74,6 +74,9 @@ struct Shape {
   // Twin dofs (the backlash model, nv 30): solves run on the reduced tree -- twins merged into their main dof, which is
   // the 20-dof robot's own tree (DevModel::paired; reduced_rhs / reduced_expand below).
   static constexpr bool PAIRED = (NV_ == 30);
+  // <equality><joint> rows (DevModel::neq) are compiled into this shape's kernels: the third shape (tests/assets/tail_biped*.xml) -- the
+  // duck's shapes have no equality and do not pay for the code
+  static constexpr bool EQ = (NV_ == 21);
   static constexpr int NVR = PAIRED ? 20 : NV_;    // reduced dofs
   static constexpr int NMR = PAIRED ? 145 : NM_;   // entries of the reduced tree layout
   static constexpr int NHR = PAIRED ? 170 : NH_;   // entries of the reduced virtual-tree layout
@@ -147,6 +150,7 @@ struct Shape {
                                       // the K blocks (born in the solver).  NOT in the row arrays: the foot-foot routine's hull copies live there.
   static constexpr int S_VF2 = 132;   // [2][6] second foot twist (warmstart candidate)
   static constexpr int S_FFX = 144;   // [6] wrench sum of the foot-foot rows
+  static constexpr int S_EQ = 150;    // [EQ_MAX] equality rows: the Hessian's off-diagonal addend -D c (force phase -> Hessian entries; the solve's scratch runs over it afterwards)
   static constexpr int S_MISC = 156;  // misc scalars (16)
   static constexpr int S_PROF = 172;  // [20] per-phase cycle counters (ODK_PROFILE builds)
   static constexpr int S_PROF2 = 192; // [16] height-field contacts: hull setup, cull pass, register loads, pair loop, iterations, list length, -, -,
@@ -2335,6 +2339,33 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     if (pos < 0) row_params(m->lim_imp[st.d_limrow], pos, m->lim_invweight[st.d_limrow], lim_sgn * QVEL[lane], D, aref);
     ED[r] = D; AREF[r] = aref;
   }
+  // ---- equality rows (<equality><joint>: DevModel::neq; shapes with S::EQ).  BOTH dof lanes of a row evaluate it -- residual, c = p'(x2),
+  // D and aref come out of LDS-resident vectors, nothing is handed over -- and each applies its own Jacobian entry (1 / -c); the row's
+  // cost and line-search terms are counted once, by the lane of joint1's dof.  Always active (an equality pushes and pulls).
+  bool eq_on = false, eq_first = false;
+  int eq_i = 0, eq_j = -1, eq_r = 0;
+  float eq_D = 0.0f, eq_aref = 0.0f, eq_c = 0.0f;
+  if constexpr (S::EQ) {
+    if (m->neq > 0 && st.d_on) {
+      const int r = m->dof_eqrow[lane];
+      if (r >= 0) {
+        eq_on = true; eq_r = r; eq_i = m->eq_dof1[r]; eq_j = m->eq_dof2[r]; eq_first = lane == eq_i;
+        const int a1 = m->eq_qadr1[r];
+        const float* pc = m->eq_poly[r];
+        float pos = QPOS[a1] - Q0[a1], vel = QVEL[eq_i];
+        if (eq_j >= 0) {
+          const int a2 = m->eq_qadr2[r];
+          const float xx = QPOS[a2] - Q0[a2];
+          pos -= pc[0] + xx * (pc[1] + xx * (pc[2] + xx * (pc[3] + xx * pc[4])));
+          eq_c = pc[1] + xx * (2.0f * pc[2] + xx * (3.0f * pc[3] + xx * 4.0f * pc[4]));
+          vel -= eq_c * QVEL[eq_j];
+        } else {
+          pos -= pc[0];
+        }
+        row_params(m->eq_imp[r], pos, m->eq_invweight[r], vel, eq_D, eq_aref);
+      }
+    }
+  }
   // foot-foot rows (32..47) are skipped wave-wide unless some env has a penetrating foot-foot contact (D = 0 rows
   // are never read again: the solver gates on D > 0 and on the same wave-uniform flag)
   const bool ff_rows = __builtin_amdgcn_ballot_w64(fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0.0f) != 0;
@@ -2459,6 +2490,14 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     jar_lim_s = lim_sgn * qas - ar; jar_lim_w = lim_sgn * warm - ar;
     cost_s += quad_cost(lim_D, jar_lim_s, fo); cost_w += quad_cost(lim_D, jar_lim_w, fo);
   }
+  float jar_eq_s = 0.0f, jar_eq_w = 0.0f;
+  if constexpr (S::EQ) {
+    if (eq_on) {   // J x = x_i - c x_j for both candidates; the quadratic cost once per row
+      jar_eq_s = QAS[eq_i] - eq_aref; jar_eq_w = WARM[eq_i] - eq_aref;
+      if (eq_j >= 0) { jar_eq_s -= eq_c * QAS[eq_j]; jar_eq_w -= eq_c * WARM[eq_j]; }
+      if (eq_first) { cost_s += 0.5f * eq_D * jar_eq_s * jar_eq_s; cost_w += 0.5f * eq_D * jar_eq_w * jar_eq_w; }
+    }
+  }
   const bool c_act[3] = {fminf(fminf(CDIST[0], CDIST[1]), fminf(CDIST[2], CDIST[3])) < 0, fminf(fminf(CDIST[4], CDIST[5]), fminf(CDIST[6], CDIST[7])) < 0,
                          fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0};
   // wave-uniform: some env of the wave has a penetrating foot-foot contact.  Without one, contact rows 32-47 have D = 0 in
@@ -2489,6 +2528,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   const float x = use_warm ? warm : qas;
   const float ma = use_warm ? ma_w : qfs;
   const float jar_fl = use_warm ? jar_fl_w : jar_fl_s, jar_lim = use_warm ? jar_lim_w : jar_lim_s;
+  const float jar_eq = use_warm ? jar_eq_w : jar_eq_s;
 #pragma unroll
   for (int t = 0; t < NCL; t++) {
     cjar[t] = use_warm ? cjv[t] : cjar[t];
@@ -2567,6 +2607,14 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     float qc = 0, hdiag_extra = 0.0f;
     if (st.d_flrow >= 0) { qc += MV[i]; hdiag_extra += MA[i]; }
     if (st.d_lim_on) { qc += lim_sgn * f_lim; if (lim_D > 0 && jar_lim < 0) hdiag_extra += lim_D; }
+    if constexpr (S::EQ) {
+      if (eq_on) {   // J^T f and J^T D J of the equality row: own entry 1 (joint1's dof) or -c (joint2's); the off-diagonal term through S_EQ
+        const float je = eq_first ? 1.0f : -eq_c;
+        qc += je * (-eq_D * jar_eq);
+        hdiag_extra += eq_D * je * je;
+        if (eq_first) SCR[S::S_EQ + eq_r] = -eq_D * eq_c;
+      }
+    }
     float cd[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) cd[k] = CDOF[k * NR + st.d_red];
@@ -2629,6 +2677,9 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       const int u = (e >> 16) & 31;
       v += (S::PAIRED && ((e >> 15) & 1)) ? pair_einv(ARM, JV, u) : JV[u];
     }
+    if constexpr (S::EQ) {
+      for (int r = 0; r < m->neq; r++) v += (e & 0x3FF) == m->eq_key[r] ? SCR[S::S_EQ + r] : 0.0f;
+    }
     const int both = fi & fj;
     if (both) {
       float cj[6];
@@ -2677,6 +2728,9 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
 #pragma unroll
         for (int k = 0; k < 6; k++) s1 = fmaf(cj[k], T1[k * NR + i], s1);
         float v = mm[t] + (((e >> 14) & 1) ? dterm : 0.0f) + (both ? s1 : 0.0f);
+        if constexpr (S::EQ) {
+          for (int r = 0; r < m->neq; r++) v += (e & 0x3FF) == m->eq_key[r] ? SCR[S::S_EQ + r] : 0.0f;
+        }
         if (t == 0) {
           float s2 = 0.0f;
 #pragma unroll
@@ -2772,6 +2826,10 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   float jv_fl = 0, jv_lim = 0;
   if (lane < nfl) jv_fl = GRAD[fs.dof];
   if (st.d_lim_on) jv_lim = lim_sgn * search;
+  float jv_eq = 0.0f, eq_Dw = 0.0f;      // the equality row's J search and its D on the lane that counts the row (0 elsewhere: exact zeros below)
+  if constexpr (S::EQ) {
+    if (eq_on && eq_first) { jv_eq = GRAD[eq_i] - (eq_j >= 0 ? eq_c * GRAD[eq_j] : 0.0f); eq_Dw = eq_D; }
+  }
   // J search of this lane's contact rows
 #pragma unroll
   for (int t = 0; t < NCL; t++) {
@@ -2812,6 +2870,15 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         const float w = jar + al[a] * jv < 0 ? 1.0f : 0.0f;
         if constexpr (COST) acc[3 * a] = fmaf(w, q0, acc[3 * a]);
         acc[3 * a + 1] = fmaf(w, q1, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, q2, acc[3 * a + 2]);
+      }
+    }
+    if constexpr (S::EQ) {   // equality row: quadratic at every step size
+      const float D = eq_Dw, jar = jar_eq, jv = jv_eq;
+      const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        if constexpr (COST) acc[3 * a] += q0;
+        acc[3 * a + 1] += q1; acc[3 * a + 2] += q2;
       }
     }
 #pragma unroll

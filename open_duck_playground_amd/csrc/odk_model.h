@@ -5,6 +5,7 @@
 
 namespace odk {
 
+constexpr int EQ_MAX = 2;     // <equality><joint> rows per model in the kernels
 constexpr int MAXV = 32;     // dofs
 constexpr int MAXQ = 32;     // qpos
 constexpr int MAXB = 20;     // bodies
@@ -152,6 +153,12 @@ struct DevModel {
   float site_pos[MAXSITE][3], site_mat[MAXSITE][9], site_quat[MAXSITE][4];
   int sensor_type[MAXSENS], sensor_site[MAXSENS], sensor_adr[MAXSENS];
   int adr_gyro, adr_local_linvel, adr_accelerometer, adr_upvector, adr_global_angvel, adr_foot_linvel[2];
+  // <equality><joint> rows the kernels model (odk_kernels.h "equality rows"; shapes with S::EQ): q1 - q1_0 = poly(q2 - q2_0) between two
+  // hinges of ONE serial chain -- its Hessian term -D c then falls on an entry the chain's block already has -- or one hinge held at
+  // poly[0].  At most EQ_MAX rows, a dof in at most one.  eq_key: low ten bits (i | j << 5) of the packed reduced entry the coupling's
+  // off-diagonal term lands on (-1: single-joint row); dof_eqrow: the row a dof takes part in (-1: none).
+  int neq, eq_dof1[EQ_MAX], eq_dof2[EQ_MAX], eq_qadr1[EQ_MAX], eq_qadr2[EQ_MAX], eq_key[EQ_MAX], dof_eqrow[MAXV];
+  float eq_poly[EQ_MAX][5], eq_imp[EQ_MAX][9], eq_invweight[EQ_MAX];
 };
 
 // Topology of a height-field prism (vertices 0..2 = top triangle counter-clockwise seen from above, 3..5 below them; faces: top,

@@ -236,18 +236,39 @@ def test_compiler_refuses_sections_the_kernels_do_not_model(tmp_path, extra, wha
         mjcf.compile_mjcf(str(path))
 
 
-def test_loader_refuses_active_equalities_by_name():
-    """<equality> joint / connect / weld compile (mjcf.py) and the float64 oracle steps them (tests/test_oracle_equality.py); the kernels'
-    row code has no such rows, so `odk_model_load` refuses a model that carries an ACTIVE one -- naming it -- and loads the same model
-    with all of them switched off (eq_active = 0: MuJoCo's own off switch)."""
+def test_loader_takes_joint_couplings_and_refuses_other_equalities_by_name():
+    """<equality> joint / connect / weld compile (mjcf.py) and the float64 oracle steps all of them (tests/test_oracle_equality.py).  The
+    kernels model <equality><joint> rows between two hinges of one serial chain, for the third model shape: `odk_model_load` takes those,
+    and refuses -- naming the constraint -- an active connect / weld, a coupling across two chains, a joint in two rows, a third row, and
+    any equality on the duck's shapes; a model whose equalities are all switched off (eq_active = 0: MuJoCo's own off switch) loads."""
     import os
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.model import Model
     m = Model.from_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "tail_biped_equality.xml"))
-    with pytest.raises(engine.OdkError, match=r"<equality><joint> \(constraint 0\) is active"):
+    act = lambda *a: Model({**m.a, "eq_active": np.array(a, np.int32)})
+    with pytest.raises(engine.OdkError, match=r"<equality><connect> \(constraint 2\) is active"):
         engine.model_reduction(m)
-    off = Model({**m.a, "eq_active": np.zeros_like(m.a["eq_active"])})
-    assert engine.model_reduction(off)["nvr"] == 21
+    with pytest.raises(engine.OdkError, match=r"<equality><weld> \(constraint 3\) is active"):
+        engine.model_reduction(act(1, 1, 0, 1))
+    assert engine.model_reduction(act(1, 1, 0, 0))["nvr"] == 21          # the two joint couplings: taken
+    assert engine.model_reduction(act(0, 0, 0, 0))["nvr"] == 21
+    # a coupling across two chains (left knee <- right knee): no entry of the tree layout
+    cross = dict(m.a); cross["eq_obj2id"] = np.array([m.a["eq_obj2id"][0], m.joint_id("right_knee"), 0, 0], np.int32); cross["eq_active"] = np.array([1, 1, 0, 0], np.int32)
+    with pytest.raises(engine.OdkError, match="one serial chain"):
+        engine.model_reduction(Model(cross))
+    # a joint in two rows
+    twice = dict(m.a); twice["eq_obj1id"] = np.array([m.a["eq_obj1id"][0], m.a["eq_obj1id"][0], 0, 0], np.int32); twice["eq_active"] = np.array([1, 1, 0, 0], np.int32)
+    with pytest.raises(engine.OdkError, match="at most one equality row"):
+        engine.model_reduction(Model(twice))
+    # the duck's shapes carry no equality code
+    from open_duck_playground_amd.model import load_task_model
+    duck = load_task_model("flat_terrain")
+    j = lambda n: duck.joint_id(n)
+    eq = dict(duck.a, eq_type=np.array([2], np.int32), eq_obj1id=np.array([j("left_ankle")], np.int32), eq_obj2id=np.array([j("left_knee")], np.int32),
+              eq_active=np.array([1], np.int32), eq_data=np.array([[0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]], np.float64), eq_solref=np.array([[0.02, 1.0]]),
+              eq_solimp=np.array([[0.9, 0.95, 0.001, 0.5, 2.0]]), neq=np.array([1], np.int32))
+    with pytest.raises(engine.OdkError, match="third model shape only"):
+        engine.model_reduction(Model(eq))
 
 
 def test_compiler_refuses_colliding_primitives(tmp_path):

@@ -828,8 +828,8 @@ def test_differential_sweep(torch_cuda, oracle_mod, parity_log, task, lanes):
 
 
 
-def test_a_robot_that_is_not_the_duck(torch_cuda, oracle_mod, parity_log):
-    """SURVEY 8(f).3 / reference README.md:74-85 ("adding a robot"): tests/assets/tail_biped.xml -- a biped with a five-link tail,
+def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, tag, eq_active=None):
+    """(body of the two tests below)  SURVEY 8(f).3 / reference README.md:74-85 ("adding a robot"): tests/assets/tail_biped.xml -- a biped with a five-link tail,
     written for this test: 21 dofs, 15 position actuators, 19 bodies, box feet, its own masses / lengths / axes / gains -- compiled by
     mjcf.py, its lane tables built by tables.py (nothing by hand), loaded as the kernels' third Shape and run through the PHYSICS
     kernels (odk_physics_step): every comparable stage of one mjx.step and the state after ten, against the float64 oracle, at
@@ -840,11 +840,14 @@ def test_a_robot_that_is_not_the_duck(torch_cuda, oracle_mod, parity_log):
     from open_duck_playground_amd.tables import build_kernel_tables, reduced_layout
     from conftest import ROOT
     torch = torch_cuda
-    model = Model.from_xml(os.path.join(ROOT, "tests", "assets", "tail_biped.xml"), sim_dt=0.002)
+    model = Model.from_xml(os.path.join(ROOT, "tests", "assets", xml), sim_dt=0.002)
+    if eq_active is not None:
+        model = Model({**model.a, "eq_active": np.asarray(eq_active, np.int32)})
     assert (model.nq, model.nv, model.nu, model.nbody, model.njnt) == (22, 21, 15, 19, 16)
     red = engine.model_reduction(model)
     assert red["paired"] == 0 and red["nvr"] == 21 and red["nMr"] == 156 and red["nHr"] == 181
     om = oracle_mod.OracleModel(model.blob())
+    ne_rows = 0 if eq_active is None else int(sum(eq_active))      # equality rows come first in the oracle's row order; the kernels keep theirs beside the row arrays
     n = 64
     rng = np.random.default_rng(41)
     nq, nv, nb = model.nq, model.nv, model.nbody
@@ -868,7 +871,7 @@ def test_a_robot_that_is_not_the_duck(torch_cuda, oracle_mod, parity_log):
     b.physics_step(ctrl_t, 1)
     gq, gv, gw = b.get_state()
     img = b.lds_image()
-    o = {k: b.lds_offset(k) for k in ("xpos", "M", "qfrc_smooth", "qacc_smooth", "contact_dist", "efc_D", "efc_aref", "qacc", "sensordata", "actuator_force")}
+    o = {k: b.lds_offset(k) for k in ("xpos", "M", "qfrc_smooth", "qacc_smooth", "contact_dist", "efc_D", "efc_aref", "qacc", "sensordata", "actuator_force", "scr")}
     tabs = build_kernel_tables(model.a); lay = reduced_layout(model.a)
     Mi, Mj = lay["ei"], lay["ej"]
     assert np.array_equal(Mi, tabs["k_M_i"]) and len(Mi) == 156
@@ -894,12 +897,13 @@ def test_a_robot_that_is_not_the_duck(torch_cuda, oracle_mod, parity_log):
         n_contact += int(act.any())
         if act.any():
             W["dist"] = max(W["dist"], np.abs(cd_g[act] - cd_o[act]).max())
-        nefc = d.i("nefc")
-        live = np.abs(d.J()).sum(axis=1) > 0
+        nefc = d.i("nefc") - ne_rows
+        assert d.i("ne") == ne_rows
+        live = (np.abs(d.J()).sum(axis=1) > 0)[ne_rows:]
         D_g, aref_g = L[o["efc_D"]: o["efc_D"] + nefc], L[o["efc_aref"]: o["efc_aref"] + nefc]
         assert ((D_g > 0) == live)[nfl:].all(), f"env {e}: active row sets differ"
-        W["D"] = max(W["D"], _rel(D_g[live], d["efc_D"][:nefc][live], 1e-6).max())
-        W["aref"] = max(W["aref"], _rel(aref_g[live], d["efc_aref"][:nefc][live], 1.0).max())
+        W["D"] = max(W["D"], _rel(D_g[live], d["efc_D"][ne_rows: ne_rows + nefc][live], 1e-6).max())
+        W["aref"] = max(W["aref"], _rel(aref_g[live], d["efc_aref"][ne_rows: ne_rows + nefc][live], 1.0).max())
         W["qacc"] = max(W["qacc"], _rel(L[o["qacc"]: o["qacc"] + nv], d["qacc"][:nv], 5.0).max())
         W["sens"] = max(W["sens"], _rel(L[o["sensordata"]: o["sensordata"] + 46], d["sensordata"][:46], 1.0).max())
         ds = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 1)
@@ -927,9 +931,43 @@ def test_a_robot_that_is_not_the_duck(torch_cuda, oracle_mod, parity_log):
     with pytest.raises(engine.OdkError):
         b.reset(seed=1)
     b.close()
-    print("tail_biped", {k: float(f"{v:.3g}") for k, v in W.items()}, "ties", n_tie, "ten substeps", T10, "ill", n_ill, "of", n)
-    parity_log.check("tail_biped/one_mjx_step", dict(STAGE_BOUNDS, force=2e-4, tie_fraction=0.15), tie_fraction=n_tie / n, **W)
-    parity_log.check("tail_biped/ten_substeps", dict(TEN_BOUNDS, ill_fraction=0.5), ill_fraction=n_ill / n, **T10)
+    print(tag, {k: float(f"{v:.3g}") for k, v in W.items()}, "ties", n_tie, "ten substeps", T10, "ill", n_ill, "of", n)
+    parity_log.check(f"{tag}/one_mjx_step", dict(STAGE_BOUNDS, force=2e-4, tie_fraction=0.15), tie_fraction=n_tie / n, **W)
+    parity_log.check(f"{tag}/ten_substeps", dict(TEN_BOUNDS, ill_fraction=0.5), ill_fraction=n_ill / n, **T10)
+    return W, T10
+
+
+def test_a_robot_that_is_not_the_duck(torch_cuda, oracle_mod, parity_log):
+    """tests/assets/tail_biped.xml through the physics kernels at the duck's bounds (see the helper above)."""
+    _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped.xml", "tail_biped")
+
+
+def test_equality_joint_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log):
+    """SURVEY 8(f).3, <equality> (reference README.md:74-85): tests/assets/tail_biped_equality.xml with its two joint couplings ACTIVE
+    (tail_yaw_2 = 0.5 tail_yaw_1; left_ankle = 0.1 - 0.5 knee + 0.2 knee^2, solref 0.01) -- rows between two dofs of one serial chain,
+    always active, evaluated by both dof lanes, their Hessian term on an entry of the chain's own block (odk_kernels.h "equality rows") --
+    through the physics kernels against the float64 oracle: every stage of one mjx.step (the solver's qacc with the rows in it), the state
+    after one step and after ten, at the duck's bounds.  And the rows must MATTER: the same states stepped without them end up elsewhere."""
+    W, T10 = _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped_equality.xml", "tail_biped_equality", eq_active=(1, 1, 0, 0))
+    # the couplings change the motion: one step with and without them from the same state
+    import os
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model
+    from conftest import ROOT
+    torch = torch_cuda
+    base = Model.from_xml(os.path.join(ROOT, "tests", "assets", "tail_biped_equality.xml"), sim_dt=0.002)
+    out = []
+    for act in ((1, 1, 0, 0), (0, 0, 0, 0)):
+        m = Model({**base.a, "eq_active": np.asarray(act, np.int32)})
+        b = engine.Batch(m, 4)
+        q = np.tile(np.asarray(m.a["key_qpos"], np.float64), (4, 1)); q[:, 2] += 0.4
+        q[:, int(m.a["jnt_qposadr"][m.joint_id("tail_yaw_1")])] = 0.4          # couplings violated: tail_yaw_2 should follow, the ankle should move
+        b.set_state(q, np.zeros((4, m.nv)), np.zeros((4, m.nv)))
+        b.physics_step(torch.tensor(np.tile(np.asarray(m.a["key_ctrl"]), (4, 1)), dtype=torch.float32, device="cuda"), 10)
+        out.append(b.get_state()[0][0].copy())
+        b.close()
+    a2 = int(base.a["jnt_qposadr"][base.joint_id("tail_yaw_2")]); ak = int(base.a["jnt_qposadr"][base.joint_id("left_ankle")])
+    assert abs(out[0][a2] - out[1][a2]) > 0.02 and abs(out[0][ak] - out[1][ak]) > 0.01, (out[0][a2], out[1][a2], out[0][ak], out[1][ak])
 
 
 @pytest.mark.parametrize("kinds", [("sphere", "sphere"), ("capsule", "capsule"), ("capsule", "sphere")], ids="-".join)
