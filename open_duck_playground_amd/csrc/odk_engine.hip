@@ -1123,6 +1123,16 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I("nbody", one, 1); m.nb = one[0]; B.I("njnt", one, 1); m.nj = one[0]; B.I("nsite", one, 1); m.nsite = one[0];
   if (!B.ok) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   if (m.nq > MAXQ || m.nv > MAXV || m.nu > MAXU || m.nb > MAXB || m.nj > MAXJ || m.nsite > MAXSITE) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model too large"); }
+  {   // <option cone="elliptic">: the oracle's Newton solver has the cone (zones, cone Hessian, exact line search); the kernels' contact rows
+      // are pyramidal condim-3 wrench rows
+    RecHdr ch;
+    if (find_rec((const unsigned char*)blob, len, "opt_cone", &ch)) {
+      int cone[1] = {0};
+      Blob Cn{(const unsigned char*)blob, len};
+      Cn.I("opt_cone", cone, 1);
+      if (cone[0] != 0) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: the kernels' contact rows are pyramidal (the oracle has elliptic cones)"); }
+    }
+  }
   // <equality> (mjcf.py compiles joint / connect / weld; the float64 oracle builds all their rows).  The kernels model <equality><joint>
   // rows between two hinges of one serial chain (odk_kernels.h "equality rows": shapes with S::EQ, at most EQ_MAX rows, a dof in at most
   // one); every other ACTIVE equality is refused by name instead of being stepped without it.  Collected here, finished below once the

@@ -199,9 +199,13 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
                 opt[k] = int(o.attrib[k])
         if "gravity" in o.attrib:
             opt["gravity"] = _floats(o.attrib["gravity"])
-        for k in ("solver", "cone", "integrator"):
+        for k in ("solver", "integrator"):
             if k in o.attrib:
-                raise NotImplementedError(f"<option {k}=...> not supported (defaults: Newton/pyramidal/Euler)")
+                raise NotImplementedError(f"<option {k}=...> not supported (defaults: Newton / Euler)")
+        if "cone" in o.attrib:      # mjtCone: pyramidal 0, elliptic 1 (elliptic: the float64 oracle has it, `odk_model_load` refuses it)
+            if o.attrib["cone"] not in ("pyramidal", "elliptic"):
+                raise ValueError(f"<option cone='{o.attrib['cone']}'>")
+            opt["cone"] = 1 if o.attrib["cone"] == "elliptic" else 0
         for f in o.findall("flag"):
             if f.attrib.get("eulerdamp") == "disable":
                 opt["eulerdamp"] = 0
@@ -495,7 +499,7 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
     out["ngeom"], out["nsite"] = I32([len(geoms)]), I32([len(sites)])
     out["opt_timestep"] = F64([opt["timestep"]]); out["opt_gravity"] = F64(opt["gravity"])
     out["opt_tolerance"] = F64([opt["tolerance"]]); out["opt_ls_tolerance"] = F64([opt["ls_tolerance"]])
-    out["opt_impratio"] = F64([opt["impratio"]])
+    out["opt_impratio"] = F64([opt["impratio"]]); out["opt_cone"] = I32([opt["cone"]])
     out["opt_iterations"] = I32([opt["iterations"]]); out["opt_ls_iterations"] = I32([opt["ls_iterations"]])
     out["opt_eulerdamp"] = I32([opt["eulerdamp"]])
 

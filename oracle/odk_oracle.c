@@ -146,6 +146,7 @@ odko_model* odko_model_load(const void* blob, uint64_t len) {
   LF("opt_timestep", &m->timestep, 1); LF("opt_gravity", m->gravity, 3); LF("opt_tolerance", &m->tolerance, 1);
   LF("opt_ls_tolerance", &m->ls_tolerance, 1); LF("opt_impratio", &m->impratio, 1); LF("stat_meaninertia", &m->meaninertia, 1);
   LI("opt_iterations", &m->iterations, 1); LI("opt_ls_iterations", &m->ls_iterations, 1); LI("opt_eulerdamp", &m->eulerdamp, 1);
+  { rec_hdr chh; if (find_rec(b, len, "opt_cone", &chh)) load_i(b, len, "opt_cone", &m->cone, 1); }   /* optional: blobs before round 5 have none (= pyramidal) */
   LI("body_parentid", m->body_parentid, ODKO_MAXB); LI("body_rootid", m->body_rootid, ODKO_MAXB); LI("body_weldid", m->body_weldid, ODKO_MAXB);
   LI("body_jntadr", m->body_jntadr, ODKO_MAXB); LI("body_jntnum", m->body_jntnum, ODKO_MAXB);
   LI("body_dofadr", m->body_dofadr, ODKO_MAXB); LI("body_dofnum", m->body_dofnum, ODKO_MAXB);
@@ -264,7 +265,7 @@ real* odko_model_field(odko_model* m, const char* name, int* count) {
 }
 #define MI(nm) if (!strcmp(name, #nm)) return m->nm;
 int odko_model_int(const odko_model* m, const char* name) {
-  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(nsite) MI(nsensor) MI(nsensordata) MI(ncgeom) MI(npair) MI(iterations) MI(ls_iterations) MI(neq)
+  MI(nq) MI(nv) MI(nu) MI(nbody) MI(njnt) MI(nsite) MI(nsensor) MI(nsensordata) MI(ncgeom) MI(npair) MI(iterations) MI(ls_iterations) MI(neq) MI(cone)
   return -1;
 }
 
@@ -273,6 +274,7 @@ int odko_model_set_int(odko_model* m, const char* name, int value) {
   if (!strcmp(name, "iterations")) { m->iterations = value; return 0; }
   if (!strcmp(name, "ls_iterations")) { m->ls_iterations = value; return 0; }
   if (!strcmp(name, "hfield_mode")) { m->hfield_mode = value; return 0; }
+  if (!strcmp(name, "cone")) { m->cone = value != 0; return 0; }
   return -1;
 }
 
@@ -1353,7 +1355,7 @@ static void make_constraint(const odko_model* m, odko_data* d) {
     r++;
   }
   d->nl = r - d->nf - d->ne;
-  /* contact rows: pyramidal condim 3 -> 4 rows per contact */
+  /* contact rows: pyramidal condim 3 -> 4 rows per contact; elliptic condim 3 -> 3 rows (normal, two tangents) */
   for (int c = 0; c < d->ncon; c++) {
     int g1 = d->contact_geom1[c], g2 = d->contact_geom2[c];
     int b1 = m->cgeom_bodyid[g1], b2 = m->cgeom_bodyid[g2];
@@ -1370,6 +1372,32 @@ static void make_constraint(const odko_model* m, odko_data* d) {
     real dist = d->contact_dist[c];
     int active = dist < 0;
     real mu = d->contact_friction[c];
+    d->contact_efc[c] = r;
+    if (m->cone) {
+      /* Elliptic cone (mjx constraint._efc_contact_elliptic / MuJoCo mj_instantiateContact + mj_makeImpedance, [UPSTREAM-MEMORY]; the cost it
+       * leads to is pinned to the documented dual cone program by tests/test_oracle_elliptic.py).  Rows = the contact frame's axes; only the
+       * normal row carries a position (the tangents' pos = 0), all three share the normal's impedance, stiffness and damping; the normal's
+       * regulariser R_n = max(MINVAL, invweight (1 - imp) / imp) with invweight = the two bodies' translational weights, the tangents'
+       * R_t = R_n / impratio; the regularised cone's mu = friction sqrt(R_t / R_n) (update_constraint). */
+      real vel[3] = {0, 0, 0};
+      for (int a = 0; a < 3; a++)
+        for (int i = 0; i < nv; i++) {
+          real v = con[a * nv + i] * active;
+          d->efc_J[(r + a) * nv + i] = v;
+          vel[a] += v * d->qvel[i];
+        }
+      efc_row_params(m, d, r, dist, t, solref, solimp, vel[0], 0.0);
+      real Rt = d->efc_R[r] / (m->impratio > MINVAL ? m->impratio : MINVAL);
+      d->contact_mu_reg[c] = mu * sqrt(Rt / d->efc_R[r]);
+      for (int a = 1; a < 3; a++) {
+        d->efc_pos[r + a] = 0; d->efc_invweight[r + a] = t; d->efc_imp[r + a] = d->efc_imp[r]; d->efc_k[r + a] = d->efc_k[r]; d->efc_b[r + a] = d->efc_b[r];
+        d->efc_R[r + a] = Rt; d->efc_D[r + a] = 1.0 / Rt;
+        d->efc_aref[r + a] = -d->efc_b[r] * vel[a];
+        d->efc_frictionloss[r + a] = 0;
+      }
+      r += 3;
+      continue;
+    }
     for (int tdir = 1; tdir <= 2; tdir++)
       for (int s = 0; s < 2; s++) {
         real f = s == 0 ? mu : -mu, vel = 0;
@@ -1487,6 +1515,7 @@ typedef struct {
   int active[ODKO_MAXEFC]; /* rows in the quadratic regime (enter the Hessian) */
   real gauss, cost;
   real grad[ODKO_MAXV], Mgrad[ODKO_MAXV], search[ODKO_MAXV];
+  int cone_zone[ODKO_MAXCON];   /* elliptic cones: 0 top (no force), 1 bottom (all rows quadratic), 2 middle (on the cone) */
 } solver_ctx;
 
 static void ctx_init(const odko_model* m, const odko_data* d, solver_ctx* c, const real* qacc) {
@@ -1499,11 +1528,55 @@ static void ctx_init(const odko_model* m, const odko_data* d, solver_ctx* c, con
     c->Jaref[r] = s - d->efc_aref[r];
   }
 }
+/* ---- elliptic cones (mjx solver / MuJoCo engine_solver.c PrimalUpdateConstraint, HessianCone, PrimalEval; [UPSTREAM-MEMORY]).
+ * One contact = 3 rows (normal, two tangents) with Jaref x = (x_n, x_1, x_2), friction mu, R = (R_n, R_t, R_t), R_t = R_n / impratio.
+ * In the scaled space U = (mu_r x_n, mu x_1, mu x_2), mu_r = mu sqrt(R_t / R_n), N = U_0, T = |U_1..2|:
+ *   top zone     N >= mu_r T (or T = 0, N >= 0):        no force, no cost;
+ *   bottom zone  mu_r N + T <= 0 (or T = 0, N < 0):     every row quadratic, f_j = -D_j x_j;
+ *   middle zone  otherwise:                             cost = 0.5 Dm (N - mu_r T)^2, Dm = D_n / (mu_r^2 (1 + mu_r^2)),
+ *                                                       f_n = -Dm (N - mu_r T) mu_r, f_j = -f_n mu U_j / T.
+ * This IS the documented dual problem  min 0.5 f^T R f + f^T x  over the cone f_n >= 0, |f_t| <= mu f_n  in closed form: bottom = the
+ * unconstrained minimiser lies in the cone, top = x in the dual cone, middle = the minimiser on the cone's boundary, value
+ * 0.5 (x_n - mu |x_t|)^2 / (R_n + mu^2 R_t) (tests/test_oracle_elliptic.py derives and checks that independently). */
+typedef struct { real mu, mur, N, T, U[3], Dm, NmT; int zone; } cone_pt;
+static cone_pt cone_eval(const odko_data* d, int c, const real* x /* Jaref of the contact's 3 rows */) {
+  cone_pt p;
+  int r = d->contact_efc[c];
+  p.mu = d->contact_friction[c]; p.mur = d->contact_mu_reg[c];
+  p.U[0] = x[0] * p.mur; p.U[1] = x[1] * p.mu; p.U[2] = x[2] * p.mu;
+  p.N = p.U[0]; p.T = sqrt(p.U[1] * p.U[1] + p.U[2] * p.U[2]);
+  real m2 = p.mur * p.mur * (1 + p.mur * p.mur);
+  p.Dm = d->efc_D[r] / (m2 > MINVAL ? m2 : MINVAL);
+  p.NmT = p.N - p.mur * p.T;
+  if (p.N >= p.mur * p.T || (p.T <= 0 && p.N >= 0)) p.zone = 0;
+  else if (p.mur * p.N + p.T <= 0 || (p.T <= 0 && p.N < 0)) p.zone = 1;
+  else p.zone = 2;
+  return p;
+}
+static int cone_contact_rows(const odko_model* m, const odko_data* d, int r) {   /* is row r one of an elliptic contact's rows? */
+  return m->cone && r >= d->ne + d->nf + d->nl;
+}
+
 /* solver._update_constraint */
 static void update_constraint(const odko_model* m, const odko_data* d, solver_ctx* c) {
   int nv = m->nv;
   real cost = 0;
+  if (m->cone)
+    for (int k = 0; k < d->ncon; k++) {
+      int r = d->contact_efc[k];
+      cone_pt p = cone_eval(d, k, c->Jaref + r);
+      c->cone_zone[k] = p.zone;
+      for (int a = 0; a < 3; a++) { c->force[r + a] = 0; c->active[r + a] = p.zone != 0; }
+      if (p.zone == 1) {
+        for (int a = 0; a < 3; a++) { c->force[r + a] = -d->efc_D[r + a] * c->Jaref[r + a]; cost += 0.5 * d->efc_D[r + a] * c->Jaref[r + a] * c->Jaref[r + a]; }
+      } else if (p.zone == 2) {
+        cost += 0.5 * p.Dm * p.NmT * p.NmT;
+        c->force[r] = -p.Dm * p.NmT * p.mur;
+        for (int a = 1; a < 3; a++) c->force[r + a] = -c->force[r] / p.T * p.U[a] * p.mu;
+      }
+    }
   for (int r = 0; r < d->nefc; r++) {
+    if (cone_contact_rows(m, d, r)) break;   /* (the contact rows are last) */
     real jar = c->Jaref[r];
     if (r >= d->ne && r < d->ne + d->nf) {
       real f = d->efc_frictionloss[r], rf = d->efc_R[r] * f;
@@ -1527,13 +1600,13 @@ static void update_constraint(const odko_model* m, const odko_data* d, solver_ct
   c->gauss = 0.5 * g;
   c->cost = cost + c->gauss;
 }
-/* solver._update_gradient (Newton): H = M + J^T diag(D*active) J, Cholesky, Mgrad = H^-1 grad */
-static void update_gradient(const odko_model* m, const odko_data* d, solver_ctx* c) {
+/* H = M + J^T (d^2 cost / d Jaref^2) J: D on the diagonal for the active quadratic rows; for an elliptic contact in its middle zone the
+ * 3 x 3 block C = S (Dm g g^T - Dm (N - mu_r T) mu_r (I_t / T - U_t U_t^T / T^3)) S with g = (1, -mu_r U_t / T), S = diag(mu_r, mu, mu) */
+static void hessian(const odko_model* m, const odko_data* d, const solver_ctx* c, real* H) {
   int nv = m->nv;
-  real H[ODKO_MAXV * ODKO_MAXV], L[ODKO_MAXV * ODKO_MAXV];
-  for (int i = 0; i < nv; i++) c->grad[i] = c->Ma[i] - d->qfrc_smooth[i] - c->qfrc_constraint[i];
   memcpy(H, d->qM, (size_t)nv * nv * sizeof(real));
   for (int r = 0; r < d->nefc; r++) {
+    if (cone_contact_rows(m, d, r)) break;
     if (!c->active[r]) continue;
     const real* J = d->efc_J + r * nv;
     for (int i = 0; i < nv; i++) {
@@ -1541,6 +1614,40 @@ static void update_gradient(const odko_model* m, const odko_data* d, solver_ctx*
       for (int j = 0; j < nv; j++) H[i * nv + j] += d->efc_D[r] * J[i] * J[j];
     }
   }
+  if (!m->cone) return;
+  for (int k = 0; k < d->ncon; k++) {
+    int r = d->contact_efc[k];
+    real C[3][3] = {{0}};
+    if (c->cone_zone[k] == 0) continue;
+    if (c->cone_zone[k] == 1) { for (int a = 0; a < 3; a++) C[a][a] = d->efc_D[r + a]; }
+    else {
+      cone_pt p = cone_eval(d, k, c->Jaref + r);
+      real g[3] = {1, -p.mur * p.U[1] / p.T, -p.mur * p.U[2] / p.T}, S[3] = {p.mur, p.mu, p.mu};
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+          real h = p.Dm * g[a] * g[b];
+          if (a > 0 && b > 0) h -= p.Dm * p.NmT * p.mur * ((a == b ? 1.0 : 0.0) / p.T - p.U[a] * p.U[b] / (p.T * p.T * p.T));
+          C[a][b] = S[a] * h * S[b];
+        }
+    }
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) {
+        if (C[a][b] == 0) continue;
+        const real* Ja = d->efc_J + (r + a) * nv; const real* Jb = d->efc_J + (r + b) * nv;
+        for (int i = 0; i < nv; i++) {
+          if (Ja[i] == 0) continue;
+          for (int j = 0; j < nv; j++) H[i * nv + j] += C[a][b] * Ja[i] * Jb[j];
+        }
+      }
+  }
+}
+
+/* solver._update_gradient (Newton): H = M + J^T diag(D*active) J, Cholesky, Mgrad = H^-1 grad */
+static void update_gradient(const odko_model* m, const odko_data* d, solver_ctx* c) {
+  int nv = m->nv;
+  real H[ODKO_MAXV * ODKO_MAXV], L[ODKO_MAXV * ODKO_MAXV];
+  for (int i = 0; i < nv; i++) c->grad[i] = c->Ma[i] - d->qfrc_smooth[i] - c->qfrc_constraint[i];
+  hessian(m, d, c, H);
   cholesky(L, H, nv);
   chol_solve(c->Mgrad, L, c->grad, nv);
 }
@@ -1548,6 +1655,7 @@ static void update_gradient(const odko_model* m, const odko_data* d, solver_ctx*
 typedef struct { real alpha, cost, deriv0, deriv1; } ls_point;
 
 typedef struct {
+  const odko_model* m;
   const odko_data* d;
   const solver_ctx* c;
   real jv[ODKO_MAXEFC], quad[ODKO_MAXEFC][3], quad_gauss[3];
@@ -1557,7 +1665,29 @@ typedef struct {
 static ls_point ls_eval(const ls_ctx* L, real alpha) {
   const odko_data* d = L->d;
   real q0 = L->quad_gauss[0], q1 = L->quad_gauss[1], q2 = L->quad_gauss[2];
-  for (int r = 0; r < d->nefc; r++) {
+  real cone_cost = 0, cone_d0 = 0, cone_d1 = 0;   /* elliptic contacts: cost and its first / second derivative along the search, exactly */
+  int nrow = d->nefc;
+  if (L->m->cone) {
+    nrow = d->ne + d->nf + d->nl;
+    for (int k = 0; k < d->ncon; k++) {
+      int r = d->contact_efc[k];
+      real x[3], v[3];
+      for (int a = 0; a < 3; a++) { v[a] = L->jv[r + a]; x[a] = L->c->Jaref[r + a] + alpha * v[a]; }
+      cone_pt p = cone_eval(d, k, x);
+      if (p.zone == 1) {
+        for (int a = 0; a < 3; a++) { cone_cost += 0.5 * d->efc_D[r + a] * x[a] * x[a]; cone_d0 += d->efc_D[r + a] * x[a] * v[a]; cone_d1 += d->efc_D[r + a] * v[a] * v[a]; }
+      } else if (p.zone == 2) {
+        real V[3] = {v[0] * p.mur, v[1] * p.mu, v[2] * p.mu};
+        real UV = p.U[1] * V[1] + p.U[2] * V[2], VV = V[1] * V[1] + V[2] * V[2];
+        real T1 = UV / p.T, T2 = VV / p.T - UV * UV / (p.T * p.T * p.T);        /* dT / d alpha, d2T / d alpha2 */
+        real g1 = V[0] - p.mur * T1;                                            /* d (N - mu_r T) / d alpha */
+        cone_cost += 0.5 * p.Dm * p.NmT * p.NmT;
+        cone_d0 += p.Dm * p.NmT * g1;
+        cone_d1 += p.Dm * (g1 * g1 - p.NmT * p.mur * T2);
+      }
+    }
+  }
+  for (int r = 0; r < nrow; r++) {
     real x = L->c->Jaref[r] + alpha * L->jv[r];
     if (r >= d->ne && r < d->ne + d->nf) {
       real f = d->efc_frictionloss[r], rf = d->efc_R[r] * f;
@@ -1570,9 +1700,10 @@ static ls_point ls_eval(const ls_ctx* L, real alpha) {
   }
   ls_point p;
   p.alpha = alpha;
-  p.cost = alpha * alpha * q2 + alpha * q1 + q0;
-  p.deriv0 = 2 * alpha * q2 + q1;
-  p.deriv1 = 2 * q2 + (q2 == 0 ? MINVAL : 0.0);
+  p.cost = alpha * alpha * q2 + alpha * q1 + q0 + cone_cost;
+  p.deriv0 = 2 * alpha * q2 + q1 + cone_d0;
+  p.deriv1 = 2 * q2 + cone_d1;
+  if (p.deriv1 == 0) p.deriv1 = MINVAL;
   return p;
 }
 static real safe_div(real a, real b) { return b == 0 ? 0.0 : a / b; }
@@ -1582,7 +1713,7 @@ static void linesearch(const odko_model* m, odko_data* d, solver_ctx* c) {
   int nv = m->nv;
   ls_ctx L;
   real mv[ODKO_MAXV], snorm = 0;
-  L.d = d; L.c = c;
+  L.m = m; L.d = d; L.c = c;
   for (int i = 0; i < nv; i++) snorm += c->search[i] * c->search[i];
   snorm = sqrt(snorm);
   real smag = snorm * m->meaninertia * (nv > 1 ? nv : 1);
@@ -1679,6 +1810,17 @@ static void solve(const odko_model* m, odko_data* d) {
   memcpy(d->qacc_warmstart, c->qacc, nv * sizeof(real));
   memcpy(d->qfrc_constraint, c->qfrc_constraint, nv * sizeof(real));
   memcpy(d->efc_force, c->force, d->nefc * sizeof(real));
+}
+
+/* tests: cost, gradient and Newton Hessian of the solver's objective at an arbitrary qacc (rows of the last odko_forward) */
+void odko_solver_probe(const odko_model* m, const odko_data* d, const real* qacc, real* cost, real* grad, real* hess) {
+  solver_ctx c;
+  ctx_init(m, d, &c, qacc);
+  update_constraint(m, d, &c);
+  for (int i = 0; i < m->nv; i++) c.grad[i] = c.Ma[i] - d->qfrc_smooth[i] - c.qfrc_constraint[i];
+  if (cost) *cost = c.cost;
+  if (grad) memcpy(grad, c.grad, m->nv * sizeof(real));
+  if (hess) hessian(m, d, &c, hess);
 }
 
 /* ------------------------------------------------------------------ sensors (mjx sensor.py) */

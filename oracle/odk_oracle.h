@@ -72,6 +72,7 @@ typedef struct {
   int nq, nv, nu, nbody, njnt, nsite, nsensor, nsensordata, ncgeom, nhullvert, nhullface;
   real timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int iterations, ls_iterations, eulerdamp;
+  int cone;   /* mjtCone: 0 pyramidal (4 rows per condim-3 contact), 1 elliptic (3 rows: normal, two tangents; odk_oracle.c "elliptic cones") */
   /* bodies */
   int body_parentid[ODKO_MAXB], body_rootid[ODKO_MAXB], body_weldid[ODKO_MAXB];
   int body_jntadr[ODKO_MAXB], body_jntnum[ODKO_MAXB], body_dofadr[ODKO_MAXB], body_dofnum[ODKO_MAXB];
@@ -139,6 +140,9 @@ typedef struct {
   real efc_J[ODKO_MAXEFC * ODKO_MAXV], efc_pos[ODKO_MAXEFC], efc_D[ODKO_MAXEFC], efc_R[ODKO_MAXEFC], efc_aref[ODKO_MAXEFC],
       efc_frictionloss[ODKO_MAXEFC], efc_force[ODKO_MAXEFC], efc_invweight[ODKO_MAXEFC], efc_b[ODKO_MAXEFC], efc_k[ODKO_MAXEFC],
       efc_imp[ODKO_MAXEFC];
+  /* elliptic cones: per contact, the first of its 3 rows, the friction coefficient and the regularised cone's mu = friction sqrt(R_t / R_n) */
+  int contact_efc[ODKO_MAXCON];
+  real contact_mu_reg[ODKO_MAXCON];
   /* velocity stage */
   real cvel[ODKO_MAXB][6], cdof_dot[ODKO_MAXV][6], cacc[ODKO_MAXB][6];
   real qfrc_bias[ODKO_MAXV], qfrc_passive[ODKO_MAXV], qfrc_actuator[ODKO_MAXV], actuator_force[ODKO_MAXU];
@@ -171,6 +175,9 @@ real* odko_model_field(odko_model* m, const char* name, int* count);
 int odko_model_int(const odko_model* m, const char* name);
 int odko_model_set_int(odko_model* m, const char* name, int value); /* "iterations" / "ls_iterations" / "hfield_mode" */
 int odko_model_eq_set_active(odko_model* m, int e, int on);          /* mjData.eq_active: equality constraint e on / off */
+/* tests: the solver's cost, gradient (nv) and Newton Hessian (nv x nv, row-major) at an arbitrary qacc, for the constraint rows of the last
+ * odko_forward on d (d is not modified) */
+void odko_solver_probe(const odko_model* m, const odko_data* d, const real* qacc, real* cost, real* grad, real* hess);
 int odko_convex_pair(const real* va, int nva, const int* ta, int nta, const real* pa, const real* ma, const real* vb, int nvb, const int* tb,
                      int ntb, const real* pb, const real* mb, real* dist4, real* pos12, real* normal3, real* sat3);
 int odko_model_convex_counts(const odko_model* m, int g, int* nv, int* nf, int* ne);

@@ -3,7 +3,7 @@
 #   tools/collect_round_profiles.sh r4      after tools/gpu_profile_round.sh r4 (kernel traces, counters, bench lines), and -- when they ran --
 #   tools/gpu_learner_trace.sh r4end, tools/gpu_train_runs.sh r4end, tools/hfield_variants.py, a `pytest -m gpu` run (parity_worst.json)
 set -eu   # a missing REQUIRED input must fail loudly: stale evidence in profiles/ is worse than none
-R=${1:-r4}; P=profiles/$R; G=gpurun_out/prof_$R
+R=${1:-r5}; P=profiles/$R; G=gpurun_out/prof_$R
 mkdir -p $P
 for t in "" _flat_terrain_backlash _rough_terrain_backlash; do
   cp $G/kernel_stats$t.csv $G/bench_under_rocprof$t.json $G/pmc_summary$t.json $G/traffic$t.json $P/

@@ -14,8 +14,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/p2 -- python3 $ROOT/tools
 python3 - $OUT $TAG <<'PY'
 import csv, glob, json, os, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
-LEARNER = ("gather_rows", "mlp_fwd", "gae_kernel", "ppo_head", "ppo_gae_head", "mlp_bwd", "dw_gemm", "grad_finish", "adam_", "sqnorm")
-WIDE = ("mlp_fwd", "mlp_bwd", "dw_gemm", "adam_", "grad_finish", "gather_rows")     # kernels whose reads are 16-byte-per-lane streams
+LEARNER = ("mlp_fwd", "gae_kernel", "ppo_head_kernel", "ppo_gae_head", "mlp_bwd", "dw_gemm", "grad_finish", "adam_", "sqnorm")     # (gather_rows: the rollout's snapshot launches now, not the learner's)
+WIDE = ("mlp_fwd", "mlp_bwd", "dw_gemm", "grad_finish")     # kernels whose reads are 16-byte-per-lane streams (Adam reads the torch-layout rows 4 bytes per lane)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -29,7 +29,7 @@ for name in sorted(agg):
     if not f or not w: continue
     fetch, write = 1024 * sum(f) / len(f), 1024 * sum(w) / len(w)
     per_step = len(f) / nadam
-    if name == "mlp_fwd" and per_step > 1.5:          # the rollout's policy launches share the kernel: keep the training launches (the larger ones)
+    if name == "mlp_fwd" and per_step > 1.02:         # the rollout's policy launches share the kernel: keep the training launches (the larger ones)
         fs, ws = sorted(f)[-nadam:], sorted(w)[-nadam:]
         fetch, write, per_step = 1024 * sum(fs) / len(fs), 1024 * sum(ws) / len(ws), 1.0
     corr = 2.0 if name in WIDE else 1.0

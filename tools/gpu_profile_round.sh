@@ -5,7 +5,7 @@
 # instruction / wait counters, the float32 operation mix and the active-lane counters -- every --pmc group its own run, never combined
 # with a trace domain -- folded into pmc_summary_<task>.json and traffic_<task>.json (what bench.py reports as roofline.traffic).
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
