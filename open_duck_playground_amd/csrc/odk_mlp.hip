@@ -45,6 +45,9 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef ODK_FWD_DBUF
+#define ODK_FWD_DBUF 0
+#endif
 constexpr int H1 = ODK_MLP_H1, H2 = ODK_MLP_H2, H3 = ODK_MLP_H3;
 constexpr int TM = ODK_MLP_TILE;       // samples per workgroup
 constexpr int CH = 128;                // layer-1 chunk width = K-slice of layer 2
@@ -54,10 +57,11 @@ constexpr int PX_MAX = KIN_MAX + 4;
 constexpr int SLACK = 64;              // the k loops fetch (never use) up to two batches past a row's end
 static_assert(TM == 16 && KIN_MAX % 16 == 0, "tile = one 16-row MFMA block, padded input width");
 // forward LDS (floats): X | chunk | layer-2 output | slack;  the layer-3 output aliases X, the output layer's partial blocks alias the chunk
-constexpr int F_X = 0, F_C = F_X + TM * PX_MAX, F_H2 = F_C + TM * PC, F_TOTAL = F_H2 + TM * P2 + SLACK;
+constexpr int NCBUF = ODK_FWD_DBUF ? 2 : 1;
+constexpr int F_X = 0, F_C = F_X + TM * PX_MAX, F_H2 = F_C + NCBUF * TM * PC, F_TOTAL = F_H2 + TM * P2 + SLACK;
 static_assert(TM * P3 <= TM * PX_MAX, "layer-3 output must fit in the X region");
 static_assert(3 * 2 * 4 * 64 <= TM * PC, "output-layer partial blocks must fit in the chunk region");
-static_assert(F_TOTAL * 4 <= 40 * 1024, "four forward workgroups per CU");
+static_assert(F_TOTAL * 4 <= (ODK_FWD_DBUF ? 53 : 40) * 1024, "four (three with two chunk buffers) forward workgroups per CU");
 // backward LDS: dz_top | dz3 | dz2 | slack
 constexpr int B_D4 = 0, B_D3 = B_D4 + TM * P4, B_D2 = B_D3 + TM * P3, B_TOTAL = B_D2 + TM * P2 + SLACK;
 
@@ -107,6 +111,9 @@ __device__ __forceinline__ void map_block(const Args& a, int b, int& net, int& t
 #endif
 #ifndef ODK_BWD_PREFETCH_G
 #define ODK_BWD_PREFETCH_G 0      // backward: a phase's swish' pieces are fetched one phase ahead instead of behind its MFMAs
+#endif
+#ifndef ODK_FWD_DBUF
+#define ODK_FWD_DBUF 0            // forward: two chunk buffers alternate, one barrier per chunk instead of two (three workgroups per CU)
 #endif
 #ifndef ODK_MLP_SETPRIO
 #define ODK_MLP_SETPRIO 0         // raise the wave's priority inside the MFMA loops
@@ -314,19 +321,24 @@ __global__ void __launch_bounds__(256, ODK_MLP_WG_PER_CU) mlp_fwd_kernel(Args a)
     f32x4 acc1[2];
     zero(acc1);
     const int col = ch * CH + w * 32 + c;
+    float* Cc = C1 + (ODK_FWD_DBUF ? (ch & 1) * TM * PC : 0);    // this chunk's buffer
     p1.run(acc1, X + c * PX + 4 * q);
     ODK_STAMP(2 + 5 * ch);
     p2.prefetch(N.wf[1], H2, w * 64 + c, q, ch * (CH / 16), CH / 16);
-    fwd_epilogue<2>(acc1, bias1[ch], C1 + w * 32 + c, PC, store ? N.h[0] + (ql * H1 + col) * 4 : nullptr, store ? N.g[0] + (ql * H1 + col) * 4 : nullptr, q,
+    fwd_epilogue<2>(acc1, bias1[ch], Cc + w * 32 + c, PC, store ? N.h[0] + (ql * H1 + col) * 4 : nullptr, store ? N.g[0] + (ql * H1 + col) * 4 : nullptr, q,
                     rows_valid);
     ODK_STAMP(3 + 5 * ch);
     __syncthreads();
     ODK_STAMP(4 + 5 * ch);
-    p2.run(acc2, C1 + c * PC + 4 * q);
+    p2.run(acc2, Cc + c * PC + 4 * q);
     ODK_STAMP(5 + 5 * ch);
     if (ch + 1 < H1 / CH) p1.prefetch(N.wf[0], H1, col + CH, q, 0, k16 >> 4);
     else p1.prefetch(N.wf[2], H3, w * 32 + c, q, 0, H2 / 16);
-    __syncthreads();
+    // one buffer: nobody may overwrite the chunk before every wave has read it.  Two buffers: the next chunk goes to the other one, and the
+    // chunk after that is written behind the next chunk's barrier, which a wave passes only after this p2.run -- no barrier here (the last
+    // chunk keeps it: the layer-2 epilogue below writes H2s, which nobody reads before the barrier that follows it, but the output layer's
+    // partial blocks alias the chunk region)
+    if (!ODK_FWD_DBUF || ch + 1 == H1 / CH) __syncthreads();
     ODK_STAMP(6 + 5 * ch);
   }
   {
