@@ -330,6 +330,34 @@ def test_indexed_step_equals_the_gathered_step(monkeypatch):
     torch.testing.assert_close(l1.losses, l2.losses, rtol=0, atol=0)
 
 
+def test_indexed_learner_grows_its_resident_rollout():
+    """A rollout larger than the resident copy was sized for (n_traj): new buffers, new descriptors, new graphs -- and the same
+    parameters afterwards as a learner that was built large enough."""
+    from open_duck_playground_amd.ppo import train as T
+    from open_duck_playground_amd.ppo.learner import FlatLearner
+    from open_duck_playground_amd.ppo.networks import PPONetworks
+    dev = torch.device("cuda")
+    cfg = T.ppo_config(); cfg.update(num_minibatches=4, num_updates_per_batch=1, tune_gemms=False)
+    N, Tn = 64, 20
+    data = _fake_rollout(N, Tn, dev, seed=12)
+    out = []
+    for n_traj in (16, 64):
+        torch.manual_seed(6)
+        n = PPONetworks(101, 212, 14).to(dev)
+        n.norm_obs.update(data["obs"]); n.norm_priv.update(data["priv"])
+        lr = FlatLearner(n, cfg, N // 4, Tn, use_graph=True, n_traj=n_traj)
+        assert lr.indexed and lr.cap == n_traj
+        lr.load_rollout_from(n, data, cfg)
+        assert lr.cap == 64 and lr.graph_a is not None
+        g = torch.Generator(device=dev).manual_seed(1)
+        lr.set_schedule(torch.randperm(N, generator=g, device=dev))
+        out.append(lr)
+    out[1]._pool.copy_(out[0]._pool)
+    for lr in out:
+        lr.run(4)
+    assert torch.equal(out[0].flat_p, out[1].flat_p) and int(out[0].cursor) == 4
+
+
 def test_flat_learner_training_step_matches_eager_and_graph_replays():
     """3 clipped-Adam steps: graph replay == plain launches == autograd + optax-style clip + torch Adam."""
     from open_duck_playground_amd.ppo import train as T
