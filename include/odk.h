@@ -356,6 +356,19 @@ typedef struct odk_gae_head_args {
 } odk_gae_head_args;
 int odk_ppo_gae_head(const odk_gae_head_args* args, void* stream);
 
+/* Column moments of a row-major float32 matrix x [rows, w] in ONE pass, accumulated in float64: partial_dev [slices][2][w] doubles receives, per row
+ * slice, the column sums and the column sums of squares (slice s takes rows s, s + slices, ...; fixed order inside a slice); the caller folds the
+ * slices (any fixed-order sum: they are few).  The observation normaliser's batch statistics (brax running_statistics.update as reached through
+ * reference common/runner.py:104-118: normalize_observations=True) without a float64 copy of the 10^7-element rollout.  slices <= 1024. */
+int odk_col_moments(const float* x_dev, long long rows, int w, int slices, double* partial_dev, void* stream);
+/* brax running_statistics.update on those moments, one launch: folds the slices of partial_dev (in slice order) into the batch's column sums s
+ * and sums of squares s2 over `rows` rows, then, in float64,
+ *   count' = count + rows;  mean' = mean + (s / rows - mean) rows / count';  summed_variance' = summed_variance + (s2 - s (mean + mean') + rows mean mean');
+ *   std = clamp(sqrt(max(summed_variance' / count', 0)), std_min, std_max)
+ * count_dev: one double; mean / summed_variance / std: float32 [w], updated in place. */
+int odk_moments_update(const double* partial_dev, int slices, int w, long long rows, double* count_dev, float* mean_dev, float* summed_variance_dev,
+                       float* std_dev, float std_min, float std_max, void* stream);
+
 /* colsum[f][c] = sum over the nblk[f] tile rows of partial[f][tile, c] for up to 8 layers in one launch (fixed order);
  * partial_dev / colsum_dev / widths / nblk are HOST arrays */
 int odk_colsum_fold(const float* const* partial_dev, float* const* colsum_dev, const int* widths, const int* nblk, int count, void* stream);

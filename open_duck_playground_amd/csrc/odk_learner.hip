@@ -742,6 +742,62 @@ __global__ void __launch_bounds__(256) grad_finish_kernel(const float* __restric
   }
 }
 
+// column sums and sums of squares of x [rows, w], float64 accumulators: block = 64 columns x 4 row phases (256-byte coalesced row reads), grid =
+// (column tiles, row slices); slice s walks rows s, s + slices, ... -- with 4 phases: rows s + slices (4 k + phase)
+__global__ void __launch_bounds__(256) col_moments_kernel(const float* __restrict__ x, long long rows, int w, int slices, double* __restrict__ partial) {
+  __shared__ double sh[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx, sl = blockIdx.y;
+  double s = 0.0, s2 = 0.0;
+  if (c < w) {
+    long long r = (long long)sl + (long long)slices * ty;
+    const long long step = 4ll * slices;
+    // eight rows in flight per thread (the launch is a latency-bound stream: bytes in flight per CU are what sets its rate)
+    for (; r + 7 * step < rows; r += 8 * step) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = x[(r + u * step) * w + c];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { s += (double)v[u]; s2 += (double)v[u] * (double)v[u]; }
+    }
+    for (; r < rows; r += step) { const float v = x[r * w + c]; s += (double)v; s2 += (double)v * (double)v; }
+  }
+  sh[0][ty][tx] = s; sh[1][ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0 && c < w) {
+    double* o = partial + (size_t)sl * 2 * w;
+    o[c] = (sh[0][0][tx] + sh[0][1][tx]) + (sh[0][2][tx] + sh[0][3][tx]);
+    o[w + c] = (sh[1][0][tx] + sh[1][1][tx]) + (sh[1][2][tx] + sh[1][3][tx]);
+  }
+}
+
+// running_statistics.update from the slice moments: block = 64 columns x 4 slice phases; every thread reads the OLD count before the barrier and the
+// one thread that owns it writes the new one after it (single workgroup per 64 columns: blocks other than 0 never write the count)
+__global__ void __launch_bounds__(256) moments_update_kernel(const double* __restrict__ partial, int slices, int w, double rows, double* __restrict__ count,
+                                                            float* __restrict__ mean, float* __restrict__ sv, float* __restrict__ sd, float std_min, float std_max) {
+  __shared__ double sh[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const double cnt0 = *count;
+  double s = 0.0, s2 = 0.0;
+  if (c < w)
+    for (int sl = ty; sl < slices; sl += 4) { const double* p = partial + (size_t)sl * 2 * w; s += p[c]; s2 += p[w + c]; }
+  sh[0][ty][tx] = s; sh[1][ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0 && c < w) {
+    s = (sh[0][0][tx] + sh[0][1][tx]) + (sh[0][2][tx] + sh[0][3][tx]);
+    s2 = (sh[1][0][tx] + sh[1][1][tx]) + (sh[1][2][tx] + sh[1][3][tx]);
+    const double cnt = cnt0 + rows, m0 = (double)mean[c];
+    const double m1 = m0 + (s / rows - m0) * (rows / cnt);
+    const double v1 = (double)sv[c] + (s2 - s * (m0 + m1) + rows * m0 * m1);
+    mean[c] = (float)m1; sv[c] = (float)v1;
+    const float sdv = (float)sqrt(fmax(v1 / cnt, 0.0));
+    sd[c] = fminf(fmaxf(sdv, std_min), std_max);
+  }
+  // the count moves once every reader has it (grid-wide: by the NEXT launch on the stream -- see the host wrapper: its own tiny launch)
+}
+__global__ void add_count_kernel(double* count, double rows) { *count += rows; }
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return odk_fail_(ODK_ERR_HIP, what);
@@ -749,6 +805,22 @@ int check_launch(const char* what) {
 }
 
 }  // namespace
+
+extern "C" int odk_moments_update(const double* partial_dev, int slices, int w, long long rows, double* count_dev, float* mean_dev, float* summed_variance_dev,
+                                  float* std_dev, float std_min, float std_max, void* stream) {
+  if (!partial_dev || !count_dev || !mean_dev || !summed_variance_dev || !std_dev || slices <= 0 || w <= 0 || rows <= 0)
+    return odk_fail_(ODK_ERR_INVALID, "odk_moments_update: bad arguments");
+  hipLaunchKernelGGL(moments_update_kernel, dim3((w + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial_dev, slices, w, (double)rows, count_dev, mean_dev,
+                     summed_variance_dev, std_dev, std_min, std_max);
+  hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, count_dev, (double)rows);      // after every block of the update has read the old count
+  return check_launch("odk_moments_update: launch failed");
+}
+
+extern "C" int odk_col_moments(const float* x_dev, long long rows, int w, int slices, double* partial_dev, void* stream) {
+  if (!x_dev || !partial_dev || rows <= 0 || w <= 0 || slices <= 0 || slices > 1024) return odk_fail_(ODK_ERR_INVALID, "odk_col_moments: bad arguments (slices 1..1024)");
+  hipLaunchKernelGGL(col_moments_kernel, dim3((w + 63) / 64, slices), dim3(256), 0, (hipStream_t)stream, x_dev, rows, w, slices, partial_dev);
+  return check_launch("odk_col_moments: launch failed");
+}
 
 extern "C" int odk_gae(const float* truncation_dev, const float* termination_dev, const float* rewards_dev, const float* values_dev,
                        const float* bootstrap_dev, float* vs_dev, float* adv_dev, float* adv_stats_dev, int B, int T, float lambda_,

@@ -166,6 +166,8 @@ def load_library() -> C.CDLL:
     L.odk_adam_clip_packed_tail.argtypes = [P, P, P, P, P, C.c_longlong] + [C.c_float] * 5 + [P, C.c_longlong, P, C.c_longlong, C.POINTER(WeightTableC), C.c_int,
                                             C.POINTER(StepTail), P]
     L.odk_ppo_gae_head.argtypes = [C.POINTER(GaeHeadArgs), P]
+    L.odk_col_moments.argtypes = [P, C.c_longlong, C.c_int, C.c_int, P, P]
+    L.odk_moments_update.argtypes = [P, C.c_int, C.c_int, C.c_longlong, P, P, P, P, C.c_float, C.c_float, P]
     L.odk_colsum_fold.argtypes = [PP, PP, IP, IP, C.c_int, P]
     L.odk_gather_rows.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.c_int, P, C.c_int, C.c_longlong, P]
     _lib = L
@@ -180,7 +182,7 @@ EXPORTED_SYMBOLS = (
     "odk_batch_get_lds", "odk_lds_offset", "odk_batch_record_size", "odk_batch_get_records", "odk_batch_set_records", "odk_batch_timing", "odk_gae", "odk_ppo_head",
     "odk_policy_sample", "odk_adam_clip", "odk_silu_bwd_colsum", "odk_colsum_partial", "odk_colsum_finalize", "odk_gather_rows", "odk_dw_gemm",
     "odk_mlp_forward", "odk_mlp_backward", "odk_mlp_set_profile", "odk_pack_weights", "odk_adam_clip_packed", "odk_colsum_fold",
-    "odk_adam_clip_packed_tail", "odk_ppo_gae_head")
+    "odk_adam_clip_packed_tail", "odk_ppo_gae_head", "odk_col_moments", "odk_moments_update")
 
 
 def _chk(rc: int):
@@ -485,6 +487,35 @@ def adam_clip_packed(params, grads, m, v, acc, fwd_packed, bwd_packed, table: We
     _chk(load_library().odk_adam_clip_packed_tail(_ptr(params), _ptr(grads), _ptr(m), _ptr(v), _ptr(acc), params.numel(), lr, b1, b2, eps,
                                                   max_grad_norm or 0.0, _ptr(fwd_packed), fwd_packed.numel(), _ptr(bwd_packed), bwd_packed.numel(),
                                                   C.byref(table.c), int(norm_blocks), C.byref(tail) if tail is not None else None, _stream(params)))
+
+
+def col_moments(x, slices: int = 1024):
+    """(column sums, column sums of squares) of a contiguous float32 CUDA matrix x [rows, w], float64, in one pass (`odk_col_moments` + a
+    fixed-order fold of its row slices): the observation normaliser's batch statistics."""
+    import torch
+    _f32c(x)
+    rows, w = x.shape
+    slices = max(1, min(int(slices), 1024, int(rows)))
+    part = torch.empty(slices, 2, w, dtype=torch.float64, device=x.device)
+    _chk(load_library().odk_col_moments(_ptr(x), int(rows), int(w), slices, C.c_void_p(part.data_ptr()), _stream(x)))
+    tot = part.sum(0)
+    return tot[0], tot[1]
+
+
+def running_stats_update(x, count, mean, summed_variance, std, std_min: float, std_max: float, slices: int = 1024):
+    """brax running_statistics.update of (count float64 [], mean / summed_variance / std float32 [w]) with the batch x [rows, w] (contiguous float32
+    CUDA), in place, three launches and no host arithmetic (`odk_col_moments` + `odk_moments_update`)."""
+    import torch
+    _f32c(x, mean, summed_variance, std)
+    rows, w = x.shape
+    if not (count.is_cuda and count.dtype == torch.float64 and count.numel() == 1):
+        raise OdkError("running_stats_update: count must be a float64 CUDA scalar")
+    slices = max(1, min(int(slices), 1024, int(rows)))
+    part = torch.empty(slices, 2, w, dtype=torch.float64, device=x.device)
+    L = load_library()
+    _chk(L.odk_col_moments(_ptr(x), int(rows), int(w), slices, C.c_void_p(part.data_ptr()), _stream(x)))
+    _chk(L.odk_moments_update(C.c_void_p(part.data_ptr()), slices, int(w), int(rows), C.c_void_p(count.data_ptr()), _ptr(mean), _ptr(summed_variance), _ptr(std),
+                              float(std_min), float(std_max), _stream(x)))
 
 
 class GaeHead:

@@ -10,6 +10,21 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+_ENGINE = []
+
+
+def _engine():
+    """the engine module when the HIP library is there (GPU rollouts), else None -- the torch path below is the CPU / fallback arithmetic"""
+    if not _ENGINE:
+        try:
+            from .. import engine
+            engine.load_library()
+            _ENGINE.append(engine)
+        except Exception:
+            _ENGINE.append(None)
+    return _ENGINE[0]
+
+
 class MLP(nn.Module):
     def __init__(self, sizes):
         super().__init__()
@@ -40,13 +55,22 @@ class RunningStats(nn.Module):
     @torch.no_grad()
     def update(self, batch: torch.Tensor, group=None):
         x = batch.reshape(-1, batch.shape[-1]).to(torch.float32)
+        eng = _engine() if (x.is_cuda and x.is_contiguous() and x.shape[0] >= 4096) else None
+        if eng is not None and group is None:
+            # single rank: the whole update on the device -- one pass over the rollout with float64 accumulators, then the running statistics
+            # in float64 (csrc/odk_learner.hip col_moments_kernel / moments_update_kernel): 0.23 ms of ~25 tiny launches and a host-to-device
+            # copy -> three launches
+            eng.running_stats_update(x, self.count, self.mean, self.summed_variance, self.std, self.std_min, self.std_max)
+            return
         n = torch.tensor([float(x.shape[0])], dtype=torch.float64, device=x.device)
         # float32 sums over chunks of <= 256 rows (one fused read each, no float64 copy of the 10^7-element rollout), the
         # chunk sums folded in float64: each chunk sum / norm carries float32 rounding (~1e-7 relative; the squared norm
         # ~2e-7), which is far below what the normaliser needs but NOT double accuracy; 2.2 ms -> 0.3 ms per update
         rows = x.shape[0]
         chunk = next((c for c in (256, 128, 64, 32) if rows % c == 0), 0)
-        if chunk and rows > chunk:
+        if eng is not None:
+            s, s2 = eng.col_moments(x)
+        elif chunk and rows > chunk:
             xv = x.view(rows // chunk, chunk, x.shape[1])
             s = xv.sum(1).double().sum(0)
             s2 = torch.linalg.vector_norm(xv, ord=2, dim=1).double().square().sum(0)

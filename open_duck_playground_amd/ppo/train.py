@@ -140,8 +140,9 @@ def sgd_epoch(net, opt, data: Dict[str, torch.Tensor], cfg: Dict, gen: torch.Gen
             # the rollout goes into the learner's resident buffers once, the training step's shuffles become ONE device array of
             # trajectory indices, and every minibatch step is one graph replay -- no gather, no host-side call between two steps
             learner.load_rollout_from(net, data, cfg)
-            perms = [torch.randperm(B, generator=gen, device=data["reward"].device) for _ in range(nup)]
-            learner.set_schedule(torch.cat(perms))
+            # the training step's shuffles as ONE batched sort of uniform keys (four torch.randperm calls were 0.18 ms of sort launches)
+            perms = torch.rand(nup, B, generator=gen, device=data["reward"].device).argsort(dim=1)
+            learner.set_schedule(perms.reshape(-1))
             learner.run(nup * nmb)
             return learner.metrics() if meter is None else None
         prep = prepare_rollout(net, data, cfg)

@@ -330,6 +330,36 @@ def test_indexed_step_equals_the_gathered_step(monkeypatch):
     torch.testing.assert_close(l1.losses, l2.losses, rtol=0, atol=0)
 
 
+def test_col_moments_kernel_matches_float64_torch():
+    """odk_col_moments (the observation normaliser's batch statistics in one pass, float64 accumulators) vs torch in float64; and
+    RunningStats.update through it == the torch path it replaces, to rounding."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.ppo.networks import RunningStats
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for rows, w in ((163840, 101), (5000, 212), (4097, 7), (33, 70)):
+        x = (torch.randn(rows, w, device="cuda", generator=g) * 3 + 1.5).contiguous()
+        s, s2 = engine.col_moments(x)
+        xd = x.double()
+        torch.testing.assert_close(s, xd.sum(0), rtol=1e-12, atol=1e-9)
+        torch.testing.assert_close(s2, (xd * xd).sum(0), rtol=1e-12, atol=1e-9)
+        a, b = engine.col_moments(x)
+        assert torch.equal(a, s) and torch.equal(b, s2)                    # fixed order: bit-reproducible
+    x = torch.randn(8192, 20, 101, device="cuda", generator=g) * 2 + 0.5
+    fast, slow = RunningStats(101).cuda(), RunningStats(101).cuda()
+    for k in range(2):
+        fast.update(x + k)
+        xs = (x + k).reshape(-1, 101)
+        n = torch.tensor([float(xs.shape[0])], dtype=torch.float64, device="cuda")
+        # the torch arithmetic of RunningStats.update on exact float64 sums
+        s, s2 = xs.double().sum(0), (xs.double() ** 2).sum(0)
+        count = slow.count + n[0]; delta = s / n[0] - slow.mean.double(); new_mean = slow.mean.double() + delta * (n[0] / count)
+        sv = slow.summed_variance.double() + (s2 - s * (slow.mean.double() + new_mean) + n[0] * slow.mean.double() * new_mean)
+        slow.count.copy_(count); slow.mean.copy_(new_mean.float()); slow.summed_variance.copy_(sv.float())
+        slow.std.copy_(torch.sqrt(torch.clamp(sv / count, min=0)).float().clamp(1e-6, 1e6))
+    torch.testing.assert_close(fast.mean, slow.mean, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(fast.std, slow.std, rtol=1e-6, atol=1e-7)
+
+
 def test_indexed_learner_grows_its_resident_rollout():
     """A rollout larger than the resident copy was sized for (n_traj): new buffers, new descriptors, new graphs -- and the same
     parameters afterwards as a learner that was built large enough."""
