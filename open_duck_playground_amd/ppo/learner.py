@@ -454,7 +454,7 @@ class FlatLearner:
         steps = perms.numel() // self.B
         if perms.numel() != steps * self.B or steps < 1 or steps > self.steps_cap:
             raise engine.OdkError(f"set_schedule: {perms.numel()} indices are not 1..{self.steps_cap} minibatches of {self.B} trajectories")
-        self.sched[:perms.numel()].copy_(perms)
+        self.sched[:perms.numel()].copy_(perms.reshape(-1))
         self.cursor.zero_()
         self._host_cursor, self._host_steps = 0, steps
         self._pool[:steps].normal_()
