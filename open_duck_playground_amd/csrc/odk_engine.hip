@@ -1123,14 +1123,14 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I("nbody", one, 1); m.nb = one[0]; B.I("njnt", one, 1); m.nj = one[0]; B.I("nsite", one, 1); m.nsite = one[0];
   if (!B.ok) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   if (m.nq > MAXQ || m.nv > MAXV || m.nu > MAXU || m.nb > MAXB || m.nj > MAXJ || m.nsite > MAXSITE) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model too large"); }
-  {   // <option cone="elliptic">: the oracle's Newton solver has the cone (zones, cone Hessian, exact line search); the kernels' contact rows
-      // are pyramidal condim-3 wrench rows
+  {   // <option cone="elliptic">: zones, cone Hessian and exact line search are compiled into the third shape's kernels (odk_kernels.h "elliptic
+      // cones"); the duck's shapes keep their pyramidal rows and refuse the option by name
     RecHdr ch;
     if (find_rec((const unsigned char*)blob, len, "opt_cone", &ch)) {
       int cone[1] = {0};
       Blob Cn{(const unsigned char*)blob, len};
       Cn.I("opt_cone", cone, 1);
-      if (cone[0] != 0) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: the kernels' contact rows are pyramidal (the oracle has elliptic cones)"); }
+      m.cone = cone[0] != 0;      // accepted for the third shape only (checked below, once the shape is known)
     }
   }
   // <equality> (mjcf.py compiles joint / connect / weld; the float64 oracle builds all their rows).  The kernels model <equality><joint>
@@ -1395,7 +1395,8 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       double mu = cg_prio[g1] > cg_prio[g2] ? cg_fric[3 * g1] : (cg_prio[g2] > cg_prio[g1] ? cg_fric[3 * g2] : fmax(cg_fric[3 * g1], cg_fric[3 * g2]));
       m.pair_mu[pr] = (float)mu;
       double t = biw[2 * cg_body[g1]] + biw[2 * cg_body[g2]];
-      m.pair_invweight[pr] = (float)((t + mu * mu * t) * 2 * mu * mu / (double)m.impratio);
+      // pyramidal rows: the pyramid edge's weight; elliptic cones: the two bodies' translational weights (the normal row's; the kernels scale the tangents)
+      m.pair_invweight[pr] = m.cone ? (float)t : (float)((t + mu * mu * t) * 2 * mu * mu / (double)m.impratio);
     }
   }
   // sites / sensors
@@ -1449,6 +1450,9 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   else if (fits(ShapeC::NQ, ShapeC::NV, ShapeC::NB, ShapeC::NU, ShapeC::NJ, ShapeC::NM, ShapeC::NH, ShapeC::NROW, ShapeC::DT, ShapeC::DV)) mo->shape = 2;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
+  if (m.cone && !(mo->shape == 2 && !m.paired && m.floor_is_plane && m.foot_prim == 0)) {
+    delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: compiled into the third shape's kernels (convex feet on a plane) only; the duck's shapes have pyramidal contact rows");
+  }
   {   // equality rows of the kernels: joint couplings inside one serial chain of a shape compiled with them
     m.neq = 0;
     for (int d = 0; d < MAXV; d++) m.dof_eqrow[d] = -1;

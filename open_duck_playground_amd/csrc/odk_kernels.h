@@ -77,6 +77,9 @@ struct Shape {
   // <equality><joint> rows (DevModel::neq) are compiled into this shape's kernels: the third shape (tests/assets/tail_biped*.xml) -- the
   // duck's shapes have no equality and do not pay for the code
   static constexpr bool EQ = (NV_ == 21);
+  // <option cone="elliptic"> (DevModel::cone) is compiled into the same shape's kernels: a contact's four row lanes hold normal | tangent 1 |
+  // tangent 2 | nothing instead of the four pyramid edges, and the cost of a contact is the cone's (odk_kernels.h "elliptic cones")
+  static constexpr bool ELL = (NV_ == 21);
   static constexpr int NVR = PAIRED ? 20 : NV_;    // reduced dofs
   static constexpr int NMR = PAIRED ? 145 : NM_;   // entries of the reduced tree layout
   static constexpr int NHR = PAIRED ? 170 : NH_;   // entries of the reduced virtual-tree layout
@@ -1706,6 +1709,67 @@ __device__ __noinline__ void hfield_prim_floor(float* L, const DevModel* __restr
 }
 
 // HF: 0 = plane floor, 1 = height-field floor under the duck's mesh feet, 2 = height-field floor under sphere / capsule feet
+// ---- elliptic cones (mjx solver / MuJoCo PrimalUpdateConstraint, HessianCone, PrimalEval as oracle/odk_oracle.c cone_eval restates them).
+// One contact = rows (normal, tangent 1, tangent 2) with Jaref x, D = (Dn, Dt, Dt), Dt = Dn impratio, friction mu, mu_r = mu / sqrt(impratio).
+// In the scaled space U = (mu_r x_n, mu x_1, mu x_2), N = U_0, T = |U_1..2|:  top zone (N >= mu_r T): no force;  bottom zone
+// (mu_r N + T <= 0): the three rows are plain quadratic rows;  middle zone: cost 0.5 Dm (N - mu_r T)^2, Dm = Dn / (mu_r^2 (1 + mu_r^2)).
+// A contact with Dn = 0 (not penetrating) has no rows: zone 0.
+struct ConeEv { float N, T, U1, U2, Dm, NmT; int zone; };
+__device__ __forceinline__ ConeEv cone_ev(float Dn, float mu, float mur, float xn, float x1, float x2) {
+  ConeEv e;
+  e.U1 = mu * x1; e.U2 = mu * x2; e.N = mur * xn;
+  e.T = __builtin_sqrtf(e.U1 * e.U1 + e.U2 * e.U2);
+  e.Dm = Dn / fmaxf(mur * mur * (1.0f + mur * mur), MINVAL_F);
+  e.NmT = e.N - mur * e.T;
+  const bool top = (e.N >= mur * e.T) || (e.T <= 0.0f && e.N >= 0.0f) || !(Dn > 0.0f);
+  const bool bot = (mur * e.N + e.T <= 0.0f) || (e.T <= 0.0f && e.N < 0.0f);
+  e.zone = top ? 0 : (bot ? 1 : 2);
+  return e;
+}
+// cost of the contact at x
+__device__ __forceinline__ float cone_cost(const ConeEv& e, float Dn, float Dt, float xn, float x1, float x2) {
+  return e.zone == 0 ? 0.0f : (e.zone == 1 ? 0.5f * (Dn * xn * xn + Dt * (x1 * x1 + x2 * x2)) : 0.5f * e.Dm * e.NmT * e.NmT);
+}
+// force of row s (0 normal, 1 / 2 tangents) at x
+__device__ __forceinline__ float cone_force(const ConeEv& e, float Dn, float Dt, float mu, float mur, float xn, float x1, float x2, int s) {
+  if (e.zone == 0 || s > 2) return 0.0f;
+  if (e.zone == 1) return s == 0 ? -Dn * xn : -Dt * (s == 1 ? x1 : x2);
+  const float fn = -e.Dm * e.NmT * mur;
+  return s == 0 ? fn : -fn / e.T * (s == 1 ? e.U1 : e.U2) * mu;
+}
+// row s of the contact's 3 x 3 block d^2 cost / d x^2
+__device__ __forceinline__ void cone_hess_row(const ConeEv& e, float Dn, float Dt, float mu, float mur, int s, float* C) {
+  C[0] = C[1] = C[2] = 0.0f;
+  if (e.zone == 0 || s > 2) return;
+  if (e.zone == 1) { C[s] = s == 0 ? Dn : Dt; return; }
+  const float iT = 1.0f / e.T;
+  const float g[3] = {1.0f, -mur * e.U1 * iT, -mur * e.U2 * iT}, Sc[3] = {mur, mu, mu}, U[3] = {0.0f, e.U1, e.U2};
+#pragma unroll
+  for (int b = 0; b < 3; b++) {
+    float h = e.Dm * g[s] * g[b];
+    if (s > 0 && b > 0) h -= e.Dm * e.NmT * mur * ((s == b ? iT : 0.0f) - U[s] * U[b] * iT * iT * iT);
+    C[b] = Sc[s] * h * Sc[b];
+  }
+}
+// cost, first and second derivative along x + alpha v
+__device__ __forceinline__ void cone_line(float Dn, float Dt, float mu, float mur, const float* x, const float* v, float& cost, float& d0, float& d1) {
+  const ConeEv e = cone_ev(Dn, mu, mur, x[0], x[1], x[2]);
+  cost = 0.0f; d0 = 0.0f; d1 = 0.0f;
+  if (e.zone == 1) {
+    cost = 0.5f * (Dn * x[0] * x[0] + Dt * (x[1] * x[1] + x[2] * x[2]));
+    d0 = Dn * x[0] * v[0] + Dt * (x[1] * v[1] + x[2] * v[2]);
+    d1 = Dn * v[0] * v[0] + Dt * (v[1] * v[1] + v[2] * v[2]);
+  } else if (e.zone == 2) {
+    const float V0 = v[0] * mur, V1 = v[1] * mu, V2 = v[2] * mu;
+    const float UV = e.U1 * V1 + e.U2 * V2, VV = V1 * V1 + V2 * V2, iT = 1.0f / e.T;
+    const float T1 = UV * iT, T2 = VV * iT - UV * UV * iT * iT * iT;
+    const float g1 = V0 - mur * T1;
+    cost = 0.5f * e.Dm * e.NmT * e.NmT;
+    d0 = e.Dm * e.NmT * g1;
+    d1 = e.Dm * (g1 * g1 - e.NmT * mur * T2);
+  }
+}
+
 template <class S, int G, int HF, bool PRE = false>
 __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevModel* __restrict__ m, const float* __restrict__ hfield, const Statics<S, G>& st, int lane, int flags, const HotSt& hot = HotSt()) {
   // RT: the packed reduced entries (DevModel::R_ent) in LDS, one copy per workgroup (load_shared): every substep reads them
@@ -2370,6 +2434,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   // are never read again: the solver gates on D > 0 and on the same wave-uniform flag)
   const bool ff_rows = __builtin_amdgcn_ballot_w64(fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0.0f) != 0;
   const bool prim_feet = !HF && m->foot_prim != 0;   // sphere / capsule feet: per-contact frames in S_FR (prim_contacts)
+  const bool ell = S::ELL && m->cone != 0;            // (wave-uniform) elliptic friction cones
   for (int rc = lane; rc < S::NCROW; rc += G) {
     const int r = r0c + rc, c = rc >> 2, s = rc & 3, pair = c >> 2;
     if (rc >= 32 && !ff_rows) { ED[r] = 0.0f; AREF[r] = 0.0f; continue; }
@@ -2379,7 +2444,14 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     // foot-foot frame: left in S_VF by the SAT routine; height-field floor: one frame per contact left in S_FR by P7
     const float* fr = (pair == 2 && dist < 0) ? SCR + S::S_VF : ((pair < 2 && (HF || prim_feet)) ? SCR + S::S_FR + 9 * c : CT + 33);
     const int td = 3 * (1 + (s >> 1));
-    const float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
+    float dir[3] = {fr[0] + fs * fr[td], fr[1] + fs * fr[td + 1], fr[2] + fs * fr[td + 2]};
+    if constexpr (S::ELL) {
+      if (ell) {   // elliptic cones: the row lanes of a contact are the frame's axes (normal, tangent 1, tangent 2); the fourth lane has no row
+        const float on3 = s < 3 ? 1.0f : 0.0f;
+        const int ax = s < 3 ? 3 * s : 0;
+        dir[0] = on3 * fr[ax]; dir[1] = on3 * fr[ax + 1]; dir[2] = on3 * fr[ax + 2];
+      }
+    }
     const float rr[3] = {CR[3 * c], CR[3 * c + 1], CR[3 * c + 2]};
     float ang[3];
     cross3(ang, rr, dir);
@@ -2397,6 +2469,16 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         for (int k = 0; k < 6; k++) vel -= wr[k] * CVEL[k * NB + b1];
       }
       row_params(CT + 6 + 9 * pair, dist, CT[3 + pair], vel, D, aref);
+      if constexpr (S::ELL) {
+        if (ell) {
+          // (mjx constraint._efc_contact_elliptic as the oracle restates it: every row takes the NORMAL row's impedance -- from the contact
+          // distance, with the two bodies' translational weights, which is what pair_invweight holds for a model with cone = 1 --; the
+          // tangents have no position term and the regulariser R_t = R_n / impratio)
+          if (s == 0) { /* D, aref as computed */ }
+          else if (s < 3) { float Dn, an; row_params(CT + 6 + 9 * pair, dist, CT[3 + pair], 0.0f, Dn, an); D = Dn * m->impratio; aref = -CT[6 + 9 * pair + 1] * vel; }
+          else { D = 0.0f; aref = 0.0f; }
+        }
+      }
     }
     ED[r] = D;
     AREF[r] = aref;
@@ -2518,7 +2600,27 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     if (D > 0) {
       const float ar = AREF[r];
       cjar[t] = contact_jx(rcl, SCR + S::S_VF) - ar; cjv[t] = contact_jx(rcl, SCR + S::S_VF2) - ar;
-      cost_s += quad_cost(D, cjar[t], fo); cost_w += quad_cost(D, cjv[t], fo);
+      if (!ell) { cost_s += quad_cost(D, cjar[t], fo); cost_w += quad_cost(D, cjv[t], fo); }
+    }
+  }
+  // elliptic cones: the four row lanes of a contact are a DPP quad -- every lane of the quad gets the contact's three Jaref (and the normal
+  // row's D) by quad_perm broadcasts (uniform control flow), lane 0 of the quad counts the contact
+  const float ell_mur = ell ? __builtin_amdgcn_rsqf(m->impratio) : 0.0f;     // mu_r = mu sqrt(R_t / R_n) = mu / sqrt(impratio); times mu below
+  auto quad3 = [](float v, float* o) { o[0] = ODK_DPP(v, 0x00, 0xF); o[1] = ODK_DPP(v, 0x55, 0xF); o[2] = ODK_DPP(v, 0xAA, 0xF); };
+  if constexpr (S::ELL) {
+    if (ell) {
+#pragma unroll
+      for (int t = 0; t < NCL; t++) {
+        if (t * G >= 32 && !any_ff) continue;
+        const int rc = lane + t * G;
+        float xs[3], xw[3];
+        quad3(cjar[t], xs); quad3(cjv[t], xw);
+        const float Dn = ODK_DPP(cD[t], 0x00, 0xF), Dt = Dn * m->impratio;
+        const float mu = CT[(rc < S::NCROW ? rc : 0) >> 4], mur = mu * ell_mur;
+        const float one = ((rc & 3) == 0 && rc < S::NCROW) ? 1.0f : 0.0f;
+        const ConeEv es = cone_ev(Dn, mu, mur, xs[0], xs[1], xs[2]), ew = cone_ev(Dn, mu, mur, xw[0], xw[1], xw[2]);
+        cost_s += one * cone_cost(es, Dn, Dt, xs[0], xs[1], xs[2]); cost_w += one * cone_cost(ew, Dn, Dt, xw[0], xw[1], xw[2]);
+      }
     }
   }
   float gauss_w;
@@ -2559,8 +2661,26 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       for (int k = 0; k < 6; k++) w[k] = W[6 * rcl + k];
       const float D = cD[t], jar = cjar[t];
       const float act = (on && D > 0 && jar < 0) ? D : 0.0f;
-      const float fr = -act * jar;
+      float fr = -act * jar;
       float v[27];
+      float u[6];      // (J^T of this row's line of the contact's Hessian block: act w for a pyramid row)
+#pragma unroll
+      for (int k = 0; k < 6; k++) u[k] = act * w[k];
+      if constexpr (S::ELL) {
+        if (ell) {   // this lane's row s of its contact: force f_s, and u = sum_b C[s][b] w_b over the contact's three wrenches (LDS)
+          float xs[3], C[3];
+          quad3(jar, xs);
+          const float Dn = ODK_DPP(D, 0x00, 0xF), Dt = Dn * m->impratio;
+          const float mu = CT[rcl >> 4], mur = mu * ell_mur;
+          const int sr = on ? (rcl & 3) : 3;
+          const ConeEv e = cone_ev(Dn, mu, mur, xs[0], xs[1], xs[2]);
+          fr = cone_force(e, Dn, Dt, mu, mur, xs[0], xs[1], xs[2], sr);
+          cone_hess_row(e, Dn, Dt, mu, mur, sr, C);
+          const float* w0 = W + 6 * (rcl & ~3);
+#pragma unroll
+          for (int k = 0; k < 6; k++) u[k] = C[0] * w0[k] + C[1] * w0[6 + k] + C[2] * w0[12 + k];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 6; k++) v[k] = fr * w[k];
       {
@@ -2569,7 +2689,10 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         for (int a = 0; a < 6; a++) {
           const float aw = act * w[a];
 #pragma unroll
-          for (int b2 = a; b2 < 6; b2++) v[q++] = aw * w[b2];
+          for (int b2 = a; b2 < 6; b2++) {
+            if constexpr (S::ELL) v[q++] = ell ? w[a] * u[b2] : aw * w[b2];      // (the pyramid rows keep their rounding: (D w_a) w_b)
+            else v[q++] = aw * w[b2];
+          }
         }
       }
 #pragma unroll
@@ -2840,6 +2963,20 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     if (on) JV[r0c + rc] = cjv[t];  // debug image only
   }
   ODK_PROF(15);
+  // elliptic cones: the contact's three Jaref and J search in every lane of its quad, once for the whole line search
+  float ls_x[NCL][3], ls_v[NCL][3], ls_Dn[NCL], ls_mu[NCL], ls_one[NCL];
+  if constexpr (S::ELL) {
+    if (ell) {
+#pragma unroll
+      for (int t = 0; t < NCL; t++) {
+        const int rc = lane + t * G;
+        quad3(cjar[t], ls_x[t]); quad3(cjv[t], ls_v[t]);
+        ls_Dn[t] = ODK_DPP(cD[t], 0x00, 0xF);
+        ls_mu[t] = CT[(rc < S::NCROW ? rc : 0) >> 4];
+        ls_one[t] = ((rc & 3) == 0 && rc < S::NCROW) ? 1.0f : 0.0f;
+      }
+    }
+  }
   const float gtol = m->tolerance * m->ls_tolerance * sqrtf(sn) * m->meaninertia * (float)(NV > 1 ? NV : 1);
   // Three step sizes at once.  The bracketing iterations only steer on the first and second derivative along the search, so
   // they evaluate those alone (COST = false: two sums per step size); the costs that pick the final step -- at lo, hi and 0 --
@@ -2884,6 +3021,20 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
 #pragma unroll
     for (int t = 0; t < NCL; t++) {
       if (t * G >= 32 && !any_ff) continue;
+      if constexpr (S::ELL) {
+        if (ell) {   // the contact's exact cost / derivatives at each step size, counted by lane 0 of its quad.  The sums the callers form are
+                     // d0 = 2 al t2 + t1 and d1 = 2 t2: a term (d0c, d1c) enters as t1 += d0c - al d1c, t2 += d1c / 2
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const float xx[3] = {ls_x[t][0] + al[a] * ls_v[t][0], ls_x[t][1] + al[a] * ls_v[t][1], ls_x[t][2] + al[a] * ls_v[t][2]};
+            float cc, d0c, d1c;
+            cone_line(ls_Dn[t], ls_Dn[t] * m->impratio, ls_mu[t], ls_mu[t] * ell_mur, xx, ls_v[t], cc, d0c, d1c);
+            if constexpr (COST) acc[3 * a] = fmaf(ls_one[t], cc, acc[3 * a]);
+            else { acc[3 * a + 1] = fmaf(ls_one[t], d0c - al[a] * d1c, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(ls_one[t], 0.5f * d1c, acc[3 * a + 2]); }
+          }
+          continue;
+        }
+      }
       const float D = cD[t], jar = cjar[t], jv = cjv[t];   // inactive rows: D = 0
       const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
 #pragma unroll

@@ -157,6 +157,7 @@ struct DevModel {
   // hinges of ONE serial chain -- its Hessian term -D c then falls on an entry the chain's block already has -- or one hinge held at
   // poly[0].  At most EQ_MAX rows, a dof in at most one.  eq_key: low ten bits (i | j << 5) of the packed reduced entry the coupling's
   // off-diagonal term lands on (-1: single-joint row); dof_eqrow: the row a dof takes part in (-1: none).
+  int cone;      // <option cone>: 0 pyramidal, 1 elliptic (shapes with S::ELL; odk_kernels.h "elliptic cones")
   int neq, eq_dof1[EQ_MAX], eq_dof2[EQ_MAX], eq_qadr1[EQ_MAX], eq_qadr2[EQ_MAX], eq_key[EQ_MAX], dof_eqrow[MAXV];
   float eq_poly[EQ_MAX][5], eq_imp[EQ_MAX][9], eq_invweight[EQ_MAX];
 };

@@ -828,7 +828,7 @@ def test_differential_sweep(torch_cuda, oracle_mod, parity_log, task, lanes):
 
 
 
-def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, tag, eq_active=None):
+def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, tag, eq_active=None, cone=False):
     """(body of the two tests below)  SURVEY 8(f).3 / reference README.md:74-85 ("adding a robot"): tests/assets/tail_biped.xml -- a biped with a five-link tail,
     written for this test: 21 dofs, 15 position actuators, 19 bodies, box feet, its own masses / lengths / axes / gains -- compiled by
     mjcf.py, its lane tables built by tables.py (nothing by hand), loaded as the kernels' third Shape and run through the PHYSICS
@@ -879,6 +879,7 @@ def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, 
     W = dict(xpos=0, M=0, qfs=0, qas=0, dist=0, D=0, aref=0, qacc=0, qpos=0, qvel=0, sens=0, force=0)
     prng = np.random.default_rng(5)
     n_tie = n_contact = 0
+    W_zone = {}
     for e in range(n):
         d = oracle_mod.OracleData(om)
         d["qpos"][:nq] = qpos[e]; d["qvel"][:nv] = qvel[e]; d["qacc_warmstart"][:nv] = warm[e]; d["ctrl"][: model.nu] = ctrl[e]
@@ -901,6 +902,17 @@ def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, 
         assert d.i("ne") == ne_rows
         live = (np.abs(d.J()).sum(axis=1) > 0)[ne_rows:]
         D_g, aref_g = L[o["efc_D"]: o["efc_D"] + nefc], L[o["efc_aref"]: o["efc_aref"] + nefc]
+        if cone:      # elliptic: the oracle has three rows per contact, the kernels keep four row lanes per contact (normal, two tangents, an empty one)
+            r0 = nefc - 3 * 12
+            fo = np.array(d["efc_force"][ne_rows + r0: ne_rows + nefc]).reshape(12, 3)      # which zone the solver left each penetrating contact in
+            for c in range(12):
+                if cd_o[c] < 0:
+                    ft = np.hypot(fo[c, 1], fo[c, 2])
+                    zone = "top" if fo[c, 0] == 0 and ft == 0 else ("middle" if ft > 0 and abs(ft - float(d["contact_friction"][c]) * fo[c, 0]) < 1e-9 * max(ft, 1.0) else "bottom")
+                    W_zone[zone] = W_zone.get(zone, 0) + 1
+            take = np.concatenate([np.arange(r0), r0 + np.array([4 * c + s_ for c in range(12) for s_ in range(3)])])
+            D_g, aref_g = L[o["efc_D"]: o["efc_D"] + r0 + 48][take], L[o["efc_aref"]: o["efc_aref"] + r0 + 48][take]
+            assert not (L[o["efc_D"] + r0 + 3: o["efc_D"] + r0 + 48: 4] != 0).any()
         assert ((D_g > 0) == live)[nfl:].all(), f"env {e}: active row sets differ"
         W["D"] = max(W["D"], _rel(D_g[live], d["efc_D"][ne_rows: ne_rows + nefc][live], 1e-6).max())
         W["aref"] = max(W["aref"], _rel(aref_g[live], d["efc_aref"][ne_rows: ne_rows + nefc][live], 1.0).max())
@@ -931,7 +943,9 @@ def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, 
     with pytest.raises(engine.OdkError):
         b.reset(seed=1)
     b.close()
-    print(tag, {k: float(f"{v:.3g}") for k, v in W.items()}, "ties", n_tie, "ten substeps", T10, "ill", n_ill, "of", n)
+    print(tag, {k: float(f"{v:.3g}") for k, v in W.items()}, "ties", n_tie, "ten substeps", T10, "ill", n_ill, "of", n, "cone zones", W_zone)
+    if cone:      # the states must exercise the cone itself (sliding contacts: measured 58), the plain quadratic zone (sticking ones: 13) and separating contacts (11)
+        assert W_zone.get("middle", 0) >= 20 and W_zone.get("bottom", 0) >= 8 and W_zone.get("top", 0) >= 4, W_zone
     parity_log.check(f"{tag}/one_mjx_step", dict(STAGE_BOUNDS, force=2e-4, tie_fraction=0.15), tie_fraction=n_tie / n, **W)
     parity_log.check(f"{tag}/ten_substeps", dict(TEN_BOUNDS, ill_fraction=0.5), ill_fraction=n_ill / n, **T10)
     return W, T10
@@ -968,6 +982,34 @@ def test_equality_joint_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log):
         b.close()
     a2 = int(base.a["jnt_qposadr"][base.joint_id("tail_yaw_2")]); ak = int(base.a["jnt_qposadr"][base.joint_id("left_ankle")])
     assert abs(out[0][a2] - out[1][a2]) > 0.02 and abs(out[0][ak] - out[1][ak]) > 0.01, (out[0][a2], out[1][a2], out[0][ak], out[1][ak])
+
+
+def test_elliptic_cones_in_the_kernels(torch_cuda, oracle_mod, parity_log):
+    """SURVEY 8(f).3, `<option cone="elliptic">` (reference README.md:74-85): tests/assets/tail_biped_elliptic.xml (impratio 3) through the
+    physics kernels -- a contact's four row lanes hold normal | tangent | tangent | nothing, the cost of a contact is the cone's three-zone
+    cost, its Hessian block the cone's 3 x 3, the line search evaluates the cone exactly at every step size (odk_kernels.h "elliptic
+    cones") -- against the float64 oracle, whose cone forces are pinned to the documented cone program (tests/test_oracle_elliptic.py):
+    every stage of one mjx.step, the state after one step and after ten, at the duck's bounds.  And the cone must MATTER: the same
+    states stepped with pyramidal rows end up elsewhere."""
+    W, T10 = _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped_elliptic.xml", "tail_biped_elliptic", cone=True)
+    import os
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model
+    from conftest import ROOT
+    torch = torch_cuda
+    base = Model.from_xml(os.path.join(ROOT, "tests", "assets", "tail_biped_elliptic.xml"), sim_dt=0.002)
+    assert int(np.asarray(base.a["opt_cone"]).reshape(-1)[0]) == 1
+    out = []
+    for cone in (1, 0):
+        m = Model({**base.a, "opt_cone": np.asarray([cone], np.int32)})
+        b = engine.Batch(m, 4)
+        q = np.tile(np.asarray(m.a["key_qpos"], np.float64), (4, 1))
+        v = np.zeros((4, m.nv)); v[:, 0] = 0.8; v[:, 1] = -0.5          # sliding on the floor: friction decides where it ends up
+        b.set_state(q, v, np.zeros((4, m.nv)))
+        b.physics_step(torch.tensor(np.tile(np.asarray(m.a["key_ctrl"]), (4, 1)), dtype=torch.float32, device="cuda"), 50)
+        out.append(b.get_state()[0][0].copy())
+        b.close()
+    assert np.isfinite(out[0]).all() and np.abs(out[0][:2] - out[1][:2]).max() > 1e-4, (out[0][:3], out[1][:3])
 
 
 @pytest.mark.parametrize("kinds", [("sphere", "sphere"), ("capsule", "capsule"), ("capsule", "sphere")], ids="-".join)

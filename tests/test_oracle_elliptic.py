@@ -62,14 +62,17 @@ def _probe(O, om, d, qacc):
     return float(cost[0]), g, H.reshape(nv, nv)
 
 
-def test_compiler_option_and_loader_refusal(robot):
+def test_compiler_option_and_which_shapes_take_it(robot):
     from open_duck_playground_amd import engine
     m, om = robot
     assert int(m.a["opt_cone"][0]) == 1 and float(m.a["opt_impratio"][0]) == 3.0 and om.L.lib.odko_model_int(om.h, b"cone") == 1
-    with pytest.raises(engine.OdkError, match="elliptic"):
-        engine.model_reduction(m)
+    assert engine.model_reduction(m)["nvr"] == 21           # the third shape's kernels have the cone (tests/test_gpu_parity.py::test_elliptic_cones_in_the_kernels)
     plain = Model.from_xml(os.path.join(ASSETS, "tail_biped.xml"))
     assert int(plain.a["opt_cone"][0]) == 0
+    from open_duck_playground_amd.model import load_task_model
+    duck = load_task_model("flat_terrain")                  # the duck's shapes keep their pyramidal rows and refuse the option by name
+    with pytest.raises(engine.OdkError, match="elliptic"):
+        engine.model_reduction(Model({**duck.a, "opt_cone": np.array([1], np.int32)}))
 
 
 def test_rows_of_an_elliptic_contact(robot, oracle_mod):
