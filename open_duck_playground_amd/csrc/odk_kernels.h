@@ -65,7 +65,7 @@ struct EnvCfg {  // device copy of odk_env_config
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (floats), per environment.  Component-major (SoA) arrays: X[k * N + item].
-template <int NQ_, int NV_, int NB_, int NU_, int NJ_, int NM_, int NH_, int NROW_, int DT_, int DV_>
+template <int NQ_, int NV_, int NB_, int NU_, int NJ_, int NM_, int NH_, int NROW_, int DT_, int DV_, bool CONE_ = false>
 struct Shape {
   static constexpr int NQ = NQ_, NV = NV_, NB = NB_, NU = NU_, NJ = NJ_, NM = NM_, NH = NH_, NROW = NROW_;
   static constexpr int DT = DT_;    // max dof depth, kinematic tree
@@ -79,7 +79,7 @@ struct Shape {
   static constexpr bool EQ = (NV_ == 21);
   // <option cone="elliptic"> (DevModel::cone) is compiled into the same shape's kernels: a contact's four row lanes hold normal | tangent 1 |
   // tangent 2 | nothing instead of the four pyramid edges, and the cost of a contact is the cone's (odk_kernels.h "elliptic cones")
-  static constexpr bool ELL = (NV_ == 21);
+  static constexpr bool ELL = (NV_ == 21) || CONE_;    // (the duck's shapes: their own instantiations with CONE_ = true, launched for models with cone = 1 only)
   static constexpr int NVR = PAIRED ? 20 : NV_;    // reduced dofs
   static constexpr int NMR = PAIRED ? 145 : NM_;   // entries of the reduced tree layout
   static constexpr int NHR = PAIRED ? 170 : NH_;   // entries of the reduced virtual-tree layout

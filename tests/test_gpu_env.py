@@ -70,11 +70,14 @@ def _ill_resets(envs, model, nobs):
 RESET_BOUNDS = dict(obs=1e-5, acc=1e-3, qpos=1e-6, qvel=1e-6)   # measured: 3.5e-6, 3.2e-4, 1.8e-7, 2e-9
 
 
-def _mk(oracle_mod, task, n, cfg_edit=None, standing=False, dr_fields=None):
+def _mk(oracle_mod, task, n, cfg_edit=None, standing=False, dr_fields=None, model_edit=None):
     import torch
     from open_duck_playground_amd import engine, randomize
     from open_duck_playground_amd.model import load_task_model
     model = load_task_model(task)
+    if model_edit:      # the task's model with some arrays replaced (e.g. opt_cone)
+        from open_duck_playground_amd.model import Model
+        model = Model({**model.a, **model_edit})
     cfg = engine.default_config(standing)
     if cfg_edit:
         cfg_edit(cfg)
@@ -441,6 +444,30 @@ def test_step_sequence_with_resync(oracle_mod, parity_log, task):
         assert int(I["imitation_i"][i]) == int(e.ints("imitation_i")[0])
     b.close()
     parity_log.check(f"env_step/{task}", {**ENV_BOUNDS, **_set_aside(task)}, **_errs(W))
+
+
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+def test_step_sequence_of_the_duck_with_elliptic_cones(oracle_mod, parity_log, task):
+    """`<option cone="elliptic">` on the duck itself: the model's `opt_cone` switched to 1 (impratio as in the file: 1), the env
+    kernels' own instantiation with the cone code (`ShapeAE` / `ShapeBE`, odk_engine.hip) against the oracle env with the same model: reset, then
+    40 env steps with random actions, physics re-synchronised before every step as in the test above, at the same bounds."""
+    def edit(cfg):
+        cfg.episode_length = 25
+    torch, model, b, envs, keep = _mk(oracle_mod, task, 32, edit, model_edit=dict(opt_cone=np.array([1], np.int32)))
+    n = len(envs)
+    b.reset(seed=13)
+    for i, e in enumerate(envs):
+        e.reset(13, i)
+    rng = np.random.default_rng(2)
+    W = _new_W()
+    W["reset_ill"] = _ill_resets(envs, model, 101)
+    for t in range(40):
+        _resync(b, envs, model)
+        act = rng.uniform(-1, 1, (n, 14)).astype(np.float32)
+        _step_and_compare(torch, b, envs, act, 101, 212, t, W)
+    assert W["n_done"] > 0 and W["n_trunc"] > 0
+    b.close()
+    parity_log.check(f"env_step_elliptic/{task}", {**ENV_BOUNDS, **_set_aside(task)}, **_errs(W))
 
 
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])

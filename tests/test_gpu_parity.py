@@ -503,6 +503,62 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
     parity_log.check(f"ten_substeps/{task}", dict(TEN_BOUNDS, ill_fraction=0.55 if "rough" in task else 0.45), qpos=wq, qvel=wv, qpos_normwise=wqn, qvel_normwise=wvn, ill_fraction=n_ill / n)
 
 
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+def test_the_duck_with_elliptic_cones(torch_cuda, oracle_mod, parity_log, task):
+    """`<option cone="elliptic">` on the duck itself: opt_cone = 1 (impratio 1, as the file has it), the physics kernels of the duck's shapes
+    with the cone code (`ShapeAE` / `ShapeBE`) against the float64 oracle: the state after one mjx.step and after ten, at the duck's bounds;
+    the model with 64 lanes per env is refused (the cone kernels run 32)."""
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model, load_task_model
+    torch = torch_cuda
+    model = load_task_model(task)
+    model = Model({**model.a, "opt_cone": np.array([1], np.int32)})
+    om = oracle_mod.OracleModel(model.blob())
+    assert om.L.lib.odko_model_int(om.h, b"cone") == 1
+    n = 128
+    rng = np.random.default_rng(23)
+    qpos, qvel = _random_states(model, n, rng, airborne_frac=0.2)
+    warm = rng.normal(0, 3.0, (n, model.nv))
+    ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.3, 0.3, (n, 14))
+    ct = torch.tensor(ctrl, dtype=torch.float32, device="cuda")
+    b = engine.Batch(model, n)
+    prng = np.random.default_rng(24)
+    W = dict(qpos=0.0, qvel=0.0, qpos_normwise=0.0, qvel_normwise=0.0); T = dict(qpos=0.0, qvel=0.0)
+    n_ill = {1: 0, 10: 0}
+    for nsub, scale in ((1, 1.0), (10, 0.3)):
+        v0 = scale * qvel; w0 = warm if nsub == 1 else np.zeros_like(warm)
+        b.set_state(qpos, v0, w0)
+        b.physics_step(ct, nsub)
+        gq, gv, _ = b.get_state()
+        for e in range(n):
+            d = _oracle_step(oracle_mod, om, qpos[e], v0[e], w0[e], ctrl[e], nsub)
+            q1, v1 = np.array(d["qpos"][: om.nq]), np.array(d["qvel"][: om.nv])
+            ill = False
+            if nsub == 1:           # one step: a contact-set tie (the helper of the stage tests)
+                d0 = oracle_mod.OracleData(om)
+                d0["qpos"][: om.nq] = qpos[e]; d0["qvel"][: om.nv] = v0[e]; d0["ctrl"][:14] = ctrl[e]; d0.forward()
+                ill = _contact_tie(oracle_mod, om, qpos[e], v0[e], ctrl[e], prng, _contacts(d0))
+            for _ in range(0 if nsub == 1 else 6):      # ten: the oracle's own sensitivity to 1e-6 of its input (a contact tie, a zone or a bracket flipping)
+                qp = qpos[e] + 1e-6 * prng.standard_normal(om.nq) * np.maximum(np.abs(qpos[e]), 0.1); vp = v0[e] + 5e-6 * prng.standard_normal(om.nv) * np.maximum(np.abs(v0[e]), 1.0)
+                dp = _oracle_step(oracle_mod, om, qp, vp, w0[e], ctrl[e], nsub)
+                ill = ill or _rel(dp["qpos"][: om.nq], q1, 1e-2).max() > 0.5 * TEN_BOUNDS["qpos"] or _rel(dp["qvel"][: om.nv], v1, 1.0).max() > 0.5 * TEN_BOUNDS["qvel"]
+            if ill:
+                n_ill[nsub] += 1
+                continue
+            if nsub == 1:
+                W["qpos"] = max(W["qpos"], _rel(gq[e], q1, 1e-2).max()); W["qvel"] = max(W["qvel"], _rel(gv[e], v1, 1.0).max())
+                W["qpos_normwise"] = max(W["qpos_normwise"], _nw(gq[e], q1)); W["qvel_normwise"] = max(W["qvel_normwise"], _nw(gv[e], v1))
+            else:
+                T["qpos"] = max(T["qpos"], _rel(gq[e], q1, 1e-2).max()); T["qvel"] = max(T["qvel"], _rel(gv[e], v1, 1.0).max())
+    b.close()
+    print(task, "elliptic: one step", W, "ten substeps", T, "ill", n_ill, "of", n)
+    parity_log.check(f"duck_elliptic/{task}/one_mjx_step", dict({k: STAGE_BOUNDS[k] for k in W}, ill_fraction=0.3), ill_fraction=n_ill[1] / n, **W)
+    parity_log.check(f"duck_elliptic/{task}/ten_substeps", dict(TEN_BOUNDS, ill_fraction=0.55), ill_fraction=n_ill[10] / n, **T)
+    cfg = engine.default_config(); cfg.lanes_per_env = 64
+    with pytest.raises(engine.OdkError, match="32 lanes"):
+        engine.Batch(model, 8, cfg)
+
+
 @pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32)])
 def test_foot_foot_contacts(torch_cuda, oracle_mod, parity_log, task, lanes):
     """Feet pressed into each other (hip rolls inwards, robot lifted off the floor): the foot-foot SAT manifold,
