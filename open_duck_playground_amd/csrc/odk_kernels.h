@@ -1715,11 +1715,13 @@ __device__ __noinline__ void hfield_prim_floor(float* L, const DevModel* __restr
 // (mu_r N + T <= 0): the three rows are plain quadratic rows;  middle zone: cost 0.5 Dm (N - mu_r T)^2, Dm = Dn / (mu_r^2 (1 + mu_r^2)).
 // A contact with Dn = 0 (not penetrating) has no rows: zone 0.
 struct ConeEv { float N, T, U1, U2, Dm, NmT; int zone; };
-__device__ __forceinline__ ConeEv cone_ev(float Dn, float mu, float mur, float xn, float x1, float x2) {
+// Dm = Dn / (mu_r^2 (1 + mu_r^2)): constant per contact and forward pass, formed once by the caller (cone_dm)
+__device__ __forceinline__ float cone_dm(float Dn, float mur) { return Dn * __builtin_amdgcn_rcpf(fmaxf(mur * mur * (1.0f + mur * mur), MINVAL_F)); }
+__device__ __forceinline__ ConeEv cone_ev(float Dn, float Dm, float mu, float mur, float xn, float x1, float x2) {
   ConeEv e;
   e.U1 = mu * x1; e.U2 = mu * x2; e.N = mur * xn;
-  e.T = __builtin_sqrtf(e.U1 * e.U1 + e.U2 * e.U2);
-  e.Dm = Dn / fmaxf(mur * mur * (1.0f + mur * mur), MINVAL_F);
+  e.T = __builtin_amdgcn_sqrtf(e.U1 * e.U1 + e.U2 * e.U2);      // v_sqrt_f32 (1 ulp): the zone tests below compare against it as it is
+  e.Dm = Dm;
   e.NmT = e.N - mur * e.T;
   const bool top = (e.N >= mur * e.T) || (e.T <= 0.0f && e.N >= 0.0f) || !(Dn > 0.0f);
   const bool bot = (mur * e.N + e.T <= 0.0f) || (e.T <= 0.0f && e.N < 0.0f);
@@ -1735,39 +1737,40 @@ __device__ __forceinline__ float cone_force(const ConeEv& e, float Dn, float Dt,
   if (e.zone == 0 || s > 2) return 0.0f;
   if (e.zone == 1) return s == 0 ? -Dn * xn : -Dt * (s == 1 ? x1 : x2);
   const float fn = -e.Dm * e.NmT * mur;
-  return s == 0 ? fn : -fn / e.T * (s == 1 ? e.U1 : e.U2) * mu;
+  return s == 0 ? fn : -fn * __builtin_amdgcn_rcpf(e.T) * (s == 1 ? e.U1 : e.U2) * mu;
 }
 // row s of the contact's 3 x 3 block d^2 cost / d x^2
 __device__ __forceinline__ void cone_hess_row(const ConeEv& e, float Dn, float Dt, float mu, float mur, int s, float* C) {
   C[0] = C[1] = C[2] = 0.0f;
   if (e.zone == 0 || s > 2) return;
   if (e.zone == 1) { C[s] = s == 0 ? Dn : Dt; return; }
-  const float iT = 1.0f / e.T;
-  const float g[3] = {1.0f, -mur * e.U1 * iT, -mur * e.U2 * iT}, Sc[3] = {mur, mu, mu}, U[3] = {0.0f, e.U1, e.U2};
+  const float iT = __builtin_amdgcn_rcpf(e.T);
+  const float g[3] = {1.0f, -mur * e.U1 * iT, -mur * e.U2 * iT}, Sc[3] = {mur, mu, mu};
+  // I_t / T - U_t U_t^T / T^3 = [U2^2, -U1 U2; -U1 U2, U1^2] / T^3: written without the difference; this lane's row by selects
+  const float i3 = iT * iT * iT, p11 = e.U2 * e.U2 * i3, p12 = -e.U1 * e.U2 * i3, p22 = e.U1 * e.U1 * i3;
+  const float P[3] = {0.0f, s == 1 ? p11 : (s == 2 ? p12 : 0.0f), s == 1 ? p12 : (s == 2 ? p22 : 0.0f)};
+  const float gs = s == 0 ? g[0] : (s == 1 ? g[1] : g[2]), Ss = s == 0 ? mur : mu;
 #pragma unroll
   for (int b = 0; b < 3; b++) {
-    float h = e.Dm * g[s] * g[b];
-    if (s > 0 && b > 0) h -= e.Dm * e.NmT * mur * ((s == b ? iT : 0.0f) - U[s] * U[b] * iT * iT * iT);
-    C[b] = Sc[s] * h * Sc[b];
+    const float h = e.Dm * gs * g[b] - e.Dm * e.NmT * mur * P[b];
+    C[b] = Ss * h * Sc[b];
   }
 }
-// cost, first and second derivative along x + alpha v
-__device__ __forceinline__ void cone_line(float Dn, float Dt, float mu, float mur, const float* x, const float* v, float& cost, float& d0, float& d1) {
-  const ConeEv e = cone_ev(Dn, mu, mur, x[0], x[1], x[2]);
-  cost = 0.0f; d0 = 0.0f; d1 = 0.0f;
-  if (e.zone == 1) {
-    cost = 0.5f * (Dn * x[0] * x[0] + Dt * (x[1] * x[1] + x[2] * x[2]));
-    d0 = Dn * x[0] * v[0] + Dt * (x[1] * v[1] + x[2] * v[2]);
-    d1 = Dn * v[0] * v[0] + Dt * (v[1] * v[1] + v[2] * v[2]);
-  } else if (e.zone == 2) {
-    const float V0 = v[0] * mur, V1 = v[1] * mu, V2 = v[2] * mu;
-    const float UV = e.U1 * V1 + e.U2 * V2, VV = V1 * V1 + V2 * V2, iT = 1.0f / e.T;
-    const float T1 = UV * iT, T2 = VV * iT - UV * UV * iT * iT * iT;
-    const float g1 = V0 - mur * T1;
-    cost = 0.5f * e.Dm * e.NmT * e.NmT;
-    d0 = e.Dm * e.NmT * g1;
-    d1 = e.Dm * (g1 * g1 - e.NmT * mur * T2);
-  }
+// cost, first and second derivative along x + alpha v (branch-free: the three zones as selects)
+__device__ __forceinline__ void cone_line(float Dn, float Dt, float Dm, float mu, float mur, const float* x, const float* v, float& cost, float& d0, float& d1) {
+  const ConeEv e = cone_ev(Dn, Dm, mu, mur, x[0], x[1], x[2]);
+  const float c1 = 0.5f * (Dn * x[0] * x[0] + Dt * (x[1] * x[1] + x[2] * x[2]));
+  const float a1 = Dn * x[0] * v[0] + Dt * (x[1] * v[1] + x[2] * v[2]);
+  const float b1 = Dn * v[0] * v[0] + Dt * (v[1] * v[1] + v[2] * v[2]);
+  const float V0 = v[0] * mur, V1 = v[1] * mu, V2 = v[2] * mu;
+  const float UV = e.U1 * V1 + e.U2 * V2, iT = __builtin_amdgcn_rcpf(e.zone == 2 ? e.T : 1.0f);
+  const float cr = e.U1 * V2 - e.U2 * V1;
+  const float T1 = UV * iT, T2 = cr * cr * iT * iT * iT;       // d2T = VV / T - UV^2 / T^3 = (U x V)^2 / T^3 (Lagrange): no difference of two large terms
+  const float g1 = V0 - mur * T1;
+  const float c2 = 0.5f * e.Dm * e.NmT * e.NmT, a2 = e.Dm * e.NmT * g1, b2 = e.Dm * (g1 * g1 - e.NmT * mur * T2);
+  cost = e.zone == 0 ? 0.0f : (e.zone == 1 ? c1 : c2);
+  d0 = e.zone == 0 ? 0.0f : (e.zone == 1 ? a1 : a2);
+  d1 = e.zone == 0 ? 0.0f : (e.zone == 1 ? b1 : b2);
 }
 
 template <class S, int G, int HF, bool PRE = false>
@@ -2618,7 +2621,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         const float Dn = ODK_DPP(cD[t], 0x00, 0xF), Dt = Dn * m->impratio;
         const float mu = CT[(rc < S::NCROW ? rc : 0) >> 4], mur = mu * ell_mur;
         const float one = ((rc & 3) == 0 && rc < S::NCROW) ? 1.0f : 0.0f;
-        const ConeEv es = cone_ev(Dn, mu, mur, xs[0], xs[1], xs[2]), ew = cone_ev(Dn, mu, mur, xw[0], xw[1], xw[2]);
+        const float Dm = cone_dm(Dn, mur);
+        const ConeEv es = cone_ev(Dn, Dm, mu, mur, xs[0], xs[1], xs[2]), ew = cone_ev(Dn, Dm, mu, mur, xw[0], xw[1], xw[2]);
         cost_s += one * cone_cost(es, Dn, Dt, xs[0], xs[1], xs[2]); cost_w += one * cone_cost(ew, Dn, Dt, xw[0], xw[1], xw[2]);
       }
     }
@@ -2673,7 +2677,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
           const float Dn = ODK_DPP(D, 0x00, 0xF), Dt = Dn * m->impratio;
           const float mu = CT[rcl >> 4], mur = mu * ell_mur;
           const int sr = on ? (rcl & 3) : 3;
-          const ConeEv e = cone_ev(Dn, mu, mur, xs[0], xs[1], xs[2]);
+          const ConeEv e = cone_ev(Dn, cone_dm(Dn, mur), mu, mur, xs[0], xs[1], xs[2]);
           fr = cone_force(e, Dn, Dt, mu, mur, xs[0], xs[1], xs[2], sr);
           cone_hess_row(e, Dn, Dt, mu, mur, sr, C);
           const float* w0 = W + 6 * (rcl & ~3);
@@ -2964,7 +2968,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   }
   ODK_PROF(15);
   // elliptic cones: the contact's three Jaref and J search in every lane of its quad, once for the whole line search
-  float ls_x[NCL][3], ls_v[NCL][3], ls_Dn[NCL], ls_mu[NCL], ls_one[NCL];
+  float ls_x[NCL][3], ls_v[NCL][3], ls_Dn[NCL], ls_Dt[NCL], ls_Dm[NCL], ls_mu[NCL], ls_mur[NCL], ls_one[NCL];
   if constexpr (S::ELL) {
     if (ell) {
 #pragma unroll
@@ -2973,6 +2977,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         quad3(cjar[t], ls_x[t]); quad3(cjv[t], ls_v[t]);
         ls_Dn[t] = ODK_DPP(cD[t], 0x00, 0xF);
         ls_mu[t] = CT[(rc < S::NCROW ? rc : 0) >> 4];
+        ls_mur[t] = ls_mu[t] * ell_mur; ls_Dt[t] = ls_Dn[t] * m->impratio; ls_Dm[t] = cone_dm(ls_Dn[t], ls_mur[t]);
         ls_one[t] = ((rc & 3) == 0 && rc < S::NCROW) ? 1.0f : 0.0f;
       }
     }
@@ -3028,7 +3033,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
           for (int a = 0; a < 3; a++) {
             const float xx[3] = {ls_x[t][0] + al[a] * ls_v[t][0], ls_x[t][1] + al[a] * ls_v[t][1], ls_x[t][2] + al[a] * ls_v[t][2]};
             float cc, d0c, d1c;
-            cone_line(ls_Dn[t], ls_Dn[t] * m->impratio, ls_mu[t], ls_mu[t] * ell_mur, xx, ls_v[t], cc, d0c, d1c);
+            cone_line(ls_Dn[t], ls_Dt[t], ls_Dm[t], ls_mu[t], ls_mur[t], xx, ls_v[t], cc, d0c, d1c);
             if constexpr (COST) acc[3 * a] = fmaf(ls_one[t], cc, acc[3 * a]);
             else { acc[3 * a + 1] = fmaf(ls_one[t], d0c - al[a] * d1c, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(ls_one[t], 0.5f * d1c, acc[3 * a + 2]); }
           }
