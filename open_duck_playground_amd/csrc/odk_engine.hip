@@ -76,8 +76,8 @@ template <class S> __device__ __forceinline__ const int* load_shared(float* lds,
 
 using ShapeA = Shape<21, 20, 18, 14, 15, 145, 170, 76, 10, 15>;   // flat_terrain
 using ShapeB = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25>;   // *_backlash
-// the same two with the elliptic-cone code compiled in (Shape::ELL): launched for a duck model with <option cone="elliptic"> on a plane floor,
-// 32 lanes per env; the default kernels above stay the instruction streams they were
+// the same two with the elliptic-cone code compiled in (Shape::ELL): launched for a duck model with <option cone="elliptic"> (plane floor, or
+// the backlash model's height field), 32 lanes per env; the default kernels above stay the instruction streams they were
 using ShapeAE = Shape<21, 20, 18, 14, 15, 145, 170, 76, 10, 15, true>;
 using ShapeBE = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25, true>;
 // A robot that is not the duck (tests/assets/tail_biped.xml: biped with a five-link tail, 21 dofs, 15 actuators, 19 bodies,
@@ -1454,8 +1454,8 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   else if (fits(ShapeC::NQ, ShapeC::NV, ShapeC::NB, ShapeC::NU, ShapeC::NJ, ShapeC::NM, ShapeC::NH, ShapeC::NROW, ShapeC::DT, ShapeC::DV)) mo->shape = 2;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
-  if (m.cone && !(m.floor_is_plane && m.foot_prim == 0)) {
-    delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: the elliptic-cone kernels are built for convex (box / mesh) feet on a plane floor");
+  if (m.cone && m.foot_prim != 0) {
+    delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: the elliptic-cone kernels are built for convex (box / mesh) feet, not sphere / capsule feet");
   }
   {   // equality rows of the kernels: joint couplings inside one serial chain of a shape compiled with them
     m.neq = 0;
@@ -1676,7 +1676,10 @@ static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st
 #endif
   // height-field floors exist only with the backlash model (scene_rough_terrain_backlash.xml) and run 32 lanes per env; sphere / capsule
   // feet on one are their own instantiation (HF = 2): its out-of-line calls must not enter the duck kernel's register allocation
-  if (!b->model.h.floor_is_plane) return b->model.h.foot_prim ? launch_sg<ShapeB, 32, 2>(which, a, st) : launch_sg<ShapeB, 32, 1>(which, a, st);
+  if (!b->model.h.floor_is_plane) {
+    if (b->model.h.cone) return launch_sg<ShapeBE, 32, 1>(which, a, st);      // (hull feet: checked at load)
+    return b->model.h.foot_prim ? launch_sg<ShapeB, 32, 2>(which, a, st) : launch_sg<ShapeB, 32, 1>(which, a, st);
+  }
   if (b->model.shape == 2) return b->G == 32 ? launch_phys<ShapeC, 32>(which, a, st) : hipErrorNotSupported;
   if (b->model.h.cone) {      // the duck with elliptic cones (plane floor, checked at load): 32 lanes per env
     if (b->G != 32) return hipErrorNotSupported;

@@ -202,7 +202,7 @@ def compile_mjcf(xml_path: str, sim_dt: Optional[float] = None) -> Dict[str, np.
         for k in ("solver", "integrator"):
             if k in o.attrib:
                 raise NotImplementedError(f"<option {k}=...> not supported (defaults: Newton / Euler)")
-        if "cone" in o.attrib:      # mjtCone: pyramidal 0, elliptic 1 (elliptic: the float64 oracle has it, the kernels on a plane floor; `odk_model_load` refuses it on a height field)
+        if "cone" in o.attrib:      # mjtCone: pyramidal 0, elliptic 1 (elliptic: the float64 oracle and the kernels have it; `odk_model_load` refuses it with sphere / capsule feet)
             if o.attrib["cone"] not in ("pyramidal", "elliptic"):
                 raise ValueError(f"<option cone='{o.attrib['cone']}'>")
             opt["cone"] = 1 if o.attrib["cone"] == "elliptic" else 0

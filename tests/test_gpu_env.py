@@ -446,7 +446,7 @@ def test_step_sequence_with_resync(oracle_mod, parity_log, task):
     parity_log.check(f"env_step/{task}", {**ENV_BOUNDS, **_set_aside(task)}, **_errs(W))
 
 
-@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
 def test_step_sequence_of_the_duck_with_elliptic_cones(oracle_mod, parity_log, task):
     """`<option cone="elliptic">` on the duck itself: the model's `opt_cone` switched to 1 (impratio as in the file: 1), the env
     kernels' own instantiation with the cone code (`ShapeAE` / `ShapeBE`, odk_engine.hip) against the oracle env with the same model: reset, then

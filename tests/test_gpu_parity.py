@@ -503,11 +503,11 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
     parity_log.check(f"ten_substeps/{task}", dict(TEN_BOUNDS, ill_fraction=0.55 if "rough" in task else 0.45), qpos=wq, qvel=wv, qpos_normwise=wqn, qvel_normwise=wvn, ill_fraction=n_ill / n)
 
 
-@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash"])
+@pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
 def test_the_duck_with_elliptic_cones(torch_cuda, oracle_mod, parity_log, task):
     """`<option cone="elliptic">` on the duck itself: opt_cone = 1 (impratio 1, as the file has it), the physics kernels of the duck's shapes
-    with the cone code (`ShapeAE` / `ShapeBE`) against the float64 oracle: the state after one mjx.step and after ten, at the duck's bounds;
-    the model with 64 lanes per env is refused (the cone kernels run 32)."""
+    with the cone code (`ShapeAE` / `ShapeBE`; plane floor and the backlash model's height field) against the float64 oracle: the state after one
+    mjx.step and after ten, at the duck's bounds; 64 lanes per env and primitive feet are refused by name (the cone kernels: 32 lanes, hulls)."""
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.model import Model, load_task_model
     torch = torch_cuda
@@ -518,6 +518,8 @@ def test_the_duck_with_elliptic_cones(torch_cuda, oracle_mod, parity_log, task):
     n = 128
     rng = np.random.default_rng(23)
     qpos, qvel = _random_states(model, n, rng, airborne_frac=0.2)
+    if "rough" in task:
+        qpos = _settle_on_terrain(oracle_mod, om, qpos, rng, qpos[:, 2] > 0.25)
     warm = rng.normal(0, 3.0, (n, model.nv))
     ctrl = np.asarray(model.a["key_ctrl"])[None] + rng.uniform(-0.3, 0.3, (n, 14))
     ct = torch.tensor(ctrl, dtype=torch.float32, device="cuda")
@@ -553,10 +555,14 @@ def test_the_duck_with_elliptic_cones(torch_cuda, oracle_mod, parity_log, task):
     b.close()
     print(task, "elliptic: one step", W, "ten substeps", T, "ill", n_ill, "of", n)
     parity_log.check(f"duck_elliptic/{task}/one_mjx_step", dict({k: STAGE_BOUNDS[k] for k in W}, ill_fraction=0.3), ill_fraction=n_ill[1] / n, **W)
-    parity_log.check(f"duck_elliptic/{task}/ten_substeps", dict(TEN_BOUNDS, ill_fraction=0.55), ill_fraction=n_ill[10] / n, **T)
+    parity_log.check(f"duck_elliptic/{task}/ten_substeps", dict(TEN_BOUNDS, ill_fraction=0.65 if "rough" in task else 0.55), ill_fraction=n_ill[10] / n, **T)
     cfg = engine.default_config(); cfg.lanes_per_env = 64
     with pytest.raises(engine.OdkError, match="32 lanes"):
         engine.Batch(model, 8, cfg)
+    if task == "flat_terrain":      # sphere / capsule feet have no cone kernels: refused by name
+        prim = _prim_feet_variant("flat_terrain", ("sphere", "capsule"))
+        with pytest.raises(engine.OdkError, match="sphere / capsule"):
+            engine.model_reduction(Model({**prim.a, "opt_cone": np.array([1], np.int32)}))
 
 
 @pytest.mark.parametrize("task,lanes", [("flat_terrain", 32), ("flat_terrain", 64), ("flat_terrain_backlash", 32)])

@@ -70,11 +70,9 @@ def test_compiler_option_and_which_shapes_take_it(robot):
     plain = Model.from_xml(os.path.join(ASSETS, "tail_biped.xml"))
     assert int(plain.a["opt_cone"][0]) == 0
     from open_duck_playground_amd.model import load_task_model
-    duck = load_task_model("flat_terrain")                  # the duck's shapes have their own cone instantiations for a plane floor ...
-    assert engine.model_reduction(Model({**duck.a, "opt_cone": np.array([1], np.int32)}))["nvr"] == 20
-    rough = load_task_model("rough_terrain_backlash")       # ... and refuse the option on a height field by name
-    with pytest.raises(engine.OdkError, match="elliptic"):
-        engine.model_reduction(Model({**rough.a, "opt_cone": np.array([1], np.int32)}))
+    for task in ("flat_terrain", "rough_terrain_backlash"):   # the duck's shapes have their own cone instantiations (plane floor and height field)
+        duck = load_task_model(task)
+        assert engine.model_reduction(Model({**duck.a, "opt_cone": np.array([1], np.int32)}))["nvr"] == 20
 
 
 def test_rows_of_an_elliptic_contact(robot, oracle_mod):
