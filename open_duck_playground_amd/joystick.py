@@ -208,6 +208,18 @@ class Joystick:
                  num_envs: int = 8192, device: int = 0, autoreset: bool = True, lanes_per_env: int = 0, env_id_offset: int = 0):
         self._config = _merge(config if config is not None else self._default_config(), config_overrides)
         self._model = constants.task_to_model(task)      # KeyError for unknown task names
+        cone = self._config.get("cone", None)
+        if cone is not None:      # BUILD-DEFINED switch (the reference edits the XML's <option cone=...>): "pyramidal" | "elliptic", optional "impratio"
+            if cone not in ("pyramidal", "elliptic"):
+                raise ValueError(f"config cone = {cone!r}: 'pyramidal' or 'elliptic'")
+            import numpy as _np
+            from .model import Model
+            edit = {"opt_cone": _np.array([1 if cone == "elliptic" else 0], _np.int32)}
+            if self._config.get("impratio", None) is not None:
+                edit["opt_impratio"] = _np.array([float(self._config.get("impratio"))], _np.float64)
+            self._model = Model({**self._model.a, **edit}, xml_path=self._model.xml_path)
+            if cone == "elliptic" and lanes_per_env == 64:
+                lanes_per_env = 32      # the cone kernels run 32 lanes per env (make_eval_env asks for 64 on small batches)
         self._task = task
         self.num_envs = int(num_envs)
         self._env_id_offset = int(env_id_offset)

@@ -33,6 +33,8 @@ class OpenDuckMiniV2Runner:
         torch.cuda.set_device(device)
         n_local = args.num_envs // self.world
         overrides = {"hfield_up_normals_only": True} if getattr(args, "hfield_up_normals_only", False) else None
+        if getattr(args, "cone", None):
+            overrides = dict(overrides or {}, cone=args.cone)
         self.env = available_envs[args.env](task=args.task, num_envs=n_local, device=device, env_id_offset=self.rank * n_local, config_overrides=overrides)
         self.action_size = self.env.action_size
         self.obs_size = int(self.env.observation_size["state"][0])
@@ -93,6 +95,8 @@ def main():
     parser.add_argument("--hfield_up_normals_only", action="store_true",
                         help="height-field floors: count a prism pair's contacts only when the normal points up (BUILD-DEFINED opt-in, DESIGN 2; "
                              "the reading under which rough_terrain_backlash trains: profiles/r4/hfield_variants.json)")
+    parser.add_argument("--cone", choices=["pyramidal", "elliptic"], default=None,
+                        help="friction cone of the contact solver (what <option cone=...> in the robot's XML sets; default: the model's own, pyramidal for the duck)")
     args = parser.parse_args()
     runner = OpenDuckMiniV2Runner(args)
     try:

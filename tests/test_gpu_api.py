@@ -555,3 +555,31 @@ def test_state_info_reads_like_the_reference():
     with pytest.raises(RuntimeError, match="stepped / reset since"):
         st6.info["command"]
     assert st6.info["truncation"] is env.batch.truncation
+
+
+def test_cone_switch_of_the_env_config():
+    """`config_overrides={"cone": "elliptic"}` (runner: `--cone elliptic`): the BUILD-DEFINED stand-in for editing `<option cone=...>` in the
+    robot's XML -- the env runs on the cone instantiation of its kernels (tests/test_gpu_env.py holds them to the oracle), its evaluation
+    sibling too (32 lanes per env although small batches ask for 64), and the friction model changes what happens: same seed, same actions,
+    different rewards.  An unknown name is refused."""
+    import torch
+    from open_duck_playground_amd.joystick import Joystick
+    outs = []
+    for cone in ("pyramidal", "elliptic"):
+        env = Joystick(task="flat_terrain", num_envs=256, config_overrides={"cone": cone})
+        assert int(env.mj_model.a["opt_cone"][0]) == (1 if cone == "elliptic" else 0)
+        st = env.reset(3)
+        g = torch.Generator(device="cuda"); g.manual_seed(7)
+        tot = torch.zeros(256, device="cuda")
+        for _ in range(30):
+            st = env.step(st, torch.empty(256, 14, device="cuda").uniform_(-1, 1, generator=g))
+            tot += st.reward
+        assert torch.isfinite(st.obs["state"]).all() and torch.isfinite(tot).all()
+        ev = env.make_eval_env(64)
+        es = ev.reset(1)
+        es = ev.step(es, torch.zeros(64, 14, device="cuda"))
+        assert torch.isfinite(es.obs["state"]).all()
+        outs.append(tot.cpu())
+    assert float((outs[0] - outs[1]).abs().max()) > 1e-3
+    with pytest.raises(ValueError, match="pyramidal"):
+        Joystick(task="flat_terrain", num_envs=8, config_overrides={"cone": "round"})
