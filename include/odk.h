@@ -103,7 +103,11 @@ void odk_obs_sizes(int env_kind, int* nobs, int* npriv);
  * capsules (cgeom_type 2 / 3 with the optional record cgeom_size[ncgeom][3]: radius, half length) -- and one floor, a plane (0) or a
  * height field (1: hfield_data + hfield_size).  ODK_ERR_UNSUPPORTED for anything else (other foot types, a hull foot beside a
  * primitive one on a height field, feet wider than two height-field cells, hulls with more than 17 vertices / 30 faces / 48 edges
- * or faces of more than four vertices). */
+ * or faces of more than four vertices).
+ * Solver options read from the blob: opt_iterations / opt_ls_iterations, opt_impratio, and the optional opt_cone (0 pyramidal, 1 elliptic:
+ * the elliptic-cone instantiations of the kernels -- hull feet, 32 lanes per env; sphere / capsule feet refuse it).  The optional eq_*
+ * records (<equality>): joint couplings between two hinges of one serial chain are taken for the third model shape, every other ACTIVE
+ * equality is refused by name. */
 int odk_model_load(const void* blob, uint64_t len, odk_model** out);
 void odk_model_free(odk_model* m);
 int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int* nbody);
