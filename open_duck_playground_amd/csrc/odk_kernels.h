@@ -79,6 +79,7 @@ struct Shape {
   static constexpr bool EQ = (NV_ == 21);
   // <option cone="elliptic"> (DevModel::cone) is compiled into the same shape's kernels: a contact's four row lanes hold normal | tangent 1 |
   // tangent 2 | nothing instead of the four pyramid edges, and the cost of a contact is the cone's (odk_kernels.h "elliptic cones")
+  static constexpr bool CONE = CONE_;                   // an instantiation that is ONLY launched for cone = 1 models: the pyramid code is compiled out
   static constexpr bool ELL = (NV_ == 21) || CONE_;    // (the duck's shapes: their own instantiations with CONE_ = true, launched for models with cone = 1 only)
   static constexpr int NVR = PAIRED ? 20 : NV_;    // reduced dofs
   static constexpr int NMR = PAIRED ? 145 : NM_;   // entries of the reduced tree layout
@@ -2437,7 +2438,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   // are never read again: the solver gates on D > 0 and on the same wave-uniform flag)
   const bool ff_rows = __builtin_amdgcn_ballot_w64(fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0.0f) != 0;
   const bool prim_feet = !HF && m->foot_prim != 0;   // sphere / capsule feet: per-contact frames in S_FR (prim_contacts)
-  const bool ell = S::ELL && m->cone != 0;            // (wave-uniform) elliptic friction cones
+  const bool ell = S::CONE || (S::ELL && m->cone != 0);   // (wave-uniform; a compile-time constant for the duck's cone instantiations) elliptic friction cones
   for (int rc = lane; rc < S::NCROW; rc += G) {
     const int r = r0c + rc, c = rc >> 2, s = rc & 3, pair = c >> 2;
     if (rc >= 32 && !ff_rows) { ED[r] = 0.0f; AREF[r] = 0.0f; continue; }
@@ -2968,7 +2969,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   }
   ODK_PROF(15);
   // elliptic cones: the contact's three Jaref and J search in every lane of its quad, once for the whole line search
-  float ls_x[NCL][3], ls_v[NCL][3], ls_Dn[NCL], ls_Dt[NCL], ls_Dm[NCL], ls_mu[NCL], ls_mur[NCL], ls_one[NCL];
+  float ls_x[NCL][3], ls_v[NCL][3], ls_Dn[NCL], ls_Dt[NCL], ls_Dm[NCL], ls_mu[NCL], ls_mur[NCL], ls_on[NCL];
   if constexpr (S::ELL) {
     if (ell) {
 #pragma unroll
@@ -2978,7 +2979,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         ls_Dn[t] = ODK_DPP(cD[t], 0x00, 0xF);
         ls_mu[t] = CT[(rc < S::NCROW ? rc : 0) >> 4];
         ls_mur[t] = ls_mu[t] * ell_mur; ls_Dt[t] = ls_Dn[t] * m->impratio; ls_Dm[t] = cone_dm(ls_Dn[t], ls_mur[t]);
-        ls_one[t] = ((rc & 3) == 0 && rc < S::NCROW) ? 1.0f : 0.0f;
+        ls_on[t] = ((rc & 3) < 3 && rc < S::NCROW) ? 1.0f : 0.0f;      // the three lanes of a contact's quad that evaluate a step size each
       }
     }
   }
@@ -3027,15 +3028,21 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     for (int t = 0; t < NCL; t++) {
       if (t * G >= 32 && !any_ff) continue;
       if constexpr (S::ELL) {
-        if (ell) {   // the contact's exact cost / derivatives at each step size, counted by lane 0 of its quad.  The sums the callers form are
-                     // d0 = 2 al t2 + t1 and d1 = 2 t2: a term (d0c, d1c) enters as t1 += d0c - al d1c, t2 += d1c / 2
+        if (ell) {   // the contact's exact cost / derivatives at the three step sizes: lane s of the contact's quad evaluates step size s (one
+                     // cone evaluation per lane instead of three; the fourth lane idles) and adds to the sums of ITS step size -- the reduction
+                     // over the lanes does the rest.  The sums the callers form are d0 = 2 al t2 + t1 and d1 = 2 t2: a term (d0c, d1c) enters
+                     // as t1 += d0c - al d1c, t2 += d1c / 2
+          const int sa = lane & 3;
+          const float als = sa == 0 ? al[0] : (sa == 1 ? al[1] : al[2]);
+          const float xx[3] = {ls_x[t][0] + als * ls_v[t][0], ls_x[t][1] + als * ls_v[t][1], ls_x[t][2] + als * ls_v[t][2]};
+          float cc, d0c, d1c;
+          cone_line(ls_Dn[t], ls_Dt[t], ls_Dm[t], ls_mu[t], ls_mur[t], xx, ls_v[t], cc, d0c, d1c);
+          const float t1c = d0c - als * d1c, t2c = 0.5f * d1c;
 #pragma unroll
           for (int a = 0; a < 3; a++) {
-            const float xx[3] = {ls_x[t][0] + al[a] * ls_v[t][0], ls_x[t][1] + al[a] * ls_v[t][1], ls_x[t][2] + al[a] * ls_v[t][2]};
-            float cc, d0c, d1c;
-            cone_line(ls_Dn[t], ls_Dt[t], ls_Dm[t], ls_mu[t], ls_mur[t], xx, ls_v[t], cc, d0c, d1c);
-            if constexpr (COST) acc[3 * a] = fmaf(ls_one[t], cc, acc[3 * a]);
-            else { acc[3 * a + 1] = fmaf(ls_one[t], d0c - al[a] * d1c, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(ls_one[t], 0.5f * d1c, acc[3 * a + 2]); }
+            const float w = sa == a ? ls_on[t] : 0.0f;
+            if constexpr (COST) acc[3 * a] = fmaf(w, cc, acc[3 * a]);
+            else { acc[3 * a + 1] = fmaf(w, t1c, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, t2c, acc[3 * a + 2]); }
           }
           continue;
         }
