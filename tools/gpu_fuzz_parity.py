@@ -17,10 +17,14 @@ from open_duck_playground_amd.model import load_task_model  # noqa: E402
 from test_gpu_parity import _contact_tie, _contacts, _oracle_step, _random_states, _rel  # noqa: E402
 
 def make_states(task, n=1024, seed=0, variant=None):
-    """CPU only: the model (variant: None | "box" | "sphere-capsule" ...: the foot colliders replaced as in tests/test_gpu_parity.py),
+    """CPU only: the model (variant: None | "elliptic" | "box" | "sphere-capsule" ...: the foot colliders replaced as in tests/test_gpu_parity.py),
     its oracle models and the random contact-rich states of the sweep"""
     if variant is None:
         model = load_task_model(task)
+    elif variant == "elliptic":      # the task's own model with <option cone="elliptic"> (the cone instantiations of the kernels)
+        from open_duck_playground_amd.model import Model
+        base = load_task_model(task)
+        model = Model({**base.a, "opt_cone": np.array([1], np.int32)})
     elif variant == "box":
         from test_gpu_parity import _box_feet_variant
         model = _box_feet_variant(task)
