@@ -442,6 +442,10 @@ def physics_leg(ctx, args, envs: int):
     rank, world, local_rank, dev = ctx
 
     model = load_task_model(args.task)
+    if getattr(args, "cone", None) == "elliptic":      # (not the BASELINE workload: the duck's model with <option cone="elliptic">, the kernels' cone instantiations)
+        import numpy as np
+        from open_duck_playground_amd.model import Model
+        model = Model({**model.a, "opt_cone": np.array([1], np.int32)})
     cfg = engine.default_config()
     cfg.noise_level = 0.0
     cfg.push_enable = 0.0
@@ -490,7 +494,7 @@ def physics_leg(ctx, args, envs: int):
     batch.close()
     if rank != 0:
         return None
-    cnt, csrc = _counters(args.task, envs)
+    cnt, csrc = _counters(args.task, envs) if getattr(args, "cone", None) != "elliptic" else ({}, None)      # (the committed counter passes are the pyramid kernels')
     traffic, flop_launch = cnt.get("hbm_bytes_per_launch"), cnt.get("valu_flop_per_launch")
     bytes_per_launch = BYTES_PER_ENV_STEP.get(args.task, 3564 if "backlash" in args.task else 2844) * envs
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -515,7 +519,7 @@ def physics_leg(ctx, args, envs: int):
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"open_duck_mini_v2 {args.task}, {envs} envs/GPU, random-action rollout "
                                "(wrappers + Joystick.step + 10 x mjx.step + obs/reward fused in one launch), "
-                               "noise off, pushes off, imitation on, auto-reset on",
+                               "noise off, pushes off, imitation on, auto-reset on" + (", ELLIPTIC friction cones (not the BASELINE workload)" if getattr(args, "cone", None) == "elliptic" else ""),
                    "mode": "physics", "envs_per_gpu": envs, "global_envs": envs * world, "n_substeps": 10,
                    "lanes_per_env": lanes, "parallelism": f"env-sharded x{world}, no collective",
                    "done_fraction_last_step": round(done_frac, 4),
@@ -583,6 +587,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--task", default=None)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--cone", default=None, choices=["pyramidal", "elliptic"], help="physics mode: the contact solver's friction cone (default: the model's own = the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="physics mode: skip the short full-PPO legs attached as `secondary`")
     ap.add_argument("--secondary-steps", type=int, default=10)
