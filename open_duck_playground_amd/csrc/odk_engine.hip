@@ -1153,10 +1153,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
         delete mo; return fail(ODK_ERR_UNSUPPORTED, "equality constraints: more than 16, or eq_* records incomplete");
       }
       for (int k = 0; k < eq_n; k++)
-        if (eq_active[k] && eq_type[k] != 2) {
-          delete mo;
-          return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d) is active: the kernels model <equality><joint> rows only (the oracle has connect / weld)", eq_type[k] == 0 ? "connect" : (eq_type[k] == 1 ? "weld" : "?"), k);
-        }
+        if (eq_active[k] && (eq_type[k] < 0 || eq_type[k] > 2)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<equality> constraint %d: type %d (connect, weld and joint are modelled)", k, eq_type[k]); }
     }
   }
   double dtv[1], g3[3], t1[1];
@@ -1460,8 +1457,47 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   {   // equality rows of the kernels: joint couplings inside one serial chain of a shape compiled with them
     m.neq = 0;
     for (int d = 0; d < MAXV; d++) m.dof_eqrow[d] = -1;
+    // <equality><connect | weld>: "path rows" (odk_kernels.h) -- the two bodies on ONE root-to-leaf path of the tree, or body2 = the world,
+    // so that the rows' J^T D J only touches entries the tree layout has; at most EQP_MAX constraints / EQP_ROWS rows.  In MJX's row order:
+    // connects first, then welds.
+    m.neqp = 0; m.eqp_nrow = 0;
+    for (int d = 0; d < MAXV; d++) m.dof_eqp[d] = 0;
+    for (int pass = 0; pass < 2; pass++)
+      for (int k = 0; k < eq_n; k++) {
+        if (!eq_active[k] || eq_type[k] != pass) continue;
+        const char* kind = pass == 0 ? "connect" : "weld";
+        const bool shape_ok = mo->shape == 2 && !m.paired;
+        const int nrow = pass == 0 ? 3 : 6;
+        if (!shape_ok || m.neqp == EQP_MAX || m.eqp_nrow + nrow > EQP_ROWS) {
+          delete mo;
+          return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d) is active: %s", kind, k,
+                      shape_ok ? "the kernels hold at most two connect / weld constraints with nine rows in total" : "equality rows are compiled into the third model shape only (the duck's kernels carry none)");
+        }
+        const int c = m.neqp, b1 = eq_o1[k], b2 = eq_o2[k] < 0 ? 0 : eq_o2[k];
+        if (b1 < 1 || b1 >= m.nb || b2 >= m.nb) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d): bad body ids", kind, k); }
+        // dofs above a body: the dofs of the body itself and of its ancestors
+        unsigned above[2] = {0u, 0u};
+        for (int s2 = 0; s2 < 2; s2++)
+          for (int b = s2 ? b2 : b1; b > 0; b = m.body_parent[b])
+            for (int d = 0; d < m.nv; d++) if (m.dof_body[d] == b) above[s2] |= 1u << d;
+        if ((above[0] & above[1]) != above[0] && (above[0] & above[1]) != above[1]) {
+          delete mo;
+          return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d): the two bodies must lie on one root-to-leaf path of the tree (or body2 be the world): a constraint across two chains closes a loop the tree layout has no entries for", kind, k);
+        }
+        for (int d = 0; d < m.nv; d++) m.dof_eqp[d] |= (((above[0] >> d) & 1) << (2 * c)) | (((above[1] >> d) & 1) << (2 * c + 1));
+        const double* da = eq_data + 11 * k;
+        for (int a = 0; a < 3; a++) { m.eqp_a1[c][a] = (float)(pass == 0 ? da[a] : da[3 + a]); m.eqp_a2[c][a] = (float)(pass == 0 ? da[3 + a] : da[a]); }
+        for (int a = 0; a < 4; a++) m.eqp_relq[c][a] = pass == 0 ? (a == 0 ? 1.0f : 0.0f) : (float)da[6 + a];
+        m.eqp_ts[c] = pass == 0 ? 0.0f : (float)da[10];
+        float sr[2] = {(float)eq_solref[2 * k], (float)eq_solref[2 * k + 1]}, si[5];
+        for (int a = 0; a < 5; a++) si[a] = (float)eq_solimp[5 * k + a];
+        pack_imp(sr, si, m.dt, m.eqp_imp[c]);
+        m.eqp_invw[c][0] = (float)(biw[2 * b1] + biw[2 * b2]); m.eqp_invw[c][1] = (float)(biw[2 * b1 + 1] + biw[2 * b2 + 1]);
+        m.eqp_type[c] = pass; m.eqp_b1[c] = b1; m.eqp_b2[c] = b2; m.eqp_row0[c] = m.eqp_nrow;
+        m.eqp_nrow += nrow; m.neqp++;
+      }
     for (int k = 0; k < eq_n; k++) {
-      if (!eq_active[k]) continue;
+      if (!eq_active[k] || eq_type[k] != 2) continue;
       const bool shape_ok = mo->shape == 2 && !m.paired;      // ShapeC::EQ
       if (!shape_ok || m.neq == EQ_MAX) {
         delete mo;

@@ -144,7 +144,11 @@ struct Shape {
   static_assert(NSENSD <= NROW, "sensordata must fit in the jv rows");
   static constexpr int O_ACTF = O_SCR + N_SCR;       // actuator_force
   static constexpr int O_QACC = O_X;                 // qacc of the last forward == final iterate
-  static constexpr int TOTAL = ((O_ACTF + NU + 3) / 4) * 4;
+  // path rows of shapes with EQ (<equality><connect | weld>, DevModel::neqp): wrenches [EQP_ROWS][12] | J [EQP_ROWS][NV] | D | aref | residual
+  static constexpr int O_EQP = ((O_ACTF + NU + 3) / 4) * 4;
+  static constexpr int EQP_W = 0, EQP_J = 12 * EQP_ROWS, EQP_D = EQP_J + EQP_ROWS * NV, EQP_AREF = EQP_D + EQP_ROWS, EQP_POS = EQP_AREF + EQP_ROWS;
+  static constexpr int N_EQP = EQ ? ((EQP_POS + EQP_ROWS + 3) / 4) * 4 : 0;
+  static constexpr int TOTAL = O_EQP + N_EQP;
   static constexpr int ENV_STRIDE = TOTAL + 160;   // floats between the images of the two envs of a workgroup (odk_engine.hip EnvL::TOTAL: + info + action)
   // scratch sub-offsets
   static constexpr int S_VF = 0;      // [2][6] foot twist of the current vector
@@ -783,6 +787,18 @@ __device__ __forceinline__ float pair_sum(const float* V, const DevModel* __rest
 // impedance / stiffness of one constraint row (mjx constraint._row); returns D = 1/R and aref
 // efc_D and efc_aref of one active row from the constants packed at load (DevModel::*_imp): impedance sigmoid of
 // |pos| / width, R = invweight (1 - imp) / imp, aref = -b vel - k imp pos  (mjx constraint._efc_row / mju_makeImpedance)
+// a row of a vector constraint: the impedance from pos_imp (the norm of the constraint's residual), the reference from the row's own pos
+__device__ __forceinline__ void row_params_imp(const float* P, float pos, float pos_imp, float invweight, float vel, float& D, float& aref) {
+  const float k = P[0], b = P[1], dmin = P[2], dmax = P[3], mid = P[5], power = P[6];
+  const float x = fabsf(pos_imp) * P[4];
+  float y;
+  if (power == 2.0f) y = x < mid ? x * x * P[7] : 1.0f - (1.0f - x) * (1.0f - x) * P[8];
+  else y = x < mid ? powf(x, power) * P[7] : 1.0f - powf(1.0f - x, power) * P[8];
+  float imp = fminf(fmaxf(dmin + y * (dmax - dmin), dmin), dmax);
+  if (x > 1.0f) imp = dmax;
+  D = imp * __builtin_amdgcn_rcpf(fmaxf(invweight * (1.0f - imp), MINVAL_F * imp));
+  aref = -b * vel - k * imp * pos;
+}
 __device__ __forceinline__ void row_params(const float* P, float pos, float invweight, float vel, float& D, float& aref) {
   const float k = P[0], b = P[1], dmin = P[2], dmax = P[3], mid = P[5], power = P[6];
   const float x = fabsf(pos) * P[4];
@@ -2434,6 +2450,90 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       }
     }
   }
+  // ---- path rows (<equality><connect | weld> between two bodies of one root-to-leaf path, or a body and the world: DevModel::neqp; shapes
+  // with S::EQ).  Lane = row builds the row's residual and its two wrenches (one per body: a point force e_k at the anchor, or for a weld's
+  // rotation rows the moment A_k of the error quaternion's derivative); lane = dof turns them into ITS Jacobian entries
+  // J_ri = m1 (w1 . cdof_i) - m2 (w2 . cdof_i), kept in registers (pj) and in LDS (the Hessian's entry lanes read both dofs'); every J v
+  // product is one reduction over the lanes.  Always active, quadratic (mjx constraint._efc_equality_connect / _weld as the oracle's
+  // make_equality restates them: the impedance of all rows of a constraint from the NORM of its residual).
+  float pj[EQP_ROWS], pjar_s[EQP_ROWS], pjar_w[EQP_ROWS];
+  int np_rows = 0;
+  float* EQW = L + S::O_EQP;
+  if constexpr (S::EQ) {
+    np_rows = m->eqp_nrow;      // (wave-uniform: one model per launch)
+#pragma unroll
+    for (int r = 0; r < EQP_ROWS; r++) { pj[r] = 0.0f; pjar_s[r] = 0.0f; pjar_w[r] = 0.0f; }
+    if (np_rows > 0) {
+      auto row_c = [&](int r) { return (m->neqp > 1 && r >= m->eqp_row0[1]) ? 1 : 0; };
+      if (lane < np_rows) {
+        const int c = row_c(lane), k = lane - m->eqp_row0[c], b1 = m->eqp_b1[c], b2 = m->eqp_b2[c];
+        float q1[4], q2[4], p1[3], p2[3], t[3];
+        for (int a = 0; a < 4; a++) { q1[a] = XQUAT[a * NB + b1]; q2[a] = XQUAT[a * NB + b2]; }
+        qrot(t, q1, m->eqp_a1[c]); for (int a = 0; a < 3; a++) p1[a] = XPOS[a * NB + b1] + t[a];
+        qrot(t, q2, m->eqp_a2[c]); for (int a = 0; a < 3; a++) p2[a] = XPOS[a * NB + b2] + t[a];
+        float w1[6] = {0, 0, 0, 0, 0, 0}, w2[6] = {0, 0, 0, 0, 0, 0}, cpos;
+        if (k < 3) {
+          const float e[3] = {k == 0 ? 1.0f : 0.0f, k == 1 ? 1.0f : 0.0f, k == 2 ? 1.0f : 0.0f};
+          const float r1[3] = {p1[0] - ref[0], p1[1] - ref[1], p1[2] - ref[2]}, r2[3] = {p2[0] - ref[0], p2[1] - ref[1], p2[2] - ref[2]};
+          cross3(w1, r1, e); cross3(w2, r2, e);
+          for (int a = 0; a < 3; a++) { w1[3 + a] = e[a]; w2[3 + a] = e[a]; }
+          cpos = (k == 0 ? p1[0] - p2[0] : (k == 1 ? p1[1] - p2[1] : p1[2] - p2[2]));
+        } else {      // weld, rotation row k - 3: error quaternion conj(q2) q1 relpose, its axis part times torquescale; d/dt = 0.5 conj(q2) (0, w1 - w2) q1 relpose
+          const int kk = k - 3;
+          const float ts = m->eqp_ts[c];
+          float quat[4], q2c[4] = {q2[0], -q2[1], -q2[2], -q2[3]}, qe[4];
+          qmul(quat, q1, m->eqp_relq[c]);
+          qmul(qe, q2c, quat);
+          cpos = (kk == 0 ? qe[1] : (kk == 1 ? qe[2] : qe[3])) * ts;
+          for (int a = 0; a < 3; a++) {
+            const float ax[4] = {0.0f, a == 0 ? 1.0f : 0.0f, a == 1 ? 1.0f : 0.0f, a == 2 ? 1.0f : 0.0f};
+            float q3[4], q4[4];
+            qmul(q3, q2c, ax); qmul(q4, q3, quat);
+            const float v = 0.5f * ts * (kk == 0 ? q4[1] : (kk == 1 ? q4[2] : q4[3]));
+            w1[a] = v; w2[a] = v;
+          }
+        }
+        for (int a = 0; a < 6; a++) { EQW[S::EQP_W + 12 * lane + a] = w1[a]; EQW[S::EQP_W + 12 * lane + 6 + a] = w2[a]; }
+        EQW[S::EQP_POS + lane] = cpos;
+      }
+      ODK_SYNC();
+      float cdv[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cdv[k] = st.d_on ? CDOF[k * NR + st.d_red] : 0.0f;
+      const int pmask = st.d_on ? m->dof_eqp[lane] : 0;
+      const float qv_l = st.d_on ? QVEL[lane] : 0.0f;
+      float vr[EQP_ROWS];
+#pragma unroll
+      for (int r = 0; r < EQP_ROWS; r++) {
+        float J = 0.0f;
+        if (r < np_rows) {
+          const int c = row_c(r);
+          const float* w = EQW + S::EQP_W + 12 * r;
+          float d1 = 0.0f, d2 = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 6; k++) { d1 = fmaf(w[k], cdv[k], d1); d2 = fmaf(w[6 + k], cdv[k], d2); }
+          J = (((pmask >> (2 * c)) & 1) ? d1 : 0.0f) - (((pmask >> (2 * c + 1)) & 1) ? d2 : 0.0f);
+          if (st.d_on) EQW[S::EQP_J + r * NV + lane] = J;
+        }
+        pj[r] = J; vr[r] = J * qv_l;
+      }
+      gsum_n<G, EQP_ROWS>(vr);
+      if (lane < np_rows) {
+        const int c = row_c(lane), k = lane - m->eqp_row0[c];
+        const int r0 = m->eqp_row0[c], r1 = (c + 1 < m->neqp) ? m->eqp_row0[c + 1] : np_rows;
+        float nrm = 0.0f;
+        for (int r = r0; r < r1; r++) { const float x = EQW[S::EQP_POS + r]; nrm = fmaf(x, x, nrm); }
+        nrm = sqrtf(nrm);
+        float vel = 0.0f;
+#pragma unroll
+        for (int r = 0; r < EQP_ROWS; r++) vel = r == lane ? vr[r] : vel;
+        float D, aref;
+        row_params_imp(m->eqp_imp[c], EQW[S::EQP_POS + lane], nrm, m->eqp_invw[c][k < 3 ? 0 : 1], vel, D, aref);
+        EQW[S::EQP_D + lane] = D; EQW[S::EQP_AREF + lane] = aref;
+      }
+      ODK_SYNC();
+    }
+  }
   // foot-foot rows (32..47) are skipped wave-wide unless some env has a penetrating foot-foot contact (D = 0 rows
   // are never read again: the solver gates on D > 0 and on the same wave-uniform flag)
   const bool ff_rows = __builtin_amdgcn_ballot_w64(fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0.0f) != 0;
@@ -2584,6 +2684,22 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       if (eq_first) { cost_s += 0.5f * eq_D * jar_eq_s * jar_eq_s; cost_w += 0.5f * eq_D * jar_eq_w * jar_eq_w; }
     }
   }
+  if constexpr (S::EQ) {
+    if (np_rows > 0) {   // path rows: J x for both candidates (one reduction per row and candidate); the row's cost counted by lane = row
+      float a9[EQP_ROWS], b9[EQP_ROWS];
+#pragma unroll
+      for (int r = 0; r < EQP_ROWS; r++) { a9[r] = pj[r] * qas; b9[r] = pj[r] * warm; }
+      gsum_n<G, EQP_ROWS>(a9); gsum_n<G, EQP_ROWS>(b9);
+#pragma unroll
+      for (int r = 0; r < EQP_ROWS; r++) {
+        if (r < np_rows) {
+          const float ar = EQW[S::EQP_AREF + r], D = EQW[S::EQP_D + r];
+          pjar_s[r] = a9[r] - ar; pjar_w[r] = b9[r] - ar;
+          if (lane == r) { cost_s += 0.5f * D * pjar_s[r] * pjar_s[r]; cost_w += 0.5f * D * pjar_w[r] * pjar_w[r]; }
+        }
+      }
+    }
+  }
   const bool c_act[3] = {fminf(fminf(CDIST[0], CDIST[1]), fminf(CDIST[2], CDIST[3])) < 0, fminf(fminf(CDIST[4], CDIST[5]), fminf(CDIST[6], CDIST[7])) < 0,
                          fminf(fminf(CDIST[8], CDIST[9]), fminf(CDIST[10], CDIST[11])) < 0};
   // wave-uniform: some env of the wave has a penetrating foot-foot contact.  Without one, contact rows 32-47 have D = 0 in
@@ -2636,6 +2752,10 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   const float ma = use_warm ? ma_w : qfs;
   const float jar_fl = use_warm ? jar_fl_w : jar_fl_s, jar_lim = use_warm ? jar_lim_w : jar_lim_s;
   const float jar_eq = use_warm ? jar_eq_w : jar_eq_s;
+  if constexpr (S::EQ) {
+#pragma unroll
+    for (int r = 0; r < EQP_ROWS; r++) pjar_s[r] = use_warm ? pjar_w[r] : pjar_s[r];      // (from here on: the chosen point's Jaref of the path rows)
+  }
 #pragma unroll
   for (int t = 0; t < NCL; t++) {
     cjar[t] = use_warm ? cjv[t] : cjar[t];
@@ -2742,6 +2862,10 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         hdiag_extra += eq_D * je * je;
         if (eq_first) SCR[S::S_EQ + eq_r] = -eq_D * eq_c;
       }
+      if (np_rows > 0) {   // J^T f of the path rows (their J^T D J goes into the Hessian entries directly: hess_entry)
+#pragma unroll
+        for (int r = 0; r < EQP_ROWS; r++) if (r < np_rows) qc += pj[r] * (-EQW[S::EQP_D + r] * pjar_s[r]);
+      }
     }
     float cd[6];
 #pragma unroll
@@ -2807,6 +2931,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
     }
     if constexpr (S::EQ) {
       for (int r = 0; r < m->neq; r++) v += (e & 0x3FF) == m->eq_key[r] ? SCR[S::S_EQ + r] : 0.0f;
+      for (int r = 0; r < np_rows; r++) v = fmaf(EQW[S::EQP_D + r] * EQW[S::EQP_J + r * NV + i], EQW[S::EQP_J + r * NV + j], v);      // path rows: D J_ri J_rj
     }
     const int both = fi & fj;
     if (both) {
@@ -2858,6 +2983,7 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         float v = mm[t] + (((e >> 14) & 1) ? dterm : 0.0f) + (both ? s1 : 0.0f);
         if constexpr (S::EQ) {
           for (int r = 0; r < m->neq; r++) v += (e & 0x3FF) == m->eq_key[r] ? SCR[S::S_EQ + r] : 0.0f;
+          for (int r = 0; r < np_rows; r++) v = fmaf(EQW[S::EQP_D + r] * EQW[S::EQP_J + r * NV + i], EQW[S::EQP_J + r * NV + j], v);
         }
         if (t == 0) {
           float s2 = 0.0f;
@@ -2955,8 +3081,17 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   if (lane < nfl) jv_fl = GRAD[fs.dof];
   if (st.d_lim_on) jv_lim = lim_sgn * search;
   float jv_eq = 0.0f, eq_Dw = 0.0f;      // the equality row's J search and its D on the lane that counts the row (0 elsewhere: exact zeros below)
+  float pr_D = 0.0f, pr_jar = 0.0f, pr_jv = 0.0f;      // the path row counted by this lane (lane = row)
   if constexpr (S::EQ) {
     if (eq_on && eq_first) { jv_eq = GRAD[eq_i] - (eq_j >= 0 ? eq_c * GRAD[eq_j] : 0.0f); eq_Dw = eq_D; }
+    if (np_rows > 0) {
+      float s9[EQP_ROWS];
+#pragma unroll
+      for (int r = 0; r < EQP_ROWS; r++) s9[r] = st.d_on ? pj[r] * search : 0.0f;
+      gsum_n<G, EQP_ROWS>(s9);
+#pragma unroll
+      for (int r = 0; r < EQP_ROWS; r++) if (r == lane && r < np_rows) { pr_D = EQW[S::EQP_D + r]; pr_jar = pjar_s[r]; pr_jv = s9[r]; }
+    }
   }
   // J search of this lane's contact rows
 #pragma unroll
@@ -3015,9 +3150,9 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
         acc[3 * a + 1] = fmaf(w, q1, acc[3 * a + 1]); acc[3 * a + 2] = fmaf(w, q2, acc[3 * a + 2]);
       }
     }
-    if constexpr (S::EQ) {   // equality row: quadratic at every step size
+    if constexpr (S::EQ) {   // equality row (joint coupling) and path row (connect / weld) of this lane: quadratic at every step size
       const float D = eq_Dw, jar = jar_eq, jv = jv_eq;
-      const float q0 = 0.5f * D * jar * jar, q1 = D * jv * jar, q2 = 0.5f * D * jv * jv;
+      const float q0 = 0.5f * D * jar * jar + 0.5f * pr_D * pr_jar * pr_jar, q1 = D * jv * jar + pr_D * pr_jv * pr_jar, q2 = 0.5f * D * jv * jv + 0.5f * pr_D * pr_jv * pr_jv;
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         if constexpr (COST) acc[3 * a] += q0;

@@ -6,6 +6,7 @@
 namespace odk {
 
 constexpr int EQ_MAX = 2;     // <equality><joint> rows per model in the kernels
+constexpr int EQP_MAX = 2, EQP_ROWS = 9;   // path constraints (connect / weld) and their rows (3 / 6 each)
 constexpr int MAXV = 32;     // dofs
 constexpr int MAXQ = 32;     // qpos
 constexpr int MAXB = 20;     // bodies
@@ -157,6 +158,12 @@ struct DevModel {
   // hinges of ONE serial chain -- its Hessian term -D c then falls on an entry the chain's block already has -- or one hinge held at
   // poly[0].  At most EQ_MAX rows, a dof in at most one.  eq_key: low ten bits (i | j << 5) of the packed reduced entry the coupling's
   // off-diagonal term lands on (-1: single-joint row); dof_eqrow: the row a dof takes part in (-1: none).
+  // <equality><connect | weld> whose two bodies lie on ONE root-to-leaf path of the tree (or body2 = the world): "path rows" (shapes with S::EQ;
+  // odk_kernels.h).  A row's Jacobian entry for dof i is m1_i (w1 . cdof_i) - m2_i (w2 . cdof_i) with a wrench per body and m = "dof i is above
+  // the body"; both supports lie on the path, so J^T D J only touches entries the tree layout has.  dof_eqp: bit 2c = above body1 of
+  // constraint c, bit 2c + 1 = above body2.
+  int neqp, eqp_nrow, eqp_type[EQP_MAX], eqp_b1[EQP_MAX], eqp_b2[EQP_MAX], eqp_row0[EQP_MAX], dof_eqp[MAXV];
+  float eqp_a1[EQP_MAX][3], eqp_a2[EQP_MAX][3], eqp_relq[EQP_MAX][4], eqp_ts[EQP_MAX], eqp_imp[EQP_MAX][9], eqp_invw[EQP_MAX][2];
   int cone;      // <option cone>: 0 pyramidal, 1 elliptic (shapes with S::ELL; odk_kernels.h "elliptic cones")
   int neq, eq_dof1[EQ_MAX], eq_dof2[EQ_MAX], eq_qadr1[EQ_MAX], eq_qadr2[EQ_MAX], eq_key[EQ_MAX], dof_eqrow[MAXV];
   float eq_poly[EQ_MAX][5], eq_imp[EQ_MAX][9], eq_invweight[EQ_MAX];

@@ -911,7 +911,8 @@ def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, 
     red = engine.model_reduction(model)
     assert red["paired"] == 0 and red["nvr"] == 21 and red["nMr"] == 156 and red["nHr"] == 181
     om = oracle_mod.OracleModel(model.blob())
-    ne_rows = 0 if eq_active is None else int(sum(eq_active))      # equality rows come first in the oracle's row order; the kernels keep theirs beside the row arrays
+    # equality rows come first in the oracle's row order (connects 3 rows each, welds 6, joints 1); the kernels keep theirs beside the row arrays
+    ne_rows = 0 if eq_active is None else int(sum(a * {0: 3, 1: 6, 2: 1}[int(t)] for a, t in zip(eq_active, np.asarray(model.a["eq_type"]).reshape(-1))))
     n = 64
     rng = np.random.default_rng(41)
     nq, nv, nb = model.nq, model.nv, model.nbody
@@ -1046,6 +1047,41 @@ def test_equality_joint_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log):
         b.close()
     a2 = int(base.a["jnt_qposadr"][base.joint_id("tail_yaw_2")]); ak = int(base.a["jnt_qposadr"][base.joint_id("left_ankle")])
     assert abs(out[0][a2] - out[1][a2]) > 0.02 and abs(out[0][ak] - out[1][ak]) > 0.01, (out[0][a2], out[1][a2], out[0][ak], out[1][ak])
+
+
+def test_connect_and_weld_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log):
+    """SURVEY 8(f).3, <equality><connect> and <weld> (reference README.md:74-85): tests/assets/tail_biped_equality.xml with ALL FOUR of its
+    constraints active -- the two joint couplings, the right foot pinned to the world (connect: 3 rows), the tail tip welded to its parent link
+    (weld: 6 rows) -- through the physics kernels against the float64 oracle at the duck's bounds.  Connect / weld run as "path rows"
+    (odk_kernels.h): both bodies on one root-to-leaf path of the tree (or the world), a wrench per body and row, the Jacobian entry of a
+    dof from ITS motion vector, the rows' J^T D J added to Hessian entries the tree layout already has.  A connect between the two feet
+    (two chains: a closed loop) is refused by name.  And the rows must MATTER."""
+    W, T10 = _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped_equality.xml", "tail_biped_equality_all", eq_active=(1, 1, 1, 1))
+    import os
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model
+    from conftest import ROOT
+    torch = torch_cuda
+    base = Model.from_xml(os.path.join(ROOT, "tests", "assets", "tail_biped_equality.xml"), sim_dt=0.002)
+    out = []
+    for act in ((0, 0, 1, 1), (0, 0, 0, 0)):
+        m = Model({**base.a, "eq_active": np.asarray(act, np.int32)})
+        b = engine.Batch(m, 4)
+        q = np.tile(np.asarray(m.a["key_qpos"], np.float64), (4, 1)); q[:, 2] += 0.3           # lifted 0.3 m above the pin's anchor (the foot's place in the key pose)
+        q[:, int(m.a["jnt_qposadr"][m.joint_id("tail_roll")])] = 0.5                               # the weld is violated: the tail tip must come back
+        b.set_state(q, np.zeros((4, m.nv)), np.zeros((4, m.nv)))
+        b.physics_step(torch.tensor(np.tile(np.asarray(m.a["key_ctrl"]), (4, 1)), dtype=torch.float32, device="cuda"), 100)
+        out.append(b.get_state()[0][0].copy())
+        b.close()
+    tr = int(base.a["jnt_qposadr"][base.joint_id("tail_roll")])
+    assert np.isfinite(out[0]).all()
+    assert out[0][2] < out[1][2] - 0.05, (out[0][2], out[1][2])                 # 0.2 s of free fall is 0.2 m; the pin pulls the foot back to its anchor faster than gravity does
+    assert abs(out[0][tr]) < 0.5 * abs(out[1][tr]) + 0.05, (out[0][tr], out[1][tr])   # the welded joint is pulled towards its reference
+    # a connect between the two feet closes a loop across two chains: refused by name
+    loop = dict(base.a); loop["eq_obj2id"] = np.array([base.a["eq_obj2id"][0], base.a["eq_obj2id"][1], base.body_id("left_foot_link"), base.a["eq_obj2id"][3]], np.int32)
+    loop["eq_active"] = np.array([0, 0, 1, 0], np.int32)
+    with pytest.raises(engine.OdkError, match="one root-to-leaf path"):
+        engine.model_reduction(Model(loop))
 
 
 @pytest.mark.parametrize("impratio", [3.0, 1.0, 10.0])
