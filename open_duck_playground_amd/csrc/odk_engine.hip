@@ -85,6 +85,10 @@ using ShapeBE = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25, true>;
 // rewards, 14 actions) is the duck's, as the reference's own joystick.py is.  What adding it took: this line, the three dispatch
 // lines below that name it, and nothing in odk_kernels.h beyond admitting nv = 21 to the chain solver.
 using ShapeC = Shape<22, 21, 19, 15, 16, 156, 181, 78, 10, 15>;
+// A second one (tests/assets/biped12.xml): a biped with SIX-dof legs (hip yaw / roll / pitch, knee, ankle pitch / roll), 18 dofs, 12 actuators,
+// 16 bodies: serial chains of six (the chain solve's block size is the shape's CL), contact wrenches in their own floats (16 bodies' cfrc | crb
+// region is too small for them).  Physics kernels only, like ShapeC.
+using ShapeD = Shape<19, 18, 16, 12, 13, 135, 171, 72, 12, 18, false, 6>;
 
 struct KArgs {
   const DevModel* m;
@@ -1007,7 +1011,7 @@ static bool build_reduced_tables(DevModel& m) {
     int e = d;
     while (e + 1 < nr && rparent[e + 1] == e) e++;
     m.rchain_first[m.nrchain] = d; m.rchain_len[m.nrchain] = e - d + 1; m.nrchain++;
-    if (e - d + 1 > 5) ok = false;
+    if (e - d + 1 > 6) ok = false;      // (the chosen shape's own chain length is checked once the shape is known)
     d = e + 1;
   }
   // the reduced dofs above a foot must be exactly the six base dofs + one whole chain (foot_twist in odk_kernels.h)
@@ -1449,8 +1453,12 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   if (fits(ShapeA::NQ, ShapeA::NV, ShapeA::NB, ShapeA::NU, ShapeA::NJ, ShapeA::NM, ShapeA::NH, ShapeA::NROW, ShapeA::DT, ShapeA::DV)) mo->shape = 0;
   else if (fits(ShapeB::NQ, ShapeB::NV, ShapeB::NB, ShapeB::NU, ShapeB::NJ, ShapeB::NM, ShapeB::NH, ShapeB::NROW, ShapeB::DT, ShapeB::DV)) mo->shape = 1;
   else if (fits(ShapeC::NQ, ShapeC::NV, ShapeC::NB, ShapeC::NU, ShapeC::NJ, ShapeC::NM, ShapeC::NH, ShapeC::NROW, ShapeC::DT, ShapeC::DV)) mo->shape = 2;
+  else if (fits(ShapeD::NQ, ShapeD::NV, ShapeD::NB, ShapeD::NU, ShapeD::NJ, ShapeD::NM, ShapeD::NH, ShapeD::NROW, ShapeD::DT, ShapeD::DV)) mo->shape = 3;
   else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
+  for (int c = 0; c < m.nrchain; c++)
+    if (m.rchain_len[c] > (mo->shape == 3 ? ShapeD::CL : 5)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "a serial chain of %d (twin-merged) dofs: the kernels of this model shape solve chains of <= %d", m.rchain_len[c], mo->shape == 3 ? ShapeD::CL : 5); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
+  if (m.cone && mo->shape == 3) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: no cone instantiation of the six-dof-leg shape"); }
   if (m.cone && m.foot_prim != 0) {
     delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: the elliptic-cone kernels are built for convex (box / mesh) feet, not sphere / capsule feet");
   }
@@ -1535,7 +1543,8 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     memset(&m.lane_st[lane], 0, sizeof(LaneSt));
     if (mo->shape == 0) compute_statics<ShapeA>(m.lane_st[lane], &m, lane);
     else if (mo->shape == 1) compute_statics<ShapeB>(m.lane_st[lane], &m, lane);
-    else compute_statics<ShapeC>(m.lane_st[lane], &m, lane);
+    else if (mo->shape == 2) compute_statics<ShapeC>(m.lane_st[lane], &m, lane);
+    else compute_statics<ShapeD>(m.lane_st[lane], &m, lane);
   }
   *out = mo;
   return ODK_OK;
@@ -1560,7 +1569,7 @@ extern "C" int odk_model_reduced(const odk_model* m, int* paired, int* nvr, int*
 }
 extern "C" int odk_model_env_lds_floats(const odk_model* m) {
   if (!m) return -1;
-  return m->shape == 0 ? EnvL<ShapeA>::TOTAL : (m->shape == 1 ? EnvL<ShapeB>::TOTAL : EnvL<ShapeC>::TOTAL);
+  return m->shape == 0 ? EnvL<ShapeA>::TOTAL : (m->shape == 1 ? EnvL<ShapeB>::TOTAL : (m->shape == 2 ? EnvL<ShapeC>::TOTAL : EnvL<ShapeD>::TOTAL));
 }
 
 template <class S> static void fill_sizes(odk_batch* b) {
@@ -1590,7 +1599,7 @@ extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, i
   b->G = cfg->lanes_per_env == 64 ? 64 : 32;
   if (m->h.cone && cfg->lanes_per_env == 64) { delete b; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: the elliptic-cone kernels run 32 lanes per env"); }
   if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 32 && cfg->lanes_per_env != 64) { delete b; return fail(ODK_ERR_INVALID, "lanes_per_env must be 0, 32 or 64"); }
-  if (m->shape == 0) fill_sizes<ShapeA>(b); else if (m->shape == 1) fill_sizes<ShapeB>(b); else fill_sizes<ShapeC>(b);
+  if (m->shape == 0) fill_sizes<ShapeA>(b); else if (m->shape == 1) fill_sizes<ShapeB>(b); else if (m->shape == 2) fill_sizes<ShapeC>(b); else fill_sizes<ShapeD>(b);
   DevPRM hp;
   memset(&hp, 0, sizeof(hp));
   hp.nx = nx; hp.ny = ny; hp.nth = nth; hp.nsteps = nsteps;
@@ -1717,6 +1726,7 @@ static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st
     return b->model.h.foot_prim ? launch_sg<ShapeB, 32, 2>(which, a, st) : launch_sg<ShapeB, 32, 1>(which, a, st);
   }
   if (b->model.shape == 2) return b->G == 32 ? launch_phys<ShapeC, 32>(which, a, st) : hipErrorNotSupported;
+  if (b->model.shape == 3) return b->G == 32 ? launch_phys<ShapeD, 32>(which, a, st) : hipErrorNotSupported;
   if (b->model.h.cone) {      // the duck with elliptic cones (plane floor, checked at load): 32 lanes per env
     if (b->G != 32) return hipErrorNotSupported;
     return b->model.shape == 0 ? launch_sg<ShapeAE, 32, 0>(which, a, st) : launch_sg<ShapeBE, 32, 0>(which, a, st);
@@ -1853,7 +1863,7 @@ extern "C" int odk_batch_get_lds(odk_batch* b, float* host) {  // debug image of
 // named offsets into the LDS image for tests
 extern "C" int odk_lds_offset(const odk_batch* b, const char* name) {
   if (!b || !name) return -1;
-#define OFF(nm, field) if (!strcmp(name, nm)) return b->model.shape == 0 ? ShapeA::field : (b->model.shape == 1 ? ShapeB::field : ShapeC::field);
+#define OFF(nm, field) if (!strcmp(name, nm)) return b->model.shape == 0 ? ShapeA::field : (b->model.shape == 1 ? ShapeB::field : (b->model.shape == 2 ? ShapeC::field : ShapeD::field));
   OFF("qpos", O_QPOS) OFF("qvel", O_QVEL) OFF("warm", O_WARM) OFF("ctrl", O_CTRL) OFF("xpos", O_XPOS) OFF("xquat", O_XQUAT) OFF("crb", O_CRB)
   OFF("cdof", O_CDOF) OFF("M", O_M) OFF("HL", O_HL) OFF("qfrc_smooth", O_QFS) OFF("qacc_smooth", O_QAS) OFF("x", O_X) OFF("Ma", O_MA)
   OFF("search", O_GRAD) OFF("mv", O_MV) OFF("efc_D", O_D) OFF("efc_aref", O_AREF) OFF("jar", O_JAR) OFF("jv", O_JV) OFF("W", O_W)

@@ -65,7 +65,7 @@ struct EnvCfg {  // device copy of odk_env_config
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (floats), per environment.  Component-major (SoA) arrays: X[k * N + item].
-template <int NQ_, int NV_, int NB_, int NU_, int NJ_, int NM_, int NH_, int NROW_, int DT_, int DV_, bool CONE_ = false>
+template <int NQ_, int NV_, int NB_, int NU_, int NJ_, int NM_, int NH_, int NROW_, int DT_, int DV_, bool CONE_ = false, int CL_ = -1>
 struct Shape {
   static constexpr int NQ = NQ_, NV = NV_, NB = NB_, NU = NU_, NJ = NJ_, NM = NM_, NH = NH_, NROW = NROW_;
   static constexpr int DT = DT_;    // max dof depth, kinematic tree
@@ -89,7 +89,7 @@ struct Shape {
   // contact-row constants.  (Friction-loss rows, actuator constants and the foot hull were tried there too: no gain, their
   // loads from the L2-resident model are already covered.)
   static constexpr int SH_CT = NMR, SHARED = SH_CT + 42;
-  static constexpr int CL = (NV_ == 20 || NV_ == 21 || PAIRED) ? 5 : 0;   // max (reduced) chain length for chain_solve: every compiled shape is a floating base + <= 3 serial chains of <= 5 (reduced) dofs (0: generic path)
+  static constexpr int CL = CL_ >= 0 ? CL_ : ((NV_ == 20 || NV_ == 21 || PAIRED) ? 5 : 0);   // max (reduced) chain length for chain_solve: every compiled shape is a floating base + <= 3 serial chains of <= 5 (reduced) dofs (0: generic path)
   // persistent over the env step
   static constexpr int O_QPOS = 0;
   static constexpr int O_QVEL = O_QPOS + NQ;
@@ -129,16 +129,17 @@ struct Shape {
   static constexpr int O_JV = O_JAR + NROW;          // J search (scratch: candidate Jaref, forces, Hessian diagonal addend)
   static constexpr int O_SC = O_JAR;                 // [2][NJ] sin/cos of the half joint angles: P0 -> P1 only, ALIASES jar (born in P9)
   static_assert(2 * NJ <= NROW, "sin/cos must fit in the jar rows");
-  static constexpr int O_W = O_CFRC;                 // [NCROW][6] contact row wrenches [r x dir; dir]; ALIASES cfrc|crb, which
-                                                     // are dead once the bias forces and M entries exist (P3/P4); W is born in P8
-  static_assert(6 * NCROW <= 16 * NB, "contact wrenches must fit in the cfrc|crb region");
+  // [NCROW][6] contact row wrenches [r x dir; dir]: ALIAS cfrc|crb, which are dead once the bias forces and M entries exist (P3/P4; W is
+  // born in P8) -- where that region is large enough (18 bodies); a smaller robot gets its own floats behind the image
+  static constexpr bool W_FITS = 6 * NCROW <= 16 * NB;
   static constexpr int O_CDIST = O_JV + NROW;        // [12]
   static constexpr int O_CR = O_CDIST + NCON;        // [12][3] contact position relative to the base origin
   static constexpr int O_SCR = O_CR + 3 * NCON;      // scratch: foot twists, wrenches, 6x6 blocks, sensor inputs
+  // (the chain solve's scratch starts at S_K = 24 and takes 3 CL 7 + 27 floats: 156 for chains of five, 177 for chains of six)
 #ifdef ODK_PROFILE
   static constexpr int N_SCR = 208;                  // + S_PROF (20) + S_PROF2 (16: sub-phases of the height-field contacts)
 #else
-  static constexpr int N_SCR = 172;                  // no S_PROF slots outside profile builds
+  static constexpr int N_SCR = (24 + 21 * CL + 27) > 172 ? 180 : 172;      // no S_PROF slots outside profile builds
 #endif
   static constexpr int O_SENS = O_JV;                // sensordata[46]: born after the line search (P10, last substep only), ALIASES jv
   static_assert(NSENSD <= NROW, "sensordata must fit in the jv rows");
@@ -148,7 +149,9 @@ struct Shape {
   static constexpr int O_EQP = ((O_ACTF + NU + 3) / 4) * 4;
   static constexpr int EQP_W = 0, EQP_J = 12 * EQP_ROWS, EQP_D = EQP_J + EQP_ROWS * NV, EQP_AREF = EQP_D + EQP_ROWS, EQP_POS = EQP_AREF + EQP_ROWS;
   static constexpr int N_EQP = EQ ? ((EQP_POS + EQP_ROWS + 3) / 4) * 4 : 0;
-  static constexpr int TOTAL = O_EQP + N_EQP;
+  static constexpr int O_WX = O_EQP + N_EQP;         // the contact row wrenches of a robot with fewer than 18 bodies
+  static constexpr int O_W = W_FITS ? O_CFRC : O_WX;
+  static constexpr int TOTAL = O_WX + (W_FITS ? 0 : 6 * NCROW);
   static constexpr int ENV_STRIDE = TOTAL + 160;   // floats between the images of the two envs of a workgroup (odk_engine.hip EnvL::TOTAL: + info + action)
   // scratch sub-offsets
   static constexpr int S_VF = 0;      // [2][6] foot twist of the current vector
@@ -943,12 +946,12 @@ namespace odk {
 template <class S, int G>
 __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict__ m, int lane, bool overlap) {
   constexpr int NB = S::NB;
-  static_assert(4 * S::NROW >= 282 && 16 * S::NB >= 6 * 48 && 6 * S::NVR >= 56, "foot-foot scratch does not fit");
+  static_assert(4 * S::NROW >= 282 && (16 * S::NB >= 6 * 48 || !S::W_FITS) && 6 * S::NVR >= 56, "foot-foot scratch does not fit");
   float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR; float* SCR = L + S::O_SCR;
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
   float* FVb = L + S::O_D;       // [2][17][3] vertices | [2][30][3] normals
-  float* AE = L + S::O_CFRC;     // [<= 48][6]
+  float* AE = L + S::O_W;        // [<= 48][6]: cfrc | crb (dead here), or the wrench floats of a robot with fewer than 18 bodies (born later: P8)
   float* RS = L + S::O_BUF6;     // RP 12 | IP 12 | NEW 32
   const int row = lane >> 4, j = lane & 15;
   const bool act = overlap && row == 0;

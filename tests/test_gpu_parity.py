@@ -890,7 +890,7 @@ def test_differential_sweep(torch_cuda, oracle_mod, parity_log, task, lanes):
 
 
 
-def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, tag, eq_active=None, cone=False, overrides=None):
+def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, tag, eq_active=None, cone=False, overrides=None, dims=(22, 21, 15, 19, 16), red_dims=(21, 156, 181)):
     """(body of the two tests below)  SURVEY 8(f).3 / reference README.md:74-85 ("adding a robot"): tests/assets/tail_biped.xml -- a biped with a five-link tail,
     written for this test: 21 dofs, 15 position actuators, 19 bodies, box feet, its own masses / lengths / axes / gains -- compiled by
     mjcf.py, its lane tables built by tables.py (nothing by hand), loaded as the kernels' third Shape and run through the PHYSICS
@@ -907,9 +907,9 @@ def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, 
         model = Model({**model.a, "eq_active": np.asarray(eq_active, np.int32)})
     if overrides:
         model = Model({**model.a, **overrides})
-    assert (model.nq, model.nv, model.nu, model.nbody, model.njnt) == (22, 21, 15, 19, 16)
+    assert (model.nq, model.nv, model.nu, model.nbody, model.njnt) == dims
     red = engine.model_reduction(model)
-    assert red["paired"] == 0 and red["nvr"] == 21 and red["nMr"] == 156 and red["nHr"] == 181
+    assert red["paired"] == 0 and (red["nvr"], red["nMr"], red["nHr"]) == red_dims
     om = oracle_mod.OracleModel(model.blob())
     # equality rows come first in the oracle's row order (connects 3 rows each, welds 6, joints 1); the kernels keep theirs beside the row arrays
     ne_rows = 0 if eq_active is None else int(sum(a * {0: 3, 1: 6, 2: 1}[int(t)] for a, t in zip(eq_active, np.asarray(model.a["eq_type"]).reshape(-1))))
@@ -939,7 +939,7 @@ def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, 
     o = {k: b.lds_offset(k) for k in ("xpos", "M", "qfrc_smooth", "qacc_smooth", "contact_dist", "efc_D", "efc_aref", "qacc", "sensordata", "actuator_force", "scr")}
     tabs = build_kernel_tables(model.a); lay = reduced_layout(model.a)
     Mi, Mj = lay["ei"], lay["ej"]
-    assert np.array_equal(Mi, tabs["k_M_i"]) and len(Mi) == 156
+    assert np.array_equal(Mi, tabs["k_M_i"]) and len(Mi) == red_dims[1]
     nfl = len(tabs["k_fl_dof"])
     W = dict(xpos=0, M=0, qfs=0, qas=0, dist=0, D=0, aref=0, qacc=0, qpos=0, qvel=0, sens=0, force=0)
     prng = np.random.default_rng(5)
@@ -1019,6 +1019,13 @@ def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, 
 def test_a_robot_that_is_not_the_duck(torch_cuda, oracle_mod, parity_log):
     """tests/assets/tail_biped.xml through the physics kernels at the duck's bounds (see the helper above)."""
     _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped.xml", "tail_biped")
+
+
+def test_a_biped_with_six_dof_legs(torch_cuda, oracle_mod, parity_log):
+    """tests/assets/biped12.xml -- hip yaw / roll / pitch, knee, ankle pitch / roll per leg: what most humanoids have, one joint more per
+    chain than the duck -- through the physics kernels at the duck's bounds: the fourth model shape (18 dofs, 12 actuators, 16 bodies),
+    whose chain solve works blocks of six and whose contact wrenches have their own floats (16 bodies' cfrc | crb region is too small)."""
+    _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "biped12.xml", "biped12", dims=(19, 18, 12, 16, 13), red_dims=(18, 135, 171))
 
 
 def test_equality_joint_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log):
