@@ -276,6 +276,27 @@ def test_loader_takes_joint_couplings_and_refuses_other_equalities_by_name():
         engine.model_reduction(Model(eq))
 
 
+def test_loader_takes_a_biped_with_six_dof_legs():
+    """tests/assets/biped12.xml (hip yaw / roll / pitch, knee, ankle pitch / roll per leg): compiled by mjcf.py, matched by `odk_model_load` against
+    the fourth instantiated shape (18 dofs, 12 actuators, 16 bodies, chains of six); equality rows and elliptic cones are not compiled into
+    that shape and are refused by name."""
+    import os
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model
+    m = Model.from_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "biped12.xml"))
+    assert (m.nq, m.nv, m.nu, m.nbody, m.njnt) == (19, 18, 12, 16, 13)
+    red = engine.model_reduction(m)
+    assert (red["paired"], red["nvr"], red["nMr"], red["nHr"]) == (0, 18, 135, 171)
+    with pytest.raises(engine.OdkError, match="six-dof-leg shape"):
+        engine.model_reduction(Model({**m.a, "opt_cone": np.array([1], np.int32)}))
+    j = m.joint_id
+    eq = dict(m.a, eq_type=np.array([2], np.int32), eq_obj1id=np.array([j("left_ankle_pitch")], np.int32), eq_obj2id=np.array([j("left_knee")], np.int32),
+              eq_active=np.array([1], np.int32), eq_data=np.array([[0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]], np.float64), eq_solref=np.array([[0.02, 1.0]]),
+              eq_solimp=np.array([[0.9, 0.95, 0.001, 0.5, 2.0]]), neq=np.array([1], np.int32))
+    with pytest.raises(engine.OdkError, match="third model shape only"):
+        engine.model_reduction(Model(eq))
+
+
 def test_compiler_refuses_colliding_primitives(tmp_path):
     from open_duck_playground_amd import mjcf
     xml = """<mujoco><compiler angle="radian"/><worldbody>
