@@ -107,7 +107,8 @@ void odk_obs_sizes(int env_kind, int* nobs, int* npriv);
  * Solver options read from the blob: opt_iterations / opt_ls_iterations, opt_impratio, and the optional opt_cone (0 pyramidal, 1 elliptic:
  * the elliptic-cone instantiations of the kernels -- hull feet, 32 lanes per env; sphere / capsule feet refuse it).  The optional eq_*
  * records (<equality>): joint couplings between two hinges of one serial chain, and connect / weld constraints whose two bodies lie on one
- * root-to-leaf path of the tree (or body2 = the world; at most two with nine rows), are taken for the third model shape; every other
+ * root-to-leaf path of the tree (or body2 = the world) or on the two foot chains (a closed loop) -- at most two with nine rows --, are
+ * taken for the third model shape; every other
  * ACTIVE equality is refused by name. */
 int odk_model_load(const void* blob, uint64_t len, odk_model** out);
 void odk_model_free(odk_model* m);

@@ -1468,7 +1468,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
     // <equality><connect | weld>: "path rows" (odk_kernels.h) -- the two bodies on ONE root-to-leaf path of the tree, or body2 = the world,
     // so that the rows' J^T D J only touches entries the tree layout has; at most EQP_MAX constraints / EQP_ROWS rows.  In MJX's row order:
     // connects first, then welds.
-    m.neqp = 0; m.eqp_nrow = 0;
+    m.neqp = 0; m.eqp_nrow = 0; m.eqp_cross = 0;
     for (int d = 0; d < MAXV; d++) m.dof_eqp[d] = 0;
     for (int pass = 0; pass < 2; pass++)
       for (int k = 0; k < eq_n; k++) {
@@ -1489,8 +1489,15 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
           for (int b = s2 ? b2 : b1; b > 0; b = m.body_parent[b])
             for (int d = 0; d < m.nv; d++) if (m.dof_body[d] == b) above[s2] |= 1u << d;
         if ((above[0] & above[1]) != above[0] && (above[0] & above[1]) != above[1]) {
-          delete mo;
-          return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d): the two bodies must lie on one root-to-leaf path of the tree (or body2 be the world): a constraint across two chains closes a loop the tree layout has no entries for", kind, k);
+          // two chains: a closed loop.  The virtual tree (the Hessian layout of an active foot-foot contact: second leg below the first foot)
+          // has an entry for every pair of dofs of base + the two foot chains -- a loop between exactly those is taken, on that layout
+          unsigned legs = 0x3Fu;
+          for (int f = 0; f < 2; f++) for (int t = 0; t < m.foot_rchain_len[f]; t++) legs |= 1u << (m.foot_rchain_first[f] + t);
+          if (((above[0] | above[1]) & ~legs) != 0u || m.paired) {
+            delete mo;
+            return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d): the two bodies must lie on one root-to-leaf path of the tree (or body2 be the world), or on the two foot chains: another loop has no entries in the Hessian's layouts", kind, k);
+          }
+          m.eqp_cross = 1;
         }
         for (int d = 0; d < m.nv; d++) m.dof_eqp[d] |= (((above[0] >> d) & 1) << (2 * c)) | (((above[1] >> d) & 1) << (2 * c + 1));
         const double* da = eq_data + 11 * k;

@@ -2924,7 +2924,9 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
   }
   ODK_SYNC();
   ODK_PROF(11);
-  const bool any_ffa = __builtin_amdgcn_ballot_w64(ff_active) != 0;   // wave-uniform: some env has an active foot-foot row
+  // wave-uniform: some env has an active foot-foot row -- or the model has a connect / weld between the two foot chains (a closed loop): both need
+  // Hessian entries between the two legs, which the virtual tree's layout has
+  const bool any_ffa = __builtin_amdgcn_ballot_w64(ff_active) != 0 || (S::EQ && m->eqp_cross != 0);
   // contact / diagonal terms of one reduced Hessian entry e (packed: DevModel::R_ent) on top of the inertia value v
   auto hess_entry = [&](int e, float v) -> float {
     const int i = e & 31, j = (e >> 5) & 31, fi = (e >> 10) & 3, fj = (e >> 12) & 3;

@@ -162,6 +162,7 @@ struct DevModel {
   // odk_kernels.h).  A row's Jacobian entry for dof i is m1_i (w1 . cdof_i) - m2_i (w2 . cdof_i) with a wrench per body and m = "dof i is above
   // the body"; both supports lie on the path, so J^T D J only touches entries the tree layout has.  dof_eqp: bit 2c = above body1 of
   // constraint c, bit 2c + 1 = above body2.
+  int eqp_cross;     // some path constraint ties the two foot chains together (a closed loop): its rows' J^T D J needs the VIRTUAL tree's entries (second leg below the first foot)
   int neqp, eqp_nrow, eqp_type[EQP_MAX], eqp_b1[EQP_MAX], eqp_b2[EQP_MAX], eqp_row0[EQP_MAX], dof_eqp[MAXV];
   float eqp_a1[EQP_MAX][3], eqp_a2[EQP_MAX][3], eqp_relq[EQP_MAX][4], eqp_ts[EQP_MAX], eqp_imp[EQP_MAX][9], eqp_invw[EQP_MAX][2];
   int cone;      // <option cone>: 0 pyramidal, 1 elliptic (shapes with S::ELL; odk_kernels.h "elliptic cones")

@@ -239,8 +239,8 @@ def test_compiler_refuses_sections_the_kernels_do_not_model(tmp_path, extra, wha
 def test_loader_takes_joint_couplings_and_refuses_other_equalities_by_name():
     """<equality> joint / connect / weld compile (mjcf.py) and the float64 oracle steps all of them (tests/test_oracle_equality.py).  The
     kernels of the third model shape model <equality><joint> rows between two hinges of one serial chain and connect / weld rows between two
-    bodies of one root-to-leaf path (or a body and the world): `odk_model_load` takes those, and refuses -- naming the constraint -- a
-    connect / weld across two chains, a coupling across two chains, a joint in two rows, a third row, and any equality on the duck's shapes;
+    bodies of one root-to-leaf path (or a body and the world): `odk_model_load` takes those, (or the two foot chains: a closed loop), and refuses -- naming the constraint -- a
+    connect / weld closing another loop, a coupling across two chains, a joint in two rows, a third row, and any equality on the duck's shapes;
     a model whose equalities are all switched off (eq_active = 0: MuJoCo's own off switch) loads."""
     import os
     from open_duck_playground_amd import engine
@@ -249,13 +249,18 @@ def test_loader_takes_joint_couplings_and_refuses_other_equalities_by_name():
     act = lambda *a: Model({**m.a, "eq_active": np.array(a, np.int32)})
     assert engine.model_reduction(m)["nvr"] == 21                         # all four (two couplings, the pinned foot, the welded tail tip): taken
     assert engine.model_reduction(act(1, 1, 0, 0))["nvr"] == 21          # the two joint couplings alone
-    # a connect / weld between the two feet: two chains, a closed loop the tree layout has no entries for
+    # a connect / weld between the two FEET closes a loop over the two leg chains: taken (the virtual tree's layout has the entries);
+    # one between a foot and the tail closes a loop the Hessian's layouts have no entries for: refused by name
     for k, kind in ((2, "connect"), (3, "weld")):
-        loop = dict(m.a); o2 = np.array(m.a["eq_obj2id"], np.int32); o1 = np.array(m.a["eq_obj1id"], np.int32)
-        o1[k] = m.body_id("right_foot_link"); o2[k] = m.body_id("left_foot_link")
-        loop["eq_obj1id"] = o1; loop["eq_obj2id"] = o2; loop["eq_active"] = np.array([0, 0, k == 2, k == 3], np.int32)
-        with pytest.raises(engine.OdkError, match=rf"<equality><{kind}> \(constraint {k}\): the two bodies must lie on one root-to-leaf path"):
-            engine.model_reduction(Model(loop))
+        for other, ok in (("left_foot_link", True), ("tail_3", False)):
+            loop = dict(m.a); o2 = np.array(m.a["eq_obj2id"], np.int32); o1 = np.array(m.a["eq_obj1id"], np.int32)
+            o1[k] = m.body_id("right_foot_link"); o2[k] = m.body_id(other)
+            loop["eq_obj1id"] = o1; loop["eq_obj2id"] = o2; loop["eq_active"] = np.array([0, 0, k == 2, k == 3], np.int32)
+            if ok:
+                assert engine.model_reduction(Model(loop))["nvr"] == 21
+            else:
+                with pytest.raises(engine.OdkError, match=rf"<equality><{kind}> \(constraint {k}\): the two bodies must lie on one root-to-leaf path.*another loop has no entries"):
+                    engine.model_reduction(Model(loop))
     assert engine.model_reduction(act(0, 0, 0, 0))["nvr"] == 21
     # a coupling across two chains (left knee <- right knee): no entry of the tree layout
     cross = dict(m.a); cross["eq_obj2id"] = np.array([m.a["eq_obj2id"][0], m.joint_id("right_knee"), 0, 0], np.int32); cross["eq_active"] = np.array([1, 1, 0, 0], np.int32)

@@ -1061,8 +1061,8 @@ def test_connect_and_weld_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log
     constraints active -- the two joint couplings, the right foot pinned to the world (connect: 3 rows), the tail tip welded to its parent link
     (weld: 6 rows) -- through the physics kernels against the float64 oracle at the duck's bounds.  Connect / weld run as "path rows"
     (odk_kernels.h): both bodies on one root-to-leaf path of the tree (or the world), a wrench per body and row, the Jacobian entry of a
-    dof from ITS motion vector, the rows' J^T D J added to Hessian entries the tree layout already has.  A connect between the two feet
-    (two chains: a closed loop) is refused by name.  And the rows must MATTER."""
+    dof from ITS motion vector, the rows' J^T D J added to Hessian entries the tree layout already has.  (A loop between the two foot
+    chains: test_a_closed_loop_between_the_feet.)  And the rows must MATTER."""
     W, T10 = _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped_equality.xml", "tail_biped_equality_all", eq_active=(1, 1, 1, 1))
     import os
     from open_duck_playground_amd import engine
@@ -1084,10 +1084,37 @@ def test_connect_and_weld_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log
     assert np.isfinite(out[0]).all()
     assert out[0][2] < out[1][2] - 0.05, (out[0][2], out[1][2])                 # 0.2 s of free fall is 0.2 m; the pin pulls the foot back to its anchor faster than gravity does
     assert abs(out[0][tr]) < 0.5 * abs(out[1][tr]) + 0.05, (out[0][tr], out[1][tr])   # the welded joint is pulled towards its reference
-    # a connect between the two feet closes a loop across two chains: refused by name
-    loop = dict(base.a); loop["eq_obj2id"] = np.array([base.a["eq_obj2id"][0], base.a["eq_obj2id"][1], base.body_id("left_foot_link"), base.a["eq_obj2id"][3]], np.int32)
-    loop["eq_active"] = np.array([0, 0, 1, 0], np.int32)
-    with pytest.raises(engine.OdkError, match="one root-to-leaf path"):
+
+
+def test_a_closed_loop_between_the_feet(torch_cuda, oracle_mod, parity_log):
+    """tests/assets/tail_biped_loop.xml: the two foot links tied together by a ball joint (<equality><connect> across the two leg chains: a CLOSED
+    kinematic loop) plus the welded tail tip, through the physics kernels against the float64 oracle at the duck's bounds.  The loop's rows are
+    path rows whose two supports lie on different chains; their J^T D J needs Hessian entries between the two legs, which the VIRTUAL tree's
+    layout has (the layout an active foot-foot contact switches to: second leg below the first foot) -- a model with such a constraint stays on
+    it.  A loop through the tail's chain has no such entries and is refused by name.  And the loop must MATTER."""
+    W, T10 = _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped_loop.xml", "tail_biped_loop", eq_active=(1, 1))
+    import os
+    from open_duck_playground_amd import engine
+    from open_duck_playground_amd.model import Model
+    from conftest import ROOT
+    torch = torch_cuda
+    base = Model.from_xml(os.path.join(ROOT, "tests", "assets", "tail_biped_loop.xml"), sim_dt=0.002)
+    out = []
+    for act in ((1, 0), (0, 0)):
+        m = Model({**base.a, "eq_active": np.asarray(act, np.int32)})
+        b = engine.Batch(m, 4)
+        q = np.tile(np.asarray(m.a["key_qpos"], np.float64), (4, 1)); q[:, 2] += 0.4
+        c = np.tile(np.asarray(m.a["key_ctrl"]), (4, 1))
+        c[:, 1] = 0.4; c[:, 11] = -0.4          # both hip rolls driven outwards: the tied feet cannot spread
+        b.set_state(q, np.zeros((4, m.nv)), np.zeros((4, m.nv)))
+        b.physics_step(torch.tensor(c, dtype=torch.float32, device="cuda"), 100)
+        out.append(b.get_state()[0][0].copy())
+        b.close()
+    lr, rr = int(base.a["jnt_qposadr"][base.joint_id("left_hip_roll")]), int(base.a["jnt_qposadr"][base.joint_id("right_hip_roll")])
+    spread = lambda q: abs(q[lr] - q[rr])
+    assert np.isfinite(out[0]).all() and spread(out[0]) < 0.6 * spread(out[1]), (spread(out[0]), spread(out[1]))
+    loop = dict(base.a); o2 = np.array(base.a["eq_obj2id"], np.int32); o2[0] = base.body_id("tail_3"); loop["eq_obj2id"] = o2
+    with pytest.raises(engine.OdkError, match="another loop has no entries"):
         engine.model_reduction(Model(loop))
 
 
