@@ -108,7 +108,7 @@ void odk_obs_sizes(int env_kind, int* nobs, int* npriv);
  * the elliptic-cone instantiations of the kernels -- hull feet, 32 lanes per env; sphere / capsule feet refuse it).  The optional eq_*
  * records (<equality>): joint couplings between two hinges of one serial chain, and connect / weld constraints whose two bodies lie on one
  * root-to-leaf path of the tree (or body2 = the world) or on the two foot chains (a closed loop) -- at most two with nine rows --, are
- * taken for the third model shape; every other
+ * taken for the third and fourth model shapes; every other
  * ACTIVE equality is refused by name. */
 int odk_model_load(const void* blob, uint64_t len, odk_model** out);
 void odk_model_free(odk_model* m);

@@ -88,7 +88,7 @@ using ShapeC = Shape<22, 21, 19, 15, 16, 156, 181, 78, 10, 15>;
 // A second one (tests/assets/biped12.xml): a biped with SIX-dof legs (hip yaw / roll / pitch, knee, ankle pitch / roll), 18 dofs, 12 actuators,
 // 16 bodies: serial chains of six (the chain solve's block size is the shape's CL), contact wrenches in their own floats (16 bodies' cfrc | crb
 // region is too small for them).  Physics kernels only, like ShapeC.
-using ShapeD = Shape<19, 18, 16, 12, 13, 135, 171, 72, 12, 18, false, 6>;
+using ShapeD = Shape<19, 18, 16, 12, 13, 135, 171, 72, 12, 18, false, 6, true>;      // (chains of six; equality rows and elliptic cones compiled in, as ShapeC)
 
 struct KArgs {
   const DevModel* m;
@@ -1458,7 +1458,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   for (int c = 0; c < m.nrchain; c++)
     if (m.rchain_len[c] > (mo->shape == 3 ? ShapeD::CL : 5)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "a serial chain of %d (twin-merged) dofs: the kernels of this model shape solve chains of <= %d", m.rchain_len[c], mo->shape == 3 ? ShapeD::CL : 5); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
-  if (m.cone && mo->shape == 3) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: no cone instantiation of the six-dof-leg shape"); }
+
   if (m.cone && m.foot_prim != 0) {
     delete mo; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: the elliptic-cone kernels are built for convex (box / mesh) feet, not sphere / capsule feet");
   }
@@ -1474,12 +1474,12 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       for (int k = 0; k < eq_n; k++) {
         if (!eq_active[k] || eq_type[k] != pass) continue;
         const char* kind = pass == 0 ? "connect" : "weld";
-        const bool shape_ok = mo->shape == 2 && !m.paired;
+        const bool shape_ok = (mo->shape == 2 || mo->shape == 3) && !m.paired;      // ShapeC / ShapeD: Shape::EQ
         const int nrow = pass == 0 ? 3 : 6;
         if (!shape_ok || m.neqp == EQP_MAX || m.eqp_nrow + nrow > EQP_ROWS) {
           delete mo;
           return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d) is active: %s", kind, k,
-                      shape_ok ? "the kernels hold at most two connect / weld constraints with nine rows in total" : "equality rows are compiled into the third model shape only (the duck's kernels carry none)");
+                      shape_ok ? "the kernels hold at most two connect / weld constraints with nine rows in total" : "equality rows are compiled into the third and fourth model shapes only (the duck's kernels carry none)");
         }
         const int c = m.neqp, b1 = eq_o1[k], b2 = eq_o2[k] < 0 ? 0 : eq_o2[k];
         if (b1 < 1 || b1 >= m.nb || b2 >= m.nb) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<equality><%s> (constraint %d): bad body ids", kind, k); }
@@ -1513,11 +1513,11 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       }
     for (int k = 0; k < eq_n; k++) {
       if (!eq_active[k] || eq_type[k] != 2) continue;
-      const bool shape_ok = mo->shape == 2 && !m.paired;      // ShapeC::EQ
+      const bool shape_ok = (mo->shape == 2 || mo->shape == 3) && !m.paired;      // ShapeC / ShapeD: Shape::EQ
       if (!shape_ok || m.neq == EQ_MAX) {
         delete mo;
         return fail(ODK_ERR_UNSUPPORTED, "<equality><joint> (constraint %d) is active: %s", k,
-                    shape_ok ? "the kernels hold at most two equality rows" : "equality rows are compiled into the third model shape only (the duck's kernels carry none)");
+                    shape_ok ? "the kernels hold at most two equality rows" : "equality rows are compiled into the third and fourth model shapes only (the duck's kernels carry none)");
       }
       const int r = m.neq, j1 = eq_o1[k], j2 = eq_o2[k];
       if (j1 < 1 || j1 >= m.nj || j2 >= m.nj || j2 == 0 || j2 == j1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "<equality><joint> (constraint %d): hinge joints expected", k); }

@@ -65,7 +65,7 @@ struct EnvCfg {  // device copy of odk_env_config
 
 // ------------------------------------------------------------------------------------------------
 // LDS layout (floats), per environment.  Component-major (SoA) arrays: X[k * N + item].
-template <int NQ_, int NV_, int NB_, int NU_, int NJ_, int NM_, int NH_, int NROW_, int DT_, int DV_, bool CONE_ = false, int CL_ = -1>
+template <int NQ_, int NV_, int NB_, int NU_, int NJ_, int NM_, int NH_, int NROW_, int DT_, int DV_, bool CONE_ = false, int CL_ = -1, bool OPT_ = false>
 struct Shape {
   static constexpr int NQ = NQ_, NV = NV_, NB = NB_, NU = NU_, NJ = NJ_, NM = NM_, NH = NH_, NROW = NROW_;
   static constexpr int DT = DT_;    // max dof depth, kinematic tree
@@ -76,11 +76,11 @@ struct Shape {
   static constexpr bool PAIRED = (NV_ == 30);
   // <equality><joint> rows (DevModel::neq) are compiled into this shape's kernels: the third shape (tests/assets/tail_biped*.xml) -- the
   // duck's shapes have no equality and do not pay for the code
-  static constexpr bool EQ = (NV_ == 21);
+  static constexpr bool EQ = (NV_ == 21) || OPT_;      // (OPT_: a shape that asks for the optional constraint code -- equality rows, elliptic cones as a runtime switch)
   // <option cone="elliptic"> (DevModel::cone) is compiled into the same shape's kernels: a contact's four row lanes hold normal | tangent 1 |
   // tangent 2 | nothing instead of the four pyramid edges, and the cost of a contact is the cone's (odk_kernels.h "elliptic cones")
   static constexpr bool CONE = CONE_;                   // an instantiation that is ONLY launched for cone = 1 models: the pyramid code is compiled out
-  static constexpr bool ELL = (NV_ == 21) || CONE_;    // (the duck's shapes: their own instantiations with CONE_ = true, launched for models with cone = 1 only)
+  static constexpr bool ELL = (NV_ == 21) || CONE_ || OPT_;    // (the duck's shapes: their own instantiations with CONE_ = true, launched for models with cone = 1 only)
   static constexpr int NVR = PAIRED ? 20 : NV_;    // reduced dofs
   static constexpr int NMR = PAIRED ? 145 : NM_;   // entries of the reduced tree layout
   static constexpr int NHR = PAIRED ? 170 : NH_;   // entries of the reduced virtual-tree layout

@@ -277,14 +277,14 @@ def test_loader_takes_joint_couplings_and_refuses_other_equalities_by_name():
     eq = dict(duck.a, eq_type=np.array([2], np.int32), eq_obj1id=np.array([j("left_ankle")], np.int32), eq_obj2id=np.array([j("left_knee")], np.int32),
               eq_active=np.array([1], np.int32), eq_data=np.array([[0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]], np.float64), eq_solref=np.array([[0.02, 1.0]]),
               eq_solimp=np.array([[0.9, 0.95, 0.001, 0.5, 2.0]]), neq=np.array([1], np.int32))
-    with pytest.raises(engine.OdkError, match="third model shape only"):
+    with pytest.raises(engine.OdkError, match="third and fourth model shapes only"):
         engine.model_reduction(Model(eq))
 
 
 def test_loader_takes_a_biped_with_six_dof_legs():
     """tests/assets/biped12.xml (hip yaw / roll / pitch, knee, ankle pitch / roll per leg): compiled by mjcf.py, matched by `odk_model_load` against
-    the fourth instantiated shape (18 dofs, 12 actuators, 16 bodies, chains of six); equality rows and elliptic cones are not compiled into
-    that shape and are refused by name."""
+    the fourth instantiated shape (18 dofs, 12 actuators, 16 bodies, chains of six), which carries the optional constraint code (equality rows,
+    elliptic cones) like the third."""
     import os
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.model import Model
@@ -292,14 +292,12 @@ def test_loader_takes_a_biped_with_six_dof_legs():
     assert (m.nq, m.nv, m.nu, m.nbody, m.njnt) == (19, 18, 12, 16, 13)
     red = engine.model_reduction(m)
     assert (red["paired"], red["nvr"], red["nMr"], red["nHr"]) == (0, 18, 135, 171)
-    with pytest.raises(engine.OdkError, match="six-dof-leg shape"):
-        engine.model_reduction(Model({**m.a, "opt_cone": np.array([1], np.int32)}))
+    assert engine.model_reduction(Model({**m.a, "opt_cone": np.array([1], np.int32)}))["nvr"] == 18      # elliptic cones: compiled into this shape too
     j = m.joint_id
     eq = dict(m.a, eq_type=np.array([2], np.int32), eq_obj1id=np.array([j("left_ankle_pitch")], np.int32), eq_obj2id=np.array([j("left_knee")], np.int32),
               eq_active=np.array([1], np.int32), eq_data=np.array([[0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0]], np.float64), eq_solref=np.array([[0.02, 1.0]]),
               eq_solimp=np.array([[0.9, 0.95, 0.001, 0.5, 2.0]]), neq=np.array([1], np.int32))
-    with pytest.raises(engine.OdkError, match="third model shape only"):
-        engine.model_reduction(Model(eq))
+    assert engine.model_reduction(Model(eq))["nvr"] == 18          # a joint coupling inside one leg: taken, like the third shape's
 
 
 def test_compiler_refuses_colliding_primitives(tmp_path):

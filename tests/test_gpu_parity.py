@@ -1028,6 +1028,22 @@ def test_a_biped_with_six_dof_legs(torch_cuda, oracle_mod, parity_log):
     _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "biped12.xml", "biped12", dims=(19, 18, 12, 16, 13), red_dims=(18, 135, 171))
 
 
+def test_the_six_dof_biped_with_elliptic_cones_and_a_coupled_ankle(torch_cuda, oracle_mod, parity_log):
+    """The optional constraint code is compiled into the fourth shape as into the third: biped12.xml with `cone="elliptic"` (impratio 2) AND a joint
+    coupling inside the left leg (ankle pitch = -0.5 knee, the parallel-bar ankle of many humanoids) through the physics kernels at the duck's bounds."""
+    from open_duck_playground_amd.model import Model
+    import os
+    from conftest import ROOT
+    base = Model.from_xml(os.path.join(ROOT, "tests", "assets", "biped12.xml"), sim_dt=0.002)
+    j = base.joint_id
+    over = dict(opt_cone=np.array([1], np.int32), opt_impratio=np.array([2.0]),
+                eq_type=np.array([2], np.int32), eq_obj1id=np.array([j("left_ankle_pitch")], np.int32), eq_obj2id=np.array([j("left_knee")], np.int32),
+                eq_active=np.array([1], np.int32), eq_data=np.array([[0.0, -0.5, 0, 0, 0, 0, 0, 0, 0, 0, 0]], np.float64), eq_solref=np.array([[0.02, 1.0]]),
+                eq_solimp=np.array([[0.9, 0.95, 0.001, 0.5, 2.0]]), neq=np.array([1], np.int32), names_eq=np.array(["ankle_bar"]))
+    _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "biped12.xml", "biped12_elliptic_coupled", eq_active=(1,), cone=True, overrides=over,
+                                       dims=(19, 18, 12, 16, 13), red_dims=(18, 135, 171))
+
+
 def test_equality_joint_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log):
     """SURVEY 8(f).3, <equality> (reference README.md:74-85): tests/assets/tail_biped_equality.xml with its two joint couplings ACTIVE
     (tail_yaw_2 = 0.5 tail_yaw_1; left_ankle = 0.1 - 0.5 knee + 0.2 knee^2, solref 0.01) -- rows between two dofs of one serial chain,
