@@ -890,7 +890,7 @@ def test_differential_sweep(torch_cuda, oracle_mod, parity_log, task, lanes):
 
 
 
-def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, tag, eq_active=None, cone=False, overrides=None, dims=(22, 21, 15, 19, 16), red_dims=(21, 156, 181)):
+def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, tag, eq_active=None, cone=False, overrides=None, dims=(22, 21, 15, 19, 16), red_dims=(21, 156, 181), ill_bound=0.5):
     """(body of the two tests below)  SURVEY 8(f).3 / reference README.md:74-85 ("adding a robot"): tests/assets/tail_biped.xml -- a biped with a five-link tail,
     written for this test: 21 dofs, 15 position actuators, 19 bodies, box feet, its own masses / lengths / axes / gains -- compiled by
     mjcf.py, its lane tables built by tables.py (nothing by hand), loaded as the kernels' third Shape and run through the PHYSICS
@@ -1012,7 +1012,7 @@ def _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, xml, 
     if cone:      # the states must exercise the cone itself (sliding contacts: measured 58), the plain quadratic zone (sticking ones: 13) and separating contacts (11)
         assert W_zone.get("middle", 0) >= 20 and W_zone.get("bottom", 0) >= 3 and W_zone.get("top", 0) >= 4, W_zone      # (impratio 10: 67 / 4 / 11)
     parity_log.check(f"{tag}/one_mjx_step", dict(STAGE_BOUNDS, force=2e-4, tie_fraction=0.15), tie_fraction=n_tie / n, **W)
-    parity_log.check(f"{tag}/ten_substeps", dict(TEN_BOUNDS, ill_fraction=0.5), ill_fraction=n_ill / n, **T10)
+    parity_log.check(f"{tag}/ten_substeps", dict(TEN_BOUNDS, ill_fraction=ill_bound), ill_fraction=n_ill / n, **T10)
     return W, T10
 
 
@@ -1079,7 +1079,8 @@ def test_connect_and_weld_rows_in_the_kernels(torch_cuda, oracle_mod, parity_log
     (odk_kernels.h): both bodies on one root-to-leaf path of the tree (or the world), a wrench per body and row, the Jacobian entry of a
     dof from ITS motion vector, the rows' J^T D J added to Hessian entries the tree layout already has.  (A loop between the two foot
     chains: test_a_closed_loop_between_the_feet.)  And the rows must MATTER."""
-    W, T10 = _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped_equality.xml", "tail_biped_equality_all", eq_active=(1, 1, 1, 1))
+    W, T10 = _robot_through_the_physics_kernels(torch_cuda, oracle_mod, parity_log, "tail_biped_equality.xml", "tail_biped_equality_all", eq_active=(1, 1, 1, 1),
+                                                ill_bound=0.6)      # (measured 31 of 64: a foot pinned centimetres from where the random state puts it is stiff)
     import os
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.model import Model
