@@ -37,6 +37,8 @@ enum odk_status {
   ODK_ERR_NOMEM = -4
 };
 
+/* Observation row strides of the duck (nu = 14 actuators).  For a robot with nu actuators (odk_model_obs_sizes): joystick.py:570-615
+ * state 17 + 6 nu, privileged_state = state + 69 + 3 nu; standing.py:524-565 state 15 + 5 nu, privileged_state = state + 26 + 3 nu. */
 #define ODK_NOBS 101     /* obs["state"]            joystick.py:570-589 */
 #define ODK_NPRIV 212    /* obs["privileged_state"] joystick.py:596-615 */
 #define ODK_NOBS_STANDING 85    /* standing.py:524-540 */
@@ -44,7 +46,7 @@ enum odk_status {
 #define ODK_ENV_JOYSTICK 0
 #define ODK_ENV_STANDING 1
 #define ODK_NMETRIC 8    /* reward/cost terms (7) + swing_peak, joystick.py:304-311 */
-#define ODK_NU 14
+#define ODK_NU 14        /* the duck's actuators; odk_model_dims reports a model's own count */
 
 /* Environment configuration == default_config() of the reference (joystick.py:49-102). */
 typedef struct {
@@ -60,7 +62,7 @@ typedef struct {
   int32_t autoreset;       /* BraxAutoResetWrapper on/off */
   int32_t episode_length;  /* EpisodeWrapper */
   int32_t n_substeps;      /* ctrl_dt / sim_dt */
-  int32_t lanes_per_env;   /* kernel geometry: 32 or 64 (0 = default) */
+  int32_t lanes_per_env;   /* kernel geometry hint: 32 or 64 (0 = default); see odk_batch_lanes */
   int32_t env_kind;        /* ODK_ENV_JOYSTICK (joystick.py) or ODK_ENV_STANDING (standing.py): selects the obs layout
                               (101/212 vs 85/153 floats per env -- the output row strides) and the reward table */
   float reset_base_qvel;   /* half-range of the base velocity noise at reset: joystick.py:253 0.05, standing.py:247 0.5 */
@@ -72,8 +74,8 @@ typedef struct {
 
 /* Caller-owned device outputs of reset/step (any pointer may be NULL to skip it). */
 typedef struct {
-  float* obs_dev;         /* [nenv, 101] */
-  float* priv_dev;        /* [nenv, 212] */
+  float* obs_dev;         /* [nenv, nobs]   (the duck: 101; odk_model_obs_sizes) */
+  float* priv_dev;        /* [nenv, npriv]  (the duck: 212) */
   float* reward_dev;      /* [nenv] */
   float* done_dev;        /* [nenv] */
   float* truncation_dev;  /* [nenv] */
@@ -95,7 +97,7 @@ const char* odk_last_error(void);
 void odk_default_config(odk_env_config* cfg);
 /* default_config() of reference standing.py:44-100 (incl. USE_IMITATION_REWARD = False, no motor speed limit) */
 void odk_default_config_standing(odk_env_config* cfg);
-/* row strides of the obs / privileged_state outputs for an env kind */
+/* row strides of the obs / privileged_state outputs for an env kind -- of the duck (14 actuators) */
 void odk_obs_sizes(int env_kind, int* nobs, int* npriv);
 
 /* mjx.put_model: parse a ModelBlob (open_duck_playground_amd/model.py; written by the MJCF compiler mjcf.py).
@@ -113,6 +115,10 @@ void odk_obs_sizes(int env_kind, int* nobs, int* npriv);
 int odk_model_load(const void* blob, uint64_t len, odk_model** out);
 void odk_model_free(odk_model* m);
 int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int* nbody);
+/* row strides of the obs / privileged_state outputs of THIS model's env kernels (what `observation_size` of the reference's env reports,
+ * base.py:277-291 / joystick.py:570-615, for a robot with the model's actuator count): the duck 101 / 212 (Standing 85 / 153), a robot
+ * with 12 actuators 89 / 194.  The per-env layout is the reference's with nu in place of 14. */
+int odk_model_obs_sizes(const odk_model* m, int env_kind, int* nobs, int* npriv);
 
 /* Twin dofs (backlash joints: a hinge declared right after another hinge on the same body, same anchor and axis) share
  * their motion column, so the kernels keep the inertia / Newton Hessian on the REDUCED tree with the twins merged
@@ -155,6 +161,9 @@ void odk_set_debug_dump(int on);
 int odk_batch_lds_size(const odk_batch* b);
 int odk_batch_get_lds(odk_batch* b, float* host_image);
 int odk_lds_offset(const odk_batch* b, const char* name);
+/* lanes per env the batch's kernels really run (odk_env_config.lanes_per_env is a hint: elliptic cones, height-field floors and robots that are
+ * not the duck exist at 32 lanes per env only) */
+int odk_batch_lanes(const odk_batch* b);
 /* raw per-env info record (floats, layout in csrc/odk_engine.hip) for tests */
 int odk_batch_record_size(const odk_batch* b);
 int odk_batch_get_records(odk_batch* b, float* host_records);

@@ -31,3 +31,28 @@ def task_to_model(task_name: str) -> Model:
     if task_name not in TASKS:
         raise KeyError(task_name)
     return load_task_model(task_name)
+
+
+class Robot:
+    """What a new robot's constants.py / base.py spell out (reference README.md:74-85), read off a compiled model instead: is it the duck, and
+    which actuated joints are leg joints (`JOINTS_ORDER_NO_HEAD`: the joints above a foot, in actuator order)."""
+
+    def __init__(self, is_open_duck: bool, joints_order_no_head):
+        self.is_open_duck, self.joints_order_no_head = bool(is_open_duck), list(joints_order_no_head)
+
+
+def robot_of(model: Model) -> Robot:
+    import numpy as np
+    a = model.a
+    act_names = [str(n) for n in a["names_actuator"]]
+    if model.nu == 14 and all(j in act_names for j in JOINTS_ORDER_NO_HEAD) and "neck_pitch" in act_names:
+        return Robot(True, JOINTS_ORDER_NO_HEAD)
+    # leg joints: actuated joints whose body is a foot's body or one of its ancestors (foot = the body of a FEET_SITES site)
+    parent = np.asarray(a["body_parentid"]); above = set()
+    for site in FEET_SITES:
+        b = int(np.asarray(a["site_bodyid"])[model.site_id(site)])
+        while b > 0:
+            above.add(b); b = int(parent[b])
+    jb = np.asarray(a["jnt_bodyid"]); trn = np.asarray(a["actuator_trnid"]).reshape(model.nu, -1)[:, 0]
+    jn = [str(n) for n in a["names_jnt"]]
+    return Robot(False, [jn[int(j)] for j in trn if int(jb[int(j)]) in above])

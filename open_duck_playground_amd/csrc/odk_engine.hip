@@ -22,34 +22,57 @@
 using namespace odk;
 
 // ================================================================================================
-// per-env HBM records (floats; ints stored bit-exact in float slots)
-namespace rec {
-constexpr int CMD = 0, LAST = 7, LAST2 = 21, LAST3 = 35, MT = 49, AIR = 63, PEAK = 65, PUSH = 67, AHIST = 69, IMU = 111;
-constexpr int EPSTEPS = 120, TRUNC = 121, DONE = 122, EPSUM = 123, EPLEN = 124, EPMET = 125;
-constexpr int KEY0 = 133, KEY1 = 134, CTR = 135, STEP = 136, PSTEP = 137, PINT = 138, IMI = 139, LCON = 140;
-constexpr int NINFO = 141;
-}  // namespace rec
+// per-env HBM records (floats; ints stored bit-exact in float slots).  The carried info of joystick.py:278-302 + the wrappers' additions,
+// sized by the robot's actuator count nu (the duck: 14 -> the offsets of rounds 1-5: LAST 7, LAST2 21, ..., AHIST 69, IMU 111, NINFO 141)
+struct RecLay {
+  int CMD, LAST, LAST2, LAST3, MT, AIR, PEAK, PUSH, AHIST, IMU, EPSTEPS, TRUNC, DONE, EPSUM, EPLEN, EPMET, KEY0, KEY1, CTR, STEP, PSTEP, PINT, IMI, LCON, NINFO;
+};
+constexpr RecLay rec_lay(int nu) {
+  RecLay r{};
+  r.CMD = 0; r.LAST = 7; r.LAST2 = r.LAST + nu; r.LAST3 = r.LAST2 + nu; r.MT = r.LAST3 + nu; r.AIR = r.MT + nu; r.PEAK = r.AIR + 2; r.PUSH = r.PEAK + 2;
+  r.AHIST = r.PUSH + 2; r.IMU = r.AHIST + 3 * nu; r.EPSTEPS = r.IMU + 9; r.TRUNC = r.EPSTEPS + 1; r.DONE = r.TRUNC + 1; r.EPSUM = r.DONE + 1; r.EPLEN = r.EPSUM + 1;
+  r.EPMET = r.EPLEN + 1; r.KEY0 = r.EPMET + ODK_NMETRIC; r.KEY1 = r.KEY0 + 1; r.CTR = r.KEY1 + 1; r.STEP = r.CTR + 1; r.PSTEP = r.STEP + 1; r.PINT = r.PSTEP + 1;
+  r.IMI = r.PINT + 1; r.LCON = r.IMI + 1; r.NINFO = r.LCON + 1;
+  return r;
+}
+static_assert(rec_lay(14).AHIST == 69 && rec_lay(14).IMU == 111 && rec_lay(14).EPSTEPS == 120 && rec_lay(14).KEY0 == 133 && rec_lay(14).NINFO == 141, "the duck's record layout");
+
+// Observation row strides (joystick.py:570-615 / standing.py:524-565) for a robot with nu actuators: the duck's 101 / 212 and 85 / 153
+constexpr int obs_nobs(int nu, bool standing) { return standing ? 15 + 5 * nu : 17 + 6 * nu; }
+constexpr int obs_npriv(int nu, bool standing) { return obs_nobs(nu, standing) + 26 + 3 * nu + (standing ? 0 : 43); }
+static_assert(obs_nobs(14, false) == ODK_NOBS && obs_npriv(14, false) == ODK_NPRIV && obs_nobs(14, true) == ODK_NOBS_STANDING && obs_npriv(14, true) == ODK_NPRIV_STANDING, "include/odk.h");
+// Random draws of an env step (stream definition shared with oracle/odk_oracle_env.c): 0 action delay | 2, 3 push | 4-6 gyro | 7-9 accelerometer |
+// 10-12 gravity | 13 .. 12 + nu joint angles | 13 + nu .. 12 + 2 nu joint velocities | 13 + 2 nu .. 19 + 2 nu command | 20 + 2 nu zero-command
+// (the duck: 13, 27, 41, 48).  Reset stream: 0-1 dxy | 2 yaw | 3 .. 2 + nu joint scale | 3 + nu .. 8 + nu base qvel | 9 + nu .. 15 + nu command |
+// 16 + nu zero-command | 17 + nu push interval (the duck: 17, 23, 30, 31).
+constexpr int draw_qvel(int nu) { return 13 + nu; }
+constexpr int draw_cmd(int nu) { return 13 + 2 * nu; }
+constexpr int draw_count(int nu) { return (17 + 2 * nu + 1) & ~1; }      // draws 4 .. 20 + 2 nu, rounded up to whole generator blocks (the duck: 46)
 
 template <class S> struct Rec {
+  static constexpr RecLay L = rec_lay(S::NU);
+  static constexpr int NOBS = obs_nobs(S::NU, false), NPRIV = obs_npriv(S::NU, false);
   static constexpr int INFO = S::NQ + 2 * S::NV;
-  static constexpr int SIZE = ((INFO + rec::NINFO + 3) / 4) * 4;
+  static constexpr int SIZE = ((INFO + L.NINFO + 3) / 4) * 4;
   static constexpr int FOBS = S::NQ + 2 * S::NV;
-  static constexpr int FSIZE = ((FOBS + ODK_NOBS + ODK_NPRIV + 3) / 4) * 4;
+  static constexpr int FSIZE = ((FOBS + NOBS + NPRIV + 3) / 4) * 4;
 };
 
 // extra LDS used by the env logic, placed after the physics arrays
 template <class S> struct EnvL {
-  static constexpr int O_INFO = S::TOTAL;          // [144]
-  static constexpr int O_ACT = O_INFO + 144;       // [16] this step's action
+  static constexpr int O_INFO = S::TOTAL;               // [N_INFO] the carried info (Rec::L)
+  static constexpr int O_ACT = O_INFO + S::N_INFO;      // [N_ACT] this step's action, then the imitation phase (2)
+  static_assert(rec_lay(S::NU).NINFO <= S::N_INFO && S::NU + 2 <= S::N_ACT, "Shape::N_INFO / N_ACT");
   // epilogue only, on top of the motion-column buffers (dead after the last forward pass): this step's random draws and the
   // reference motion (evaluated in the epilogue: reward and privileged obs are its only readers)
-  static constexpr int O_NZ = S::O_BUF6;           // [46] draw_block
-  static constexpr int O_REF = S::O_BUF6 + 48;     // [40] current_reference_motion
-  static_assert(48 + 40 <= 6 * S::NVR, "draws + reference motion must fit in BUF6");
-  static constexpr int O_PRIV = S::O_M;            // [212] aliases M|HL (dead after the last forward)
-  static constexpr int TOTAL = O_ACT + 16;
+  static constexpr int NDRAW = draw_count(S::NU);
+  static constexpr int O_NZ = S::O_BUF6;                          // [NDRAW] draw_block
+  static constexpr int O_REF = S::O_BUF6 + ((NDRAW + 3) / 4) * 4;   // [40] current_reference_motion
+  static_assert(((NDRAW + 3) / 4) * 4 + 40 <= 6 * S::NVR && NDRAW <= 64, "draws + reference motion must fit in BUF6");
+  static constexpr int O_PRIV = S::O_M;            // [NPRIV] aliases M|HL (dead after the last forward)
+  static constexpr int TOTAL = O_ACT + S::N_ACT;
   static_assert(TOTAL == S::ENV_STRIDE, "Shape::ENV_STRIDE is the distance between the two env images of a workgroup");
-  static_assert(S::NMR + S::NHR >= ODK_NPRIV, "privileged obs must fit in the M|HL region");
+  static_assert(S::NMR + S::NHR >= Rec<S>::NPRIV, "privileged obs must fit in the M|HL region");
   // per WORKGROUP, behind the envs' images: static tables shared by the envs of the workgroup
   static constexpr int SHARED = S::SHARED;       // DevModel::R_ent | contact-row constants (forward_env: RT, CT)
   static constexpr int wg_floats(int envs) { return envs * TOTAL + SHARED; }
@@ -81,14 +104,20 @@ using ShapeB = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25>;   // *_backlash
 using ShapeAE = Shape<21, 20, 18, 14, 15, 145, 170, 76, 10, 15, true>;
 using ShapeBE = Shape<31, 30, 18, 14, 25, 285, 385, 86, 15, 25, true>;
 // A robot that is not the duck (tests/assets/tail_biped.xml: biped with a five-link tail, 21 dofs, 15 actuators, 19 bodies,
-// box feet): the PHYSICS kernels only (odk_physics_step, state / debug accessors) -- the env kernels' task logic (observation layout,
-// rewards, 14 actions) is the duck's, as the reference's own joystick.py is.  What adding it took: this line, the three dispatch
-// lines below that name it, and nothing in odk_kernels.h beyond admitting nv = 21 to the chain solver.
+// box feet): reset / step / physics kernels -- the env kernels' task logic is joystick.py's with the robot's own tables (rec_lay, obs_nobs: sized
+// by Shape::NU; actuators, default pose, sites and sensor addresses from the ModelBlob), imitation and Standing stay the duck's.  What adding it
+// took: this line, the dispatch lines below that name it (tools/new_shape.py prints both for an XML), and nothing in odk_kernels.h beyond
+// admitting nv = 21 to the chain solver.
 using ShapeC = Shape<22, 21, 19, 15, 16, 156, 181, 78, 10, 15>;
 // A second one (tests/assets/biped12.xml): a biped with SIX-dof legs (hip yaw / roll / pitch, knee, ankle pitch / roll), 18 dofs, 12 actuators,
 // 16 bodies: serial chains of six (the chain solve's block size is the shape's CL), contact wrenches in their own floats (16 bodies' cfrc | crb
-// region is too small for them).  Physics kernels only, like ShapeC.
+// region is too small for them).  Env kernels as for ShapeC (12 actions, observations 89 / 194 floats).
 using ShapeD = Shape<19, 18, 16, 12, 13, 135, 171, 72, 12, 18, false, 6, true>;      // (chains of six; equality rows and elliptic cones compiled in, as ShapeC)
+// The compiled model shapes, by the index odk_model carries: every per-shape dispatch of the host code below goes through this list, so a
+// new robot is ONE `using` line above and ONE entry here (tools/new_shape.py <xml> prints both).  Entries 0 and 1 are the duck's two models
+// (their cone / height-field / 64-lane instantiations are chosen in launch()); entries from 2 on run reset / step / physics kernels at 32
+// lanes per env on a plane floor.
+#define ODK_SHAPES(X) X(0, ShapeA) X(1, ShapeB) X(2, ShapeC) X(3, ShapeD)
 
 struct KArgs {
   const DevModel* m;
@@ -228,14 +257,14 @@ __device__ inline void sample_command(const EnvCfg& c, uint32_t k0, uint32_t k1,
   out = (z < 0.1f) ? 0.0f : c.cmd_range[k][0] + u * (c.cmd_range[k][1] - c.cmd_range[k][0]);
 }
 
-// Draws 4 .. 49 of stream (k0, k1, ctr) in ONE threefry evaluation: lane l < 23 computes block l + 2, whose two words are
+// Draws 4 .. 3 + NDRAW of stream (k0, k1, ctr) in ONE threefry evaluation: lane l < NDRAW / 2 computes block l + 2, whose two words are
 // draws 4 + 2 l and 5 + 2 l; NZ[i - 4] = draw i.  (The observation noise and the command resampling used to call the
 // generator from inside divergent branches: ~8 serial threefry evaluations per env step.)
-constexpr int ODK_NDRAW = 46;
+template <int NDRAW>
 __device__ __forceinline__ void draw_block(uint32_t k0, uint32_t k1, uint32_t ctr, float* NZ, int lane) {
   uint32_t a, b;
   threefry2x32(k0, k1, ctr, (uint32_t)(lane + 2), a, b);
-  if (lane < ODK_NDRAW / 2) { NZ[2 * lane] = (float)(a >> 8) * (1.0f / 16777216.0f); NZ[2 * lane + 1] = (float)(b >> 8) * (1.0f / 16777216.0f); }
+  if (lane < NDRAW / 2) { NZ[2 * lane] = (float)(a >> 8) * (1.0f / 16777216.0f); NZ[2 * lane + 1] = (float)(b >> 8) * (1.0f / 16777216.0f); }
   ODK_SYNC();
 }
 
@@ -251,42 +280,44 @@ __device__ __forceinline__ void build_obs_kind(float* L, const DevModel* m, cons
   const float* QPOS = L + S::O_QPOS; const float* QVEL = L + S::O_QVEL;
   const float lvl = c.noise_level;
   constexpr int NU = S::NU;
+  constexpr RecLay RL = rec_lay(NU);
+  constexpr int NOBS = obs_nobs(NU, false), DQV = draw_qvel(NU) - 4;   // (draw i sits at NZ[i - 4])
   const float con0 = contact[0], con1 = contact[1], ph0 = phase[0], ph1 = phase[1];
   // imu history ring (noisy gravity, never emitted: joystick.py:522-530)
   float ng = 0;
   if (lane < 3) ng = SCR[S::S_MISC + 10 + lane] + (2.0f * NZ[10 - 4 + lane] - 1.0f) * lvl * c.noise_gravity;
   float h0 = 0, h1 = 0;
-  if (lane < 3) { h0 = INFO[rec::IMU + lane]; h1 = INFO[rec::IMU + 3 + lane]; }
+  if (lane < 3) { h0 = INFO[RL.IMU + lane]; h1 = INFO[RL.IMU + 3 + lane]; }
   ODK_SYNC();
-  if (lane < 3) { INFO[rec::IMU + lane] = ng; INFO[rec::IMU + 3 + lane] = h0; INFO[rec::IMU + 6 + lane] = h1; }
+  if (lane < 3) { INFO[RL.IMU + lane] = ng; INFO[RL.IMU + 3 + lane] = h0; INFO[RL.IMU + 6 + lane] = h1; }
   // Standing (standing.py:524-565) = the Joystick layout minus motor_targets, imitation phase, reference motion, imitation_i
   constexpr bool standing = KIND != 0;
-  constexpr int NP = standing ? ODK_NPRIV_STANDING : ODK_NPRIV;
+  constexpr int NP = obs_npriv(NU, standing);
 #pragma unroll
   for (int it = 0; it < (NP + G - 1) / G; it++) {
     const int ks = lane + it * G;
     __builtin_assume(ks >= it * G && ks < it * G + G);
     if (ks >= NP) continue;
-    const int k = !standing ? ks : (ks < 13 + 5 * NU ? ks : (ks < 15 + 5 * NU ? ks + NU : ks + ODK_NOBS - (15 + 5 * NU)));
+    const int k = !standing ? ks : (ks < 13 + 5 * NU ? ks : (ks < 15 + 5 * NU ? ks + NU : ks + NOBS - (15 + 5 * NU)));
     float v = 0;
     if (k < 3) v = SENS[m->adr_gyro + k] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_gyro;
     else if (k < 6) v = SENS[m->adr_accelerometer + k - 3] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_accelerometer;
-    else if (k < 13) v = INFO[rec::CMD + k - 6];
+    else if (k < 13) v = INFO[RL.CMD + k - 6];
     else if (k < 13 + NU) {
       const int u = k - 13, bq = m->act_backlash_qposadr[u];
       const float ja = QPOS[m->act_qposadr[u]] + (bq >= 0 ? QPOS[bq] : 0.0f);
       v = ja + (2.0f * NZ[13 - 4 + u] - 1.0f) * lvl * c.qpos_noise_scale[u] - m->key_ctrl[u];
     } else if (k < 13 + 2 * NU) {
       const int u = k - 13 - NU;
-      v = (QVEL[m->act_dofadr[u]] + (2.0f * NZ[27 - 4 + u] - 1.0f) * lvl * c.noise_joint_vel) * c.dof_vel_scale;
-    } else if (k < 13 + 3 * NU) v = INFO[rec::LAST + k - 13 - 2 * NU];
-    else if (k < 13 + 4 * NU) v = INFO[rec::LAST2 + k - 13 - 3 * NU];
-    else if (k < 13 + 5 * NU) v = INFO[rec::LAST3 + k - 13 - 4 * NU];
-    else if (k < 13 + 6 * NU) v = INFO[rec::MT + k - 13 - 5 * NU];
+      v = (QVEL[m->act_dofadr[u]] + (2.0f * NZ[DQV + u] - 1.0f) * lvl * c.noise_joint_vel) * c.dof_vel_scale;
+    } else if (k < 13 + 3 * NU) v = INFO[RL.LAST + k - 13 - 2 * NU];
+    else if (k < 13 + 4 * NU) v = INFO[RL.LAST2 + k - 13 - 3 * NU];
+    else if (k < 13 + 5 * NU) v = INFO[RL.LAST3 + k - 13 - 4 * NU];
+    else if (k < 13 + 6 * NU) v = INFO[RL.MT + k - 13 - 5 * NU];
     else if (k < 15 + 6 * NU) v = (k - 13 - 6 * NU) ? con1 : con0;   // (scalars + selects: a runtime index parks the two-element arrays in scratch)
     else if (k < 17 + 6 * NU) v = (k - 15 - 6 * NU) ? ph1 : ph0;
     else {
-      int q = k - ODK_NOBS;  // privileged tail (joystick.py:596-615)
+      int q = k - NOBS;  // privileged tail (joystick.py:596-615)
       if (q < 3) v = SENS[m->adr_gyro + q];
       else if (q < 6) v = SENS[m->adr_accelerometer + q - 3];
       else if (q < 9) v = SCR[S::S_MISC + 10 + q - 6];
@@ -298,7 +329,7 @@ __device__ __forceinline__ void build_obs_kind(float* L, const DevModel* m, cons
       else if (q < 16 + 3 * NU) v = L[S::O_ACTF + q - 16 - 2 * NU];
       else if (q < 18 + 3 * NU) v = (q - 16 - 3 * NU) ? con1 : con0;
       else if (q < 24 + 3 * NU) { const int t = q - 18 - 3 * NU; v = SENS[m->adr_foot_linvel[t / 3] + t % 3]; }
-      else if (q < 26 + 3 * NU) v = INFO[rec::AIR + q - 24 - 3 * NU];
+      else if (q < 26 + 3 * NU) v = INFO[RL.AIR + q - 24 - 3 * NU];
       else if (q < 66 + 3 * NU) v = L[E::O_REF + q - 26 - 3 * NU];
       else if (q == 66 + 3 * NU) v = (float)imitation_i;
       else v = (q - 67 - 3 * NU) ? ph1 : ph0;
@@ -343,6 +374,8 @@ template <class S, int G, int HF>
 __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
+  constexpr int NU = S::NU;
+  constexpr RecLay RL = rec_lay(NU);
   const int slot = threadIdx.x / G, lane = threadIdx.x % G;
   const int env = blockIdx.x * (64 / G) + slot;
   const bool live = env < a.nenv;
@@ -364,7 +397,7 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
   const uint32_t kr = k1 ^ 0x52535421u;
   for (int i = lane; i < S::NQ; i += G) L[S::O_QPOS + i] = m->key_qpos[i];
   for (int i = lane; i < S::NV; i += G) { L[S::O_QVEL + i] = 0; L[S::O_WARM + i] = 0; }
-  for (int i = lane; i < 144; i += G) INFO[i] = 0;
+  for (int i = lane; i < S::N_INFO; i += G) INFO[i] = 0;
   ODK_SYNC();
   if (lane < 2) L[S::O_QPOS + lane] += -0.05f + rng_uniform(k0, kr, 0, lane) * 0.1f;
   if (lane == 2) {
@@ -375,32 +408,32 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
     qmul(r, q0, qz);
     for (int k = 0; k < 4; k++) L[S::O_QPOS + 3 + k] = r[k];
   }
-  if (lane >= 3 && lane < 9) L[S::O_QVEL + lane - 3] = -c.reset_base_qvel + rng_uniform(k0, kr, 0, 17 + lane - 3) * (2.0f * c.reset_base_qvel);
+  if (lane >= 3 && lane < 9) L[S::O_QVEL + lane - 3] = -c.reset_base_qvel + rng_uniform(k0, kr, 0, 3 + NU + lane - 3) * (2.0f * c.reset_base_qvel);
   for (int u = lane; u < S::NU; u += G) {
     const float v = L[S::O_QPOS + m->act_qposadr[u]] * (0.5f + rng_uniform(k0, kr, 0, 3 + u));
     L[S::O_QPOS + m->act_qposadr[u]] = v;
     L[S::O_CTRL + u] = v;
-    INFO[rec::MT + u] = c.kind != 0 ? 0.0f : m->key_ctrl[u];   // standing.py:279 starts from zeros
+    INFO[RL.MT + u] = c.kind != 0 ? 0.0f : m->key_ctrl[u];   // standing.py:279 starts from zeros
   }
-  if (lane < 7) sample_command(c, k0, kr, 0, 23, lane, INFO[rec::CMD + lane]);
+  if (lane < 7) sample_command(c, k0, kr, 0, 9 + NU, lane, INFO[RL.CMD + lane]);
   ODK_SYNC();
   forward_env<S, G, HF>(L, RT, m, a.hfield, st, lane, 1);
   if (a.dbg_lds && live) dump_lds<S, G>(a.dbg_lds, L, env, lane);
-  const float pint = c.push_interval_range[0] + rng_uniform(k0, kr, 0, 31) * (c.push_interval_range[1] - c.push_interval_range[0]);
+  const float pint = c.push_interval_range[0] + rng_uniform(k0, kr, 0, 17 + NU) * (c.push_interval_range[1] - c.push_interval_range[0]);
   const int push_interval_steps = (int)rintf(pint / c.ctrl_dt);
-  if (c.use_imitation) prm_eval<G>(&a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], 0, L + E::O_REF, lane);
+  if (c.use_imitation) prm_eval<G>(&a.prm, a.prm_table, INFO[RL.CMD], INFO[RL.CMD + 1], INFO[RL.CMD + 2], 0, L + E::O_REF, lane);
   else for (int k = lane; k < 40; k += G) L[E::O_REF + k] = 0;
   ODK_SYNC();
   float contact[2];
   foot_contact_flags(L + S::O_CDIST, contact);
   const float phase[2] = {0, 0};
   // stash state before the obs overwrites the M|HL region?  (qpos/qvel/warm live elsewhere: safe)
-  draw_block(k0, k1, 0u, L + E::O_NZ, lane);   // the motion-column buffers are dead after the forward pass
+  draw_block<E::NDRAW>(k0, k1, 0u, L + E::O_NZ, lane);   // the motion-column buffers are dead after the forward pass
   build_obs<S, G>(L, m, c, contact, L + E::O_NZ, 0, phase, lane);
   if (lane == 0) {
-    INFO[rec::KEY0] = i2f((int)k0); INFO[rec::KEY1] = i2f((int)k1); INFO[rec::CTR] = i2f(1);
-    INFO[rec::STEP] = i2f(0); INFO[rec::PSTEP] = i2f(0); INFO[rec::PINT] = i2f(push_interval_steps);
-    INFO[rec::IMI] = i2f(0); INFO[rec::LCON] = i2f(0);
+    INFO[RL.KEY0] = i2f((int)k0); INFO[RL.KEY1] = i2f((int)k1); INFO[RL.CTR] = i2f(1);
+    INFO[RL.STEP] = i2f(0); INFO[RL.PSTEP] = i2f(0); INFO[RL.PINT] = i2f(push_interval_steps);
+    INFO[RL.IMI] = i2f(0); INFO[RL.LCON] = i2f(0);
   }
   ODK_SYNC();
   if (live) {
@@ -411,11 +444,11 @@ __global__ void __launch_bounds__(64) reset_kernel(KArgs a) {
       rc[S::NQ + i] = L[S::O_QVEL + i]; fs[S::NQ + i] = L[S::O_QVEL + i];
       rc[S::NQ + S::NV + i] = L[S::O_WARM + i]; fs[S::NQ + S::NV + i] = L[S::O_WARM + i];
     }
-    for (int k = lane; k < ODK_NPRIV; k += G) {
-      if (k < ODK_NOBS) fs[R::FOBS + k] = L[E::O_PRIV + k];
-      fs[R::FOBS + ODK_NOBS + k] = L[E::O_PRIV + k];
+    for (int k = lane; k < R::NPRIV; k += G) {
+      if (k < R::NOBS) fs[R::FOBS + k] = L[E::O_PRIV + k];
+      fs[R::FOBS + R::NOBS + k] = L[E::O_PRIV + k];
     }
-    for (int k = lane; k < rec::NINFO; k += G) rc[R::INFO + k] = INFO[k];
+    for (int k = lane; k < RL.NINFO; k += G) rc[R::INFO + k] = INFO[k];
     float metrics[ODK_NMETRIC] = {0, 0, 0, 0, 0, 0, 0, 0};
     write_outputs<S, G>(a, L, env, 0.0f, 0.0f, 0.0f, metrics, lane);
   }
@@ -431,6 +464,7 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   extern __shared__ float lds[];
   using E = EnvL<S>; using R = Rec<S>;
   constexpr int NU = S::NU;
+  constexpr RecLay RL = rec_lay(NU);
   const int slot = threadIdx.x / G, lane = threadIdx.x % G;
   const int env = blockIdx.x * (64 / G) + slot;
   const bool live = env < a.nenv;
@@ -452,7 +486,7 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   // consecutive floats), then the LDS stores
   {
     G2L<S::NQ + 2 * S::NV, G> g_state;   // qpos|qvel|warm are contiguous in LDS too
-    G2L<rec::NINFO, G> g_info;
+    G2L<RL.NINFO, G> g_info;
     G2L<NU, G> g_act;
     ParamLoad<S, G> g_par;
     const float* drp = a.dr ? a.dr + (size_t)e * DRL<S>::SIZE : nullptr;
@@ -466,13 +500,13 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
 #endif
   Statics<S, G> st;
   load_statics<S, G>(st, m, lane);
-  const uint32_t k0 = (uint32_t)f2i(INFO[rec::KEY0]), k1 = (uint32_t)f2i(INFO[rec::KEY1]), ctr = (uint32_t)f2i(INFO[rec::CTR]);
-  int step = f2i(INFO[rec::STEP]), push_step = f2i(INFO[rec::PSTEP]);
-  const int push_int = f2i(INFO[rec::PINT]);
-  int imi = f2i(INFO[rec::IMI]);
-  const int lcon = f2i(INFO[rec::LCON]);
-  const float prev_done = INFO[rec::DONE];
-  float ep_steps = prev_done != 0.0f ? 0.0f : INFO[rec::EPSTEPS];  // AutoReset.step prologue
+  const uint32_t k0 = (uint32_t)f2i(INFO[RL.KEY0]), k1 = (uint32_t)f2i(INFO[RL.KEY1]), ctr = (uint32_t)f2i(INFO[RL.CTR]);
+  int step = f2i(INFO[RL.STEP]), push_step = f2i(INFO[RL.PSTEP]);
+  const int push_int = f2i(INFO[RL.PINT]);
+  int imi = f2i(INFO[RL.IMI]);
+  const int lcon = f2i(INFO[RL.LCON]);
+  const float prev_done = INFO[RL.DONE];
+  float ep_steps = prev_done != 0.0f ? 0.0f : INFO[RL.EPSTEPS];  // AutoReset.step prologue
   const float dt = c.ctrl_dt;
   // ---- imitation phase + reference motion (:325-355)
   float phase[2] = {0, 0};
@@ -481,15 +515,15 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
     imi = (imi + 1) % a.prm.nsteps;
     const float ph = ((float)imi / (float)a.prm.nsteps) * 2.0f * PI_F;
     phase[0] = cosf(ph); phase[1] = sinf(ph);
-    prm_eval_regs<G>(&a.prm, a.prm_table, INFO[rec::CMD], INFO[rec::CMD + 1], INFO[rec::CMD + 2], imi, ref0, ref1, lane);   // (:347-353)
+    prm_eval_regs<G>(&a.prm, a.prm_table, INFO[RL.CMD], INFO[RL.CMD + 1], INFO[RL.CMD + 2], imi, ref0, ref1, lane);   // (:347-353)
   } else {
     imi = 0;
   }
   // ---- action delay ring (:362-376): roll by nu, newest first
   float h0 = 0, h1 = 0;
-  for (int u = lane; u < NU; u += G) { h0 = INFO[rec::AHIST + u]; h1 = INFO[rec::AHIST + NU + u]; }
+  for (int u = lane; u < NU; u += G) { h0 = INFO[RL.AHIST + u]; h1 = INFO[RL.AHIST + NU + u]; }
   ODK_SYNC();
-  for (int u = lane; u < NU; u += G) { INFO[rec::AHIST + u] = ACT[u]; INFO[rec::AHIST + NU + u] = h0; INFO[rec::AHIST + 2 * NU + u] = h1; }
+  for (int u = lane; u < NU; u += G) { INFO[RL.AHIST + u] = ACT[u]; INFO[RL.AHIST + NU + u] = h0; INFO[RL.AHIST + 2 * NU + u] = h1; }
   ODK_SYNC();
   uint32_t w0, w1, w2, w3;   // draws 0 | 1 (unused) and 2 | 3: two generator blocks
   threefry2x32(k0, k1, ctr, 0u, w0, w1);
@@ -504,16 +538,16 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   // values only the epilogue needs go back to LDS now instead of riding through the substep loop in scratch:
   // info["push"], the imitation counter, its phase (two spare floats behind the action), the episode step counter
   if (lane == 0) {
-    INFO[rec::PUSH] = push[0]; INFO[rec::PUSH + 1] = push[1];
-    INFO[rec::IMI] = i2f(imi);
+    INFO[RL.PUSH] = push[0]; INFO[RL.PUSH + 1] = push[1];
+    INFO[RL.IMI] = i2f(imi);
     ACT[NU] = phase[0]; ACT[NU + 1] = phase[1];
-    INFO[rec::EPSTEPS] = ep_steps;
+    INFO[RL.EPSTEPS] = ep_steps;
   }
   // ---- motor targets with speed limit (:404-417)
   for (int u = lane; u < NU; u += G) {
-    float mt = m->key_ctrl[u] + INFO[rec::AHIST + aidx * NU + u] * c.action_scale;
+    float mt = m->key_ctrl[u] + INFO[RL.AHIST + aidx * NU + u] * c.action_scale;
     if (c.use_motor_speed_limits) {
-      const float prev = INFO[rec::MT + u], lim = c.max_motor_velocity * dt;
+      const float prev = INFO[RL.MT + u], lim = c.max_motor_velocity * dt;
       mt = fminf(fmaxf(mt, prev - lim), prev + lim);
     }
     CTRL[u] = mt;
@@ -556,14 +590,14 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   const DevModel* mp = reinterpret_cast<const DevModel*>(reinterpret_cast<const char*>(m) + opaque1);
   // ... and for the RNG key / counter: everything derived from them (threefry key schedules of the observation-noise
   // draws) is recomputed here instead of riding through the loop in scratch
-  const uint32_t k0e = (uint32_t)f2i(INFO[rec::KEY0]), k1e = (uint32_t)f2i(INFO[rec::KEY1]), ctre = (uint32_t)f2i(INFO[rec::CTR]);
-  const int imi_e = f2i(INFO[rec::IMI]);
+  const uint32_t k0e = (uint32_t)f2i(INFO[RL.KEY0]), k1e = (uint32_t)f2i(INFO[RL.KEY1]), ctre = (uint32_t)f2i(INFO[RL.CTR]);
+  const int imi_e = f2i(INFO[RL.IMI]);
   const float phase_e[2] = {ACT[NU], ACT[NU + 1]};
-  int step_e = f2i(INFO[rec::STEP]), push_step_e = f2i(INFO[rec::PSTEP]);
-  float ep_steps_e = INFO[rec::EPSTEPS];
-  const float prev_done_e = INFO[rec::DONE];
-  for (int u = lane; u < NU; u += G) INFO[rec::MT + u] = CTRL[u];  // info["motor_targets"] (:422)
-  draw_block(k0e, k1e, ctre, L + E::O_NZ, lane);   // the motion-column buffers are dead after the last forward pass
+  int step_e = f2i(INFO[RL.STEP]), push_step_e = f2i(INFO[RL.PSTEP]);
+  float ep_steps_e = INFO[RL.EPSTEPS];
+  const float prev_done_e = INFO[RL.DONE];
+  for (int u = lane; u < NU; u += G) INFO[RL.MT + u] = CTRL[u];  // info["motor_targets"] (:422)
+  draw_block<E::NDRAW>(k0e, k1e, ctre, L + E::O_NZ, lane);   // the motion-column buffers are dead after the last forward pass
   // reference motion of this step: evaluated in the prologue, parked here (reward and privileged obs are its only readers)
   if (lane < 40) L[E::O_REF + lane] = ref0;
   if (lane < 8) L[E::O_REF + 32 + lane] = ref1;
@@ -573,11 +607,11 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   foot_contact_flags(L + S::O_CDIST, contact);
   float air[2], peak[2];
   for (int f = 0; f < 2; f++) {
-    air[f] = INFO[rec::AIR + f] + dt;
-    peak[f] = fmaxf(INFO[rec::PEAK + f], L[S::O_SCR + S::S_MISC + 8 + f]);
+    air[f] = INFO[RL.AIR + f] + dt;
+    peak[f] = fmaxf(INFO[RL.PEAK + f], L[S::O_SCR + S::S_MISC + 8 + f]);
   }
   ODK_SYNC();
-  if (lane < 2) INFO[rec::AIR + lane] = air[lane];
+  if (lane < 2) INFO[RL.AIR + lane] = air[lane];
   ODK_SYNC();
   // ---- termination (:483-485)
   float nanflag = 0;
@@ -592,13 +626,13 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
     const float jq = L[S::O_QPOS + mp->act_qposadr[u]], jv = L[S::O_QVEL + mp->act_dofadr[u]];
     const float af = L[S::O_ACTF + u];
     t_tq = af * af;
-    const float da = ACT[u] - INFO[rec::LAST + u];
+    const float da = ACT[u] - INFO[RL.LAST + u];
     t_ar = da * da;
     const bool leg = u < 5 || u >= 9;
     const bool counted = c.kind == 0 || leg;   // Standing: cost_stand_still(..., ignore_head=True) (standing.py:590-597)
     t_pose = counted ? fabsf(jq - mp->key_ctrl[u]) : 0.0f;
     t_vel = counted ? fabsf(jv) : 0.0f;
-    if (c.kind != 0 && !leg) { const float dh = jq - INFO[rec::CMD + 3 + (u - 5)]; t_jp = dh * dh; }   // cost_head_pos (rewards.py:131-147)
+    if (c.kind != 0 && !leg) { const float dh = jq - INFO[RL.CMD + 3 + (u - 5)]; t_jp = dh * dh; }   // cost_head_pos (rewards.py:131-147)
     if (c.kind == 0 && leg) {  // joints[:5] ++ joints[9:] vs ref[:5] ++ ref[11:16]  (custom_rewards.py:80-88)
       const int ri = u < 5 ? u : u + 2;
       const float dp = jq - REF[ri], dv = jv - REF[16 + ri];
@@ -608,7 +642,7 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   t_tq = gsum<G>(t_tq); t_ar = gsum<G>(t_ar); t_pose = gsum<G>(t_pose); t_vel = gsum<G>(t_vel); t_jp = gsum<G>(t_jp); t_jv = gsum<G>(t_jv);
   float rew[7];
   {
-    const float* cmd = INFO + rec::CMD;
+    const float* cmd = INFO + RL.CMD;
     const float* lv = L + S::O_SENS + mp->adr_local_linvel;
     const float* gy = L + S::O_SENS + mp->adr_gyro;
     const float ex = (cmd[0] - lv[0]) * (cmd[0] - lv[0]);
@@ -649,12 +683,13 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   // ---- info updates (:449-469)
   step_e += 1; push_step_e += 1;
   float la = 0, lla = 0;
-  for (int u = lane; u < NU; u += G) { la = INFO[rec::LAST + u]; lla = INFO[rec::LAST2 + u]; }
+  for (int u = lane; u < NU; u += G) { la = INFO[RL.LAST + u]; lla = INFO[RL.LAST2 + u]; }
   ODK_SYNC();
-  for (int u = lane; u < NU; u += G) { INFO[rec::LAST3 + u] = lla; INFO[rec::LAST2 + u] = la; INFO[rec::LAST + u] = ACT[u]; }
-  if (step_e > 500 && lane < 7) {   // sample_command (joystick.py:671-725) on draws 41 .. 48 of this step
-    const float z = NZ[41 + 7 - 4], u = NZ[41 - 4 + lane];
-    INFO[rec::CMD + lane] = (z < 0.1f) ? 0.0f : c.cmd_range[lane][0] + u * (c.cmd_range[lane][1] - c.cmd_range[lane][0]);
+  for (int u = lane; u < NU; u += G) { INFO[RL.LAST3 + u] = lla; INFO[RL.LAST2 + u] = la; INFO[RL.LAST + u] = ACT[u]; }
+  if (step_e > 500 && lane < 7) {   // sample_command (joystick.py:671-725) on draws 13 + 2 nu .. 20 + 2 nu of this step (the duck: 41 .. 48)
+    constexpr int DC = draw_cmd(NU) - 4;
+    const float z = NZ[DC + 7], u = NZ[DC + lane];
+    INFO[RL.CMD + lane] = (z < 0.1f) ? 0.0f : c.cmd_range[lane][0] + u * (c.cmd_range[lane][1] - c.cmd_range[lane][0]);
   }
   if (done_env || step_e > 500) step_e = 0;
   int lcon_new = 0;
@@ -672,19 +707,19 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
   const float keep = 1.0f - prev_done_e;  // info['episode_done'] of the previous step
   ODK_SYNC();
   if (lane == 0) {
-    INFO[rec::AIR] = air[0]; INFO[rec::AIR + 1] = air[1]; INFO[rec::PEAK] = peak[0]; INFO[rec::PEAK + 1] = peak[1];
-    INFO[rec::EPSTEPS] = ep_steps_e; INFO[rec::TRUNC] = trunc; INFO[rec::DONE] = done_f;
-    INFO[rec::EPSUM] = (INFO[rec::EPSUM] + reward) * keep; INFO[rec::EPLEN] = (INFO[rec::EPLEN] + 1.0f) * keep;
-    for (int k = 0; k < ODK_NMETRIC; k++) INFO[rec::EPMET + k] = (INFO[rec::EPMET + k] + metrics[k]) * keep;
-    INFO[rec::CTR] = i2f((int)(ctre + 1)); INFO[rec::STEP] = i2f(step_e); INFO[rec::PSTEP] = i2f(push_step_e);
-    INFO[rec::LCON] = i2f(lcon_new);
+    INFO[RL.AIR] = air[0]; INFO[RL.AIR + 1] = air[1]; INFO[RL.PEAK] = peak[0]; INFO[RL.PEAK + 1] = peak[1];
+    INFO[RL.EPSTEPS] = ep_steps_e; INFO[RL.TRUNC] = trunc; INFO[RL.DONE] = done_f;
+    INFO[RL.EPSUM] = (INFO[RL.EPSUM] + reward) * keep; INFO[RL.EPLEN] = (INFO[RL.EPLEN] + 1.0f) * keep;
+    for (int k = 0; k < ODK_NMETRIC; k++) INFO[RL.EPMET + k] = (INFO[RL.EPMET + k] + metrics[k]) * keep;
+    INFO[RL.CTR] = i2f((int)(ctre + 1)); INFO[RL.STEP] = i2f(step_e); INFO[RL.PSTEP] = i2f(push_step_e);
+    INFO[RL.LCON] = i2f(lcon_new);
   }
   ODK_SYNC();
   // ---- AutoReset.step epilogue: data, obs <- first_* where done (info is NOT reset)
   if (done_f != 0.0f && c.autoreset) {
     const float* fs = a.first + (size_t)e * R::FSIZE;
     for (int i = lane; i < S::NQ + 2 * S::NV; i += G) L[S::O_QPOS + i] = fs[i];
-    for (int k = lane; k < ODK_NPRIV; k += G) L[E::O_PRIV + k] = fs[R::FOBS + ODK_NOBS + k];
+    for (int k = lane; k < R::NPRIV; k += G) L[E::O_PRIV + k] = fs[R::FOBS + R::NOBS + k];
     // first_obs["state"] == first_priv[:101] by construction; every lane re-reads only what it wrote: no barrier
   }
   if (live) {
@@ -696,7 +731,7 @@ __global__ void __launch_bounds__(64, ODK_STEP_WAVES) step_kernel(KArgs a) {
     asm volatile("" : "+v"(e_out));
     float* rco = reinterpret_cast<float*>(reinterpret_cast<char*>(a.recs + (size_t)e_out * R::SIZE) + opaque1);
     for (int i = lane; i < S::NQ + 2 * S::NV; i += G) rco[i] = L[S::O_QPOS + i];
-    for (int k = lane; k < rec::NINFO; k += G) rco[R::INFO + k] = INFO[k];
+    for (int k = lane; k < RL.NINFO; k += G) rco[R::INFO + k] = INFO[k];
     write_outputs<S, G>(a, L, env, reward, done_f, trunc, metrics, lane);
   }
 #ifdef ODK_PROFILE
@@ -799,6 +834,10 @@ extern "C" void odk_default_config_standing(odk_env_config* c) {   // reference 
 extern "C" void odk_obs_sizes(int env_kind, int* nobs, int* npriv) {
   if (nobs) *nobs = env_kind == ODK_ENV_STANDING ? ODK_NOBS_STANDING : ODK_NOBS;
   if (npriv) *npriv = env_kind == ODK_ENV_STANDING ? ODK_NPRIV_STANDING : ODK_NPRIV;
+}
+static void obs_sizes_nu(int nu, int env_kind, int* nobs, int* npriv) {
+  if (nobs) *nobs = obs_nobs(nu, env_kind == ODK_ENV_STANDING);
+  if (npriv) *npriv = obs_npriv(nu, env_kind == ODK_ENV_STANDING);
 }
 
 // ---- blob parsing
@@ -1447,16 +1486,23 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   fill_body_st(m);
   int dt_max = 0, dv_max = 0;
   for (int d = 0; d < m.nv; d++) { dt_max = m.dof_depth[d] > dt_max ? m.dof_depth[d] : dt_max; dv_max = m.vdof_depth[d] > dv_max ? m.vdof_depth[d] : dv_max; }
-  auto fits = [&](int nq, int nv, int nb, int nu, int nj, int nM, int nH, int nrow, int DT, int DV) {
-    return m.nq == nq && m.nv == nv && m.nb == nb && m.nu == nu && m.nj == nj && m.nM == nM && m.nH == nH && m.nrow == nrow && dt_max <= DT && dv_max <= DV;
-  };
-  if (fits(ShapeA::NQ, ShapeA::NV, ShapeA::NB, ShapeA::NU, ShapeA::NJ, ShapeA::NM, ShapeA::NH, ShapeA::NROW, ShapeA::DT, ShapeA::DV)) mo->shape = 0;
-  else if (fits(ShapeB::NQ, ShapeB::NV, ShapeB::NB, ShapeB::NU, ShapeB::NJ, ShapeB::NM, ShapeB::NH, ShapeB::NROW, ShapeB::DT, ShapeB::DV)) mo->shape = 1;
-  else if (fits(ShapeC::NQ, ShapeC::NV, ShapeC::NB, ShapeC::NU, ShapeC::NJ, ShapeC::NM, ShapeC::NH, ShapeC::NROW, ShapeC::DT, ShapeC::DV)) mo->shape = 2;
-  else if (fits(ShapeD::NQ, ShapeD::NV, ShapeD::NB, ShapeD::NU, ShapeD::NJ, ShapeD::NM, ShapeD::NH, ShapeD::NROW, ShapeD::DT, ShapeD::DV)) mo->shape = 3;
-  else { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nM=%d nH=%d nrow=%d has no compiled kernel", m.nq, m.nv, m.nb, m.nM, m.nH, m.nrow); }
+  mo->shape = -1;
+#define X(i, S) if (mo->shape < 0 && m.nq == S::NQ && m.nv == S::NV && m.nb == S::NB && m.nu == S::NU && m.nj == S::NJ && m.nM == S::NM && m.nH == S::NH && m.nrow == S::NROW && \
+                    dt_max <= S::DT && dv_max <= S::DV) mo->shape = i;
+  ODK_SHAPES(X)
+#undef X
+  if (mo->shape < 0) {
+    const int dtm = dt_max, dvm = dv_max;
+    delete mo;
+    return fail(ODK_ERR_UNSUPPORTED, "model shape nq=%d nv=%d nb=%d nu=%d nj=%d nM=%d nH=%d nrow=%d depth=%d vdepth=%d has no compiled kernel (tools/new_shape.py <xml> prints the two lines to add to odk_engine.hip)",
+                m.nq, m.nv, m.nb, m.nu, m.nj, m.nM, m.nH, m.nrow, dtm, dvm);
+  }
+  int shape_cl = 5; bool shape_eq = false;
+#define X(i, S) if (mo->shape == i) { shape_cl = S::CL; shape_eq = S::EQ; }
+  ODK_SHAPES(X)
+#undef X
   for (int c = 0; c < m.nrchain; c++)
-    if (m.rchain_len[c] > (mo->shape == 3 ? ShapeD::CL : 5)) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "a serial chain of %d (twin-merged) dofs: the kernels of this model shape solve chains of <= %d", m.rchain_len[c], mo->shape == 3 ? ShapeD::CL : 5); }
+    if (m.rchain_len[c] > shape_cl) { const int len = m.rchain_len[c]; delete mo; return fail(ODK_ERR_UNSUPPORTED, "a serial chain of %d (twin-merged) dofs: the kernels of this model shape solve chains of <= %d", len, shape_cl); }
   if (!m.floor_is_plane && mo->shape != 1) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "height-field floors are built for the backlash model only"); }
 
   if (m.cone && m.foot_prim != 0) {
@@ -1474,7 +1520,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       for (int k = 0; k < eq_n; k++) {
         if (!eq_active[k] || eq_type[k] != pass) continue;
         const char* kind = pass == 0 ? "connect" : "weld";
-        const bool shape_ok = (mo->shape == 2 || mo->shape == 3) && !m.paired;      // ShapeC / ShapeD: Shape::EQ
+        const bool shape_ok = shape_eq && !m.paired;      // shapes compiled with the optional constraint code (Shape::EQ)
         const int nrow = pass == 0 ? 3 : 6;
         if (!shape_ok || m.neqp == EQP_MAX || m.eqp_nrow + nrow > EQP_ROWS) {
           delete mo;
@@ -1513,7 +1559,7 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       }
     for (int k = 0; k < eq_n; k++) {
       if (!eq_active[k] || eq_type[k] != 2) continue;
-      const bool shape_ok = (mo->shape == 2 || mo->shape == 3) && !m.paired;      // ShapeC / ShapeD: Shape::EQ
+      const bool shape_ok = shape_eq && !m.paired;      // shapes compiled with the optional constraint code (Shape::EQ)
       if (!shape_ok || m.neq == EQ_MAX) {
         delete mo;
         return fail(ODK_ERR_UNSUPPORTED, "<equality><joint> (constraint %d) is active: %s", k,
@@ -1548,10 +1594,9 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   if (mo->shape != 1 && m.paired) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "twin dofs in a model of the 20-dof shape"); }
   for (int lane = 0; lane < 64; lane++) {   // per-lane statics of the kernels (LaneSt)
     memset(&m.lane_st[lane], 0, sizeof(LaneSt));
-    if (mo->shape == 0) compute_statics<ShapeA>(m.lane_st[lane], &m, lane);
-    else if (mo->shape == 1) compute_statics<ShapeB>(m.lane_st[lane], &m, lane);
-    else if (mo->shape == 2) compute_statics<ShapeC>(m.lane_st[lane], &m, lane);
-    else compute_statics<ShapeD>(m.lane_st[lane], &m, lane);
+#define X(i, S) if (mo->shape == i) compute_statics<S>(m.lane_st[lane], &m, lane);
+    ODK_SHAPES(X)
+#undef X
   }
   *out = mo;
   return ODK_OK;
@@ -1560,6 +1605,11 @@ extern "C" void odk_model_free(odk_model* m) { delete m; }
 extern "C" int odk_model_dims(const odk_model* m, int* nq, int* nv, int* nu, int* nbody) {
   if (!m) return fail(ODK_ERR_INVALID, "null model");
   if (nq) *nq = m->h.nq; if (nv) *nv = m->h.nv; if (nu) *nu = m->h.nu; if (nbody) *nbody = m->h.nb;
+  return ODK_OK;
+}
+extern "C" int odk_model_obs_sizes(const odk_model* m, int env_kind, int* nobs, int* npriv) {
+  if (!m) return fail(ODK_ERR_INVALID, "null model");
+  obs_sizes_nu(m->h.nu, env_kind, nobs, npriv);
   return ODK_OK;
 }
 
@@ -1576,14 +1626,17 @@ extern "C" int odk_model_reduced(const odk_model* m, int* paired, int* nvr, int*
 }
 extern "C" int odk_model_env_lds_floats(const odk_model* m) {
   if (!m) return -1;
-  return m->shape == 0 ? EnvL<ShapeA>::TOTAL : (m->shape == 1 ? EnvL<ShapeB>::TOTAL : (m->shape == 2 ? EnvL<ShapeC>::TOTAL : EnvL<ShapeD>::TOTAL));
+#define X(i, S) if (m->shape == i) return EnvL<S>::TOTAL;
+  ODK_SHAPES(X)
+#undef X
+  return -1;
 }
 
 template <class S> static void fill_sizes(odk_batch* b) {
   b->rec_size = Rec<S>::SIZE; b->frec_size = Rec<S>::FSIZE; b->lds_total = S::TOTAL; b->dr_size = DRL<S>::SIZE; b->env_lds = EnvL<S>::TOTAL;
 }
 
-static void to_dev_cfg(const odk_env_config& c, EnvCfg& d) {
+static void to_dev_cfg(const odk_env_config& c, EnvCfg& d, int nu) {
   d.ctrl_dt = c.ctrl_dt; d.action_scale = c.action_scale; d.dof_vel_scale = c.dof_vel_scale; d.max_motor_velocity = c.max_motor_velocity;
   d.noise_level = c.noise_level; d.noise_gyro = c.noise_gyro; d.noise_accelerometer = c.noise_accelerometer; d.noise_gravity = c.noise_gravity;
   d.noise_joint_vel = c.noise_joint_vel;
@@ -1594,7 +1647,7 @@ static void to_dev_cfg(const odk_env_config& c, EnvCfg& d) {
   d.use_imitation = c.use_imitation; d.use_motor_speed_limits = c.use_motor_speed_limits; d.autoreset = c.autoreset;
   d.episode_length = c.episode_length; d.n_substeps = c.n_substeps;
   d.kind = c.env_kind; d.reset_base_qvel = c.reset_base_qvel;
-  odk_obs_sizes(c.env_kind, &d.nobs, &d.npriv);
+  obs_sizes_nu(nu, c.env_kind, &d.nobs, &d.npriv);
 }
 
 extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, int nenv, int device, const float* prm_table, const double* dxs, int nx,
@@ -1603,10 +1656,14 @@ extern "C" int odk_batch_create(const odk_model* m, const odk_env_config* cfg, i
   HIPCHK(hipSetDevice(device));
   odk_batch* b = new odk_batch();
   b->model = *m; b->nenv = nenv; b->device = device; b->cfg = *cfg;
-  b->G = cfg->lanes_per_env == 64 ? 64 : 32;
-  if (m->h.cone && cfg->lanes_per_env == 64) { delete b; return fail(ODK_ERR_UNSUPPORTED, "<option cone=\"elliptic\">: the elliptic-cone kernels run 32 lanes per env"); }
   if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 32 && cfg->lanes_per_env != 64) { delete b; return fail(ODK_ERR_INVALID, "lanes_per_env must be 0, 32 or 64"); }
-  if (m->shape == 0) fill_sizes<ShapeA>(b); else if (m->shape == 1) fill_sizes<ShapeB>(b); else if (m->shape == 2) fill_sizes<ShapeC>(b); else fill_sizes<ShapeD>(b);
+  // lanes_per_env is a geometry HINT (one env per wave finishes a small batch's step sooner): the instantiations that exist at 32 lanes per env only
+  // -- elliptic cones (whatever set the model's opt_cone: the XML's <option cone> or a config switch), height-field floors, robots that are not the
+  // duck -- run there whatever was asked (odk_batch_lanes reports it)
+  b->G = (cfg->lanes_per_env == 64 && !m->h.cone && m->h.floor_is_plane && m->shape < 2) ? 64 : 32;
+#define X(i, S) if (m->shape == i) fill_sizes<S>(b);
+  ODK_SHAPES(X)
+#undef X
   DevPRM hp;
   memset(&hp, 0, sizeof(hp));
   hp.nx = nx; hp.ny = ny; hp.nth = nth; hp.nsteps = nsteps;
@@ -1704,17 +1761,12 @@ template <class S, int G, int HF> static hipError_t launch_sg(int which, const K
   else hipLaunchKernelGGL((physics_kernel<S, G, HF>), dim3(grid), dim3(64), lds, st, a);
   return hipGetLastError();
 }
-// physics only (ShapeC: a robot whose task logic is not the duck's)
-template <class S, int G> static hipError_t launch_phys(int which, const KArgs& a, hipStream_t st) {
-  if (which != K_PHYS) return hipErrorNotSupported;
-  const int per_block = 64 / G;
-  const int grid = (a.nenv + per_block - 1) / per_block;
-  hipLaunchKernelGGL((physics_kernel<S, G, 0>), dim3(grid), dim3(64), (size_t)EnvL<S>::wg_floats(per_block) * sizeof(float), st, a);
-  return hipGetLastError();
-}
 static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st) {
 #if defined(ODK_DEV_C32)   // development build: the tail_biped shape alone
-  if (b->model.shape == 2 && b->G == 32) return launch_phys<ShapeC, 32>(which, a, st);
+  if (b->model.shape == 2 && b->G == 32) return launch_sg<ShapeC, 32, 0>(which, a, st);
+  return hipErrorNotSupported;
+#elif defined(ODK_DEV_D32)   // development build: the six-dof biped's shape alone
+  if (b->model.shape == 3 && b->G == 32) return launch_sg<ShapeD, 32, 0>(which, a, st);
   return hipErrorNotSupported;
 #elif defined(ODK_DEV_B32)   // development builds: one instantiation only (make libodk_devB.so / libodk_devA.so: ~25 s instead of 2 min)
   if (b->model.shape == 1 && b->model.h.floor_is_plane && b->G == 32) return launch_sg<ShapeB, 32, 0>(which, a, st);
@@ -1732,8 +1784,10 @@ static hipError_t launch(odk_batch* b, int which, const KArgs& a, hipStream_t st
     if (b->model.h.cone) return launch_sg<ShapeBE, 32, 1>(which, a, st);      // (hull feet: checked at load)
     return b->model.h.foot_prim ? launch_sg<ShapeB, 32, 2>(which, a, st) : launch_sg<ShapeB, 32, 1>(which, a, st);
   }
-  if (b->model.shape == 2) return b->G == 32 ? launch_phys<ShapeC, 32>(which, a, st) : hipErrorNotSupported;
-  if (b->model.shape == 3) return b->G == 32 ? launch_phys<ShapeD, 32>(which, a, st) : hipErrorNotSupported;
+  // robots that are not the duck (reference README.md:74-85): reset / step / physics kernels of their own shape, 32 lanes per env
+#define X(i, S) if (i >= 2 && b->model.shape == i) return b->G == 32 ? launch_sg<S, 32, 0>(which, a, st) : hipErrorNotSupported;
+  ODK_SHAPES(X)
+#undef X
   if (b->model.h.cone) {      // the duck with elliptic cones (plane floor, checked at load): 32 lanes per env
     if (b->G != 32) return hipErrorNotSupported;
     return b->model.shape == 0 ? launch_sg<ShapeAE, 32, 0>(which, a, st) : launch_sg<ShapeBE, 32, 0>(which, a, st);
@@ -1749,7 +1803,18 @@ static void base_args(odk_batch* b, KArgs& a, const odk_outputs* o) {
   a.dr = b->dr_enabled ? b->d_dr : nullptr; a.nenv = b->nenv; a.n_substeps = b->cfg.n_substeps;
   a.dbg_lds = nullptr;
   if (o) { a.obs = o->obs_dev; a.priv = o->priv_dev; a.reward = o->reward_dev; a.done = o->done_dev; a.trunc = o->truncation_dev; a.metrics = o->metrics_dev; }
-  to_dev_cfg(b->cfg, a.cfg);
+  to_dev_cfg(b->cfg, a.cfg, b->model.h.nu);
+}
+
+// The env kernels' task logic is joystick.py's with the robot's own tables (actuators, default pose, feet / imu sites, sensor addresses from the
+// ModelBlob).  What stays the duck's: the imitation reward (its reference-motion table and joint map: custom_rewards.py:80-88) and the Standing
+// task's head joints (standing.py:590-597, rewards.py:131-147 index the duck's actuators 5..8) -- refused by name for another robot's
+// odk_reset / odk_step (odk_physics_step has no task logic)
+static int env_logic_ok(const odk_batch* b) {
+  if (b->model.shape >= 2 && (b->cfg.use_imitation || b->cfg.env_kind != ODK_ENV_JOYSTICK))
+    return fail(ODK_ERR_UNSUPPORTED, "%s on a robot that is not the duck: the reference-motion table / the head joints are open_duck_mini_v2's (set use_imitation = 0, env_kind = ODK_ENV_JOYSTICK)",
+                b->cfg.use_imitation ? "use_imitation" : "the Standing task");
+  return ODK_OK;
 }
 
 static int g_debug_dump = 0;
@@ -1757,6 +1822,7 @@ extern "C" void odk_set_debug_dump(int on) { g_debug_dump = on; }
 
 extern "C" int odk_reset(odk_batch* b, uint32_t seed, uint32_t env_id_offset, const odk_outputs* outs, void* stream) {
   if (!b) return fail(ODK_ERR_INVALID, "null batch");
+  if (int rc = env_logic_ok(b)) return rc;
   HIPCHK(hipSetDevice(b->device));
   KArgs a;
   base_args(b, a, outs);
@@ -1768,6 +1834,7 @@ extern "C" int odk_reset(odk_batch* b, uint32_t seed, uint32_t env_id_offset, co
 
 extern "C" int odk_step(odk_batch* b, const float* action_dev, const odk_outputs* outs, void* stream) {
   if (!b || !action_dev) return fail(ODK_ERR_INVALID, "null argument");
+  if (int rc = env_logic_ok(b)) return rc;
   HIPCHK(hipSetDevice(b->device));
   KArgs a;
   base_args(b, a, outs);
@@ -1820,22 +1887,24 @@ extern "C" int odk_batch_timing(odk_batch* b, int enable, float* avg_ms, int* la
   return ODK_OK;
 }
 
+extern "C" int odk_batch_lanes(const odk_batch* b) { return b ? b->G : -1; }
 extern "C" int odk_batch_record_size(const odk_batch* b) { return b ? b->rec_size : -1; }
 extern "C" int odk_batch_lds_size(const odk_batch* b) { return b ? b->lds_total : -1; }
 extern "C" int odk_record_field(const odk_batch* b, const char* name, int* offset, int* count, int* kind) {
   if (!b || !name) return fail(ODK_ERR_INVALID, "null argument");
   const int nq = b->model.h.nq, nv = b->model.h.nv, I = nq + 2 * nv, nu = b->model.h.nu;
+  const RecLay RL = rec_lay(nu);
   struct F { const char* name; int off, n, kind; };
   const F tab[] = {
     {"qpos", 0, nq, 0}, {"qvel", nq, nv, 0}, {"qacc_warmstart", nq + nv, nv, 0},
-    {"command", I + rec::CMD, 7, 0}, {"last_act", I + rec::LAST, nu, 0}, {"last_last_act", I + rec::LAST2, nu, 0},
-    {"last_last_last_act", I + rec::LAST3, nu, 0}, {"motor_targets", I + rec::MT, nu, 0}, {"feet_air_time", I + rec::AIR, 2, 0},
-    {"swing_peak", I + rec::PEAK, 2, 0}, {"push", I + rec::PUSH, 2, 0}, {"action_history", I + rec::AHIST, 3 * nu, 0},
-    {"imu_history", I + rec::IMU, 9, 0}, {"steps", I + rec::EPSTEPS, 1, 0}, {"truncation", I + rec::TRUNC, 1, 0},
-    {"episode_done", I + rec::DONE, 1, 0}, {"episode_metrics/sum_reward", I + rec::EPSUM, 1, 0}, {"episode_metrics/length", I + rec::EPLEN, 1, 0},
-    {"episode_metrics/reward_terms", I + rec::EPMET, 8, 0}, {"rng", I + rec::KEY0, 3, 1}, {"step", I + rec::STEP, 1, 1},
-    {"push_step", I + rec::PSTEP, 1, 1}, {"push_interval_steps", I + rec::PINT, 1, 1}, {"imitation_i", I + rec::IMI, 1, 1},
-    {"last_contact", I + rec::LCON, 1, 2},
+    {"command", I + RL.CMD, 7, 0}, {"last_act", I + RL.LAST, nu, 0}, {"last_last_act", I + RL.LAST2, nu, 0},
+    {"last_last_last_act", I + RL.LAST3, nu, 0}, {"motor_targets", I + RL.MT, nu, 0}, {"feet_air_time", I + RL.AIR, 2, 0},
+    {"swing_peak", I + RL.PEAK, 2, 0}, {"push", I + RL.PUSH, 2, 0}, {"action_history", I + RL.AHIST, 3 * nu, 0},
+    {"imu_history", I + RL.IMU, 9, 0}, {"steps", I + RL.EPSTEPS, 1, 0}, {"truncation", I + RL.TRUNC, 1, 0},
+    {"episode_done", I + RL.DONE, 1, 0}, {"episode_metrics/sum_reward", I + RL.EPSUM, 1, 0}, {"episode_metrics/length", I + RL.EPLEN, 1, 0},
+    {"episode_metrics/reward_terms", I + RL.EPMET, 8, 0}, {"rng", I + RL.KEY0, 3, 1}, {"step", I + RL.STEP, 1, 1},
+    {"push_step", I + RL.PSTEP, 1, 1}, {"push_interval_steps", I + RL.PINT, 1, 1}, {"imitation_i", I + RL.IMI, 1, 1},
+    {"last_contact", I + RL.LCON, 1, 2},
   };
   for (const F& f : tab)
     if (!strcmp(name, f.name)) {
@@ -1868,14 +1937,41 @@ extern "C" int odk_batch_get_lds(odk_batch* b, float* host) {  // debug image of
   return ODK_OK;
 }
 // named offsets into the LDS image for tests
+template <class S> static int lds_off(const char* name) {
+  if (!strcmp(name, "qpos")) return S::O_QPOS;
+  if (!strcmp(name, "qvel")) return S::O_QVEL;
+  if (!strcmp(name, "warm")) return S::O_WARM;
+  if (!strcmp(name, "ctrl")) return S::O_CTRL;
+  if (!strcmp(name, "xpos")) return S::O_XPOS;
+  if (!strcmp(name, "xquat")) return S::O_XQUAT;
+  if (!strcmp(name, "crb")) return S::O_CRB;
+  if (!strcmp(name, "cdof")) return S::O_CDOF;
+  if (!strcmp(name, "M")) return S::O_M;
+  if (!strcmp(name, "HL")) return S::O_HL;
+  if (!strcmp(name, "qfrc_smooth")) return S::O_QFS;
+  if (!strcmp(name, "qacc_smooth")) return S::O_QAS;
+  if (!strcmp(name, "x")) return S::O_X;
+  if (!strcmp(name, "Ma")) return S::O_MA;
+  if (!strcmp(name, "search")) return S::O_GRAD;
+  if (!strcmp(name, "mv")) return S::O_MV;
+  if (!strcmp(name, "efc_D")) return S::O_D;
+  if (!strcmp(name, "efc_aref")) return S::O_AREF;
+  if (!strcmp(name, "jar")) return S::O_JAR;
+  if (!strcmp(name, "jv")) return S::O_JV;
+  if (!strcmp(name, "W")) return S::O_W;
+  if (!strcmp(name, "contact_dist")) return S::O_CDIST;
+  if (!strcmp(name, "contact_r")) return S::O_CR;
+  if (!strcmp(name, "scr")) return S::O_SCR;
+  if (!strcmp(name, "sensordata")) return S::O_SENS;
+  if (!strcmp(name, "actuator_force")) return S::O_ACTF;
+  if (!strcmp(name, "qacc")) return S::O_QACC;
+  return -1;
+}
 extern "C" int odk_lds_offset(const odk_batch* b, const char* name) {
   if (!b || !name) return -1;
-#define OFF(nm, field) if (!strcmp(name, nm)) return b->model.shape == 0 ? ShapeA::field : (b->model.shape == 1 ? ShapeB::field : (b->model.shape == 2 ? ShapeC::field : ShapeD::field));
-  OFF("qpos", O_QPOS) OFF("qvel", O_QVEL) OFF("warm", O_WARM) OFF("ctrl", O_CTRL) OFF("xpos", O_XPOS) OFF("xquat", O_XQUAT) OFF("crb", O_CRB)
-  OFF("cdof", O_CDOF) OFF("M", O_M) OFF("HL", O_HL) OFF("qfrc_smooth", O_QFS) OFF("qacc_smooth", O_QAS) OFF("x", O_X) OFF("Ma", O_MA)
-  OFF("search", O_GRAD) OFF("mv", O_MV) OFF("efc_D", O_D) OFF("efc_aref", O_AREF) OFF("jar", O_JAR) OFF("jv", O_JV) OFF("W", O_W)
-  OFF("contact_dist", O_CDIST) OFF("contact_r", O_CR) OFF("scr", O_SCR) OFF("sensordata", O_SENS) OFF("actuator_force", O_ACTF) OFF("qacc", O_QACC)
-#undef OFF
+#define X(i, S) if (b->model.shape == i) return lds_off<S>(name);
+  ODK_SHAPES(X)
+#undef X
   return -1;
 }
 

@@ -135,11 +135,26 @@ struct Shape {
   static constexpr int O_CDIST = O_JV + NROW;        // [12]
   static constexpr int O_CR = O_CDIST + NCON;        // [12][3] contact position relative to the base origin
   static constexpr int O_SCR = O_CR + 3 * NCON;      // scratch: foot twists, wrenches, 6x6 blocks, sensor inputs
-  // (the chain solve's scratch starts at S_K = 24 and takes 3 CL 7 + 27 floats: 156 for chains of five, 177 for chains of six)
+  // scratch sub-offsets
+  static constexpr int S_VF = 0;      // [2][6] foot twist of the current vector
+  static constexpr int S_FF = 12;     // [2][6] foot wrench sums
+  static constexpr int S_K = 24;      // [3][36] K_L, K_R, K_X
+  static constexpr int S_FR = S_K;    // [8][9] frames of the floor contacts (height field / primitive feet): contact phase -> row phase only, ALIASES
+                                      // the K blocks (born in the solver).  NOT in the row arrays: the foot-foot routine's hull copies live there.
+  static constexpr int S_VF2 = 132;   // [2][6] second foot twist (warmstart candidate)
+  static constexpr int S_FFX = 144;   // [6] wrench sum of the foot-foot rows
+  static constexpr int S_EQ = 150;    // [EQ_MAX] equality rows: the Hessian's off-diagonal addend -D c (force phase -> Hessian entries; the solve's scratch runs over it afterwards)
+  // the chain solve's scratch starts at S_K and takes 3 CL 7 + 27 floats (156 for chains of five: up to S_MISC; 177 for chains of six): it runs over
+  // S_VF2 / S_FFX / S_EQ, which are dead by then -- but never over the misc scalars, which the env kernels' epilogue reads (foot heights, gravity)
+  static constexpr int S_SOLVE_END = S_K + 21 * CL + 27;
+  static constexpr int S_MISC = S_SOLVE_END > 156 ? S_SOLVE_END : 156;  // misc scalars (16)
+  static constexpr int S_PROF = S_MISC + 16;   // [20] per-phase cycle counters (ODK_PROFILE builds)
+  static constexpr int S_PROF2 = S_PROF + 20;  // [16] height-field contacts: hull setup, cull pass, register loads, pair loop, iterations, list length, -, -,
+                                               //      then inside a pair: select + prism, face query, Gauss-map tests, passing pairs, faces / polygons, clip + manifold, merge
 #ifdef ODK_PROFILE
-  static constexpr int N_SCR = 208;                  // + S_PROF (20) + S_PROF2 (16: sub-phases of the height-field contacts)
+  static constexpr int N_SCR = S_PROF2 + 16;
 #else
-  static constexpr int N_SCR = (24 + 21 * CL + 27) > 172 ? 180 : 172;      // no S_PROF slots outside profile builds
+  static constexpr int N_SCR = ((S_MISC + 16 + 3) / 4) * 4;      // no S_PROF slots outside profile builds (172 for chains of five)
 #endif
   static constexpr int O_SENS = O_JV;                // sensordata[46]: born after the line search (P10, last substep only), ALIASES jv
   static_assert(NSENSD <= NROW, "sensordata must fit in the jv rows");
@@ -152,20 +167,10 @@ struct Shape {
   static constexpr int O_WX = O_EQP + N_EQP;         // the contact row wrenches of a robot with fewer than 18 bodies
   static constexpr int O_W = W_FITS ? O_CFRC : O_WX;
   static constexpr int TOTAL = O_WX + (W_FITS ? 0 : 6 * NCROW);
-  static constexpr int ENV_STRIDE = TOTAL + 160;   // floats between the images of the two envs of a workgroup (odk_engine.hip EnvL::TOTAL: + info + action)
-  // scratch sub-offsets
-  static constexpr int S_VF = 0;      // [2][6] foot twist of the current vector
-  static constexpr int S_FF = 12;     // [2][6] foot wrench sums
-  static constexpr int S_K = 24;      // [3][36] K_L, K_R, K_X
-  static constexpr int S_FR = S_K;    // [8][9] frames of the floor contacts (height field / primitive feet): contact phase -> row phase only, ALIASES
-                                      // the K blocks (born in the solver).  NOT in the row arrays: the foot-foot routine's hull copies live there.
-  static constexpr int S_VF2 = 132;   // [2][6] second foot twist (warmstart candidate)
-  static constexpr int S_FFX = 144;   // [6] wrench sum of the foot-foot rows
-  static constexpr int S_EQ = 150;    // [EQ_MAX] equality rows: the Hessian's off-diagonal addend -D c (force phase -> Hessian entries; the solve's scratch runs over it afterwards)
-  static constexpr int S_MISC = 156;  // misc scalars (16)
-  static constexpr int S_PROF = 172;  // [20] per-phase cycle counters (ODK_PROFILE builds)
-  static constexpr int S_PROF2 = 192; // [16] height-field contacts: hull setup, cull pass, register loads, pair loop, iterations, list length, -, -,
-                                      //      then inside a pair: select + prism, face query, Gauss-map tests, passing pairs, faces / polygons, clip + manifold, merge
+  // the env logic's floats behind the physics image (odk_engine.hip EnvL): the carried info (43 + 7 NU floats, rec_lay) and this step's action + the
+  // imitation phase, both rounded up to whole float4s (the duck: 144 + 16)
+  static constexpr int N_INFO = ((43 + 7 * NU + 3) / 4) * 4, N_ACT = ((NU + 2 + 3) / 4) * 4;
+  static constexpr int ENV_STRIDE = TOTAL + N_INFO + N_ACT;   // floats between the images of the two envs of a workgroup (odk_engine.hip EnvL::TOTAL)
 };
 
 // Phase timing (build with -DODK_PROFILE): lane 0 accumulates shader-clock deltas per phase into the

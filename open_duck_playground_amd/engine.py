@@ -19,7 +19,7 @@ from .model import Model, asset_path
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("ODK_LIB", os.path.join(_CSRC, "libodk.so"))  # ODK_LIB: e.g. the -DODK_PROFILE build
 
-NOBS, NPRIV, NMETRIC, NU = 101, 212, 8, 14
+NOBS, NPRIV, NMETRIC, NU = 101, 212, 8, 14      # the duck's sizes; a Batch reports its model's own (nobs, npriv, model.nu)
 ADAM_ACC_FLOATS = 2 + 1024   # ODK_ADAM_ACC_FLOATS (include/odk.h)
 METRIC_NAMES = ("reward/tracking_lin_vel", "reward/tracking_ang_vel", "cost/torques", "cost/action_rate", "cost/stand_still",
                 "reward/alive", "reward/imitation", "swing_peak")
@@ -126,6 +126,8 @@ def load_library() -> C.CDLL:
     L.odk_model_load.argtypes = [C.c_char_p, C.c_uint64, PP]
     L.odk_model_free.argtypes = [P]
     L.odk_model_dims.argtypes = [P] + [C.POINTER(C.c_int)] * 4
+    L.odk_model_obs_sizes.argtypes = [P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.odk_batch_lanes.argtypes = [P]
     L.odk_model_reduced.argtypes = [P] + [C.POINTER(C.c_int)] * 6
     L.odk_model_env_lds_floats.argtypes = [P]
     L.odk_batch_create.argtypes = [P, C.POINTER(EnvConfig), C.c_int, C.c_int, FP, DP, C.c_int, DP, C.c_int, DP, C.c_int, DP, C.c_int, PP]
@@ -175,7 +177,7 @@ def load_library() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "odk_last_error", "odk_default_config", "odk_default_config_standing", "odk_obs_sizes", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_model_reduced",
+    "odk_last_error", "odk_default_config", "odk_default_config_standing", "odk_obs_sizes", "odk_model_load", "odk_model_free", "odk_model_dims", "odk_model_obs_sizes", "odk_batch_lanes", "odk_model_reduced",
     "odk_model_env_lds_floats", "odk_batch_create",
     "odk_batch_destroy", "odk_batch_set_config", "odk_batch_set_param", "odk_reset", "odk_step", "odk_physics_step",
     "odk_batch_get_state", "odk_batch_set_state", "odk_batch_get_debug", "odk_set_debug_dump", "odk_batch_lds_size",
@@ -198,10 +200,24 @@ def default_config(standing: bool = False) -> EnvConfig:
 
 
 def obs_sizes(env_kind: int):
-    """(nobs, npriv) row strides of the observation outputs for an env kind (0 Joystick, 1 Standing)."""
+    """(nobs, npriv) row strides of the observation outputs for an env kind (0 Joystick, 1 Standing) -- of the duck (14 actuators)."""
     a, b = C.c_int(0), C.c_int(0)
     load_library().odk_obs_sizes(int(env_kind), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def model_obs_sizes(model: Model, env_kind: int = 0):
+    """(nobs, npriv) of `model`'s env kernels (`odk_model_obs_sizes`): the reference's layout with the robot's actuator count; host-only."""
+    L = load_library()
+    blob = model.blob()
+    h = C.c_void_p()
+    _chk(L.odk_model_load(blob, len(blob), C.byref(h)))
+    try:
+        a, b = C.c_int(0), C.c_int(0)
+        _chk(L.odk_model_obs_sizes(h, int(env_kind), C.byref(a), C.byref(b)))
+        return a.value, b.value
+    finally:
+        L.odk_model_free(h)
 
 
 def model_reduction(model: Model) -> Dict:
@@ -762,7 +778,10 @@ class Batch:
                                      len(dys), _dp(dths), len(dths), _dp(ranges), int(prm["nb_steps_in_period"][0]), C.byref(self._b)))
         dev = torch.device("cuda", self.device)
         f32 = dict(dtype=torch.float32, device=dev)
-        self.nobs, self.npriv = obs_sizes(self.cfg.env_kind)
+        a_, b_ = C.c_int(0), C.c_int(0)
+        _chk(self.L.odk_model_obs_sizes(self._m, int(self.cfg.env_kind), C.byref(a_), C.byref(b_)))
+        self.nobs, self.npriv = a_.value, b_.value
+        self.lanes_per_env = int(self.L.odk_batch_lanes(self._b))      # what the kernels run (cfg.lanes_per_env is a hint)
         self.obs = torch.zeros(self.nenv, self.nobs, **f32)
         self.priv = torch.zeros(self.nenv, self.npriv, **f32)
         self.reward = torch.zeros(self.nenv, **f32)
@@ -790,7 +809,7 @@ class Batch:
         _chk(self.L.odk_reset(self._b, seed & 0xFFFFFFFF, env_id_offset, C.byref(self._outs), self._stream()))
 
     def step(self, action):
-        assert action.is_cuda and action.dtype == self.torch.float32 and action.is_contiguous() and tuple(action.shape) == (self.nenv, NU)
+        assert action.is_cuda and action.dtype == self.torch.float32 and action.is_contiguous() and tuple(action.shape) == (self.nenv, self.model.nu)
         self.generation += 1
         _chk(self.L.odk_step(self._b, C.c_void_p(action.data_ptr()), C.byref(self._outs), self._stream()))
 
@@ -810,7 +829,7 @@ class Batch:
         _chk(self.L.odk_batch_set_state(self._b, *[None if a is None else _fp(a) for a in arrs]))
 
     def get_debug(self):
-        s = np.zeros((self.nenv, 46), np.float32); a = np.zeros((self.nenv, NU), np.float32)
+        s = np.zeros((self.nenv, 46), np.float32); a = np.zeros((self.nenv, self.model.nu), np.float32)
         c = np.zeros((self.nenv, 12), np.float32); q = np.zeros((self.nenv, self.model.nv), np.float32)
         _chk(self.L.odk_batch_get_debug(self._b, _fp(s), _fp(a), _fp(c), _fp(q)))
         return dict(sensordata=s, actuator_force=a, contact_dist=c, qacc=q)

@@ -69,8 +69,9 @@ REWARD_SLOTS = ("tracking_lin_vel", "tracking_ang_vel", "torques", "action_rate"
 
 def to_engine_config(cfg: ConfigDict, autoreset: bool = True, lanes_per_env: int = 0, standing: bool = False,
                      reward_slots=REWARD_SLOTS, use_imitation: bool = USE_IMITATION_REWARD,
-                     use_motor_speed_limits: bool = USE_MOTOR_SPEED_LIMITS) -> engine.EnvConfig:
-    """reference config -> odk_env_config (include/odk.h)."""
+                     use_motor_speed_limits: bool = USE_MOTOR_SPEED_LIMITS, joints_order_no_head=None) -> engine.EnvConfig:
+    """reference config -> odk_env_config (include/odk.h).  `joints_order_no_head`: the robot's leg joints in actuator order (what a new robot's
+    constants.py sets, reference README.md:74-85); default: the duck's."""
     c = engine.default_config(standing)
     c.ctrl_dt, c.action_scale, c.dof_vel_scale = cfg.ctrl_dt, cfg.action_scale, cfg.dof_vel_scale
     c.max_motor_velocity = cfg.get("max_motor_velocity", 0.0)
@@ -81,7 +82,7 @@ def to_engine_config(cfg: ConfigDict, autoreset: bool = True, lanes_per_env: int
     c.noise_gravity, c.noise_joint_vel = n.scales.gravity, n.scales.joint_vel
     # BUG-COMPAT (joystick.py:184-200): indices taken on the 10-entry JOINTS_ORDER_NO_HEAD, written into the 14-entry array
     scale = np.zeros(16, np.float32)
-    for idx, j in enumerate(constants.JOINTS_ORDER_NO_HEAD):
+    for idx, j in enumerate((constants.JOINTS_ORDER_NO_HEAD if joints_order_no_head is None else list(joints_order_no_head))[:16]):
         scale[idx] = n.scales.hip_pos if "_hip" in j else (n.scales.knee_pos if "_knee" in j else n.scales.ankle_pos)
     for i in range(16):
         c.qpos_noise_scale[i] = float(scale[i])
@@ -205,9 +206,22 @@ class Joystick:
     METRIC_NAMES = engine.METRIC_NAMES
 
     def __init__(self, task: str = "flat_terrain", config: Optional[ConfigDict] = None, config_overrides: Optional[Dict[str, Any]] = None,
-                 num_envs: int = 8192, device: int = 0, autoreset: bool = True, lanes_per_env: int = 0, env_id_offset: int = 0):
+                 num_envs: int = 8192, device: int = 0, autoreset: bool = True, lanes_per_env: int = 0, env_id_offset: int = 0,
+                 xml_path: Optional[str] = None, model=None):
+        """`xml_path` / `model` (additive): a robot of one's own instead of a shipped task -- the MJCF (compiled by mjcf.py) or a compiled `Model`.
+        The reference's recipe for a new robot (README.md:74-85) copies base.py / constants.py / joystick.py and edits names; here the names the
+        reference looks up (constants.py: sites `imu`, `left_foot`, `right_foot`; geoms `left_foot_bottom_tpu`, `right_foot_bottom_tpu`, `floor`;
+        the 15 sensors; keyframe `home`) are what the XML must carry, and the index tables of base.py:63-125 / joystick.py:121-200 come out of the
+        compiled model.  Such a robot runs the Joystick task without the imitation reward (the reference-motion table is the duck's)."""
         self._config = _merge(config if config is not None else self._default_config(), config_overrides)
-        self._model = constants.task_to_model(task)      # KeyError for unknown task names
+        if model is not None:
+            self._model = model
+        elif xml_path is not None:
+            from .model import Model
+            self._model = Model.from_xml(xml_path, sim_dt=float(self._config.sim_dt))
+        else:
+            self._model = constants.task_to_model(task)      # KeyError for unknown task names
+        self._robot = constants.robot_of(self._model)
         cone = self._config.get("cone", None)
         if cone is not None:      # BUILD-DEFINED switch (the reference edits the XML's <option cone=...>): "pyramidal" | "elliptic", optional "impratio"
             if cone not in ("pyramidal", "elliptic"):
@@ -218,8 +232,8 @@ class Joystick:
             if self._config.get("impratio", None) is not None:
                 edit["opt_impratio"] = _np.array([float(self._config.get("impratio"))], _np.float64)
             self._model = Model({**self._model.a, **edit}, xml_path=self._model.xml_path)
-            if cone == "elliptic" and lanes_per_env == 64:
-                lanes_per_env = 32      # the cone kernels run 32 lanes per env (make_eval_env asks for 64 on small batches)
+        # (lanes_per_env is a hint: a model with elliptic cones -- from this switch or from its own XML --, a height field or a robot that is not the
+        # duck runs 32 lanes per env whatever is asked here; `batch.lanes_per_env` reports it)
         self._task = task
         self.num_envs = int(num_envs)
         self._env_id_offset = int(env_id_offset)
@@ -229,7 +243,8 @@ class Joystick:
         return default_config()
 
     def _engine_config(self, autoreset: bool, lanes_per_env: int) -> engine.EnvConfig:
-        return to_engine_config(self._config, autoreset, lanes_per_env)
+        return to_engine_config(self._config, autoreset, lanes_per_env, use_imitation=USE_IMITATION_REWARD and self._robot.is_open_duck,
+                                joints_order_no_head=self._robot.joints_order_no_head)
 
     # ---- reference accessors (base.py:277-291, MjxEnv)
     @property
@@ -258,7 +273,7 @@ class Joystick:
         # a few hundred envs leave most SIMDs empty, so an evaluation of 1000 sequential steps is bound by ONE wave's latency:
         # 64 lanes per env (one env per wave) finish a step 7 % sooner than two envs sharing a wave (0.194 vs 0.209 ms at 128 envs)
         return type(self)(task=self._task, config=self._config, num_envs=num_envs, device=self._batch.device, autoreset=True,
-                          lanes_per_env=64 if num_envs <= 1024 else 0, env_id_offset=1 << 24)
+                          lanes_per_env=64 if num_envs <= 1024 else 0, env_id_offset=1 << 24, model=self._model)
 
     def randomize(self, rng: np.random.Generator):
         """randomization_fn hook of brax ppo.train (reference runner.py:26, common/runner.py:108)."""

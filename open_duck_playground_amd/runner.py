@@ -35,7 +35,10 @@ class OpenDuckMiniV2Runner:
         overrides = {"hfield_up_normals_only": True} if getattr(args, "hfield_up_normals_only", False) else None
         if getattr(args, "cone", None):
             overrides = dict(overrides or {}, cone=args.cone)
-        self.env = available_envs[args.env](task=args.task, num_envs=n_local, device=device, env_id_offset=self.rank * n_local, config_overrides=overrides)
+        extra = {}
+        if getattr(args, "xml", None):      # a robot of one's own (reference README.md:74-85 "Adding a new robot"): its MJCF instead of a shipped task
+            extra["xml_path"] = args.xml
+        self.env = available_envs[args.env](task=args.task, num_envs=n_local, device=device, env_id_offset=self.rank * n_local, config_overrides=overrides, **extra)
         self.action_size = self.env.action_size
         self.obs_size = int(self.env.observation_size["state"][0])
         # one generator per (seed, rank, stream): stream 0 = training envs, 1 = evaluation envs (ppo/train.py)
@@ -97,6 +100,10 @@ def main():
                              "the reading under which rough_terrain_backlash trains: profiles/r4/hfield_variants.json)")
     parser.add_argument("--cone", choices=["pyramidal", "elliptic"], default=None,
                         help="friction cone of the contact solver (what <option cone=...> in the robot's XML sets; default: the model's own, pyramidal for the duck)")
+    parser.add_argument("--xml", type=str, default=None,
+                        help="train a robot of your own: path of its MJCF (additive; the reference's recipe is a copy of this package per robot, README.md:74-85). "
+                             "The XML carries the names constants.py looks up (sites imu / left_foot / right_foot, geoms left_foot_bottom_tpu / right_foot_bottom_tpu / "
+                             "floor, the 15 sensors, keyframe home); its model shape needs a compiled kernel: tools/new_shape.py <xml> prints the lines to add")
     args = parser.parse_args()
     runner = OpenDuckMiniV2Runner(args)
     try:

@@ -15,12 +15,13 @@
  * threefry2x32, 20 rounds (Salmon et al. 2011; the same block function JAX uses).
  *   env key      = TF(key=(seed, 'ODK1'), ctr=(env_id, 0))
  *   uniform(idx) = word[idx&1] of TF(key, ctr=(rng_ctr, idx>>1)), mapped to [0,1) by (w>>8)*2^-24
- * step draw ids (rng_ctr = 0 at reset's observation, then 1,2,...):
+ * step draw ids (rng_ctr = 0 at reset's observation, then 1,2,...), nu = the robot's actuators (the duck: 14):
  *   0 action-delay index | 2 push theta | 3 push magnitude | 4-6 gyro | 7-9 accelerometer |
  *   10-12 gravity (10 also drives the IMU-delay index: the reference reuses that key,
- *   joystick.py:513-529) | 13-26 joint angles | 27-40 joint velocities | 41-47 command | 48 zero-command
- * reset draw ids (key1 ^ 'RST!', ctr 0): 0-1 dxy | 2 yaw | 3-16 joint scale | 17-22 base qvel |
- *   23-29 command | 30 zero-command | 31 push interval */
+ *   joystick.py:513-529) | 13 .. 12+nu joint angles | 13+nu .. 12+2nu joint velocities | 13+2nu .. 19+2nu command |
+ *   20+2nu zero-command                                              (the duck: 13-26 | 27-40 | 41-47 | 48)
+ * reset draw ids (key1 ^ 'RST!', ctr 0): 0-1 dxy | 2 yaw | 3 .. 2+nu joint scale | 3+nu .. 8+nu base qvel |
+ *   9+nu .. 15+nu command | 16+nu zero-command | 17+nu push interval  (the duck: 3-16 | 17-22 | 23-29 | 30 | 31) */
 static uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 static void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t* o0, uint32_t* o1) {
   static const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
@@ -330,7 +331,7 @@ static void get_obs(odko_env* e, const real* contact) {
     ja[u] = d->qpos[e->act_qposadr[u]] + bl; /* joint_angles + joint_backlash (zeros where no twin) */
     jv[u] = d->qvel[e->act_dofadr[u]];
     nja[u] = ja[u] + (2.0 * U(e, 13 + u) - 1.0) * lvl * c->qpos_noise_scale[u];
-    njv[u] = jv[u] + (2.0 * U(e, 27 + u) - 1.0) * lvl * c->noise_joint_vel;
+    njv[u] = jv[u] + (2.0 * U(e, 13 + nu + u) - 1.0) * lvl * c->noise_joint_vel;
   }
   real* o = e->obs;
   int p = 0;
@@ -393,11 +394,11 @@ void odko_env_reset(odko_env* e, uint32_t seed, uint32_t env_id) {
   quat_mul_local(nq, d->qpos + 3, qz);
   memcpy(d->qpos + 3, nq, sizeof(nq));
   for (int u = 0; u < nu; u++) d->qpos[e->act_qposadr[u]] *= 0.5 + UR(e, 3 + u) * 1.0;
-  for (int k = 0; k < 6; k++) d->qvel[k] = -e->cfg.reset_base_qvel + UR(e, 17 + k) * (2 * e->cfg.reset_base_qvel);
+  for (int k = 0; k < 6; k++) d->qvel[k] = -e->cfg.reset_base_qvel + UR(e, 3 + nu + k) * (2 * e->cfg.reset_base_qvel);
   for (int u = 0; u < nu; u++) d->ctrl[u] = d->qpos[e->act_qposadr[u]];
   odko_forward(m, d);
-  sample_command(e, 1, 23, e->command);
-  real push_interval = e->cfg.push_interval_range[0] + UR(e, 31) * (e->cfg.push_interval_range[1] - e->cfg.push_interval_range[0]);
+  sample_command(e, 1, 9 + nu, e->command);
+  real push_interval = e->cfg.push_interval_range[0] + UR(e, 17 + nu) * (e->cfg.push_interval_range[1] - e->cfg.push_interval_range[0]);
   e->push_interval_steps = (int)rint(push_interval / e->cfg.ctrl_dt);
   if (e->cfg.use_imitation) odko_prm_eval(e->prm, e->command[0], e->command[1], e->command[2], 0, e->current_reference_motion);
   else memset(e->current_reference_motion, 0, sizeof(e->current_reference_motion));
@@ -503,7 +504,7 @@ void odko_env_step(odko_env* e, const real* action) {
   memcpy(e->last_last_last_act, e->last_last_act, sizeof(e->last_act));
   memcpy(e->last_last_act, e->last_act, sizeof(e->last_act));
   for (int u = 0; u < nu; u++) e->last_act[u] = action[u];
-  if (e->step > 500) sample_command(e, 0, 41, e->command);
+  if (e->step > 500) sample_command(e, 0, 13 + 2 * nu, e->command);
   if (done || e->step > 500) e->step = 0;
   for (int f = 0; f < 2; f++) {
     if (contact[f] != 0) { e->feet_air_time[f] = 0; e->swing_peak[f] = 0; }

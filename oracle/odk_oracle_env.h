@@ -17,8 +17,10 @@
 #define ODK_ORACLE_ENV_H
 #include "odk_oracle.h"
 
-#define ODKO_NOBS 101
-#define ODKO_NPRIV 212
+/* capacity of the observation arrays: 17 + 6 nu / + 69 + 3 nu floats for nu <= ODKO_MAXU = 16 actuators (the duck, nu = 14: 101 / 212;
+ * odko_env_nobs / odko_env_npriv give an env's own sizes, the rest of the arrays is zero) */
+#define ODKO_NOBS 113
+#define ODKO_NPRIV 230
 #define ODKO_NMETRIC 8 /* tracking_lin_vel, tracking_ang_vel, torques, action_rate, stand_still, alive, imitation, swing_peak */
 
 typedef struct {

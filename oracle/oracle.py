@@ -152,12 +152,33 @@ class _Fields:
         return self.view(name)
 
 
+def _blob_ints(blob: bytes, names):
+    """int32 records of an ODKM blob by name (layout: open_duck_playground_amd/model.py; the oracle keeps its own reader)"""
+    import struct
+    out = {}
+    if len(blob) < 16 or blob[:4] != b"ODKM":
+        return out
+    n = struct.unpack_from("<I", blob, 8)[0]
+    off = 16
+    for _ in range(n):
+        nm, code, ndim, s0, s1, s2, s3, nbytes = struct.unpack_from("<32sII4IQ", blob, off)
+        off += 64
+        key = nm.rstrip(b"\0").decode()
+        if key in names and code == 1:
+            out[key] = np.frombuffer(blob, dtype="<i4", count=nbytes // 4, offset=off).copy()
+        off += nbytes + ((-nbytes) % 8)
+    return out
+
+
 class OracleModel:
-    def __init__(self, blob: bytes, f32: bool = False, _handle=None):
+    def __init__(self, blob: bytes, f32: bool = False, _handle=None, _named=None):
         self.L = lib(f32)
         self.h = _handle if _handle is not None else self.L.lib.odko_model_load(blob, len(blob))
         if not self.h:
             raise ValueError("odko_model_load failed")
+        # the named objects the env logic looks up (reference base.py:63-125, joystick.py:121-181: imu / feet sites, feet / floor geoms, sensor
+        # addresses), as the model compiler resolved them: OracleEnv hands them to the C env (whose defaults are the duck's)
+        self.named = _named if _named is not None else _blob_ints(blob, ("k_site_imu", "k_site_feet", "k_foot_cgeom", "k_floor_cgeom", "k_adr"))
         self.f = _Fields(self.L, self.h, self.L.lib.odko_model_field)
         for k in ("nq", "nv", "nu", "nbody", "njnt", "nsite", "nsensordata", "ncgeom", "npair", "neq"):
             setattr(self, k, self.L.lib.odko_model_int(self.h, k.encode()))
@@ -184,7 +205,7 @@ class OracleModel:
         self.L.lib.odko_model_jitter_hulls(self.h, int(seed), rel)
 
     def copy(self) -> "OracleModel":
-        return OracleModel(b"", self.L.f32, _handle=self.L.lib.odko_model_copy(self.h))
+        return OracleModel(b"", self.L.f32, _handle=self.L.lib.odko_model_copy(self.h), _named=self.named)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -283,6 +304,14 @@ class OracleEnv:
         self.f = _Fields(self.L, self.h, self.L.lib.odko_env_field)
         self.cfg = _Fields(self.L, self.h, self.L.lib.odko_env_config)
         self.data = OracleData(model, _handle=self.L.lib.odko_env_data(self.h), owner=False)
+        nm = getattr(model, "named", None) or {}
+        if _handle is None and len(nm) == 5:      # (a clone carries its parent's)
+            self.ints("imu_site")[0] = nm["k_site_imu"][0]; self.ints("feet_site")[:] = nm["k_site_feet"][:2]
+            self.ints("feet_cgeom")[:] = nm["k_foot_cgeom"][:2]; self.ints("floor_cgeom")[0] = nm["k_floor_cgeom"][0]
+            a = nm["k_adr"]
+            for k, name in enumerate(("adr_gyro", "adr_local_linvel", "adr_accelerometer", "adr_upvector", "adr_global_angvel")):
+                self.ints(name)[0] = a[k]
+            self.ints("adr_foot_linvel")[:] = a[5:7]
 
     def clone(self) -> "OracleEnv":
         """an independent copy of the whole env (state, info, wrappers, config) sharing the model and the motion table"""

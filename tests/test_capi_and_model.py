@@ -300,6 +300,66 @@ def test_loader_takes_a_biped_with_six_dof_legs():
     assert engine.model_reduction(Model(eq))["nvr"] == 18          # a joint coupling inside one leg: taken, like the third shape's
 
 
+def test_observation_sizes_and_robot_constants_follow_the_model(model_a, model_b):
+    """`odk_model_obs_sizes` (what `observation_size` of the reference's env reports, joystick.py:570-615 with the robot's actuator count) and
+    `constants.robot_of` (what a new robot's constants.py spells out, reference README.md:74-85), host-only: the duck 101 / 212 and 85 / 153,
+    a twelve-actuator biped 89 / 194, the tail biped (15 actuators) 107 / 221."""
+    import os
+    from open_duck_playground_amd import constants, engine
+    from open_duck_playground_amd.model import Model
+    assets = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+    assert engine.model_obs_sizes(model_a, 0) == engine.obs_sizes(0) == (101, 212) and engine.model_obs_sizes(model_b, 1) == engine.obs_sizes(1) == (85, 153)
+    b12 = Model.from_xml(os.path.join(assets, "biped12.xml"))
+    tb = Model.from_xml(os.path.join(assets, "tail_biped.xml"))
+    assert engine.model_obs_sizes(b12, 0) == (89, 194) and engine.model_obs_sizes(tb, 0) == (107, 221)
+    assert constants.robot_of(model_a).is_open_duck and constants.robot_of(model_b).is_open_duck
+    assert constants.robot_of(model_a).joints_order_no_head == constants.JOINTS_ORDER_NO_HEAD
+    r = constants.robot_of(b12)
+    assert not r.is_open_duck and r.joints_order_no_head == [str(n) for n in b12.a["names_actuator"]]      # every actuator of this robot is a leg joint
+    r = constants.robot_of(tb)
+    assert not r.is_open_duck and len(r.joints_order_no_head) == 10 and all("tail" not in j for j in r.joints_order_no_head)
+    # the engine config of such a robot: no imitation reward, qpos noise by the robot's own joint names
+    from open_duck_playground_amd import joystick
+    cfg = joystick.to_engine_config(joystick.default_config(), use_imitation=False, joints_order_no_head=constants.robot_of(b12).joints_order_no_head)
+    assert cfg.use_imitation == 0
+    np.testing.assert_allclose(list(cfg.qpos_noise_scale)[:12], [0.03, 0.03, 0.03, 0.05, 0.08, 0.08] * 2, rtol=1e-6)
+
+
+def test_new_shape_tool_names_the_lines_a_new_robot_needs(tmp_path, capsys):
+    """tools/new_shape.py (reference README.md:74-85 "Adding a new robot"): a robot a compiled shape takes -> its env sizes and the runner line;
+    a robot with another model shape (biped12 with an extra torso joint chain) -> the `using Shape<...>` line and the ODK_SHAPES entry."""
+    import importlib.util, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("new_shape", os.path.join(root, "tools", "new_shape.py"))
+    ns = importlib.util.module_from_spec(spec); spec.loader.exec_module(ns)
+    import sys
+    argv = sys.argv
+    try:
+        sys.argv = ["new_shape.py", os.path.join(root, "tests", "assets", "biped12.xml")]
+        assert ns.main() == 0
+        out = capsys.readouterr().out
+        assert "a compiled kernel shape takes it" in out and "action 12, observation 89, privileged observation 194" in out and "--xml" in out
+        # the same robot with a two-link neck on the trunk (two more hinges + actuators): 20 dofs, 14 actuators, but not the duck's tree
+        src = open(os.path.join(root, "tests", "assets", "biped12.xml")).read()
+        neck = ('<body name="neck" pos="0.02 0 0.12"><inertial pos="0 0 0.02" mass="0.05" fullinertia="2e-5 2e-5 1e-5 0 0 0"/><joint name="neck_a" axis="0 1 0" range="-0.5 0.5"/>'
+                '<body name="head" pos="0 0 0.04"><inertial pos="0 0 0.02" mass="0.08" fullinertia="4e-5 4e-5 3e-5 0 0 0"/><joint name="neck_b" axis="0 0 1" range="-0.8 0.8"/></body></body>')
+        src = src.replace('<body name="left_hip_yaw_link"', neck + '<body name="left_hip_yaw_link"', 1)
+        src = src.replace('</actuator>', '<position name="neck_a" joint="neck_a" kp="5" forcerange="-1 1" inheritrange="1"/><position name="neck_b" joint="neck_b" kp="5" forcerange="-1 1" inheritrange="1"/></actuator>')
+        src = src.replace('0 0 -0.4 0.8 -0.4 0  0 0 -0.4 0.8 -0.4 0" ctrl="0 0 -0.4 0.8 -0.4 0  0 0 -0.4 0.8 -0.4 0"', '0 0  0 0 -0.4 0.8 -0.4 0  0 0 -0.4 0.8 -0.4 0" ctrl="0 0 -0.4 0.8 -0.4 0  0 0 -0.4 0.8 -0.4 0  0 0"')
+        xml = tmp_path / "biped12_neck.xml"
+        xml.write_text(src)
+        sys.argv = ["new_shape.py", str(xml)]
+        assert ns.main() == 1
+        out = capsys.readouterr().out
+        m = re.search(r"using ShapeX = Shape<([^>]*)>;", out)
+        assert m, out
+        dims = [t.strip() for t in m.group(1).split(",")]
+        assert dims[:5] == ["21", "20", "18", "14", "15"] and dims[-3:] == ["false", "6", "true"]      # nq, nv, nbody, nu, njnt ...; chains of six; optional constraint code
+        assert "X(4, ShapeX)" in out and "ODK_SHAPES" in out
+    finally:
+        sys.argv = argv
+
+
 def test_compiler_refuses_colliding_primitives(tmp_path):
     from open_duck_playground_amd import mjcf
     xml = """<mujoco><compiler angle="radian"/><worldbody>

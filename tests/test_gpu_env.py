@@ -70,15 +70,25 @@ def _ill_resets(envs, model, nobs):
 RESET_BOUNDS = dict(obs=1e-5, acc=1e-3, qpos=1e-6, qvel=1e-6)   # measured: 3.5e-6, 3.2e-4, 1.8e-7, 2e-9
 
 
+def _xml_model(xml):
+    import os
+    from open_duck_playground_amd.model import Model
+    return Model.from_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", xml), sim_dt=0.002)
+
+
 def _mk(oracle_mod, task, n, cfg_edit=None, standing=False, dr_fields=None, model_edit=None):
+    """`task`: a shipped task name, or the file name of a robot under tests/assets/ (a robot that is not the duck: no imitation reward)"""
     import torch
     from open_duck_playground_amd import engine, randomize
     from open_duck_playground_amd.model import load_task_model
-    model = load_task_model(task)
+    robot = task.endswith(".xml")
+    model = _xml_model(task) if robot else load_task_model(task)
     if model_edit:      # the task's model with some arrays replaced (e.g. opt_cone)
         from open_duck_playground_amd.model import Model
         model = Model({**model.a, **model_edit})
     cfg = engine.default_config(standing)
+    if robot:
+        cfg.use_imitation = 0
     if cfg_edit:
         cfg_edit(cfg)
     b = engine.Batch(model, n, cfg)
@@ -94,6 +104,7 @@ def _mk(oracle_mod, task, n, cfg_edit=None, standing=False, dr_fields=None, mode
         e.cfg["episode_length"][0] = cfg.episode_length
         e.cfg["noise_level"][0] = cfg.noise_level
         e.cfg["push_enable"][0] = cfg.push_enable
+        e.cfg["use_imitation"][0] = cfg.use_imitation
     return torch, model, b, envs, (base, prm, oms)
 
 
@@ -639,3 +650,170 @@ def test_standing_python_env_surface():
     assert set(st.metrics) == {"cost/orientation", "cost/head_pos", "cost/torques", "cost/action_rate", "cost/stand_still", "reward/alive", "swing_peak"}
     assert tuple(st.obs["state"].shape) == (64, 85) and torch.isfinite(st.obs["privileged_state"]).all()
     assert float(st.metrics["reward/alive"].min()) == 20.0 and float(st.metrics["cost/head_pos"].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Robots that are not the duck through odk_reset / odk_step (reference README.md:74-85 "Adding a new robot"): the env kernels
+# instantiated for their shapes -- observation / action / history sizes from the robot's actuator count, actuators, default pose, feet and
+# imu sites, sensor addresses from the ModelBlob -- against the nu-generic oracle env, at the duck's bounds.
+ROBOTS = [("biped12.xml", 12, 89, 194), ("tail_biped.xml", 15, 107, 221)]
+# The error bounds are the duck's (measured: obs 2.3e-5, accelerometer 2.0e-4, reward 5.4e-6, metrics 2.0e-4; 0 unexplained).  What differs is how
+# many env steps the ORACLE sets aside by its own sensitivity: these robots stand on BOX feet, whose four sole vertices touch a plane floor at the
+# same depth -- the manifold's arg-max steps tie by construction whenever a foot lies flat (measured 8.8 % / 10.4 % / 12.6 % of the env steps
+# against the duck's 2-5 % on its 17-vertex hull): bound = measured + ~7 points.
+SET_ASIDE_BOX = dict(SET_ASIDE, ill_fraction=0.2)
+
+
+@pytest.mark.parametrize("xml,nu,nobs,npriv", ROBOTS)
+def test_reset_of_a_robot_that_is_not_the_duck(oracle_mod, parity_log, xml, nu, nobs, npriv):
+    torch, model, b, envs, keep = _mk(oracle_mod, xml, 32)
+    assert model.nu == nu and (b.nobs, b.npriv) == (nobs, npriv) == (envs[0].nobs, envs[0].npriv) and tuple(b.obs.shape) == (32, nobs)
+    assert b.lanes_per_env == 32
+    b.reset(seed=5, env_id_offset=100)
+    obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy()
+    qpos, qvel, warm = b.get_state()
+    I = b.info()
+    W = dict(obs=0.0, acc=0.0, qpos=0.0, qvel=0.0)
+    for i, e in enumerate(envs):
+        e.reset(5, 100 + i)
+    ill = _ill_resets(envs, model, nobs)
+    for i, e in enumerate(envs):
+        W["qpos"] = max(W["qpos"], np.abs(qpos[i] - e.data["qpos"][: model.nq]).max())
+        W["qvel"] = max(W["qvel"], np.abs(qvel[i] - e.data["qvel"][: model.nv]).max())
+        o, a = _obs_err(obs[i], priv[i], e, nobs, npriv)
+        W["obs"] = max(W["obs"], o); W["acc"] = max(W["acc"], 0.0 if i in ill else a)
+        np.testing.assert_allclose(I["command"][i], e["command"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(I["motor_targets"][i], e["motor_targets"][:nu], rtol=1e-6, atol=1e-7)
+        assert I["action_history"].shape[1] == 3 * nu
+        assert int(I["push_interval_steps"][i]) == int(e.ints("push_interval_steps")[0])
+    b.close()
+    parity_log.check(f"robot_env/{xml}/reset", RESET_BOUNDS, **W)
+
+
+@pytest.mark.parametrize("xml,nu,nobs,npriv", ROBOTS)
+def test_step_sequence_of_a_robot_that_is_not_the_duck(oracle_mod, parity_log, xml, nu, nobs, npriv):
+    """`test_step_sequence_with_resync` for a robot that is not the duck: 60 env steps with random actions, observation noise, pushes, truncation
+    and auto-reset on; physics re-synchronised before every step, the carried info (rings sized by the robot's actuator count, RNG counters,
+    episode counters) running free on the GPU."""
+    def edit(cfg):
+        cfg.episode_length = 25
+    torch, model, b, envs, keep = _mk(oracle_mod, xml, 32, edit)
+    n = len(envs)
+    b.reset(seed=9)
+    for i, e in enumerate(envs):
+        e.reset(9, i)
+    rng = np.random.default_rng(0)
+    W = _new_W()
+    W["reset_ill"] = _ill_resets(envs, model, nobs)
+    for t in range(60):
+        _resync(b, envs, model)
+        act = rng.uniform(-1, 1, (n, nu)).astype(np.float32)
+        _step_and_compare(torch, b, envs, act, nobs, npriv, t, W)
+    assert W["n_trunc"] > 0, "sequence must cross truncations"
+    I = b.info()
+    for i, e in enumerate(envs):
+        np.testing.assert_allclose(I["last_act"][i], e["last_act"][:nu], atol=1e-6)
+        np.testing.assert_allclose(I["last_last_last_act"][i], e["last_last_last_act"][:nu], atol=1e-6)
+        np.testing.assert_allclose(I["action_history"][i], e["action_history"][:3 * nu], atol=1e-6)
+        assert int(I["rng"][i, 2]) == int(e.ints("rng_ctr")[0])
+        assert int(I["imitation_i"][i]) == 0
+    b.close()
+    parity_log.check(f"robot_env/{xml}/env_step", {**ENV_BOUNDS, **SET_ASIDE_BOX}, **_errs(W))
+
+
+def test_a_robot_that_is_not_the_duck_with_domain_randomisation_and_command_resampling(oracle_mod, parity_log):
+    """biped12 with randomize.py's per-env model fields through odk_reset / odk_step, and info["step"] preset so that some envs resample their
+    command inside the sequence (draws 13 + 2 nu ...)."""
+    from open_duck_playground_amd import randomize
+    xml, nu, nobs, npriv = ROBOTS[0]
+    n = 32
+    fields, _ = randomize.domain_randomize(_xml_model(xml), np.random.default_rng(17), n)
+
+    def edit(cfg):
+        cfg.episode_length = 20
+    torch, model, b, envs, keep = _mk(oracle_mod, xml, n, edit, dr_fields=fields)
+    b.reset(seed=21)
+    obs = b.obs.cpu().numpy(); priv = b.priv.cpu().numpy()
+    WR = dict(obs=0.0, acc=0.0)
+    for i, e in enumerate(envs):
+        e.reset(21, i)
+    ill = _ill_resets(envs, model, nobs)
+    for i, e in enumerate(envs):
+        o, a = _obs_err(obs[i], priv[i], e, nobs, npriv)
+        WR["obs"] = max(WR["obs"], o); WR["acc"] = max(WR["acc"], 0.0 if i in ill else a)
+    I = b.info()
+    preset = np.where(np.arange(n) % 2 == 0, 500, 7).astype(np.int32)
+    I["step"][:] = preset
+    b.set_records(I["_records"])
+    old_cmd = np.stack([np.array(e["command"][:7]) for e in envs])
+    for i, e in enumerate(envs):
+        e.ints("step")[0] = int(preset[i])
+    rng = np.random.default_rng(6)
+    W = _new_W()
+    W["reset_ill"] = ill
+    n_resampled = 0
+    for t in range(30):
+        _resync(b, envs, model)
+        act = rng.uniform(-1, 1, (n, nu)).astype(np.float32)
+        _step_and_compare(torch, b, envs, act, nobs, npriv, t, W)
+        if t == 0:
+            I = b.info()
+            for i, e in enumerate(envs):
+                np.testing.assert_allclose(I["command"][i], np.array(e["command"][:7]), rtol=1e-6, atol=1e-7)
+                n_resampled += int(preset[i] == 500 and not np.array_equal(np.array(e["command"][:7]), old_cmd[i]))
+    assert n_resampled >= n // 2 - 2
+    b.close()
+    parity_log.check(f"robot_env/{xml}/dr/reset", dict(obs=RESET_BOUNDS["obs"], acc=RESET_BOUNDS["acc"]), **WR)
+    parity_log.check(f"robot_env/{xml}/dr/env_step", {**ENV_BOUNDS, **SET_ASIDE_BOX}, **_errs(W))
+
+
+def test_python_env_surface_of_a_robot_from_its_xml():
+    """`Joystick(xml_path=...)` (runner --xml): sizes, stepping, the evaluation sibling, and the refusals (Standing / imitation are the duck's)."""
+    import os
+    import torch
+    from open_duck_playground_amd import engine, joystick, standing
+    xml = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "biped12.xml")
+    env = joystick.Joystick(xml_path=xml, num_envs=64)
+    assert env.action_size == 12 and env.observation_size == {"state": (89,), "privileged_state": (194,)} and env.xml_path == xml
+    st = env.reset(0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(5):
+        st = env.step(st, torch.empty(64, 12, device="cuda").uniform_(-1, 1, generator=g))
+    assert tuple(st.obs["state"].shape) == (64, 89) and torch.isfinite(st.obs["privileged_state"]).all() and torch.isfinite(st.reward).all()
+    assert float(st.metrics["reward/alive"].min()) == 20.0 and float(st.metrics["reward/imitation"].abs().max()) == 0.0
+    assert tuple(st.info["action_history"].shape) == (64, 36) and tuple(st.info["motor_targets"].shape) == (64, 12)
+    ev = env.make_eval_env(128)      # asks for 64 lanes per env; this robot's kernels exist at 32
+    assert ev.batch.lanes_per_env == 32 and ev.action_size == 12
+    ev.reset(1)
+    ev.step(None, torch.zeros(128, 12, device="cuda"))
+    assert torch.isfinite(ev.batch.obs).all()
+    env.randomize(np.random.default_rng(0))      # randomize.py's fields apply to any robot
+    env.step(st, torch.zeros(64, 12, device="cuda"))
+    assert torch.isfinite(env.batch.reward).all()
+    with pytest.raises(engine.OdkError, match="not the duck"):
+        standing.Standing(xml_path=xml, num_envs=8).reset(0)
+
+
+def test_a_model_whose_own_xml_sets_the_elliptic_cone_evaluates_at_32_lanes(tmp_path):
+    """the cone of a model may come from its XML (`<option cone="elliptic">`, the reference's way) and not from the
+    `cone` config switch; the evaluation sibling asks for 64 lanes per env on small batches and must still get the cone kernels (32)."""
+    import os
+    import torch
+    from open_duck_playground_amd import joystick
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "biped12.xml")).read()
+    xml = tmp_path / "biped12_elliptic.xml"
+    xml.write_text(src.replace('<option timestep="0.002"', '<option cone="elliptic" impratio="2" timestep="0.002"'))
+    env = joystick.Joystick(xml_path=str(xml), num_envs=32)
+    assert int(env.mj_model.a["opt_cone"][0]) == 1
+    ev = env.make_eval_env(64)
+    assert ev.batch.lanes_per_env == 32
+    st = ev.reset(0)
+    st = ev.step(st, torch.zeros(64, 12, device="cuda"))
+    assert torch.isfinite(st.obs["state"]).all()
+    from open_duck_playground_amd.model import Model, load_task_model
+    duck = load_task_model("flat_terrain")
+    env2 = joystick.Joystick(model=Model({**duck.a, "opt_cone": np.array([1], np.int32)}), num_envs=32)      # the duck with the cone in the model itself
+    ev2 = env2.make_eval_env(64)
+    assert ev2.batch.lanes_per_env == 32
+    ev2.step(ev2.reset(0), torch.zeros(64, 14, device="cuda"))
+    assert torch.isfinite(ev2.batch.obs).all()

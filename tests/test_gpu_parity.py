@@ -507,7 +507,7 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
 def test_the_duck_with_elliptic_cones(torch_cuda, oracle_mod, parity_log, task):
     """`<option cone="elliptic">` on the duck itself: opt_cone = 1 (impratio 1, as the file has it), the physics kernels of the duck's shapes
     with the cone code (`ShapeAE` / `ShapeBE`; plane floor and the backlash model's height field) against the float64 oracle: the state after one
-    mjx.step and after ten, at the duck's bounds; 64 lanes per env and primitive feet are refused by name (the cone kernels: 32 lanes, hulls)."""
+    mjx.step and after ten, at the duck's bounds; asked for 64 lanes per env the batch runs the cone kernels' 32; primitive feet are refused by name."""
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.model import Model, load_task_model
     torch = torch_cuda
@@ -556,9 +556,10 @@ def test_the_duck_with_elliptic_cones(torch_cuda, oracle_mod, parity_log, task):
     print(task, "elliptic: one step", W, "ten substeps", T, "ill", n_ill, "of", n)
     parity_log.check(f"duck_elliptic/{task}/one_mjx_step", dict({k: STAGE_BOUNDS[k] for k in W}, ill_fraction=0.3), ill_fraction=n_ill[1] / n, **W)
     parity_log.check(f"duck_elliptic/{task}/ten_substeps", dict(TEN_BOUNDS, ill_fraction=0.65 if "rough" in task else 0.55), ill_fraction=n_ill[10] / n, **T)
-    cfg = engine.default_config(); cfg.lanes_per_env = 64
-    with pytest.raises(engine.OdkError, match="32 lanes"):
-        engine.Batch(model, 8, cfg)
+    cfg = engine.default_config(); cfg.lanes_per_env = 64      # a hint: the cone kernels exist at 32 lanes per env, and that is what runs
+    b64 = engine.Batch(model, 8, cfg)
+    assert b64.lanes_per_env == 32
+    b64.close()
     if task == "flat_terrain":      # sphere / capsule feet have no cone kernels: refused by name
         prim = _prim_feet_variant("flat_terrain", ("sphere", "capsule"))
         with pytest.raises(engine.OdkError, match="sphere / capsule"):

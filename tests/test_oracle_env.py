@@ -203,3 +203,79 @@ def test_standing_step_rewards_and_no_speed_limit(senv, model_a):
     assert m[4] == pytest.approx(-expected[4], rel=1e-9)
     total = sum(expected.values()) * 0.02
     assert e["reward"][0] == pytest.approx(min(max(total, 0.0), 1e4), rel=1e-9, abs=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# A robot that is not the duck (reference README.md:74-85): tests/assets/biped12.xml, 12 actuators.  The env logic is joystick.py's with
+# nu = 12 in place of 14: observation 17 + 6 nu = 89 floats, privileged 89 + 69 + 3 nu = 194; every draw id behind the joint block moves
+# with nu (odk_oracle_env.c header).
+@pytest.fixture()
+def benv(oracle_mod, prm_arrays):
+    import os
+    from open_duck_playground_amd.model import Model
+    model = Model.from_xml(os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "biped12.xml"), sim_dt=0.002)
+    om = oracle_mod.OracleModel(model.blob())
+    prm = oracle_mod.OraclePRM(prm_arrays)
+    e = oracle_mod.OracleEnv(om, prm)
+    e.cfg["use_imitation"][0] = 0.0      # the reference-motion table is the duck's
+    e._keep = (om, prm, model)
+    return e
+
+
+def test_a_twelve_actuator_robot_reset_and_obs_layout(benv):
+    model = benv._keep[2]
+    nu = 12
+    assert (benv.nobs, benv.npriv) == (17 + 6 * nu, 17 + 6 * nu + 69 + 3 * nu) == (89, 194)
+    benv.cfg["noise_level"][0] = 0.0
+    benv.reset(3, 7)
+    q = benv.data["qpos"][: model.nq]
+    home = model.a["key_qpos"]
+    assert abs(q[0]) <= 0.05 and abs(q[1]) <= 0.05 and q[2] == pytest.approx(home[2])
+    obs, priv = benv["obs"], benv["priv"]
+    np.testing.assert_allclose(obs[6:13], benv["command"])
+    np.testing.assert_allclose(obs[13:13 + nu], q[7:] - model.a["key_ctrl"], atol=1e-12)          # joint angles - default (:541-549)
+    np.testing.assert_allclose(obs[13 + 2 * nu:13 + 5 * nu], 0)                                   # three action histories
+    np.testing.assert_allclose(obs[13 + 5 * nu:13 + 6 * nu], model.a["key_ctrl"])                 # motor_targets (:285)
+    np.testing.assert_allclose(obs[15 + 6 * nu:17 + 6 * nu], 0)                                   # imitation phase
+    np.testing.assert_allclose(obs[89:], 0); np.testing.assert_allclose(priv[194:], 0)            # nothing behind the robot's own sizes
+    np.testing.assert_allclose(priv[:89], obs[:89])
+    np.testing.assert_allclose(priv[89:92], benv.data["sensordata"][0:3])                         # gyro
+    assert priv[89 + 15 + 2 * nu] == pytest.approx(q[2])                                          # root height
+    np.testing.assert_allclose(priv[89 + 26 + 3 * nu:89 + 66 + 3 * nu], 0)                        # current_reference_motion: none
+    # reset draws: the base velocity uses draws 3 + nu .. 8 + nu, the command 9 + nu .., the push interval 17 + nu
+    k = benv.ints("key")
+    U = lambda i: benv.L.lib.odko_rng_uniform(int(k[0]), int(k[1]) ^ 0x52535421, 0, i)
+    np.testing.assert_allclose(benv.data["qvel"][:6], [-0.05 + U(3 + nu + j) * 0.1 for j in range(6)], rtol=1e-6)
+    assert benv.ints("push_interval_steps")[0] == int(np.rint((5.0 + U(17 + nu) * 5.0) / 0.02))
+
+
+def test_a_twelve_actuator_robot_step_noise_draws_and_rewards(benv):
+    model = benv._keep[2]
+    nu = 12
+    benv.cfg["push_enable"][0] = 0.0
+    benv.reset(5, 1)
+    a = np.linspace(-0.5, 0.5, nu)
+    pre = benv.clone()
+    benv.step(a)
+    # the same step without noise: the obs differ by exactly the draws the header names
+    pre.cfg["noise_level"][0] = 0.0
+    pre.step(a)
+    k = benv.ints("key")
+    U = lambda i: benv.L.lib.odko_rng_uniform(int(k[0]), int(k[1]), 1, i)
+    d = np.array(benv["obs"][:89]) - np.array(pre["obs"][:89])
+    np.testing.assert_allclose(d[0:3], [(2 * U(4 + j) - 1) * 0.1 for j in range(3)], atol=1e-7)                      # gyro
+    scale = np.array(benv.cfg["qpos_noise_scale"][:nu])
+    np.testing.assert_allclose(d[13:13 + nu], [(2 * U(13 + u) - 1) * scale[u] for u in range(nu)], atol=1e-7)       # joint angles
+    np.testing.assert_allclose(d[13 + nu:13 + 2 * nu], [(2 * U(13 + nu + u) - 1) * 2.5 * 0.05 for u in range(nu)], atol=1e-7)   # joint velocities
+    np.testing.assert_allclose(d[13 + 2 * nu:], 0, atol=1e-12)
+    m = benv["metrics"][:8]
+    assert m[5] == pytest.approx(20.0) and m[6] == 0.0                # alive; no imitation reward for this robot
+    np.testing.assert_allclose(benv["last_act"][:nu], a)
+    np.testing.assert_allclose(benv["action_history"][:nu], a)
+    # command resampling reads draws 13 + 2 nu .. 20 + 2 nu
+    benv.ints("step")[0] = 500
+    benv.step(a)
+    U2 = lambda i: benv.L.lib.odko_rng_uniform(int(k[0]), int(k[1]), 2, i)
+    cr = np.array(benv.cfg["cmd_range"][:14]).reshape(7, 2)
+    want = np.zeros(7) if U2(20 + 2 * nu) < 0.1 else np.array([cr[j, 0] + U2(13 + 2 * nu + j) * (cr[j, 1] - cr[j, 0]) for j in range(7)])
+    np.testing.assert_allclose(benv["command"][:7], want, rtol=1e-6, atol=1e-9)
