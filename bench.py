@@ -161,21 +161,70 @@ def cpu_baseline(task: str, target_seconds: float = 12.0):
                       f"{os.cpu_count()} logical CPUs visible), same random-action protocol.  MuJoCo-C: {why}"}
 
 
-def _spawn_ranks(args, argv) -> int:
-    """Plain `python bench.py --gpus N` (no launcher around it): start the N ranks as a CHILD `torch.distributed.run` -- never an
-    exec, and before this process has imported torch or touched the GPU -- with the same arguments; the children inherit stdout,
-    so rank 0's JSON line is this command's output, and their exit code is this command's."""
-    import socket
+IPC_VAR = "HSA_ENABLE_IPC_MODE_LEGACY"
+# The pool's host driver only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL / device-memory sharing across processes fails with
+# `hipIpcGetMemHandle: invalid argument` (the environment's own note; the variable is exported on the boxes).  bench.py therefore sets 0 where the
+# variable is absent -- and, because no multi-GPU box has ever run this file, never lets that guess decide a run: a launch whose ranks die before a
+# result line exists is started ONCE more with the variable flipped (fresh child processes, never a re-exec), and the line says which setting worked.
+RCCL_FAILURE_MARKS = ("NCCL", "RCCL", "nccl", "rccl", "hipIpc", "ProcessGroupNCCL", "DistBackendError", "unhandled system error", "invalid argument")
+
+
+def ipc_flipped(env: dict) -> dict:
+    """a copy of `env` with the IPC mode the other way round ("0" <-> "1"; absent counts as the runtime's default, legacy = "1")"""
+    e = dict(env)
+    e[IPC_VAR] = "1" if e.get(IPC_VAR, "1") == "0" else "0"
+    return e
+
+
+def looks_like_rccl_failure(text: str) -> bool:
+    return any(m in (text or "") for m in RCCL_FAILURE_MARKS)
+
+
+def _relay(cmd, env, runner=None):
+    """runs one launch of the ranks, relays their stdout line by line; returns (exit code, saw a result line, stderr tail)"""
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if runner is not None:          # (tests: a stand-in for the child launch)
+        return runner(cmd, env)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    import threading
+    err_lines = []
+    t = threading.Thread(target=lambda: [(err_lines.append(l), sys.stderr.write(l)) for l in p.stderr], daemon=True)
+    t.start()
+    saw = False
+    for line in p.stdout:
+        saw = saw or line.startswith("{")
+        sys.stdout.write(line); sys.stdout.flush()
+    rc = p.wait()
+    t.join(timeout=5)
+    return rc, saw, "".join(err_lines[-200:])
+
+
+def _spawn_ranks(args, argv, runner=None) -> int:
+    """Plain `python bench.py --gpus N` (no launcher around it): start the N ranks as a CHILD `torch.distributed.run` -- never an
+    exec, and before this process has imported torch or touched the GPU -- with the same arguments; rank 0's JSON line is relayed as
+    this command's output, the children's exit code is this command's.  A launch that dies WITHOUT a result line on what looks like an
+    RCCL / IPC failure is started once more with HSA_ENABLE_IPC_MODE_LEGACY flipped (ODK_BENCH_IPC_RETRIED=1 tells the ranks to say so
+    in the line)."""
+    import socket
+
+    def launch(env):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+        return _relay(cmd, env, runner)
+
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // args.gpus)))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
-    return subprocess.call(cmd, env=env)
+    env.setdefault(IPC_VAR, "0")
+    rc, saw, err = launch(env)
+    if rc != 0 and not saw and looks_like_rccl_failure(err):
+        env2 = ipc_flipped(env)
+        env2["ODK_BENCH_IPC_RETRIED"] = "1"
+        sys.stderr.write(f"bench.py: the ranks died before a result line on an RCCL / IPC failure with {IPC_VAR}={env[IPC_VAR]}; one more launch with {IPC_VAR}={env2[IPC_VAR]}\n")
+        rc, saw, err = launch(env2)
+    return rc
 
 
 def _init_dist(args):
@@ -193,16 +242,78 @@ def _init_dist(args):
     local_rank = int(os.environ.get("ODK_BENCH_DEVICE", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path exists for the env engine)")
-    if backend == "nccl" and world > 1 and torch.cuda.device_count() < world:
+    if backend == "nccl" and world > 1 and torch.cuda.device_count() < world and os.environ.get("ODK_BENCH_ALLOW_SHARED_DEVICE") != "1":
         raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} HIP devices are visible (RCCL wants one rank per device)")
     torch.cuda.set_device(local_rank)
+    DIST_INFO.update(backend=None, ipc_mode_legacy=os.environ.get(IPC_VAR), ipc_retried=os.environ.get("ODK_BENCH_IPC_RETRIED") == "1")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        DIST_INFO["device"] = torch.cuda.get_device_name(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)                                                            # the first collective builds the communicator
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"first all-reduce returned {probe.item()} on {world} ranks")
+                DIST_INFO["backend"] = "nccl"
+            except Exception as e:      # noqa: BLE001 -- whatever RCCL raises here, the message is what the operator needs
+                DIST_INFO["rccl_error"] = rccl_diagnostics(e, rank, local_rank)
+                sys.stderr.write(DIST_INFO["rccl_error"] + "\n")
+                if args.mode == "ppo":      # the gradient all-reduce IS the workload: no fallback
+                    raise SystemExit(DIST_INFO["rccl_error"])
+                # The headline shards independent envs: its only collectives are the barrier and the max-over-ranks of the elapsed time.  Those go
+                # over gloo when RCCL cannot be brought up, and the line says so.
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:      # noqa: BLE001
+                    pass
+                # (a store of its own: independent of the launcher's agent store and of whatever the failed attempt left in it)
+                store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ.get("MASTER_PORT", "29500")) + 57, world, is_master=(rank == 0))
+                dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
+                DIST_INFO["backend"] = "gloo (control plane only: RCCL did not come up)"
         else:
             dist.init_process_group(backend)
+            DIST_INFO["backend"] = backend
     return rank, world, local_rank, torch.device("cuda", local_rank)
+
+
+DIST_INFO = {}
+
+
+def rccl_diagnostics(exc, rank: int, local_rank: int) -> str:
+    """what an operator needs when RCCL does not come up: the error, this rank's device, the library version, the IPC setting"""
+    import torch
+    try:
+        name = torch.cuda.get_device_name(local_rank)
+    except Exception:      # noqa: BLE001
+        name = "?"
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:      # noqa: BLE001
+        ver = "?"
+    return (f"bench.py rank {rank} (device {local_rank}: {name}; RCCL {ver}; {IPC_VAR}={os.environ.get(IPC_VAR)}; NCCL_DEBUG={os.environ.get('NCCL_DEBUG')}): "
+            f"RCCL init / first collective failed: {type(exc).__name__}: {exc}")
+
+
+def reduce_max_scalar(x: float, dev) -> float:
+    """max over the ranks of a host scalar, on whatever backend the group runs (RCCL wants device tensors, gloo host tensors)"""
+    import torch
+    import torch.distributed as dist
+    on_dev = str(DIST_INFO.get("backend", "")).startswith("nccl")
+    t = torch.tensor([x], device=dev if on_dev else "cpu", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def agree_any(flag: bool, dev) -> bool:
+    """true on every rank as soon as one rank says so (the ranks take the same exit path / retry decision)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(flag)
+    return reduce_max_scalar(1.0 if flag else 0.0, dev) > 0.5
 
 
 def _envs_per_rank(args, world: int) -> int:
@@ -322,7 +433,7 @@ def _split_learner_ms(net, opt, data, cfg, gen, steps: int):
     return res
 
 
-def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "weak", force_split: bool = False):
+def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "weak", force_split: bool = False, allreduce_form: str = "auto", probe: bool = False):
     """K full PPO training steps after W warm-up ones on this rank's `envs` envs (BASELINE configs 3 / 4 on 1 GPU, 5 on N: envs
     sharded, flat gradient all-reduced over RCCL in each of the 128 minibatch steps).  Returns the result line on rank 0."""
     import numpy as np
@@ -356,12 +467,24 @@ def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "
         if rec: rec[1].record()
         net.norm_obs.update(data["obs"], grp); net.norm_priv.update(data["priv"], grp)
         if learner is None:
-            learner = T.make_learner(net, data, cfg, world, grp)
+            kw = {} if (allreduce_form == "auto" or world == 1) else dict(capture_allreduce=(allreduce_form == "captured"))
+            learner = T.make_learner(net, data, cfg, world, grp, **kw)
         T.sgd_epoch(net, opt, data, cfg, gen, world, grp, learner=learner, meter=T.LossMeter())
         if rec: rec[2].record()
         return data
 
     _clock_ramp(dev)
+    if probe:      # two training steps in the requested form, then the replicas' parameters bit for bit (raises on a mismatch)
+        for _ in range(2):
+            training_step()
+        barrier()
+        if world > 1:
+            T.assert_replicas_identical(net, grp)
+        form = "captured" if (learner is not None and getattr(learner, "capture_allreduce", False)) else "split"
+        if learner is not None:
+            learner.close()
+        env.close() if hasattr(env, "close") else None
+        return {"probe": "ok", "allreduce_form": form, "n_gpus": world} if rank == 0 else None
     for _ in range(max(warmup, 1)):      # (the first step builds the learner and captures its graphs: never timed)
         training_step()
     barrier()
@@ -415,6 +538,7 @@ def ppo_leg(ctx, task: str, envs: int, steps: int, warmup: int, scaling: str = "
                        "rollout_ms_per_training_step": round(rollout_ms, 3), "learner_ms_per_training_step": round(learner_ms, 3),
                        "allreduce_ms_per_training_step_isolated": None if allreduce_ms is None else round(allreduce_ms, 3),
                        "learner_path": "fused whole-network kernels" if (learner is not None and getattr(learner, "fused", None) is not None) else "library GEMMs / autograd",
+                       "allreduce_form": None if world == 1 else ("captured" if (learner is not None and getattr(learner, "capture_allreduce", False)) else "split"),
                        "reward_per_step_last_rollout": round(float(data["reward"].mean()), 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
                          "traffic": cnt.get("hbm_bytes_per_sgd_step"), "counter_source": csrc,
@@ -482,9 +606,7 @@ def physics_leg(ctx, args, envs: int):
         el = time.perf_counter() - t0
         k += args.steps
         if world > 1:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            el = reduce_max_scalar(el, dev)
         times.append(el)
     elapsed = sum(times) / len(times)
     kernel_ms, launches = batch.timing(False)
@@ -529,42 +651,96 @@ def physics_leg(ctx, args, envs: int):
     }
 
 
-def _secondary_child(ctx, task: str, envs_arg: int, scaling: str, steps: int, timeout: float, leg_index: int):
+def _secondary_child(ctx, task: str, envs_arg: int, scaling: str, steps: int, timeout: float, leg_index: int, extra_argv=(), env_over=None, tag="leg"):
     """One full-PPO leg in a FRESH CHILD PROCESS per rank (`bench.py --mode ppo ...`, started with subprocess -- never an exec -- after
     this process has measured the headline): a hard fault in a leg (a GPU memory fault aborting the HSA runtime, a SIGSEGV in the
     library, a stuck collective) ends the child, not the process that holds the headline.  Under N > 1 ranks every rank starts its
     own child with the launcher's RANK / LOCAL_RANK / WORLD_SIZE and a rendezvous port of its own.  Returns (result line or None,
-    error text or None); a child past `timeout` is killed by its exact PID."""
+    error text or None, path of the child's full stderr); a child past `timeout` is killed by its exact PID."""
     import subprocess
+    import tempfile
     rank, world = ctx[0], ctx[1]
     env = dict(os.environ)
+    env.update(env_over or {})
     if world > 1:
         env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 101 + leg_index)
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the child ranks rendezvous among themselves: rank 0's child hosts the store on the new port
+        env.setdefault("NCCL_DEBUG", "WARN")               # RCCL's own words on a failure end up in the stderr file
     cmd = [sys.executable, os.path.abspath(__file__), "--mode", "ppo", "--task", task, "--gpus", str(world), "--envs", str(envs_arg), "--scaling", scaling,
-           "--steps", str(steps), "--warmup", "4"]
+           "--steps", str(steps), "--warmup", "4"] + list(extra_argv)
+    log_dir = os.environ.get("ODK_BENCH_LOG_DIR") or os.path.join(tempfile.gettempdir(), "odk_bench_logs")
+    os.makedirs(log_dir, exist_ok=True)
+    err_path = os.path.join(log_dir, f"secondary_{task}_{tag}_rank{rank}.stderr")
     try:
-        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        with open(err_path, "w") as ef:
+            p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=ef, text=True)
+            try:
+                so, _ = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                so, _ = p.communicate()
+                return None, f"leg still running after {timeout:.0f} s: killed (stderr: {err_path})", err_path
     except OSError as e:
-        return None, f"could not start the leg: {e}"
-    try:
-        so, se = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        p.kill()
-        so, se = p.communicate()
-        return None, f"leg still running after {timeout:.0f} s: killed"
+        return None, f"could not start the leg: {e}", err_path
     if p.returncode != 0:
-        tail = " | ".join([l for l in se.strip().splitlines() if l.strip()][-3:])
-        return None, f"leg exited with code {p.returncode}: {tail[-400:]}"
+        se = open(err_path, errors="replace").read()
+        tail = " | ".join([l for l in se.strip().splitlines() if l.strip()][-6:])
+        return None, f"leg exited with code {p.returncode}: {tail[-1200:]} (full stderr: {err_path})", err_path
     if rank != 0:
-        return None, None
+        return None, None, err_path
     lines = [l for l in so.splitlines() if l.startswith("{")]
     if not lines:
-        return None, "leg printed no result line"
+        return None, f"leg printed no result line (stderr: {err_path})", err_path
     try:
-        return json.loads(lines[-1]), None
+        return json.loads(lines[-1]), None, err_path
     except ValueError as e:
-        return None, f"leg's result line does not parse: {e}"
+        return None, f"leg's result line does not parse: {e}", err_path
+
+
+def choose_allreduce_form(probe_ok_everywhere: bool) -> str:
+    """the data-parallel form of the timed PPO steps: the all-reduce captured inside the step graph (one replay per 32 steps: +1.3 % over a single
+    GPU's step on a one-rank group) when a probe on the real ranks kept the replicas bit-identical, else graph A -> host-issued all-reduce -> graph B
+    (+8.6 %)"""
+    return "captured" if probe_ok_everywhere else "split"
+
+
+def run_secondary_leg(ctx, dev, task, envs_arg, scaling, steps, budget, leg_index, child=None):
+    """One `secondary` entry under N >= 1 ranks.  N > 1: (1) a PROBE child per rank -- two training steps with the all-reduce captured, replicas
+    compared bit for bit; the ranks agree on its outcome; (2) the timed leg in the form `choose_allreduce_form` names; (3) if a child died on what looks
+    like an RCCL / IPC failure, ONE more attempt with HSA_ENABLE_IPC_MODE_LEGACY flipped (all ranks take that decision together).  Returns (entry for
+    `secondary` on rank 0 -- or None on the other ranks --, failed flag agreed by all ranks)."""
+    child = child or _secondary_child
+    rank, world = ctx[0], ctx[1]
+    notes = {}
+    env_over = {}
+    form_argv = []
+    t_probe = min(120.0, budget * 0.3)
+    if world > 1:
+        for attempt in range(2):
+            _, perr, ppath = child(ctx, task, envs_arg, scaling, 2, t_probe, 20 + leg_index + 40 * attempt, extra_argv=["--allreduce-form", "captured", "--probe"],
+                                   env_over=env_over, tag=f"probe{attempt}")
+            bad = agree_any(perr is not None, dev)
+            text = (perr or "") + (open(ppath, errors="replace").read()[-4000:] if (perr is not None and os.path.exists(ppath)) else "")
+            rccl = agree_any(perr is not None and looks_like_rccl_failure(text), dev)
+            notes[f"allreduce_probe{'_retry' if attempt else ''}"] = "ok" if not bad else (perr or "failed on another rank")
+            if not bad or not rccl or attempt == 1:
+                break
+            env_over = {IPC_VAR: ipc_flipped(dict(os.environ, **env_over))[IPC_VAR]}      # every rank flips together
+            notes["ipc_mode_legacy_flipped_to"] = env_over[IPC_VAR]
+        if bad and env_over:      # the flipped setting did not help either: the timed leg runs with the environment as it was given
+            env_over = {}
+        form = choose_allreduce_form(not bad)
+        form_argv = ["--allreduce-form", form]
+        notes["allreduce_form"] = form
+    leg, err, path = child(ctx, task, envs_arg, scaling, steps, budget - (t_probe if world > 1 else 0.0), leg_index, extra_argv=form_argv, env_over=env_over, tag="timed")
+    failed = agree_any(err is not None, dev)
+    if world > 1:
+        notes["ipc_mode_legacy"] = dict(os.environ, **env_over).get(IPC_VAR)
+    if rank != 0:
+        return None, failed
+    if err is not None or leg is None:
+        return dict({"task": task, "mode": "ppo", "error": err or "a peer rank's leg failed", "stderr_file": path}, **notes), failed
+    return dict(_brief(leg), **notes), failed
 
 
 def _brief(leg: dict) -> dict:
@@ -592,6 +768,11 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="physics mode: skip the short full-PPO legs attached as `secondary`")
     ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--secondary-timeout", type=float, default=300.0, help="seconds for ALL secondary legs together (each child gets an equal share)")
+    ap.add_argument("--allreduce-form", default="auto", choices=["auto", "split", "captured"],
+                    help="ppo mode, N > 1 ranks: the gradient all-reduce between graph A and graph B issued from the host (split), or captured inside the step graph "
+                         "(captured: one replay per 32 minibatch steps); auto = $ODK_LEARNER_CAPTURE_ALLREDUCE, else split.  The headline's secondary leg probes "
+                         "`captured` in a child first and falls back to `split`")
+    ap.add_argument("--probe", action="store_true", help="ppo mode: two training steps, replicas compared bit for bit, one line {\"probe\": \"ok\"}; no timing")
     ap.add_argument("--force-split", action="store_true", help="ppo mode, 1 GPU: also time the data-parallel form of the minibatch step on a one-rank RCCL group "
                     "(graph A -> all-reduce -> graph B, and the all-reduce captured in one graph)")
     args = ap.parse_args()
@@ -607,7 +788,7 @@ def main():
 
     if args.mode == "ppo":
         out = ppo_leg(ctx, args.task or "flat_terrain_backlash", envs, args.steps if args.steps is not None else 10,
-                      args.warmup if args.warmup is not None else 3, args.scaling, args.force_split)
+                      args.warmup if args.warmup is not None else 3, args.scaling, args.force_split, allreduce_form=args.allreduce_form, probe=args.probe)
         if rank == 0:
             print(json.dumps(out), flush=True)
     else:
@@ -631,18 +812,19 @@ def main():
                 dist.barrier()          # every rank has finished the headline before any rank's child claims its GPU
             sec = []
             for k, task in enumerate(tasks):
-                leg, err = _secondary_child(ctx, task, args.envs, args.scaling, args.secondary_steps, args.secondary_timeout / len(tasks), k)
-                if err is not None:
-                    failed += 1
-                    sec.append({"task": task, "mode": "ppo", "error": err})
-                elif leg is not None:
-                    sec.append(_brief(leg))
+                entry, bad = run_secondary_leg(ctx, ctx[3], task, args.envs, args.scaling, args.secondary_steps, args.secondary_timeout / len(tasks), k)
+                failed += int(bad)          # (agreed across the ranks: every rank takes the same exit path below)
+                if entry is not None:
+                    sec.append(entry)
             if rank == 0:
                 out["secondary"] = sec
+        if rank == 0 and world > 1:
+            out["config"]["launch"] = {k: v for k, v in DIST_INFO.items() if v is not None}
         if rank == 0:
             print(json.dumps(out), flush=True)
         if failed:
-            # the headline went out; a failed / abandoned leg still shows in the exit code (and in `secondary`)
+            # the headline went out; a failed / abandoned leg still shows in the exit code (and in `secondary`).  `failed` is the same on every
+            # rank (run_secondary_leg agrees on it over the live group), so every rank leaves this way together.
             sys.stdout.flush()
             os._exit(3)        # (a rank whose peers' children are stuck cannot join them through destroy_process_group)
     if world > 1:

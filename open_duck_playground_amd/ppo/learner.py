@@ -458,6 +458,17 @@ class FlatLearner:
         self.cursor.zero_()
         self._host_cursor, self._host_steps = 0, steps
         self._pool[:steps].normal_()
+        if self.capture_allreduce and self.world > 1:
+            # With the all-reduce captured inside the step graphs, `run()`'s choice between the K-step graph and single steps decides how many
+            # collectives a replay issues: every rank must make the same choice, i.e. hold the same (K, schedule length).  One tiny all-reduce per
+            # schedule (one per training step) -- a mismatch would otherwise show up as a hang inside a captured collective.
+            import torch.distributed as dist
+            mine = torch.tensor([float(getattr(self, "K", 0)), float(steps)], device=self.sched.device)
+            lo, hi = mine.clone(), mine.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group); dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if not (torch.equal(lo, mine) and torch.equal(hi, mine)):
+                raise engine.OdkError(f"FlatLearner (captured all-reduce): ranks disagree on (steps per graph, schedule length): mine {mine.tolist()}, "
+                                      f"min {lo.tolist()}, max {hi.tolist()}")
 
     NOISE_POOL = 128   # minibatch steps per refill (= steps per training step in the reference configuration)
 
