@@ -522,7 +522,7 @@ static void make_frame(real* frame, const real* n) {
  * arithmetic and jp.argmax takes the first index; in floating point the zeros come out as +-1e-10 residues and the pick -- and
  * with it how many of the four slots repeat which point, i.e. the weight of each contact -- would be rounding noise, different
  * in float32 and float64.  With the threshold both resolve the tie like exact arithmetic does. */
-#define AREA0(v) ((v) < 1e-7 ? 0.0 : (v))
+#define AREA0(v) area0(v)
 #define AREA_TIE 1e-7
 /* ---- decision margins (test infrastructure of the test infrastructure).  The collision routines take discrete decisions -- which
  * axis separates best, face or edge contact, which face is incident, which side of a clipping plane, which candidates span the
@@ -539,7 +539,7 @@ static __thread real g_margin[4] = {1e30, 1e30, 1e30, 1e30};
  * is the reference, 4 edge contact or face contact (the EDGE_TOL threshold), 8 which face is incident, 16 side of a clipping
  * plane, 32 the manifold's arg-max steps (band in relative units: eps_rel), 64 the cut behind the fourth-deepest height-field
  * contact, 128 (the one solver decision) the Newton solver's starting point, warm start or unconstrained acceleration, when their
- * costs are within eps_rel of each other; 256 / 512: the line search (see ls_search).  This is how the parity tests ask "does the kernel's answer follow from the oracle's own algorithm when THIS class
+ * costs are within eps_rel of each other; 256 / 512: the line search (see ls_search); 1024: the AREA0 cut of the manifold's area measures (area0).  This is how the parity tests ask "does the kernel's answer follow from the oracle's own algorithm when THIS class
  * of near-ties falls the other way": an implementation that carries its constants in another precision resolves a tie between
  * two hull features the same way substep after substep, which neither a single flip nor noise on the state reproduces. */
 static __thread int g_bias_mask = 0, g_bias_request = 0, g_bias_first = 0, g_bias_last = 1 << 30, g_bias_pass = 0;
@@ -551,6 +551,15 @@ void odko_set_tie_bias_window(int mask, real eps, real eps_rel, int first, int l
 }
 void odko_set_tie_bias(int mask, real eps, real eps_rel) { odko_set_tie_bias_window(mask, eps, eps_rel, 0, 1 << 30); }
 #define BIAS(bit, gap) ((g_bias_mask & (bit)) && fabs(gap) < g_bias_eps)
+/* the AREA0 cut itself is a decision: an area measure within rounding of the 1e-7 m^2 threshold counts as zero in one precision and as itself in the
+ * other.  Tie class 1024: inside a band of eps x 1 cm around the threshold (a length error of eps on a lever of a centimetre) the cut falls the other
+ * way.  (Found by the rollout-state test of round 6: a fallen robot's foot lying on its side in the terrain, a sliver manifold whose area measure
+ * sat at 1.0e-7.) */
+static real area0(real v) {
+  int small = v < 1e-7;
+  if ((g_bias_mask & 1024) && fabs(v - 1e-7) < g_bias_eps * 1e-2) small = !small;
+  return small ? 0.0 : v;
+}
 static void margin_reset(void) { for (int k = 0; k < 4; k++) g_margin[k] = 1e30; }
 static void margin_note(int k, real gap) { gap = fabs(gap); if (gap < g_margin[k]) g_margin[k] = gap; }
 /* gap between the largest and the runner-up of v[0..n) among entries whose POINT differs from the winner's */

@@ -122,7 +122,7 @@ _ENV_FIELDS = ("command", "last_act", "last_last_act", "last_last_last_act", "mo
 # decision classes of the oracle's collision routines that the referee may bias (oracle/odk_oracle.c "Tie bias")
 TIE_CLASSES = ((4, "edge_or_face_contact"), (8, "incident_face"), (1, "separating_face"), (2, "reference_polytope"), (16, "clipping_plane_side"),
                (32, "manifold_argmax"), (64, "fourth_deepest_cut"), (128, "warm_start_pick"), (256, "line_search_bracket_end"),
-               (512, "line_search_comparison"))
+               (512, "line_search_comparison"), (1024, "area_zero_cut"))
 _ENV_INTS = ("last_contact", "key", "step", "push_step", "push_interval_steps", "imitation_i", "rng_ctr")
 
 
