@@ -540,7 +540,7 @@ def test_env_step_ten_substeps_on_rollout_states(torch_cuda, oracle_mod, parity_
     float32-scale discontinuity of the map (`_conditioning`) are set aside: at most 10 %; the others are judged at the north-star bound, floored
     and norm-wise.  A judged state beyond the bound goes to the referee of the env tests' kind: the float64 oracle re-run with ONE class of its
     discrete decisions biased to the runner-up inside a 2e-6 band (whole step, then single substeps), then the oracle's float32 build -- a run that
-    lands on the kernel's state explains it causally; explained states are bounded at 2 % (measured: 0 / 0 / 1.6 %), unexplained ones at 0."""
+    lands on the kernel's state explains it causally; explained states are bounded at 1 % (3 % on the height field; measured 0.2 / 0 / 1.6 %), unexplained ones at 0."""
     from open_duck_playground_amd import engine
     from open_duck_playground_amd.model import load_task_model
     torch = torch_cuda
@@ -661,7 +661,7 @@ def test_env_step_ten_substeps_on_rollout_states(torch_cuda, oracle_mod, parity_
     parity_log.rec(f"ten_substeps_rollout_states/{task}", None, states=n, judged=judged, **{"n_" + k: v for k, v in kinds.items()}, **{"ill_" + k: v for k, v in ill_by_kind.items()},
                    **{"explained_by_" + k: v for k, v in why.items()})
     assert kinds.get("post_reset", 0) >= 32 and kinds.get("rollout", 0) >= 200
-    parity_log.check(f"ten_substeps_rollout_states/{task}", dict(TEN_BOUNDS, ill_fraction=0.10, explained_fraction=0.02, unexplained=0), qpos=wq, qvel=wv, qpos_normwise=wqn,
+    parity_log.check(f"ten_substeps_rollout_states/{task}", dict(TEN_BOUNDS, ill_fraction=0.10, explained_fraction=0.03 if "rough" in task else 0.01, unexplained=0), qpos=wq, qvel=wv, qpos_normwise=wqn,
                      qvel_normwise=wvn, ill_fraction=n_ill / n, explained_fraction=n_explained / max(judged, 1), unexplained=n_unexplained)
 
 
