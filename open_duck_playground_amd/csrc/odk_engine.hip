@@ -1170,14 +1170,15 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
   B.I("nbody", one, 1); m.nb = one[0]; B.I("njnt", one, 1); m.nj = one[0]; B.I("nsite", one, 1); m.nsite = one[0];
   if (!B.ok) { delete mo; return fail(ODK_ERR_INVALID, "odk_model_load: missing %s", B.missing.c_str()); }
   if (m.nq > MAXQ || m.nv > MAXV || m.nu > MAXU || m.nb > MAXB || m.nj > MAXJ || m.nsite > MAXSITE) { delete mo; return fail(ODK_ERR_UNSUPPORTED, "model too large"); }
-  {   // <option cone="elliptic">: zones, cone Hessian and exact line search are compiled into the third shape's kernels (odk_kernels.h "elliptic
-      // cones"); the duck's shapes keep their pyramidal rows and refuse the option by name
+  {   // <option cone="elliptic">: zones, cone Hessian and exact line search (odk_kernels.h "elliptic cones") are accepted for EVERY compiled shape
+      // with hull feet, at 32 lanes per env: the third and fourth shapes carry the code as a runtime switch (Shape::ELL), the duck's two shapes have
+      // instantiations of their own with it (ShapeAE / ShapeBE; launch()).  The only refusal is sphere / capsule feet (below, by name).
     RecHdr ch;
     if (find_rec((const unsigned char*)blob, len, "opt_cone", &ch)) {
       int cone[1] = {0};
       Blob Cn{(const unsigned char*)blob, len};
       Cn.I("opt_cone", cone, 1);
-      m.cone = cone[0] != 0;      // accepted for the third shape only (checked below, once the shape is known)
+      m.cone = cone[0] != 0;
     }
   }
   // <equality> (mjcf.py compiles joint / connect / weld; the float64 oracle builds all their rows).  The kernels model <equality><joint>

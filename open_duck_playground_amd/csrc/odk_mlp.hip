@@ -118,13 +118,18 @@ __device__ __forceinline__ void map_block(const Args& a, int b, int& net, int& t
 #ifndef ODK_MLP_SETPRIO
 #define ODK_MLP_SETPRIO 0         // raise the wave's priority inside the MFMA loops
 #endif
-template <int NBLK, int U>
+template <int NBLK, int U, bool RING = false>      // RING: the diagnostic build's forward kernel (weights from LDS: diag bits 5 / 6)
 struct Phase {
   f32x4 fb[U][NBLK];
   const f32x4* B; unsigned lane_off, blk_off; int N4, ng;
 #ifdef ODK_MLP_DIAG    // diagnostic build (make libodk_mlpdiag.so; tools/gpu_mlp_wg_profile.py): bit 0 = every group re-reads group 0 (L1 hits), bit 1 = no MFMAs,
-                       // bit 2 = no operand loads inside the loops, bit 3 = no activation stores, bit 4 = half of the weight loads
+                       // bit 2 = no operand loads inside the loops, bit 3 = no activation stores, bit 4 = half of the weight loads,
+                       // bit 5 (round 6: what would a SHARED WEIGHT RING IN LDS buy at best?) = the weights come from LDS instead of global memory -- every B piece
+                       // is one ds_read_b128 from an 8 KB region behind the workgroup's image, with the real layout's bank pattern, no fill and no synchronisation --,
+                       // bit 6 = with bit 5, every third k-group is ALSO fetched from global memory and written to that region (a ring filled once per CU by the
+                       // three tile groups it serves: each group's share of the fill traffic)
   int diag = 0;
+  float* ring = nullptr;
 #else
   static constexpr int diag = 0;
 #endif
@@ -136,6 +141,14 @@ struct Phase {
 #pragma unroll
       for (int k = 0; k < NBLK; k++) {
         if ((diag & 16) && (k & 1)) xb[u][k] = xb[u][k - 1];       // (diag 16, tools: half of the weight loads: what the launch would cost with twice the reuse per piece)
+#ifdef ODK_MLP_DIAG
+        else if (RING && (diag & 32)) {
+          f32x4* slot = reinterpret_cast<f32x4*>(ring) + ((G & 1) << 8);
+          const unsigned pi = (lane_off + blk_off * k) & 255u;
+          if ((diag & 64) && G % 3 == 0) slot[pi] = bp[lane_off + blk_off * k];
+          xb[u][k] = slot[pi];
+        }
+#endif
         else xb[u][k] = bp[lane_off + blk_off * k];
       }
     }
@@ -235,10 +248,16 @@ __global__ void __launch_bounds__(256, ODK_MLP_WG_PER_CU) mlp_fwd_kernel(Args a)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = lane >> 4, c = lane & 15;
   const int kin = N.n_in, k16 = pad16(kin), PX = k16 + 4;
   float* X = lds + F_X; float* C1 = lds + F_C; float* H2s = lds + F_H2; float* H3s = lds + F_X;
+#ifdef ODK_MLP_DIAG
+  Phase<2, 2, true> p1; Phase<4, 1, true> p2;
+#else
   Phase<2, 2> p1;     // layer 1 (32 columns of the current chunk), layer 3, output layer
   Phase<4, 1> p2;     // layer 2, K-slice = the chunk, 64 columns
+#endif
 #ifdef ODK_MLP_DIAG
   p1.diag = p2.diag = a.diag;
+  p1.ring = p2.ring = lds + ((F_TOTAL + 3) & ~3);
+  if (a.diag & 32) { for (int i = threadIdx.x; i < 2048; i += 256) p1.ring[i] = 0.01f; __syncthreads(); }
 #endif
   ODK_WG_BEGIN();
   ODK_STAMP(0);
@@ -802,8 +821,13 @@ extern "C" int odk_mlp_forward(const odk_mlp_desc* nets, int count, void* stream
   if (!nets || count < 1 || count > 2) return odk_fail_(ODK_ERR_INVALID, "odk_mlp_forward: 1 or 2 networks");
   Args a; int tiles; const char* err = nullptr;
   if (fill_args(a, nets, count, false, tiles, err)) return odk_fail_(ODK_ERR_INVALID, err);
-  if (odk_func_lds_attr_((const void*)mlp_fwd_kernel, 1, F_TOTAL * 4)) return odk_fail_(ODK_ERR_HIP, "odk_mlp_forward: the device refuses the kernel's dynamic LDS size");
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(tiles), dim3(256), F_TOTAL * 4, (hipStream_t)stream, a);
+#ifdef ODK_MLP_DIAG
+  const int fwd_lds = ((F_TOTAL + 3) & ~3) * 4 + 8192;      // (+ the stand-in for a weight ring: diag bits 5 / 6)
+#else
+  const int fwd_lds = F_TOTAL * 4;
+#endif
+  if (odk_func_lds_attr_((const void*)mlp_fwd_kernel, 1, fwd_lds)) return odk_fail_(ODK_ERR_HIP, "odk_mlp_forward: the device refuses the kernel's dynamic LDS size");
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(tiles), dim3(256), fwd_lds, (hipStream_t)stream, a);
   return check_launch("odk_mlp_forward: launch failed");
 }
 

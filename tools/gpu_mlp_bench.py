@@ -39,6 +39,13 @@ ws = torch.empty(KS * engine.DwGemm.workspace_stride(tot), device="cuda")
 dw = engine.DwGemm(dw_layers, flat_g, ws, KS)
 
 
+if os.environ.get("ODK_MLP_DIAG"):      # diagnostic variants of the network launches (ODK_LIB=.../libodk_mlpdiag.so; results are WRONG): csrc/odk_mlp.hip
+    import ctypes
+    L = engine.load_library()
+    L.odk_mlp_set_diag.argtypes = [ctypes.c_int]
+    L.odk_mlp_set_diag(int(os.environ["ODK_MLP_DIAG"]))
+
+
 def timeit(fn, reps=200):
     for _ in range(10): fn()
     torch.cuda.synchronize()
