@@ -1023,7 +1023,13 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   long long _hp = clock64();
 #define HF_PROF(i) do { if (lane == 0) { const long long _t = clock64(); L[S::O_SCR + S::S_PROF2 + (i)] += (float)(_t - _hp); _hp = _t; } } while (0)
 #define HF_COUNT(i, v) do { if (lane == 0) L[S::O_SCR + S::S_PROF2 + (i)] += (float)(v); } while (0)
+#ifdef ODK_PROF_CULL      // (investigation build: the cull pass's own sub-phases in slots 8 .. 13, separate clock; the pair loop's sub-timers then mean nothing)
+#define HF_CULL(i) do { if (lane == 0) { const long long _t = clock64(); L[S::O_SCR + S::S_PROF2 + 8 + (i)] += (float)(_t - _hc); _hc = _t; } } while (0)
 #else
+#define HF_CULL(i) do { } while (0)
+#endif
+#else
+#define HF_CULL(i) do { } while (0)
 #define HF_PROF(i) do { } while (0)
 #define HF_COUNT(i, v) do { } while (0)
 #endif
@@ -1145,10 +1151,15 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     const int p = 16 * pass + j;
     const bool valid = p < nprism;
     if (__builtin_amdgcn_ballot_w64(valid) == 0 || (pass == 1 && HF_KNOCK(0))) break;
+#if defined(ODK_PROFILE) && defined(ODK_PROF_CULL)
+    long long _hc = clock64();
+#endif
     float z[3] = {0.0f, 0.0f, 0.0f};
     if (valid) { int cc[3], rr[3]; corners(p, ncw, cc, rr); for (int k = 0; k < 3; k++) z[k] = hf[(rmin + rr[k]) * nc + cmin + cc[k]] * sz; }
+    HF_CULL(0);      // heights
     Prism P;
     prism(valid ? p : 0, ncw, z, P);
+    HF_CULL(1);      // prism
     // plane offsets n . v0 of the five faces (v0: vertex 0 / 3 / 0 / 1 / 2), then min over the hull's vertices of n . v - offset: the top face
     // in a loop over the vertices (batches of six: the LDS reads of a batch are in flight together), the other four from the hull's extents
     float d5[5], s5[5];
@@ -1175,6 +1186,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     }
     s5[0] = stop;
     }
+    HF_CULL(2);      // vertex loop
     float sep = -3.0e38f; int face = 0;
 #pragma unroll
     for (int fa = 0; fa < 5; fa++) { const float sv = s5[fa] - d5[fa]; if (sv > sep) { sep = sv; face = fa; } }
@@ -1205,12 +1217,14 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
       }
       }
     }
+    HF_CULL(3);      // face loop
     const float bound = fmaxf(sep, sep_b);
     const bool keep = valid && !(bound > 0.0f);
     const unsigned rowmask = (unsigned)((__builtin_amdgcn_ballot_w64(keep) >> (threadIdx.x & 48u)) & 0xFFFFull);
     const int pos = cnt + __popc(rowmask & ((1u << j) - 1u));
     if (keep) { float* o = LIST + 6 * pos; o[0] = __int_as_float(p | (face << 8)); o[1] = z[0]; o[2] = z[1]; o[3] = z[2]; o[4] = sep; o[5] = bound; }
     cnt += __popc(rowmask);
+    HF_CULL(4);      // list write
   }
   ODK_SYNC();
   {   // the list in ascending (sep, prism) order: an entry's place is the number of entries before it
