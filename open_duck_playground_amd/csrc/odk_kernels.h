@@ -1036,8 +1036,11 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   float* FV = L + S::O_CFRC + f * 51; float* FN = L + S::O_CFRC + 102 + f * 90;
   float* RS = L + (f ? S::O_BUF6B : S::O_BUF6);
   float* PV = RS;                                                      // prism vertices [6][3]
-  float* FD = L + S::O_X + f * 30;                                      // [<= 30] plane offsets of the hull's faces (x | Ma | search | mv: dead until the solver)
-  static_assert(4 * S::NV >= 60, "hull face offsets");
+  // [<= 30][4] the hull's faces as (normal, plane offset) records for the cull pass's face loop: ONE 16-byte LDS read per face instead of four dwords
+  // (round 6).  Foot 0: the H / factor region (dead between the solve for qacc_smooth and the Hessian's entries), foot 1: x | Ma | search | mv (dead
+  // until the solver); both 16-byte aligned.
+  float* FN4 = L + (f ? S::O_X : ((S::O_HL + 3) & ~3));
+  static_assert(4 * S::NV >= 4 * HULL_MAXF && S::NHR >= 4 * HULL_MAXF + 3 && S::O_X % 4 == 0 && S::ENV_STRIDE % 4 == 0, "hull face records");
   float* META = RS + 106;                                              // for the other rows: ncw, hull centroid [3], mask of this foot's open list entries, the entry this ROW took last (foot << 8 | entry)
   static_assert(6 * S::NVR >= 111, "row scratch + window record");
   float* RL = L + S::O_D + f * 172;
@@ -1090,7 +1093,8 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
     float nw[3];
     for (int k = 0; k < 3; k++) { nw[k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2]; FN[3 * t + k] = nw[k]; }
-    FD[t] = m->foot_foff[f][t] + dot3(nw, Pw);   // the face's plane offset in the window frame: n . (P + R v) = n_b . v_b + n . P
+    // the face's plane offset in the window frame: n . (P + R v) = n_b . v_b + n . P
+    *reinterpret_cast<float4*>(FN4 + 4 * t) = make_float4(nw[0], nw[1], nw[2], m->foot_foff[f][t] + dot3(nw, Pw));
   }
   }
   float fc[3];
@@ -1203,12 +1207,12 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
       HF_TOUCH(z[0]);
 #pragma unroll 1
       for (int t0 = 0; t0 < nfu; t0 += 5) {      // (batches of five faces: 20 LDS reads in flight together)
-        float fnv[5][4];
+        float4 fnv[5];
 #pragma unroll
-        for (int u = 0; u < 5; u++) { const int t = t0 + u < HULL_MAXF ? t0 + u : 0; fnv[u][0] = FN[3 * t]; fnv[u][1] = FN[3 * t + 1]; fnv[u][2] = FN[3 * t + 2]; fnv[u][3] = FD[t]; }
+        for (int u = 0; u < 5; u++) { const int t = t0 + u < HULL_MAXF ? t0 + u : 0; fnv[u] = *reinterpret_cast<const float4*>(FN4 + 4 * t); }
 #pragma unroll
         for (int u = 0; u < 5; u++) {
-          const float n0 = fnv[u][0], n1 = fnv[u][1], n2 = fnv[u][2], dd = fnv[u][3];
+          const float n0 = fnv[u].x, n1 = fnv[u].y, n2 = fnv[u].z, dd = fnv[u].w;
           const float h0 = n0 * P.x[0] + n1 * P.y[0], h1 = n0 * P.x[1] + n1 * P.y[1], h2 = n0 * P.x[2] + n1 * P.y[2];
           const float top = fminf(fminf(h0 + n2 * z[0], h1 + n2 * z[1]), h2 + n2 * z[2]), bot = fminf(fminf(h0, h1), h2) + n2 * zb;
           const float sv = fminf(top, bot) - dd;
