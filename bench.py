@@ -195,7 +195,7 @@ def _relay(cmd, env, runner=None):
         saw = saw or line.startswith("{")
         sys.stdout.write(line); sys.stdout.flush()
     rc = p.wait()
-    t.join(timeout=5)
+    t.join(timeout=60)      # (the pipe closes when the last rank exits: the relay ends by itself; the limit only guards against a stray grandchild)
     return rc, saw, "".join(err_lines[-200:])
 
 
