@@ -1,5 +1,5 @@
 """The resynchronised env-step comparison of tests/test_gpu_env.py::test_step_sequence_with_resync at a larger size (GPU box):
-    python tools/gpu_env_sweep.py [task = flat_terrain] [n_envs = 256] [steps = 30] [seed = 9] [cone = pyramidal | elliptic]
+    python tools/gpu_env_sweep.py [task = flat_terrain | a robot's XML under tests/assets/, e.g. biped12.xml] [n_envs = 256] [steps = 30] [seed = 9] [cone = pyramidal | elliptic]
 prints the judged worst errors, the fraction of env steps set aside by the oracle's own sensitivity and the outliers."""
 import os
 import sys
@@ -29,10 +29,11 @@ for i, e in enumerate(envs):
     e.reset(seed, i)
 rng = np.random.default_rng(seed + 100)
 W = T._new_W()
-W["reset_ill"] = T._ill_resets(envs, model, 101)
+nobs, npriv, nu = b.nobs, b.npriv, model.nu      # (the duck: 101 / 212 / 14)
+W["reset_ill"] = T._ill_resets(envs, model, nobs)
 for t in range(steps):
     T._resync(b, envs, model)
-    act = rng.uniform(-1, 1, (n, 14)).astype(np.float32)
-    T._step_and_compare(torch, b, envs, act, 101, 212, t, W)
+    act = rng.uniform(-1, 1, (n, nu)).astype(np.float32)
+    T._step_and_compare(torch, b, envs, act, nobs, npriv, t, W)
 print(task, cone, {k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in T._errs(W).items()}, "done", W["n_done"], "trunc", W["n_trunc"])
 b.close()
