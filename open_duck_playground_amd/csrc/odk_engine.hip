@@ -117,7 +117,15 @@ using ShapeD = Shape<19, 18, 16, 12, 13, 135, 171, 72, 12, 18, false, 6, true>; 
 // new robot is ONE `using` line above and ONE entry here (tools/new_shape.py <xml> prints both).  Entries 0 and 1 are the duck's two models
 // (their cone / height-field / 64-lane instantiations are chosen in launch()); entries from 2 on run reset / step / physics kernels at 32
 // lanes per env on a plane floor.
-#define ODK_SHAPES(X) X(0, ShapeA) X(1, ShapeB) X(2, ShapeC) X(3, ShapeD)
+// Robots added without editing this file: `python tools/new_shape.py robot.xml --add` writes csrc/odk_shapes_user.h -- one `using ShapeU<k> = Shape<...>;`
+// line per robot and `#define ODK_USER_SHAPES(X) X(4, ShapeU0) ...` -- and rebuilds the library.
+#if __has_include("odk_shapes_user.h")
+#include "odk_shapes_user.h"
+#endif
+#ifndef ODK_USER_SHAPES
+#define ODK_USER_SHAPES(X)
+#endif
+#define ODK_SHAPES(X) X(0, ShapeA) X(1, ShapeB) X(2, ShapeC) X(3, ShapeD) ODK_USER_SHAPES(X)
 
 struct KArgs {
   const DevModel* m;

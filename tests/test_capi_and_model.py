@@ -356,6 +356,20 @@ def test_new_shape_tool_names_the_lines_a_new_robot_needs(tmp_path, capsys):
         dims = [t.strip() for t in m.group(1).split(",")]
         assert dims[:5] == ["21", "20", "18", "14", "15"] and dims[-3:] == ["false", "6", "true"]      # nq, nv, nbody, nu, njnt ...; chains of six; optional constraint code
         assert "X(4, ShapeX)" in out and "ODK_SHAPES" in out
+        # `--add` without touching the tree: the user header in a directory of its own, the kernels' static_asserts checked by a syntax-only compile
+        hdr = tmp_path / "odk_shapes_user.h"
+        alias = ns.add_user_shape(m.group(1), header=str(hdr))
+        assert alias == "ShapeU0" and ns.add_user_shape(m.group(1), header=str(hdr)) == "ShapeU0"      # idempotent
+        text = hdr.read_text()
+        assert f"using ShapeU0 = Shape<{m.group(1)}>;" in text and "#define ODK_USER_SHAPES(X) X(4, ShapeU0)" in text
+        ok, err = ns.syntax_check(include_dir=str(tmp_path))
+        assert ok, err
+        # a shape the kernels cannot take (60 constraint rows: the foot-foot routine's scratch does not fit) stops at a static_assert, by name
+        bad = m.group(1).split(",")
+        bad[7] = " 60"
+        ns.add_user_shape(",".join(bad), header=str(hdr))
+        ok, err = ns.syntax_check(include_dir=str(tmp_path))
+        assert not ok and "static assertion" in err
     finally:
         sys.argv = argv
 
