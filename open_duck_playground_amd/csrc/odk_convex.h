@@ -419,9 +419,12 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
 #pragma unroll
         for (int i = 0; i < 9; i++) {
           const float adc = pr[FA[i]], bdc = pr[FBK[i]];
-          const bool ok = RB.on[s] & (cb[i] * db[i] < 0.0f) & (adc * bdc < 0.0f) & (cb[i] * bdc > 0.0f);   // (no short circuit: selects, not branches)
+          // cb db < 0 and adc bdc < 0 and cb bdc > 0  <=>  max(cb db, adc bdc, -(cb bdc)) < 0: one v_max3_f32 + one compare instead of three compares and
+          // two scalar ANDs per pair (round 6)
+          const bool ok = fmaxf(fmaxf(cb[i] * db[i], adc * bdc), -(cb[i] * bdc)) < 0.0f;
           pass |= ok ? (1u << (9 * s + i)) : 0u;
         }
+        pass &= RB.on[s] ? ~0u : ~(0x1FFu << (9 * s));      // (a lane without a hull edge in this slot passes nothing)
       }
     }
     SAT_PROF(2);

@@ -1005,6 +1005,11 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
 // registers over the whole loop.  LDS: hull vertices / face normals in the height field's frame in cfrc | crb; per row the prism's
 // vertices + the two polygons of the face contact in BUF6 / BUF6B; per row prism list, running best four, current four in
 // D | aref | jar | jv; at the end the eight contact frames go to jv ([8][9], read by the constraint-row phase).
+// index into DevModel::hf_assign from the four rows' open-entry counts (one byte each), each capped at four
+__host__ __device__ __forceinline__ int hf_assign_index(unsigned n_pk) {
+  const unsigned c0 = min(n_pk & 255u, 4u), c1 = min((n_pk >> 8) & 255u, 4u), c2 = min((n_pk >> 16) & 255u, 4u), c3 = min(n_pk >> 24, 4u);
+  return (int)(c0 + 5u * (c1 + 5u * (c2 + 5u * c3)));
+}
 template <class S, int G>
 __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __restrict__ m, const float* __restrict__ hf, int lane) {
   constexpr int NB = S::NB;
@@ -1184,7 +1189,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     for (int q0 = 0; q0 < nvu; q0 += 6) {
       float vv[6][3];
 #pragma unroll
-      for (int t = 0; t < 6; t++) { const int q = q0 + t < HULL_MAXV ? q0 + t : 0; vv[t][0] = FV[3 * q]; vv[t][1] = FV[3 * q + 1]; vv[t][2] = FV[3 * q + 2]; }
+      for (int t = 0; t < 6; t++) { const int q = q0 + t; vv[t][0] = FV[3 * q]; vv[t][1] = FV[3 * q + 1]; vv[t][2] = FV[3 * q + 2]; }      // (q <= 17: inside the hull region, masked below)
 #pragma unroll
       for (int t = 0; t < 6; t++) stop = fminf(stop, dot3(P.nt, vv[t]) + (q0 + t < nvt ? 0.0f : 3.0e38f));
     }
@@ -1209,7 +1214,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
       for (int t0 = 0; t0 < nfu; t0 += 5) {      // (batches of five faces: 20 LDS reads in flight together)
         float4 fnv[5];
 #pragma unroll
-        for (int u = 0; u < 5; u++) { const int t = t0 + u < HULL_MAXF ? t0 + u : 0; fnv[u] = *reinterpret_cast<const float4*>(FN4 + 4 * t); }
+        for (int u = 0; u < 5; u++) fnv[u] = *reinterpret_cast<const float4*>(FN4 + 4 * (t0 + u));      // (t0 + u <= 29: inside the records' region, masked below)
 #pragma unroll
         for (int u = 0; u < 5; u++) {
           const float n0 = fnv[u].x, n1 = fnv[u].y, n2 = fnv[u].z, dd = fnv[u].w;
@@ -1271,7 +1276,6 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   EdgeRegs<3> RB;
   FaceRegs<2> FB;
   float* LISTt = LIST; float* TOPt = TOP;
-  unsigned cur_pk = 0u | (1u << 8) | (2u << 16) | (3u << 24);   // wave-uniform: the foot each row is on
   const float s0 = j < cnt ? LIST[6 * j + 5] : 3.0e38f, s1 = j + 16 < cnt ? LIST[6 * (j + 16) + 5] : 3.0e38f;   // own list's bounds (sorted)
   unsigned taken = 0u;        // row-uniform: entries of the own list that some row has taken
   const bool up_only = HF_FILTER(m) == 3;   // (read once: every compiler barrier in the loop would fetch it again)
@@ -1298,38 +1302,13 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
 #pragma unroll
     for (int t = 0; t < 4; t++) { open_t[t] = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(tgt_meta(t)[4])); n_pk |= (unsigned)__popc(open_t[t]) << (8 * t); }
     if (n_pk == 0u || HF_KNOCK(2)) break;
-    // assignment: rows keep their foot while it has open entries for them, the others go where most are left
-    unsigned asg_pk = 0u, tgt_pk = 0u, rnk_pk = 0u, on_pk = 0u;
-    // The common case needs none of it: a row can only help another when some row has nothing open WHILE some foot has two or more open entries.
-    // Otherwise every row works the first open entry of its own foot (round 6: ~250 dependent scalar instructions per iteration in that case).
-    const unsigned nz_pk = ((n_pk & 0xFFu) ? 1u : 0u) | ((n_pk & 0xFF00u) ? 1u << 8 : 0u) | ((n_pk & 0xFF0000u) ? 1u << 16 : 0u) | ((n_pk & 0xFF000000u) ? 1u << 24 : 0u);
-    const bool none_idle = nz_pk == 0x01010101u, none_rich = (n_pk & 0xFEFEFEFEu) == 0u;
-    if (none_idle || none_rich) {
-      tgt_pk = 0u | (1u << 8) | (2u << 16) | (3u << 24);
-      asg_pk = nz_pk;
-      on_pk = (nz_pk & 1u) | ((nz_pk >> 7) & 2u) | ((nz_pk >> 14) & 4u) | ((nz_pk >> 21) & 8u);
-    } else {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const unsigned c = (cur_pk >> (8 * r)) & 3u;
-      const unsigned left = ((n_pk >> (8 * c)) & 255u) - ((asg_pk >> (8 * c)) & 255u);
-      if (left > 0u) { tgt_pk |= c << (8 * r); rnk_pk |= ((asg_pk >> (8 * c)) & 255u) << (8 * r); asg_pk += 1u << (8 * c); on_pk |= 1u << r; }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      if (!((on_pk >> r) & 1u)) {
-        unsigned bt = 0u, bl = 0u;
-#pragma unroll
-        for (unsigned t = 0; t < 4; t++) { const unsigned left = ((n_pk >> (8 * t)) & 255u) - ((asg_pk >> (8 * t)) & 255u); if (left > bl) { bl = left; bt = t; } }
-        if (bl > 0u) { tgt_pk |= bt << (8 * r); rnk_pk |= ((asg_pk >> (8 * bt)) & 255u) << (8 * r); asg_pk += 1u << (8 * bt); on_pk |= 1u << r; }
-        else tgt_pk |= ((cur_pk >> (8 * r)) & 3u) << (8 * r);
-      }
-    }
-    }
-    cur_pk = tgt_pk;
-    const unsigned maxq = max(max(asg_pk & 255u, (asg_pk >> 8) & 255u), max((asg_pk >> 16) & 255u, (asg_pk >> 24) & 255u)) - 1u;
-    const int my_tg = (int)((tgt_pk >> (8 * r_own)) & 3u), my_q = (int)((rnk_pk >> (8 * r_own)) & 255u);
-    const bool my_on = (on_pk >> r_own) & 1u;
+    // assignment: a row works its own foot while that has open entries, an idle row goes where most are left.  The rule is a function of the four
+    // counts capped at four (a foot can use its own row and three helpers): ONE scalar load from a 625-entry table built at model load
+    // (DevModel::hf_assign; the ~300 dependent scalar instructions that derived it in place were the largest single block of the loop's scalar work: round 6)
+    const unsigned aw = (unsigned)m->hf_assign[hf_assign_index(n_pk)];
+    const unsigned maxq = (aw >> 20) & 3u;
+    const int my_tg = (int)((aw >> (2 * r_own)) & 3u), my_q = (int)((aw >> (8 + 2 * r_own)) & 3u);
+    const bool my_on = (aw >> (16 + r_own)) & 1u;
     // a row on a new foot: that hull's tables, the window's width and centroid, its faces / edges into the registers
     const bool sw = my_on && my_tg != tg;
     if (__builtin_amdgcn_ballot_w64(sw) != 0) {

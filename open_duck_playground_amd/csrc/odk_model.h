@@ -148,6 +148,9 @@ struct DevModel {
   // height-field floor (rough terrain): geom frame = (plane_pos, floor_mat); samples live in HBM (KArgs.hfield)
   int hfield_nrow, hfield_ncol;
   float hfield_size[4], floor_mat[9];
+  // height-field pair loop: the rows' assignment to feet as a function of the four open-entry counts capped at four (odk_kernels.h hf_assign_index):
+  // foot of row r (2 bits each) | rank among the rows on that foot << 8 (2 bits each) | row has work << 16 | (most rows on one foot - 1) << 20
+  int hf_assign[625];
   int hfield_filter;   // per batch (odk_env_config.hfield_up_normals_only): 0 = none, 3 = a pair's contacts count only when its normal points up
   // sites / sensors
   int site_body[MAXSITE], site_imu, site_feet[2];
