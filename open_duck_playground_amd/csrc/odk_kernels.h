@@ -1014,7 +1014,7 @@ template <class S, int G>
 __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __restrict__ m, const float* __restrict__ hf, int lane) {
   constexpr int NB = S::NB;
   static_assert(G == 32, "height-field floors run 32 lanes per env (two 16-lane rows = two feet)");
-  static_assert(4 * S::NROW >= 344 && 16 * S::NB >= 282 && 6 * S::NVR >= 106 && S::NROW >= 72, "height-field scratch does not fit");
+  static_assert(4 * S::NROW >= 344 && 16 * S::NB >= 288 && 6 * S::NVR >= 106 && S::NROW >= 72, "height-field scratch does not fit");
   float* CDIST = L + S::O_CDIST; float* CR = L + S::O_CR;
   const float* XPOS = L + S::O_XPOS; const float* XQUAT = L + S::O_XQUAT; const float* QPOS = L + S::O_QPOS;
   const float ref[3] = {QPOS[0], QPOS[1], QPOS[2]};
@@ -1038,7 +1038,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
 #define HF_PROF(i) do { } while (0)
 #define HF_COUNT(i, v) do { } while (0)
 #endif
-  float* FV = L + S::O_CFRC + f * 51; float* FN = L + S::O_CFRC + 102 + f * 90;
+  float* FV = L + S::O_CFRC + f * 54; float* FN = L + S::O_CFRC + 108 + f * 90;      // [2][18][3] vertices (entries past a hull's last: copies of vertex 0) | [2][30][3] normals
   float* RS = L + (f ? S::O_BUF6B : S::O_BUF6);
   float* PV = RS;                                                      // prism vertices [6][3]
   // [<= 30][4] the hull's faces as (normal, plane offset) records for the cull pass's face loop: ONE 16-byte LDS read per face instead of four dwords
@@ -1090,16 +1090,23 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   Pw[0] -= org[0]; Pw[1] -= org[1];
   HF_REP(8) {
   HF_TOUCH(Pw[0]);
-  for (int v = j; v < nvt; v += 16) {
-    const float vb[3] = {m->foot_vert[f][v][0], m->foot_vert[f][v][1], m->foot_vert[f][v][2]};
+  // (the cull pass's loops run unmasked over 18 vertices / the faces in fives: the entries past a hull's last are copies of vertex 0 -- no change to
+  // a minimum -- and face records that separate nothing)
+  for (int v = j; v < 18; v += 16) {
+    const int vs = v < nvt ? v : 0;
+    const float vb[3] = {m->foot_vert[f][vs][0], m->foot_vert[f][vs][1], m->foot_vert[f][vs][2]};
     for (int k = 0; k < 3; k++) FV[3 * v + k] = Pw[k] + Rw[3 * k] * vb[0] + Rw[3 * k + 1] * vb[1] + Rw[3 * k + 2] * vb[2];
   }
-  for (int t = j; t < nfc; t += 16) {
-    const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
-    float nw[3];
-    for (int k = 0; k < 3; k++) { nw[k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2]; FN[3 * t + k] = nw[k]; }
-    // the face's plane offset in the window frame: n . (P + R v) = n_b . v_b + n . P
-    *reinterpret_cast<float4*>(FN4 + 4 * t) = make_float4(nw[0], nw[1], nw[2], m->foot_foff[f][t] + dot3(nw, Pw));
+  for (int t = j; t < HULL_MAXF; t += 16) {
+    if (t < nfc) {
+      const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
+      float nw[3];
+      for (int k = 0; k < 3; k++) { nw[k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2]; FN[3 * t + k] = nw[k]; }
+      // the face's plane offset in the window frame: n . (P + R v) = n_b . v_b + n . P
+      *reinterpret_cast<float4*>(FN4 + 4 * t) = make_float4(nw[0], nw[1], nw[2], m->foot_foff[f][t] + dot3(nw, Pw));
+    } else {
+      *reinterpret_cast<float4*>(FN4 + 4 * t) = make_float4(0.0f, 0.0f, 0.0f, 3.0e38f);
+    }
   }
   }
   float fc[3];
@@ -1189,9 +1196,9 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     for (int q0 = 0; q0 < nvu; q0 += 6) {
       float vv[6][3];
 #pragma unroll
-      for (int t = 0; t < 6; t++) { const int q = q0 + t; vv[t][0] = FV[3 * q]; vv[t][1] = FV[3 * q + 1]; vv[t][2] = FV[3 * q + 2]; }      // (q <= 17: inside the hull region, masked below)
+      for (int t = 0; t < 6; t++) { const int q = q0 + t; vv[t][0] = FV[3 * q]; vv[t][1] = FV[3 * q + 1]; vv[t][2] = FV[3 * q + 2]; }      // (q <= 17: padded with copies of vertex 0)
 #pragma unroll
-      for (int t = 0; t < 6; t++) stop = fminf(stop, dot3(P.nt, vv[t]) + (q0 + t < nvt ? 0.0f : 3.0e38f));
+      for (int t = 0; t < 6; t++) stop = fminf(stop, dot3(P.nt, vv[t]));
     }
     s5[0] = stop;
     }
@@ -1214,14 +1221,14 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
       for (int t0 = 0; t0 < nfu; t0 += 5) {      // (batches of five faces: 20 LDS reads in flight together)
         float4 fnv[5];
 #pragma unroll
-        for (int u = 0; u < 5; u++) fnv[u] = *reinterpret_cast<const float4*>(FN4 + 4 * (t0 + u));      // (t0 + u <= 29: inside the records' region, masked below)
+        for (int u = 0; u < 5; u++) fnv[u] = *reinterpret_cast<const float4*>(FN4 + 4 * (t0 + u));      // (t0 + u <= 29: records past the hull's last separate nothing)
 #pragma unroll
         for (int u = 0; u < 5; u++) {
           const float n0 = fnv[u].x, n1 = fnv[u].y, n2 = fnv[u].z, dd = fnv[u].w;
           const float h0 = n0 * P.x[0] + n1 * P.y[0], h1 = n0 * P.x[1] + n1 * P.y[1], h2 = n0 * P.x[2] + n1 * P.y[2];
           const float top = fminf(fminf(h0 + n2 * z[0], h1 + n2 * z[1]), h2 + n2 * z[2]), bot = fminf(fminf(h0, h1), h2) + n2 * zb;
           const float sv = fminf(top, bot) - dd;
-          sep_b = (t0 + u < nfc && sv > sep_b) ? sv : sep_b;
+          sep_b = fmaxf(sep_b, sv);
         }
       }
       }
@@ -1240,8 +1247,10 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     float e0[6], e1[6];
     for (int t = 0; t < 6; t++) { e0[t] = LIST[6 * j + t]; e1[t] = j < 2 ? LIST[6 * (j + 16) + t] : 0.0f; }
     int rk0 = 0, rk1 = 0;
-#pragma unroll 6
-    for (int q = 0; q < 18; q++) {
+    // (trip count: the longest list of the wave's four rows -- three entries on average, not the list's capacity)
+    const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)), max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
+#pragma unroll 1
+    for (int q = 0; q < cmax; q++) {
       const float sq = LIST[6 * q + 5];
       const bool in = q < cnt;
       rk0 += (in && (sq < e0[5] || (sq == e0[5] && q < j))) ? 1 : 0;
@@ -1317,7 +1326,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
         float* Lt = tgt_L(tg); const int ft = tg & 1;
         const float* mt = tgt_meta(tg);
         ncw_t = __float_as_int(mt[0]);
-        B.V = Lt + S::O_CFRC + ft * 51; B.N = Lt + S::O_CFRC + 102 + ft * 90;
+        B.V = Lt + S::O_CFRC + ft * 54; B.N = Lt + S::O_CFRC + 108 + ft * 90;
         B.poly = &m->foot_poly[ft][0][0]; B.edge = &m->foot_edge[ft][0][0];
         B.nv = m->foot_nvert[ft]; B.nf = m->foot_npoly[ft]; B.ne = m->foot_nedge[ft];
         B.c[0] = mt[1]; B.c[1] = mt[2]; B.c[2] = mt[3];
