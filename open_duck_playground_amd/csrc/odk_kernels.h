@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   // until the solver); both 16-byte aligned.
   float* FN4 = L + (f ? S::O_X : ((S::O_HL + 3) & ~3));
   static_assert(4 * S::NV >= 4 * HULL_MAXF && S::NHR >= 4 * HULL_MAXF + 3 && S::O_X % 4 == 0 && S::ENV_STRIDE % 4 == 0, "hull face records");
-  float* META = RS + 106;                                              // for the other rows: ncw, hull centroid [3], mask of this foot's open list entries, the entry this ROW took last (foot << 8 | entry)
+  float* META = RS + 106;                                              // for the other rows: ncw, hull centroid [3]  (the loop's bookkeeping -- open entries, entries taken -- lives in scalar registers)
   static_assert(6 * S::NVR >= 111, "row scratch + window record");
   float* RL = L + S::O_D + f * 172;
   float* LIST = RL; float* TOP = RL + 108; float* NEW = RL + 140;      // [18][6] | [4][8] | [4][8]
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   float fc[3];
   for (int k = 0; k < 3; k++) fc[k] = Pw[k] + Rw[3 * k] * m->foot_centroid[f][0] + Rw[3 * k + 1] * m->foot_centroid[f][1] + Rw[3 * k + 2] * m->foot_centroid[f][2];
   if (j < 4) { float* o = TOP + 8 * j; o[0] = 1.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f; o[5] = 0.0f; o[6] = 1.0f; o[7] = 1.0e9f + (float)j; }
-  if (j == 0) { META[0] = __int_as_float(ncw); META[1] = fc[0]; META[2] = fc[1]; META[3] = fc[2]; META[5] = __int_as_float(0xFFFF); }
+  if (j == 0) { META[0] = __int_as_float(ncw); META[1] = fc[0]; META[2] = fc[1]; META[3] = fc[2]; }
   ODK_SYNC();
   const float idiag = 1.0f / sqrtf(dx * dx + dy * dy);
   // prism p = 2 (ri ncw + ci) + tri of this row's window: grid corners of its top triangle (counter-clockwise seen from above)
@@ -1162,11 +1162,10 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   // ---- pass over the window, lane = prism: the prism's own face query against the hull vertices; survivors into the list
   int cnt = 0;
   const int nprism = (ncw > 0 && nrw > 0) ? 2 * ncw * nrw : 0;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; pass++) {
-    const int p = 16 * pass + j;
+  {      // (prisms 0 .. 15: one pass; a 3 x 3 window's last two are done below, lane = hull vertex / face)
+    constexpr int pass = 0;
+    const int p = j;
     const bool valid = p < nprism;
-    if (__builtin_amdgcn_ballot_w64(valid) == 0 || (pass == 1 && HF_KNOCK(0))) break;
 #if defined(ODK_PROFILE) && defined(ODK_PROF_CULL)
     long long _hc = clock64();
 #endif
@@ -1242,6 +1241,50 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     cnt += __popc(rowmask);
     HF_CULL(4);      // list write
   }
+  // Prisms 16 / 17 (a 3 x 3 window only): a second pass of the loops above would run them for two lanes of sixteen.  Here the prism is the ROW's
+  // and the lanes are the hull's: lane = vertex for the top plane (row minimum), lane = two face records for the hull's query (row maximum) --
+  // the same minima / maxima, ~150 instructions per prism instead of a ~1 000-instruction pass (round 6).
+  if (__builtin_amdgcn_ballot_w64(nprism > 16) != 0 && !HF_KNOCK(0)) {
+#pragma unroll 1
+    for (int p = 16; p < 18; p++) {
+      const bool valid = p < nprism;      // (row-uniform)
+      float z[3] = {0.0f, 0.0f, 0.0f};
+      if (valid) { int cc[3], rr[3]; corners(p, ncw, cc, rr); for (int k = 0; k < 3; k++) z[k] = hf[(rmin + rr[k]) * nc + cmin + cc[k]] * sz; }
+      Prism P;
+      prism(valid ? p : 0, ncw, z, P);
+      float d5[5], s5[5];
+      d5[0] = P.nt[0] * P.x[0] + P.nt[1] * P.y[0] + P.nt[2] * P.z[0]; d5[1] = base;
+      d5[2] = P.ns[0][0] * P.x[0] + P.ns[0][1] * P.y[0]; d5[3] = P.ns[1][0] * P.x[1] + P.ns[1][1] * P.y[1]; d5[4] = P.ns[2][0] * P.x[2] + P.ns[2][1] * P.y[2];
+      {
+        const bool up = !(p & 1);
+        s5[1] = -e_zmax; s5[2] = up ? -e_ymax : e_ymin; s5[3] = up ? e_wmin : -e_wmax; s5[4] = up ? -e_xmax : e_xmin;
+        const int v1 = j < 2 ? j + 16 : 0;      // (18 vertex slots, the last ones copies of vertex 0)
+        const float va[3] = {FV[3 * j], FV[3 * j + 1], FV[3 * j + 2]}, vb[3] = {FV[3 * v1], FV[3 * v1 + 1], FV[3 * v1 + 2]};
+        s5[0] = fkey_inv(rreduce_u<false>(fkey(fminf(dot3(P.nt, va), dot3(P.nt, vb)))));
+      }
+      float sep = -3.0e38f; int face = 0;
+#pragma unroll
+      for (int fa = 0; fa < 5; fa++) { const float sv = s5[fa] - d5[fa]; if (sv > sep) { sep = sv; face = fa; } }
+      float sb = -3.0e38f;
+      {
+        const float zb = -base;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int t = j + 16 * u < HULL_MAXF ? j + 16 * u : 0;      // (30 records, those past the hull's last separate nothing)
+          const float4 fr = *reinterpret_cast<const float4*>(FN4 + 4 * t);
+          const float n0 = fr.x, n1 = fr.y, n2 = fr.z, dd = fr.w;
+          const float h0 = n0 * P.x[0] + n1 * P.y[0], h1 = n0 * P.x[1] + n1 * P.y[1], h2 = n0 * P.x[2] + n1 * P.y[2];
+          const float top = fminf(fminf(h0 + n2 * z[0], h1 + n2 * z[1]), h2 + n2 * z[2]), bot = fminf(fminf(h0, h1), h2) + n2 * zb;
+          sb = fmaxf(sb, fminf(top, bot) - dd);
+        }
+      }
+      const float sep_b = fkey_inv(rreduce_u<true>(fkey(sb)));
+      const float bound = fmaxf(sep, sep_b);
+      const bool keep = valid && !(bound > 0.0f);
+      if (keep && j == 0) { float* o = LIST + 6 * cnt; o[0] = __int_as_float(p | (face << 8)); o[1] = z[0]; o[2] = z[1]; o[3] = z[2]; o[4] = sep; o[5] = bound; }
+      cnt += keep ? 1 : 0;
+    }
+  }
   ODK_SYNC();
   {   // the list in ascending (sep, prism) order: an entry's place is the number of entries before it
     float e0[6], e1[6];
@@ -1286,7 +1329,11 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   FaceRegs<2> FB;
   float* LISTt = LIST; float* TOPt = TOP;
   const float s0 = j < cnt ? LIST[6 * j + 5] : 3.0e38f, s1 = j + 16 < cnt ? LIST[6 * (j + 16) + 5] : 3.0e38f;   // own list's bounds (sorted)
-  unsigned taken = 0u;        // row-uniform: entries of the own list that some row has taken
+  // Bookkeeping of the loop in SCALAR registers (round 6): which entries of the four lists have been taken (two 64-bit words: foot t's 18 bits at
+  // 32 (t & 1) of word t >> 1), and what every row took in the iteration before (read from the rows' registers by v_readlane) -- no exchange through
+  // LDS, no barrier, nothing of it on the vector pipe.
+  unsigned long long taken01 = 0ull, taken23 = 0ull;
+  int last_pk = 0xFFFF;       // row-uniform: the entry this row took in the iteration before (foot << 8 | entry), 0xFFFF: none
   const bool up_only = HF_FILTER(m) == 3;   // (read once: every compiler barrier in the loop would fetch it again)
 #ifdef ODK_PROFILE
   _hp = clock64();   // (slot 2 counts the passing edge pairs of lane 0's row: odk_convex.h)
@@ -1297,19 +1344,24 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
 #pragma unroll 1
   for (;;) {
     asm volatile("; HF_LOOP_BEGIN" ::: "memory");
-    {   // open entries of this row's own list: the prefix of the sorted list within reach of the fourth-deepest contact so far,
-        // less the entries taken (by any row) in the iterations before
-#pragma unroll
-      for (int r = 0; r < 4; r++) { const int pk = __float_as_int(tgt_meta(r)[5]); taken |= (pk >> 8) == r_own ? 1u << (pk & 31) : 0u; }
-      const float lim = TOP[8 * 3];
-      const unsigned m0 = (unsigned)((__builtin_amdgcn_ballot_w64(!(s0 > lim)) >> (threadIdx.x & 48u)) & 0xFFFFull);
-      const unsigned m1 = (unsigned)((__builtin_amdgcn_ballot_w64(!(s1 > lim)) >> (threadIdx.x & 48u)) & 0x3ull);
-      if (j == 0) META[4] = __uint_as_float((m0 | (m1 << 16)) & ~taken);
-    }
-    ODK_SYNC();
     unsigned open_t[4], n_pk = 0u;
+    {   // open entries of every row's own list: the prefix of the sorted list within reach of the fourth-deepest contact so far (one wave-wide
+        // ballot holds all four rows' bits), less the entries taken (by any row) in the iterations before
 #pragma unroll
-    for (int t = 0; t < 4; t++) { open_t[t] = (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(tgt_meta(t)[4])); n_pk |= (unsigned)__popc(open_t[t]) << (8 * t); }
+      for (int r = 0; r < 4; r++) {
+        const unsigned pk = (unsigned)__builtin_amdgcn_readlane(last_pk, 16 * r);
+        const unsigned long long bit = pk == 0xFFFFu ? 0ull : 1ull << ((pk & 31u) + ((pk >> 8) & 1u) * 32u);
+        taken01 |= (pk >> 9) ? 0ull : bit; taken23 |= (pk >> 9) ? bit : 0ull;
+      }
+      const float lim = TOP[8 * 3];
+      const unsigned long long b0 = __builtin_amdgcn_ballot_w64(!(s0 > lim)), b1 = __builtin_amdgcn_ballot_w64(!(s1 > lim));
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const unsigned tk = (unsigned)((t < 2 ? taken01 : taken23) >> (32 * (t & 1)));
+        open_t[t] = ((unsigned)((b0 >> (16 * t)) & 0xFFFFull) | ((unsigned)((b1 >> (16 * t)) & 0x3ull) << 16)) & ~tk;
+        n_pk |= (unsigned)__popc(open_t[t]) << (8 * t);
+      }
+    }
     if (n_pk == 0u || HF_KNOCK(2)) break;
     // assignment: a row works its own foot while that has open entries, an idle row goes where most are left.  The rule is a function of the four
     // counts capped at four (a foot can use its own row and three helpers): ONE scalar load from a 625-entry table built at model load
@@ -1346,7 +1398,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     for (int q = 0; q < 3; q++) wsel = q < my_q ? wsel & (wsel - 1u) : wsel;
     const bool act = my_on && wsel != 0u;
     const int kk = act ? __ffs((int)wsel) - 1 : 0;
-    if (j == 0) META[5] = __int_as_float(act ? (my_tg << 8) | kk : 0xFFFF);
+    last_pk = act ? (my_tg << 8) | kk : 0xFFFF;
     const float* en = LISTt + 6 * kk;
     const int pf = act ? __float_as_int(en[0]) : 0;
     const int p = pf & 255, face_a = pf >> 8;
