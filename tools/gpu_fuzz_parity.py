@@ -128,6 +128,32 @@ def sweep(task, n=1024, seed=0, lanes=32, nsub=1, dist_tol=1e-6, verbose=True, v
             if sens > 3e-5:
                 stat["solver_branch"] += 1
                 continue
+        # the referee of the parity tests (oracle "Tie bias"): one class of the oracle's discrete decisions taking its runner-up inside a rounding-level
+        # band reproduces what the kernel did (round 6: a foot-foot pair whose separating face is one of the sole's two coplanar triangles)
+        from test_gpu_parity import ILL_CLASSES
+        hit = None
+        for eps, eps_rel in ((1e-7, 1e-6), (2e-6, 1e-4)):
+            for bit, name in ILL_CLASSES:
+                O.set_tie_bias(bit, eps, eps_rel)
+                try:
+                    db = O.OracleData(om)
+                    db["qpos"][: om.nq] = qpos[e]; db["qvel"][: om.nv] = qvel[e]; db["qacc_warmstart"][: om.nv] = warm[e]; db["ctrl"][:14] = ctrl[e]
+                    db.forward()
+                    cb = np.array(db["contact_dist"][:12])
+                    sb = np.concatenate([np.sort(cb[4 * p: 4 * p + 4]) for p in range(3)])
+                    ab = (sb < 0) | (sg < 0)
+                    dsb = _oracle_step(O, om, qpos[e], qvel[e], warm[e], ctrl[e], nsub)
+                finally:
+                    O.set_tie_bias(0)
+                if (nsub > 1 or not ab.any() or np.abs(sg[ab] - sb[ab]).max() < 2e-6) and _rel(gv[e], np.array(dsb["qvel"][: om.nv]), 1.0).max() < (1e-4 if nsub == 1 else 1e-3):
+                    hit = f"{name}@{eps:g}"
+                    break
+            if hit:
+                break
+        if hit:
+            stat["tie_class"] = stat.get("tie_class", 0) + 1
+            stat.setdefault("tie_classes", {})[hit] = stat.get("tie_classes", {}).get(hit, 0) + 1
+            continue
         stat["unexplained"] += 1
         if verbose:
             print(f"  UNEXPLAINED {task} seed {seed} env {e}: dist err {derr:.2e} qvel err {verr:.2e}")
