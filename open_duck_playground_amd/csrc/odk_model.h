@@ -148,9 +148,6 @@ struct DevModel {
   // height-field floor (rough terrain): geom frame = (plane_pos, floor_mat); samples live in HBM (KArgs.hfield)
   int hfield_nrow, hfield_ncol;
   float hfield_size[4], floor_mat[9];
-  // height-field pair loop: the rows' assignment to feet as a function of the four open-entry counts capped at four (odk_kernels.h hf_assign_index):
-  // foot of row r (2 bits each) | rank among the rows on that foot << 8 (2 bits each) | row has work << 16 | (most rows on one foot - 1) << 20
-  int hf_assign[625];
   int hfield_filter;   // per batch (odk_env_config.hfield_up_normals_only): 0 = none, 3 = a pair's contacts count only when its normal points up
   // sites / sensors
   int site_body[MAXSITE], site_imu, site_feet[2];
@@ -171,6 +168,10 @@ struct DevModel {
   int cone;      // <option cone>: 0 pyramidal, 1 elliptic (shapes with S::ELL; odk_kernels.h "elliptic cones")
   int neq, eq_dof1[EQ_MAX], eq_dof2[EQ_MAX], eq_qadr1[EQ_MAX], eq_qadr2[EQ_MAX], eq_key[EQ_MAX], dof_eqrow[MAXV];
   float eq_poly[EQ_MAX][5], eq_imp[EQ_MAX][9], eq_invweight[EQ_MAX];
+  // height-field pair loop: the rows' assignment to feet as a function of the four open-entry counts capped at four (odk_kernels.h hf_assign_index);
+  // at the END of the record: the plane-floor kernels' loads keep the offsets -- and so the instruction streams -- they had:
+  // foot of row r (2 bits each) | rank among the rows on that foot << 8 (2 bits each) | row has work << 16 | (most rows on one foot - 1) << 20
+  int hf_assign[625];
 };
 
 // Topology of a height-field prism (vertices 0..2 = top triangle counter-clockwise seen from above, 3..5 below them; faces: top,
