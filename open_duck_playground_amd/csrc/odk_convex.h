@@ -503,29 +503,31 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
   float n_ref[3], n_inc[3];
   int pf_pk;    // the hull face involved (reference or incident), packed polygon
   int pa_f;     // the prism face involved
-  if (ref_a) {  // row-uniform
-    pa_f = face_a;
-    n_ref[0] = face_a == 0 ? P.nt[0] : (face_a == 1 ? 0.0f : (face_a == 2 ? P.ns[0][0] : (face_a == 3 ? P.ns[1][0] : P.ns[2][0])));
-    n_ref[1] = face_a == 0 ? P.nt[1] : (face_a == 1 ? 0.0f : (face_a == 2 ? P.ns[0][1] : (face_a == 3 ? P.ns[1][1] : P.ns[2][1])));
-    n_ref[2] = face_a == 0 ? P.nt[2] : (face_a == 1 ? -1.0f : 0.0f);
+  // The two cases -- the prism's face is the reference (ref_a) or the hull's -- are ONE sequence with the roles swapped at the end: the rows of a
+  // wave rarely agree on the case, and as two row-uniform branches every row walked through both (round 6).  Prism face: face_a, or the one most
+  // anti-parallel to the hull's separating face (first minimum); hull face: face_b, or the one most anti-parallel to that prism face.
+  {
+    float nhb[3];
+    ld3(nhb, B.N + 3 * face_b);
+    float bestp = 3.0e38f; int pf = 0;
+#pragma unroll
+    for (int f = 0; f < 5; f++) { float nf[3]; prism_norm(P, f, nf); const float sc = dot3(nf, nhb); if (sc < bestp) { bestp = sc; pf = f; } }
+    pa_f = ref_a ? face_a : pf;
+    float npr[3];
+    npr[0] = pa_f == 0 ? P.nt[0] : (pa_f == 1 ? 0.0f : (pa_f == 2 ? P.ns[0][0] : (pa_f == 3 ? P.ns[1][0] : P.ns[2][0])));
+    npr[1] = pa_f == 0 ? P.nt[1] : (pa_f == 1 ? 0.0f : (pa_f == 2 ? P.ns[0][1] : (pa_f == 3 ? P.ns[1][1] : P.ns[2][1])));
+    npr[2] = pa_f == 0 ? P.nt[2] : (pa_f == 1 ? -1.0f : 0.0f);
     float best = -3.0e38f, vm; int bi = 0x7FFFFFFF;
 #pragma unroll
-    for (int s = 0; s < NFS; s++) { const float sc = -dot3(fn[s], n_ref); if (FB.on[s] && sc > best) { best = sc; bi = j + 16 * s; } }
+    for (int s = 0; s < NFS; s++) { const float sc = -dot3(fn[s], npr); if (FB.on[s] && sc > best) { best = sc; bi = j + 16 * s; } }
     int inc = row_argmax(best, bi, vm);
     inc = (unsigned)inc < (unsigned)B.nf ? inc : 0;
-    const int sl = inc >> 4;
-    ld3(n_inc, B.N + 3 * inc);
-    pf_pk = __float_as_int(row_get(__int_as_float(sl == 0 ? FB.poly[0] : FB.poly[NFS - 1]), inc & 15));
-  } else {
-    const int sl = face_b >> 4;
-    ld3(n_ref, B.N + 3 * face_b);
-    pf_pk = __float_as_int(row_get(__int_as_float(sl == 0 ? FB.poly[0] : FB.poly[NFS - 1]), face_b & 15));
-    float best = 3.0e38f; pa_f = 0;   // most anti-parallel prism face, first minimum
+    const int hface = ref_a ? inc : face_b;
+    float nh[3];
+    ld3(nh, B.N + 3 * hface);
+    pf_pk = __float_as_int(row_get(__int_as_float((hface >> 4) == 0 ? FB.poly[0] : FB.poly[NFS - 1]), hface & 15));
 #pragma unroll
-    for (int f = 0; f < 5; f++) { float nf[3]; prism_norm(P, f, nf); const float sc = dot3(nf, n_ref); if (sc < best) { best = sc; pa_f = f; } }
-    n_inc[0] = pa_f == 0 ? P.nt[0] : (pa_f == 1 ? 0.0f : (pa_f == 2 ? P.ns[0][0] : (pa_f == 3 ? P.ns[1][0] : P.ns[2][0])));
-    n_inc[1] = pa_f == 0 ? P.nt[1] : (pa_f == 1 ? 0.0f : (pa_f == 2 ? P.ns[0][1] : (pa_f == 3 ? P.ns[1][1] : P.ns[2][1])));
-    n_inc[2] = pa_f == 0 ? P.nt[2] : (pa_f == 1 ? -1.0f : 0.0f);
+    for (int k = 0; k < 3; k++) { n_ref[k] = ref_a ? npr[k] : nh[k]; n_inc[k] = ref_a ? nh[k] : npr[k]; }
   }
   static_assert(NFS == 2, "face slots: face = lane + 16 slot, two slots");
   // packed prism polygons (count | v0 << 3 | v1 << 6 | v2 << 9 | v3 << 12), selected without a table load
