@@ -221,6 +221,7 @@ struct RowScratch { float* RP; float* IP; float* NEW; float* PW; float* VV; };  
 // _clip -- (incident edge e clipped by the reference side planes) x 2, then (reference edge, projected on the incident plane along
 // the reference normal, clipped by the incident side planes) x 2 -- projected on the reference plane, four of them by
 // _manifold_points, written to S.NEW with the normal sg * n_ref (skip: an edge contact replaces them).
+template <bool PULL = false>      // PULL: lanes 0 .. 3 fetch the four chosen candidates from their lanes and write them in ONE block (the height-field loop)
 __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int icnt, const float* n_ref, const float* n_inc, float sg, bool skip, int j, bool act) {
   const int e = j >> 1, which = j & 1, np = 2 * (icnt + rcnt);
   const bool cand = j < np;
@@ -250,13 +251,28 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
   int idx[4];
   manifold4_row(pref, cand, mask, n_ref, np, j, idx);
   ODK_SYNC();
+  if constexpr (PULL) {
+    // (four predicated blocks of seven LDS writes each -> four lane fetches and one block: round 6)
+    const float pen = -off;
+    const int src = j == 0 ? idx[0] : (j == 1 ? idx[1] : (j == 2 ? idx[2] : idx[3]));
+    const float w0 = row_get(mask ? -pen : 1.0f, src);
+    float w[3];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (act && !skip && j == idx[k]) {
-      const float pen = -off;
-      float* o = S.NEW + 8 * k;
-      o[0] = mask ? -pen : 1.0f;
-      for (int t = 0; t < 3; t++) { o[1 + t] = pref[t] - 0.5f * pen * n_ref[t]; o[4 + t] = sg * n_ref[t]; }
+    for (int t = 0; t < 3; t++) w[t] = row_get(pref[t] - 0.5f * pen * n_ref[t], src);
+    if (act && !skip && j < 4) {
+      float* o = S.NEW + 8 * j;
+      o[0] = w0;
+      for (int t = 0; t < 3; t++) { o[1 + t] = w[t]; o[4 + t] = sg * n_ref[t]; }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (act && !skip && j == idx[k]) {
+        const float pen = -off;
+        float* o = S.NEW + 8 * k;
+        o[0] = mask ? -pen : 1.0f;
+        for (int t = 0; t < 3; t++) { o[1 + t] = pref[t] - 0.5f * pen * n_ref[t]; o[4 + t] = sg * n_ref[t]; }
+      }
     }
   }
 }
@@ -549,7 +565,7 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
   }
   ODK_SYNC();
   SAT_PROF(4);
-  if (!(knock & 32)) HF_REP(14) { HF_TOUCH(n_ref[0]); manifold_row(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act); }
+  if (!(knock & 32)) HF_REP(14) { HF_TOUCH(n_ref[0]); manifold_row<true>(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act); }
   SAT_PROF(5);
   if (is_edge) {   // row-uniform
     int ia = pair >> 22;
