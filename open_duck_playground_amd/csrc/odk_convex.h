@@ -176,6 +176,7 @@ __device__ __forceinline__ void manifold4_row(const float* p, bool cand, bool ma
 
 // mjx _clip_edge_to_planes: the edge (p0, p1) against the side planes of polygon Q (nq vertices at QP, normal qn); the `which`-th
 // of the two clipped points, returns the mask
+template <bool FULL4 = false>      // FULL4: all four planes for every lane (the height-field loop, below)
 __device__ __forceinline__ bool clip_edge_row(const float* p0, const float* p1, const float* QP, int nq, const float* qn, int which, float* out) {
   // Every point the routine can return lies on the edge: p0 + t (p1 - p0).  What is kept per plane is the parameter t, not the
   // point: "most along the edge" is t |d|^2 (from p0) and (1 - t) |d|^2 (from p1) without forming the candidate, the second end's
@@ -191,7 +192,9 @@ __device__ __forceinline__ bool clip_edge_row(const float* p0, const float* p1, 
   for (int k = 0; k < 4; k++) ld3(Q[k], QP + 3 * (k < nq ? k : 0));
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    if (k >= nq) break;   // (nq is 3 or 4)
+    // (nq is 3 or 4.  FULL4: no early exit for a triangle -- its fourth plane is its first again (Q[3] is a copy of Q[0], so the edge is Q[2] -> Q[0]) and a
+    // plane met twice changes nothing below (strict comparisons); the rows of a wave mix triangles and quads, so the exit only cost its branch: round 6.)
+    if (!FULL4 && k >= nq) break;
     const float* pa = k == 0 ? (nq == 4 ? Q[3] : Q[2]) : Q[k - 1]; const float* pb = Q[k];
     float e[3], pn[3], t0[3];
     sub3(e, pb, pa);
@@ -240,7 +243,7 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
       for (int k = 0; k < 3; k++) { a[k] += ta * n_ref[k]; b[k] += tb * n_ref[k]; }
     }
     const float qn[3] = {subj ? n_ref[0] : n_inc[0], subj ? n_ref[1] : n_inc[1], subj ? n_ref[2] : n_inc[2]};
-    const bool m1 = clip_edge_row(a, b, subj ? S.RP : S.IP, subj ? rcnt : icnt, qn, which, pt);
+    const bool m1 = clip_edge_row<PULL>(a, b, subj ? S.RP : S.IP, subj ? rcnt : icnt, qn, which, pt);
     mask = cand && m1;
   }
   float t0[3], pref[3];
