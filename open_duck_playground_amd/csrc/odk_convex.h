@@ -532,10 +532,12 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
 #pragma unroll
     for (int f = 0; f < 5; f++) { float nf[3]; prism_norm(P, f, nf); const float sc = dot3(nf, nhb); if (sc < bestp) { bestp = sc; pf = f; } }
     pa_f = ref_a ? face_a : pf;
-    float npr[3];
-    npr[0] = pa_f == 0 ? P.nt[0] : (pa_f == 1 ? 0.0f : (pa_f == 2 ? P.ns[0][0] : (pa_f == 3 ? P.ns[1][0] : P.ns[2][0])));
-    npr[1] = pa_f == 0 ? P.nt[1] : (pa_f == 1 ? 0.0f : (pa_f == 2 ? P.ns[0][1] : (pa_f == 3 ? P.ns[1][1] : P.ns[2][1])));
-    npr[2] = pa_f == 0 ? P.nt[2] : (pa_f == 1 ? -1.0f : 0.0f);
+    // (one select per statement: the nested five-way form was compiled into basic blocks with exec-mask bookkeeping, ~40 instructions a component)
+    float npr[3] = {P.ns[2][0], P.ns[2][1], 0.0f};
+    npr[0] = pa_f == 3 ? P.ns[1][0] : npr[0]; npr[1] = pa_f == 3 ? P.ns[1][1] : npr[1];
+    npr[0] = pa_f == 2 ? P.ns[0][0] : npr[0]; npr[1] = pa_f == 2 ? P.ns[0][1] : npr[1];
+    npr[0] = pa_f == 1 ? 0.0f : npr[0]; npr[1] = pa_f == 1 ? 0.0f : npr[1]; npr[2] = pa_f == 1 ? -1.0f : npr[2];
+    npr[0] = pa_f == 0 ? P.nt[0] : npr[0]; npr[1] = pa_f == 0 ? P.nt[1] : npr[1]; npr[2] = pa_f == 0 ? P.nt[2] : npr[2];
     float best = -3.0e38f, vm; int bi = 0x7FFFFFFF;
 #pragma unroll
     for (int s = 0; s < NFS; s++) { const float sc = -dot3(fn[s], npr); if (FB.on[s] && sc > best) { best = sc; bi = j + 16 * s; } }
@@ -550,8 +552,9 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
   }
   static_assert(NFS == 2, "face slots: face = lane + 16 slot, two slots");
   // packed prism polygons (count | v0 << 3 | v1 << 6 | v2 << 9 | v3 << 12), selected without a table load
-  const int pp_pk = pa_f == 0 ? (3 | 0 << 3 | 1 << 6 | 2 << 9 | 0 << 12) : (pa_f == 1 ? (3 | 3 << 3 | 5 << 6 | 4 << 9 | 3 << 12)
-                  : (pa_f == 2 ? (4 | 0 << 3 | 3 << 6 | 4 << 9 | 1 << 12) : (pa_f == 3 ? (4 | 1 << 3 | 4 << 6 | 5 << 9 | 2 << 12) : (4 | 2 << 3 | 5 << 6 | 3 << 9 | 0 << 12))));
+  constexpr unsigned long long PPK = (unsigned long long)(3 | 0 << 3 | 1 << 6 | 2 << 9 | 0 << 12) | (unsigned long long)(3 | 3 << 3 | 5 << 6 | 4 << 9 | 3 << 12) << 15 |
+                                     (unsigned long long)(4 | 0 << 3 | 3 << 6 | 4 << 9 | 1 << 12) << 30 | (unsigned long long)(4 | 1 << 3 | 4 << 6 | 5 << 9 | 2 << 12) << 45;
+  const int pp_pk = pa_f == 4 ? (4 | 2 << 3 | 5 << 6 | 3 << 9 | 0 << 12) : (int)((PPK >> (15 * (pa_f & 3))) & 0x7FFFull);      // (a shift, not five-way selects: those became branches)
   const int pcnt = pp_pk & 7, fcnt = pf_pk & 7;
   const int rcnt = ref_a ? pcnt : fcnt, icnt = ref_a ? fcnt : pcnt;
   ODK_SYNC();
@@ -563,7 +566,8 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
       const int v = from_prism ? (pp_pk >> (3 + 3 * k)) & 7 : (pf_pk >> (3 + 5 * k)) & 31;
       const float* src = (from_prism ? PV : B.V) + 3 * v;
       float* dst = (isr ? S.RP : S.IP) + 3 * k;
-      dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+      const float c0 = src[0], c1 = src[1], c2 = src[2];      // (all three reads, then the writes: element by element each write waited for its own read)
+      dst[0] = c0; dst[1] = c1; dst[2] = c2;
     }
   }
   ODK_SYNC();
@@ -574,8 +578,12 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
     int ia = pair >> 22;
     ia = ia < 9 ? ia : 0;
     const int evv = pair & 0xFFFF;
-    const int va = ia == 2 || ia == 4 ? 3 : (ia == 6 ? 4 : (ia == 1 || ia == 5 ? 1 : (ia == 7 ? 2 : 0)));   // PRISM_EDGE[ia][0]
-    const int vb = ia == 0 ? 1 : (ia == 1 || ia == 8 ? 2 : (ia == 3 ? 3 : (ia == 4 || ia == 5 ? 4 : 5)));       // PRISM_EDGE[ia][1]
+    // PRISM_EDGE[ia][0] / [1] from packed tables, three bits per edge (nested selects became branches)
+    constexpr unsigned VA = 0u | 1u << 3 | 3u << 6 | 0u << 9 | 3u << 12 | 1u << 15 | 4u << 18 | 2u << 21 | 0u << 24;
+    constexpr unsigned VB = 1u | 2u << 3 | 5u << 6 | 3u << 9 | 4u << 12 | 4u << 15 | 5u << 18 | 5u << 21 | 2u << 24;
+    static_assert(PRISM_EDGE[0][0] == 0 && PRISM_EDGE[2][0] == 3 && PRISM_EDGE[6][0] == 4 && PRISM_EDGE[7][0] == 2 && PRISM_EDGE[8][0] == 0 && PRISM_EDGE[0][1] == 1 &&
+                  PRISM_EDGE[2][1] == 5 && PRISM_EDGE[3][1] == 3 && PRISM_EDGE[5][1] == 4 && PRISM_EDGE[8][1] == 2, "packed prism edge vertices");
+    const int va = (int)((VA >> (3 * ia)) & 7u), vb = (int)((VB >> (3 * ia)) & 7u);
     edge_contact_row(PV + 3 * va, PV + 3 * vb, B.V + 3 * (evv & 255), B.V + 3 * ((evv >> 8) & 255), sep_e, eax, S, j, act);
   }
   ODK_SYNC();
@@ -589,7 +597,8 @@ __device__ __forceinline__ void merge_top4_row(float* TOP, const float* NEW, int
   for (int k = 0; k < 8; k++) mine[k] = src[k];
   for (int k = 0; k < 8; k++) { const float* e = k < 4 ? TOP + 8 * k : NEW + 8 * (k - 4); dist[k] = e[0]; cidx[k] = e[7]; }
   int rank = 0;
-  for (int k = 0; k < 8; k++) rank += (dist[k] < mine[0] || (dist[k] == mine[0] && cidx[k] < mine[7])) ? 1 : 0;
+  // (bitwise, not short-circuit: `||` / `&&` here were eight branches per merge)
+  for (int k = 0; k < 8; k++) rank += (int)((dist[k] < mine[0]) | ((dist[k] == mine[0]) & (cidx[k] < mine[7])));
   ODK_SYNC();
   if (act && j < 8 && rank < 4) { float* o = TOP + 8 * rank; for (int k = 0; k < 8; k++) o[k] = mine[k]; }
   ODK_SYNC();

@@ -1118,7 +1118,9 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   // prism p = 2 (ri ncw + ci) + tri of this row's window: grid corners of its top triangle (counter-clockwise seen from above)
   auto corners = [&](int p, int ncw, int* cc, int* rr) {
     const int q = p >> 1, tri = p & 1;
-    const int ri = ncw == 1 ? q : (ncw == 2 ? (q >> 1) : (q >= 6 ? 2 : (q >= 3 ? 1 : 0)));
+    // q / ncw for q <= 8, ncw = 1 / 2 / 3 as a multiply and a shift (q 32 >> 5, q 16 >> 5, q 11 >> 5): the nested selects this replaces were compiled into
+    // four basic blocks with exec-mask bookkeeping, once per pair-loop iteration and once per cull pass (round 6)
+    const int ri = (q * (ncw == 1 ? 32 : (ncw == 2 ? 16 : 11))) >> 5;
     const int c = q - ri * ncw, r = ri;   // relative to (cmin, rmin)
     cc[0] = tri ? c + 1 : c; rr[0] = tri ? r + 1 : r; cc[1] = tri ? c : c + 1; rr[1] = tri ? r + 1 : r; cc[2] = tri ? c + 1 : c; rr[2] = tri ? r : r + 1;
   };
@@ -1394,7 +1396,8 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     if (lane == 0) L[S::O_SCR + S::S_PROF2 + 7] += (float)(clock64() - _hp);   // (of `select + prism`: up to the end of the row switch)
 #endif
     // the open entry of rank my_q of that foot's (sorted) list
-    unsigned wsel = my_tg == 0 ? open_t[0] : (my_tg == 1 ? open_t[1] : (my_tg == 2 ? open_t[2] : open_t[3]));
+    unsigned wsel = open_t[3];      // (one select per statement: the nested form became branches)
+    wsel = my_tg == 2 ? open_t[2] : wsel; wsel = my_tg == 1 ? open_t[1] : wsel; wsel = my_tg == 0 ? open_t[0] : wsel;
     for (int q = 0; q < 3; q++) wsel = q < my_q ? wsel & (wsel - 1u) : wsel;
     const bool act = my_on && wsel != 0u;
     const int kk = act ? __ffs((int)wsel) - 1 : 0;
@@ -1654,7 +1657,9 @@ __device__ __noinline__ void hfield_prim_floor(float* L, const DevModel* __restr
     Prism P;
     {
       const int pp = valid ? p : 0, q = pp >> 1, tri = pp & 1;
-      const int ri = ncw == 1 ? q : (ncw == 2 ? (q >> 1) : (q >= 6 ? 2 : (q >= 3 ? 1 : 0)));
+      // q / ncw for q <= 8, ncw = 1 / 2 / 3 as a multiply and a shift (q 32 >> 5, q 16 >> 5, q 11 >> 5): the nested selects this replaces were compiled into
+    // four basic blocks with exec-mask bookkeeping, once per pair-loop iteration and once per cull pass (round 6)
+    const int ri = (q * (ncw == 1 ? 32 : (ncw == 2 ? 16 : 11))) >> 5;
       const int c = q - ri * ncw;
       const int cc[3] = {tri ? c + 1 : c, tri ? c : c + 1, tri ? c + 1 : c}, rr[3] = {tri ? ri + 1 : ri, tri ? ri + 1 : ri, tri ? ri : ri + 1};
       for (int k = 0; k < 3; k++) { P.x[k] = (float)cc[k] * dx; P.y[k] = (float)rr[k] * dy; P.z[k] = valid ? hf[(rmin + rr[k]) * nc + cmin + cc[k]] * sz : 0.0f; }
