@@ -2473,25 +2473,24 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
             for (int j = 0; j < 3; j++) AA[3 * i + j] = fR[f][3 * i] * m->foot_obb_axes[f][j] + fR[f][3 * i + 1] * m->foot_obb_axes[f][3 + j] + fR[f][3 * i + 2] * m->foot_obb_axes[f][6 + j];
         }
         for (int k = 0; k < 3; k++) tt[k] = c2[k] - c1[k];
-        // axis of this lane: 0-2 faces of box 1, 3-5 faces of box 2, 6-14 edge x edge
-        const int ia = lane < 3 ? lane : (lane < 6 ? 0 : (lane - 6) / 3), ib = lane < 3 ? 0 : (lane < 6 ? lane - 3 : (lane - 6) % 3);
+        // axis of this lane: 0-2 faces of box 1, 3-5 faces of box 2, 6-14 edge x edge.  Written without nested selects / if-else chains: those were
+        // compiled into basic blocks with exec-mask bookkeeping (seven if / else pairs in this block alone: round 6)
+        constexpr unsigned IA = 0u | 1u << 2 | 2u << 4 | 0u << 6 | 0u << 8 | 0u << 10 | 0u << 12 | 0u << 14 | 0u << 16 | 1u << 18 | 1u << 20 | 1u << 22 | 2u << 24 | 2u << 26 | 2u << 28;
+        constexpr unsigned IB = 0u | 0u << 2 | 0u << 4 | 0u << 6 | 1u << 8 | 2u << 10 | 0u << 12 | 1u << 14 | 2u << 16 | 0u << 18 | 1u << 20 | 2u << 22 | 0u << 24 | 1u << 26 | 2u << 28;
+        const int ia = (int)((IA >> (2 * lane)) & 3u), ib = (int)((IB >> (2 * lane)) & 3u);
         float e1[3], e2[3], ax[3];
   #pragma unroll
         for (int k = 0; k < 3; k++) {
-          e1[k] = ia == 0 ? A1[3 * k] : (ia == 1 ? A1[3 * k + 1] : A1[3 * k + 2]);
-          e2[k] = ib == 0 ? A2[3 * k] : (ib == 1 ? A2[3 * k + 1] : A2[3 * k + 2]);
+          e1[k] = A1[3 * k + 2]; e1[k] = ia == 1 ? A1[3 * k + 1] : e1[k]; e1[k] = ia == 0 ? A1[3 * k] : e1[k];
+          e2[k] = A2[3 * k + 2]; e2[k] = ib == 1 ? A2[3 * k + 1] : e2[k]; e2[k] = ib == 0 ? A2[3 * k] : e2[k];
         }
-        bool ok = true;
-        if (lane < 3) { ax[0] = e1[0]; ax[1] = e1[1]; ax[2] = e1[2]; }
-        else if (lane < 6) { ax[0] = e2[0]; ax[1] = e2[1]; ax[2] = e2[2]; }
-        else {
-          cross3(ax, e1, e2);
-          const float n = sqrtf(dot3(ax, ax));
-          ok = n >= 1e-6f;
-          const float inv = ok ? 1.0f / n : 0.0f;
-          ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
-        }
-        if (ok) {
+        cross3(ax, e1, e2);
+        const float n = sqrtf(dot3(ax, ax));
+        const bool edge = lane >= 6, ok = !edge | (n >= 1e-6f);
+        const float inv = n >= 1e-6f ? 1.0f / n : 0.0f;
+  #pragma unroll
+        for (int k = 0; k < 3; k++) { ax[k] *= inv; ax[k] = lane < 6 ? e2[k] : ax[k]; ax[k] = lane < 3 ? e1[k] : ax[k]; }
+        {
           float r1 = 0, r2 = 0;
   #pragma unroll
           for (int k = 0; k < 3; k++) {
@@ -2499,7 +2498,8 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
             r1 += m->foot_obb_half[0][k] * fabsf(dot3(ax, b1));
             r2 += m->foot_obb_half[1][k] * fabsf(dot3(ax, b2));
           }
-          sep = fabsf(dot3(tt, ax)) - r1 - r2;
+          const float sv = fabsf(dot3(tt, ax)) - r1 - r2;
+          sep = ok ? sv : sep;
         }
       }
       boxsep = gmax<G>(sep);   // (inside the wave-uniform branch: cross-lane ops stay in uniform control flow)
