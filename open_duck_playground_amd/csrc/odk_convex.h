@@ -237,9 +237,10 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
     const float* src = subj ? S.IP : S.RP;
     float a[3], b[3];
     ld3(a, src + 3 * (er == 0 ? cntp - 1 : er - 1)); ld3(b, src + 3 * (er < cntp ? er : 0));
-    if (!subj) {   // reference edge: projected on the incident plane along the reference normal
+    if (PULL || !subj) {   // reference edge: projected on the incident plane along the reference normal (PULL: every lane walks through it with a zero step for the
+                           // incident edges -- some lane of the wave always takes the branch, and as an if / else it cost its exec-mask bookkeeping on top)
       const float d = dot3(S.IP, n_inc), den = dot3(n_ref, n_inc), dinv = __builtin_amdgcn_rcpf(den + (den == 0.0f ? 1e-6f : 0.0f));
-      const float ta = (d - dot3(a, n_inc)) * dinv, tb = (d - dot3(b, n_inc)) * dinv;
+      const float ta = subj ? 0.0f : (d - dot3(a, n_inc)) * dinv, tb = subj ? 0.0f : (d - dot3(b, n_inc)) * dinv;
       for (int k = 0; k < 3; k++) { a[k] += ta * n_ref[k]; b[k] += tb * n_ref[k]; }
     }
     const float qn[3] = {subj ? n_ref[0] : n_inc[0], subj ? n_ref[1] : n_inc[1], subj ? n_ref[2] : n_inc[2]};
@@ -257,7 +258,8 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
   if constexpr (PULL) {
     // (four predicated blocks of seven LDS writes each -> four lane fetches and one block: round 6)
     const float pen = -off;
-    const int src = j == 0 ? idx[0] : (j == 1 ? idx[1] : (j == 2 ? idx[2] : idx[3]));
+    int src = idx[3];      // (one select per statement: nested, they become branches)
+    src = j == 2 ? idx[2] : src; src = j == 1 ? idx[1] : src; src = j == 0 ? idx[0] : src;
     const float w0 = row_get(mask ? -pen : 1.0f, src);
     float w[3];
 #pragma unroll
