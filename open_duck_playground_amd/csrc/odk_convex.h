@@ -225,7 +225,7 @@ struct RowScratch { float* RP; float* IP; float* NEW; float* PW; float* VV; };  
 // the reference normal, clipped by the incident side planes) x 2 -- projected on the reference plane, four of them by
 // _manifold_points, written to S.NEW with the normal sg * n_ref (skip: an edge contact replaces them).
 template <bool PULL = false>      // PULL: lanes 0 .. 3 fetch the four chosen candidates from their lanes and write them in ONE block (the height-field loop)
-__device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int icnt, const float* n_ref, const float* n_inc, float sg, bool skip, int j, bool act) {
+__device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int icnt, const float* n_ref, const float* n_inc, float sg, bool skip, int j, bool act, float cidx0 = 0.0f) {
   const int e = j >> 1, which = j & 1, np = 2 * (icnt + rcnt);
   const bool cand = j < np;
   float pt[3] = {0.0f, 0.0f, 0.0f};
@@ -268,6 +268,7 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
       float* o = S.NEW + 8 * j;
       o[0] = w0;
       for (int t = 0; t < 3; t++) { o[1 + t] = w[t]; o[4 + t] = sg * n_ref[t]; }
+      o[7] = cidx0 + (float)j;      // candidate index in MJX's list: prism-major, then the pair's four slots
     }
   } else {
 #pragma unroll
@@ -283,20 +284,33 @@ __device__ __forceinline__ void manifold_row(const RowScratch& S, int rcnt, int 
 }
 
 // ONE contact at the closest points of the edges (p1, q1) / (p2, q2) (Ericson 5.1.9), depth sep, normal ax; slots 1..3 inactive
-__device__ __forceinline__ void edge_contact_row(const float* p1, const float* q1, const float* p2, const float* q2, float sep, const float* ax, const RowScratch& S, int j, bool act) {
+template <bool REGS = false>      // REGS (the height-field loop): the end points in registers before the writes, the clamping cases as selects
+__device__ __forceinline__ void edge_contact_row(const float* p1_, const float* q1, const float* p2_, const float* q2, float sep, const float* ax, const RowScratch& S, int j, bool act, float cidx0 = 0.0f) {
   float d1[3], d2[3], r[3];
+  // (REGS: read once -- through the pointers every use after a write to S.NEW is a new LDS round trip, the writes may alias them for all the compiler knows)
+  float p1r[3], p2r[3];
+  if constexpr (REGS) { ld3(p1r, p1_); ld3(p2r, p2_); }
+  const float* p1 = REGS ? p1r : p1_; const float* p2 = REGS ? p2r : p2_;
   sub3(d1, q1, p1); sub3(d2, q2, p2); sub3(r, p1, p2);
   const float a = dot3(d1, d1), ee = dot3(d2, d2), f = dot3(d2, r), c = dot3(d1, r), b = dot3(d1, d2), den = a * ee - b * b;
   const float ainv = __builtin_amdgcn_rcpf(a > 1e-30f ? a : 1.0f), einv = __builtin_amdgcn_rcpf(ee > 1e-30f ? ee : 1.0f);
   float s = den > 1e-30f ? (b * f - c * ee) * __builtin_amdgcn_rcpf(den) : 0.0f;
   s = fminf(fmaxf(s, 0.0f), 1.0f);
   float t = (b * s + f) * einv;
-  if (t < 0.0f) { t = 0.0f; s = fminf(fmaxf(-c * ainv, 0.0f), 1.0f); }
-  else if (t > 1.0f) { t = 1.0f; s = fminf(fmaxf((b - c) * ainv, 0.0f), 1.0f); }
+  if constexpr (REGS) {
+    const bool lo = t < 0.0f, hi = t > 1.0f;
+    const float s_lo = fminf(fmaxf(-c * ainv, 0.0f), 1.0f), s_hi = fminf(fmaxf((b - c) * ainv, 0.0f), 1.0f);
+    s = hi ? s_hi : s; s = lo ? s_lo : s;
+    t = hi ? 1.0f : t; t = lo ? 0.0f : t;
+  } else {
+    if (t < 0.0f) { t = 0.0f; s = fminf(fmaxf(-c * ainv, 0.0f), 1.0f); }
+    else if (t > 1.0f) { t = 1.0f; s = fminf(fmaxf((b - c) * ainv, 0.0f), 1.0f); }
+  }
   if (act && j < 4) {
     float* o = S.NEW + 8 * j;
     o[0] = j == 0 ? sep : 1.0f;
     for (int k = 0; k < 3; k++) { o[1 + k] = 0.5f * ((p1[k] + s * d1[k]) + (p2[k] + t * d2[k])); o[4 + k] = ax[k]; }
+    if constexpr (REGS) o[7] = cidx0 + (float)j;
   }
 }
 
@@ -381,7 +395,7 @@ template <int NFS> __device__ __forceinline__ void face_regs_from_rec(FaceRegs<N
 // faces / edges of this lane in FB / RB); PV: the prism's vertices in LDS for the polygon fetch
 template <int NFS, int NSLOT>
 __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, const float* PV, const Cvx& B, const FaceRegs<NFS>& FB, const EdgeRegs<NSLOT>& RB,
-                                              float sep_a, int face_a, const RowScratch& S, int j, bool act, int knock   // knock: 0 outside the timing experiment (ODK_HF_KNOCK)
+                                              float sep_a, int face_a, const RowScratch& S, int j, bool act, float cidx0, int knock   // cidx0: candidate index of the pair's first contact; knock: 0 outside the timing experiment (ODK_HF_KNOCK)
 #ifdef ODK_PROFILE
                                               , float* prof, long long& tp
 #endif
@@ -574,7 +588,7 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
   }
   ODK_SYNC();
   SAT_PROF(4);
-  if (!(knock & 32)) HF_REP(14) { HF_TOUCH(n_ref[0]); manifold_row<true>(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act); }
+  if (!(knock & 32)) HF_REP(14) { HF_TOUCH(n_ref[0]); manifold_row<true>(S, rcnt, icnt, n_ref, n_inc, ref_a ? 1.0f : -1.0f, is_edge, j, act, cidx0); }
   SAT_PROF(5);
   if (is_edge) {   // row-uniform
     int ia = pair >> 22;
@@ -586,7 +600,7 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
     static_assert(PRISM_EDGE[0][0] == 0 && PRISM_EDGE[2][0] == 3 && PRISM_EDGE[6][0] == 4 && PRISM_EDGE[7][0] == 2 && PRISM_EDGE[8][0] == 0 && PRISM_EDGE[0][1] == 1 &&
                   PRISM_EDGE[2][1] == 5 && PRISM_EDGE[3][1] == 3 && PRISM_EDGE[5][1] == 4 && PRISM_EDGE[8][1] == 2, "packed prism edge vertices");
     const int va = (int)((VA >> (3 * ia)) & 7u), vb = (int)((VB >> (3 * ia)) & 7u);
-    edge_contact_row(PV + 3 * va, PV + 3 * vb, B.V + 3 * (evv & 255), B.V + 3 * ((evv >> 8) & 255), sep_e, eax, S, j, act);
+    edge_contact_row<true>(PV + 3 * va, PV + 3 * vb, B.V + 3 * (evv & 255), B.V + 3 * ((evv >> 8) & 255), sep_e, eax, S, j, act, cidx0);
   }
   ODK_SYNC();
 }

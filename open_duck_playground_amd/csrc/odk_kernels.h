@@ -1052,6 +1052,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   float* LIST = RL; float* TOP = RL + 108; float* NEW = RL + 140;      // [18][6] | [4][8] | [4][8]
   const RowScratch RSS = {RS + 18, RS + 30, NEW, RS + 42, RS + 58};    // RP [4][3], IP [4][3], the row's list of passing edge pairs [64] (PW | VV)
   const float* Rh = m->floor_mat; const float ph[3] = {m->plane_pos[0], m->plane_pos[1], m->plane_pos[2]};
+  const int nvt = m->foot_nvert[f], nfc = m->foot_npoly[f];
   // ---- the hull in the height field's frame: v_h = Rh^T (P + R v - ph)
   float Rw[9], Pw[3], cl[3];
   {
@@ -1065,7 +1066,6 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
       Pw[a] = Rh[a] * P[0] + Rh[3 + a] * P[1] + Rh[6 + a] * P[2];
     }
   }
-  const int nvt = m->foot_nvert[f], nfc = m->foot_npoly[f];
   for (int k = 0; k < 3; k++) cl[k] = Pw[k] + Rw[3 * k] * m->foot_obb_center[f][0] + Rw[3 * k + 1] * m->foot_obb_center[f][1] + Rw[3 * k + 2] * m->foot_obb_center[f][2];
   // ---- cells under the bounding sphere
   const int nc = m->hfield_ncol, nr = m->hfield_nrow;
@@ -1088,25 +1088,33 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   // a millimetre, and float32 coordinates in the height field's own frame would carry ~1e-6 m of rounding each.
   const float org[2] = {-sx + (float)cmin * dx, -sy + (float)rmin * dy};
   Pw[0] -= org[0]; Pw[1] -= org[1];
+  // this lane's share of the hull in the body frame (vertices / faces j and j + 16; past the last: vertex 0 / face 0), all of it asked for at once
+  float hb_v[2][3], hb_n[2][3], hb_off[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int vs = j + 16 * u < nvt ? j + 16 * u : 0, ts = j + 16 * u < nfc ? j + 16 * u : 0;
+    for (int k = 0; k < 3; k++) { hb_v[u][k] = m->foot_vert[f][vs][k]; hb_n[u][k] = m->foot_fnorm[f][ts][k]; }
+    hb_off[u] = m->foot_foff[f][ts];
+  }
   HF_REP(8) {
   HF_TOUCH(Pw[0]);
   // (the cull pass's loops run unmasked over 18 vertices / the faces in fives: the entries past a hull's last are copies of vertex 0 -- no change to
   // a minimum -- and face records that separate nothing)
-  for (int v = j; v < 18; v += 16) {
-    const int vs = v < nvt ? v : 0;
-    const float vb[3] = {m->foot_vert[f][vs][0], m->foot_vert[f][vs][1], m->foot_vert[f][vs][2]};
-    for (int k = 0; k < 3; k++) FV[3 * v + k] = Pw[k] + Rw[3 * k] * vb[0] + Rw[3 * k + 1] * vb[1] + Rw[3 * k + 2] * vb[2];
-  }
-  for (int t = j; t < HULL_MAXF; t += 16) {
-    if (t < nfc) {
-      const float nb[3] = {m->foot_fnorm[f][t][0], m->foot_fnorm[f][t][1], m->foot_fnorm[f][t][2]};
-      float nw[3];
-      for (int k = 0; k < 3; k++) { nw[k] = Rw[3 * k] * nb[0] + Rw[3 * k + 1] * nb[1] + Rw[3 * k + 2] * nb[2]; FN[3 * t + k] = nw[k]; }
-      // the face's plane offset in the window frame: n . (P + R v) = n_b . v_b + n . P
-      *reinterpret_cast<float4*>(FN4 + 4 * t) = make_float4(nw[0], nw[1], nw[2], m->foot_foff[f][t] + dot3(nw, Pw));
-    } else {
-      *reinterpret_cast<float4*>(FN4 + 4 * t) = make_float4(0.0f, 0.0f, 0.0f, 3.0e38f);
+  // A lane's two vertices (j, j + 16) and two faces; their body-frame data were read at the top of the routine (hb_*), all at once: as two rolled loops each
+  // element's reads waited for their own round trip to the L2 -- eight exposed latencies per foot and substep (round 6).
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int v = j + 16 * u, t = j + 16 * u;
+    float vw[3], nw[3];
+    for (int k = 0; k < 3; k++) {
+      vw[k] = Pw[k] + Rw[3 * k] * hb_v[u][0] + Rw[3 * k + 1] * hb_v[u][1] + Rw[3 * k + 2] * hb_v[u][2];
+      nw[k] = Rw[3 * k] * hb_n[u][0] + Rw[3 * k + 1] * hb_n[u][1] + Rw[3 * k + 2] * hb_n[u][2];
     }
+    // the face's plane offset in the window frame: n . (P + R v) = n_b . v_b + n . P; past the hull's last face: a record that separates nothing
+    const bool real = t < nfc;
+    const float4 rec = make_float4(real ? nw[0] : 0.0f, real ? nw[1] : 0.0f, real ? nw[2] : 0.0f, real ? hb_off[u] + dot3(nw, Pw) : 3.0e38f);
+    if (u == 0 || v < 18) { FV[3 * v] = vw[0]; FV[3 * v + 1] = vw[1]; FV[3 * v + 2] = vw[2]; }
+    if (u == 0 || t < HULL_MAXF) { FN[3 * t] = nw[0]; FN[3 * t + 1] = nw[1]; FN[3 * t + 2] = nw[2]; *reinterpret_cast<float4*>(FN4 + 4 * t) = rec; }      // (normals past the last face are never read)
   }
   }
   float fc[3];
@@ -1420,11 +1428,10 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     float* prof = lane == 0 ? L + S::O_SCR + S::S_PROF2 + 8 : nullptr;
     long long tp = clock64();
     if (prof) { prof[0] += (float)(tp - _hp); }
-    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act, 0, prof, tp);
+    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act, (float)(4 * p), 0, prof, tp);
 #else
-    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act, knock);
+    sat_prism_row<2, 3>(P, pc, PV, B, FB, RB, sep_a, face_a, RSS, j, act, (float)(4 * p), knock);
 #endif
-    if (act && j < 4) NEW[8 * j + 7] = (float)(4 * p + j);   // candidate index in MJX's list: prism-major, then the pair's four slots
     // opt-in (odk_env_config.hfield_up_normals_only; oracle hfield_mode 3; default off): a pair's contacts count only when its
     // normal points up -- one wave-uniform flag from the batch's model, nothing on the default path but the test
     if (up_only) {
