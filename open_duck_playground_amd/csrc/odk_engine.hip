@@ -1391,24 +1391,6 @@ extern "C" int odk_model_load(const void* blob, uint64_t len, odk_model** out) {
       }
     }
   }
-  {   // DevModel::hf_assign: a row works its own foot while that has open entries; an idle row goes where most are left (lowest foot among equals)
-    for (int idx = 0; idx < 625; idx++) {
-      const int c[4] = {idx % 5, (idx / 5) % 5, (idx / 25) % 5, idx / 125};
-      int asg[4] = {0, 0, 0, 0}, tgt[4], rnk[4] = {0, 0, 0, 0}, on[4] = {0, 0, 0, 0};
-      for (int r = 0; r < 4; r++) { tgt[r] = r; if (c[r] > 0) { asg[r] = 1; on[r] = 1; } }
-      for (int r = 0; r < 4; r++) {
-        if (on[r]) continue;
-        int bt = -1, bl = 0;
-        for (int t = 0; t < 4; t++) if (c[t] - asg[t] > bl) { bl = c[t] - asg[t]; bt = t; }
-        if (bt >= 0) { tgt[r] = bt; rnk[r] = asg[bt]; asg[bt]++; on[r] = 1; }
-      }
-      int mq = 1;
-      for (int t = 0; t < 4; t++) mq = asg[t] > mq ? asg[t] : mq;
-      unsigned w = 0;
-      for (int r = 0; r < 4; r++) w |= (unsigned)tgt[r] << (2 * r) | (unsigned)rnk[r] << (8 + 2 * r) | (unsigned)on[r] << (16 + r);
-      m.hf_assign[idx] = (int)(w | (unsigned)(mq - 1) << 20);
-    }
-  }
   for (int f = 0; f < 2; f++) m.foot_sphere_r[f] = sqrtf(m.foot_obb_half[f][0] * m.foot_obb_half[f][0] + m.foot_obb_half[f][1] * m.foot_obb_half[f][1] + m.foot_obb_half[f][2] * m.foot_obb_half[f][2]);
   {   // a height-field prism's topology: the kernels' compile-time tables (odk_model.h) against this file's table builder
     const double pv[6][3] = {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {0, 0, 0}, {1, 0, 0}, {0, 1, 0}};

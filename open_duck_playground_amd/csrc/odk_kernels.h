@@ -1005,7 +1005,8 @@ __device__ __noinline__ void foot_foot_sat(float* L, const DevModel* __restrict_
 // registers over the whole loop.  LDS: hull vertices / face normals in the height field's frame in cfrc | crb; per row the prism's
 // vertices + the two polygons of the face contact in BUF6 / BUF6B; per row prism list, running best four, current four in
 // D | aref | jar | jv; at the end the eight contact frames go to jv ([8][9], read by the constraint-row phase).
-// index into DevModel::hf_assign from the four rows' open-entry counts (one byte each), each capped at four
+__constant__ HfAssign ODK_HF_ASSIGN = make_hf_assign();
+// index into that table from the four rows' open-entry counts (one byte each), each capped at four
 __host__ __device__ __forceinline__ int hf_assign_index(unsigned n_pk) {
   const unsigned c0 = min(n_pk & 255u, 4u), c1 = min((n_pk >> 8) & 255u, 4u), c2 = min((n_pk >> 16) & 255u, 4u), c3 = min(n_pk >> 24, 4u);
   return (int)(c0 + 5u * (c1 + 5u * (c2 + 5u * c3)));
@@ -1374,9 +1375,9 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     }
     if (n_pk == 0u || HF_KNOCK(2)) break;
     // assignment: a row works its own foot while that has open entries, an idle row goes where most are left.  The rule is a function of the four
-    // counts capped at four (a foot can use its own row and three helpers): ONE scalar load from a 625-entry table built at model load
-    // (DevModel::hf_assign; the ~300 dependent scalar instructions that derived it in place were the largest single block of the loop's scalar work: round 6)
-    const unsigned aw = (unsigned)m->hf_assign[hf_assign_index(n_pk)];
+    // counts capped at four (a foot can use its own row and three helpers): ONE scalar load from a 625-entry table in constant memory
+    // (odk_model.h make_hf_assign; the ~300 dependent scalar instructions that derived it in place were the largest single block of the loop's scalar work: round 6)
+    const unsigned aw = (unsigned)ODK_HF_ASSIGN.v[hf_assign_index(n_pk)];
     const unsigned maxq = (aw >> 20) & 3u;
     const int my_tg = (int)((aw >> (2 * r_own)) & 3u), my_q = (int)((aw >> (8 + 2 * r_own)) & 3u);
     const bool my_on = (aw >> (16 + r_own)) & 1u;

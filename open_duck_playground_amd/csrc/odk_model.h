@@ -168,10 +168,6 @@ struct DevModel {
   int cone;      // <option cone>: 0 pyramidal, 1 elliptic (shapes with S::ELL; odk_kernels.h "elliptic cones")
   int neq, eq_dof1[EQ_MAX], eq_dof2[EQ_MAX], eq_qadr1[EQ_MAX], eq_qadr2[EQ_MAX], eq_key[EQ_MAX], dof_eqrow[MAXV];
   float eq_poly[EQ_MAX][5], eq_imp[EQ_MAX][9], eq_invweight[EQ_MAX];
-  // height-field pair loop: the rows' assignment to feet as a function of the four open-entry counts capped at four (odk_kernels.h hf_assign_index);
-  // at the END of the record: the plane-floor kernels' loads keep the offsets -- and so the instruction streams -- they had:
-  // foot of row r (2 bits each) | rank among the rows on that foot << 8 (2 bits each) | row has work << 16 | (most rows on one foot - 1) << 20
-  int hf_assign[625];
 };
 
 // Topology of a height-field prism (vertices 0..2 = top triangle counter-clockwise seen from above, 3..5 below them; faces: top,
@@ -180,6 +176,32 @@ struct DevModel {
 // build_convex_tables -- the routine that prepares the foot hulls -- makes exactly these tables of a prism's eight triangles.
 constexpr int PRISM_EDGE[9][4] = {{0, 1, 0, 2}, {1, 2, 0, 3}, {3, 5, 1, 4}, {0, 3, 2, 4}, {3, 4, 2, 1}, {1, 4, 3, 2}, {4, 5, 3, 1}, {2, 5, 4, 3}, {0, 2, 4, 0}};
 constexpr int PRISM_POLY[5][5] = {{3, 0, 1, 2, 0}, {3, 3, 5, 4, 3}, {4, 0, 3, 4, 1}, {4, 1, 4, 5, 2}, {4, 2, 5, 3, 0}};
+
+// Height-field pair loop: the assignment of the wave's four rows to feet as a function of the four rows' open-entry counts, each capped at four (index = c0 + 5 (c1 + 5 (c2 + 5 c3)):
+// odk_kernels.h hf_assign_index).  A row works its own foot while that has open entries; an idle row goes where most are left (lowest foot among equals).  Entry: foot of row r
+// (2 bits each) | rank among the rows on that foot << 8 (2 bits each) | row has work << 16 | (most rows on one foot - 1) << 20.  Built at COMPILE time and kept in constant memory:
+// the kernel's lookup is one scalar load (as a field of DevModel it was a vector load from global memory per iteration: round 6).
+struct HfAssign { int v[625]; };
+constexpr HfAssign make_hf_assign() {
+  HfAssign T{};
+  for (int idx = 0; idx < 625; idx++) {
+    const int c[4] = {idx % 5, (idx / 5) % 5, (idx / 25) % 5, idx / 125};
+    int asg[4] = {0, 0, 0, 0}, tgt[4] = {0, 1, 2, 3}, rnk[4] = {0, 0, 0, 0}, on[4] = {0, 0, 0, 0};
+    for (int r = 0; r < 4; r++) if (c[r] > 0) { asg[r] = 1; on[r] = 1; }
+    for (int r = 0; r < 4; r++) {
+      if (on[r]) continue;
+      int bt = -1, bl = 0;
+      for (int t = 0; t < 4; t++) if (c[t] - asg[t] > bl) { bl = c[t] - asg[t]; bt = t; }
+      if (bt >= 0) { tgt[r] = bt; rnk[r] = asg[bt]; asg[bt]++; on[r] = 1; }
+    }
+    int mq = 1;
+    for (int t = 0; t < 4; t++) mq = asg[t] > mq ? asg[t] : mq;
+    unsigned w = 0;
+    for (int r = 0; r < 4; r++) w |= (unsigned)tgt[r] << (2 * r) | (unsigned)rnk[r] << (8 + 2 * r) | (unsigned)on[r] << (16 + r);
+    T.v[idx] = (int)(w | (unsigned)(mq - 1) << 20);
+  }
+  return T;
+}
 
 // reference-motion table header (poly_reference_motion.py)
 struct DevPRM {
