@@ -1344,7 +1344,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   // 32 (t & 1) of word t >> 1), and what every row took in the iteration before (read from the rows' registers by v_readlane) -- no exchange through
   // LDS, no barrier, nothing of it on the vector pipe.
   unsigned long long taken01 = 0ull, taken23 = 0ull;
-  int last_pk = 0xFFFF;       // row-uniform: the entry this row took in the iteration before (foot << 8 | entry), 0xFFFF: none
+  int last_pk = 31;           // row-uniform: the entry this row took in the iteration before (foot << 8 | entry); none: entry 31 of foot 0, which no list has
   const bool up_only = HF_FILTER(m) == 3;   // (read once: every compiler barrier in the loop would fetch it again)
 #ifdef ODK_PROFILE
   _hp = clock64();   // (slot 2 counts the passing edge pairs of lane 0's row: odk_convex.h)
@@ -1360,8 +1360,8 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
         // ballot holds all four rows' bits), less the entries taken (by any row) in the iterations before
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const unsigned pk = (unsigned)__builtin_amdgcn_readlane(last_pk, 16 * r);
-        const unsigned long long bit = pk == 0xFFFFu ? 0ull : 1ull << ((pk & 31u) + ((pk >> 8) & 1u) * 32u);
+        const unsigned pk = (unsigned)__builtin_amdgcn_readlane(last_pk, 16 * r);      // ("none" = foot 0, entry 31: a bit no list has)
+        const unsigned long long bit = 1ull << ((pk & 31u) + ((pk >> 8) & 1u) * 32u);
         taken01 |= (pk >> 9) ? 0ull : bit; taken23 |= (pk >> 9) ? bit : 0ull;
       }
       const float lim = TOP[8 * 3];
@@ -1410,7 +1410,7 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
     for (int q = 0; q < 3; q++) wsel = q < my_q ? wsel & (wsel - 1u) : wsel;
     const bool act = my_on && wsel != 0u;
     const int kk = act ? __ffs((int)wsel) - 1 : 0;
-    last_pk = act ? (my_tg << 8) | kk : 0xFFFF;
+    last_pk = act ? (my_tg << 8) | kk : 31;
     const float* en = LISTt + 6 * kk;
     const int pf = act ? __float_as_int(en[0]) : 0;
     const int p = pf & 255, face_a = pf >> 8;
