@@ -496,10 +496,8 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
         }
       }
       ODK_SYNC();
-#pragma unroll 1
-      for (int t = 0; t < 4 && __builtin_amdgcn_ballot_w64(wb + 16 * t < total) != 0; t++) {
-        const bool has = wb + 16 * t + j < total;
-        const unsigned en = has ? __float_as_uint(PL[16 * t + j]) : 0u;
+      // one pair of the list: written without branches (a lane without an entry, or with edges closer to parallel than 1e-4 (sine), leaves `best` alone)
+      auto eval_pair = [&](unsigned en, bool has) {
         const int i = en >> 22;
         // prism edge i: vertices from the packed table (va | vb << 3, 6 bits per edge), geometry from the LDS copy
         const unsigned long long PKE = 0ull | (0ull | 1ull << 3) | ((1ull | 2ull << 3) << 6) | ((3ull | 5ull << 3) << 12) | ((0ull | 3ull << 3) << 18) |
@@ -510,14 +508,25 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
         sub3(ea, qa, pa); sub3(eb, qb, pb); sub3(ta, pa, pc);
         cross3(ax, ea, eb);
         const float l2 = dot3(ax, ax);
-        if (has && l2 >= 1e-8f * dot3(ea, ea) * dot3(eb, eb) && l2 > 1e-30f) {   // edges closer to parallel than 1e-4 (sine) give no axis
-          const float inv = rsqrtf(l2);
-          ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
-          if (dot3(ax, ta) < 0.0f) { ax[0] = -ax[0]; ax[1] = -ax[1]; ax[2] = -ax[2]; }
-          sub3(tt, pb, pa);
-          const float sp = dot3(ax, tt);
-          if (sp > best || (sp == best && (int)en < bi)) { best = sp; bi = (int)en; bax[0] = ax[0]; bax[1] = ax[1]; bax[2] = ax[2]; }   // (entries order like (i, hull edge))
-        }
+        const bool ok = has & (l2 >= 1e-8f * dot3(ea, ea) * dot3(eb, eb)) & (l2 > 1e-30f);
+        const float inv = rsqrtf(l2);
+        ax[0] *= inv; ax[1] *= inv; ax[2] *= inv;
+        const bool flip = dot3(ax, ta) < 0.0f;
+        ax[0] = flip ? -ax[0] : ax[0]; ax[1] = flip ? -ax[1] : ax[1]; ax[2] = flip ? -ax[2] : ax[2];
+        sub3(tt, pb, pa);
+        const float sp = dot3(ax, tt);
+        const bool better = ok & ((sp > best) | ((sp == best) & ((int)en < bi)));   // (entries order like (i, hull edge))
+        best = better ? sp : best; bi = better ? (int)en : bi;
+        bax[0] = better ? ax[0] : bax[0]; bax[1] = better ? ax[1] : bax[1]; bax[2] = better ? ax[2] : bax[2];
+      };
+      // two entries per trip (j + 16 t, j + 16 (t + 1)): both entries' LDS reads are in flight together; a row's list holds 17 pairs on average, so the
+      // second one is rarely idle for the whole wave (round 6; one entry per trip before: two dependent LDS round trips per 16 pairs)
+#pragma unroll 1
+      for (int t = 0; t < 4 && __builtin_amdgcn_ballot_w64(wb + 16 * t < total) != 0; t += 2) {
+        const bool has0 = wb + 16 * t + j < total, has1 = wb + 16 * (t + 1) + j < total;
+        const unsigned en0 = has0 ? __float_as_uint(PL[16 * t + j]) : 0u, en1 = has1 ? __float_as_uint(PL[16 * (t + 1) + j]) : 0u;
+        eval_pair(en0, has0);
+        eval_pair(en1, has1);
       }
       ODK_SYNC();
     }
