@@ -1228,12 +1228,12 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
       HF_REP(10) {
       HF_TOUCH(z[0]);
 #pragma unroll 1
-      for (int t0 = 0; t0 < nfu; t0 += 5) {      // (batches of five faces: 20 LDS reads in flight together)
-        float4 fnv[5];
+      for (int t0 = 0; t0 < nfu; t0 += 10) {      // (batches of ten faces: ten 16-byte LDS reads in flight together, three waits per pass)
+        float4 fnv[10];
 #pragma unroll
-        for (int u = 0; u < 5; u++) fnv[u] = *reinterpret_cast<const float4*>(FN4 + 4 * (t0 + u));      // (t0 + u <= 29: records past the hull's last separate nothing)
+        for (int u = 0; u < 10; u++) fnv[u] = *reinterpret_cast<const float4*>(FN4 + 4 * (t0 + u));      // (t0 + u <= 29: records past the hull's last separate nothing)
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
+        for (int u = 0; u < 10; u++) {
           const float n0 = fnv[u].x, n1 = fnv[u].y, n2 = fnv[u].z, dd = fnv[u].w;
           const float h0 = n0 * P.x[0] + n1 * P.y[0], h1 = n0 * P.x[1] + n1 * P.y[1], h2 = n0 * P.x[2] + n1 * P.y[2];
           const float top = fminf(fminf(h0 + n2 * z[0], h1 + n2 * z[1]), h2 + n2 * z[2]), bot = fminf(fminf(h0, h1), h2) + n2 * zb;
