@@ -291,6 +291,7 @@ __device__ __forceinline__ void build_obs_kind(float* L, const DevModel* m, cons
   constexpr RecLay RL = rec_lay(NU);
   constexpr int NOBS = obs_nobs(NU, false), DQV = draw_qvel(NU) - 4;   // (draw i sits at NZ[i - 4])
   const float con0 = contact[0], con1 = contact[1], ph0 = phase[0], ph1 = phase[1];
+  const int adr_gyro = m->adr_gyro, adr_acc = m->adr_accelerometer, adr_lin = m->adr_local_linvel, adr_ang = m->adr_global_angvel;   // (read once, up front)
   // imu history ring (noisy gravity, never emitted: joystick.py:522-530)
   float ng = 0;
   if (lane < 3) ng = SCR[S::S_MISC + 10 + lane] + (2.0f * NZ[10 - 4 + lane] - 1.0f) * lvl * c.noise_gravity;
@@ -307,17 +308,37 @@ __device__ __forceinline__ void build_obs_kind(float* L, const DevModel* m, cons
     __builtin_assume(ks >= it * G && ks < it * G + G);
     if (ks >= NP) continue;
     const int k = !standing ? ks : (ks < 13 + 5 * NU ? ks : (ks < 15 + 5 * NU ? ks + NU : ks + NOBS - (15 + 5 * NU)));
+    // This element's reads of the model's tables, ALL AT ONCE and before the case analysis (indices clamped: a lane outside a case reads a valid slot and drops the
+    // value; cases that cannot occur in this unrolled iteration lose their reads with them).  Inside the cases every read was a global load followed by its own
+    // wait -- ~40 exposed round trips per env step in this routine (round 6).
+    const int q = k - NOBS;   // privileged tail (joystick.py:596-615)
+    const int uA = min(max(k - 13, 0), NU - 1), uV = min(max(k - 13 - NU, 0), NU - 1), uQ = min(max(q - 15, 0), NU - 1), uQV = min(max(q - 15 - NU, 0), NU - 1);
+    const int tF = min(max(q - 18 - 3 * NU, 0), 5);
+    const int A_bq = m->act_backlash_qposadr[uA], A_aq = m->act_qposadr[uA], V_ad = m->act_dofadr[uV];
+    const float A_kc = m->key_ctrl[uA], A_ns = c.qpos_noise_scale[uA];
+    const int Q_bq = m->act_backlash_qposadr[uQ], Q_aq = m->act_qposadr[uQ], QV_ad = m->act_dofadr[uQV], F_adr = m->adr_foot_linvel[tF >= 3 ? 1 : 0];
+    const float Q_kc = m->key_ctrl[uQ];
+    {   // (the optimiser sinks a read into the one case that uses it, which is where it came from: the values a case of THIS unrolled iteration can use are pinned here,
+        // all in flight together; `it` is a constant after unrolling, so the tests below cost nothing)
+      const int k_lo = standing ? 0 : it * G, k_hi = standing ? NP + NOBS : it * G + G;      // (Standing re-maps ks: every case stays possible)
+      auto hits = [&](int lo, int hi) { return k_lo < hi && k_hi > lo; };
+      if (hits(13, 13 + NU)) asm volatile("" :: "v"(A_bq), "v"(A_aq), "v"(A_kc), "v"(A_ns));
+      if (hits(13 + NU, 13 + 2 * NU)) asm volatile("" :: "v"(V_ad));
+      if (hits(NOBS + 15, NOBS + 15 + NU)) asm volatile("" :: "v"(Q_bq), "v"(Q_aq), "v"(Q_kc));
+      if (hits(NOBS + 15 + NU, NOBS + 15 + 2 * NU)) asm volatile("" :: "v"(QV_ad));
+      if (hits(NOBS + 18 + 3 * NU, NOBS + 24 + 3 * NU)) asm volatile("" :: "v"(F_adr));
+    }
     float v = 0;
-    if (k < 3) v = SENS[m->adr_gyro + k] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_gyro;
-    else if (k < 6) v = SENS[m->adr_accelerometer + k - 3] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_accelerometer;
+    if (k < 3) v = SENS[adr_gyro + k] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_gyro;
+    else if (k < 6) v = SENS[adr_acc + k - 3] + (2.0f * NZ[k] - 1.0f) * lvl * c.noise_accelerometer;
     else if (k < 13) v = INFO[RL.CMD + k - 6];
     else if (k < 13 + NU) {
-      const int u = k - 13, bq = m->act_backlash_qposadr[u];
-      const float ja = QPOS[m->act_qposadr[u]] + (bq >= 0 ? QPOS[bq] : 0.0f);
-      v = ja + (2.0f * NZ[13 - 4 + u] - 1.0f) * lvl * c.qpos_noise_scale[u] - m->key_ctrl[u];
+      const int u = k - 13;
+      const float ja = QPOS[A_aq] + (A_bq >= 0 ? QPOS[A_bq] : 0.0f);
+      v = ja + (2.0f * NZ[13 - 4 + u] - 1.0f) * lvl * A_ns - A_kc;
     } else if (k < 13 + 2 * NU) {
       const int u = k - 13 - NU;
-      v = (QVEL[m->act_dofadr[u]] + (2.0f * NZ[DQV + u] - 1.0f) * lvl * c.noise_joint_vel) * c.dof_vel_scale;
+      v = (QVEL[V_ad] + (2.0f * NZ[DQV + u] - 1.0f) * lvl * c.noise_joint_vel) * c.dof_vel_scale;
     } else if (k < 13 + 3 * NU) v = INFO[RL.LAST + k - 13 - 2 * NU];
     else if (k < 13 + 4 * NU) v = INFO[RL.LAST2 + k - 13 - 3 * NU];
     else if (k < 13 + 5 * NU) v = INFO[RL.LAST3 + k - 13 - 4 * NU];
@@ -325,18 +346,17 @@ __device__ __forceinline__ void build_obs_kind(float* L, const DevModel* m, cons
     else if (k < 15 + 6 * NU) v = (k - 13 - 6 * NU) ? con1 : con0;   // (scalars + selects: a runtime index parks the two-element arrays in scratch)
     else if (k < 17 + 6 * NU) v = (k - 15 - 6 * NU) ? ph1 : ph0;
     else {
-      int q = k - NOBS;  // privileged tail (joystick.py:596-615)
-      if (q < 3) v = SENS[m->adr_gyro + q];
-      else if (q < 6) v = SENS[m->adr_accelerometer + q - 3];
+      if (q < 3) v = SENS[adr_gyro + q];
+      else if (q < 6) v = SENS[adr_acc + q - 3];
       else if (q < 9) v = SCR[S::S_MISC + 10 + q - 6];
-      else if (q < 12) v = SENS[m->adr_local_linvel + q - 9];
-      else if (q < 15) v = SENS[m->adr_global_angvel + q - 12];
-      else if (q < 15 + NU) { const int u = q - 15, bq = m->act_backlash_qposadr[u]; v = QPOS[m->act_qposadr[u]] + (bq >= 0 ? QPOS[bq] : 0.0f) - m->key_ctrl[u]; }
-      else if (q < 15 + 2 * NU) v = QVEL[m->act_dofadr[q - 15 - NU]];
+      else if (q < 12) v = SENS[adr_lin + q - 9];
+      else if (q < 15) v = SENS[adr_ang + q - 12];
+      else if (q < 15 + NU) v = QPOS[Q_aq] + (Q_bq >= 0 ? QPOS[Q_bq] : 0.0f) - Q_kc;
+      else if (q < 15 + 2 * NU) v = QVEL[QV_ad];
       else if (q == 15 + 2 * NU) v = QPOS[2];
       else if (q < 16 + 3 * NU) v = L[S::O_ACTF + q - 16 - 2 * NU];
       else if (q < 18 + 3 * NU) v = (q - 16 - 3 * NU) ? con1 : con0;
-      else if (q < 24 + 3 * NU) { const int t = q - 18 - 3 * NU; v = SENS[m->adr_foot_linvel[t / 3] + t % 3]; }
+      else if (q < 24 + 3 * NU) { const int t = q - 18 - 3 * NU; v = SENS[F_adr + (t >= 3 ? t - 3 : t)]; }
       else if (q < 26 + 3 * NU) v = INFO[RL.AIR + q - 24 - 3 * NU];
       else if (q < 66 + 3 * NU) v = L[E::O_REF + q - 26 - 3 * NU];
       else if (q == 66 + 3 * NU) v = (float)imitation_i;
