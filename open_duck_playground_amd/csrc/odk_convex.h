@@ -506,11 +506,16 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
         const unsigned base = (unsigned)RB.vv[s] | ((unsigned)(j + 16 * s) << 16);
 #pragma unroll 1
         for (unsigned bits = (pass >> (9 * s)) & 0x1FFu; __builtin_amdgcn_ballot_w64(bits != 0u) != 0; ) {
-          const bool on = bits != 0u;   // (one predicated write per trip, everything else unconditional: 0 & (0 - 1) stays 0)
-          const int i = __ffs((int)bits) - 1;
-          if (on & ((unsigned)pos < 64u)) PL[pos] = __uint_as_float(base | ((unsigned)i << 22));
-          pos += on ? 1 : 0;
+          // (two bits per trip: half the loop-control round trips; predicated writes, everything else unconditional: 0 & (0 - 1) stays 0)
+          const bool on0 = bits != 0u;
+          const int i0 = __ffs((int)bits) - 1;
           bits &= bits - 1u;
+          const bool on1 = bits != 0u;
+          const int i1 = __ffs((int)bits) - 1;
+          bits &= bits - 1u;
+          if (on0 & ((unsigned)pos < 64u)) PL[pos] = __uint_as_float(base | ((unsigned)i0 << 22));
+          if (on1 & ((unsigned)(pos + 1) < 64u)) PL[pos + 1] = __uint_as_float(base | ((unsigned)i1 << 22));
+          pos += (on0 ? 1 : 0) + (on1 ? 1 : 0);
         }
       }
       ODK_SYNC();
