@@ -638,15 +638,36 @@ __device__ __forceinline__ void chain_solve(const float* A, float* VEC, float* X
   const bool col = lane < 24 && bcol < P;   // lanes that hold a column (all zeros when the chain does not exist: len = 0)
   float T[CL][CL], v[CL], dinv[CL];
   // ---- load T and this lane's column (rows beyond the chain's length are identity padding)
+  // (All reads first, unconditionally, and PINNED: left alone the optimiser turns every `valid ? read : constant` into a read under its own exec mask -- twenty blocks of
+  // `v_mov default; s_and_saveexec; ds_read; s_or exec` with branches between them, twice per substep: round 6.)
+  float tr[CL][CL], cvr[CL];
 #pragma unroll
   for (int p = 0; p < CL; p++) {
     const bool valid = p < len;
     const int radr = valid ? madr + p * (d0 + 1) + (p * (p - 1)) / 2 : 0;
 #pragma unroll
-    for (int q = 0; q <= p; q++) { const float t = A[radr + d0 + q]; T[p][q] = valid ? t : (q == p ? 1.0f : 0.0f); }
+    for (int q = 0; q <= p; q++) tr[p][q] = A[radr + d0 + q];
     const float* src = bcol < NB6 ? A + radr + bcol : VEC + (valid ? first + p : 0);
-    const float cv = *src;
-    v[p] = valid ? cv : 0.0f;
+    cvr[p] = *src;
+  }
+  static_assert(CL <= 6, "pins below");
+#pragma unroll
+  for (int p = 0; p < CL; p++) {
+    switch (p) {
+      case 0: asm volatile("" :: "v"(tr[0][0]), "v"(cvr[0])); break;
+      case 1: asm volatile("" :: "v"(tr[1][0]), "v"(tr[1][1]), "v"(cvr[1])); break;
+      case 2: asm volatile("" :: "v"(tr[2][0]), "v"(tr[2][1]), "v"(tr[2][2]), "v"(cvr[2])); break;
+      case 3: asm volatile("" :: "v"(tr[3][0]), "v"(tr[3][1]), "v"(tr[3][2]), "v"(tr[3][3]), "v"(cvr[3])); break;
+      case 4: asm volatile("" :: "v"(tr[4][0]), "v"(tr[4][1]), "v"(tr[4][2]), "v"(tr[4][3]), "v"(tr[4][4]), "v"(cvr[4])); break;
+      default: asm volatile("" :: "v"(tr[CL - 1][0]), "v"(tr[CL - 1][1]), "v"(tr[CL - 1][2]), "v"(tr[CL - 1][3]), "v"(tr[CL - 1][4]), "v"(tr[CL - 1][CL - 1]), "v"(cvr[CL - 1])); break;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < CL; p++) {
+    const bool valid = p < len;
+#pragma unroll
+    for (int q = 0; q <= p; q++) T[p][q] = valid ? tr[p][q] : (q == p ? 1.0f : 0.0f);
+    v[p] = valid ? cvr[p] : 0.0f;
   }
   // ---- eliminate the chain from its leaf: L entries replace T, the column becomes L^-T (column)
 #pragma unroll
