@@ -547,7 +547,10 @@ __device__ __forceinline__ void sat_prism_row(const Prism& P, const float* pc, c
 #pragma unroll 1
       for (int t = 0; t < 4 && __builtin_amdgcn_ballot_w64(wb + 16 * t < total) != 0; t += 2) {
         const bool has0 = wb + 16 * t + j < total, has1 = wb + 16 * (t + 1) + j < total;
-        const unsigned en0 = has0 ? __float_as_uint(PL[16 * t + j]) : 0u, en1 = has1 ? __float_as_uint(PL[16 * (t + 1) + j]) : 0u;
+        // (both entries read by every lane and pinned: the list's 64 slots always exist; as `has ? read : 0` each read sat under its own exec mask)
+        const float r0 = PL[(16 * t + j) & 63], r1 = PL[(16 * (t + 1) + j) & 63];
+        asm volatile("" :: "v"(r0), "v"(r1));
+        const unsigned en0 = has0 ? __float_as_uint(r0) : 0u, en1 = has1 ? __float_as_uint(r1) : 0u;
         eval_pair(en0, has0);
         eval_pair(en1, has1);
       }

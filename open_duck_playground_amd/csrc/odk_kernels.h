@@ -1320,7 +1320,12 @@ __device__ __forceinline__ void hfield_contacts(float* L, const DevModel* __rest
   ODK_SYNC();
   {   // the list in ascending (sep, prism) order: an entry's place is the number of entries before it
     float e0[6], e1[6];
-    for (int t = 0; t < 6; t++) { e0[t] = LIST[6 * j + t]; e1[t] = j < 2 ? LIST[6 * (j + 16) + t] : 0.0f; }
+    {   // (entries 16 / 17 exist for lanes 0 / 1 only: read by every lane through a clamped index and pinned -- as `j < 2 ? read : 0` each of the six became a read under its own exec mask)
+      const int j1 = j < 2 ? j + 16 : 0;
+      for (int t = 0; t < 6; t++) { e0[t] = LIST[6 * j + t]; e1[t] = LIST[6 * j1 + t]; }
+      asm volatile("" :: "v"(e1[0]), "v"(e1[1]), "v"(e1[2]), "v"(e1[3]), "v"(e1[4]), "v"(e1[5]));
+      for (int t = 0; t < 6; t++) e1[t] = j < 2 ? e1[t] : 0.0f;
+    }
     int rk0 = 0, rk1 = 0;
     // (trip count: the longest list of the wave's four rows -- three entries on average, not the list's capacity)
     const int cmax = max(max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 16)), max(__builtin_amdgcn_readlane(cnt, 32), __builtin_amdgcn_readlane(cnt, 48)));
