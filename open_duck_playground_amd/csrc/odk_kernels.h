@@ -2203,7 +2203,11 @@ __device__ __forceinline__ void forward_env(float* L, const int* RT, const DevMo
       float R[9];
       q2mat(R, q);
       float ip[3] = {bs.ipos[0], bs.ipos[1], bs.ipos[2]};
-      if (lane == 1) { ip[0] = L[S::O_IPOS1]; ip[1] = L[S::O_IPOS1 + 1]; ip[2] = L[S::O_IPOS1 + 2]; }
+      {   // (body 1's per-env centre of mass: read by every lane -- a broadcast -- and pinned; as an `if (lane == 1)` the three reads became three blocks under their own exec mask)
+        const float i0 = L[S::O_IPOS1], i1 = L[S::O_IPOS1 + 1], i2 = L[S::O_IPOS1 + 2];
+        asm volatile("" :: "v"(i0), "v"(i1), "v"(i2));
+        ip[0] = lane == 1 ? i0 : ip[0]; ip[1] = lane == 1 ? i1 : ip[1]; ip[2] = lane == 1 ? i2 : ip[2];
+      }
       float off[3];
       for (int k = 0; k < 3; k++) off[k] = p[k] + R[3 * k] * ip[0] + R[3 * k + 1] * ip[1] + R[3 * k + 2] * ip[2] - ref[k];
       const float* f = bs.inertia;
